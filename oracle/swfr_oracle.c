@@ -1,0 +1,1345 @@
+/*
+ * swfr_oracle.c -- TEST INFRASTRUCTURE ONLY.  Never linked into the product.
+ *
+ * CPU restatement (plain C, single thread) of the arithmetic the reference's pixel-correct
+ * path delegates to: node-canvas 2.6.1 -> Cairo 1.16 image backend -> pixman 0.40
+ * (pinned in /root/reference/ts/yarn.lock:835-837; call sites
+ * ts/src/lib/renderers/canvas-renderer.ts:69-78,179-188,207-350).  That code is a
+ * third-party dependency which is NOT under /root/reference, so this file restates its
+ * published algorithm behind a mini "cairo context" API that
+ * oracle/oracle_backend.py drives with the same call sequence the reference issues.
+ *
+ * Pinning: tests/test_oracle_goldens.py checks this file against every golden the
+ * reference's own tests hold for the path (tests/flat-shapes/<asterisk>/shape.png,
+ * tests/flat-morph-shapes/homestuck-beta-29/{0,32768,65536}.png) and, when the container's
+ * libcairo.so.2 (1.16.0) is present, tests/test_oracle_vs_cairo.py fuzzes it against that.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
+ *
+ * Sections:  [A.1] fixed point  [A.2] path  [A.3] spline  [A.5b] polygon + limits
+ *            [A.8] stroker      [A.5] tor scan converter  [A.6] boxes  [A.7] compositing
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <limits.h>
+
+#define EXPORT __attribute__((visibility("default")))
+
+typedef int32_t fx_t;                       /* 24.8 fixed */
+typedef struct { fx_t x, y; } pt_t;
+typedef struct { double xx, yx, xy, yy, x0, y0; } mat_t;
+
+#define FX_ONE 256
+#define GRID_X 256
+#define GRID_Y 15
+
+/* ------------------------------------------------------------------ [A.1] fixed point */
+static fx_t fx_from_double(double d) { return (fx_t)nearbyint(d * 256.0); }   /* rint, ties-to-even */
+static double fx_to_double(fx_t f) { return (double)f / 256.0; }
+static int fx_floor_i(fx_t f) { return f >> 8; }
+static int fx_ceil_i(fx_t f) { return (f + 255) >> 8; }
+
+static void mat_identity(mat_t *m) { m->xx = 1; m->yx = 0; m->xy = 0; m->yy = 1; m->x0 = 0; m->y0 = 0; }
+/* r = a * b : apply a first, then b (cairo_matrix_multiply) */
+static void mat_multiply(mat_t *r, const mat_t *a, const mat_t *b)
+{
+    mat_t t;
+    t.xx = a->xx * b->xx + a->yx * b->xy;
+    t.yx = a->xx * b->yx + a->yx * b->yy;
+    t.xy = a->xy * b->xx + a->yy * b->xy;
+    t.yy = a->xy * b->yx + a->yy * b->yy;
+    t.x0 = a->x0 * b->xx + a->y0 * b->xy + b->x0;
+    t.y0 = a->x0 * b->yx + a->y0 * b->yy + b->y0;
+    *r = t;
+}
+static void mat_point(const mat_t *m, double *x, double *y)
+{
+    double nx = m->xx * *x + m->xy * *y + m->x0;
+    double ny = m->yx * *x + m->yy * *y + m->y0;
+    *x = nx; *y = ny;
+}
+static void mat_distance(const mat_t *m, double *dx, double *dy)
+{
+    double nx = m->xx * *dx + m->xy * *dy;
+    double ny = m->yx * *dx + m->yy * *dy;
+    *dx = nx; *dy = ny;
+}
+static double mat_det(const mat_t *m) { return m->xx * m->yy - m->yx * m->xy; }
+static int mat_invert(mat_t *m)
+{
+    double det = mat_det(m);
+    mat_t r;
+    if (det == 0 || !isfinite(det)) return 0;
+    r.xx = m->yy / det;  r.yx = -m->yx / det;
+    r.xy = -m->xy / det; r.yy = m->xx / det;
+    r.x0 = (m->xy * m->y0 - m->yy * m->x0) / det;
+    r.y0 = (m->yx * m->x0 - m->xx * m->y0) / det;
+    *m = r;
+    return 1;
+}
+static int mat_is_identity(const mat_t *m)
+{
+    return m->xx == 1 && m->yx == 0 && m->xy == 0 && m->yy == 1 && m->x0 == 0 && m->y0 == 0;
+}
+
+/* ------------------------------------------------------------------ [A.2] path */
+enum { OP_MOVE = 0, OP_LINE = 1, OP_CURVE = 2, OP_CLOSE = 3 };
+
+typedef struct {
+    uint8_t *ops; int nops, cops;
+    pt_t *pts; int npts, cpts;
+    pt_t cur, last_move;
+    int has_cur, needs_move_to, has_extents;
+    int fill_is_rect, stroke_is_rect;
+    pt_t e1, e2;                            /* extents of all op points */
+} path_t;
+
+static void path_reset(path_t *p)
+{
+    p->nops = p->npts = 0;
+    p->has_cur = 0; p->needs_move_to = 1; p->has_extents = 0;
+    p->fill_is_rect = p->stroke_is_rect = 1;
+    p->cur.x = p->cur.y = 0; p->last_move = p->cur;
+}
+static void path_ext(path_t *p, pt_t q)
+{
+    if (!p->has_extents) { p->e1 = p->e2 = q; p->has_extents = 1; return; }
+    if (q.x < p->e1.x) p->e1.x = q.x;
+    if (q.x > p->e2.x) p->e2.x = q.x;
+    if (q.y < p->e1.y) p->e1.y = q.y;
+    if (q.y > p->e2.y) p->e2.y = q.y;
+}
+static void path_add(path_t *p, int op, const pt_t *pts, int n)
+{
+    if (p->nops == p->cops) { p->cops = p->cops ? 2 * p->cops : 64; p->ops = realloc(p->ops, p->cops); }
+    if (p->npts + n > p->cpts) { p->cpts = p->cpts ? 2 * p->cpts + n : 128; p->pts = realloc(p->pts, sizeof(pt_t) * p->cpts); }
+    p->ops[p->nops++] = (uint8_t)op;
+    for (int i = 0; i < n; i++) p->pts[p->npts++] = pts[i];
+}
+static int path_last_op(const path_t *p) { return p->nops ? p->ops[p->nops - 1] : -1; }
+static void path_drop_line_to(path_t *p) { p->nops--; p->npts--; }
+
+static void path_new_sub_path(path_t *p)
+{
+    if (!p->needs_move_to) {
+        if (p->fill_is_rect)   /* implicit close for fill */
+            p->fill_is_rect = p->cur.x == p->last_move.x || p->cur.y == p->last_move.y;
+        p->needs_move_to = 1;
+    }
+    p->has_cur = 0;
+}
+static void path_move_to(path_t *p, fx_t x, fx_t y)
+{
+    path_new_sub_path(p);
+    p->has_cur = 1;
+    p->cur.x = x; p->cur.y = y;
+    p->last_move = p->cur;
+}
+static void path_move_to_apply(path_t *p)
+{
+    if (!p->needs_move_to) return;
+    p->needs_move_to = 0;
+    path_ext(p, p->cur);
+    p->last_move = p->cur;
+    path_add(p, OP_MOVE, &p->cur, 1);
+}
+static void path_line_to(path_t *p, fx_t x, fx_t y)
+{
+    pt_t q = { x, y };
+    if (!p->has_cur) { path_move_to(p, x, y); return; }
+    path_move_to_apply(p);
+    /* a degenerate line is kept only directly after a MOVE_TO */
+    if (path_last_op(p) != OP_MOVE && x == p->cur.x && y == p->cur.y) return;
+    /* collinear merge / replacement of a degenerate previous line */
+    if (path_last_op(p) == OP_LINE) {
+        pt_t pp = p->pts[p->npts - 2];
+        if (pp.x == p->cur.x && pp.y == p->cur.y) {
+            path_drop_line_to(p);
+        } else {
+            int64_t pdx = (int64_t)p->cur.x - pp.x, pdy = (int64_t)p->cur.y - pp.y;
+            int64_t sdx = (int64_t)x - p->cur.x, sdy = (int64_t)y - p->cur.y;
+            if (pdy * sdx == sdy * pdx &&
+                !(((pdx * sdx) >> 8) + ((pdy * sdy) >> 8) < 0))       /* not backwards */
+                path_drop_line_to(p);
+        }
+    }
+    if (p->stroke_is_rect) {
+        p->stroke_is_rect = p->cur.x == x || p->cur.y == y;
+        p->fill_is_rect &= p->stroke_is_rect;
+    }
+    p->cur = q;
+    path_ext(p, q);
+    path_add(p, OP_LINE, &q, 1);
+}
+static void path_curve_to(path_t *p, fx_t x0, fx_t y0, fx_t x1, fx_t y1, fx_t x2, fx_t y2)
+{
+    pt_t q[3] = { { x0, y0 }, { x1, y1 }, { x2, y2 } };
+    if (p->has_cur && p->cur.x == x2 && p->cur.y == y2 &&
+        x1 == x2 && x0 == x2 && y1 == y2 && y0 == y2) { path_line_to(p, x2, y2); return; }
+    if (!p->has_cur) path_move_to(p, x0, y0);
+    path_move_to_apply(p);
+    if (path_last_op(p) == OP_LINE) {
+        pt_t pp = p->pts[p->npts - 2];
+        if (pp.x == p->cur.x && pp.y == p->cur.y) path_drop_line_to(p);
+    }
+    /* extents: control-point box (a superset of cairo's tight curve box; only used to decide
+       whether polygon limits apply, where a superset is equivalent -- see DESIGN.md) */
+    path_ext(p, q[0]); path_ext(p, q[1]); path_ext(p, q[2]);
+    p->cur = q[2];
+    p->fill_is_rect = p->stroke_is_rect = 0;
+    path_add(p, OP_CURVE, q, 3);
+}
+static void path_close(path_t *p)
+{
+    if (!p->has_cur) return;
+    path_line_to(p, p->last_move.x, p->last_move.y);
+    /* cairo drops a trailing line_to that the close implies; irrelevant for fills, and the
+       reference never calls closePath() (canvas-renderer.ts has no closePath call) */
+    p->needs_move_to = 1;
+    path_add(p, OP_CLOSE, NULL, 0);
+}
+static int path_fill_is_rectilinear(const path_t *p)
+{
+    if (!p->fill_is_rect) return 0;
+    if (!p->has_cur || p->needs_move_to) return 1;
+    return p->cur.x == p->last_move.x || p->cur.y == p->last_move.y;
+}
+
+/* ------------------------------------------------------------------ polygon */
+typedef struct { pt_t p1, p2; fx_t top, bottom; int dir; } pedge_t;
+typedef struct {
+    pedge_t *e; int n, cap;
+    int has_limits; pt_t l1, l2;
+    pt_t x1, x2;                            /* extents (min,max) */
+} polygon_t;
+
+static void polygon_init(polygon_t *g, int has_limits, pt_t l1, pt_t l2)
+{
+    g->n = 0; g->has_limits = has_limits; g->l1 = l1; g->l2 = l2;
+    g->x1.x = g->x1.y = INT32_MAX; g->x2.x = g->x2.y = INT32_MIN;
+}
+static fx_t edge_x_for_y(const pt_t *p1, const pt_t *p2, fx_t y)
+{
+    if (y == p1->y) return p1->x;
+    if (y == p2->y) return p2->x;
+    int64_t dy = (int64_t)p2->y - p1->y;
+    fx_t x = p1->x;
+    if (dy != 0) {
+        int64_t num = ((int64_t)y - p1->y) * ((int64_t)p2->x - p1->x);
+        int64_t q = num / dy, r = num % dy;
+        if (r != 0 && ((r < 0) != (dy < 0))) q--;      /* floor */
+        x += (fx_t)q;
+    }
+    return x;
+}
+static fx_t edge_y_for_x(const pt_t *p1, const pt_t *p2, fx_t x)
+{
+    if (x == p1->x) return p1->y;
+    if (x == p2->x) return p2->y;
+    int64_t dx = (int64_t)p2->x - p1->x;
+    fx_t y = p1->y;
+    if (dx != 0) {
+        int64_t num = ((int64_t)x - p1->x) * ((int64_t)p2->y - p1->y);
+        int64_t q = num / dx, r = num % dx;
+        if (r != 0 && ((r < 0) != (dx < 0))) q--;
+        y += (fx_t)q;
+    }
+    return y;
+}
+static void polygon_raw_add(polygon_t *g, const pt_t *p1, const pt_t *p2, fx_t top, fx_t bottom, int dir)
+{
+    if (g->n == g->cap) { g->cap = g->cap ? 2 * g->cap : 64; g->e = realloc(g->e, sizeof(pedge_t) * g->cap); }
+    pedge_t *e = &g->e[g->n++];
+    e->p1 = *p1; e->p2 = *p2; e->top = top; e->bottom = bottom; e->dir = dir;
+    if (top < g->x1.y) g->x1.y = top;
+    if (bottom > g->x2.y) g->x2.y = bottom;
+    if (p1->x < g->x1.x || p1->x > g->x2.x) {
+        fx_t x = p1->x;
+        if (top != p1->y) x = edge_x_for_y(p1, p2, top);
+        if (x < g->x1.x) g->x1.x = x;
+        if (x > g->x2.x) g->x2.x = x;
+    }
+    if (p2->x < g->x1.x || p2->x > g->x2.x) {
+        fx_t x = p2->x;
+        if (bottom != p2->y) x = edge_x_for_y(p1, p2, bottom);
+        if (x < g->x1.x) g->x1.x = x;
+        if (x > g->x2.x) g->x2.x = x;
+    }
+}
+/* [A.5b] _add_clipped_edge */
+static void polygon_add_clipped(polygon_t *g, const pt_t *p1, const pt_t *p2, fx_t top, fx_t bottom, int dir)
+{
+    pt_t l1 = g->l1, l2 = g->l2, bot_left = { l1.x, l2.y }, top_right = { l2.x, l1.y };
+    if (top >= l2.y || bottom <= l1.y) return;
+    fx_t top_y = top > l1.y ? top : l1.y, bot_y = bottom < l2.y ? bottom : l2.y;
+    fx_t pleft = p1->x < p2->x ? p1->x : p2->x, pright = p1->x > p2->x ? p1->x : p2->x;
+    if (l1.x <= pleft && pright <= l2.x) { polygon_raw_add(g, p1, p2, top_y, bot_y, dir); return; }
+    if (pright <= l1.x) { polygon_raw_add(g, &l1, &bot_left, top_y, bot_y, dir); return; }
+    if (l2.x <= pleft) { polygon_raw_add(g, &top_right, &l2, top_y, bot_y, dir); return; }
+    fx_t left_y, right_y;
+    int tlbr = (p1->x <= p2->x) == (p1->y <= p2->y);
+    if (tlbr) {
+        if (pleft >= l1.x) left_y = top_y;
+        else { left_y = edge_y_for_x(p1, p2, l1.x); if (edge_x_for_y(p1, p2, left_y) < l1.x) left_y++; }
+        if (left_y > bot_y) left_y = bot_y;
+        if (top_y < left_y) { polygon_raw_add(g, &l1, &bot_left, top_y, left_y, dir); top_y = left_y; }
+        if (pright <= l2.x) right_y = bot_y;
+        else { right_y = edge_y_for_x(p1, p2, l2.x); if (edge_x_for_y(p1, p2, right_y) > l2.x) right_y--; }
+        if (right_y < top_y) right_y = top_y;
+        if (bot_y > right_y) { polygon_raw_add(g, &top_right, &l2, right_y, bot_y, dir); bot_y = right_y; }
+    } else {
+        if (pright <= l2.x) right_y = top_y;
+        else { right_y = edge_y_for_x(p1, p2, l2.x); if (edge_x_for_y(p1, p2, right_y) > l2.x) right_y++; }
+        if (right_y > bot_y) right_y = bot_y;
+        if (top_y < right_y) { polygon_raw_add(g, &top_right, &l2, top_y, right_y, dir); top_y = right_y; }
+        if (pleft >= l1.x) left_y = bot_y;
+        else { left_y = edge_y_for_x(p1, p2, l1.x); if (edge_x_for_y(p1, p2, left_y) < l1.x) left_y--; }
+        if (left_y < top_y) left_y = top_y;
+        if (bot_y > left_y) { polygon_raw_add(g, &l1, &bot_left, left_y, bot_y, dir); bot_y = left_y; }
+    }
+    if (top_y != bot_y) polygon_raw_add(g, p1, p2, top_y, bot_y, dir);
+}
+static void polygon_add_edge(polygon_t *g, const pt_t *a, const pt_t *b, int dir)
+{
+    const pt_t *p1 = a, *p2 = b;
+    if (p1->y == p2->y) return;                         /* horizontal edges are dropped */
+    if (p1->y > p2->y) { p1 = b; p2 = a; dir = -dir; }
+    if (g->has_limits) {
+        if (p2->y <= g->l1.y || p1->y >= g->l2.y) return;
+        polygon_add_clipped(g, p1, p2, p1->y, p2->y, dir);
+    } else
+        polygon_raw_add(g, p1, p2, p1->y, p2->y, dir);
+}
+
+/* ------------------------------------------------------------------ [A.3] spline */
+typedef void (*add_point_fn)(void *closure, const pt_t *p);
+typedef struct { pt_t a, b, c, d; } knots_t;
+typedef struct { add_point_fn fn; void *closure; pt_t last; } spline_t;
+
+static void spline_add_point(spline_t *s, const pt_t *p)
+{
+    if (p->x == s->last.x && p->y == s->last.y) return;
+    s->last = *p;
+    s->fn(s->closure, p);
+}
+static void lerp_half(const pt_t *a, const pt_t *b, pt_t *r)
+{
+    r->x = a->x + ((b->x - a->x) >> 1);
+    r->y = a->y + ((b->y - a->y) >> 1);
+}
+static double spline_error_squared(const knots_t *k)
+{
+    double bdx = fx_to_double(k->b.x - k->a.x), bdy = fx_to_double(k->b.y - k->a.y);
+    double cdx = fx_to_double(k->c.x - k->a.x), cdy = fx_to_double(k->c.y - k->a.y);
+    if (k->a.x != k->d.x || k->a.y != k->d.y) {
+        double dx = fx_to_double(k->d.x - k->a.x), dy = fx_to_double(k->d.y - k->a.y);
+        double v = dx * dx + dy * dy, u;
+        u = bdx * dx + bdy * dy;
+        if (u <= 0) { /* keep */ } else if (u >= v) { bdx -= dx; bdy -= dy; }
+        else { bdx -= u / v * dx; bdy -= u / v * dy; }
+        u = cdx * dx + cdy * dy;
+        if (u <= 0) { /* keep */ } else if (u >= v) { cdx -= dx; cdy -= dy; }
+        else { cdx -= u / v * dx; cdy -= u / v * dy; }
+    }
+    double berr = bdx * bdx + bdy * bdy, cerr = cdx * cdx + cdy * cdy;
+    return berr > cerr ? berr : cerr;
+}
+static void spline_decompose_into(knots_t *s1, double tol2, spline_t *out)
+{
+    if (spline_error_squared(s1) < tol2) { spline_add_point(out, &s1->a); return; }
+    knots_t s2;
+    pt_t ab, bc, cd, abbc, bccd, fin;
+    lerp_half(&s1->a, &s1->b, &ab); lerp_half(&s1->b, &s1->c, &bc); lerp_half(&s1->c, &s1->d, &cd);
+    lerp_half(&ab, &bc, &abbc); lerp_half(&bc, &cd, &bccd); lerp_half(&abbc, &bccd, &fin);
+    s2.a = fin; s2.b = bccd; s2.c = cd; s2.d = s1->d;
+    s1->b = ab; s1->c = abbc; s1->d = fin;
+    spline_decompose_into(s1, tol2, out);
+    spline_decompose_into(&s2, tol2, out);
+}
+/* returns 0 when the spline degenerates to the line a->d (caller emits line_to(d)) */
+static int spline_flatten(const pt_t *a, const pt_t *b, const pt_t *c, const pt_t *d, double tol,
+                          add_point_fn fn, void *closure)
+{
+    if (a->x == b->x && a->y == b->y && c->x == d->x && c->y == d->y) return 0;
+    spline_t s = { fn, closure, *a };
+    knots_t k = { *a, *b, *c, *d };
+    spline_decompose_into(&k, tol * tol, &s);
+    fn(closure, d);                                       /* final point is always emitted */
+    return 1;
+}
+
+/* ------------------------------------------------------------------ filler */
+typedef struct { polygon_t *g; pt_t cur, last_move; } filler_t;
+static void filler_line_to(void *c, const pt_t *p)
+{
+    filler_t *f = c;
+    polygon_add_edge(f->g, &f->cur, p, 1);
+    f->cur = *p;
+}
+static int box_contains(const pt_t *l1, const pt_t *l2, const pt_t *p)
+{
+    return p->x >= l1->x && p->x <= l2->x && p->y >= l1->y && p->y <= l2->y;
+}
+static int spline_intersects(const pt_t *a, const pt_t *b, const pt_t *c, const pt_t *d, const pt_t *l1, const pt_t *l2)
+{
+    if (box_contains(l1, l2, a) || box_contains(l1, l2, b) || box_contains(l1, l2, c) || box_contains(l1, l2, d)) return 1;
+    pt_t m1 = *a, m2 = *a;
+    const pt_t *q[3] = { b, c, d };
+    for (int i = 0; i < 3; i++) {
+        if (q[i]->x < m1.x) m1.x = q[i]->x;
+        if (q[i]->x > m2.x) m2.x = q[i]->x;
+        if (q[i]->y < m1.y) m1.y = q[i]->y;
+        if (q[i]->y > m2.y) m2.y = q[i]->y;
+    }
+    if (m2.x <= l1->x || m1.x >= l2->x || m2.y <= l1->y || m1.y >= l2->y) return 0;
+    return 1;
+}
+static void path_fill_to_polygon(const path_t *p, double tol, polygon_t *g)
+{
+    filler_t f = { g, { 0, 0 }, { 0, 0 } };
+    const pt_t *pts = p->pts;
+    for (int i = 0; i < p->nops; i++) {
+        switch (p->ops[i]) {
+        case OP_MOVE:
+            filler_line_to(&f, &f.last_move);             /* close current sub-path */
+            f.cur = f.last_move = pts[0]; pts += 1; break;
+        case OP_LINE:
+            filler_line_to(&f, &pts[0]); pts += 1; break;
+        case OP_CURVE:
+            if (g->has_limits && !spline_intersects(&f.cur, &pts[0], &pts[1], &pts[2], &g->l1, &g->l2))
+                filler_line_to(&f, &pts[2]);
+            else if (!spline_flatten(&f.cur, &pts[0], &pts[1], &pts[2], tol, filler_line_to, &f))
+                filler_line_to(&f, &pts[2]);
+            pts += 3; break;
+        case OP_CLOSE:
+            filler_line_to(&f, &f.last_move); break;
+        }
+    }
+    filler_line_to(&f, &f.last_move);
+}
+
+/* ------------------------------------------------------------------ [A.8] stroker */
+typedef struct { pt_t *p; int n, cap; int dir; } contour_t;
+typedef struct {
+    pt_t ccw, point, cw;
+    int64_t dvx, dvy;                       /* dev_vector (fixed deltas) */
+    double dsx, dsy;                        /* unit device slope */
+    double length;
+} face_t;
+typedef struct {
+    contour_t cw, ccw;
+    polygon_t *g;
+    const mat_t *ctm, *inv;
+    int ctm_det_positive, ctm_identity;
+    double half_width, miter_limit, tol;
+    int join, cap;
+    int64_t contour_tol;
+    pt_t first_point;
+    int has_initial_sub_path, has_current_face, has_first_face;
+    face_t current_face, first_face;
+    int unsupported;
+} stroker_t;
+
+static void contour_reset(contour_t *c) { c->n = 0; }
+static void contour_push(contour_t *c, const pt_t *p)
+{
+    if (c->n == c->cap) { c->cap = c->cap ? 2 * c->cap : 64; c->p = realloc(c->p, sizeof(pt_t) * c->cap); }
+    c->p[c->n++] = *p;
+}
+static int within_tolerance(const pt_t *a, const pt_t *b, int64_t tol)
+{
+    int64_t dx = (int64_t)a->x - b->x, dy = (int64_t)a->y - b->y;
+    return dx * dx + dy * dy < tol;
+}
+static void contour_add_point(stroker_t *s, contour_t *c, const pt_t *p)
+{
+    if (c->n && within_tolerance(p, &c->p[c->n - 1], s->contour_tol)) return;
+    contour_push(c, p);
+}
+static void polygon_add_contour(polygon_t *g, const contour_t *c)
+{
+    if (c->n <= 1) return;
+    for (int i = 1; i < c->n; i++) polygon_add_edge(g, &c->p[i - 1], &c->p[i], c->dir);
+}
+static double normalize_slope(double *dx, double *dy)
+{
+    double dx0 = *dx, dy0 = *dy, mag;
+    if (dx0 == 0.0) { *dx = 0.0; if (dy0 > 0.0) { mag = dy0; *dy = 1.0; } else { mag = -dy0; *dy = -1.0; } }
+    else if (dy0 == 0.0) { *dy = 0.0; if (dx0 > 0.0) { mag = dx0; *dx = 1.0; } else { mag = -dx0; *dx = -1.0; } }
+    else { mag = hypot(dx0, dy0); *dx = dx0 / mag; *dy = dy0 / mag; }
+    return mag;
+}
+static void compute_face(const pt_t *point, int64_t ddx, int64_t ddy, stroker_t *s, face_t *f)
+{
+    double sdx = (double)ddx / 256.0, sdy = (double)ddy / 256.0, fdx, fdy;
+    f->length = normalize_slope(&sdx, &sdy);
+    f->dsx = sdx; f->dsy = sdy;
+    if (!s->ctm_identity) {
+        mat_distance(s->inv, &sdx, &sdy);
+        normalize_slope(&sdx, &sdy);
+        if (s->ctm_det_positive) { fdx = -sdy * s->half_width; fdy = sdx * s->half_width; }
+        else { fdx = sdy * s->half_width; fdy = -sdx * s->half_width; }
+        mat_distance(s->ctm, &fdx, &fdy);
+    } else { fdx = -sdy * s->half_width; fdy = sdx * s->half_width; }
+    fx_t ox = fx_from_double(fdx), oy = fx_from_double(fdy);
+    f->ccw.x = point->x + ox; f->ccw.y = point->y + oy;
+    f->point = *point;
+    f->cw.x = point->x - ox; f->cw.y = point->y - oy;
+    f->dvx = ddx; f->dvy = ddy;
+}
+static int slope_compare(int64_t adx, int64_t ady, int64_t bdx, int64_t bdy)
+{
+    int64_t l = ady * bdx, r = bdy * adx;
+    if (l != r) return l < r ? -1 : 1;
+    if (adx == 0 && ady == 0 && bdx == 0 && bdy == 0) return 0;
+    if (adx == 0 && ady == 0) return 1;
+    if (bdx == 0 && bdy == 0) return -1;
+    if (((adx ^ bdx) < 0) || ((ady ^ bdy) < 0)) return (adx > 0 || (adx == 0 && ady > 0)) ? -1 : 1;
+    return 0;
+}
+static int slope_compare_sgn(double dx1, double dy1, double dx2, double dy2)
+{
+    double c = dx1 * dy2 - dx2 * dy1;
+    return c > 0 ? 1 : c < 0 ? -1 : 0;
+}
+static void inner_join(stroker_t *s, const face_t *in, const face_t *out, int clockwise)
+{
+    contour_t *inner = clockwise ? &s->ccw : &s->cw;
+    const pt_t *outpt = clockwise ? &out->ccw : &out->cw;
+    contour_add_point(s, inner, &in->point);
+    contour_add_point(s, inner, outpt);
+}
+static void outer_join(stroker_t *s, const face_t *in, const face_t *out, int clockwise)
+{
+    if (in->cw.x == out->cw.x && in->cw.y == out->cw.y && in->ccw.x == out->ccw.x && in->ccw.y == out->ccw.y) return;
+    const pt_t *inpt = clockwise ? &in->cw : &in->ccw, *outpt = clockwise ? &out->cw : &out->ccw;
+    contour_t *outer = clockwise ? &s->cw : &s->ccw;
+    if (s->join == 1) { s->unsupported = 1; }           /* ROUND joins: pen not restated */
+    if (s->join == 0) {                                  /* MITER */
+        double in_dot_out = in->dsx * out->dsx + in->dsy * out->dsy, ml = s->miter_limit;
+        if (2 <= ml * ml * (1 + in_dot_out)) {
+            double x1 = fx_to_double(inpt->x), y1 = fx_to_double(inpt->y), dx1 = in->dsx, dy1 = in->dsy;
+            double x2 = fx_to_double(outpt->x), y2 = fx_to_double(outpt->y), dx2 = out->dsx, dy2 = out->dsy;
+            double my = (((x2 - x1) * dy1 * dy2 - y2 * dx2 * dy1 + y1 * dx1 * dy2) / (dx1 * dy2 - dx2 * dy1));
+            double mx = fabs(dy1) >= fabs(dy2) ? (my - y1) * dx1 / dy1 + x1 : (my - y2) * dx2 / dy2 + x2;
+            double ix = fx_to_double(in->point.x), iy = fx_to_double(in->point.y);
+            double fdx1 = x1 - ix, fdy1 = y1 - iy, fdx2 = x2 - ix, fdy2 = y2 - iy, mdx = mx - ix, mdy = my - iy;
+            if (slope_compare_sgn(fdx1, fdy1, mdx, mdy) != slope_compare_sgn(fdx2, fdy2, mdx, mdy)) {
+                pt_t p = { fx_from_double(mx), fx_from_double(my) };
+                outer->p[outer->n - 1] = p;
+                return;
+            }
+        }
+    }
+    contour_add_point(s, outer, outpt);                  /* BEVEL, or a rejected miter */
+}
+static void add_cap(stroker_t *s, const face_t *f, contour_t *c)
+{
+    if (s->cap != 0) s->unsupported = 1;                 /* only BUTT is restated */
+    contour_add_point(s, c, &f->cw);
+}
+static void add_caps(stroker_t *s)
+{
+    if (s->has_initial_sub_path && !s->has_first_face && !s->has_current_face && s->cap == 1) { s->unsupported = 1; return; }
+    if (s->has_current_face) add_cap(s, &s->current_face, &s->ccw);
+    polygon_add_contour(s->g, &s->ccw);
+    contour_reset(&s->ccw);
+    if (s->has_first_face) {
+        face_t r = s->first_face;
+        contour_push(&s->ccw, &s->first_face.cw);
+        r.dvx = -r.dvx; r.dvy = -r.dvy; r.dsx = -r.dsx; r.dsy = -r.dsy;
+        pt_t t = r.cw; r.cw = r.ccw; r.ccw = t;
+        add_cap(s, &r, &s->ccw);
+        polygon_add_contour(s->g, &s->ccw);
+        contour_reset(&s->ccw);
+    }
+    polygon_add_contour(s->g, &s->cw);
+}
+static void stroker_move_to(stroker_t *s, const pt_t *p)
+{
+    add_caps(s);
+    s->has_first_face = s->has_current_face = s->has_initial_sub_path = 0;
+    s->first_point = *p;
+    contour_reset(&s->cw); contour_reset(&s->ccw);
+    s->current_face.point = *p;
+}
+static void stroker_line_to(void *closure, const pt_t *point)
+{
+    stroker_t *s = closure;
+    face_t start;
+    pt_t *p1 = &s->current_face.point;
+    s->has_initial_sub_path = 1;
+    if (p1->x == point->x && p1->y == point->y) return;
+    int64_t ddx = (int64_t)point->x - p1->x, ddy = (int64_t)point->y - p1->y;
+    compute_face(p1, ddx, ddy, s, &start);
+    if (s->has_current_face) {
+        int cw = slope_compare(s->current_face.dvx, s->current_face.dvy, start.dvx, start.dvy);
+        if (cw) {
+            cw = cw < 0;
+            if (!within_tolerance(&s->current_face.ccw, &start.ccw, s->contour_tol) ||
+                !within_tolerance(&s->current_face.cw, &start.cw, s->contour_tol)) {
+                outer_join(s, &s->current_face, &start, cw);
+                inner_join(s, &s->current_face, &start, cw);
+            }
+        }
+    } else {
+        if (!s->has_first_face) { s->first_face = start; s->has_first_face = 1; }
+        s->has_current_face = 1;
+        contour_add_point(s, &s->cw, &start.cw);
+        contour_add_point(s, &s->ccw, &start.ccw);
+    }
+    s->current_face = start;
+    s->current_face.point = *point;
+    s->current_face.ccw.x += (fx_t)ddx; s->current_face.ccw.y += (fx_t)ddy;
+    s->current_face.cw.x += (fx_t)ddx; s->current_face.cw.y += (fx_t)ddy;
+    contour_add_point(s, &s->cw, &s->current_face.cw);
+    contour_add_point(s, &s->ccw, &s->current_face.ccw);
+}
+/* closed sub-paths and curves inside strokes are outside the validated subset:
+   curves are flattened with the fill flattener (cairo adds pen-based cusp handling) */
+static int path_stroke_to_polygon(const path_t *p, stroker_t *s)
+{
+    const pt_t *pts = p->pts;
+    for (int i = 0; i < p->nops; i++) {
+        switch (p->ops[i]) {
+        case OP_MOVE: stroker_move_to(s, &pts[0]); pts += 1; break;
+        case OP_LINE: stroker_line_to(s, &pts[0]); pts += 1; break;
+        case OP_CURVE:
+            s->unsupported = 1;
+            if (!spline_flatten(&s->current_face.point, &pts[0], &pts[1], &pts[2], s->tol, stroker_line_to, s))
+                stroker_line_to(s, &pts[2]);
+            pts += 3; break;
+        case OP_CLOSE: s->unsupported = 1; stroker_line_to(s, &s->first_point); break;
+        }
+    }
+    add_caps(s);
+    return s->unsupported;
+}
+
+/* ------------------------------------------------------------------ sources + surface */
+enum { SRC_SOLID = 0, SRC_RADIAL = 1, SRC_LINEAR = 2, SRC_SURFACE = 3 };
+typedef struct { double t; double r, g, b, a; } stop_t;
+typedef struct {
+    int kind;
+    uint32_t pixel;                          /* SOLID: premultiplied ARGB */
+    mat_t inv;                               /* device -> pattern space */
+    double cx0, cy0, r0, cx1, cy1, r1;       /* RADIAL / LINEAR (x0,y0,x1,y1) */
+    stop_t *stops; int nstops;
+    const uint32_t *tex; int tw, th, extend; /* SURFACE: premultiplied ARGB, extend 0 none / 1 repeat */
+} source_t;
+
+typedef struct {
+    mat_t ctm; double line_width; int cap, join; double miter_limit; int fill_rule;
+} gstate_t;
+
+typedef struct swfo_ctx {
+    int w, h; uint32_t *px; int is_clear;
+    gstate_t gs[64]; int ngs;
+    path_t path;
+    source_t src;
+    int last_unsupported;
+    /* scratch */
+    int32_t *ch, *ua; int *touched; int ntouched; uint8_t *tmark;
+    uint8_t *rowcov;
+} swfo_ctx;
+
+/* ------------------------------------------------------------------ [A.7] compositing */
+static inline uint32_t mul8x2_8(uint32_t a, uint8_t b)
+{
+    uint32_t t = (a & 0xff00ff) * b + 0x7f007f;
+    return ((t + ((t >> 8) & 0xff00ff)) >> 8) & 0xff00ff;
+}
+static inline uint32_t add8x2_8x2(uint32_t a, uint32_t b)
+{
+    uint32_t t = a + b;
+    t |= 0x1000100 - ((t >> 8) & 0xff00ff);
+    return t & 0xff00ff;
+}
+static inline uint32_t lerp8x4(uint32_t src, uint8_t a, uint32_t dst)
+{
+    return add8x2_8x2(mul8x2_8(src, a), mul8x2_8(dst, (uint8_t)~a)) |
+           (add8x2_8x2(mul8x2_8(src >> 8, a), mul8x2_8(dst >> 8, (uint8_t)~a)) << 8);
+}
+/* pixman: UN8x4_MUL_UN8 / over */
+static inline uint32_t pm_mul_un8(uint32_t x, uint8_t a)
+{
+    uint32_t rb = (x & 0xff00ff) * a + 0x800080;
+    rb = ((rb + ((rb >> 8) & 0xff00ff)) >> 8) & 0xff00ff;
+    uint32_t ag = ((x >> 8) & 0xff00ff) * a + 0x800080;
+    ag = ((ag + ((ag >> 8) & 0xff00ff)) >> 8) & 0xff00ff;
+    return rb | (ag << 8);
+}
+static inline uint32_t pm_add_sat(uint32_t x, uint32_t y)
+{
+    uint32_t rb = (x & 0xff00ff) + (y & 0xff00ff);
+    rb |= 0x1000100 - ((rb >> 8) & 0xff00ff); rb &= 0xff00ff;
+    uint32_t ag = ((x >> 8) & 0xff00ff) + ((y >> 8) & 0xff00ff);
+    ag |= 0x1000100 - ((ag >> 8) & 0xff00ff); ag &= 0xff00ff;
+    return rb | (ag << 8);
+}
+static inline uint32_t pm_over(uint32_t src, uint32_t dst)
+{
+    return pm_add_sat(pm_mul_un8(dst, (uint8_t)(~src >> 24)), src);
+}
+
+static uint32_t color_to_pixel(double r, double g, double b, double a)
+{
+    /* _cairo_color_init_rgba: premultiply in doubles, _cairo_color_double_to_short, >> 8 */
+    uint32_t rs = (uint32_t)(uint16_t)(r * a * 65535.0 + 0.5), gs = (uint32_t)(uint16_t)(g * a * 65535.0 + 0.5);
+    uint32_t bs = (uint32_t)(uint16_t)(b * a * 65535.0 + 0.5), as = (uint32_t)(uint16_t)(a * 65535.0 + 0.5);
+    return ((as >> 8) << 24) | ((rs >> 8) << 16) | ((gs >> 8) << 8) | (bs >> 8);
+}
+
+/* gradient / texture sampling: float64 model of pixman's general path (+-1 LSB) */
+static uint32_t gradient_color(const source_t *s, double t)
+{
+    const stop_t *st = s->stops; int n = s->nstops;
+    double r, g, b, a;
+    if (n == 0) return 0;
+    if (t <= st[0].t) { r = st[0].r; g = st[0].g; b = st[0].b; a = st[0].a; }
+    else if (t >= st[n - 1].t) { r = st[n - 1].r; g = st[n - 1].g; b = st[n - 1].b; a = st[n - 1].a; }
+    else {
+        int i = 0;
+        while (i + 1 < n && st[i + 1].t <= t) i++;
+        double span = st[i + 1].t - st[i].t, f = span > 0 ? (t - st[i].t) / span : 0;
+        r = st[i].r + (st[i + 1].r - st[i].r) * f; g = st[i].g + (st[i + 1].g - st[i].g) * f;
+        b = st[i].b + (st[i + 1].b - st[i].b) * f; a = st[i].a + (st[i + 1].a - st[i].a) * f;
+    }
+    uint32_t A = (uint32_t)(a * 255.0 + 0.5), R = (uint32_t)(r * a * 255.0 + 0.5);
+    uint32_t G = (uint32_t)(g * a * 255.0 + 0.5), B = (uint32_t)(b * a * 255.0 + 0.5);
+    return (A << 24) | (R << 16) | (G << 8) | B;
+}
+static uint32_t sample_source(const source_t *s, int px, int py)
+{
+    double x = px + 0.5, y = py + 0.5;
+    mat_point(&s->inv, &x, &y);
+    if (s->kind == SRC_RADIAL) {
+        /* |p - c(t)| = r(t), larger root, PAD extend */
+        double cdx = s->cx1 - s->cx0, cdy = s->cy1 - s->cy0, dr = s->r1 - s->r0;
+        double pdx = x - s->cx0, pdy = y - s->cy0;
+        double A = cdx * cdx + cdy * cdy - dr * dr;
+        double B = pdx * cdx + pdy * cdy + s->r0 * dr;
+        double C = pdx * pdx + pdy * pdy - s->r0 * s->r0;
+        double t;
+        if (A == 0) { if (B == 0) return 0; t = 0.5 * C / B; if (s->r0 + t * dr < 0) return 0; }
+        else {
+            double disc = B * B - A * C;
+            if (disc < 0) return 0;
+            double sq = sqrt(disc), t0 = (B + sq) / A, t1 = (B - sq) / A;
+            if (s->r0 + t0 * dr >= 0) t = t0; else if (s->r0 + t1 * dr >= 0) t = t1; else return 0;
+        }
+        if (t < 0) t = 0; if (t > 1) t = 1;
+        return gradient_color(s, t);
+    }
+    if (s->kind == SRC_LINEAR) {
+        double dx = s->cx1 - s->cx0, dy = s->cy1 - s->cy0, l = dx * dx + dy * dy;
+        double t = l == 0 ? 0 : ((x - s->cx0) * dx + (y - s->cy0) * dy) / l;
+        if (t < 0) t = 0; if (t > 1) t = 1;
+        return gradient_color(s, t);
+    }
+    /* SRC_SURFACE: bilinear (7-bit weights) -- matches CAIRO_FILTER_GOOD only for magnification */
+    double u = x - 0.5, v = y - 0.5;
+    int x0 = (int)floor(u), y0 = (int)floor(v);
+    int wx = (int)floor((u - x0) * 128.0), wy = (int)floor((v - y0) * 128.0);
+    uint32_t c[4];
+    for (int k = 0; k < 4; k++) {
+        int xx = x0 + (k & 1), yy = y0 + (k >> 1);
+        if (s->extend == 1) { xx = ((xx % s->tw) + s->tw) % s->tw; yy = ((yy % s->th) + s->th) % s->th; c[k] = s->tex[yy * s->tw + xx]; }
+        else c[k] = (xx < 0 || yy < 0 || xx >= s->tw || yy >= s->th) ? 0 : s->tex[yy * s->tw + xx];
+    }
+    uint32_t out = 0;
+    for (int sh = 0; sh < 32; sh += 8) {
+        uint32_t v00 = (c[0] >> sh) & 255, v10 = (c[1] >> sh) & 255, v01 = (c[2] >> sh) & 255, v11 = (c[3] >> sh) & 255;
+        uint32_t acc = v00 * (128 - wx) * (128 - wy) + v10 * wx * (128 - wy) + v01 * (128 - wx) * wy + v11 * wx * wy;
+        out |= ((acc >> 14) & 255) << sh;
+    }
+    return out;
+}
+
+/* one coverage span [x0,x1) of row y with 8-bit coverage `cov` */
+static void composite_span(swfo_ctx *c, int lerp_mode, int y, int x0, int x1, uint8_t cov)
+{
+    if (!cov || x0 >= x1) return;
+    uint32_t *d = c->px + (size_t)y * c->w + x0;
+    int n = x1 - x0;
+    const source_t *s = &c->src;
+    if (s->kind == SRC_SOLID) {
+        uint32_t p = s->pixel;
+        if (lerp_mode) {
+            if (cov == 0xff) while (n--) *d++ = p;
+            else while (n--) { *d = lerp8x4(p, cov, *d); d++; }
+        } else {                                           /* pixman over_n_8_8888 */
+            if (cov == 0xff) { if ((p >> 24) == 0xff) while (n--) *d++ = p; else while (n--) { *d = pm_over(p, *d); d++; } }
+            else { uint32_t m = pm_mul_un8(p, cov); while (n--) { *d = pm_over(m, *d); d++; } }
+        }
+        return;
+    }
+    for (int i = 0; i < n; i++, d++) {
+        uint32_t sp = pm_mul_un8(sample_source(s, x0 + i, y), cov);
+        *d = lerp_mode ? sp : pm_over(sp, *d);             /* SRC on a clear surface / OVER */
+    }
+}
+
+/* ------------------------------------------------------------------ [A.5] tor scan converter */
+typedef struct { int64_t quo, rem; } qr_t;
+typedef struct tedge {
+    struct tedge *next, *prev;
+    int ytop, height_left, dir, cell;
+    qr_t x, dxdy, dxdy_full;
+    int64_t dy;
+} tedge_t;
+
+static inline void qr_norm(qr_t *x, int64_t dy)
+{
+    if (x->rem < 0) { x->quo--; x->rem += dy; } else if (x->rem >= dy) { x->quo++; x->rem -= dy; }
+}
+static tedge_t *merge_sorted_edges(tedge_t *head_a, tedge_t *head_b)
+{
+    tedge_t *head, **next, *prev;
+    int x;
+    prev = head_a->prev;
+    next = &head;
+    if (head_a->cell <= head_b->cell) head = head_a;
+    else { head = head_b; head_b->prev = prev; goto start_with_b; }
+    do {
+        x = head_b->cell;
+        while (head_a != NULL && head_a->cell <= x) { prev = head_a; next = &head_a->next; head_a = head_a->next; }
+        head_b->prev = prev; *next = head_b;
+        if (head_a == NULL) return head;
+start_with_b:
+        x = head_a->cell;
+        while (head_b != NULL && head_b->cell <= x) { prev = head_b; next = &head_b->next; head_b = head_b->next; }
+        head_a->prev = prev; *next = head_a;
+        if (head_b == NULL) return head;
+    } while (1);
+}
+static tedge_t *sort_edges(tedge_t *list, unsigned level, tedge_t **head_out)
+{
+    tedge_t *head_other = list->next, *remaining;
+    if (head_other == NULL) { *head_out = list; return NULL; }
+    remaining = head_other->next;
+    if (list->cell <= head_other->cell) { *head_out = list; head_other->next = NULL; }
+    else { *head_out = head_other; head_other->prev = list->prev; head_other->next = list; list->prev = head_other; list->next = NULL; }
+    for (unsigned i = 0; i < level && remaining; i++) {
+        remaining = sort_edges(remaining, i, &head_other);
+        *head_out = merge_sorted_edges(*head_out, head_other);
+    }
+    return remaining;
+}
+
+typedef struct {
+    tedge_t head, tail;
+    swfo_ctx *c;
+    int xmin, xmax;                          /* pixel columns of the converter */
+} active_t;
+
+static inline void cell_add(swfo_ctx *c, int xmin, int xmax, int ix, int dch, int dua)
+{
+    /* cells left of xmin keep covered_height (folded into the first column) but lose area;
+       cells at/after xmax are never emitted (SURVEY A.5 "converter x-range") */
+    if (ix >= xmax) return;
+    if (ix < xmin) { ix = xmin; dua = 0; }
+    int k = ix - xmin;
+    if (!c->tmark[k]) { c->tmark[k] = 1; c->touched[c->ntouched++] = k; }
+    c->ch[k] += dch; c->ua[k] += dua;
+}
+static void cell_subspan(active_t *a, int x1, int x2)
+{
+    if (x1 == x2) return;
+    cell_add(a->c, a->xmin, a->xmax, x1 >> 8, 1, 2 * (x1 & 255));
+    cell_add(a->c, a->xmin, a->xmax, x2 >> 8, -1, -2 * (x2 & 255));
+}
+static inline void full_step(tedge_t *e)
+{
+    if (e->dy == 0) return;
+    e->x.quo += e->dxdy_full.quo; e->x.rem += e->dxdy_full.rem;
+    qr_norm(&e->x, e->dy);
+    e->cell = (int)(e->x.quo + (e->x.rem >= e->dy / 2));
+}
+static void render_edge(active_t *a, tedge_t *e, int sign)
+{
+    qr_t x1 = e->x, x2;
+    full_step(e);
+    x2 = e->x;
+    if (e->dy) {
+        x1.quo -= e->dxdy.quo / 2; x1.rem -= e->dxdy.rem / 2; qr_norm(&x1, e->dy);
+        x2.quo -= e->dxdy.quo / 2; x2.rem -= e->dxdy.rem / 2; qr_norm(&x2, e->dy);
+    }
+    int ix1 = (int)(x1.quo >> 8), fx1 = (int)(x1.quo & 255), ix2 = (int)(x2.quo >> 8), fx2 = (int)(x2.quo & 255);
+    swfo_ctx *c = a->c;
+    if (ix1 == ix2) { cell_add(c, a->xmin, a->xmax, ix1, sign * GRID_Y, sign * (fx1 + fx2) * GRID_Y); return; }
+    if (ix2 < ix1) { qr_t t = x1; x1 = x2; x2 = t; int ti = ix1; ix1 = ix2; ix2 = ti; ti = fx1; fx1 = fx2; fx2 = ti; }
+    int64_t dx = (x2.quo - x1.quo) * e->dy + (x2.rem - x1.rem);
+    int64_t tmp = (int64_t)(ix1 + 1) * GRID_X * e->dy;
+    tmp -= x1.quo * e->dy + x1.rem;
+    tmp *= GRID_Y;
+    qr_t y = { tmp / dx, tmp % dx };
+    cell_add(c, a->xmin, a->xmax, ix1, sign * (int)y.quo, sign * (int)y.quo * (GRID_X + fx1));
+    int y_last = (int)y.quo;
+    if (ix1 + 1 < ix2) {
+        qr_t full = { (int64_t)GRID_Y * GRID_X * e->dy / dx, (int64_t)GRID_Y * GRID_X * e->dy % dx };
+        ++ix1;
+        do {
+            y.quo += full.quo; y.rem += full.rem;
+            if (y.rem >= dx) { y.quo++; y.rem -= dx; }
+            cell_add(c, a->xmin, a->xmax, ix1, sign * (int)(y.quo - y_last), sign * (int)(y.quo - y_last) * GRID_X);
+            y_last = (int)y.quo;
+            ++ix1;
+        } while (ix1 != ix2);
+    }
+    cell_add(c, a->xmin, a->xmax, ix2, sign * (GRID_Y - y_last), sign * (GRID_Y - y_last) * fx2);
+}
+static inline void edge_dec(tedge_t *e, int h)
+{
+    e->height_left -= h;
+    if (e->height_left == 0) { e->prev->next = e->next; e->next->prev = e->prev; }
+}
+static void full_row(active_t *a, unsigned mask)
+{
+    tedge_t *left = a->head.next;
+    while (left != &a->tail) {
+        tedge_t *right;
+        int winding;
+        edge_dec(left, GRID_Y);
+        winding = left->dir;
+        right = left->next;
+        do {
+            edge_dec(right, GRID_Y);
+            winding += right->dir;
+            if ((winding & mask) == 0 && right->next->cell != right->cell) break;
+            full_step(right);
+            right = right->next;
+        } while (1);
+        render_edge(a, left, +1);
+        render_edge(a, right, -1);
+        left = right->next;
+    }
+}
+static void sub_row(active_t *a, unsigned mask)
+{
+    tedge_t *edge = a->head.next;
+    int xstart = INT_MIN, prev_x = INT_MIN, winding = 0;
+    while (edge != &a->tail) {
+        tedge_t *next = edge->next;
+        int xend = edge->cell;
+        if (--edge->height_left) {
+            if (edge->dy) {
+                edge->x.quo += edge->dxdy.quo; edge->x.rem += edge->dxdy.rem;
+                qr_norm(&edge->x, edge->dy);
+                edge->cell = (int)(edge->x.quo + (edge->x.rem >= edge->dy / 2));
+            }
+            if (edge->cell < prev_x) {
+                tedge_t *pos = edge->prev;
+                pos->next = next; next->prev = pos;
+                do pos = pos->prev; while (edge->cell < pos->cell);
+                pos->next->prev = edge; edge->next = pos->next; edge->prev = pos; pos->next = edge;
+            } else prev_x = edge->cell;
+        } else { edge->prev->next = next; next->prev = edge->prev; }
+        winding += edge->dir;
+        if ((winding & mask) == 0) {
+            if (next->cell != xend) { cell_subspan(a, xstart, xend); xstart = INT_MIN; }
+        } else if (xstart == INT_MIN) xstart = xend;
+        edge = next;
+    }
+}
+static int can_do_full_row(active_t *a)
+{
+    int prev_x = INT_MIN, min_height = INT_MAX;
+    for (tedge_t *e = a->head.next; e != &a->tail; e = e->next) if (e->height_left < min_height) min_height = e->height_left;
+    if (min_height < GRID_Y) return 0;
+    for (tedge_t *e = a->head.next; e != &a->tail; e = e->next) {
+        int cell;
+        if (e->dy) {
+            qr_t x = e->x;
+            x.quo += e->dxdy_full.quo; x.rem += e->dxdy_full.rem;
+            qr_norm(&x, e->dy);
+            cell = (int)(x.quo + (x.rem >= e->dy / 2));
+        } else cell = e->cell;
+        if (cell < prev_x) return 0;
+        prev_x = cell;
+    }
+    return 1;
+}
+static int cmp_int(const void *a, const void *b) { return *(const int *)a - *(const int *)b; }
+
+/* emit the accumulated cells of one pixel row as coverage spans (blit of the cell list) */
+static void blit_row(swfo_ctx *c, int lerp_mode, int y, int xmin, int xmax)
+{
+    if (!c->ntouched) return;
+    qsort(c->touched, c->ntouched, sizeof(int), cmp_int);
+    int cover = 0, prev_x = xmin;
+    for (int t = 0; t < c->ntouched; t++) {
+        int k = c->touched[t], x = xmin + k;
+        if (x > prev_x) composite_span(c, lerp_mode, y, prev_x, x, (uint8_t)(((cover) * 17 + 256) >> 9));
+        cover += c->ch[k] * GRID_X * 2;
+        int area = cover - c->ua[k];
+        composite_span(c, lerp_mode, y, x, x + 1, (uint8_t)((area * 17 + 256) >> 9));
+        prev_x = x + 1;
+        c->ch[k] = 0; c->ua[k] = 0; c->tmark[k] = 0;
+    }
+    if (prev_x < xmax) composite_span(c, lerp_mode, y, prev_x, xmax, (uint8_t)((cover * 17 + 256) >> 9));
+    c->ntouched = 0;
+}
+
+/* rasterise polygon `g` with the tor converter over pixel rect [xmin,xmax) x [ymin,ymax) */
+static void tor_render(swfo_ctx *c, const polygon_t *g, int even_odd, int lerp_mode, int xmin, int ymin, int xmax, int ymax)
+{
+    int h = ymax - ymin;
+    if (h <= 0 || xmax <= xmin) return;
+    tedge_t *pool = malloc(sizeof(tedge_t) * (g->n ? g->n : 1));
+    tedge_t **ybuckets = calloc(h, sizeof(tedge_t *));
+    int ne = 0, gymin = ymin * GRID_Y, gymax = ymax * GRID_Y;
+    for (int i = 0; i < g->n; i++) {
+        const pedge_t *pe = &g->e[i];
+        int ytop = (int)(((int64_t)GRID_Y * pe->top + 128) >> 8), ybot = (int)(((int64_t)GRID_Y * pe->bottom + 128) >> 8);
+        if (ytop < gymin) ytop = gymin;
+        if (ybot > gymax) ybot = gymax;
+        if (ybot <= ytop) continue;
+        tedge_t *e = &pool[ne++];
+        const pt_t *p1, *p2;
+        e->ytop = ytop; e->height_left = ybot - ytop;
+        if (pe->p2.y > pe->p1.y) { e->dir = pe->dir; p1 = &pe->p1; p2 = &pe->p2; }
+        else { e->dir = -pe->dir; p1 = &pe->p2; p2 = &pe->p1; }
+        if (p2->x == p1->x) {
+            e->cell = p1->x; e->x.quo = p1->x; e->x.rem = 0;
+            e->dxdy.quo = e->dxdy.rem = 0; e->dxdy_full.quo = e->dxdy_full.rem = 0; e->dy = 0;
+        } else {
+            int64_t Ex = (int64_t)(p2->x - p1->x) * GRID_X;
+            int64_t Ey = (int64_t)(p2->y - p1->y) * GRID_Y * 512;
+            e->dxdy.quo = Ex * 512 / Ey; e->dxdy.rem = Ex * 512 % Ey;
+            int64_t tmp = (int64_t)(2 * ytop + 1) << 8;
+            tmp -= (int64_t)p1->y * GRID_Y * 2;
+            tmp *= Ex;
+            e->x.quo = tmp / Ey; e->x.rem = tmp % Ey;
+            e->x.quo += p1->x;
+            qr_norm(&e->x, Ey);
+            if (e->height_left >= GRID_Y) { tmp = Ex * (2 * GRID_Y << 8); e->dxdy_full.quo = tmp / Ey; e->dxdy_full.rem = tmp % Ey; }
+            else e->dxdy_full.quo = e->dxdy_full.rem = 0;
+            e->cell = (int)(e->x.quo + (e->x.rem >= Ey / 2));
+            e->dy = Ey;
+        }
+        int ix = (ytop - gymin) / GRID_Y;
+        e->prev = NULL; e->next = ybuckets[ix]; ybuckets[ix] = e;     /* push front */
+    }
+    active_t a;
+    a.c = c; a.xmin = xmin; a.xmax = xmax;
+    a.head.cell = INT_MIN; a.head.prev = NULL; a.head.next = &a.tail; a.head.height_left = INT_MAX; a.head.dy = 0; a.head.dir = 0;
+    a.tail.cell = INT_MAX; a.tail.prev = &a.head; a.tail.next = NULL; a.tail.height_left = INT_MAX; a.tail.dy = 0; a.tail.dir = 0;
+    unsigned mask = even_odd ? 1u : ~0u;
+    tedge_t *buckets[GRID_Y];
+    memset(buckets, 0, sizeof(buckets));
+    for (int i = 0; i < h; i++) {
+        int do_full = 0, max_suby = 0;
+        /* polygon_fill_buckets */
+        for (tedge_t *e = ybuckets[i]; e;) {
+            tedge_t *nx = e->next;
+            int suby = e->ytop - (i * GRID_Y + gymin);
+            if (buckets[suby]) buckets[suby]->prev = e;
+            e->next = buckets[suby]; e->prev = NULL; buckets[suby] = e;
+            if (suby > max_suby) max_suby = suby;
+            e = nx;
+        }
+        if (max_suby == 0) {
+            if (buckets[0]) {
+                tedge_t *sorted;
+                sort_edges(buckets[0], UINT_MAX, &sorted);
+                a.head.next = merge_sorted_edges(a.head.next, sorted);
+                buckets[0] = NULL;
+            }
+            if (a.head.next == &a.tail) continue;
+            do_full = can_do_full_row(&a);
+        }
+        if (do_full) full_row(&a, mask);
+        else {
+            for (int sub = 0; sub < GRID_Y; sub++) {
+                if (buckets[sub]) {
+                    tedge_t *sorted;
+                    sort_edges(buckets[sub], UINT_MAX, &sorted);
+                    a.head.next = merge_sorted_edges(a.head.next, sorted);
+                    buckets[sub] = NULL;
+                }
+                sub_row(&a, mask);
+            }
+        }
+        blit_row(c, lerp_mode, ymin + i, xmin, xmax);
+    }
+    free(pool); free(ybuckets);
+}
+
+/* ------------------------------------------------------------------ [A.6] rectilinear -> boxes */
+typedef struct { fx_t x; fx_t top, bottom; int dir; } vedge_t;
+static int cmp_fx(const void *a, const void *b) { fx_t x = *(const fx_t *)a, y = *(const fx_t *)b; return (x > y) - (x < y); }
+static int cmp_vedge(const void *a, const void *b) { const vedge_t *x = a, *y = b; return (x->x > y->x) - (x->x < y->x); }
+
+static void boxes_render(swfo_ctx *c, const polygon_t *g, int even_odd, int lerp_mode)
+{
+    /* exact area of the fill region per pixel: c = sum wx*wy over disjoint boxes, alpha = (c>>8)-(c>>16) */
+    int n = g->n;
+    if (!n) return;
+    vedge_t *ve = malloc(sizeof(vedge_t) * n);
+    fx_t *ys = malloc(sizeof(fx_t) * 2 * n);
+    for (int i = 0; i < n; i++) {
+        ve[i].x = g->e[i].p1.x; ve[i].top = g->e[i].top; ve[i].bottom = g->e[i].bottom; ve[i].dir = g->e[i].dir;
+        ys[2 * i] = g->e[i].top; ys[2 * i + 1] = g->e[i].bottom;
+    }
+    qsort(ys, 2 * n, sizeof(fx_t), cmp_fx);
+    qsort(ve, n, sizeof(vedge_t), cmp_vedge);
+    int px0 = fx_floor_i(g->x1.x), px1 = fx_ceil_i(g->x2.x), py0 = fx_floor_i(g->x1.y), py1 = fx_ceil_i(g->x2.y);
+    if (px0 < 0) px0 = 0; if (py0 < 0) py0 = 0; if (px1 > c->w) px1 = c->w; if (py1 > c->h) py1 = c->h;
+    int bw = px1 - px0, bh = py1 - py0;
+    if (bw <= 0 || bh <= 0) { free(ve); free(ys); return; }
+    uint32_t *acc = calloc((size_t)bw * bh, sizeof(uint32_t));
+    unsigned mask = even_odd ? 1u : ~0u;
+    for (int s = 0; s + 1 < 2 * n; s++) {
+        fx_t ya = ys[s], yb = ys[s + 1];
+        if (ya == yb) continue;
+        int winding = 0; fx_t xstart = 0; int inside = 0;
+        for (int i = 0; i < n; i++) {
+            if (!(ve[i].top <= ya && ve[i].bottom >= yb)) continue;
+            winding += ve[i].dir;
+            int now = (winding & mask) != 0;
+            if (now && !inside) { xstart = ve[i].x; inside = 1; }
+            else if (!now && inside) {
+                fx_t xa = xstart, xb = ve[i].x;
+                inside = 0;
+                if (xa == xb) continue;
+                /* box (xa,ya)-(xb,yb) */
+                fx_t cxa = xa < px0 * 256 ? px0 * 256 : xa, cxb = xb > px1 * 256 ? px1 * 256 : xb;
+                fx_t cya = ya < py0 * 256 ? py0 * 256 : ya, cyb = yb > py1 * 256 ? py1 * 256 : yb;
+                if (cxa >= cxb || cya >= cyb) continue;
+                for (int py = cya >> 8; py <= (cyb - 1) >> 8; py++) {
+                    int wy = (cyb < (py + 1) * 256 ? cyb : (py + 1) * 256) - (cya > py * 256 ? cya : py * 256);
+                    uint32_t *row = acc + (size_t)(py - py0) * bw;
+                    for (int px = cxa >> 8; px <= (cxb - 1) >> 8; px++) {
+                        int wx = (cxb < (px + 1) * 256 ? cxb : (px + 1) * 256) - (cxa > px * 256 ? cxa : px * 256);
+                        row[px - px0] += (uint32_t)(wx * wy);
+                    }
+                }
+            }
+        }
+    }
+    for (int y = 0; y < bh; y++) {
+        const uint32_t *row = acc + (size_t)y * bw;
+        int x = 0;
+        while (x < bw) {
+            uint32_t v = row[x]; int x2 = x + 1;
+            while (x2 < bw && row[x2] == v) x2++;
+            composite_span(c, lerp_mode, py0 + y, px0 + x, px0 + x2, (uint8_t)((v >> 8) - (v >> 16)));
+            x = x2;
+        }
+    }
+    free(acc); free(ve); free(ys);
+}
+
+/* ------------------------------------------------------------------ draw ops */
+/* common front end: decides NOTHING_TO_DO, limits, lerp-vs-over, is_clear bookkeeping */
+static int op_bounds(swfo_ctx *c, pt_t e1, pt_t e2, int *needs_limits)
+{
+    /* approximate extents rounded out to pixels, intersected with the surface */
+    if (!(e1.x < e2.x && e1.y < e2.y)) {
+        /* cairo keeps degenerate (zero-area) extents as an empty rectangle -> nothing to do */
+        return 0;
+    }
+    int x0 = fx_floor_i(e1.x), y0 = fx_floor_i(e1.y), x1 = fx_ceil_i(e2.x), y1 = fx_ceil_i(e2.y);
+    *needs_limits = !(x0 >= 0 && y0 >= 0 && x1 <= c->w && y1 <= c->h);
+    if (x0 < 0) x0 = 0; if (y0 < 0) y0 = 0; if (x1 > c->w) x1 = c->w; if (y1 > c->h) y1 = c->h;
+    return x0 < x1 && y0 < y1;
+}
+static int source_is_clear(const source_t *s) { return s->kind == SRC_SOLID && (s->pixel >> 24) == 0; }
+static int source_is_opaque_solid(const source_t *s) { return s->kind == SRC_SOLID && (s->pixel >> 24) == 0xff; }
+
+static void ensure_scratch(swfo_ctx *c)
+{
+    if (c->ch) return;
+    int n = c->w + 2;
+    c->ch = calloc(n, sizeof(int32_t)); c->ua = calloc(n, sizeof(int32_t));
+    c->touched = malloc(sizeof(int) * n); c->tmark = calloc(n, 1); c->ntouched = 0;
+}
+static void render_polygon(swfo_ctx *c, polygon_t *g, int even_odd)
+{
+    ensure_scratch(c);
+    if (!g->n) return;
+    int lerp_mode = source_is_opaque_solid(&c->src) || c->is_clear;
+    int xmin = fx_floor_i(g->x1.x), xmax = fx_ceil_i(g->x2.x), ymin = fx_floor_i(g->x1.y), ymax = fx_ceil_i(g->x2.y);
+    if (xmin < 0) xmin = 0; if (ymin < 0) ymin = 0; if (xmax > c->w) xmax = c->w; if (ymax > c->h) ymax = c->h;
+    tor_render(c, g, even_odd, lerp_mode, xmin, ymin, xmax, ymax);
+}
+
+EXPORT int swfo_fill_preserve(swfo_ctx *c)
+{
+    path_t *p = &c->path;
+    gstate_t *gs = &c->gs[c->ngs - 1];
+    int needs_limits = 0;
+    c->last_unsupported = 0;
+    if (source_is_clear(&c->src)) return 0;               /* OVER with a clear source: no-op */
+    if (!p->has_extents || !op_bounds(c, p->e1, p->e2, &needs_limits)) return 0;   /* NOTHING_TO_DO */
+    polygon_t g; memset(&g, 0, sizeof(g));
+    pt_t l1 = { 0, 0 }, l2 = { c->w * 256, c->h * 256 };
+    polygon_init(&g, needs_limits, l1, l2);
+    path_fill_to_polygon(p, 0.1, &g);
+    if (path_fill_is_rectilinear(p)) {
+        int lerp_mode = source_is_opaque_solid(&c->src) || c->is_clear;
+        boxes_render(c, &g, gs->fill_rule, lerp_mode);
+    } else
+        render_polygon(c, &g, gs->fill_rule);
+    free(g.e);
+    c->is_clear = 0;
+    return 0;
+}
+
+EXPORT int swfo_stroke_preserve(swfo_ctx *c)
+{
+    path_t *p = &c->path;
+    gstate_t *gs = &c->gs[c->ngs - 1];
+    c->last_unsupported = 0;
+    if (source_is_clear(&c->src)) return 0;
+    if (!p->has_extents) return 0;
+    /* approximate stroke extents: path box grown by the device-space line radius (miter: x limit) */
+    mat_t inv = gs->ctm;
+    if (!mat_invert(&inv)) return 0;
+    double hw = gs->line_width / 2.0, sx = hypot(gs->ctm.xx, gs->ctm.yx), sy = hypot(gs->ctm.xy, gs->ctm.yy);
+    double grow = hw * (sx > sy ? sx : sy) * (gs->join == 0 ? (gs->miter_limit > M_SQRT2 ? gs->miter_limit : M_SQRT2) : M_SQRT2);
+    pt_t e1 = { p->e1.x - fx_from_double(grow) - 1, p->e1.y - fx_from_double(grow) - 1 };
+    pt_t e2 = { p->e2.x + fx_from_double(grow) + 1, p->e2.y + fx_from_double(grow) + 1 };
+    int needs_limits = 0;
+    if (!op_bounds(c, e1, e2, &needs_limits)) return 0;
+    polygon_t g; memset(&g, 0, sizeof(g));
+    pt_t l1 = { 0, 0 }, l2 = { c->w * 256, c->h * 256 };
+    polygon_init(&g, needs_limits, l1, l2);
+    stroker_t s; memset(&s, 0, sizeof(s));
+    s.cw.dir = 1; s.ccw.dir = -1;
+    s.g = &g; s.ctm = &gs->ctm; s.inv = &inv;
+    s.ctm_identity = mat_is_identity(&inv);
+    s.ctm_det_positive = mat_det(&gs->ctm) >= 0.0;
+    s.half_width = hw; s.miter_limit = gs->miter_limit; s.tol = 0.1;
+    s.join = gs->join; s.cap = gs->cap;
+    { double t = 0.1 * 256.0; s.contour_tol = (int64_t)(t * t); }
+    if (p->stroke_is_rect) s.unsupported = 1;             /* rectilinear stroker not restated (A.4) */
+    c->last_unsupported = path_stroke_to_polygon(p, &s);
+    render_polygon(c, &g, 0);
+    free(g.e); free(s.cw.p); free(s.ccw.p);
+    c->is_clear = 0;
+    return c->last_unsupported;
+}
+
+/* ------------------------------------------------------------------ context API */
+EXPORT swfo_ctx *swfo_create(int w, int h)
+{
+    swfo_ctx *c = calloc(1, sizeof(*c));
+    c->w = w; c->h = h; c->px = calloc((size_t)w * h, 4); c->is_clear = 1;
+    c->ngs = 1; mat_identity(&c->gs[0].ctm);
+    c->gs[0].line_width = 2.0; c->gs[0].miter_limit = 10.0; c->gs[0].cap = 0; c->gs[0].join = 0; c->gs[0].fill_rule = 0;
+    path_reset(&c->path);
+    c->src.kind = SRC_SOLID; c->src.pixel = 0xff000000u;
+    return c;
+}
+EXPORT void swfo_destroy(swfo_ctx *c)
+{
+    if (!c) return;
+    free(c->px); free(c->path.ops); free(c->path.pts); free(c->src.stops);
+    free(c->ch); free(c->ua); free(c->touched); free(c->tmark);
+    free(c);
+}
+EXPORT void swfo_save(swfo_ctx *c) { if (c->ngs < 64) { c->gs[c->ngs] = c->gs[c->ngs - 1]; c->ngs++; } }
+EXPORT void swfo_restore(swfo_ctx *c) { if (c->ngs > 1) c->ngs--; }
+EXPORT void swfo_identity_matrix(swfo_ctx *c) { mat_identity(&c->gs[c->ngs - 1].ctm); }
+EXPORT void swfo_transform(swfo_ctx *c, double xx, double yx, double xy, double yy, double x0, double y0)
+{
+    mat_t m = { xx, yx, xy, yy, x0, y0 };
+    mat_multiply(&c->gs[c->ngs - 1].ctm, &m, &c->gs[c->ngs - 1].ctm);
+}
+EXPORT void swfo_scale(swfo_ctx *c, double sx, double sy) { swfo_transform(c, sx, 0, 0, sy, 0, 0); }
+EXPORT void swfo_clear_all(swfo_ctx *c) { memset(c->px, 0, (size_t)c->w * c->h * 4); c->is_clear = 1; }
+EXPORT void swfo_new_path(swfo_ctx *c) { path_reset(&c->path); }
+EXPORT void swfo_move_to(swfo_ctx *c, double x, double y)
+{
+    mat_point(&c->gs[c->ngs - 1].ctm, &x, &y);
+    path_move_to(&c->path, fx_from_double(x), fx_from_double(y));
+}
+EXPORT void swfo_line_to(swfo_ctx *c, double x, double y)
+{
+    mat_point(&c->gs[c->ngs - 1].ctm, &x, &y);
+    path_line_to(&c->path, fx_from_double(x), fx_from_double(y));
+}
+EXPORT void swfo_curve_to(swfo_ctx *c, double x1, double y1, double x2, double y2, double x3, double y3)
+{
+    const mat_t *m = &c->gs[c->ngs - 1].ctm;
+    mat_point(m, &x1, &y1); mat_point(m, &x2, &y2); mat_point(m, &x3, &y3);
+    path_curve_to(&c->path, fx_from_double(x1), fx_from_double(y1), fx_from_double(x2), fx_from_double(y2),
+                  fx_from_double(x3), fx_from_double(y3));
+}
+EXPORT void swfo_close_path(swfo_ctx *c) { path_close(&c->path); }
+/* cairo_get_current_point: the 24.8-quantised point mapped back through CTM^-1; (0,0) when none */
+EXPORT int swfo_get_current_point(swfo_ctx *c, double *x, double *y)
+{
+    if (!c->path.has_cur) { *x = 0; *y = 0; return 0; }
+    mat_t inv = c->gs[c->ngs - 1].ctm;
+    *x = fx_to_double(c->path.cur.x); *y = fx_to_double(c->path.cur.y);
+    if (mat_invert(&inv)) mat_point(&inv, x, y);
+    return 1;
+}
+/* Context2d::QuadraticCurveTo of node-canvas 2.6.1 */
+EXPORT void swfo_quadratic_curve_to(swfo_ctx *c, double x1, double y1, double x2, double y2)
+{
+    double x, y;
+    swfo_get_current_point(c, &x, &y);
+    if (x == 0 && y == 0) { x = x1; y = y1; }
+    double k = 2.0 / 3.0;
+    swfo_curve_to(c, x + k * (x1 - x), y + k * (y1 - y), x2 + k * (x1 - x2), y2 + k * (y1 - y2), x2, y2);
+}
+EXPORT void swfo_set_source_rgba(swfo_ctx *c, double r, double g, double b, double a)
+{
+    c->src.kind = SRC_SOLID; c->src.pixel = color_to_pixel(r, g, b, a);
+}
+static void lock_pattern_matrix(swfo_ctx *c)
+{
+    /* the pattern space is the user space at set_source time: device -> pattern = CTM^-1 */
+    c->src.inv = c->gs[c->ngs - 1].ctm;
+    if (!mat_invert(&c->src.inv)) mat_identity(&c->src.inv);
+}
+EXPORT void swfo_set_source_gradient(swfo_ctx *c, int linear, double x0, double y0, double r0, double x1, double y1, double r1,
+                                     int nstops, const double *offsets, const double *rgba)
+{
+    c->src.kind = linear ? SRC_LINEAR : SRC_RADIAL;
+    c->src.cx0 = x0; c->src.cy0 = y0; c->src.r0 = r0; c->src.cx1 = x1; c->src.cy1 = y1; c->src.r1 = r1;
+    free(c->src.stops);
+    c->src.stops = malloc(sizeof(stop_t) * (nstops ? nstops : 1)); c->src.nstops = nstops;
+    for (int i = 0; i < nstops; i++) {
+        stop_t s = { offsets[i], rgba[4 * i], rgba[4 * i + 1], rgba[4 * i + 2], rgba[4 * i + 3] };
+        /* cairo keeps stops sorted by offset, stable */
+        int j = i;
+        while (j > 0 && c->src.stops[j - 1].t > s.t) { c->src.stops[j] = c->src.stops[j - 1]; j--; }
+        c->src.stops[j] = s;
+    }
+    lock_pattern_matrix(c);
+}
+EXPORT void swfo_set_source_surface(swfo_ctx *c, const uint32_t *argb_premul, int tw, int th, int extend)
+{
+    c->src.kind = SRC_SURFACE; c->src.tex = argb_premul; c->src.tw = tw; c->src.th = th; c->src.extend = extend;
+    lock_pattern_matrix(c);
+}
+EXPORT void swfo_set_line_width(swfo_ctx *c, double w) { c->gs[c->ngs - 1].line_width = w; }
+EXPORT void swfo_set_line_cap(swfo_ctx *c, int cap) { c->gs[c->ngs - 1].cap = cap; }
+EXPORT void swfo_set_line_join(swfo_ctx *c, int join) { c->gs[c->ngs - 1].join = join; }
+EXPORT void swfo_set_fill_rule(swfo_ctx *c, int even_odd) { c->gs[c->ngs - 1].fill_rule = even_odd; }
+EXPORT const uint32_t *swfo_pixels(swfo_ctx *c) { return c->px; }
+EXPORT int swfo_is_clear(swfo_ctx *c) { return c->is_clear; }
+
+/* Direct entry for timing/large scenes: fill closed polygons given in 24.8 device coordinates.
+   counts[i] vertices each, colours premultiplied ARGB.  Same code path as swfo_fill_preserve. */
+EXPORT void swfo_fill_polygons_fixed(swfo_ctx *c, const int32_t *xy, const int32_t *counts, const uint32_t *argb,
+                                     int npoly, int even_odd)
+{
+    const int32_t *q = xy;
+    for (int i = 0; i < npoly; i++) {
+        path_reset(&c->path);
+        for (int k = 0; k < counts[i]; k++, q += 2) {
+            if (k == 0) path_move_to(&c->path, q[0], q[1]); else path_line_to(&c->path, q[0], q[1]);
+        }
+        c->src.kind = SRC_SOLID; c->src.pixel = argb[i];
+        c->gs[c->ngs - 1].fill_rule = even_odd;
+        swfo_fill_preserve(c);
+    }
+}
