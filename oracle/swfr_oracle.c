@@ -228,9 +228,9 @@ static fx_t edge_x_for_y(const pt_t *p1, const pt_t *p2, fx_t y)
     fx_t x = p1->x;
     if (dy != 0) {
         int64_t num = ((int64_t)y - p1->y) * ((int64_t)p2->x - p1->x);
-        int64_t q = num / dy, r = num % dy;
-        if (r != 0 && ((r < 0) != (dy < 0))) q--;      /* floor */
-        x += (fx_t)q;
+        /* _cairo_fixed_mul_div_floor is a plain C (truncating) division despite its name:
+           pinned by fuzzing off-frame polygons against libcairo (floor: 10/6000 differ) */
+        x += (fx_t)(num / dy);
     }
     return x;
 }
@@ -242,9 +242,7 @@ static fx_t edge_y_for_x(const pt_t *p1, const pt_t *p2, fx_t x)
     fx_t y = p1->y;
     if (dx != 0) {
         int64_t num = ((int64_t)x - p1->x) * ((int64_t)p2->y - p1->y);
-        int64_t q = num / dx, r = num % dx;
-        if (r != 0 && ((r < 0) != (dx < 0))) q--;
-        y += (fx_t)q;
+        y += (fx_t)(num / dx);
     }
     return y;
 }
@@ -450,8 +448,10 @@ static void contour_push(contour_t *c, const pt_t *p)
 }
 static int within_tolerance(const pt_t *a, const pt_t *b, int64_t tol)
 {
-    int64_t dx = (int64_t)a->x - b->x, dy = (int64_t)a->y - b->y;
-    return dx * dx + dy * dy < tol;
+    /* Cairo 1.16.0's within_tolerance() starts with an unconditional `return FALSE`: fuzzing
+       against libcairo shows 65/3000 differing strokes with the distance test and 0/3000 without. */
+    (void)a; (void)b; (void)tol;
+    return 0;
 }
 static void contour_add_point(stroker_t *s, contour_t *c, const pt_t *p)
 {
@@ -1338,6 +1338,7 @@ EXPORT void swfo_fill_polygons_fixed(swfo_ctx *c, const int32_t *xy, const int32
         for (int k = 0; k < counts[i]; k++, q += 2) {
             if (k == 0) path_move_to(&c->path, q[0], q[1]); else path_line_to(&c->path, q[0], q[1]);
         }
+        path_close(&c->path);                              /* closed polygons */
         c->src.kind = SRC_SOLID; c->src.pixel = argb[i];
         c->gs[c->ngs - 1].fill_rule = even_odd;
         swfo_fill_preserve(c);
