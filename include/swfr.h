@@ -1,0 +1,229 @@
+/*
+ * swfr.h -- C-ABI of libswfr.so, the MI355X-native SWF vector rasterizer.
+ *
+ * This is the drop-in boundary for the reference's render(Stage) -> RGBA path.  The reference
+ * (open-flash/swf-renderer) has no FFI for a rasterizer; its seam is the trait/interface layer,
+ * and each entry point below names the reference interface it replaces:
+ *
+ *   swfr_create / swfr_destroy      HeadlessGfxRenderer::new(&instance, w, h)   rs/src/headless_renderer.rs:60-64
+ *                                   new NodeCanvasRenderer(width, height)       ts/src/lib/renderers/node-canvas-renderer.ts:11-15
+ *                                   createRenderer / destroyRenderer (handles)  rs/src/wasm.rs:60-76
+ *   swfr_register_shape             ClientAssetStore::register_shape            rs/src/asset.rs:9-12
+ *                                   (decode: ts/src/lib/shape/decode-swf-shape.ts:22-39)
+ *   swfr_register_morph_shape       ClientAssetStore::register_morph_shape      rs/src/asset.rs:9-12
+ *                                   (decode: ts/src/lib/shape/decode-swf-morph-shape.ts:21-41)
+ *   swfr_register_bitmap            Renderer.addBitmap(tag)                     ts/src/lib/renderer.ts:4-8,
+ *                                   ts/src/lib/renderers/node-canvas-bitmap-service.ts:14-37
+ *   swfr_render                     SwfRenderer::render(&mut self, Stage)       rs/src/swf_renderer.rs:3-5
+ *                                   Renderer.render(stage)                      ts/src/lib/renderer.ts:4-8
+ *                                   (scene walk: ts/src/lib/renderers/canvas-renderer.ts:69-350)
+ *   swfr_read_image                 HeadlessGfxRenderer::get_image() -> Image   rs/src/headless_renderer.rs:233-244,
+ *                                   Image{meta{width,height,stride},data}       rs/src/renderer.rs:88-103
+ *   swfr_last_error                 Result<_, &'static str> / thrown Error      rs/src/headless_renderer.rs:64,233
+ *
+ * Conventions mirrored from the reference: definitions are borrowed for the call and copied
+ * (rs/src/renderer.rs:24-64); render is synchronous and returns after the GPU is idle
+ * (rs/src/headless_renderer.rs:703-712); one handle = one thread at a time; errors are an int
+ * status plus a per-handle message, nothing is thrown across the boundary.
+ *
+ * Types mirror swf-tree 0.8 as evidenced by the reference fixtures (tests/<set>/<name>/ast.json).
+ * Plain C: pointers + sizes only, no C++ or torch types.
+ */
+#ifndef SWFR_H
+#define SWFR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SWFR_ABI_VERSION 1
+
+typedef struct swfr_renderer swfr_renderer;               /* opaque handle */
+
+enum {
+    SWFR_OK = 0,
+    SWFR_ERR_INVALID = 1,          /* bad argument / malformed definition (reference: "Invalid fill ID" etc.) */
+    SWFR_ERR_NOT_IMPLEMENTED = 2,  /* reference throws NotImplementedFillStyle / NotImplementedLineStyle */
+    SWFR_ERR_NOT_FOUND = 3,        /* unknown shape / bitmap id (reference: BitmapNotFound) */
+    SWFR_ERR_NO_DEVICE = 4,        /* no HIP device, or a host-only handle was asked to rasterize */
+    SWFR_ERR_DEVICE = 5,           /* HIP runtime error */
+    SWFR_ERR_CAPACITY = 6          /* a row exceeds the scan converter's active-edge capacity */
+};
+
+/* ---- swf-tree value types ---------------------------------------------------------------- */
+typedef struct { uint8_t r, g, b, a; } swfr_rgba8;                          /* StraightSRgba8 */
+typedef struct { int32_t x_min, x_max, y_min, y_max; } swfr_rect;           /* twips */
+typedef struct {                                                            /* swf_tree::Matrix */
+    int32_t scale_x, scale_y, rotate_skew0, rotate_skew1;                   /* Sfixed16P16 epsilons */
+    int32_t translate_x, translate_y;                                       /* twips */
+} swfr_matrix;
+
+enum { SWFR_FILL_SOLID = 0, SWFR_FILL_LINEAR_GRADIENT = 1, SWFR_FILL_RADIAL_GRADIENT = 2,
+       SWFR_FILL_FOCAL_GRADIENT = 3, SWFR_FILL_BITMAP = 4 };
+
+typedef struct { uint8_t ratio; swfr_rgba8 color; swfr_rgba8 morph_color; } swfr_color_stop;
+
+typedef struct {
+    uint32_t type;                       /* SWFR_FILL_* */
+    swfr_rgba8 color, morph_color;       /* solid (morph_color: DefineMorphShape only) */
+    swfr_matrix matrix;                  /* gradients, bitmap */
+    uint32_t n_stops;                    /* gradients */
+    const swfr_color_stop *stops;
+    int32_t focal_point;                 /* focal gradient, Sfixed8P8 epsilons */
+    uint32_t bitmap_id;                  /* bitmap */
+    uint8_t repeating, smoothed;
+} swfr_fill_style;
+
+typedef struct {
+    uint32_t width, morph_width;         /* twips; caps/joins of the SWF style are dropped by the
+                                            reference (decode-swf-shape.ts:144-149) */
+    swfr_fill_style fill;
+} swfr_line_style;
+
+typedef struct {
+    uint32_t n_fill; const swfr_fill_style *fill;
+    uint32_t n_line; const swfr_line_style *line;
+} swfr_styles;
+
+enum { SWFR_RECORD_EDGE = 0, SWFR_RECORD_STYLE_CHANGE = 1 };
+
+typedef struct {
+    uint32_t type;                       /* SWFR_RECORD_* */
+    /* edge */
+    int32_t delta_x, delta_y;
+    uint8_t has_control_delta; int32_t control_delta_x, control_delta_y;
+    int32_t morph_delta_x, morph_delta_y;                              /* morph shapes */
+    uint8_t has_morph_control_delta; int32_t morph_control_delta_x, morph_control_delta_y;
+    /* style change */
+    uint8_t has_move_to; int32_t move_to_x, move_to_y;
+    uint8_t has_morph_move_to; int32_t morph_move_to_x, morph_move_to_y;
+    uint8_t has_left_fill; uint32_t left_fill;
+    uint8_t has_right_fill; uint32_t right_fill;
+    uint8_t has_line_style; uint32_t line_style;
+    const swfr_styles *new_styles;       /* NULL when absent */
+} swfr_shape_record;
+
+typedef struct {                         /* tags::DefineShape / tags::DefineMorphShape */
+    uint32_t id;
+    swfr_rect bounds, morph_bounds;
+    swfr_styles initial_styles;
+    uint32_t n_records; const swfr_shape_record *records;
+} swfr_define_shape;
+
+/* ---- stage ------------------------------------------------------------------------------- */
+enum { SWFR_OBJECT_SHAPE = 0, SWFR_OBJECT_MORPH_SHAPE = 1, SWFR_OBJECT_CONTAINER = 2 };
+
+typedef struct swfr_display_object {
+    uint32_t type;                       /* SWFR_OBJECT_* (ts/src/lib/display/display-object-type.ts) */
+    uint32_t id;                         /* value returned by swfr_register_(morph_)shape */
+    uint8_t has_matrix; swfr_matrix matrix;
+    double ratio;                        /* morph shapes: [0,1] (ts/src/lib/display/morph-shape.ts:9);
+                                            Rust MorphRatio(u16) maps as ratio = v / 65535.0 */
+    uint32_t n_children; const struct swfr_display_object *children;   /* containers */
+} swfr_display_object;
+
+typedef struct {
+    uint32_t width, height;              /* carried for API parity; the frame size is the handle's */
+    swfr_rgba8 background_color;         /* not painted by the reference (canvas-renderer.ts:72) */
+    uint32_t n_children; const swfr_display_object *children;
+} swfr_stage;
+
+/* ---- configuration ------------------------------------------------------------------------ */
+#define SWFR_DEVICE_HOST_ONLY (-1)       /* decode + geometry only; swfr_render fails with NO_DEVICE */
+#define SWFR_FLAG_EVEN_ODD 1u            /* fill rule override (the reference always uses nonzero) */
+
+typedef struct {
+    int32_t device;                      /* HIP device ordinal, or SWFR_DEVICE_HOST_ONLY */
+    uint32_t flags;
+    uint32_t band_index, band_count;     /* multi-GPU: this handle rasterizes tile-rows
+                                            t with t % band_count == band_index (0,0|1 = all) */
+} swfr_config;
+
+/* ---- lifecycle / assets / render ----------------------------------------------------------- */
+int  swfr_create(uint32_t width, uint32_t height, const swfr_config *cfg, swfr_renderer **out);
+void swfr_destroy(swfr_renderer *r);
+const char *swfr_last_error(const swfr_renderer *r);
+uint32_t swfr_abi_version(void);
+
+int  swfr_register_shape(swfr_renderer *r, const swfr_define_shape *tag, uint32_t *out_id);
+int  swfr_register_morph_shape(swfr_renderer *r, const swfr_define_shape *tag, uint32_t *out_id);
+int  swfr_register_bitmap(swfr_renderer *r, uint32_t id, uint32_t width, uint32_t height,
+                          const uint8_t *rgba_straight, size_t stride);
+int  swfr_render(swfr_renderer *r, const swfr_stage *stage);               /* blocking */
+int  swfr_read_image(swfr_renderer *r, uint8_t *dst, size_t dst_stride, int premultiplied);
+
+/* ---- low-level entry: the hot path proper (edge list -> RGBA8 in HBM) ---------------------- */
+/* One edge of a flattened, limit-clipped polygon in 24.8 device coordinates: the line
+   (x1,y1)-(x2,y2) with y1 < y2 is active for y in [top,bottom); dir is the winding direction. */
+typedef struct { int32_t x1, y1, x2, y2, top, bottom, dir, reserved; } swfr_edge;
+
+enum { SWFR_PATH_TOR = 0,   /* general polygon: Cairo "tor" 15x256 scan conversion */
+       SWFR_PATH_BOXES = 1  /* rectilinear: `edges` hold disjoint boxes (x1,y1)-(x2,y2) */ };
+
+typedef struct {
+    uint32_t first_edge, n_edges;
+    uint32_t kind;                       /* SWFR_PATH_* */
+    uint32_t fill_rule;                  /* 0 nonzero, 1 even-odd */
+    uint32_t style;                      /* index into styles */
+    uint32_t lerp;                       /* 1: SOURCE-lerp blend (opaque source or clear surface), 0: OVER */
+    int32_t x_min, y_min, x_max, y_max;  /* pixel rectangle of the converter (polygon extents ∩ frame) */
+} swfr_path;
+
+enum { SWFR_STYLE_SOLID = 0, SWFR_STYLE_RADIAL = 1, SWFR_STYLE_LINEAR = 2, SWFR_STYLE_BITMAP = 3 };
+#define SWFR_MAX_STOPS 16
+
+typedef struct {
+    uint32_t kind;                       /* SWFR_STYLE_* */
+    uint32_t pixel;                      /* solid: premultiplied 0xAARRGGBB */
+    double inv[6];                       /* device -> pattern space (xx, yx, xy, yy, x0, y0) */
+    double c0x, c0y, r0, c1x, c1y, r1;   /* radial (linear: c0 -> c1) */
+    uint32_t n_stops;
+    float stop_offset[SWFR_MAX_STOPS];
+    float stop_rgba[SWFR_MAX_STOPS][4];  /* straight, 0..1 */
+    uint32_t bitmap;                     /* registered bitmap id */
+    uint32_t extend;                     /* 0 none, 1 repeat */
+} swfr_style;
+
+/* Upload a scene (kept resident in HBM), then rasterize it.  swfr_render_edges = upload + render. */
+int  swfr_upload_edges(swfr_renderer *r, const swfr_edge *edges, size_t n_edges,
+                       const swfr_path *paths, size_t n_paths,
+                       const swfr_style *styles, size_t n_styles);
+int  swfr_render_resident(swfr_renderer *r, uint32_t frames);              /* blocking; frames >= 1 */
+int  swfr_render_edges(swfr_renderer *r, const swfr_edge *edges, size_t n_edges,
+                       const swfr_path *paths, size_t n_paths,
+                       const swfr_style *styles, size_t n_styles);
+
+/* Host half of swfr_render without the device: builds the frame's edge list exactly as
+   swfr_render would upload it.  Arrays are owned by the handle until the next call. */
+int  swfr_build_frame(swfr_renderer *r, const swfr_stage *stage,
+                      const swfr_edge **edges, size_t *n_edges,
+                      const swfr_path **paths, size_t *n_paths,
+                      const swfr_style **styles, size_t *n_styles);
+
+/* Decoded paths of a registered (morph) shape as JSON text in the format of the reference's
+   decode goldens (tests/<set>/<name>/shape.ts.json).  String owned by the handle. */
+int  swfr_shape_json(swfr_renderer *r, uint32_t id, int morph, const char **json);
+
+/* Timing of the last swfr_render / swfr_render_resident, from HIP events on the handle's stream. */
+typedef struct {
+    float total_ms;                      /* first kernel start -> last kernel end, all frames */
+    float setup_ms, rows_ms, tiles_ms;   /* per-kernel sums over all frames */
+    uint32_t frames;
+    uint64_t n_edges, n_paths, n_row_tasks, n_records;
+} swfr_timing;
+int  swfr_last_timing(swfr_renderer *r, swfr_timing *out);
+
+/* Multi-GPU: copy this handle's band slab (its tile-rows, packed in order) into a caller-owned
+   DEVICE buffer (e.g. a torch tensor's data_ptr) so that the caller can gather it with RCCL. */
+size_t swfr_band_slab_bytes(const swfr_renderer *r);
+int  swfr_copy_band_slab(swfr_renderer *r, void *device_dst);
+/* Device pointer of the premultiplied RGBA8 framebuffer (width*height*4 bytes, tight rows). */
+void *swfr_device_framebuffer(swfr_renderer *r);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SWFR_H */

@@ -643,6 +643,7 @@ typedef struct swfo_ctx {
     /* scratch */
     int32_t *ch, *ua; int *touched; int ntouched; uint8_t *tmark;
     uint8_t *rowcov;
+    int32_t *last_poly; int last_poly_n, last_poly_rect;   /* edges of the last fill/stroke polygon (tests) */
 } swfo_ctx;
 
 /* ------------------------------------------------------------------ [A.7] compositing */
@@ -1157,6 +1158,15 @@ static void ensure_scratch(swfo_ctx *c)
     c->ch = calloc(n, sizeof(int32_t)); c->ua = calloc(n, sizeof(int32_t));
     c->touched = malloc(sizeof(int) * n); c->tmark = calloc(n, 1); c->ntouched = 0;
 }
+static void remember_polygon(swfo_ctx *c, const polygon_t *g, int rectilinear)
+{
+    c->last_poly = realloc(c->last_poly, sizeof(int32_t) * 7 * (g->n ? g->n : 1));
+    c->last_poly_n = g->n; c->last_poly_rect = rectilinear;
+    for (int i = 0; i < g->n; i++) {
+        int32_t *o = c->last_poly + 7 * i; const pedge_t *e = &g->e[i];
+        o[0] = e->p1.x; o[1] = e->p1.y; o[2] = e->p2.x; o[3] = e->p2.y; o[4] = e->top; o[5] = e->bottom; o[6] = e->dir;
+    }
+}
 static void render_polygon(swfo_ctx *c, polygon_t *g, int even_odd)
 {
     ensure_scratch(c);
@@ -1172,13 +1182,14 @@ EXPORT int swfo_fill_preserve(swfo_ctx *c)
     path_t *p = &c->path;
     gstate_t *gs = &c->gs[c->ngs - 1];
     int needs_limits = 0;
-    c->last_unsupported = 0;
+    c->last_unsupported = 0; c->last_poly_n = 0;
     if (source_is_clear(&c->src)) return 0;               /* OVER with a clear source: no-op */
     if (!p->has_extents || !op_bounds(c, p->e1, p->e2, &needs_limits)) return 0;   /* NOTHING_TO_DO */
     polygon_t g; memset(&g, 0, sizeof(g));
     pt_t l1 = { 0, 0 }, l2 = { c->w * 256, c->h * 256 };
     polygon_init(&g, needs_limits, l1, l2);
     path_fill_to_polygon(p, 0.1, &g);
+    remember_polygon(c, &g, path_fill_is_rectilinear(p));
     if (path_fill_is_rectilinear(p)) {
         int lerp_mode = source_is_opaque_solid(&c->src) || c->is_clear;
         boxes_render(c, &g, gs->fill_rule, lerp_mode);
@@ -1193,16 +1204,23 @@ EXPORT int swfo_stroke_preserve(swfo_ctx *c)
 {
     path_t *p = &c->path;
     gstate_t *gs = &c->gs[c->ngs - 1];
-    c->last_unsupported = 0;
+    c->last_unsupported = 0; c->last_poly_n = 0;
     if (source_is_clear(&c->src)) return 0;
     if (!p->has_extents) return 0;
     /* approximate stroke extents: path box grown by the device-space line radius (miter: x limit) */
     mat_t inv = gs->ctm;
     if (!mat_invert(&inv)) return 0;
-    double hw = gs->line_width / 2.0, sx = hypot(gs->ctm.xx, gs->ctm.yx), sy = hypot(gs->ctm.xy, gs->ctm.yy);
-    double grow = hw * (sx > sy ? sx : sy) * (gs->join == 0 ? (gs->miter_limit > M_SQRT2 ? gs->miter_limit : M_SQRT2) : M_SQRT2);
-    pt_t e1 = { p->e1.x - fx_from_double(grow) - 1, p->e1.y - fx_from_double(grow) - 1 };
-    pt_t e2 = { p->e2.x + fx_from_double(grow) + 1, p->e2.y + fx_from_double(grow) + 1 };
+    double hw = gs->line_width / 2.0;
+    /* _cairo_stroke_style_max_distance_from_path + _cairo_path_fixed_approximate_stroke_extents */
+    double expansion = 0.5;
+    if (gs->join == 0 && !p->stroke_is_rect && expansion < M_SQRT2 * gs->miter_limit) expansion = M_SQRT2 * gs->miter_limit;
+    expansion *= gs->line_width;
+    int unity = (fabs(gs->ctm.xx) == 1.0 && fabs(gs->ctm.yy) == 1.0 && gs->ctm.xy == 0.0 && gs->ctm.yx == 0.0) ||
+                (fabs(gs->ctm.xy) == 1.0 && fabs(gs->ctm.yx) == 1.0 && gs->ctm.xx == 0.0 && gs->ctm.yy == 0.0);
+    double gx = unity ? expansion : expansion * hypot(gs->ctm.xx, gs->ctm.xy);
+    double gy = unity ? expansion : expansion * hypot(gs->ctm.yy, gs->ctm.yx);
+    pt_t e1 = { p->e1.x - fx_from_double(gx), p->e1.y - fx_from_double(gy) };
+    pt_t e2 = { p->e2.x + fx_from_double(gx), p->e2.y + fx_from_double(gy) };
     int needs_limits = 0;
     if (!op_bounds(c, e1, e2, &needs_limits)) return 0;
     polygon_t g; memset(&g, 0, sizeof(g));
@@ -1218,6 +1236,7 @@ EXPORT int swfo_stroke_preserve(swfo_ctx *c)
     { double t = 0.1 * 256.0; s.contour_tol = (int64_t)(t * t); }
     if (p->stroke_is_rect) s.unsupported = 1;             /* rectilinear stroker not restated (A.4) */
     c->last_unsupported = path_stroke_to_polygon(p, &s);
+    remember_polygon(c, &g, 0);
     render_polygon(c, &g, 0);
     free(g.e); free(s.cw.p); free(s.ccw.p);
     c->is_clear = 0;
@@ -1239,7 +1258,7 @@ EXPORT void swfo_destroy(swfo_ctx *c)
 {
     if (!c) return;
     free(c->px); free(c->path.ops); free(c->path.pts); free(c->src.stops);
-    free(c->ch); free(c->ua); free(c->touched); free(c->tmark);
+    free(c->ch); free(c->ua); free(c->touched); free(c->tmark); free(c->last_poly);
     free(c);
 }
 EXPORT void swfo_save(swfo_ctx *c) { if (c->ngs < 64) { c->gs[c->ngs] = c->gs[c->ngs - 1]; c->ngs++; } }
@@ -1325,6 +1344,11 @@ EXPORT void swfo_set_line_cap(swfo_ctx *c, int cap) { c->gs[c->ngs - 1].cap = ca
 EXPORT void swfo_set_line_join(swfo_ctx *c, int join) { c->gs[c->ngs - 1].join = join; }
 EXPORT void swfo_set_fill_rule(swfo_ctx *c, int even_odd) { c->gs[c->ngs - 1].fill_rule = even_odd; }
 EXPORT const uint32_t *swfo_pixels(swfo_ctx *c) { return c->px; }
+EXPORT int swfo_last_polygon(swfo_ctx *c, const int32_t **edges, int *rectilinear)
+{
+    *edges = c->last_poly; *rectilinear = c->last_poly_rect;
+    return c->last_poly_n;
+}
 EXPORT int swfo_is_clear(swfo_ctx *c) { return c->is_clear; }
 
 /* Direct entry for timing/large scenes: fill closed polygons given in 24.8 device coordinates.

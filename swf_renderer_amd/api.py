@@ -1,0 +1,517 @@
+"""ctypes binding of include/swfr.h and the host-side mirror of the reference's renderer interface.
+
+`Renderer` mirrors ts/src/lib/renderer.ts:4-8 (`render(stage)`, `addBitmap(tag)`) and
+ts/src/lib/renderers/node-canvas-renderer.ts:7-24 (`new NodeCanvasRenderer(width, height)`), with
+`register_shape` / `register_morph_shape` from rs/src/asset.rs:9-12.  Stages and tags are the
+swf-tree JSON objects of the reference fixtures (tests/<set>/<name>/ast.json).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+OK, ERR_INVALID, ERR_NOT_IMPLEMENTED, ERR_NOT_FOUND, ERR_NO_DEVICE, ERR_DEVICE, ERR_CAPACITY = range(7)
+DEVICE_HOST_ONLY = -1
+FLAG_EVEN_ODD = 1
+PATH_TOR, PATH_BOXES = 0, 1
+STYLE_SOLID, STYLE_RADIAL, STYLE_LINEAR, STYLE_BITMAP = 0, 1, 2, 3
+MAX_STOPS = 16
+
+EXPORTS = [
+    "swfr_abi_version", "swfr_create", "swfr_destroy", "swfr_last_error", "swfr_register_shape",
+    "swfr_register_morph_shape", "swfr_register_bitmap", "swfr_render", "swfr_read_image", "swfr_upload_edges",
+    "swfr_render_resident", "swfr_render_edges", "swfr_build_frame", "swfr_shape_json", "swfr_last_timing",
+    "swfr_band_slab_bytes", "swfr_copy_band_slab", "swfr_device_framebuffer",
+]
+
+
+class SwfrError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("swfr error %d: %s" % (code, message))
+        self.code = code
+
+
+# ---- struct mirrors of include/swfr.h ---------------------------------------------------------
+class Rgba8(C.Structure):
+    _fields_ = [("r", C.c_uint8), ("g", C.c_uint8), ("b", C.c_uint8), ("a", C.c_uint8)]
+
+
+class Rect(C.Structure):
+    _fields_ = [("x_min", C.c_int32), ("x_max", C.c_int32), ("y_min", C.c_int32), ("y_max", C.c_int32)]
+
+
+class Matrix(C.Structure):
+    _fields_ = [("scale_x", C.c_int32), ("scale_y", C.c_int32), ("rotate_skew0", C.c_int32), ("rotate_skew1", C.c_int32),
+                ("translate_x", C.c_int32), ("translate_y", C.c_int32)]
+
+
+class ColorStop(C.Structure):
+    _fields_ = [("ratio", C.c_uint8), ("color", Rgba8), ("morph_color", Rgba8)]
+
+
+class FillStyle(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("color", Rgba8), ("morph_color", Rgba8), ("matrix", Matrix), ("n_stops", C.c_uint32),
+                ("stops", C.POINTER(ColorStop)), ("focal_point", C.c_int32), ("bitmap_id", C.c_uint32),
+                ("repeating", C.c_uint8), ("smoothed", C.c_uint8)]
+
+
+class LineStyle(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("morph_width", C.c_uint32), ("fill", FillStyle)]
+
+
+class Styles(C.Structure):
+    _fields_ = [("n_fill", C.c_uint32), ("fill", C.POINTER(FillStyle)), ("n_line", C.c_uint32), ("line", C.POINTER(LineStyle))]
+
+
+class ShapeRecord(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("delta_x", C.c_int32), ("delta_y", C.c_int32),
+                ("has_control_delta", C.c_uint8), ("control_delta_x", C.c_int32), ("control_delta_y", C.c_int32),
+                ("morph_delta_x", C.c_int32), ("morph_delta_y", C.c_int32),
+                ("has_morph_control_delta", C.c_uint8), ("morph_control_delta_x", C.c_int32), ("morph_control_delta_y", C.c_int32),
+                ("has_move_to", C.c_uint8), ("move_to_x", C.c_int32), ("move_to_y", C.c_int32),
+                ("has_morph_move_to", C.c_uint8), ("morph_move_to_x", C.c_int32), ("morph_move_to_y", C.c_int32),
+                ("has_left_fill", C.c_uint8), ("left_fill", C.c_uint32),
+                ("has_right_fill", C.c_uint8), ("right_fill", C.c_uint32),
+                ("has_line_style", C.c_uint8), ("line_style", C.c_uint32),
+                ("new_styles", C.POINTER(Styles))]
+
+
+class DefineShape(C.Structure):
+    _fields_ = [("id", C.c_uint32), ("bounds", Rect), ("morph_bounds", Rect), ("initial_styles", Styles),
+                ("n_records", C.c_uint32), ("records", C.POINTER(ShapeRecord))]
+
+
+class DisplayObject(C.Structure):
+    pass
+
+
+DisplayObject._fields_ = [("type", C.c_uint32), ("id", C.c_uint32), ("has_matrix", C.c_uint8), ("matrix", Matrix),
+                          ("ratio", C.c_double), ("n_children", C.c_uint32), ("children", C.POINTER(DisplayObject))]
+
+
+class Stage(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("background_color", Rgba8), ("n_children", C.c_uint32),
+                ("children", C.POINTER(DisplayObject))]
+
+
+class Config(C.Structure):
+    _fields_ = [("device", C.c_int32), ("flags", C.c_uint32), ("band_index", C.c_uint32), ("band_count", C.c_uint32)]
+
+
+class Edge(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("x1", "y1", "x2", "y2", "top", "bottom", "dir", "reserved")]
+
+
+class Path(C.Structure):
+    _fields_ = [("first_edge", C.c_uint32), ("n_edges", C.c_uint32), ("kind", C.c_uint32), ("fill_rule", C.c_uint32),
+                ("style", C.c_uint32), ("lerp", C.c_uint32), ("x_min", C.c_int32), ("y_min", C.c_int32),
+                ("x_max", C.c_int32), ("y_max", C.c_int32)]
+
+
+class Style(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("pixel", C.c_uint32), ("inv", C.c_double * 6),
+                ("c0x", C.c_double), ("c0y", C.c_double), ("r0", C.c_double), ("c1x", C.c_double), ("c1y", C.c_double), ("r1", C.c_double),
+                ("n_stops", C.c_uint32), ("stop_offset", C.c_float * MAX_STOPS), ("stop_rgba", (C.c_float * 4) * MAX_STOPS),
+                ("bitmap", C.c_uint32), ("extend", C.c_uint32)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("total_ms", C.c_float), ("setup_ms", C.c_float), ("rows_ms", C.c_float), ("tiles_ms", C.c_float),
+                ("frames", C.c_uint32), ("n_edges", C.c_uint64), ("n_paths", C.c_uint64), ("n_row_tasks", C.c_uint64),
+                ("n_records", C.c_uint64)]
+
+
+EDGE_DTYPE = np.dtype([(n, "<i4") for n in ("x1", "y1", "x2", "y2", "top", "bottom", "dir", "reserved")])
+PATH_DTYPE = np.dtype([("first_edge", "<u4"), ("n_edges", "<u4"), ("kind", "<u4"), ("fill_rule", "<u4"), ("style", "<u4"),
+                       ("lerp", "<u4"), ("x_min", "<i4"), ("y_min", "<i4"), ("x_max", "<i4"), ("y_max", "<i4")])
+assert EDGE_DTYPE.itemsize == C.sizeof(Edge) and PATH_DTYPE.itemsize == C.sizeof(Path)
+
+
+def library_path() -> str:
+    return os.path.join(_HERE, "libswfr.so")
+
+
+def load_library():
+    """Loads libswfr.so; fails loudly when the HIP extension has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise ImportError("libswfr.so is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(needs hipcc); there is no CPU fallback for rasterization")
+    L = C.CDLL(path)
+    P, I, U = C.c_void_p, C.c_int, C.c_uint32
+    L.swfr_abi_version.restype = U
+    L.swfr_create.restype = I
+    L.swfr_create.argtypes = [U, U, C.POINTER(Config), C.POINTER(P)]
+    L.swfr_destroy.restype = None
+    L.swfr_destroy.argtypes = [P]
+    L.swfr_last_error.restype = C.c_char_p
+    L.swfr_last_error.argtypes = [P]
+    for fn in ("swfr_register_shape", "swfr_register_morph_shape"):
+        getattr(L, fn).restype = I
+        getattr(L, fn).argtypes = [P, C.POINTER(DefineShape), C.POINTER(U)]
+    L.swfr_register_bitmap.restype = I
+    L.swfr_register_bitmap.argtypes = [P, U, U, U, P, C.c_size_t]
+    L.swfr_render.restype = I
+    L.swfr_render.argtypes = [P, C.POINTER(Stage)]
+    L.swfr_read_image.restype = I
+    L.swfr_read_image.argtypes = [P, P, C.c_size_t, I]
+    for fn in ("swfr_upload_edges", "swfr_render_edges"):
+        getattr(L, fn).restype = I
+        getattr(L, fn).argtypes = [P, P, C.c_size_t, P, C.c_size_t, P, C.c_size_t]
+    L.swfr_render_resident.restype = I
+    L.swfr_render_resident.argtypes = [P, U]
+    L.swfr_build_frame.restype = I
+    L.swfr_build_frame.argtypes = [P, C.POINTER(Stage), C.POINTER(P), C.POINTER(C.c_size_t), C.POINTER(P), C.POINTER(C.c_size_t),
+                                   C.POINTER(P), C.POINTER(C.c_size_t)]
+    L.swfr_shape_json.restype = I
+    L.swfr_shape_json.argtypes = [P, U, I, C.POINTER(C.c_char_p)]
+    L.swfr_last_timing.restype = I
+    L.swfr_last_timing.argtypes = [P, C.POINTER(Timing)]
+    L.swfr_band_slab_bytes.restype = C.c_size_t
+    L.swfr_band_slab_bytes.argtypes = [P]
+    L.swfr_copy_band_slab.restype = I
+    L.swfr_copy_band_slab.argtypes = [P, P]
+    L.swfr_device_framebuffer.restype = P
+    L.swfr_device_framebuffer.argtypes = [P]
+    if L.swfr_abi_version() != 1:
+        raise ImportError("libswfr.so ABI mismatch")
+    _LIB = L
+    return L
+
+
+# ---- swf-tree JSON -> C structs ------------------------------------------------------------------
+_FILL_TYPES = {"solid": 0, "linear-gradient": 1, "radial-gradient": 2, "focal-gradient": 3, "bitmap": 4}
+
+
+class _Arena:
+    """Keeps every ctypes object referenced by pointer alive for the duration of one call."""
+
+    def __init__(self):
+        self.keep = []
+
+    def array(self, ctype, items):
+        arr = (ctype * max(len(items), 1))(*items)
+        self.keep.append(arr)
+        return arr
+
+
+def _rgba(c):
+    return Rgba8(c["r"], c["g"], c["b"], c["a"])
+
+
+def _matrix(m):
+    return Matrix(m["scale_x"], m["scale_y"], m["rotate_skew0"], m["rotate_skew1"], m["translate_x"], m["translate_y"])
+
+
+def _fill(arena, s):
+    if s["type"] not in _FILL_TYPES:
+        raise SwfrError(ERR_INVALID, "UnknownFillStyle")
+    f = FillStyle()
+    f.type = _FILL_TYPES[s["type"]]
+    if "color" in s:
+        f.color = _rgba(s["color"])
+        f.morph_color = _rgba(s.get("morph_color", s["color"]))
+    if "matrix" in s:
+        f.matrix = _matrix(s["matrix"])
+    if "gradient" in s:
+        stops = [ColorStop(c["ratio"], _rgba(c["color"]), _rgba(c.get("morph_color", c["color"]))) for c in s["gradient"]["colors"]]
+        arr = arena.array(ColorStop, stops)
+        f.n_stops = len(stops)
+        f.stops = C.cast(arr, C.POINTER(ColorStop))
+    if "focal_point" in s:
+        fp = s["focal_point"]
+        f.focal_point = int(fp["epsilons"]) if isinstance(fp, dict) else int(round(float(fp) * 256))
+    if "bitmap_id" in s:
+        f.bitmap_id = s["bitmap_id"]
+        f.repeating = 1 if s.get("repeating") else 0
+        f.smoothed = 1 if s.get("smoothed") else 0
+    return f
+
+
+def _styles(arena, fills, lines):
+    st = Styles()
+    fa = arena.array(FillStyle, [_fill(arena, f) for f in fills])
+    la = arena.array(LineStyle, [LineStyle(l["width"], l.get("morph_width", l["width"]), _fill(arena, l["fill"])) for l in lines])
+    st.n_fill, st.fill = len(fills), C.cast(fa, C.POINTER(FillStyle))
+    st.n_line, st.line = len(lines), C.cast(la, C.POINTER(LineStyle))
+    return st
+
+
+def _define_shape(arena, tag):
+    d = DefineShape()
+    d.id = tag.get("id", 0)
+    b = tag["bounds"]
+    d.bounds = Rect(b["x_min"], b["x_max"], b["y_min"], b["y_max"])
+    mb = tag.get("morph_bounds", b)
+    d.morph_bounds = Rect(mb["x_min"], mb["x_max"], mb["y_min"], mb["y_max"])
+    ini = tag["shape"]["initial_styles"]
+    d.initial_styles = _styles(arena, ini["fill"], ini["line"])
+    recs = []
+    for r in tag["shape"]["records"]:
+        rec = ShapeRecord()
+        if r["type"] == "edge":
+            rec.type = 0
+            rec.delta_x, rec.delta_y = r["delta"]["x"], r["delta"]["y"]
+            md = r.get("morph_delta", r["delta"])
+            rec.morph_delta_x, rec.morph_delta_y = md["x"], md["y"]
+            if r.get("control_delta") is not None:
+                rec.has_control_delta = 1
+                rec.control_delta_x, rec.control_delta_y = r["control_delta"]["x"], r["control_delta"]["y"]
+            if r.get("morph_control_delta") is not None:
+                rec.has_morph_control_delta = 1
+                rec.morph_control_delta_x, rec.morph_control_delta_y = r["morph_control_delta"]["x"], r["morph_control_delta"]["y"]
+        elif r["type"] == "style-change":
+            rec.type = 1
+            if r.get("move_to") is not None:
+                rec.has_move_to = 1
+                rec.move_to_x, rec.move_to_y = r["move_to"]["x"], r["move_to"]["y"]
+            if r.get("morph_move_to") is not None:
+                rec.has_morph_move_to = 1
+                rec.morph_move_to_x, rec.morph_move_to_y = r["morph_move_to"]["x"], r["morph_move_to"]["y"]
+            for key in ("left_fill", "right_fill", "line_style"):
+                if r.get(key) is not None:
+                    setattr(rec, "has_" + key, 1)
+                    setattr(rec, key, r[key])
+            if r.get("new_styles") is not None:
+                ns = _styles(arena, r["new_styles"]["fill"], r["new_styles"]["line"])
+                arena.keep.append(ns)
+                rec.new_styles = C.pointer(ns)
+        else:
+            raise SwfrError(ERR_INVALID, "UnreachableCode")
+        recs.append(rec)
+    ra = arena.array(ShapeRecord, recs)
+    d.n_records, d.records = len(recs), C.cast(ra, C.POINTER(ShapeRecord))
+    return d
+
+
+def decode_x_swf_bmp(data: bytes):
+    """`image/x-swf-bmp` format 3 (zlib colour-mapped) -> (width, height, straight RGBA bytes).
+
+    Host-side mirror of decodeXSwfBmpSync (ts/src/lib/decode-x-swf-bmp.ts:9-41): rows are padded to 4
+    bytes, the palette is opaque, out-of-range indices are opaque black.
+    """
+    import zlib
+    if data[0] != 3:
+        raise SwfrError(ERR_NOT_IMPLEMENTED, "UnsupportedXSwfBmpFormatId: %d" % data[0])
+    width, height = int.from_bytes(data[1:3], "little"), int.from_bytes(data[3:5], "little")
+    padded = width + ((4 - (width % 4)) % 4)
+    n_colors = data[5] + 1
+    src = np.frombuffer(zlib.decompress(bytes(data[6:])), dtype=np.uint8)
+    palette = np.zeros((256, 4), dtype=np.uint8)
+    palette[:, 3] = 255
+    palette[:n_colors, :3] = src[:3 * n_colors].reshape(n_colors, 3)
+    idx = src[3 * n_colors:3 * n_colors + padded * height].reshape(height, padded)[:, :width]
+    return width, height, palette[idx].tobytes()
+
+
+class Renderer:
+    """`new NodeCanvasRenderer(width, height)` + `Renderer{render, addBitmap}` over libswfr.so."""
+
+    def __init__(self, width, height, device=0, even_odd=False, band_index=0, band_count=0):
+        self.L = load_library()
+        self.width, self.height = int(width), int(height)
+        cfg = Config(int(device), FLAG_EVEN_ODD if even_odd else 0, band_index, band_count)
+        h = C.c_void_p()
+        rc = self.L.swfr_create(self.width, self.height, C.byref(cfg), C.byref(h))
+        if rc != OK:
+            raise SwfrError(rc, "swfr_create failed (no HIP device?)" if rc == ERR_NO_DEVICE else "swfr_create failed")
+        self.h = h
+        self._ids = {}        # id(tag) -> (registered id, tag)  [the reference's WeakMap caches]
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.swfr_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _check(self, rc):
+        if rc != OK:
+            raise SwfrError(rc, self.L.swfr_last_error(self.h).decode("utf-8", "replace"))
+
+    # -- assets
+    def register_shape(self, tag) -> int:
+        arena = _Arena()
+        d = _define_shape(arena, tag)
+        out = C.c_uint32()
+        self._check(self.L.swfr_register_shape(self.h, C.byref(d), C.byref(out)))
+        return out.value
+
+    def register_morph_shape(self, tag) -> int:
+        arena = _Arena()
+        d = _define_shape(arena, tag)
+        out = C.c_uint32()
+        self._check(self.L.swfr_register_morph_shape(self.h, C.byref(d), C.byref(out)))
+        return out.value
+
+    def add_bitmap(self, tag):
+        """Renderer.addBitmap(tag: DefineBitmap)."""
+        if tag["media_type"] != "image/x-swf-bmp":
+            raise SwfrError(ERR_NOT_IMPLEMENTED, "NotImplemented: Support for %s images" % tag["media_type"])
+        data = tag["data"]
+        if isinstance(data, str):
+            data = bytes.fromhex(data)
+        w, h, rgba = decode_x_swf_bmp(data)
+        self.register_bitmap(tag["id"], w, h, rgba)
+
+    def register_bitmap(self, bitmap_id, width, height, rgba_straight: bytes):
+        buf = (C.c_uint8 * len(rgba_straight)).from_buffer_copy(rgba_straight)
+        self._check(self.L.swfr_register_bitmap(self.h, bitmap_id, width, height, C.cast(buf, C.c_void_p), width * 4))
+
+    def shape_json(self, shape_id, morph=False) -> str:
+        out = C.c_char_p()
+        self._check(self.L.swfr_shape_json(self.h, shape_id, 1 if morph else 0, C.byref(out)))
+        return out.value.decode("utf-8")
+
+    # -- stage
+    def _object(self, arena, obj):
+        d = DisplayObject()
+        t = obj["type"]
+        if obj.get("matrix") is not None:
+            d.has_matrix = 1
+            d.matrix = _matrix(obj["matrix"])
+        if t == "container":
+            d.type = 2
+            kids = arena.array(DisplayObject, [self._object(arena, c) for c in obj["children"]])
+            d.n_children, d.children = len(obj["children"]), C.cast(kids, C.POINTER(DisplayObject))
+            return d
+        if t not in ("shape", "morph-shape"):
+            raise SwfrError(ERR_INVALID, "UnexpectedDisplayObjectType")
+        morph = t == "morph-shape"
+        d.type = 1 if morph else 0
+        if "definition" in obj:
+            key = (id(obj["definition"]), morph)
+            if key not in self._ids:
+                reg = self.register_morph_shape if morph else self.register_shape
+                self._ids[key] = (reg(obj["definition"]), obj["definition"])
+            d.id = self._ids[key][0]
+        else:
+            d.id = obj["id"]
+        if morph:
+            d.ratio = float(obj["ratio"])
+        return d
+
+    def _stage(self, arena, stage):
+        s = Stage()
+        s.width, s.height = stage.get("width", self.width), stage.get("height", self.height)
+        bg = stage.get("background_color") or {"r": 0, "g": 0, "b": 0, "a": 0}
+        s.background_color = _rgba(bg)
+        kids = arena.array(DisplayObject, [self._object(arena, c) for c in stage["children"]])
+        s.n_children, s.children = len(stage["children"]), C.cast(kids, C.POINTER(DisplayObject))
+        return s
+
+    def render(self, stage):
+        """Renderer.render(stage): blocking; the image stays in HBM until read_image()."""
+        arena = _Arena()
+        s = self._stage(arena, stage)
+        self._check(self.L.swfr_render(self.h, C.byref(s)))
+
+    def build_frame(self, stage):
+        """Host half only: (edges, paths, styles) exactly as render() would upload them."""
+        arena = _Arena()
+        s = self._stage(arena, stage)
+        pe, pp, ps = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        ne, npth, ns = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        self._check(self.L.swfr_build_frame(self.h, C.byref(s), C.byref(pe), C.byref(ne), C.byref(pp), C.byref(npth),
+                                            C.byref(ps), C.byref(ns)))
+        edges = np.frombuffer((C.c_char * (ne.value * EDGE_DTYPE.itemsize)).from_address(pe.value), dtype=EDGE_DTYPE).copy() \
+            if ne.value else np.zeros(0, EDGE_DTYPE)
+        paths = np.frombuffer((C.c_char * (npth.value * PATH_DTYPE.itemsize)).from_address(pp.value), dtype=PATH_DTYPE).copy() \
+            if npth.value else np.zeros(0, PATH_DTYPE)
+        styles = [Style.from_buffer_copy((C.c_char * C.sizeof(Style)).from_address(ps.value + i * C.sizeof(Style)))
+                  for i in range(ns.value)]
+        return edges, paths, styles
+
+    # -- low level (the hot path proper)
+    @staticmethod
+    def _styles_array(styles):
+        arr = (Style * max(len(styles), 1))(*styles)
+        return arr
+
+    def upload_edges(self, edges: np.ndarray, paths: np.ndarray, styles):
+        edges = np.ascontiguousarray(edges, dtype=EDGE_DTYPE)
+        paths = np.ascontiguousarray(paths, dtype=PATH_DTYPE)
+        sarr = self._styles_array(styles)
+        self._check(self.L.swfr_upload_edges(self.h, edges.ctypes.data, len(edges), paths.ctypes.data, len(paths),
+                                             C.cast(sarr, C.c_void_p), len(styles)))
+
+    def render_resident(self, frames=1):
+        self._check(self.L.swfr_render_resident(self.h, frames))
+
+    def render_edges(self, edges, paths, styles):
+        self.upload_edges(edges, paths, styles)
+        self.render_resident(1)
+
+    def timing(self) -> dict:
+        t = Timing()
+        self.L.swfr_last_timing(self.h, C.byref(t))
+        return {n: getattr(t, n) for n, _ in Timing._fields_}
+
+    def read_image(self, premultiplied=False) -> np.ndarray:
+        """HxWx4 uint8 RGBA; straight (as the reference's PNG/getImageData) unless premultiplied=True."""
+        out = np.empty((self.height, self.width, 4), dtype=np.uint8)
+        self._check(self.L.swfr_read_image(self.h, out.ctypes.data, self.width * 4, 1 if premultiplied else 0))
+        return out
+
+    def band_slab_bytes(self) -> int:
+        return self.L.swfr_band_slab_bytes(self.h)
+
+    def copy_band_slab(self, device_ptr: int):
+        self._check(self.L.swfr_copy_band_slab(self.h, device_ptr))
+
+
+def solid_style(pixel_argb_premultiplied: int) -> Style:
+    s = Style()
+    s.kind = STYLE_SOLID
+    s.pixel = pixel_argb_premultiplied
+    return s
+
+
+def polygons_to_scene(fixed_xy: np.ndarray, colors_rgba8: np.ndarray, width: int, height: int):
+    """Closed polygons in 24.8 device coordinates (all inside the frame) -> (edges, paths, styles).
+
+    Used for the synthetic benchmark scenes: the flattened, painter-ordered edge list a host would
+    produce for opaque solid stars.  fixed_xy: int32 [n, verts, 2]; colours straight RGBA8.
+    """
+    n, verts, _ = fixed_xy.shape
+    a = fixed_xy
+    b = np.roll(fixed_xy, -1, axis=1)
+    down = a[..., 1] < b[..., 1]
+    flat = a[..., 1] == b[..., 1]
+    e = np.zeros((n, verts), dtype=EDGE_DTYPE)
+    e["x1"] = np.where(down, a[..., 0], b[..., 0])
+    e["y1"] = np.where(down, a[..., 1], b[..., 1])
+    e["x2"] = np.where(down, b[..., 0], a[..., 0])
+    e["y2"] = np.where(down, b[..., 1], a[..., 1])
+    e["top"], e["bottom"] = e["y1"], e["y2"]
+    e["dir"] = np.where(down, 1, -1)
+    keep = ~flat
+    counts = keep.sum(axis=1).astype(np.uint32)
+    edges = e[keep]
+    paths = np.zeros(n, dtype=PATH_DTYPE)
+    paths["first_edge"] = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.uint32)
+    paths["n_edges"] = counts
+    paths["kind"] = PATH_TOR
+    paths["style"] = np.arange(n, dtype=np.uint32)
+    paths["lerp"] = 1
+    paths["x_min"] = np.maximum(fixed_xy[..., 0].min(axis=1) >> 8, 0)
+    paths["y_min"] = np.maximum(fixed_xy[..., 1].min(axis=1) >> 8, 0)
+    paths["x_max"] = np.minimum((fixed_xy[..., 0].max(axis=1) + 255) >> 8, width)
+    paths["y_max"] = np.minimum((fixed_xy[..., 1].max(axis=1) + 255) >> 8, height)
+    c = colors_rgba8.astype(np.uint32)
+    al = c[:, 3]
+    # cairo_set_source_rgba(r/255, ...): premultiply in doubles, 16-bit shorts, >> 8
+    def sh(v):
+        return ((v * 65535.0 + 0.5).astype(np.uint32) & 0xFFFF) >> 8
+    af = al / 255.0
+    pix = (sh(af) << 24) | (sh(c[:, 0] / 255.0 * af) << 16) | (sh(c[:, 1] / 255.0 * af) << 8) | sh(c[:, 2] / 255.0 * af)
+    styles = [solid_style(int(p)) for p in pix]
+    return edges, paths, styles

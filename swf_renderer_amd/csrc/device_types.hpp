@@ -1,0 +1,45 @@
+// device_types.hpp -- records shared by the HIP kernels and the host-side renderer.
+#pragma once
+
+#include <stdint.h>
+
+#include "../../include/swfr.h"
+
+namespace swfr {
+
+constexpr int TILE_W = 64;   // one wavefront lane per pixel column
+constexpr int TILE_H = 16;   // 4 waves x 4 rows
+
+// Per-edge constants of the tor scan converter (SURVEY.md A.5 make_edge), 64 bytes.
+struct DevEdge {
+    int32_t ytop, ybot;      // active sub-rows [ytop, ybot), 15 per pixel row, clamped to the path's rows
+    int32_t x1, y1;          // upper end point of the line (24.8)
+    int32_t dir, pad;
+    int64_t ex;              // (x2 - x1) * 256
+    int64_t dy;              // (y2 - y1) * 15 * 512, 0 for vertical edges
+    int64_t dq, dr;          // per-sub-row slope: truncated quotient / remainder of ex*512 / dy
+    int64_t pad2;
+};
+static_assert(sizeof(DevEdge) == 64, "DevEdge layout");
+
+using DevPath = swfr_path;   // 40 bytes: first_edge, n_edges, kind, fill_rule, style, lerp, pixel rect
+
+enum : uint32_t { ROW_EMPTY = 0, ROW_FULL = 1, ROW_SUB = 2 };
+struct RowInfo {
+    uint32_t rec_off;
+    uint16_t n_rec;
+    uint16_t mode;
+};
+
+// record = {edge index, roles}: FULL rows carry REC_FULL | 1 (left, +1) or | 2 (right, -1);
+// SUB rows carry 15 two-bit fields, field s = 1 (a span opens at this edge in sub-row s) or 2 (closes)
+constexpr uint32_t REC_FULL = 0x80000000u;
+
+enum : uint32_t { CNT_RECORDS = 0, CNT_ERROR = 1, CNT_WORDS = 4 };
+
+struct DevBitmap {
+    const uint32_t* pixels;  // premultiplied ARGB, tight rows
+    uint32_t width, height;
+};
+
+}  // namespace swfr

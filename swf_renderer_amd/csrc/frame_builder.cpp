@@ -1,0 +1,301 @@
+// frame_builder.cpp -- see frame_builder.hpp.
+#include "frame_builder.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+namespace swfr {
+namespace {
+
+inline double lerp(double a, double b, double r) { return b * r + a * (1 - r); }  // canvas-renderer.ts:24-26
+
+struct Css {
+    int r, g, b, a;
+};
+// fromNormalizedColor (ts/src/lib/css-color.ts:11-13) then node-canvas' CSS colour parse: R is
+// `& 0xff`-truncated, G/B truncate to ints, alpha is quantised to 8 bits in float.
+Css css_color(double r, double g, double b, double a) {
+    Css c;
+    c.r = int(r * 255.0) & 0xff;
+    c.g = std::clamp(int(g * 255.0), 0, 255);
+    c.b = std::clamp(int(b * 255.0), 0, 255);
+    const float af = float(std::clamp(a, 0.0, 1.0));
+    c.a = int(af * 255.0f);
+    return c;
+}
+// cairo_set_source_rgba(r/255, g/255, b/255, a/255): premultiply in doubles, 16-bit shorts, >> 8.
+uint32_t premultiplied_pixel(const Css& c) {
+    const double r = c.r / 255.0, g = c.g / 255.0, b = c.b / 255.0, a = c.a / 255.0;
+    auto sh = [](double v) { return uint32_t(uint16_t(v * 65535.0 + 0.5)) >> 8; };
+    return (sh(a) << 24) | (sh(r * a) << 16) | (sh(g * a) << 8) | sh(b * a);
+}
+Css morph_color(const swfr_rgba8& s, const swfr_rgba8& e, bool morph, double ratio) {
+    if (!morph) return css_color(s.r / 255.0, s.g / 255.0, s.b / 255.0, s.a / 255.0);
+    return css_color(lerp(s.r / 255.0, e.r / 255.0, ratio), lerp(s.g / 255.0, e.g / 255.0, ratio),
+                     lerp(s.b / 255.0, e.b / 255.0, ratio), lerp(s.a / 255.0, e.a / 255.0, ratio));
+}
+
+}  // namespace
+
+Affine FrameBuilder::matrix_of(const swfr_matrix& m) {
+    // applyMatrix (canvas-renderer.ts:179-188): transform(scaleX, rotateSkew0, rotateSkew1, scaleY, tx, ty)
+    Affine a;
+    a.xx = m.scale_x / 65536.0;
+    a.yx = m.rotate_skew0 / 65536.0;
+    a.xy = m.rotate_skew1 / 65536.0;
+    a.yy = m.scale_y / 65536.0;
+    a.x0 = m.translate_x;
+    a.y0 = m.translate_y;
+    return a;
+}
+
+const DecodedShape* FrameBuilder::shape(uint32_t id, bool morph) const {
+    const auto& v = morph ? morphs_ : shapes_;
+    return id < v.size() ? &v[id] : nullptr;
+}
+
+void FrameBuilder::build(const swfr_stage& stage) {
+    edges_.clear();
+    paths_.clear();
+    styles_.clear();
+    stack_.clear();
+    surface_clear_ = true;  // clearRect over the whole canvas (canvas-renderer.ts:70-71)
+    State s;
+    s.ctm = Affine::scale(1.0 / 20.0, 1.0 / 20.0);  // twips -> px (:74)
+    stack_.push_back(s);
+    for (uint32_t i = 0; i < stage.n_children; ++i) draw(stage.children[i], 0);
+}
+
+void FrameBuilder::draw(const swfr_display_object& obj, int depth) {
+    if (depth > 256) throw StatusError{SWFR_ERR_INVALID, "display tree too deep"};
+    stack_.push_back(stack_.back());  // context.save()
+    struct Pop {
+        std::vector<State>& s;
+        ~Pop() { s.pop_back(); }
+    } pop{stack_};
+    if (obj.has_matrix) stack_.back().ctm = matrix_of(obj.matrix).then(stack_.back().ctm);
+    switch (obj.type) {
+        case SWFR_OBJECT_CONTAINER:
+            for (uint32_t i = 0; i < obj.n_children; ++i) draw(obj.children[i], depth + 1);
+            break;
+        case SWFR_OBJECT_SHAPE: {
+            const DecodedShape* sh = shape(obj.id, false);
+            if (!sh) throw StatusError{SWFR_ERR_NOT_FOUND, "unknown shape id"};
+            for (const StyledPath& p : sh->paths) draw_path(p, false, 0.0);
+            break;
+        }
+        case SWFR_OBJECT_MORPH_SHAPE: {
+            const DecodedShape* sh = shape(obj.id, true);
+            if (!sh) throw StatusError{SWFR_ERR_NOT_FOUND, "unknown morph shape id"};
+            for (const StyledPath& p : sh->paths) draw_path(p, true, obj.ratio);
+            break;
+        }
+        default:
+            throw StatusError{SWFR_ERR_INVALID, "UnexpectedDisplayObjectType"};
+    }
+}
+
+void FrameBuilder::trace(const StyledPath& p, bool morph, double ratio) {
+    const Affine& ctm = stack_.back().ctm;
+    auto val = [&](const Coord& c) { return morph ? lerp(c.s, c.e, ratio) : c.s; };
+    auto dev = [&](double x, double y) {
+        ctm.apply(x, y);
+        return Pt{to_fixed(x), to_fixed(y)};
+    };
+    path_.clear();
+    for (const PathCommand& c : p.commands) {
+        switch (c.kind) {
+            case PathCommand::MoveTo:
+                path_.move_to(dev(val(c.x), val(c.y)));
+                break;
+            case PathCommand::LineTo:
+                path_.line_to(dev(val(c.x), val(c.y)));
+                break;
+            case PathCommand::CurveTo: {
+                // node-canvas quadraticCurveTo: the current point is the quantised device point mapped
+                // back to user space; (0,0) stands for "no current point" and selects the control point
+                double x = 0, y = 0;
+                if (path_.has_current_point()) {
+                    Affine inv = ctm;
+                    x = from_fixed(path_.current_point().x);
+                    y = from_fixed(path_.current_point().y);
+                    if (inv.invert()) inv.apply(x, y);
+                }
+                const double x1 = val(c.cx), y1 = val(c.cy), x2 = val(c.x), y2 = val(c.y);
+                if (x == 0 && y == 0) {
+                    x = x1;
+                    y = y1;
+                }
+                const double k = 2.0 / 3.0;
+                path_.cubic_to(dev(x + k * (x1 - x), y + k * (y1 - y)), dev(x2 + k * (x1 - x2), y2 + k * (y1 - y2)), dev(x2, y2));
+                break;
+            }
+        }
+    }
+}
+
+void FrameBuilder::draw_path(const StyledPath& p, bool morph, double ratio) {
+    if ((!p.has_fill && !p.has_line) || p.commands.empty()) return;
+    trace(p, morph, ratio);
+    if (p.has_fill) emit_fill(p.fill, morph, ratio);
+    if (p.has_line) emit_stroke(p, morph, ratio);
+}
+
+bool FrameBuilder::frame_bounds(Pt lo, Pt hi, bool& needs_clip) const {
+    if (!(lo.x < hi.x && lo.y < hi.y)) return false;
+    int x0 = floor_px(lo.x), y0 = floor_px(lo.y), x1 = ceil_px(hi.x), y1 = ceil_px(hi.y);
+    needs_clip = !(x0 >= 0 && y0 >= 0 && x1 <= int(w_) && y1 <= int(h_));
+    x0 = std::max(x0, 0);
+    y0 = std::max(y0, 0);
+    x1 = std::min(x1, int(w_));
+    y1 = std::min(y1, int(h_));
+    return x0 < x1 && y0 < y1;
+}
+
+uint32_t FrameBuilder::push_solid(uint32_t pixel) {
+    swfr_style st;
+    std::memset(&st, 0, sizeof st);
+    st.kind = SWFR_STYLE_SOLID;
+    st.pixel = pixel;
+    styles_.push_back(st);
+    return uint32_t(styles_.size() - 1);
+}
+
+void FrameBuilder::emit_polygon(Polygon& poly, bool rectilinear, uint32_t style, bool opaque_solid) {
+    const bool lerp_blend = opaque_solid || surface_clear_;
+    surface_clear_ = false;  // any drawing op that was not "nothing to do" dirties the surface
+    if (poly.empty()) return;
+    swfr_path p;
+    std::memset(&p, 0, sizeof p);
+    p.first_edge = uint32_t(edges_.size());
+    p.fill_rule = even_odd_ ? 1 : 0;
+    p.style = style;
+    p.lerp = lerp_blend ? 1 : 0;
+    p.x_min = std::max(floor_px(poly.ext_min().x), 0);
+    p.y_min = std::max(floor_px(poly.ext_min().y), 0);
+    p.x_max = std::min(ceil_px(poly.ext_max().x), int(w_));
+    p.y_max = std::min(ceil_px(poly.ext_max().y), int(h_));
+    if (p.x_min >= p.x_max || p.y_min >= p.y_max) return;
+    if (rectilinear) {
+        p.kind = SWFR_PATH_BOXES;
+        rectilinear_to_boxes(poly, even_odd_, edges_);
+    } else {
+        p.kind = SWFR_PATH_TOR;
+        edges_.insert(edges_.end(), poly.edges().begin(), poly.edges().end());
+    }
+    p.n_edges = uint32_t(edges_.size()) - p.first_edge;
+    if (p.n_edges) paths_.push_back(p);
+}
+
+void FrameBuilder::emit_fill(const OwnedFill& f, bool morph, double ratio) {
+    const swfr_fill_style& s = f.style;
+    uint32_t style_index = 0;
+    bool opaque_solid = false;
+    // context.save(); <source>; fill(); context.restore()  (canvas-renderer.ts:292-336)
+    if (s.type == SWFR_FILL_SOLID) {
+        const uint32_t px = premultiplied_pixel(morph_color(s.color, s.morph_color, morph, ratio));
+        if ((px >> 24) == 0) return;  // Cairo: OVER with a clear source is a no-op
+        opaque_solid = (px >> 24) == 0xff;
+        style_index = push_solid(px);
+    } else if (s.type == SWFR_FILL_BITMAP) {
+        auto it = bitmaps_.find(s.bitmap_id);
+        if (it == bitmaps_.end()) throw StatusError{SWFR_ERR_NOT_FOUND, "BitmapNotFound: " + std::to_string(s.bitmap_id)};
+        swfr_style st;
+        std::memset(&st, 0, sizeof st);
+        st.kind = SWFR_STYLE_BITMAP;
+        Affine inv = matrix_of(s.matrix).then(stack_.back().ctm);
+        if (!inv.invert()) return;
+        const double m[6] = {inv.xx, inv.yx, inv.xy, inv.yy, inv.x0, inv.y0};
+        std::memcpy(st.inv, m, sizeof m);
+        st.bitmap = s.bitmap_id;
+        st.extend = s.repeating ? 1 : 0;
+        styles_.push_back(st);
+        style_index = uint32_t(styles_.size() - 1);
+    } else {
+        // Radial == focal with focalPoint 0 (decode-swf-shape.ts:127-133); createRadialGradient(
+        // f*16384, 0, 0, 0, 0, 16384) under fill.matrix (canvas-renderer.ts:320-331).  Linear gradients
+        // throw NotImplementedFillStyle in the reference (:332-333); here they are the documented
+        // extension createLinearGradient(-16384, 0, 16384, 0).
+        if (f.stops.size() > SWFR_MAX_STOPS) throw StatusError{SWFR_ERR_CAPACITY, "too many gradient stops"};
+        swfr_style st;
+        std::memset(&st, 0, sizeof st);
+        Affine inv = matrix_of(s.matrix).then(stack_.back().ctm);
+        if (!inv.invert()) return;
+        const double m[6] = {inv.xx, inv.yx, inv.xy, inv.yy, inv.x0, inv.y0};
+        std::memcpy(st.inv, m, sizeof m);
+        const double R = 16384.0;
+        if (s.type == SWFR_FILL_LINEAR_GRADIENT) {
+            st.kind = SWFR_STYLE_LINEAR;
+            st.c0x = -R; st.c1x = R;
+        } else {
+            st.kind = SWFR_STYLE_RADIAL;
+            const double focal = s.type == SWFR_FILL_FOCAL_GRADIENT ? s.focal_point / 256.0 : 0.0;
+            st.c0x = lerp(0, R, focal);
+            st.r0 = 0; st.r1 = R;
+        }
+        // stops sorted by offset, stable (cairo_pattern_add_color_stop keeps them ordered)
+        std::vector<swfr_color_stop> stops = f.stops;
+        std::stable_sort(stops.begin(), stops.end(), [](const swfr_color_stop& a, const swfr_color_stop& b) { return a.ratio < b.ratio; });
+        st.n_stops = uint32_t(stops.size());
+        for (size_t i = 0; i < stops.size(); ++i) {
+            const Css c = css_color(stops[i].color.r / 255.0, stops[i].color.g / 255.0, stops[i].color.b / 255.0, stops[i].color.a / 255.0);
+            st.stop_offset[i] = float(stops[i].ratio / 255.0);
+            st.stop_rgba[i][0] = float(c.r / 255.0);
+            st.stop_rgba[i][1] = float(c.g / 255.0);
+            st.stop_rgba[i][2] = float(c.b / 255.0);
+            st.stop_rgba[i][3] = float(c.a / 255.0);
+        }
+        styles_.push_back(st);
+        style_index = uint32_t(styles_.size() - 1);
+    }
+    if (path_.empty_extents()) return;
+    bool needs_clip = false;
+    if (!frame_bounds(path_.box_min(), path_.box_max(), needs_clip)) return;  // nothing to do: surface stays clear
+    Polygon poly;
+    const Pt lo{0, 0}, hi{fixed_t(w_) * 256, fixed_t(h_) * 256};
+    poly.reset(needs_clip, lo, hi);
+    if (needs_clip) fill_to_polygon_clipped(path_, poly, lo, hi); else fill_to_polygon(path_, poly);
+    emit_polygon(poly, path_.fill_is_rectilinear(), style_index, opaque_solid);
+}
+
+void FrameBuilder::emit_stroke(const StyledPath& p, bool morph, double ratio) {
+    if (p.fill.style.type != SWFR_FILL_SOLID) throw StatusError{SWFR_ERR_NOT_IMPLEMENTED, "NotImplementedLineStyle"};
+    State& st = stack_.back();
+    const double width = morph ? lerp(p.width, p.morph_width, ratio) : double(p.width);
+    if (width > 0) st.line_width = width;  // node-canvas ignores non-positive widths
+    const uint32_t px = premultiplied_pixel(morph_color(p.fill.style.color, p.fill.style.morph_color, morph, ratio));
+    if (morph) st.cap = st.join = 1;  // lineCap = lineJoin = "round" (canvas-renderer.ts:263-264)
+    if ((px >> 24) == 0) return;
+    if (path_.empty_extents()) return;
+    // approximate stroke extents: path box grown by the style's maximum distance from the path
+    double expansion = 0.5;
+    if (st.join == 0 && !path_.stroke_is_rectilinear() && expansion < M_SQRT2 * 10.0) expansion = M_SQRT2 * 10.0;
+    expansion *= st.line_width;
+    const Affine& c = st.ctm;
+    const bool unity = (std::fabs(c.xx) == 1.0 && std::fabs(c.yy) == 1.0 && c.xy == 0.0 && c.yx == 0.0) ||
+                       (std::fabs(c.xy) == 1.0 && std::fabs(c.yx) == 1.0 && c.xx == 0.0 && c.yy == 0.0);
+    const double gx = unity ? expansion : expansion * std::hypot(c.xx, c.xy);
+    const double gy = unity ? expansion : expansion * std::hypot(c.yy, c.yx);
+    Pt lo = path_.box_min(), hi = path_.box_max();
+    lo.x -= to_fixed(gx); lo.y -= to_fixed(gy);
+    hi.x += to_fixed(gx); hi.y += to_fixed(gy);
+    bool needs_clip = false;
+    if (!frame_bounds(lo, hi, needs_clip)) return;
+    Polygon poly;
+    poly.reset(needs_clip, Pt{0, 0}, Pt{fixed_t(w_) * 256, fixed_t(h_) * 256});
+    StrokeParams sp;
+    sp.line_width = st.line_width;
+    sp.cap = st.cap;
+    sp.join = st.join;
+    if (!stroke_to_polygon(path_, sp, st.ctm, poly))
+        throw StatusError{SWFR_ERR_NOT_IMPLEMENTED, "stroke needs round joins/caps, closed sub-paths, curves or the rectilinear stroker"};
+    const bool opaque = (px >> 24) == 0xff;
+    const uint32_t style_index = push_solid(px);
+    // strokes are filled non-zero regardless of the configured fill rule
+    const bool saved = even_odd_;
+    even_odd_ = false;
+    emit_polygon(poly, false, style_index, opaque);
+    even_odd_ = saved;
+}
+
+}  // namespace swfr

@@ -1,0 +1,70 @@
+// frame_builder.hpp -- host scene walk: Stage -> painter-ordered edge list + path/style tables.
+//
+// Mirrors CanvasRenderer (ts/src/lib/renderers/canvas-renderer.ts:61-350): reset CTM, clear,
+// scale(1/20), matrix stack over containers/shapes/morph shapes, per path beginPath + commands +
+// fill() / stroke().  Instead of calling a Canvas it emits what the GPU scan converter consumes.
+#pragma once
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/swfr.h"
+#include "geometry.hpp"
+#include "shape_decoder.hpp"
+
+namespace swfr {
+
+struct BitmapInfo {
+    uint32_t width = 0, height = 0;
+};
+
+struct StatusError {
+    int code;
+    std::string message;
+};
+
+class FrameBuilder {
+public:
+    FrameBuilder(uint32_t width, uint32_t height, bool even_odd) : w_(width), h_(height), even_odd_(even_odd) {}
+
+    uint32_t add_shape(DecodedShape s) { shapes_.push_back(std::move(s)); return uint32_t(shapes_.size() - 1); }
+    uint32_t add_morph_shape(DecodedShape s) { morphs_.push_back(std::move(s)); return uint32_t(morphs_.size() - 1); }
+    void add_bitmap(uint32_t id, BitmapInfo info) { bitmaps_[id] = info; }
+    const DecodedShape* shape(uint32_t id, bool morph) const;
+
+    // Throws StatusError.  Results stay valid until the next build().
+    void build(const swfr_stage& stage);
+    const std::vector<swfr_edge>& edges() const { return edges_; }
+    const std::vector<swfr_path>& paths() const { return paths_; }
+    const std::vector<swfr_style>& styles() const { return styles_; }
+
+private:
+    struct State {
+        Affine ctm;
+        double line_width = 1.0;  // node-canvas creates its context with line width 1
+        int cap = 0, join = 0;
+    };
+    void draw(const swfr_display_object& obj, int depth);
+    void draw_path(const StyledPath& p, bool morph, double ratio);
+    void trace(const StyledPath& p, bool morph, double ratio);
+    void emit_fill(const OwnedFill& f, bool morph, double ratio);
+    void emit_stroke(const StyledPath& p, bool morph, double ratio);
+    void emit_polygon(Polygon& poly, bool rectilinear, uint32_t style, bool opaque_solid);
+    uint32_t push_solid(uint32_t pixel);
+    bool frame_bounds(Pt lo, Pt hi, bool& needs_clip) const;
+    static Affine matrix_of(const swfr_matrix& m);
+
+    uint32_t w_, h_;
+    bool even_odd_;
+    std::vector<DecodedShape> shapes_, morphs_;
+    std::map<uint32_t, BitmapInfo> bitmaps_;
+    std::vector<State> stack_;
+    DevicePath path_;
+    bool surface_clear_ = true;
+    std::vector<swfr_edge> edges_;
+    std::vector<swfr_path> paths_;
+    std::vector<swfr_style> styles_;
+};
+
+}  // namespace swfr

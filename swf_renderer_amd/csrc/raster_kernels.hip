@@ -1,0 +1,674 @@
+// raster_kernels.hip -- CDNA4 (gfx950) kernels of the hot path: edge list -> RGBA8 framebuffer in HBM.
+//
+// Pipeline per frame (all on one stream, no host round trips):
+//   k_setup  one thread per edge: Cairo "tor" edge constants (sub-row span, slope quotient/remainder)
+//            [SURVEY.md A.5 make_edge]
+//   k_rows   one lane per (path, pixel row): gathers the row's active edges, decides the row mode
+//            (analytic FULL row vs 15x sub-sampled SUB row), sorts by cell and runs the winding prefix
+//            to give every edge its role (span start / span end / interior).  Output: compact per-row
+//            records {edge, roles}.                                   [A.5 can_do_full_row/full_row/sub_row]
+//   k_tiles  one 256-thread workgroup per 64x16-pixel tile: walks the paths overlapping the tile in
+//            painter's order; accumulates covered-height / uncovered-area per cell in LDS (atomics),
+//            wave64 prefix sum along x, coverage -> 8-bit alpha, shades (solid / gradient / bitmap)
+//            and blends into the tile-resident pixels held in registers; one coalesced store per pixel.
+//                                                                      [A.5 render_edge/blit, A.6, A.7]
+// Integer arithmetic is exact (int64 products, double-estimated quotients with integer fix-up), so
+// results are bit-identical to the CPU scan converter for solid fills.
+//
+// No MFMA here: there is no dense contraction on this path; the roof is HBM store bandwidth.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_types.hpp"
+
+namespace swfr {
+
+// ---------------------------------------------------------------------------------------------
+// exact helpers
+// ---------------------------------------------------------------------------------------------
+// floor(a / b) for b > 0 with remainder in [0, b); quotient magnitude < 2^31 in all call sites.
+__device__ __forceinline__ void floor_div(int64_t a, int64_t b, int64_t& q, int64_t& r) {
+    q = (int64_t)floor((double)a / (double)b);
+    r = a - q * b;
+    while (r < 0) { --q; r += b; }
+    while (r >= b) { ++q; r -= b; }
+}
+// C (truncating) division, b > 0.
+__device__ __forceinline__ void trunc_div(int64_t a, int64_t b, int64_t& q, int64_t& r) {
+    floor_div(a, b, q, r);
+    if (a < 0 && r != 0) { ++q; r -= b; }
+}
+// x of the edge at the centre of sub-row s: quo + rem/dy, rem in [0,dy)  (closed form of A.5 stepping)
+__device__ __forceinline__ void edge_x_at(const DevEdge& e, int s, int32_t& quo, int64_t& rem) {
+    if (e.dy == 0) { quo = e.x1; rem = 0; return; }
+    const int64_t a = ((int64_t)(2 * s + 1) << 8) - 30 * (int64_t)e.y1;
+    int64_t q, r;
+    floor_div(a * e.ex, e.dy, q, r);
+    quo = e.x1 + (int32_t)q;
+    rem = r;
+}
+__device__ __forceinline__ int cell_of(int32_t quo, int64_t rem, int64_t dy) { return quo + (rem >= dy / 2 ? 1 : 0); }
+__device__ __forceinline__ void step_x(int32_t& quo, int64_t& rem, const DevEdge& e) {
+    quo += (int32_t)e.dq; rem += e.dr;
+    if (rem < 0) { --quo; rem += e.dy; } else if (rem >= e.dy) { ++quo; rem -= e.dy; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_setup
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_setup(const swfr_edge* __restrict__ in, const DevPath* __restrict__ paths,
+                                               DevEdge* __restrict__ out, uint32_t n_edges) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_edges) return;
+    const swfr_edge e = in[i];
+    const DevPath p = paths[e.reserved];
+    DevEdge d;
+    d.x1 = e.x1; d.y1 = e.y1; d.dir = e.dir; d.pad = 0;
+    if (p.kind != SWFR_PATH_TOR) {          // boxes are consumed raw by k_tiles
+        d.ytop = d.ybot = 0; d.dy = 0; d.ex = 0; d.dq = d.dr = 0;
+        out[i] = d;
+        return;
+    }
+    int ytop = (int)((15ll * e.top + 128) >> 8), ybot = (int)((15ll * e.bottom + 128) >> 8);
+    ytop = max(ytop, p.y_min * 15);
+    ybot = min(ybot, p.y_max * 15);
+    if (ybot <= ytop) { ytop = ybot = 0; }  // never active
+    d.ytop = ytop; d.ybot = ybot;
+    if (e.x1 == e.x2) {
+        d.dy = 0; d.ex = 0; d.dq = d.dr = 0;
+    } else {
+        d.ex = (int64_t)(e.x2 - e.x1) * 256;
+        d.dy = (int64_t)(e.y2 - e.y1) * 15 * 512;
+        trunc_div(d.ex * 512, d.dy, d.dq, d.dr);
+    }
+    out[i] = d;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_rows
+// ---------------------------------------------------------------------------------------------
+#define ROWS_MAXA 32
+
+struct RowLds {
+    int32_t eid[ROWS_MAXA][64];
+    int32_t quo[ROWS_MAXA][64];
+    int32_t rem_lo[ROWS_MAXA][64];
+    int32_t rem_hi[ROWS_MAXA][64];
+    int32_t cell[ROWS_MAXA][64];
+    int32_t aux[ROWS_MAXA][64];     // FULL check: end cell; SUB: role bits
+    uint8_t ord[ROWS_MAXA][64];
+};
+
+__global__ __launch_bounds__(64) void k_rows(const DevEdge* __restrict__ edges, const DevPath* __restrict__ paths,
+                                             const uint32_t* __restrict__ row_base, uint32_t n_paths,
+                                             RowInfo* __restrict__ rows, uint2* __restrict__ records,
+                                             uint32_t* __restrict__ counters, uint32_t n_tasks,
+                                             uint32_t band_index, uint32_t band_count) {
+    __shared__ RowLds L;
+    const int lane = threadIdx.x;
+    const uint32_t t = blockIdx.x * 64 + lane;
+    uint32_t n_out = 0;      // records this lane will write
+    uint32_t mode = ROW_EMPTY;
+    int n = 0;
+    DevPath P;
+    int r = 0, s0 = 0;
+    bool live = t < n_tasks;
+    if (live) {
+        // task -> (path, row): upper_bound on the prefix array
+        uint32_t lo = 0, hi = n_paths;
+        while (lo + 1 < hi) { const uint32_t mid = (lo + hi) >> 1; if (row_base[mid] <= t) lo = mid; else hi = mid; }
+        P = paths[lo];
+        r = P.y_min + (int)(t - row_base[lo]);
+        s0 = r * 15;
+        if (P.kind != SWFR_PATH_TOR) live = false;
+        else if (band_count > 1 && (uint32_t)((r / TILE_H) % band_count) != band_index) live = false;
+    }
+    if (live) {
+        bool mid_row = false, overflow = false;
+        for (uint32_t k = 0; k < P.n_edges; ++k) {
+            const uint32_t e = P.first_edge + k;
+            const int ytop = edges[e].ytop, ybot = edges[e].ybot;
+            if (ybot <= s0 || ytop >= s0 + 15) continue;
+            if (n < ROWS_MAXA) { L.eid[n][lane] = (int32_t)e; ++n; } else overflow = true;
+            mid_row |= (ytop > s0) | (ybot < s0 + 15);
+        }
+        if (overflow) { atomicOr(&counters[CNT_ERROR], 1u); n = 0; }
+        const unsigned mask = P.fill_rule ? 1u : ~0u;
+        bool full = false;
+        if (n > 0 && !mid_row) {
+            // ---- candidate FULL row: order by cell at the row start, check the order after a full step
+            for (int k = 0; k < n; ++k) {
+                const DevEdge e = edges[L.eid[k][lane]];
+                int32_t q; int64_t rm;
+                edge_x_at(e, s0, q, rm);
+                L.cell[k][lane] = e.dy ? cell_of(q, rm, e.dy) : e.x1;
+                int32_t q2; int64_t r2;
+                edge_x_at(e, s0 + 15, q2, r2);
+                L.aux[k][lane] = e.dy ? cell_of(q2, r2, e.dy) : e.x1;
+                // tie-break key among edges already active: position one sub-row earlier
+                int32_t qp = q; int64_t rp = rm;
+                if (e.dy && e.ytop < s0) { qp -= (int32_t)e.dq; rp -= e.dr; if (rp < 0) { --qp; rp += e.dy; } else if (rp >= e.dy) { ++qp; rp -= e.dy; } }
+                L.quo[k][lane] = e.dy ? cell_of(qp, rp, e.dy) : e.x1;
+                L.rem_lo[k][lane] = (e.ytop == s0) ? 1 : 0;   // new at this row: sorts after existing edges on ties
+                L.ord[k][lane] = (uint8_t)k;
+            }
+            for (int i = 1; i < n; ++i) {          // stable insertion sort on (cell, is_new, previous cell)
+                const uint8_t ki = L.ord[i][lane];
+                const int ci = L.cell[ki][lane], ni = L.rem_lo[ki][lane], pi = L.quo[ki][lane];
+                int j = i - 1;
+                while (j >= 0) {
+                    const uint8_t kj = L.ord[j][lane];
+                    const int cj = L.cell[kj][lane], nj = L.rem_lo[kj][lane], pj = L.quo[kj][lane];
+                    bool greater = cj > ci || (cj == ci && (nj > ni || (nj == ni && ni == 0 && pj > pi)));
+                    if (!greater) break;
+                    L.ord[j + 1][lane] = kj; --j;
+                }
+                L.ord[j + 1][lane] = ki;
+            }
+            full = true;
+            int prev = INT32_MIN;
+            for (int i = 0; i < n; ++i) { const int c = L.aux[L.ord[i][lane]][lane]; if (c < prev) { full = false; break; } prev = c; }
+        }
+        if (n > 0 && full) {
+            mode = ROW_FULL;
+            for (int k = 0; k < n; ++k) L.aux[k][lane] = 0;
+            int i = 0;
+            while (i < n) {
+                const int kl = L.ord[i][lane];
+                int w = edges[L.eid[kl][lane]].dir;
+                int j = i + 1;
+                while (j < n) {
+                    const int kj = L.ord[j][lane];
+                    w += edges[L.eid[kj][lane]].dir;
+                    const bool last_of_group = (j + 1 == n) || (L.cell[L.ord[j + 1][lane]][lane] != L.cell[kj][lane]);
+                    if (((unsigned)w & mask) == 0 && last_of_group) break;
+                    ++j;
+                }
+                if (j >= n) break;                 // unbalanced winding: no span
+                L.aux[kl][lane] = REC_FULL | 1;    // left edge, sign +1
+                L.aux[L.ord[j][lane]][lane] = REC_FULL | 2;  // right edge, sign -1
+                i = j + 1;
+            }
+        } else if (n > 0) {
+            // ---- SUB row: 15 sample rows, edges sorted by cell, spans between winding transitions
+            mode = ROW_SUB;
+            int na = 0;
+            for (int k = 0; k < n; ++k) L.aux[k][lane] = 0;
+            for (int s = 0; s < 15; ++s) {
+                const int ss = s0 + s;
+                for (int k = 0; k < n; ++k) {       // activate edges whose first sub-row is ss
+                    const DevEdge e = edges[L.eid[k][lane]];
+                    const int first = max(e.ytop, s0);
+                    if (first != ss) continue;
+                    int32_t q; int64_t rm;
+                    edge_x_at(e, ss, q, rm);
+                    L.quo[k][lane] = q; L.rem_lo[k][lane] = (int32_t)(uint32_t)rm; L.rem_hi[k][lane] = (int32_t)(rm >> 32);
+                    L.cell[k][lane] = e.dy ? cell_of(q, rm, e.dy) : e.x1;
+                    L.ord[na][lane] = (uint8_t)k; ++na;
+                }
+                for (int i = 1; i < na; ++i) {      // stable insertion sort by cell
+                    const uint8_t ki = L.ord[i][lane];
+                    const int ci = L.cell[ki][lane];
+                    int j = i - 1;
+                    while (j >= 0 && L.cell[L.ord[j][lane]][lane] > ci) { L.ord[j + 1][lane] = L.ord[j][lane]; --j; }
+                    L.ord[j + 1][lane] = ki;
+                }
+                // winding walk over groups of equal cell: a group opens a span when the winding enters
+                // "inside" across it, closes one when it leaves
+                int w = 0, i = 0;
+                while (i < na) {
+                    const int kf = L.ord[i][lane];
+                    const int c = L.cell[kf][lane];
+                    const bool in_before = ((unsigned)w & mask) != 0;
+                    int j = i;
+                    while (j < na && L.cell[L.ord[j][lane]][lane] == c) { w += edges[L.eid[L.ord[j][lane]][lane]].dir; ++j; }
+                    const bool in_after = ((unsigned)w & mask) != 0;
+                    if (in_after != in_before) L.aux[kf][lane] |= (in_after ? 1 : 2) << (2 * s);
+                    i = j;
+                }
+                // retire edges whose last sub-row was ss, step the others
+                int keep = 0;
+                for (int i2 = 0; i2 < na; ++i2) {
+                    const int k = L.ord[i2][lane];
+                    const DevEdge e = edges[L.eid[k][lane]];
+                    if (e.ybot == ss + 1) continue;
+                    if (e.dy) {
+                        int32_t q = L.quo[k][lane];
+                        int64_t rm = ((int64_t)L.rem_hi[k][lane] << 32) | (uint32_t)L.rem_lo[k][lane];
+                        step_x(q, rm, e);
+                        L.quo[k][lane] = q; L.rem_lo[k][lane] = (int32_t)(uint32_t)rm; L.rem_hi[k][lane] = (int32_t)(rm >> 32);
+                        L.cell[k][lane] = cell_of(q, rm, e.dy);
+                    }
+                    L.ord[keep][lane] = (uint8_t)k; ++keep;
+                }
+                na = keep;
+            }
+        }
+        for (int k = 0; k < n; ++k) n_out += L.aux[k][lane] != 0;
+    }
+    // ---- wave-level allocation of record slots: one atomic per wave
+    uint32_t incl = n_out;
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+    const uint32_t total = __shfl(incl, 63);
+    uint32_t base = 0;
+    if (lane == 0 && total) base = atomicAdd(&counters[CNT_RECORDS], total);
+    base = __shfl(base, 0);
+    if (t < n_tasks) {
+        uint32_t off = base + incl - n_out;
+        RowInfo ri; ri.rec_off = off; ri.n_rec = (uint16_t)n_out; ri.mode = (uint16_t)mode;
+        rows[t] = ri;
+        for (int k = 0; k < n; ++k) {
+            const int32_t roles = L.aux[k][lane];
+            if (roles) records[off++] = make_uint2((uint32_t)L.eid[k][lane], (uint32_t)roles);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_tiles helpers: blending (A.7), shading
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mul8x2_7f(uint32_t a, uint32_t b) {
+    uint32_t t = (a & 0xff00ffu) * b + 0x7f007fu;
+    return ((t + ((t >> 8) & 0xff00ffu)) >> 8) & 0xff00ffu;
+}
+__device__ __forceinline__ uint32_t add8x2_sat(uint32_t a, uint32_t b) {
+    uint32_t t = a + b;
+    t |= 0x1000100u - ((t >> 8) & 0xff00ffu);
+    return t & 0xff00ffu;
+}
+// Cairo's span lerp for SOURCE with 8-bit coverage (0x7f rounding)
+__device__ __forceinline__ uint32_t lerp_pixel(uint32_t src, uint32_t a, uint32_t dst) {
+    const uint32_t ia = 255u - a;
+    return add8x2_sat(mul8x2_7f(src, a), mul8x2_7f(dst, ia)) | (add8x2_sat(mul8x2_7f(src >> 8, a), mul8x2_7f(dst >> 8, ia)) << 8);
+}
+// pixman UN8x4_MUL_UN8 (0x80 rounding) and OVER
+__device__ __forceinline__ uint32_t mul_un8(uint32_t x, uint32_t a) {
+    uint32_t rb = (x & 0xff00ffu) * a + 0x800080u;
+    rb = ((rb + ((rb >> 8) & 0xff00ffu)) >> 8) & 0xff00ffu;
+    uint32_t ag = ((x >> 8) & 0xff00ffu) * a + 0x800080u;
+    ag = ((ag + ((ag >> 8) & 0xff00ffu)) >> 8) & 0xff00ffu;
+    return rb | (ag << 8);
+}
+__device__ __forceinline__ uint32_t over_pixel(uint32_t src, uint32_t dst) {
+    const uint32_t m = mul_un8(dst, 255u - (src >> 24));
+    const uint32_t rb = add8x2_sat(m & 0xff00ffu, src & 0xff00ffu);
+    const uint32_t ag = add8x2_sat((m >> 8) & 0xff00ffu, (src >> 8) & 0xff00ffu);
+    return rb | (ag << 8);
+}
+
+__device__ uint32_t gradient_color(const swfr_style& s, double t) {
+    const int n = (int)s.n_stops;
+    if (n == 0) return 0;
+    double r, g, b, a;
+    if (t <= (double)s.stop_offset[0]) { r = s.stop_rgba[0][0]; g = s.stop_rgba[0][1]; b = s.stop_rgba[0][2]; a = s.stop_rgba[0][3]; }
+    else if (t >= (double)s.stop_offset[n - 1]) { r = s.stop_rgba[n - 1][0]; g = s.stop_rgba[n - 1][1]; b = s.stop_rgba[n - 1][2]; a = s.stop_rgba[n - 1][3]; }
+    else {
+        int i = 0;
+        while (i + 1 < n && (double)s.stop_offset[i + 1] <= t) ++i;
+        const double t0 = s.stop_offset[i], t1 = s.stop_offset[i + 1], span = t1 - t0, f = span > 0 ? (t - t0) / span : 0;
+        r = s.stop_rgba[i][0] + ((double)s.stop_rgba[i + 1][0] - s.stop_rgba[i][0]) * f;
+        g = s.stop_rgba[i][1] + ((double)s.stop_rgba[i + 1][1] - s.stop_rgba[i][1]) * f;
+        b = s.stop_rgba[i][2] + ((double)s.stop_rgba[i + 1][2] - s.stop_rgba[i][2]) * f;
+        a = s.stop_rgba[i][3] + ((double)s.stop_rgba[i + 1][3] - s.stop_rgba[i][3]) * f;
+    }
+    const uint32_t A = (uint32_t)(a * 255.0 + 0.5), R = (uint32_t)(r * a * 255.0 + 0.5);
+    const uint32_t G = (uint32_t)(g * a * 255.0 + 0.5), B = (uint32_t)(b * a * 255.0 + 0.5);
+    return (A << 24) | (R << 16) | (G << 8) | B;
+}
+
+// premultiplied ARGB source colour at pixel centre (px+0.5, py+0.5): float64 model of pixman's
+// general path (gradients within +-1 LSB of Cairo)
+__device__ uint32_t shade(const swfr_style& s, const DevBitmap* __restrict__ bitmaps, int px, int py) {
+    double x = px + 0.5, y = py + 0.5;
+    const double ux = s.inv[0] * x + s.inv[2] * y + s.inv[4];
+    const double uy = s.inv[1] * x + s.inv[3] * y + s.inv[5];
+    if (s.kind == SWFR_STYLE_RADIAL) {
+        const double cdx = s.c1x - s.c0x, cdy = s.c1y - s.c0y, dr = s.r1 - s.r0;
+        const double pdx = ux - s.c0x, pdy = uy - s.c0y;
+        const double A = cdx * cdx + cdy * cdy - dr * dr;
+        const double B = pdx * cdx + pdy * cdy + s.r0 * dr;
+        const double C = pdx * pdx + pdy * pdy - s.r0 * s.r0;
+        double t;
+        if (A == 0) { if (B == 0) return 0; t = 0.5 * C / B; if (s.r0 + t * dr < 0) return 0; }
+        else {
+            const double disc = B * B - A * C;
+            if (disc < 0) return 0;
+            const double sq = sqrt(disc), t0 = (B + sq) / A, t1 = (B - sq) / A;
+            if (s.r0 + t0 * dr >= 0) t = t0; else if (s.r0 + t1 * dr >= 0) t = t1; else return 0;
+        }
+        t = fmin(fmax(t, 0.0), 1.0);
+        return gradient_color(s, t);
+    }
+    if (s.kind == SWFR_STYLE_LINEAR) {
+        const double dx = s.c1x - s.c0x, dy = s.c1y - s.c0y, l = dx * dx + dy * dy;
+        double t = l == 0 ? 0 : ((ux - s.c0x) * dx + (uy - s.c0y) * dy) / l;
+        t = fmin(fmax(t, 0.0), 1.0);
+        return gradient_color(s, t);
+    }
+    // bitmap: bilinear with 7-bit weights
+    const DevBitmap bm = bitmaps[s.bitmap];
+    const double u = ux - 0.5, v = uy - 0.5;
+    const int x0 = (int)floor(u), y0 = (int)floor(v);
+    const int wx = (int)floor((u - x0) * 128.0), wy = (int)floor((v - y0) * 128.0);
+    uint32_t c[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int xx = x0 + (k & 1), yy = y0 + (k >> 1);
+        if (s.extend == 1) {
+            xx = ((xx % (int)bm.width) + (int)bm.width) % (int)bm.width;
+            yy = ((yy % (int)bm.height) + (int)bm.height) % (int)bm.height;
+            c[k] = bm.pixels[(size_t)yy * bm.width + xx];
+        } else {
+            c[k] = (xx < 0 || yy < 0 || xx >= (int)bm.width || yy >= (int)bm.height) ? 0u : bm.pixels[(size_t)yy * bm.width + xx];
+        }
+    }
+    uint32_t out = 0;
+#pragma unroll
+    for (int sh = 0; sh < 32; sh += 8) {
+        const uint32_t v00 = (c[0] >> sh) & 255, v10 = (c[1] >> sh) & 255, v01 = (c[2] >> sh) & 255, v11 = (c[3] >> sh) & 255;
+        const uint32_t acc = v00 * (128 - wx) * (128 - wy) + v10 * wx * (128 - wy) + v01 * (128 - wx) * wy + v11 * wx * wy;
+        out |= ((acc >> 14) & 255) << sh;
+    }
+    return out;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_tiles
+// ---------------------------------------------------------------------------------------------
+#define ACC_STRIDE 66                 // 64 cells + carry slot + touched flag
+#define ACC_CARRY 64
+#define ACC_TOUCH 65
+#define LIST_CAP 1024
+
+struct TileCtx {
+    int tx0, ty0, xminp, xmaxp;
+};
+
+// accumulate one cell contribution (covered height dch, uncovered area dua) of row `acc`
+__device__ __forceinline__ void cell_add(int* acc, const TileCtx& c, int i, int dch, int dua) {
+    if (i >= c.xmaxp) return;                            // at/after the converter's right bound: never emitted
+    if (i < c.xminp) { i = c.xminp; dua = 0; }           // left of it: height only, folded into the first column
+    if (i < c.tx0) { atomicAdd(&acc[ACC_CARRY], dch); return; }
+    if (i >= c.tx0 + TILE_W) return;
+    atomicAdd(&acc[i - c.tx0], dch * (1 << 20) + dua);
+}
+
+// FULL-row edge (A.5 render_edge): analytic trapezoid coverage of one edge over one pixel row
+__device__ void full_edge(const DevEdge& e, int s0, int sign, int* acc, const TileCtx& c) {
+    int32_t q1, q2; int64_t r1, r2;
+    edge_x_at(e, s0, q1, r1);
+    edge_x_at(e, s0 + 15, q2, r2);
+    if (e.dy) {                                           // back from the sub-row centre to the row top
+        const int32_t hq = (int32_t)(e.dq / 2); const int64_t hr = e.dr / 2;
+        q1 -= hq; r1 -= hr; if (r1 < 0) { --q1; r1 += e.dy; } else if (r1 >= e.dy) { ++q1; r1 -= e.dy; }
+        q2 -= hq; r2 -= hr; if (r2 < 0) { --q2; r2 += e.dy; } else if (r2 >= e.dy) { ++q2; r2 -= e.dy; }
+    }
+    int ix1 = q1 >> 8, f1 = q1 & 255, ix2 = q2 >> 8, f2 = q2 & 255;
+    if (ix1 == ix2) { cell_add(acc, c, ix1, sign * 15, sign * (f1 + f2) * 15); return; }
+    if (ix2 < ix1) { int t = ix1; ix1 = ix2; ix2 = t; t = f1; f1 = f2; f2 = t; int32_t tq = q1; q1 = q2; q2 = tq; int64_t tr = r1; r1 = r2; r2 = tr; }
+    const int lo = max(c.tx0, c.xminp);                  // first column whose own area matters to this tile
+    const int hi = min(c.tx0 + TILE_W, c.xmaxp);         // one past the last such column
+    if (ix1 >= hi) return;                               // entirely to the right: invisible here
+    const int64_t dx = (int64_t)(q2 - q1) * e.dy + (r2 - r1);
+    const int64_t t0 = ((int64_t)((ix1 + 1) * 256 - q1) * e.dy - r1) * 15;
+    const int64_t F = 15ll * 256 * e.dy;
+    // Y(col) = covered sub-rows accumulated over columns ix1..col (ix1 <= col < ix2), exact floor
+    const int first = max(ix1, lo);
+    int y_prev = 0;
+    if (first > ix1) {
+        // columns ix1..first-1 lie left of the tile (or of the converter): only their summed height counts
+        if (first - 1 >= ix2) { cell_add(acc, c, lo - 1, sign * 15, 0); return; }
+        int64_t q, r;
+        floor_div(t0 + (int64_t)(first - 1 - ix1) * F, dx, q, r);
+        y_prev = (int)q;
+        cell_add(acc, c, lo - 1, sign * y_prev, 0);
+    }
+    int64_t yq = 0, yr = 0, fq = 0, fr = 0;
+    if (first < ix2) {
+        floor_div(t0 + (int64_t)(first - ix1) * F, dx, yq, yr);
+        floor_div(F, dx, fq, fr);
+    }
+    for (int col = first; col < hi && col <= ix2; ++col) {
+        if (col == ix2) { cell_add(acc, c, col, sign * (15 - y_prev), sign * (15 - y_prev) * f2); break; }
+        if (col > first) { yq += fq; yr += fr; if (yr >= dx) { ++yq; yr -= dx; } }
+        const int h = (int)yq - y_prev;
+        cell_add(acc, c, col, sign * h, sign * h * (col == ix1 ? 256 + f1 : 256));
+        y_prev = (int)yq;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_tiles(const swfr_edge* __restrict__ raw_edges, const DevEdge* __restrict__ edges,
+                                               const DevPath* __restrict__ paths, uint32_t n_paths,
+                                               const uint32_t* __restrict__ row_base, const RowInfo* __restrict__ rows,
+                                               const uint2* __restrict__ records, const swfr_style* __restrict__ styles,
+                                               const DevBitmap* __restrict__ bitmaps, uint32_t* __restrict__ fb,
+                                               int width, int height, int tiles_x, uint32_t band_index, uint32_t band_count,
+                                               uint32_t n_tile_rows_local) {
+    __shared__ int acc[TILE_H][ACC_STRIDE];
+    __shared__ uint32_t list[LIST_CAP];
+    __shared__ uint32_t wave_cnt[4];
+    __shared__ uint32_t list_n;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // blockIdx -> tile: consecutive blocks walk along x inside one tile-row (neighbouring tiles share
+    // paths, so they hit the same L2 when co-scheduled round-robin over XCDs in groups of 8)
+    const int tile = blockIdx.x;
+    const int tcol = tile % tiles_x;
+    int trow = tile / tiles_x;
+    if (band_count > 1) trow = trow * band_count + band_index;
+    const int tx0 = tcol * TILE_W, ty0 = trow * TILE_H;
+    if (ty0 >= height) return;
+
+    uint32_t px[4] = {0u, 0u, 0u, 0u};                    // rows 4*wave .. 4*wave+3, column tx0+lane (premultiplied ARGB)
+    for (int i = tid; i < TILE_H * ACC_STRIDE; i += 256) (&acc[0][0])[i] = 0;
+    __syncthreads();
+
+    for (uint32_t chunk = 0; chunk < n_paths; chunk += LIST_CAP) {
+        // ---- bin: paths of this chunk whose pixel rectangle overlaps the tile, in painter's order
+        if (tid == 0) list_n = 0;
+        __syncthreads();
+        const uint32_t chunk_end = min(chunk + LIST_CAP, n_paths);
+        for (uint32_t base = chunk; base < chunk_end; base += 256) {
+            const uint32_t p = base + tid;
+            bool hit = false;
+            if (p < chunk_end) {
+                const DevPath P = paths[p];
+                hit = P.x_min < tx0 + TILE_W && P.x_max > tx0 && P.y_min < ty0 + TILE_H && P.y_max > ty0;
+            }
+            const unsigned long long b = __ballot(hit);
+            if (lane == 0) wave_cnt[wave] = __popcll(b);
+            __syncthreads();
+            uint32_t off = list_n;
+            for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+            if (hit) list[off + __popcll(b & ((1ull << lane) - 1ull))] = p;
+            __syncthreads();
+            if (tid == 0) list_n += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+            __syncthreads();
+        }
+        const uint32_t ln = list_n;
+
+        for (uint32_t li = 0; li < ln; ++li) {
+            const uint32_t pi = list[li];
+            const DevPath P = paths[pi];
+            uint32_t alpha[4] = {0u, 0u, 0u, 0u};
+            const int row_lo = max(P.y_min, ty0), row_hi = min(P.y_max, ty0 + TILE_H);
+
+            if (P.kind == SWFR_PATH_BOXES) {
+                // ---- rectilinear (A.6): exact area of disjoint boxes, alpha = (c>>8) - (c>>16)
+                uint32_t cov[4] = {0u, 0u, 0u, 0u};
+                const int cx = tx0 + lane;
+                for (uint32_t k = 0; k < P.n_edges; ++k) {
+                    const swfr_edge bx = raw_edges[P.first_edge + k];
+                    const int wx = min(bx.x2, (cx + 1) * 256) - max(bx.x1, cx * 256);
+                    if (wx <= 0) continue;
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int cy = ty0 + wave * 4 + rr;
+                        const int wy = min(bx.y2, (cy + 1) * 256) - max(bx.y1, cy * 256);
+                        if (wy > 0) cov[rr] += (uint32_t)(wx * wy);
+                    }
+                }
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) alpha[rr] = ((cov[rr] >> 8) - (cov[rr] >> 16)) & 255u;
+            } else {
+                // ---- tor (A.5): per-row records -> covered height / uncovered area per cell
+                TileCtx c; c.tx0 = tx0; c.ty0 = ty0; c.xminp = P.x_min; c.xmaxp = P.x_max;
+                const int row = tid >> 4, slot = tid & 15;
+                const int y = ty0 + row;
+                if (y >= row_lo && y < row_hi) {
+                    const RowInfo ri = rows[row_base[pi] + (uint32_t)(y - P.y_min)];
+                    const int s0 = y * 15;
+                    if (slot == 0 && ri.n_rec) acc[row][ACC_TOUCH] = 1;
+                    for (uint32_t k = slot; k < ri.n_rec; k += 16) {
+                        const uint2 rec = records[ri.rec_off + k];
+                        const DevEdge e = edges[rec.x];
+                        if (rec.y & REC_FULL) {
+                            full_edge(e, s0, (rec.y & 1) ? +1 : -1, acc[row], c);
+                        } else {
+                            const int first = max(e.ytop, s0), last = min(e.ybot, s0 + 15);
+                            int32_t q; int64_t rm;
+                            edge_x_at(e, first, q, rm);
+                            for (int ss = first; ss < last; ++ss) {
+                                const uint32_t role = (rec.y >> (2 * (ss - s0))) & 3u;
+                                if (role) {
+                                    const int cell = e.dy ? cell_of(q, rm, e.dy) : e.x1;
+                                    const int sgn = role == 1 ? 1 : -1;
+                                    cell_add(acc[row], c, cell >> 8, sgn, sgn * 2 * (cell & 255));
+                                }
+                                if (e.dy) step_x(q, rm, e);
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int rw = wave * 4 + rr;
+                    if (!acc[rw][ACC_TOUCH]) continue;            // wave-uniform
+                    const int v = acc[rw][lane];
+                    const int carry = acc[rw][ACC_CARRY];
+                    const int ua = (v << 12) >> 12;               // low 20 bits, sign-extended
+                    int ch = (v - ua) >> 20;
+                    if (lane == 0) ch += carry;
+                    int scan = ch;                                 // wave64 inclusive prefix sum along x
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(scan, d); if (lane >= d) scan += o; }
+                    const int area = scan * 512 - ua;
+                    uint32_t a = (uint32_t)((area * 17 + 256) >> 9) & 255u;
+                    const int cx = tx0 + lane;
+                    if (cx < P.x_min || cx >= P.x_max) a = 0;
+                    alpha[rr] = a;
+                }
+                __syncthreads();
+                // clear the accumulators this path used
+                if (y >= row_lo && y < row_hi) {
+#pragma unroll
+                    for (int k = slot; k < ACC_STRIDE; k += 16) acc[row][k] = 0;
+                }
+                __syncthreads();
+            }
+
+            // ---- shade + blend (A.7) into the tile-resident pixels
+            const swfr_style& S = styles[P.style];
+            const uint32_t kind = S.kind;
+            const uint32_t solid = S.pixel;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const uint32_t a = alpha[rr];
+                if (!a) continue;
+                const int cy = ty0 + wave * 4 + rr;
+                if (cy < row_lo || cy >= row_hi) continue;
+                if (kind == SWFR_STYLE_SOLID) {
+                    if (P.lerp) {
+                        px[rr] = a == 255u ? solid : lerp_pixel(solid, a, px[rr]);
+                    } else {
+                        const uint32_t s = a == 255u ? solid : mul_un8(solid, a);
+                        px[rr] = over_pixel(s, px[rr]);
+                    }
+                } else {
+                    const uint32_t s = mul_un8(shade(S, bitmaps, tx0 + lane, cy), a);
+                    px[rr] = P.lerp ? s : over_pixel(s, px[rr]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- one store per pixel: premultiplied R,G,B,A bytes; a wave writes 256 contiguous bytes per row
+    const int cx = tx0 + lane;
+    if (cx < width) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int cy = ty0 + wave * 4 + rr;
+            if (cy >= height) continue;
+            const uint32_t p = px[rr];
+            const uint32_t rgba = (p & 0xff00ff00u) | ((p >> 16) & 0xffu) | ((p & 0xffu) << 16);
+            size_t row_index = (size_t)cy;
+            if (band_count > 1) row_index = (size_t)cy;   // full-frame addressing; band slabs are packed by k_pack_band
+            fb[row_index * (size_t)width + cx] = rgba;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// auxiliary kernels
+// ---------------------------------------------------------------------------------------------
+// un-premultiply (node-canvas getImageData / PNG encode): c' = (c*255 + a/2) / a, a == 0 -> 0
+__global__ __launch_bounds__(256) void k_unpremultiply(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t p = in[i];
+    const uint32_t a = p >> 24;
+    if (a == 0) { out[i] = 0; return; }
+    const uint32_t r = ((p & 255u) * 255u + a / 2) / a, g = (((p >> 8) & 255u) * 255u + a / 2) / a, b = (((p >> 16) & 255u) * 255u + a / 2) / a;
+    out[i] = (a << 24) | (b << 16) | (g << 8) | r;
+}
+
+// pack this rank's tile-rows (t % band_count == band_index) into a dense slab for the RCCL gather
+__global__ __launch_bounds__(256) void k_pack_band(const uint32_t* __restrict__ fb, uint32_t* __restrict__ slab, int width, int height,
+                                                   uint32_t band_index, uint32_t band_count, uint32_t n_tile_rows_local) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t per_tile_row = (size_t)width * TILE_H;
+    if (i >= per_tile_row * n_tile_rows_local) return;
+    const uint32_t lt = (uint32_t)(i / per_tile_row);
+    const size_t within = i % per_tile_row;
+    const size_t y = (size_t)(lt * band_count + band_index) * TILE_H + within / width;
+    slab[i] = y < (size_t)height ? fb[y * width + within % width] : 0u;
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers (called from renderer.cpp, which is compiled as plain C++ by the same hipcc)
+// ---------------------------------------------------------------------------------------------
+void launch_setup(hipStream_t st, const swfr_edge* in, const DevPath* paths, DevEdge* out, uint32_t n_edges) {
+    if (!n_edges) return;
+    hipLaunchKernelGGL(k_setup, dim3((n_edges + 255) / 256), dim3(256), 0, st, in, paths, out, n_edges);
+}
+void launch_rows(hipStream_t st, const DevEdge* edges, const DevPath* paths, const uint32_t* row_base, uint32_t n_paths,
+                 RowInfo* rows, uint2* records, uint32_t* counters, uint32_t n_tasks, uint32_t band_index, uint32_t band_count) {
+    if (!n_tasks) return;
+    hipLaunchKernelGGL(k_rows, dim3((n_tasks + 63) / 64), dim3(64), 0, st, edges, paths, row_base, n_paths, rows, records,
+                       counters, n_tasks, band_index, band_count);
+}
+void launch_tiles(hipStream_t st, const swfr_edge* raw, const DevEdge* edges, const DevPath* paths, uint32_t n_paths,
+                  const uint32_t* row_base, const RowInfo* rows, const uint2* records, const swfr_style* styles,
+                  const DevBitmap* bitmaps, uint32_t* fb, int width, int height, uint32_t band_index, uint32_t band_count) {
+    const int tiles_x = (width + TILE_W - 1) / TILE_W, tile_rows = (height + TILE_H - 1) / TILE_H;
+    uint32_t local_rows = tile_rows;
+    if (band_count > 1) local_rows = (tile_rows > (int)band_index) ? (tile_rows - band_index + band_count - 1) / band_count : 0;
+    if (!local_rows) return;
+    hipLaunchKernelGGL(k_tiles, dim3(tiles_x * local_rows), dim3(256), 0, st, raw, edges, paths, n_paths, row_base, rows, records,
+                       styles, bitmaps, fb, width, height, tiles_x, band_index, band_count, local_rows);
+}
+void launch_unpremultiply(hipStream_t st, const uint32_t* in, uint32_t* out, size_t n) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_unpremultiply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, out, n);
+}
+void launch_pack_band(hipStream_t st, const uint32_t* fb, uint32_t* slab, int width, int height, uint32_t band_index,
+                      uint32_t band_count, uint32_t local_rows) {
+    const size_t n = (size_t)width * TILE_H * local_rows;
+    if (!n) return;
+    hipLaunchKernelGGL(k_pack_band, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, fb, slab, width, height, band_index,
+                       band_count, local_rows);
+}
+
+}  // namespace swfr

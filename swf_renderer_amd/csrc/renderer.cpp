@@ -1,0 +1,458 @@
+// renderer.cpp -- the C-ABI of include/swfr.h: handle, asset store, host frame build, device pipeline.
+//
+// There is NO CPU rasterization fallback in this library: without a HIP device swfr_create fails
+// (unless the caller explicitly asks for a host-only handle, which can decode and build edge lists
+// but refuses to render).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/swfr.h"
+#include "device_types.hpp"
+#include "frame_builder.hpp"
+#include "shape_decoder.hpp"
+
+namespace swfr {
+void launch_setup(hipStream_t, const swfr_edge*, const DevPath*, DevEdge*, uint32_t);
+void launch_rows(hipStream_t, const DevEdge*, const DevPath*, const uint32_t*, uint32_t, RowInfo*, uint2*, uint32_t*, uint32_t,
+                 uint32_t, uint32_t);
+void launch_tiles(hipStream_t, const swfr_edge*, const DevEdge*, const DevPath*, uint32_t, const uint32_t*, const RowInfo*,
+                  const uint2*, const swfr_style*, const DevBitmap*, uint32_t*, int, int, uint32_t, uint32_t);
+void launch_unpremultiply(hipStream_t, const uint32_t*, uint32_t*, size_t);
+void launch_pack_band(hipStream_t, const uint32_t*, uint32_t*, int, int, uint32_t, uint32_t, uint32_t);
+}  // namespace swfr
+
+using namespace swfr;
+
+namespace {
+
+struct HipError {
+    hipError_t code;
+    const char* what;
+};
+#define HIP_CHECK(expr)                                 \
+    do {                                                \
+        hipError_t _e = (expr);                         \
+        if (_e != hipSuccess) throw HipError{_e, #expr}; \
+    } while (0)
+
+// grow-only device buffer
+template <class T>
+struct DevBuf {
+    T* ptr = nullptr;
+    size_t cap = 0;
+    void reserve(size_t n) {
+        if (n <= cap) return;
+        if (ptr) HIP_CHECK(hipFree(ptr));
+        ptr = nullptr;
+        cap = 0;
+        size_t want = std::max<size_t>(n, 64);
+        want += want / 2;
+        HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&ptr), want * sizeof(T)));
+        cap = want;
+    }
+    void release() {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+    }
+};
+
+struct DeviceBitmap {
+    uint32_t* pixels = nullptr;
+    uint32_t width = 0, height = 0;
+};
+
+}  // namespace
+
+struct swfr_renderer {
+    uint32_t width = 0, height = 0;
+    swfr_config cfg{};
+    bool has_device = false;
+    std::string error;
+    std::unique_ptr<FrameBuilder> builder;
+    std::string json_scratch;
+
+    // device state
+    hipStream_t stream = nullptr;
+    std::vector<hipEvent_t> ev;             // 4 per frame of the last swfr_render_resident call
+    DevBuf<swfr_edge> d_raw;
+    DevBuf<DevEdge> d_edges;
+    DevBuf<DevPath> d_paths;
+    DevBuf<swfr_style> d_styles;
+    DevBuf<uint32_t> d_row_base;
+    DevBuf<RowInfo> d_rows;
+    DevBuf<uint2> d_records;
+    DevBuf<uint32_t> d_counters;
+    DevBuf<DevBitmap> d_bitmap_table;
+    DevBuf<uint32_t> d_fb, d_tmp;
+    std::map<uint32_t, DeviceBitmap> bitmaps;
+    std::vector<DevBitmap> bitmap_table;   // indexed by bitmap id
+    bool bitmap_table_dirty = false;
+    // resident scene
+    size_t n_edges = 0, n_paths = 0, n_styles = 0, n_tasks = 0, rec_cap = 0;
+    bool scene_ready = false, fb_valid = false;
+    swfr_timing timing{};
+
+    ~swfr_renderer() {
+        if (has_device) {
+            (void)hipSetDevice(cfg.device);
+            d_raw.release(); d_edges.release(); d_paths.release(); d_styles.release(); d_row_base.release();
+            d_rows.release(); d_records.release(); d_counters.release(); d_bitmap_table.release(); d_fb.release(); d_tmp.release();
+            for (auto& kv : bitmaps) if (kv.second.pixels) (void)hipFree(kv.second.pixels);
+            for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+            if (stream) (void)hipStreamDestroy(stream);
+        }
+    }
+};
+
+namespace {
+
+int fail(swfr_renderer* r, int code, const std::string& msg) {
+    if (r) r->error = msg;
+    return code;
+}
+
+template <class F>
+int guarded(swfr_renderer* r, F&& f) {
+    try {
+        if (r && r->has_device) HIP_CHECK(hipSetDevice(r->cfg.device));
+        return f();
+    } catch (const StatusError& e) {
+        return fail(r, e.code, e.message);
+    } catch (const HipError& e) {
+        return fail(r, SWFR_ERR_DEVICE, std::string(e.what) + ": " + hipGetErrorString(e.code));
+    } catch (const std::bad_alloc&) {
+        return fail(r, SWFR_ERR_CAPACITY, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(r, SWFR_ERR_INVALID, e.what());
+    }
+}
+
+uint32_t local_tile_rows(const swfr_renderer* r) {
+    const uint32_t tile_rows = (r->height + TILE_H - 1) / TILE_H;
+    const uint32_t bc = r->cfg.band_count > 1 ? r->cfg.band_count : 1, bi = r->cfg.band_count > 1 ? r->cfg.band_index : 0;
+    if (tile_rows <= bi) return 0;
+    return (tile_rows - bi + bc - 1) / bc;
+}
+
+// Validate a caller-supplied scene so that no kernel can index out of bounds.
+void validate_scene(const swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_path* paths, size_t n_paths,
+                    const swfr_style* styles, size_t n_styles) {
+    (void)edges;
+    for (size_t i = 0; i < n_paths; ++i) {
+        const swfr_path& p = paths[i];
+        if (size_t(p.first_edge) + p.n_edges > n_edges) throw StatusError{SWFR_ERR_INVALID, "path edge range out of bounds"};
+        if (p.style >= n_styles) throw StatusError{SWFR_ERR_INVALID, "path style index out of bounds"};
+        if (p.kind > SWFR_PATH_BOXES) throw StatusError{SWFR_ERR_INVALID, "unknown path kind"};
+        if (p.x_min < 0 || p.y_min < 0 || p.x_max > int(r->width) || p.y_max > int(r->height) || p.x_min > p.x_max || p.y_min > p.y_max)
+            throw StatusError{SWFR_ERR_INVALID, "path pixel rectangle outside the frame"};
+    }
+    for (size_t i = 0; i < n_styles; ++i) {
+        const swfr_style& s = styles[i];
+        if (s.kind > SWFR_STYLE_BITMAP) throw StatusError{SWFR_ERR_INVALID, "unknown style kind"};
+        if (s.n_stops > SWFR_MAX_STOPS) throw StatusError{SWFR_ERR_INVALID, "too many gradient stops"};
+        if (s.kind == SWFR_STYLE_BITMAP && !r->bitmaps.count(s.bitmap)) throw StatusError{SWFR_ERR_NOT_FOUND, "BitmapNotFound"};
+    }
+}
+
+int upload(swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_path* paths, size_t n_paths,
+           const swfr_style* styles, size_t n_styles) {
+    if (!r->has_device) return fail(r, SWFR_ERR_NO_DEVICE, "host-only handle cannot rasterize");
+    validate_scene(r, edges, n_edges, paths, n_paths, styles, n_styles);
+    r->scene_ready = false;
+    // stage: edges tagged with their path index; row prefix over tor paths; record capacity bound
+    std::vector<swfr_edge> staged(edges, edges + n_edges);
+    for (auto& e : staged) e.reserved = 0;            // overwritten below with the owning path's index
+    std::vector<uint32_t> row_base(n_paths + 1, 0);
+    size_t rec_cap = 0;
+    for (size_t i = 0; i < n_paths; ++i) {
+        const swfr_path& p = paths[i];
+        for (uint32_t k = 0; k < p.n_edges; ++k) staged[p.first_edge + k].reserved = int32_t(i);
+        uint32_t rows = 0;
+        if (p.kind == SWFR_PATH_TOR) {
+            rows = uint32_t(p.y_max - p.y_min);
+            for (uint32_t k = 0; k < p.n_edges; ++k) {
+                const swfr_edge& e = edges[p.first_edge + k];
+                // rows an edge can be active in: [top, bottom) in pixels, clamped to the path
+                const int64_t top = std::max<int64_t>(e.top, int64_t(p.y_min) * 256), bot = std::min<int64_t>(e.bottom, int64_t(p.y_max) * 256);
+                if (bot > top) rec_cap += size_t((bot + 255) / 256 - top / 256 + 1);
+            }
+        }
+        row_base[i + 1] = row_base[i] + rows;
+    }
+    r->n_edges = n_edges; r->n_paths = n_paths; r->n_styles = n_styles;
+    r->n_tasks = row_base[n_paths];
+    r->rec_cap = rec_cap + 64;
+    r->d_raw.reserve(n_edges); r->d_edges.reserve(n_edges); r->d_paths.reserve(n_paths); r->d_styles.reserve(n_styles);
+    r->d_row_base.reserve(n_paths + 1); r->d_rows.reserve(r->n_tasks); r->d_records.reserve(r->rec_cap);
+    r->d_counters.reserve(CNT_WORDS);
+    if (n_edges) HIP_CHECK(hipMemcpyAsync(r->d_raw.ptr, staged.data(), n_edges * sizeof(swfr_edge), hipMemcpyHostToDevice, r->stream));
+    if (n_paths) HIP_CHECK(hipMemcpyAsync(r->d_paths.ptr, paths, n_paths * sizeof(swfr_path), hipMemcpyHostToDevice, r->stream));
+    if (n_styles) HIP_CHECK(hipMemcpyAsync(r->d_styles.ptr, styles, n_styles * sizeof(swfr_style), hipMemcpyHostToDevice, r->stream));
+    HIP_CHECK(hipMemcpyAsync(r->d_row_base.ptr, row_base.data(), (n_paths + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, r->stream));
+    if (r->bitmap_table_dirty) {
+        r->d_bitmap_table.reserve(r->bitmap_table.size());
+        if (!r->bitmap_table.empty())
+            HIP_CHECK(hipMemcpyAsync(r->d_bitmap_table.ptr, r->bitmap_table.data(), r->bitmap_table.size() * sizeof(DevBitmap),
+                                     hipMemcpyHostToDevice, r->stream));
+        r->bitmap_table_dirty = false;
+    }
+    HIP_CHECK(hipStreamSynchronize(r->stream));   // staging vectors die at scope exit
+    r->scene_ready = true;
+    return SWFR_OK;
+}
+
+int render_resident(swfr_renderer* r, uint32_t frames) {
+    if (!r->has_device) return fail(r, SWFR_ERR_NO_DEVICE, "host-only handle cannot rasterize");
+    if (!r->scene_ready) return fail(r, SWFR_ERR_INVALID, "no scene uploaded");
+    if (frames == 0) frames = 1;
+    const uint32_t bc = r->cfg.band_count > 1 ? r->cfg.band_count : 1, bi = r->cfg.band_count > 1 ? r->cfg.band_index : 0;
+    float setup_ms = 0, rows_ms = 0, tiles_ms = 0, total_ms = 0;
+    uint32_t counters[CNT_WORDS] = {0, 0, 0, 0};
+    if (frames > 4096) frames = 4096;
+    while (r->ev.size() < size_t(frames) * 4) {
+        hipEvent_t e = nullptr;
+        HIP_CHECK(hipEventCreate(&e));
+        r->ev.push_back(e);
+    }
+    // all frames are queued back to back; events bracket every kernel on the handle's own stream
+    for (uint32_t f = 0; f < frames; ++f) {
+        hipEvent_t* e = &r->ev[size_t(f) * 4];
+        HIP_CHECK(hipMemsetAsync(r->d_counters.ptr, 0, CNT_WORDS * sizeof(uint32_t), r->stream));
+        HIP_CHECK(hipEventRecord(e[0], r->stream));
+        if (r->n_paths) launch_setup(r->stream, r->d_raw.ptr, r->d_paths.ptr, r->d_edges.ptr, uint32_t(r->n_edges));
+        HIP_CHECK(hipEventRecord(e[1], r->stream));
+        launch_rows(r->stream, r->d_edges.ptr, r->d_paths.ptr, r->d_row_base.ptr, uint32_t(r->n_paths), r->d_rows.ptr, r->d_records.ptr,
+                    r->d_counters.ptr, uint32_t(r->n_tasks), bi, bc);
+        HIP_CHECK(hipEventRecord(e[2], r->stream));
+        launch_tiles(r->stream, r->d_raw.ptr, r->d_edges.ptr, r->d_paths.ptr, uint32_t(r->n_paths), r->d_row_base.ptr, r->d_rows.ptr,
+                     r->d_records.ptr, r->d_styles.ptr, r->d_bitmap_table.ptr, r->d_fb.ptr, int(r->width), int(r->height), bi, bc);
+        HIP_CHECK(hipEventRecord(e[3], r->stream));
+    }
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(r->stream));
+    for (uint32_t f = 0; f < frames; ++f) {
+        hipEvent_t* e = &r->ev[size_t(f) * 4];
+        float a = 0, b = 0, c = 0;
+        HIP_CHECK(hipEventElapsedTime(&a, e[0], e[1]));
+        HIP_CHECK(hipEventElapsedTime(&b, e[1], e[2]));
+        HIP_CHECK(hipEventElapsedTime(&c, e[2], e[3]));
+        setup_ms += a; rows_ms += b; tiles_ms += c;
+    }
+    HIP_CHECK(hipEventElapsedTime(&total_ms, r->ev[0], r->ev[size_t(frames - 1) * 4 + 3]));
+    HIP_CHECK(hipMemcpy(counters, r->d_counters.ptr, sizeof counters, hipMemcpyDeviceToHost));
+    r->timing = swfr_timing{total_ms, setup_ms, rows_ms, tiles_ms, frames, r->n_edges, r->n_paths, r->n_tasks, counters[CNT_RECORDS]};
+    r->fb_valid = true;
+    if (counters[CNT_ERROR]) {
+        r->fb_valid = false;
+        return fail(r, SWFR_ERR_CAPACITY, "a pixel row has more than 32 active edges of one path (scan converter capacity)");
+    }
+    if (counters[CNT_RECORDS] > r->rec_cap) {
+        r->fb_valid = false;
+        return fail(r, SWFR_ERR_CAPACITY, "row record buffer overflow");
+    }
+    return SWFR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+#pragma GCC visibility push(default)
+
+uint32_t swfr_abi_version(void) { return SWFR_ABI_VERSION; }
+
+const char* swfr_last_error(const swfr_renderer* r) { return r ? r->error.c_str() : "null handle"; }
+
+int swfr_create(uint32_t width, uint32_t height, const swfr_config* cfg, swfr_renderer** out) {
+    if (!out) return SWFR_ERR_INVALID;
+    *out = nullptr;
+    if (width == 0 || height == 0 || width > 32768 || height > 32768) return SWFR_ERR_INVALID;
+    std::unique_ptr<swfr_renderer> r(new (std::nothrow) swfr_renderer);
+    if (!r) return SWFR_ERR_CAPACITY;
+    r->width = width;
+    r->height = height;
+    if (cfg) r->cfg = *cfg;
+    if (r->cfg.band_count > 1 && r->cfg.band_index >= r->cfg.band_count) return SWFR_ERR_INVALID;
+    r->builder.reset(new FrameBuilder(width, height, (r->cfg.flags & SWFR_FLAG_EVEN_ODD) != 0));
+    if (r->cfg.device == SWFR_DEVICE_HOST_ONLY) {
+        *out = r.release();
+        return SWFR_OK;
+    }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return SWFR_ERR_NO_DEVICE;
+    if (r->cfg.device < 0 || r->cfg.device >= count) return SWFR_ERR_NO_DEVICE;
+    r->has_device = true;
+    swfr_renderer* raw = r.get();
+    const int rc = guarded(raw, [&]() {
+        HIP_CHECK(hipStreamCreateWithFlags(&raw->stream, hipStreamNonBlocking));
+        raw->d_fb.reserve(size_t(width) * height);
+        HIP_CHECK(hipMemsetAsync(raw->d_fb.ptr, 0, size_t(width) * height * 4, raw->stream));
+        raw->d_counters.reserve(CNT_WORDS);
+        HIP_CHECK(hipStreamSynchronize(raw->stream));
+        return int(SWFR_OK);
+    });
+    if (rc != SWFR_OK) return rc;
+    *out = r.release();
+    return SWFR_OK;
+}
+
+void swfr_destroy(swfr_renderer* r) { delete r; }
+
+int swfr_register_shape(swfr_renderer* r, const swfr_define_shape* tag, uint32_t* out_id) {
+    if (!r || !tag || !out_id) return fail(r, SWFR_ERR_INVALID, "null argument");
+    return guarded(r, [&]() {
+        *out_id = r->builder->add_shape(decode_shape(*tag, false));
+        return int(SWFR_OK);
+    });
+}
+
+int swfr_register_morph_shape(swfr_renderer* r, const swfr_define_shape* tag, uint32_t* out_id) {
+    if (!r || !tag || !out_id) return fail(r, SWFR_ERR_INVALID, "null argument");
+    return guarded(r, [&]() {
+        *out_id = r->builder->add_morph_shape(decode_shape(*tag, true));
+        return int(SWFR_OK);
+    });
+}
+
+int swfr_register_bitmap(swfr_renderer* r, uint32_t id, uint32_t width, uint32_t height, const uint8_t* rgba, size_t stride) {
+    if (!r || !rgba || width == 0 || height == 0 || stride < size_t(width) * 4) return fail(r, SWFR_ERR_INVALID, "bad bitmap");
+    if (id > 65535) return fail(r, SWFR_ERR_INVALID, "bitmap id out of range");
+    return guarded(r, [&]() {
+        r->builder->add_bitmap(id, BitmapInfo{width, height});
+        if (!r->has_device) return int(SWFR_OK);
+        // putImageData: straight RGBA -> premultiplied ARGB (c * a / 255)
+        std::vector<uint32_t> argb(size_t(width) * height);
+        for (uint32_t y = 0; y < height; ++y) {
+            const uint8_t* row = rgba + size_t(y) * stride;
+            for (uint32_t x = 0; x < width; ++x) {
+                const uint32_t a = row[4 * x + 3];
+                const uint32_t pr = row[4 * x] * a / 255, pg = row[4 * x + 1] * a / 255, pb = row[4 * x + 2] * a / 255;
+                argb[size_t(y) * width + x] = (a << 24) | (pr << 16) | (pg << 8) | pb;
+            }
+        }
+        DeviceBitmap& slot = r->bitmaps[id];
+        if (slot.pixels) HIP_CHECK(hipFree(slot.pixels));
+        slot = DeviceBitmap{};
+        HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&slot.pixels), argb.size() * 4));
+        HIP_CHECK(hipMemcpy(slot.pixels, argb.data(), argb.size() * 4, hipMemcpyHostToDevice));
+        slot.width = width;
+        slot.height = height;
+        if (r->bitmap_table.size() <= id) r->bitmap_table.resize(id + 1, DevBitmap{nullptr, 0, 0});
+        r->bitmap_table[id] = DevBitmap{slot.pixels, width, height};
+        r->bitmap_table_dirty = true;
+        return int(SWFR_OK);
+    });
+}
+
+int swfr_build_frame(swfr_renderer* r, const swfr_stage* stage, const swfr_edge** edges, size_t* n_edges, const swfr_path** paths,
+                     size_t* n_paths, const swfr_style** styles, size_t* n_styles) {
+    if (!r || !stage) return fail(r, SWFR_ERR_INVALID, "null argument");
+    return guarded(r, [&]() {
+        r->builder->build(*stage);
+        if (edges) *edges = r->builder->edges().data();
+        if (n_edges) *n_edges = r->builder->edges().size();
+        if (paths) *paths = r->builder->paths().data();
+        if (n_paths) *n_paths = r->builder->paths().size();
+        if (styles) *styles = r->builder->styles().data();
+        if (n_styles) *n_styles = r->builder->styles().size();
+        return int(SWFR_OK);
+    });
+}
+
+int swfr_upload_edges(swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_path* paths, size_t n_paths,
+                      const swfr_style* styles, size_t n_styles) {
+    if (!r || (n_edges && !edges) || (n_paths && !paths) || (n_styles && !styles)) return fail(r, SWFR_ERR_INVALID, "null argument");
+    return guarded(r, [&]() { return upload(r, edges, n_edges, paths, n_paths, styles, n_styles); });
+}
+
+int swfr_render_resident(swfr_renderer* r, uint32_t frames) {
+    if (!r) return SWFR_ERR_INVALID;
+    return guarded(r, [&]() { return render_resident(r, frames); });
+}
+
+int swfr_render_edges(swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_path* paths, size_t n_paths,
+                      const swfr_style* styles, size_t n_styles) {
+    const int rc = swfr_upload_edges(r, edges, n_edges, paths, n_paths, styles, n_styles);
+    if (rc != SWFR_OK) return rc;
+    return swfr_render_resident(r, 1);
+}
+
+int swfr_render(swfr_renderer* r, const swfr_stage* stage) {
+    if (!r || !stage) return fail(r, SWFR_ERR_INVALID, "null argument");
+    if (!r->has_device) return fail(r, SWFR_ERR_NO_DEVICE, "host-only handle cannot rasterize");
+    return guarded(r, [&]() {
+        r->builder->build(*stage);
+        const auto& e = r->builder->edges();
+        const auto& p = r->builder->paths();
+        const auto& s = r->builder->styles();
+        const int rc = upload(r, e.data(), e.size(), p.data(), p.size(), s.data(), s.size());
+        if (rc != SWFR_OK) return rc;
+        return render_resident(r, 1);
+    });
+}
+
+int swfr_read_image(swfr_renderer* r, uint8_t* dst, size_t dst_stride, int premultiplied) {
+    if (!r || !dst || dst_stride < size_t(r->width) * 4) return fail(r, SWFR_ERR_INVALID, "bad destination");
+    if (!r->has_device) return fail(r, SWFR_ERR_NO_DEVICE, "host-only handle has no image");
+    if (!r->fb_valid) return fail(r, SWFR_ERR_INVALID, "nothing rendered yet");
+    return guarded(r, [&]() {
+        const size_t n = size_t(r->width) * r->height;
+        const uint32_t* src = r->d_fb.ptr;
+        if (!premultiplied) {
+            r->d_tmp.reserve(n);
+            launch_unpremultiply(r->stream, r->d_fb.ptr, r->d_tmp.ptr, n);
+            src = r->d_tmp.ptr;
+        }
+        HIP_CHECK(hipMemcpy2DAsync(dst, dst_stride, src, size_t(r->width) * 4, size_t(r->width) * 4, r->height, hipMemcpyDeviceToHost,
+                                   r->stream));
+        HIP_CHECK(hipStreamSynchronize(r->stream));
+        return int(SWFR_OK);
+    });
+}
+
+int swfr_shape_json(swfr_renderer* r, uint32_t id, int morph, const char** json) {
+    if (!r || !json) return fail(r, SWFR_ERR_INVALID, "null argument");
+    return guarded(r, [&]() {
+        const DecodedShape* s = r->builder->shape(id, morph != 0);
+        if (!s) throw StatusError{SWFR_ERR_NOT_FOUND, "unknown shape id"};
+        r->json_scratch = shape_to_json(*s);
+        *json = r->json_scratch.c_str();
+        return int(SWFR_OK);
+    });
+}
+
+int swfr_last_timing(swfr_renderer* r, swfr_timing* out) {
+    if (!r || !out) return SWFR_ERR_INVALID;
+    *out = r->timing;
+    return SWFR_OK;
+}
+
+size_t swfr_band_slab_bytes(const swfr_renderer* r) {
+    if (!r) return 0;
+    return size_t(local_tile_rows(r)) * TILE_H * r->width * 4;
+}
+
+int swfr_copy_band_slab(swfr_renderer* r, void* device_dst) {
+    if (!r || !device_dst) return fail(r, SWFR_ERR_INVALID, "null argument");
+    if (!r->has_device) return fail(r, SWFR_ERR_NO_DEVICE, "host-only handle");
+    return guarded(r, [&]() {
+        const uint32_t bc = r->cfg.band_count > 1 ? r->cfg.band_count : 1, bi = r->cfg.band_count > 1 ? r->cfg.band_index : 0;
+        launch_pack_band(r->stream, r->d_fb.ptr, static_cast<uint32_t*>(device_dst), int(r->width), int(r->height), bi, bc, local_tile_rows(r));
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(r->stream));
+        return int(SWFR_OK);
+    });
+}
+
+void* swfr_device_framebuffer(swfr_renderer* r) { return (r && r->has_device) ? r->d_fb.ptr : nullptr; }
+
+#pragma GCC visibility pop
+}  // extern "C"
