@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""bench.py -- headline metric of BASELINE.json: Mpixels/s rasterized (+ frames/s) at 4K on the 10k-edge
+synthetic shape set (scene S1).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step is one pass of the hot path over one frame: edge setup -> per-row winding -> tile raster/shade/blend
+-> RGBA8 framebuffer in HBM, with the edge list already resident in HBM.  With N > 1 the frame's tile-rows
+are sharded over the ranks (strong scaling: the frame is fixed) and every step ends with one RCCL gather of
+the band slabs to rank 0, where the frame is assembled.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured ceiling
+
+
+def cpu_baseline(fx, cols, W, H, budget_s=12.0):
+    """The oracle (single-thread C restatement) timed on this box's host cores on a bounded sample."""
+    import numpy as np
+    from oracle import oracle_backend as ob
+    L = ob.lib()
+    argb = ((cols[:, 3].astype(np.uint32) << 24) | (cols[:, 0].astype(np.uint32) << 16) |
+            (cols[:, 1].astype(np.uint32) << 8) | cols[:, 2]).astype(np.uint32)
+    counts = np.full(len(fx), fx.shape[1], dtype=np.int32)
+    xy = np.ascontiguousarray(fx.reshape(-1))
+    frames, t0 = 0, time.perf_counter()
+    while True:
+        ctx = L.swfo_create(W, H)
+        L.swfo_fill_polygons_fixed(ctx, xy.ctypes.data, counts.ctypes.data, argb.ctypes.data, len(fx), 0)
+        L.swfo_destroy(ctx)
+        frames += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or frames >= 200:
+            break
+    return {"value": round(W * H * frames / dt / 1e6, 2), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+            "sample": "%d full S1 frames (3840x2160, 1000 stars) in %.1f s, single thread, oracle/swfr_oracle.c" % (frames, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import swf_renderer_amd as S
+    from swf_renderer_amd import api, synth, distributed as D
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    cfg = synth.S1
+    W, H = cfg["width"], cfg["height"]
+    pts, cols = synth.scene(**cfg)
+    fx = synth.twips_to_fixed(pts)
+    # host half through the product's own C++ frame builder (register_shape + scene walk), as swfr_render does
+    host = S.Renderer(W, H, device=api.DEVICE_HOST_ONLY)
+    t0 = time.perf_counter()
+    stage = api.stars_to_stage(pts, cols)
+    edges, paths, styles = host.build_frame(stage)
+    t_host = time.perf_counter() - t0
+    host.close()
+
+    r = S.Renderer(W, H, device=local_rank, band_index=rank if world > 1 else 0, band_count=world if world > 1 else 0)
+    r.upload_edges(edges, paths, styles)                      # inputs resident in HBM before the timed region
+    slab = None
+    if world > 1:
+        slab = torch.empty(D.slab_shape(W, H, rank, world), dtype=torch.uint8, device="cuda")
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step_multi():
+        r.render_resident(1)
+        r.copy_band_slab(slab.data_ptr())
+        return D.gather_slabs(slab, W, H, rank, world, dst=0)
+
+    # ---- warmup
+    if world == 1:
+        r.render_resident(max(args.warmup, 1))
+    else:
+        for _ in range(max(args.warmup, 1)):
+            step_multi()
+    sync_all()
+    # ---- timed region: exactly K steps
+    t0 = time.perf_counter()
+    if world == 1:
+        r.render_resident(args.steps)                         # K frames queued back to back on the handle's stream
+    else:
+        for _ in range(args.steps):
+            out = step_multi()
+    sync_all()
+    dt = time.perf_counter() - t0
+    tm = r.timing()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        n_edges, n_paths = len(edges), len(paths)
+        algo_bytes = 4 * W * H + 16 * n_edges + 16 * n_paths           # SURVEY.md 8(d), per frame = per k_tiles launch
+        if world > 1:
+            algo_bytes = 4 * W * D.local_tile_rows(H, 0, world) * D.TILE_H + 16 * n_edges + 16 * n_paths
+        tiles_ms = tm["tiles_ms"] / max(tm["frames"], 1)
+        achieved = algo_bytes / (tiles_ms * 1e-3) / 1e9 if tiles_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_k_tiles.json")
+        if os.path.exists(pmc) and world == 1:
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        line = {
+            "metric": "Mpixels/sec rasterized @ 4K, 10k-edge synthetic shape set",
+            "value": round(W * H * args.steps / dt / 1e6, 2),
+            "unit": "Mpixels/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "frames_per_sec": round(args.steps / dt, 1),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "int64/u8",
+            "data": "synthetic",
+            "config": {"workload": "S1: 3840x2160, 1000 ten-vertex stars = 10k edges, opaque solid, nonzero, seed 0xC0FFEE",
+                       "n_edges": n_edges, "n_paths": n_paths,
+                       "sharding": "tile-row bands interleaved over %d rank(s)%s" % (world, ", one RCCL gather per frame" if world > 1 else ""),
+                       "host_edge_list_build_ms": round(t_host * 1e3, 2)},
+            "kernel_ms_per_frame": {"k_setup": round(tm["setup_ms"] / tm["frames"], 4), "k_rows": round(tm["rows_ms"] / tm["frames"], 4),
+                                    "k_tiles": round(tiles_ms, 4)},
+            "roofline": {"bound": "hbm", "kernel": "k_tiles", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": algo_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(fx, cols, W, H)
+        print(json.dumps(line), flush=True)
+    r.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -118,7 +118,7 @@ enum { SWFR_OBJECT_SHAPE = 0, SWFR_OBJECT_MORPH_SHAPE = 1, SWFR_OBJECT_CONTAINER
 
 typedef struct swfr_display_object {
     uint32_t type;                       /* SWFR_OBJECT_* (ts/src/lib/display/display-object-type.ts) */
-    uint32_t id;                         /* value returned by swfr_register_(morph_)shape */
+    uint32_t id;                         /* value returned by swfr_register_shape / swfr_register_morph_shape */
     uint8_t has_matrix; swfr_matrix matrix;
     double ratio;                        /* morph shapes: [0,1] (ts/src/lib/display/morph-shape.ts:9);
                                             Rust MorphRatio(u16) maps as ratio = v / 65535.0 */

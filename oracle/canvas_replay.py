@@ -53,6 +53,13 @@ def _decode_gradient(g):
     return out
 
 
+def _sfixed8p8(v):
+    # swf-tree Sfixed8P8: {"epsilons": n} in JSON; valueOf() = n / 256
+    if isinstance(v, dict):
+        return _js_num(v["epsilons"] / 256.0)
+    return _js_num(float(v))
+
+
 def _decode_fill(s):
     # decodeFillStyle, decode-swf-shape.ts:110-139
     t = s["type"]
@@ -61,7 +68,7 @@ def _decode_fill(s):
                 "repeating": s["repeating"], "smoothed": s["smoothed"]}
     if t == "focal-gradient":
         return {"type": FILL_FOCAL, "matrix": s["matrix"], "gradient": _decode_gradient(s["gradient"]),
-                "focalPoint": s["focal_point"] / 256.0 if isinstance(s["focal_point"], int) else float(s["focal_point"])}
+                "focalPoint": _sfixed8p8(s["focal_point"])}
     if t == "linear-gradient":
         return {"type": FILL_LINEAR, "matrix": s["matrix"], "gradient": _decode_gradient(s["gradient"])}
     if t == "radial-gradient":
@@ -370,8 +377,12 @@ class CanvasReplay:
 
     GRAD_RADIUS = 16384  # canvas-renderer.ts:322
 
-    def __init__(self, backend):
+    def __init__(self, backend, linear_extension=False):
         self.be = backend
+        # Linear gradients throw NotImplementedFillStyle in the reference (canvas-renderer.ts:332-333).
+        # linear_extension=True enables the documented beyond-reference behaviour:
+        # createLinearGradient(-16384, 0, 16384, 0) under fill.matrix.
+        self.linear_extension = linear_extension
         self.bitmaps = {}
         self._shape_cache = {}
         self._morph_cache = {}
@@ -468,6 +479,10 @@ class CanvasReplay:
                 self._apply_matrix(f["matrix"])
                 stops = [(s["ratio"],) + css_rgba(s["color"]) for s in f["gradient"]["colors"]]
                 be.set_fill_radial(_lerp(0, self.GRAD_RADIUS, f["focalPoint"]), 0, 0, 0, 0, self.GRAD_RADIUS, stops)
+            elif f["type"] == FILL_LINEAR and self.linear_extension:
+                self._apply_matrix(f["matrix"])
+                stops = [(s["ratio"],) + css_rgba(s["color"]) for s in f["gradient"]["colors"]]
+                be.set_fill_linear(-self.GRAD_RADIUS, 0, self.GRAD_RADIUS, 0, stops)
             else:
                 be.restore()
                 raise NotImplementedError("NotImplementedFillStyle")

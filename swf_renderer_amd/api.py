@@ -475,27 +475,47 @@ def solid_style(pixel_argb_premultiplied: int) -> Style:
     return s
 
 
-def polygons_to_scene(fixed_xy: np.ndarray, colors_rgba8: np.ndarray, width: int, height: int):
-    """Closed polygons in 24.8 device coordinates (all inside the frame) -> (edges, paths, styles).
+def _merge_collinear(poly):
+    """Vertices of a closed polyline p0..pn-1 (explicit final line back to p0) after Cairo's
+    line_to merge: a vertex is dropped when the segments before and after it have equal slope and
+    do not reverse.  p0 is never dropped (the path starts there)."""
+    pts = [tuple(int(v) for v in poly[0])]
+    seq = [tuple(int(v) for v in q) for q in poly[1:]] + [pts[0]]
+    for q in seq:
+        if q == pts[-1]:
+            continue
+        if len(pts) >= 2:
+            ax, ay = pts[-1][0] - pts[-2][0], pts[-1][1] - pts[-2][1]
+            bx, by = q[0] - pts[-1][0], q[1] - pts[-1][1]
+            if ay * bx == by * ax and not (((ax * bx) >> 8) + ((ay * by) >> 8) < 0):
+                pts.pop()
+        pts.append(q)
+    return pts  # last == first
 
-    Used for the synthetic benchmark scenes: the flattened, painter-ordered edge list a host would
-    produce for opaque solid stars.  fixed_xy: int32 [n, verts, 2]; colours straight RGBA8.
+
+def polygons_to_scene(fixed_xy: np.ndarray, colors_rgba8: np.ndarray, width: int, height: int):
+    """Polygons in 24.8 device coordinates (all inside the frame), drawn the way the reference draws a
+    one-fill shape (moveTo p0, lineTo p1..pn-1, lineTo p0, fill) -> (edges, paths, styles).
+
+    This is the edge list the host produces for the synthetic benchmark scenes (opaque solid stars);
+    tests check it against swfr_build_frame on the same shapes.  fixed_xy: int32 [n, verts, 2].
     """
-    n, verts, _ = fixed_xy.shape
-    a = fixed_xy
-    b = np.roll(fixed_xy, -1, axis=1)
-    down = a[..., 1] < b[..., 1]
-    flat = a[..., 1] == b[..., 1]
-    e = np.zeros((n, verts), dtype=EDGE_DTYPE)
-    e["x1"] = np.where(down, a[..., 0], b[..., 0])
-    e["y1"] = np.where(down, a[..., 1], b[..., 1])
-    e["x2"] = np.where(down, b[..., 0], a[..., 0])
-    e["y2"] = np.where(down, b[..., 1], a[..., 1])
-    e["top"], e["bottom"] = e["y1"], e["y2"]
-    e["dir"] = np.where(down, 1, -1)
-    keep = ~flat
-    counts = keep.sum(axis=1).astype(np.uint32)
-    edges = e[keep]
+    n = fixed_xy.shape[0]
+    edge_rows, counts = [], []
+    for i in range(n):
+        pts = _merge_collinear(fixed_xy[i])
+        c = 0
+        for a, b in zip(pts[:-1], pts[1:]):
+            if a[1] == b[1]:
+                continue
+            if a[1] < b[1]:
+                edge_rows.append((a[0], a[1], b[0], b[1], a[1], b[1], 1, 0))
+            else:
+                edge_rows.append((b[0], b[1], a[0], a[1], b[1], a[1], -1, 0))
+            c += 1
+        counts.append(c)
+    edges = np.array(edge_rows, dtype=np.int32).view(EDGE_DTYPE).reshape(-1) if edge_rows else np.zeros(0, EDGE_DTYPE)
+    counts = np.array(counts, dtype=np.uint32)
     paths = np.zeros(n, dtype=PATH_DTYPE)
     paths["first_edge"] = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.uint32)
     paths["n_edges"] = counts
@@ -507,11 +527,31 @@ def polygons_to_scene(fixed_xy: np.ndarray, colors_rgba8: np.ndarray, width: int
     paths["x_max"] = np.minimum((fixed_xy[..., 0].max(axis=1) + 255) >> 8, width)
     paths["y_max"] = np.minimum((fixed_xy[..., 1].max(axis=1) + 255) >> 8, height)
     c = colors_rgba8.astype(np.uint32)
-    al = c[:, 3]
-    # cairo_set_source_rgba(r/255, ...): premultiply in doubles, 16-bit shorts, >> 8
-    def sh(v):
+    af = c[:, 3] / 255.0
+
+    def sh(v):  # cairo_set_source_rgba: premultiply in doubles, 16-bit shorts, >> 8
         return ((v * 65535.0 + 0.5).astype(np.uint32) & 0xFFFF) >> 8
-    af = al / 255.0
+
     pix = (sh(af) << 24) | (sh(c[:, 0] / 255.0 * af) << 16) | (sh(c[:, 1] / 255.0 * af) << 8) | sh(c[:, 2] / 255.0 * af)
     styles = [solid_style(int(p)) for p in pix]
-    return edges, paths, styles
+    keep = counts > 0
+    return edges, paths[keep], styles
+
+
+def stars_to_stage(twips: np.ndarray, colors_rgba8: np.ndarray):
+    """The same polygons as swf-tree DefineShape tags + a Stage (one shape per polygon, painter's order =
+    index): the input of the full reference-API path (register_shape + render)."""
+    children = []
+    for i in range(twips.shape[0]):
+        p = twips[i]
+        recs = [{"type": "style-change", "move_to": {"x": int(p[0, 0]), "y": int(p[0, 1])}, "left_fill": 1}]
+        n = p.shape[0]
+        for k in range(1, n + 1):
+            a, b = p[k - 1], p[k % n]
+            recs.append({"type": "edge", "delta": {"x": int(b[0] - a[0]), "y": int(b[1] - a[1])}})
+        col = {"r": int(colors_rgba8[i, 0]), "g": int(colors_rgba8[i, 1]), "b": int(colors_rgba8[i, 2]), "a": int(colors_rgba8[i, 3])}
+        tag = {"id": i + 1, "bounds": {"x_min": int(p[:, 0].min()), "x_max": int(p[:, 0].max()),
+                                        "y_min": int(p[:, 1].min()), "y_max": int(p[:, 1].max())},
+               "shape": {"initial_styles": {"fill": [{"type": "solid", "color": col}], "line": []}, "records": recs}}
+        children.append({"type": "shape", "definition": tag})
+    return {"children": children}

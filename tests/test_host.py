@@ -1,0 +1,153 @@
+"""Host logic of the product without a GPU: the C-ABI library loads and exports every symbol of
+include/swfr.h, decode matches the reference goldens, and the frame builder's edge lists equal the
+oracle's polygons edge for edge."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import scenarios
+import swf_renderer_amd as S
+from helpers import fixture, fixture_text
+from oracle import canvas_replay as cr, oracle_backend as ob
+from swf_renderer_amd import api, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SC = scenarios.scenarios()
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "swfr.h")).read()
+    declared = set(re.findall(r"^(?:int|void|const char \*|uint32_t|size_t|void \*)\s*\*?(swfr_[a-z_]+)\s*\(", header, re.M))
+    assert declared == set(api.EXPORTS), declared ^ set(api.EXPORTS)
+    L = S.load_library()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.swfr_abi_version() == 1
+
+
+def test_no_device_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(S.SwfrError) as e:
+        S.Renderer(32, 32)
+    assert e.value.code == api.ERR_NO_DEVICE
+    r = S.Renderer(32, 32, device=api.DEVICE_HOST_ONLY)
+    with pytest.raises(S.SwfrError) as e:
+        r.render({"children": []})
+    assert e.value.code == api.ERR_NO_DEVICE     # no CPU rasterization fallback exists
+
+
+@pytest.mark.parametrize("name", ["squares", "triangle", "homestuck-beta-1", "homestuck-beta-4"])
+def test_decode_shape_json_golden(name):
+    r = S.Renderer(8, 8, device=api.DEVICE_HOST_ONLY)
+    sid = r.register_shape(fixture(name))
+    assert r.shape_json(sid) == fixture_text(name + ".shape.ts.json")
+
+
+def test_decode_morph_shape_json_golden():
+    r = S.Renderer(8, 8, device=api.DEVICE_HOST_ONLY)
+    sid = r.register_morph_shape(fixture("homestuck-beta-29"))
+    assert r.shape_json(sid, morph=True) == fixture_text("homestuck-beta-29.shape.ts.json")
+
+
+def test_bitmap_decode_matches_reference_pam():
+    tag = fixture("homestuck-beta-3.bitmap")
+    w, h, rgba = api.decode_x_swf_bmp(bytes.fromhex(tag["data"]))
+    with open(os.path.join(ROOT, "tests", "golden", "fixtures", "homestuck-beta-3.pam"), "rb") as f:
+        assert cr.image_to_pam(w, h, rgba) == f.read()
+
+
+class _Tap(ob.OracleBackend):
+    """Oracle backend that records the polygon of every fill()/stroke()."""
+
+    def __init__(self, w, h):
+        super().__init__(w, h)
+        self.polys = []
+        self.L.swfo_last_polygon.restype = ctypes.c_int
+        self.L.swfo_last_polygon.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.POINTER(ctypes.c_int32)), ctypes.POINTER(ctypes.c_int)]
+
+    def _grab(self):
+        p, rect = ctypes.POINTER(ctypes.c_int32)(), ctypes.c_int()
+        n = self.L.swfo_last_polygon(self.ctx, ctypes.byref(p), ctypes.byref(rect))
+        if n:
+            self.polys.append((np.ctypeslib.as_array(p, shape=(n, 7)).copy(), rect.value))
+
+    def fill(self):
+        super().fill()
+        self._grab()
+
+    def stroke(self):
+        super().stroke()
+        self._grab()
+
+
+@pytest.mark.parametrize("name", sorted(SC))
+def test_frame_edges_equal_oracle_polygons(name):
+    sc = SC[name]
+    r = S.Renderer(sc["width"], sc["height"], device=api.DEVICE_HOST_ONLY, even_odd=bool(sc.get("even_odd")))
+    for b in sc.get("bitmaps", []):
+        r.add_bitmap(b)
+    edges, paths, styles = r.build_frame(sc["stage"])
+    tap = _Tap(sc["width"], sc["height"])
+    rp = cr.CanvasReplay(tap, linear_extension=True)
+    for b in sc.get("bitmaps", []):
+        rp.add_bitmap(b)
+    rp.render(sc["stage"])
+    assert len(paths) == len(tap.polys)
+    for pth, (pe, rect) in zip(paths, tap.polys):
+        e = edges[pth["first_edge"]: pth["first_edge"] + pth["n_edges"]]
+        if rect:
+            assert pth["kind"] == api.PATH_BOXES
+            continue
+        assert pth["kind"] == api.PATH_TOR
+        got = np.stack([e[k] for k in ("x1", "y1", "x2", "y2", "top", "bottom", "dir")], 1)
+        assert got.shape == pe.shape and (got == pe).all()
+    tap.close()
+
+
+def test_synthetic_scene_builder_equals_host_api():
+    pts, cols = synth.scene(seed=synth.S1["seed"], n_shapes=300, width=3840, height=2160)
+    e1, p1, s1 = api.polygons_to_scene(synth.twips_to_fixed(pts), cols, 3840, 2160)
+    r = S.Renderer(3840, 2160, device=api.DEVICE_HOST_ONLY)
+    e2, p2, s2 = r.build_frame(api.stars_to_stage(pts, cols))
+    assert e1.tobytes() == e2.tobytes() and p1.tobytes() == p2.tobytes()
+    assert [s.pixel for s in s1] == [s.pixel for s in s2]
+
+
+def test_reference_error_behaviour():
+    r = S.Renderer(8, 8, device=api.DEVICE_HOST_ONLY)
+    bad = fixture("triangle")
+    bad["shape"]["records"][0]["left_fill"] = 9
+    with pytest.raises(S.SwfrError) as e:          # decode-swf-shape.ts:410-421 "Invalid fill ID"
+        r.register_shape(bad)
+    assert e.value.code == api.ERR_INVALID and "Invalid fill ID" in str(e.value)
+    tag = fixture("homestuck-beta-4")              # bitmap 3 never added: node-canvas-bitmap-service.ts:39-45
+    with pytest.raises(S.SwfrError) as e:
+        r.build_frame(cr.stage_for_shape(tag)[2])
+    assert e.value.code == api.ERR_NOT_FOUND and "BitmapNotFound" in str(e.value)
+    with pytest.raises(S.SwfrError) as e:          # unknown display object / id
+        r.build_frame({"children": [{"type": "shape", "id": 77}]})
+    assert e.value.code == api.ERR_NOT_FOUND
+    morph = fixture("homestuck-beta-29")
+    morph["shape"]["initial_styles"]["fill"][0] = {"type": "radial-gradient", "matrix": morph["shape"]["initial_styles"]["fill"][0].get("matrix", scenarios._m()), "gradient": scenarios._grad([(0, (0, 0, 0))])}
+    with pytest.raises(S.SwfrError) as e:          # decode-swf-morph-shape.ts:94-106 "Unknown fill type"
+        r.register_morph_shape(morph)
+    assert "Unknown fill type" in str(e.value)
+
+
+def test_empty_and_degenerate_inputs():
+    r = S.Renderer(16, 16, device=api.DEVICE_HOST_ONLY)
+    e, p, s = r.build_frame({"children": []})
+    assert len(e) == 0 and len(p) == 0
+    # a shape whose path is a single point / zero-area produces nothing
+    tag = scenarios._poly_shape([(100, 100), (100, 100), (100, 100)], {"type": "solid", "color": scenarios._rgba(1, 2, 3)})
+    e, p, s = r.build_frame({"children": [{"type": "shape", "definition": tag}]})
+    assert len(p) == 0
+    # fully off-frame geometry is dropped before it reaches the device
+    tag = scenarios._poly_shape([(-5000, -5000), (-4000, -5000), (-4500, -4000)], {"type": "solid", "color": scenarios._rgba(1, 2, 3)})
+    e, p, s = r.build_frame({"children": [{"type": "shape", "definition": tag}]})
+    assert len(p) == 0

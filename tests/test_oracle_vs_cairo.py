@@ -1,0 +1,107 @@
+"""Pins oracle/swfr_oracle.c against the container's libcairo 1.16.0 by fuzzing (skipped where the
+library is absent; the committed goldens cover the same ground on the GPU box)."""
+import numpy as np
+import pytest
+
+from oracle import cairo_backend as cb, oracle_backend as ob
+
+pytestmark = pytest.mark.skipif(not cb.available(), reason="libcairo not installed")
+
+
+def _draw(be, ops):
+    be.set_transform_identity()
+    be.clear_all()
+    for op in ops:
+        if op[0] == "poly":
+            _, pts, col, eo, curves = op
+            be.begin_path()
+            be.move_to(*pts[0])
+            i = 1
+            while i < len(pts):
+                if curves and i + 1 < len(pts) and curves[i]:
+                    be.quadratic_curve_to(pts[i][0], pts[i][1], pts[i + 1][0], pts[i + 1][1])
+                    i += 2
+                else:
+                    be.line_to(*pts[i])
+                    i += 1
+            be.set_fill_rule(eo)
+            be.set_fill_rgba(*col)
+            be.fill()
+        else:
+            _, pts, col, wd = op
+            be.begin_path()
+            be.move_to(*pts[0])
+            for p in pts[1:]:
+                be.line_to(*p)
+            be.set_line_width(wd)
+            be.set_stroke_rgba(*col)
+            be.stroke()
+
+
+def _same(W, H, ops):
+    a = cb.CairoBackend(W, H); _draw(a, ops); ca = a.premultiplied_rgba(); a.close()
+    b = ob.OracleBackend(W, H); _draw(b, ops); oa = b.premultiplied_rgba(); b.close()
+    return (ca == oa).all()
+
+
+def _pts(rng, W, H, n, mode):
+    if mode == "quarter":
+        return [(float(rng.integers(0, 4 * W)) / 4, float(rng.integers(0, 4 * H)) / 4) for _ in range(n)]
+    if mode == "integer":
+        return [(float(rng.integers(0, W)), float(rng.integers(0, H))) for _ in range(n)]
+    if mode == "offframe":
+        return [(float(rng.uniform(-30, W + 30)), float(rng.uniform(-30, H + 30))) for _ in range(n)]
+    if mode == "shallow":
+        y = rng.uniform(0, H)
+        return [(float(rng.uniform(0, W)), float(y + rng.uniform(-2, 2))) for _ in range(n)]
+    if mode == "steep":
+        x = rng.uniform(0, W)
+        return [(float(x + rng.uniform(-2, 2)), float(rng.uniform(0, H))) for _ in range(n)]
+    return [(float(rng.uniform(0, W)), float(rng.uniform(0, H))) for _ in range(n)]
+
+
+@pytest.mark.parametrize("mode", ["uniform", "quarter", "integer", "offframe", "shallow", "steep"])
+def test_polygons_both_fill_rules(mode):
+    rng = np.random.default_rng(hash(mode) % 1000)
+    for _ in range(250):
+        W, H = int(rng.integers(16, 64)), int(rng.integers(16, 64))
+        ops = [("poly", _pts(rng, W, H, int(rng.integers(3, 9)), mode), (int(rng.integers(0, 256)), 7, 99, 255),
+                bool(rng.integers(0, 2)), None)]
+        assert _same(W, H, ops), ops
+
+
+def test_quadratic_curves():
+    rng = np.random.default_rng(3)
+    for _ in range(250):
+        n = int(rng.integers(4, 9))
+        ops = [("poly", _pts(rng, 48, 40, n, "uniform"), (10, 200, 30, 255), False, [bool(rng.integers(0, 2)) for _ in range(n)])]
+        assert _same(48, 40, ops), ops
+
+
+def test_translucent_painters_order():
+    rng = np.random.default_rng(4)
+    for _ in range(250):
+        ops = [("poly", _pts(rng, 40, 40, int(rng.integers(3, 7)), "uniform"),
+                (int(rng.integers(0, 256)), int(rng.integers(0, 256)), int(rng.integers(0, 256)), int(rng.choice([255, 128, 37, 200, 1, 254]))),
+                False, None) for _ in range(3)]
+        assert _same(40, 40, ops), ops
+
+
+def test_open_strokes_miter_butt():
+    rng = np.random.default_rng(5)
+    for _ in range(400):
+        ops = [("stroke", _pts(rng, 48, 40, int(rng.integers(2, 7)), "uniform"), (0, 0, 0, 255), float(rng.uniform(0.5, 6)))]
+        assert _same(48, 40, ops), ops
+
+
+def test_rectangles_box_path():
+    rng = np.random.default_rng(6)
+    for _ in range(250):
+        ops = []
+        for _k in range(int(rng.integers(1, 4))):
+            x0, y0 = rng.uniform(-5, 40), rng.uniform(-5, 40)
+            x1, y1 = x0 + rng.uniform(0, 30), y0 + rng.uniform(0, 30)
+            q = lambda v: float(np.round(v * rng.choice([1, 2, 4, 20])) / rng.choice([1, 2, 4, 20]))
+            x0, y0, x1, y1 = map(q, (x0, y0, x1, y1))
+            ops.append(("poly", [(x0, y0), (x1, y0), (x1, y1), (x0, y1)], (int(rng.integers(0, 256)), 9, 0, int(rng.choice([255, 100]))), False, None))
+        assert _same(40, 40, ops), ops
