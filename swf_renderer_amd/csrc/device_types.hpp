@@ -31,11 +31,16 @@ struct RowInfo {
     uint16_t mode;
 };
 
-// record = {edge index, roles}: FULL rows carry REC_FULL | 1 (left, +1) or | 2 (right, -1);
-// SUB rows carry 15 two-bit fields, field s = 1 (a span opens at this edge in sub-row s) or 2 (closes)
+// record = {edge index, roles, column range}: FULL rows carry REC_FULL | 1 (left, +1) or | 2 (right, -1);
+// SUB rows carry 15 two-bit fields, field s = 1 (a span opens at this edge in sub-row s) or 2 (closes).
+// cols = lo | hi << 16: the pixel columns (clamped to [0, 65535]) this record's contributions fall in.
 constexpr uint32_t REC_FULL = 0x80000000u;
+struct Rec {
+    uint32_t eid, roles, cols;
+};
 
-enum : uint32_t { CNT_RECORDS = 0, CNT_ERROR = 1, CNT_WORDS = 4 };
+enum : uint32_t { CNT_RECORDS = 0, CNT_ERROR = 1, CNT_OVERFLOW = 2, CNT_WORDS = 4 };
+constexpr int ROWS_CHUNK = 64;       // pixel rows per k_rows workgroup (one lane per row)
 
 struct DevBitmap {
     const uint32_t* pixels;  // premultiplied ARGB, tight rows

@@ -1,19 +1,22 @@
 // raster_kernels.hip -- CDNA4 (gfx950) kernels of the hot path: edge list -> RGBA8 framebuffer in HBM.
 //
 // Pipeline per frame (all on one stream, no host round trips):
-//   k_setup  one thread per edge: Cairo "tor" edge constants (sub-row span, slope quotient/remainder)
-//            [SURVEY.md A.5 make_edge]
-//   k_rows   one lane per (path, pixel row): gathers the row's active edges, decides the row mode
-//            (analytic FULL row vs 15x sub-sampled SUB row), sorts by cell and runs the winding prefix
-//            to give every edge its role (span start / span end / interior).  Output: compact per-row
-//            records {edge, roles}.                                   [A.5 can_do_full_row/full_row/sub_row]
-//   k_tiles  one 256-thread workgroup per 64x16-pixel tile: walks the paths overlapping the tile in
-//            painter's order; accumulates covered-height / uncovered-area per cell in LDS (atomics),
-//            wave64 prefix sum along x, coverage -> 8-bit alpha, shades (solid / gradient / bitmap)
-//            and blends into the tile-resident pixels held in registers; one coalesced store per pixel.
-//                                                                      [A.5 render_edge/blit, A.6, A.7]
-// Integer arithmetic is exact (int64 products, double-estimated quotients with integer fix-up), so
-// results are bit-identical to the CPU scan converter for solid fills.
+//   k_setup     one thread per edge: Cairo "tor" edge constants (sub-row span, slope quotient/remainder)
+//               [SURVEY.md A.5 make_edge]
+//   k_bands     one workgroup per tile-row: painter-ordered list of the paths whose rows touch the band
+//   k_rows      one workgroup per (path, 64 pixel rows), one lane per row: gathers the row's active edges,
+//               decides the row mode (analytic FULL row vs 15x sub-sampled SUB row), sorts by cell and runs
+//               the winding prefix to give every edge its role (span start / span end / interior).
+//               Output: compact per-row records {edge, roles, column range}.   [A.5 can_do_full_row/full_row/sub_row]
+//   k_rows_big  same routine with a 4x larger per-row capacity for the rows that overflowed k_rows
+//   k_tiles     one 256-thread workgroup per 64x16-pixel tile: bins the band's paths to the tile, classifies
+//               each (empty / fully covered / partial), culls everything under the last opaque full cover,
+//               then walks the rest in painter's order: covered-height / uncovered-area per cell in LDS
+//               (atomics, double buffered), wave64 DPP prefix sum along x, coverage -> 8-bit alpha, shade
+//               (solid / gradient / bitmap), blend into tile-resident pixels held in registers; one coalesced
+//               store per pixel.                                            [A.5 render_edge/blit, A.6, A.7]
+// Integer arithmetic is exact (int64 products, double-estimated quotients with integer fix-up), so results are
+// bit-identical to the CPU scan converter for solid fills.
 //
 // No MFMA here: there is no dense contraction on this path; the roof is HBM store bandwidth.
 #include <hip/hip_runtime.h>
@@ -52,6 +55,28 @@ __device__ __forceinline__ void step_x(int32_t& quo, int64_t& rem, const DevEdge
     quo += (int32_t)e.dq; rem += e.dr;
     if (rem < 0) { --quo; rem += e.dy; } else if (rem >= e.dy) { ++quo; rem -= e.dy; }
 }
+// FULL-row end points of an edge over pixel row s0/15, stepped back from the sub-row centre to the row top
+__device__ __forceinline__ void full_row_ends(const DevEdge& e, int s0, int32_t& q1, int64_t& r1, int32_t& q2, int64_t& r2) {
+    edge_x_at(e, s0, q1, r1);
+    edge_x_at(e, s0 + 15, q2, r2);
+    if (e.dy) {
+        const int32_t hq = (int32_t)(e.dq / 2); const int64_t hr = e.dr / 2;
+        q1 -= hq; r1 -= hr; if (r1 < 0) { --q1; r1 += e.dy; } else if (r1 >= e.dy) { ++q1; r1 -= e.dy; }
+        q2 -= hq; r2 -= hr; if (r2 < 0) { --q2; r2 += e.dy; } else if (r2 >= e.dy) { ++q2; r2 -= e.dy; }
+    }
+}
+__device__ __forceinline__ uint32_t clamp_col(int c) { return (uint32_t)min(max(c, 0), 65535); }
+
+// wave64 inclusive prefix sum with DPP row shifts + row broadcasts (no LDS traffic)
+__device__ __forceinline__ int wave_scan_incl(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1,3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2,3
+    return v;
+}
 
 // ---------------------------------------------------------------------------------------------
 // k_setup
@@ -63,7 +88,7 @@ __global__ __launch_bounds__(256) void k_setup(const swfr_edge* __restrict__ in,
     const swfr_edge e = in[i];
     const DevPath p = paths[e.reserved];
     DevEdge d;
-    d.x1 = e.x1; d.y1 = e.y1; d.dir = e.dir; d.pad = 0;
+    d.x1 = e.x1; d.y1 = e.y1; d.dir = e.dir; d.pad = 0; d.pad2 = 0;
     if (p.kind != SWFR_PATH_TOR) {          // boxes are consumed raw by k_tiles
         d.ytop = d.ybot = 0; d.dy = 0; d.ex = 0; d.dq = d.dr = 0;
         out[i] = d;
@@ -85,182 +110,443 @@ __global__ __launch_bounds__(256) void k_setup(const swfr_edge* __restrict__ in,
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_bands: per tile-row, the paths whose pixel rows intersect it, in painter's order
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bands(const DevPath* __restrict__ paths, uint32_t n_paths,
+                                               const uint32_t* __restrict__ band_off, uint32_t* __restrict__ band_list) {
+    __shared__ uint32_t wave_cnt[4];
+    __shared__ uint32_t total;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int band = blockIdx.x;
+    const int y0 = band * TILE_H, y1 = y0 + TILE_H;
+    uint32_t* out = band_list + band_off[band];
+    if (tid == 0) total = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n_paths; base += 256) {
+        const uint32_t p = base + tid;
+        bool hit = false;
+        if (p < n_paths) { const DevPath P = paths[p]; hit = P.y_min < y1 && P.y_max > y0; }
+        const unsigned long long b = __ballot(hit);
+        if (lane == 0) wave_cnt[wave] = __popcll(b);
+        __syncthreads();
+        uint32_t off = total;
+        for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+        if (hit) out[off + __popcll(b & ((1ull << lane) - 1ull))] = p;
+        __syncthreads();
+        if (tid == 0) total += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_rows
 // ---------------------------------------------------------------------------------------------
-#define ROWS_MAXA 32
-
+template <int MAXA>
 struct RowLds {
-    int32_t eid[ROWS_MAXA][64];
-    int32_t quo[ROWS_MAXA][64];
-    int32_t rem_lo[ROWS_MAXA][64];
-    int32_t rem_hi[ROWS_MAXA][64];
-    int32_t cell[ROWS_MAXA][64];
-    int32_t aux[ROWS_MAXA][64];     // FULL check: end cell; SUB: role bits
-    uint8_t ord[ROWS_MAXA][64];
+    int32_t eid[MAXA][64];      // edge index relative to the path's first edge
+    int32_t quo[MAXA][64];      // SUB: x quotient;  FULL check: cell one sub-row earlier
+    int32_t rem_lo[MAXA][64];   // SUB: x remainder; FULL check: "starts in this row" flag
+    int32_t rem_hi[MAXA][64];
+    int32_t cell[MAXA][64];
+    int32_t aux[MAXA][64];      // FULL check: cell after a full step; then the role bits
+    int32_t cols[MAXA][64];     // lo | hi << 16 column range of the contributions
+    uint8_t ord[MAXA][64];
 };
 
-__global__ __launch_bounds__(64) void k_rows(const DevEdge* __restrict__ edges, const DevPath* __restrict__ paths,
-                                             const uint32_t* __restrict__ row_base, uint32_t n_paths,
-                                             RowInfo* __restrict__ rows, uint2* __restrict__ records,
-                                             uint32_t* __restrict__ counters, uint32_t n_tasks,
-                                             uint32_t band_index, uint32_t band_count) {
-    __shared__ RowLds L;
-    const int lane = threadIdx.x;
-    const uint32_t t = blockIdx.x * 64 + lane;
-    uint32_t n_out = 0;      // records this lane will write
-    uint32_t mode = ROW_EMPTY;
+struct RowResult {
+    uint32_t mode;
+    int n;              // active edges gathered (<= MAXA)
+    bool overflow;
+};
+
+// One pixel row r of path P for this lane.  E points at the path's edges (LDS copy or global).
+template <int MAXA, class LDS>
+__device__ __forceinline__ RowResult process_row(const DevEdge* E, const DevPath& P, int r, LDS& L, int lane) {
+    RowResult res; res.mode = ROW_EMPTY; res.n = 0; res.overflow = false;
+    const int s0 = r * 15;
     int n = 0;
-    DevPath P;
-    int r = 0, s0 = 0;
-    bool live = t < n_tasks;
-    if (live) {
-        // task -> (path, row): upper_bound on the prefix array
-        uint32_t lo = 0, hi = n_paths;
-        while (lo + 1 < hi) { const uint32_t mid = (lo + hi) >> 1; if (row_base[mid] <= t) lo = mid; else hi = mid; }
-        P = paths[lo];
-        r = P.y_min + (int)(t - row_base[lo]);
-        s0 = r * 15;
-        if (P.kind != SWFR_PATH_TOR) live = false;
-        else if (band_count > 1 && (uint32_t)((r / TILE_H) % band_count) != band_index) live = false;
+    bool mid_row = false;
+    for (uint32_t k = 0; k < P.n_edges; ++k) {
+        const int ytop = E[k].ytop, ybot = E[k].ybot;
+        if (ybot <= s0 || ytop >= s0 + 15) continue;
+        if (n < MAXA) { L.eid[n][lane] = (int32_t)k; ++n; } else res.overflow = true;
+        mid_row |= (ytop > s0) | (ybot < s0 + 15);
     }
-    if (live) {
-        bool mid_row = false, overflow = false;
-        for (uint32_t k = 0; k < P.n_edges; ++k) {
-            const uint32_t e = P.first_edge + k;
-            const int ytop = edges[e].ytop, ybot = edges[e].ybot;
-            if (ybot <= s0 || ytop >= s0 + 15) continue;
-            if (n < ROWS_MAXA) { L.eid[n][lane] = (int32_t)e; ++n; } else overflow = true;
-            mid_row |= (ytop > s0) | (ybot < s0 + 15);
+    if (res.overflow) return res;
+    res.n = n;
+    if (n == 0) return res;
+    const unsigned mask = P.fill_rule ? 1u : ~0u;
+    bool full = false;
+    if (!mid_row) {
+        // ---- candidate FULL row: order by cell at the row start, check the order after a full step
+        for (int k = 0; k < n; ++k) {
+            const DevEdge e = E[L.eid[k][lane]];
+            int32_t q; int64_t rm;
+            edge_x_at(e, s0, q, rm);
+            L.cell[k][lane] = e.dy ? cell_of(q, rm, e.dy) : e.x1;
+            int32_t q2; int64_t r2;
+            edge_x_at(e, s0 + 15, q2, r2);
+            L.aux[k][lane] = e.dy ? cell_of(q2, r2, e.dy) : e.x1;
+            // tie-break key among edges already active: the cell one sub-row earlier
+            int32_t qp = q; int64_t rp = rm;
+            if (e.dy && e.ytop < s0) { qp -= (int32_t)e.dq; rp -= e.dr; if (rp < 0) { --qp; rp += e.dy; } else if (rp >= e.dy) { ++qp; rp -= e.dy; } }
+            L.quo[k][lane] = e.dy ? cell_of(qp, rp, e.dy) : e.x1;
+            L.rem_lo[k][lane] = (e.ytop == s0) ? 1 : 0;   // new in this row: sorts after active edges on ties
+            L.ord[k][lane] = (uint8_t)k;
         }
-        if (overflow) { atomicOr(&counters[CNT_ERROR], 1u); n = 0; }
-        const unsigned mask = P.fill_rule ? 1u : ~0u;
-        bool full = false;
-        if (n > 0 && !mid_row) {
-            // ---- candidate FULL row: order by cell at the row start, check the order after a full step
-            for (int k = 0; k < n; ++k) {
-                const DevEdge e = edges[L.eid[k][lane]];
-                int32_t q; int64_t rm;
-                edge_x_at(e, s0, q, rm);
-                L.cell[k][lane] = e.dy ? cell_of(q, rm, e.dy) : e.x1;
-                int32_t q2; int64_t r2;
-                edge_x_at(e, s0 + 15, q2, r2);
-                L.aux[k][lane] = e.dy ? cell_of(q2, r2, e.dy) : e.x1;
-                // tie-break key among edges already active: position one sub-row earlier
-                int32_t qp = q; int64_t rp = rm;
-                if (e.dy && e.ytop < s0) { qp -= (int32_t)e.dq; rp -= e.dr; if (rp < 0) { --qp; rp += e.dy; } else if (rp >= e.dy) { ++qp; rp -= e.dy; } }
-                L.quo[k][lane] = e.dy ? cell_of(qp, rp, e.dy) : e.x1;
-                L.rem_lo[k][lane] = (e.ytop == s0) ? 1 : 0;   // new at this row: sorts after existing edges on ties
-                L.ord[k][lane] = (uint8_t)k;
+        for (int i = 1; i < n; ++i) {          // stable insertion sort on (cell, is_new, previous cell)
+            const uint8_t ki = L.ord[i][lane];
+            const int ci = L.cell[ki][lane], ni = L.rem_lo[ki][lane], pi = L.quo[ki][lane];
+            int j = i - 1;
+            while (j >= 0) {
+                const uint8_t kj = L.ord[j][lane];
+                const int cj = L.cell[kj][lane], nj = L.rem_lo[kj][lane], pj = L.quo[kj][lane];
+                const bool greater = cj > ci || (cj == ci && (nj > ni || (nj == ni && ni == 0 && pj > pi)));
+                if (!greater) break;
+                L.ord[j + 1][lane] = kj; --j;
             }
-            for (int i = 1; i < n; ++i) {          // stable insertion sort on (cell, is_new, previous cell)
+            L.ord[j + 1][lane] = ki;
+        }
+        full = true;
+        int prev = INT32_MIN;
+        for (int i = 0; i < n; ++i) { const int c = L.aux[L.ord[i][lane]][lane]; if (c < prev) { full = false; break; } prev = c; }
+    }
+    if (full) {
+        res.mode = ROW_FULL;
+        for (int k = 0; k < n; ++k) L.aux[k][lane] = 0;
+        int i = 0;
+        while (i < n) {
+            const int kl = L.ord[i][lane];
+            int w = E[L.eid[kl][lane]].dir;
+            int j = i + 1;
+            while (j < n) {
+                const int kj = L.ord[j][lane];
+                w += E[L.eid[kj][lane]].dir;
+                const bool last_of_group = (j + 1 == n) || (L.cell[L.ord[j + 1][lane]][lane] != L.cell[kj][lane]);
+                if (((unsigned)w & mask) == 0 && last_of_group) break;
+                ++j;
+            }
+            if (j >= n) break;                 // unbalanced winding: no span
+            const int kr = L.ord[j][lane];
+            L.aux[kl][lane] = (int32_t)(REC_FULL | 1u);    // left edge, sign +1
+            L.aux[kr][lane] = (int32_t)(REC_FULL | 2u);    // right edge, sign -1
+            i = j + 1;
+        }
+        for (int k = 0; k < n; ++k) {          // column range of the analytic contribution
+            if (!L.aux[k][lane]) continue;
+            const DevEdge e = E[L.eid[k][lane]];
+            int32_t q1, q2; int64_t r1, r2;
+            full_row_ends(e, s0, q1, r1, q2, r2);
+            const int a = q1 >> 8, b = q2 >> 8;
+            L.cols[k][lane] = (int32_t)(clamp_col(min(a, b)) | (clamp_col(max(a, b)) << 16));
+        }
+    } else {
+        // ---- SUB row: 15 sample rows, edges sorted by cell, spans between winding transitions
+        res.mode = ROW_SUB;
+        int na = 0;
+        for (int k = 0; k < n; ++k) { L.aux[k][lane] = 0; L.cols[k][lane] = 0x0000ffff; }   // lo = 65535, hi = 0
+        for (int s = 0; s < 15; ++s) {
+            const int ss = s0 + s;
+            for (int k = 0; k < n; ++k) {       // activate edges whose first sub-row is ss
+                const DevEdge& er = E[L.eid[k][lane]];
+                const int first = max(er.ytop, s0);
+                if (first != ss) continue;
+                const DevEdge e = er;
+                int32_t q; int64_t rm;
+                edge_x_at(e, ss, q, rm);
+                L.quo[k][lane] = q; L.rem_lo[k][lane] = (int32_t)(uint32_t)rm; L.rem_hi[k][lane] = (int32_t)(rm >> 32);
+                L.cell[k][lane] = e.dy ? cell_of(q, rm, e.dy) : e.x1;
+                L.ord[na][lane] = (uint8_t)k; ++na;
+            }
+            for (int i = 1; i < na; ++i) {      // stable insertion sort by cell
                 const uint8_t ki = L.ord[i][lane];
-                const int ci = L.cell[ki][lane], ni = L.rem_lo[ki][lane], pi = L.quo[ki][lane];
+                const int ci = L.cell[ki][lane];
                 int j = i - 1;
-                while (j >= 0) {
-                    const uint8_t kj = L.ord[j][lane];
-                    const int cj = L.cell[kj][lane], nj = L.rem_lo[kj][lane], pj = L.quo[kj][lane];
-                    bool greater = cj > ci || (cj == ci && (nj > ni || (nj == ni && ni == 0 && pj > pi)));
-                    if (!greater) break;
-                    L.ord[j + 1][lane] = kj; --j;
-                }
+                while (j >= 0 && L.cell[L.ord[j][lane]][lane] > ci) { L.ord[j + 1][lane] = L.ord[j][lane]; --j; }
                 L.ord[j + 1][lane] = ki;
             }
-            full = true;
-            int prev = INT32_MIN;
-            for (int i = 0; i < n; ++i) { const int c = L.aux[L.ord[i][lane]][lane]; if (c < prev) { full = false; break; } prev = c; }
-        }
-        if (n > 0 && full) {
-            mode = ROW_FULL;
-            for (int k = 0; k < n; ++k) L.aux[k][lane] = 0;
-            int i = 0;
-            while (i < n) {
-                const int kl = L.ord[i][lane];
-                int w = edges[L.eid[kl][lane]].dir;
-                int j = i + 1;
-                while (j < n) {
-                    const int kj = L.ord[j][lane];
-                    w += edges[L.eid[kj][lane]].dir;
-                    const bool last_of_group = (j + 1 == n) || (L.cell[L.ord[j + 1][lane]][lane] != L.cell[kj][lane]);
-                    if (((unsigned)w & mask) == 0 && last_of_group) break;
-                    ++j;
+            // winding walk over groups of equal cell: a group opens a span when the winding enters
+            // "inside" across it, closes one when it leaves
+            int w = 0, i = 0;
+            while (i < na) {
+                const int kf = L.ord[i][lane];
+                const int c = L.cell[kf][lane];
+                const bool in_before = ((unsigned)w & mask) != 0;
+                int j = i;
+                while (j < na && L.cell[L.ord[j][lane]][lane] == c) { w += E[L.eid[L.ord[j][lane]][lane]].dir; ++j; }
+                const bool in_after = ((unsigned)w & mask) != 0;
+                if (in_after != in_before) {
+                    L.aux[kf][lane] |= (in_after ? 1 : 2) << (2 * s);
+                    const uint32_t col = clamp_col(c >> 8), old = (uint32_t)L.cols[kf][lane];
+                    L.cols[kf][lane] = (int32_t)(min(old & 0xffffu, col) | (max(old >> 16, col) << 16));
                 }
-                if (j >= n) break;                 // unbalanced winding: no span
-                L.aux[kl][lane] = REC_FULL | 1;    // left edge, sign +1
-                L.aux[L.ord[j][lane]][lane] = REC_FULL | 2;  // right edge, sign -1
-                i = j + 1;
+                i = j;
             }
-        } else if (n > 0) {
-            // ---- SUB row: 15 sample rows, edges sorted by cell, spans between winding transitions
-            mode = ROW_SUB;
-            int na = 0;
-            for (int k = 0; k < n; ++k) L.aux[k][lane] = 0;
-            for (int s = 0; s < 15; ++s) {
-                const int ss = s0 + s;
-                for (int k = 0; k < n; ++k) {       // activate edges whose first sub-row is ss
-                    const DevEdge e = edges[L.eid[k][lane]];
-                    const int first = max(e.ytop, s0);
-                    if (first != ss) continue;
-                    int32_t q; int64_t rm;
-                    edge_x_at(e, ss, q, rm);
+            // retire edges whose last sub-row was ss, step the others
+            int keep = 0;
+            for (int i2 = 0; i2 < na; ++i2) {
+                const int k = L.ord[i2][lane];
+                const DevEdge& er = E[L.eid[k][lane]];
+                if (er.ybot == ss + 1) continue;
+                if (er.dy) {
+                    const DevEdge e = er;
+                    int32_t q = L.quo[k][lane];
+                    int64_t rm = ((int64_t)L.rem_hi[k][lane] << 32) | (uint32_t)L.rem_lo[k][lane];
+                    step_x(q, rm, e);
                     L.quo[k][lane] = q; L.rem_lo[k][lane] = (int32_t)(uint32_t)rm; L.rem_hi[k][lane] = (int32_t)(rm >> 32);
-                    L.cell[k][lane] = e.dy ? cell_of(q, rm, e.dy) : e.x1;
-                    L.ord[na][lane] = (uint8_t)k; ++na;
+                    L.cell[k][lane] = cell_of(q, rm, e.dy);
                 }
-                for (int i = 1; i < na; ++i) {      // stable insertion sort by cell
-                    const uint8_t ki = L.ord[i][lane];
-                    const int ci = L.cell[ki][lane];
-                    int j = i - 1;
-                    while (j >= 0 && L.cell[L.ord[j][lane]][lane] > ci) { L.ord[j + 1][lane] = L.ord[j][lane]; --j; }
-                    L.ord[j + 1][lane] = ki;
+                L.ord[keep][lane] = (uint8_t)k; ++keep;
+            }
+            na = keep;
+        }
+    }
+    return res;
+}
+
+#define ROWS_FAST_N 8            // active edges per row handled in registers by k_rows
+#define ROWS_BIG_MAXA 64         // capacity of the generic (LDS list) routine in k_rows_big
+#define ROWS_STAGE 64            // paths with at most this many edges are staged into LDS
+
+struct FastLds {
+    uint16_t eid[ROWS_FAST_N][64];      // per row (lane): local indices of its active edges
+    int32_t roles[ROWS_FAST_N][64];     // SUB rows: role bits, OR-ed in by the 15 sub-row lanes
+    int32_t clo[ROWS_FAST_N][64], chi[ROWS_FAST_N][64];
+};
+
+// Register-resident row routine for rows with at most ROWS_FAST_N active edges.
+//   phase A (lane = row): gather the active edges, FULL/SUB decision by pairwise order tests, FULL roles from
+//                         winding prefix sums (no sort: every test is a sum over "edge i sorts before edge j")
+//   phase B (lane = (SUB row, sub-row)): four SUB rows x 15 sample rows per pass; closed-form x per sample,
+//                         open/close role per group of equal cells, OR-ed into the row's role words in LDS
+template <class EPTR>
+__device__ __forceinline__ void fast_rows(EPTR E, const DevPath& P, int r, bool live, int fast_limit, FastLds& F, int lane,
+                                          uint32_t& mode_out, int& n_out_edges, bool& overflow_out,
+                                          int32_t (&roles)[ROWS_FAST_N], int32_t (&cols)[ROWS_FAST_N], int (&el)[ROWS_FAST_N]) {
+    const int s0 = r * 15;
+    const unsigned mask = P.fill_rule ? 1u : ~0u;
+    int n = 0;
+    bool mid_row = false, overflow = false;
+    int cs[ROWS_FAST_N], ce[ROWS_FAST_N], cp[ROWS_FAST_N], dr[ROWS_FAST_N], nw[ROWS_FAST_N];
+#pragma unroll
+    for (int s = 0; s < ROWS_FAST_N; ++s) { cs[s] = ce[s] = cp[s] = dr[s] = nw[s] = 0; el[s] = 0; roles[s] = 0; cols[s] = 0; }
+    if (live) {
+        for (uint32_t k = 0; k < P.n_edges; ++k) {
+            const int ytop = E[k].ytop, ybot = E[k].ybot;
+            if (ybot <= s0 || ytop >= s0 + 15) continue;
+            if (n >= fast_limit) { overflow = true; break; }
+            mid_row |= (ytop > s0) | (ybot < s0 + 15);
+            const DevEdge e = E[k];
+            int32_t q; int64_t rm;
+            int c0 = e.x1, c1 = e.x1, cpv = e.x1;
+            if (e.dy && !mid_row) {                       // keys are only needed while the row can still be FULL
+                edge_x_at(e, s0, q, rm);
+                c0 = cell_of(q, rm, e.dy);
+                int32_t q2; int64_t r2;
+                edge_x_at(e, s0 + 15, q2, r2);
+                c1 = cell_of(q2, r2, e.dy);
+                cpv = c0;
+                if (e.ytop < s0) { q -= (int32_t)e.dq; rm -= e.dr; if (rm < 0) { --q; rm += e.dy; } else if (rm >= e.dy) { ++q; rm -= e.dy; } cpv = cell_of(q, rm, e.dy); }
+            }
+#pragma unroll
+            for (int s = 0; s < ROWS_FAST_N; ++s) if (s == n) { el[s] = (int)k; cs[s] = c0; ce[s] = c1; cp[s] = cpv; dr[s] = e.dir; nw[s] = (e.ytop == s0) ? 1 : 0; }
+            ++n;
+        }
+    }
+    if (overflow) n = 0;
+    uint32_t mode = ROW_EMPTY;
+    bool is_sub = false;
+    if (n > 0) {
+        bool full = !mid_row;
+        int wb[ROWS_FAST_N];
+        unsigned firstg = 0, lastg = 0;
+        if (full) {
+#pragma unroll
+            for (int j = 0; j < ROWS_FAST_N; ++j) {
+                int w = 0; bool fg = true, lg = true;
+#pragma unroll
+                for (int i = 0; i < ROWS_FAST_N; ++i) {
+                    if (i == j) continue;
+                    const bool valid = i < n && j < n;
+                    // does edge i sort before edge j?  (cell, active-before-new, previous cell, path order)
+                    const bool tie = cs[i] == cs[j];
+                    const bool tie2 = nw[i] == nw[j];
+                    const bool t3 = nw[i] == 0 ? (cp[i] < cp[j] || (cp[i] == cp[j] && i < j)) : (i < j);
+                    const bool before = cs[i] < cs[j] || (tie && (nw[i] < nw[j] || (tie2 && t3)));
+                    if (valid && before) { w += dr[i]; if (ce[i] > ce[j]) full = false; if (tie) fg = false; }
+                    if (valid && !before && tie) lg = false;
                 }
-                // winding walk over groups of equal cell: a group opens a span when the winding enters
-                // "inside" across it, closes one when it leaves
-                int w = 0, i = 0;
-                while (i < na) {
-                    const int kf = L.ord[i][lane];
-                    const int c = L.cell[kf][lane];
-                    const bool in_before = ((unsigned)w & mask) != 0;
-                    int j = i;
-                    while (j < na && L.cell[L.ord[j][lane]][lane] == c) { w += edges[L.eid[L.ord[j][lane]][lane]].dir; ++j; }
-                    const bool in_after = ((unsigned)w & mask) != 0;
-                    if (in_after != in_before) L.aux[kf][lane] |= (in_after ? 1 : 2) << (2 * s);
-                    i = j;
-                }
-                // retire edges whose last sub-row was ss, step the others
-                int keep = 0;
-                for (int i2 = 0; i2 < na; ++i2) {
-                    const int k = L.ord[i2][lane];
-                    const DevEdge e = edges[L.eid[k][lane]];
-                    if (e.ybot == ss + 1) continue;
-                    if (e.dy) {
-                        int32_t q = L.quo[k][lane];
-                        int64_t rm = ((int64_t)L.rem_hi[k][lane] << 32) | (uint32_t)L.rem_lo[k][lane];
-                        step_x(q, rm, e);
-                        L.quo[k][lane] = q; L.rem_lo[k][lane] = (int32_t)(uint32_t)rm; L.rem_hi[k][lane] = (int32_t)(rm >> 32);
-                        L.cell[k][lane] = cell_of(q, rm, e.dy);
-                    }
-                    L.ord[keep][lane] = (uint8_t)k; ++keep;
-                }
-                na = keep;
+                wb[j] = w;
+                if (fg) firstg |= 1u << j;
+                if (lg) lastg |= 1u << j;
             }
         }
-        for (int k = 0; k < n; ++k) n_out += L.aux[k][lane] != 0;
+        if (full) {
+            mode = ROW_FULL;
+#pragma unroll
+            for (int j = 0; j < ROWS_FAST_N; ++j) {
+                if (j >= n) continue;
+                const bool in_b = ((unsigned)wb[j] & mask) != 0, in_a = ((unsigned)(wb[j] + dr[j]) & mask) != 0;
+                uint32_t role = 0;
+                if (!in_b && ((firstg >> j) & 1u)) role = REC_FULL | 1u;          // left edge of a span
+                else if (!in_a && ((lastg >> j) & 1u)) role = REC_FULL | 2u;      // right edge
+                if (role) {
+                    const DevEdge e = E[el[j]];
+                    int32_t q1, q2; int64_t r1, r2;
+                    full_row_ends(e, s0, q1, r1, q2, r2);
+                    const int a = q1 >> 8, b = q2 >> 8;
+                    cols[j] = (int32_t)(clamp_col(min(a, b)) | (clamp_col(max(a, b)) << 16));
+                }
+                roles[j] = (int32_t)role;
+            }
+        } else {
+            mode = ROW_SUB;
+            is_sub = true;
+#pragma unroll
+            for (int s = 0; s < ROWS_FAST_N; ++s) { F.eid[s][lane] = (uint16_t)el[s]; F.roles[s][lane] = 0; F.clo[s][lane] = 65535; F.chi[s][lane] = 0; }
+        }
+    }
+    // ---- phase B: the wave's SUB rows, 4 rows x 15 sub-rows per pass
+    unsigned long long pending = __ballot(is_sub);
+    const int g = lane / 15, sub = lane - g * 15;
+    const int n_all = n;
+    while (pending) {
+        // the g-th pending row of this pass
+        unsigned long long m = pending;
+        int R = -1;
+        for (int t = 0; t <= g && t < 4; ++t) { if (!m) { R = -1; break; } R = __ffsll((long long)m) - 1; m &= m - 1; }
+        if (g >= 4) R = -1;
+        // consume up to four rows
+        for (int t = 0; t < 4 && pending; ++t) pending &= pending - 1;
+        // cross-lane reads must run with every lane active: ds_bpermute returns 0 for a disabled source lane
+        const int Rsrc = R >= 0 ? R : 0;
+        const int nR = __shfl(n_all, Rsrc);
+        const int rR = __shfl(r, Rsrc);
+        if (R >= 0) {
+            const int ss = rR * 15 + sub;
+            int cc[ROWS_FAST_N], dd[ROWS_FAST_N];
+            unsigned act = 0;
+#pragma unroll
+            for (int s = 0; s < ROWS_FAST_N; ++s) {
+                cc[s] = 0; dd[s] = 0;
+                if (s < nR) {
+                    const DevEdge e = E[F.eid[s][R]];
+                    if (e.ytop <= ss && ss < e.ybot) {
+                        act |= 1u << s;
+                        dd[s] = e.dir;
+                        if (e.dy) { int32_t q; int64_t rm; edge_x_at(e, ss, q, rm); cc[s] = cell_of(q, rm, e.dy); } else cc[s] = e.x1;
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < ROWS_FAST_N; ++j) {
+                if (!((act >> j) & 1u)) continue;
+                int wbj = 0, gsum = dd[j]; bool rep = true;
+#pragma unroll
+                for (int i = 0; i < ROWS_FAST_N; ++i) {
+                    if (i == j || !((act >> i) & 1u)) continue;
+                    if (cc[i] < cc[j]) wbj += dd[i];
+                    else if (cc[i] == cc[j]) { gsum += dd[i]; if (i < j) rep = false; }
+                }
+                if (!rep) continue;                      // one edge per group of equal cells carries the role
+                const bool in_b = ((unsigned)wbj & mask) != 0, in_a = ((unsigned)(wbj + gsum) & mask) != 0;
+                if (in_a != in_b) {
+                    atomicOr(&F.roles[j][R], (in_a ? 1 : 2) << (2 * sub));
+                    const int col = (int)clamp_col(cc[j] >> 8);
+                    atomicMin(&F.clo[j][R], col);
+                    atomicMax(&F.chi[j][R], col);
+                }
+            }
+        }
+    }
+    if (is_sub) {
+#pragma unroll
+        for (int s = 0; s < ROWS_FAST_N; ++s) { roles[s] = F.roles[s][lane]; cols[s] = (int32_t)((uint32_t)F.clo[s][lane] | ((uint32_t)F.chi[s][lane] << 16)); }
+    }
+    mode_out = mode; n_out_edges = n; overflow_out = overflow;
+}
+
+__global__ __launch_bounds__(64) void k_rows(const DevEdge* __restrict__ edges, const DevPath* __restrict__ paths,
+                                             const uint32_t* __restrict__ row_base, const uint32_t* __restrict__ chunk_base,
+                                             uint32_t n_paths, RowInfo* __restrict__ rows, Rec* __restrict__ records,
+                                             uint32_t* __restrict__ counters, uint32_t* __restrict__ overflow_list,
+                                             uint32_t band_index, uint32_t band_count, int fast_limit) {
+    __shared__ FastLds F;
+    __shared__ DevEdge staged[ROWS_STAGE];
+    const int lane = threadIdx.x;
+    // workgroup -> (path, chunk of 64 rows): wave-uniform, so path and edge reads are scalar
+    uint32_t lo = 0, hi = n_paths;
+    const uint32_t chunk = blockIdx.x;
+    while (lo + 1 < hi) { const uint32_t mid = (lo + hi) >> 1; if (chunk_base[mid] <= chunk) lo = mid; else hi = mid; }
+    const DevPath P = paths[lo];
+    const int r = P.y_min + (int)(chunk - chunk_base[lo]) * ROWS_CHUNK + lane;
+    const bool in_path = P.kind == SWFR_PATH_TOR && r < P.y_max;
+    bool live = in_path;
+    if (live && band_count > 1 && (uint32_t)((r / TILE_H) % band_count) != band_index) live = false;
+    const uint32_t t = row_base[lo] + (uint32_t)(r - P.y_min);          // row task index (valid when in_path)
+    if (P.n_edges > 65535u) fast_limit = 0;                             // 16-bit local edge indices in the fast path
+    const bool use_lds = P.n_edges <= ROWS_STAGE;
+    if (use_lds) {
+        if ((uint32_t)lane < P.n_edges) staged[lane] = edges[P.first_edge + lane];
+        __syncthreads();
+    }
+    uint32_t mode; int n; bool overflow;
+    int32_t roles[ROWS_FAST_N], cols[ROWS_FAST_N]; int el[ROWS_FAST_N];
+    if (use_lds) fast_rows((const DevEdge*)staged, P, r, live, fast_limit, F, lane, mode, n, overflow, roles, cols, el);
+    else fast_rows(edges + P.first_edge, P, r, live, fast_limit, F, lane, mode, n, overflow, roles, cols, el);
+    uint32_t n_out = 0;
+#pragma unroll
+    for (int s = 0; s < ROWS_FAST_N; ++s) n_out += (s < n && roles[s] != 0) ? 1u : 0u;
+    if (overflow) {                                                     // handled by k_rows_big
+        const uint32_t slot = atomicAdd(&counters[CNT_OVERFLOW], 1u);
+        overflow_list[slot] = t;
     }
     // ---- wave-level allocation of record slots: one atomic per wave
-    uint32_t incl = n_out;
-    for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+    const uint32_t incl = (uint32_t)wave_scan_incl((int)n_out);
     const uint32_t total = __shfl(incl, 63);
     uint32_t base = 0;
     if (lane == 0 && total) base = atomicAdd(&counters[CNT_RECORDS], total);
     base = __shfl(base, 0);
-    if (t < n_tasks) {
+    if (in_path && !overflow) {
         uint32_t off = base + incl - n_out;
         RowInfo ri; ri.rec_off = off; ri.n_rec = (uint16_t)n_out; ri.mode = (uint16_t)mode;
         rows[t] = ri;
-        for (int k = 0; k < n; ++k) {
-            const int32_t roles = L.aux[k][lane];
-            if (roles) records[off++] = make_uint2((uint32_t)L.eid[k][lane], (uint32_t)roles);
+#pragma unroll
+        for (int s = 0; s < ROWS_FAST_N; ++s) {
+            if (s < n && roles[s] != 0) { Rec rc; rc.eid = P.first_edge + (uint32_t)el[s]; rc.roles = (uint32_t)roles[s]; rc.cols = (uint32_t)cols[s]; records[off++] = rc; }
         }
+    }
+}
+
+// Rows with more than ROWS_MAXA active edges: one lane per overflowed row, 4x the capacity.
+__global__ __launch_bounds__(64) void k_rows_big(const DevEdge* __restrict__ edges, const DevPath* __restrict__ paths,
+                                                 const uint32_t* __restrict__ row_base, uint32_t n_paths,
+                                                 RowInfo* __restrict__ rows, Rec* __restrict__ records,
+                                                 uint32_t* __restrict__ counters, const uint32_t* __restrict__ overflow_list) {
+    __shared__ RowLds<ROWS_BIG_MAXA> L;
+    const int lane = threadIdx.x;
+    const uint32_t count = counters[CNT_OVERFLOW];
+    for (uint32_t i = blockIdx.x * 64 + lane; i < count; i += gridDim.x * 64) {
+        const uint32_t t = overflow_list[i];
+        uint32_t lo = 0, hi = n_paths;
+        while (lo + 1 < hi) { const uint32_t mid = (lo + hi) >> 1; if (row_base[mid] <= t) lo = mid; else hi = mid; }
+        const DevPath P = paths[lo];
+        const int r = P.y_min + (int)(t - row_base[lo]);
+        const RowResult res = process_row<ROWS_BIG_MAXA>(edges + P.first_edge, P, r, L, lane);
+        RowInfo ri; ri.rec_off = 0; ri.n_rec = 0; ri.mode = ROW_EMPTY;
+        if (res.overflow) {
+            atomicOr(&counters[CNT_ERROR], 1u);
+        } else {
+            uint32_t n_out = 0;
+            for (int k = 0; k < res.n; ++k) n_out += L.aux[k][lane] != 0;
+            uint32_t off = n_out ? atomicAdd(&counters[CNT_RECORDS], n_out) : 0u;
+            ri.rec_off = off; ri.n_rec = (uint16_t)n_out; ri.mode = (uint16_t)res.mode;
+            for (int k = 0; k < res.n; ++k) {
+                const int32_t roles = L.aux[k][lane];
+                if (roles) { Rec rc; rc.eid = P.first_edge + (uint32_t)L.eid[k][lane]; rc.roles = (uint32_t)roles; rc.cols = (uint32_t)L.cols[k][lane]; records[off++] = rc; }
+            }
+        }
+        rows[t] = ri;
     }
 }
 
@@ -318,7 +604,7 @@ __device__ uint32_t gradient_color(const swfr_style& s, double t) {
 
 // premultiplied ARGB source colour at pixel centre (px+0.5, py+0.5): float64 model of pixman's
 // general path (gradients within +-1 LSB of Cairo)
-__device__ uint32_t shade(const swfr_style& s, const DevBitmap* __restrict__ bitmaps, int px, int py) {
+__device__ __noinline__ uint32_t shade(const swfr_style& s, const DevBitmap* __restrict__ bitmaps, int px, int py) {
     double x = px + 0.5, y = py + 0.5;
     const double ux = s.inv[0] * x + s.inv[2] * y + s.inv[4];
     const double uy = s.inv[1] * x + s.inv[3] * y + s.inv[5];
@@ -378,11 +664,23 @@ __device__ uint32_t shade(const swfr_style& s, const DevBitmap* __restrict__ bit
 #define ACC_STRIDE 66                 // 64 cells + carry slot + touched flag
 #define ACC_CARRY 64
 #define ACC_TOUCH 65
-#define LIST_CAP 1024
+#define LIST_CAP 512
+
+// classification of a (tile, path) pair
+#define CLS_PARTIAL 1u                // some row needs the general accumulate + scan path
+#define CLS_NOTFULL 2u                // some in-frame row of the tile is not uniformly alpha 255
+#define CLS_NONEMPTY 4u               // some row has coverage
+#define CLS_BOX 8u                    // rectilinear path evaluated per pixel from its boxes
 
 struct TileCtx {
-    int tx0, ty0, xminp, xmaxp;
+    int tx0, xminp, xmaxp;
 };
+
+// net covered height a record adds to everything right of it
+__device__ __forceinline__ int record_height(uint32_t roles) {
+    if (roles & REC_FULL) return (roles & 1u) ? 15 : -15;
+    return __popc(roles & 0x15555555u) - __popc(roles & 0x2aaaaaaau);
+}
 
 // accumulate one cell contribution (covered height dch, uncovered area dua) of row `acc`
 __device__ __forceinline__ void cell_add(int* acc, const TileCtx& c, int i, int dch, int dua) {
@@ -396,13 +694,7 @@ __device__ __forceinline__ void cell_add(int* acc, const TileCtx& c, int i, int 
 // FULL-row edge (A.5 render_edge): analytic trapezoid coverage of one edge over one pixel row
 __device__ void full_edge(const DevEdge& e, int s0, int sign, int* acc, const TileCtx& c) {
     int32_t q1, q2; int64_t r1, r2;
-    edge_x_at(e, s0, q1, r1);
-    edge_x_at(e, s0 + 15, q2, r2);
-    if (e.dy) {                                           // back from the sub-row centre to the row top
-        const int32_t hq = (int32_t)(e.dq / 2); const int64_t hr = e.dr / 2;
-        q1 -= hq; r1 -= hr; if (r1 < 0) { --q1; r1 += e.dy; } else if (r1 >= e.dy) { ++q1; r1 -= e.dy; }
-        q2 -= hq; r2 -= hr; if (r2 < 0) { --q2; r2 += e.dy; } else if (r2 >= e.dy) { ++q2; r2 -= e.dy; }
-    }
+    full_row_ends(e, s0, q1, r1, q2, r2);
     int ix1 = q1 >> 8, f1 = q1 & 255, ix2 = q2 >> 8, f2 = q2 & 255;
     if (ix1 == ix2) { cell_add(acc, c, ix1, sign * 15, sign * (f1 + f2) * 15); return; }
     if (ix2 < ix1) { int t = ix1; ix1 = ix2; ix2 = t; t = f1; f1 = f2; f2 = t; int32_t tq = q1; q1 = q2; q2 = tq; int64_t tr = r1; r1 = r2; r2 = tr; }
@@ -437,63 +729,169 @@ __device__ void full_edge(const DevEdge& e, int s0, int sign, int* acc, const Ti
     }
 }
 
+// phase 1 of a partial tor path: every (row, record) adds its cells into acc (LDS atomics)
+__device__ __forceinline__ void accumulate_path(const DevPath& P, uint32_t row_base_p, const RowInfo* __restrict__ rows,
+                                                const Rec* __restrict__ records, const DevEdge* __restrict__ edges,
+                                                int (*acc)[ACC_STRIDE], int tx0, int ty0, int tid) {
+    const int row = tid >> 4, slot = tid & 15;
+    const int y = ty0 + row;
+    if (y < P.y_min || y >= P.y_max) return;
+    const RowInfo ri = rows[row_base_p + (uint32_t)(y - P.y_min)];
+    if (!ri.n_rec) return;
+    TileCtx c; c.tx0 = tx0; c.xminp = P.x_min; c.xmaxp = P.x_max;
+    const int s0 = y * 15;
+    if (slot == 0) acc[row][ACC_TOUCH] = 1;
+    for (uint32_t k = slot; k < ri.n_rec; k += 16) {
+        const Rec rec = records[ri.rec_off + k];
+        const int clo = (int)(rec.cols & 0xffffu), chi = (int)(rec.cols >> 16);
+        if (clo >= tx0 + TILE_W && clo < 65535) continue;           // entirely right of the tile
+        if (chi < tx0 && chi < 65535) {                             // entirely left: only its net height reaches us
+            cell_add(acc[row], c, chi, record_height(rec.roles), 0);
+            continue;
+        }
+        const DevEdge e = edges[rec.eid];
+        if (rec.roles & REC_FULL) {
+            full_edge(e, s0, (rec.roles & 1u) ? +1 : -1, acc[row], c);
+        } else {
+            const int first = max(e.ytop, s0), last = min(e.ybot, s0 + 15);
+            int32_t q; int64_t rm;
+            edge_x_at(e, first, q, rm);
+            for (int ss = first; ss < last; ++ss) {
+                const uint32_t role = (rec.roles >> (2 * (ss - s0))) & 3u;
+                if (role) {
+                    const int cell = e.dy ? cell_of(q, rm, e.dy) : e.x1;
+                    const int sgn = role == 1 ? 1 : -1;
+                    cell_add(acc[row], c, cell >> 8, sgn, sgn * 2 * (cell & 255));
+                }
+                if (e.dy) step_x(q, rm, e);
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_tiles(const swfr_edge* __restrict__ raw_edges, const DevEdge* __restrict__ edges,
-                                               const DevPath* __restrict__ paths, uint32_t n_paths,
+                                               const DevPath* __restrict__ paths, const uint32_t* __restrict__ band_off,
+                                               const uint32_t* __restrict__ band_list,
                                                const uint32_t* __restrict__ row_base, const RowInfo* __restrict__ rows,
-                                               const uint2* __restrict__ records, const swfr_style* __restrict__ styles,
+                                               const Rec* __restrict__ records, const swfr_style* __restrict__ styles,
                                                const DevBitmap* __restrict__ bitmaps, uint32_t* __restrict__ fb,
-                                               int width, int height, int tiles_x, uint32_t band_index, uint32_t band_count,
-                                               uint32_t n_tile_rows_local) {
-    __shared__ int acc[TILE_H][ACC_STRIDE];
+                                               int width, int height, int tiles_x, uint32_t band_index, uint32_t band_count) {
+    __shared__ int acc[2][TILE_H][ACC_STRIDE];
     __shared__ uint32_t list[LIST_CAP];
+    __shared__ uint32_t cls[LIST_CAP];
     __shared__ uint32_t wave_cnt[4];
     __shared__ uint32_t list_n;
+    __shared__ int cover_from;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // blockIdx -> tile: consecutive blocks walk along x inside one tile-row (neighbouring tiles share
-    // paths, so they hit the same L2 when co-scheduled round-robin over XCDs in groups of 8)
+    // blockIdx -> tile: consecutive workgroups walk along x inside one tile-row, so the 8 tiles that are
+    // co-scheduled round-robin over the 8 XCDs read the same band list / path records
     const int tile = blockIdx.x;
     const int tcol = tile % tiles_x;
     int trow = tile / tiles_x;
-    if (band_count > 1) trow = trow * band_count + band_index;
+    if (band_count > 1) trow = trow * (int)band_count + (int)band_index;
     const int tx0 = tcol * TILE_W, ty0 = trow * TILE_H;
     if (ty0 >= height) return;
+    const int tile_x1 = min(tx0 + TILE_W, width), tile_y1 = min(ty0 + TILE_H, height);
 
     uint32_t px[4] = {0u, 0u, 0u, 0u};                    // rows 4*wave .. 4*wave+3, column tx0+lane (premultiplied ARGB)
-    for (int i = tid; i < TILE_H * ACC_STRIDE; i += 256) (&acc[0][0])[i] = 0;
-    __syncthreads();
+    for (int i = tid; i < 2 * TILE_H * ACC_STRIDE; i += 256) (&acc[0][0][0])[i] = 0;
 
-    for (uint32_t chunk = 0; chunk < n_paths; chunk += LIST_CAP) {
-        // ---- bin: paths of this chunk whose pixel rectangle overlaps the tile, in painter's order
-        if (tid == 0) list_n = 0;
+    const uint32_t band_begin = band_off[trow], band_end = band_off[trow + 1];
+    for (uint32_t chunk = band_begin; chunk < band_end; chunk += LIST_CAP) {
+        // ---- bin: paths of the band whose pixel rectangle overlaps the tile, in painter's order
+        if (tid == 0) { list_n = 0; cover_from = 0; }
         __syncthreads();
-        const uint32_t chunk_end = min(chunk + LIST_CAP, n_paths);
+        const uint32_t chunk_end = min(chunk + LIST_CAP, band_end);
         for (uint32_t base = chunk; base < chunk_end; base += 256) {
-            const uint32_t p = base + tid;
+            const uint32_t bi = base + tid;
             bool hit = false;
-            if (p < chunk_end) {
+            uint32_t p = 0;
+            if (bi < chunk_end) {
+                p = band_list[bi];
                 const DevPath P = paths[p];
-                hit = P.x_min < tx0 + TILE_W && P.x_max > tx0 && P.y_min < ty0 + TILE_H && P.y_max > ty0;
+                hit = P.x_min < tile_x1 && P.x_max > tx0 && P.y_min < tile_y1 && P.y_max > ty0;
             }
             const unsigned long long b = __ballot(hit);
             if (lane == 0) wave_cnt[wave] = __popcll(b);
             __syncthreads();
             uint32_t off = list_n;
             for (int w = 0; w < wave; ++w) off += wave_cnt[w];
-            if (hit) list[off + __popcll(b & ((1ull << lane) - 1ull))] = p;
+            if (hit) { const uint32_t at = off + __popcll(b & ((1ull << lane) - 1ull)); list[at] = p; cls[at] = 0; }
             __syncthreads();
             if (tid == 0) list_n += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
             __syncthreads();
         }
-        const uint32_t ln = list_n;
+        const int ln = (int)list_n;
 
-        for (uint32_t li = 0; li < ln; ++li) {
+        // ---- classify every (tile, path): 16 paths x 16 rows per pass; no edge arithmetic, records only
+        for (int base = 0; base < ln; base += 16) {
+            const int li = base + (tid >> 4), row = tid & 15;
+            const int y = ty0 + row;
+            if (li < ln && y < height) {
+                const uint32_t pi = list[li];
+                const DevPath P = paths[pi];
+                uint32_t f = 0;
+                if (P.kind == SWFR_PATH_BOXES) {
+                    f = CLS_BOX | CLS_NONEMPTY | CLS_NOTFULL;
+                    if (P.n_edges == 1) {                 // one box that contains the whole tile: full cover
+                        const swfr_edge bx = raw_edges[P.first_edge];
+                        if (bx.x1 <= tx0 * 256 && bx.x2 >= tile_x1 * 256 && bx.y1 <= ty0 * 256 && bx.y2 >= tile_y1 * 256) f = CLS_NONEMPTY;
+                    }
+                } else if (y < P.y_min || y >= P.y_max) {
+                    f = CLS_NOTFULL;
+                } else {
+                    const RowInfo ri = rows[row_base[pi] + (uint32_t)(y - P.y_min)];
+                    int carry = 0;
+                    bool inter = false;
+                    for (uint32_t k = 0; k < ri.n_rec; ++k) {
+                        const Rec rec = records[ri.rec_off + k];
+                        const int clo = (int)(rec.cols & 0xffffu), chi = (int)(rec.cols >> 16);
+                        if (chi < tx0 && chi < 65535) carry += record_height(rec.roles);
+                        else if (clo >= tx0 + TILE_W && clo < 65535) { /* right of the tile */ }
+                        else inter = true;
+                    }
+                    const bool inside_x = P.x_min <= tx0 && P.x_max >= tile_x1;
+                    const uint32_t a = (uint32_t)((carry * 512 * 17 + 256) >> 9) & 255u;
+                    if (inter) f = CLS_PARTIAL | CLS_NOTFULL | CLS_NONEMPTY;
+                    else if (a == 0) f = CLS_NOTFULL;
+                    else if (a == 255 && inside_x) f = CLS_NONEMPTY;
+                    else f = CLS_PARTIAL | CLS_NOTFULL | CLS_NONEMPTY;   // uniform partial alpha or column masking
+                }
+                if (f) atomicOr(&cls[li], f);
+            }
+        }
+        __syncthreads();
+        // ---- occlusion: everything below the last opaque, lerp-blended full cover is invisible in this tile
+        for (int li = tid; li < ln; li += 256) {
+            const uint32_t f = cls[li];
+            if ((f & (CLS_PARTIAL | CLS_NOTFULL | CLS_BOX)) == 0 && (f & CLS_NONEMPTY)) {
+                const DevPath P = paths[list[li]];
+                const swfr_style& S = styles[P.style];
+                if (P.lerp && S.kind == SWFR_STYLE_SOLID && (S.pixel >> 24) == 0xffu) atomicMax(&cover_from, li);
+            }
+        }
+        __syncthreads();
+        const int start = cover_from;
+
+        // ---- painter's order walk; tor-partial paths are software pipelined over two accumulator buffers
+        int buf = 0;
+        int nxt = -1;                                          // next partial tor path at or after `start`
+        for (int li = start; li < ln; ++li) if ((cls[li] & (CLS_PARTIAL | CLS_BOX)) == CLS_PARTIAL) { nxt = li; break; }
+        if (nxt >= 0) {
+            const uint32_t pi = list[nxt];
+            accumulate_path(paths[pi], row_base[pi], rows, records, edges, acc[buf], tx0, ty0, tid);
+        }
+        __syncthreads();
+        for (int li = start; li < ln; ++li) {
+            const uint32_t f = cls[li];
+            if (!(f & CLS_NONEMPTY)) continue;
             const uint32_t pi = list[li];
             const DevPath P = paths[pi];
-            uint32_t alpha[4] = {0u, 0u, 0u, 0u};
             const int row_lo = max(P.y_min, ty0), row_hi = min(P.y_max, ty0 + TILE_H);
-
-            if (P.kind == SWFR_PATH_BOXES) {
+            uint32_t alpha[4] = {0u, 0u, 0u, 0u};
+            const bool is_partial_tor = (f & (CLS_PARTIAL | CLS_BOX)) == CLS_PARTIAL;
+            if (f & CLS_BOX) {
                 // ---- rectilinear (A.6): exact area of disjoint boxes, alpha = (c>>8) - (c>>16)
                 uint32_t cov[4] = {0u, 0u, 0u, 0u};
                 const int cx = tx0 + lane;
@@ -510,62 +908,37 @@ __global__ __launch_bounds__(256) void k_tiles(const swfr_edge* __restrict__ raw
                 }
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) alpha[rr] = ((cov[rr] >> 8) - (cov[rr] >> 16)) & 255u;
-            } else {
-                // ---- tor (A.5): per-row records -> covered height / uncovered area per cell
-                TileCtx c; c.tx0 = tx0; c.ty0 = ty0; c.xminp = P.x_min; c.xmaxp = P.x_max;
-                const int row = tid >> 4, slot = tid & 15;
-                const int y = ty0 + row;
-                if (y >= row_lo && y < row_hi) {
-                    const RowInfo ri = rows[row_base[pi] + (uint32_t)(y - P.y_min)];
-                    const int s0 = y * 15;
-                    if (slot == 0 && ri.n_rec) acc[row][ACC_TOUCH] = 1;
-                    for (uint32_t k = slot; k < ri.n_rec; k += 16) {
-                        const uint2 rec = records[ri.rec_off + k];
-                        const DevEdge e = edges[rec.x];
-                        if (rec.y & REC_FULL) {
-                            full_edge(e, s0, (rec.y & 1) ? +1 : -1, acc[row], c);
-                        } else {
-                            const int first = max(e.ytop, s0), last = min(e.ybot, s0 + 15);
-                            int32_t q; int64_t rm;
-                            edge_x_at(e, first, q, rm);
-                            for (int ss = first; ss < last; ++ss) {
-                                const uint32_t role = (rec.y >> (2 * (ss - s0))) & 3u;
-                                if (role) {
-                                    const int cell = e.dy ? cell_of(q, rm, e.dy) : e.x1;
-                                    const int sgn = role == 1 ? 1 : -1;
-                                    cell_add(acc[row], c, cell >> 8, sgn, sgn * 2 * (cell & 255));
-                                }
-                                if (e.dy) step_x(q, rm, e);
-                            }
-                        }
-                    }
+            } else if (is_partial_tor) {
+                // phase 1 of the NEXT partial path goes into the other buffer while this one is consumed
+                nxt = -1;
+                for (int lj = li + 1; lj < ln; ++lj) if ((cls[lj] & (CLS_PARTIAL | CLS_BOX)) == CLS_PARTIAL) { nxt = lj; break; }
+                if (nxt >= 0) {
+                    const uint32_t pn = list[nxt];
+                    accumulate_path(paths[pn], row_base[pn], rows, records, edges, acc[buf ^ 1], tx0, ty0, tid);
                 }
-                __syncthreads();
+                // phase 2: per row, wave64 prefix sum of covered height, coverage -> alpha; clears as it reads
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) {
                     const int rw = wave * 4 + rr;
-                    if (!acc[rw][ACC_TOUCH]) continue;            // wave-uniform
-                    const int v = acc[rw][lane];
-                    const int carry = acc[rw][ACC_CARRY];
-                    const int ua = (v << 12) >> 12;               // low 20 bits, sign-extended
+                    if (!acc[buf][rw][ACC_TOUCH]) continue;            // wave-uniform
+                    const int v = acc[buf][rw][lane];
+                    const int carry = acc[buf][rw][ACC_CARRY];
+                    acc[buf][rw][lane] = 0;
+                    if (lane < 2) acc[buf][rw][ACC_CARRY + lane] = 0;
+                    const int ua = (v << 12) >> 12;                    // low 20 bits, sign-extended
                     int ch = (v - ua) >> 20;
                     if (lane == 0) ch += carry;
-                    int scan = ch;                                 // wave64 inclusive prefix sum along x
-#pragma unroll
-                    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(scan, d); if (lane >= d) scan += o; }
+                    const int scan = wave_scan_incl(ch);
                     const int area = scan * 512 - ua;
                     uint32_t a = (uint32_t)((area * 17 + 256) >> 9) & 255u;
                     const int cx = tx0 + lane;
                     if (cx < P.x_min || cx >= P.x_max) a = 0;
                     alpha[rr] = a;
                 }
-                __syncthreads();
-                // clear the accumulators this path used
-                if (y >= row_lo && y < row_hi) {
+            } else {
+                // full cover: every in-frame pixel of the tile has coverage 255
 #pragma unroll
-                    for (int k = slot; k < ACC_STRIDE; k += 16) acc[row][k] = 0;
-                }
-                __syncthreads();
+                for (int rr = 0; rr < 4; ++rr) alpha[rr] = 255u;
             }
 
             // ---- shade + blend (A.7) into the tile-resident pixels
@@ -590,6 +963,7 @@ __global__ __launch_bounds__(256) void k_tiles(const swfr_edge* __restrict__ raw
                     px[rr] = P.lerp ? s : over_pixel(s, px[rr]);
                 }
             }
+            if (is_partial_tor) { __syncthreads(); buf ^= 1; }
         }
         __syncthreads();
     }
@@ -603,9 +977,7 @@ __global__ __launch_bounds__(256) void k_tiles(const swfr_edge* __restrict__ raw
             if (cy >= height) continue;
             const uint32_t p = px[rr];
             const uint32_t rgba = (p & 0xff00ff00u) | ((p >> 16) & 0xffu) | ((p & 0xffu) << 16);
-            size_t row_index = (size_t)cy;
-            if (band_count > 1) row_index = (size_t)cy;   // full-frame addressing; band slabs are packed by k_pack_band
-            fb[row_index * (size_t)width + cx] = rgba;
+            fb[(size_t)cy * (size_t)width + cx] = rgba;
         }
     }
 }
@@ -643,21 +1015,30 @@ void launch_setup(hipStream_t st, const swfr_edge* in, const DevPath* paths, Dev
     if (!n_edges) return;
     hipLaunchKernelGGL(k_setup, dim3((n_edges + 255) / 256), dim3(256), 0, st, in, paths, out, n_edges);
 }
-void launch_rows(hipStream_t st, const DevEdge* edges, const DevPath* paths, const uint32_t* row_base, uint32_t n_paths,
-                 RowInfo* rows, uint2* records, uint32_t* counters, uint32_t n_tasks, uint32_t band_index, uint32_t band_count) {
-    if (!n_tasks) return;
-    hipLaunchKernelGGL(k_rows, dim3((n_tasks + 63) / 64), dim3(64), 0, st, edges, paths, row_base, n_paths, rows, records,
-                       counters, n_tasks, band_index, band_count);
+void launch_bands(hipStream_t st, const DevPath* paths, uint32_t n_paths, const uint32_t* band_off, uint32_t* band_list, uint32_t n_bands) {
+    if (!n_bands || !n_paths) return;
+    hipLaunchKernelGGL(k_bands, dim3(n_bands), dim3(256), 0, st, paths, n_paths, band_off, band_list);
 }
-void launch_tiles(hipStream_t st, const swfr_edge* raw, const DevEdge* edges, const DevPath* paths, uint32_t n_paths,
-                  const uint32_t* row_base, const RowInfo* rows, const uint2* records, const swfr_style* styles,
-                  const DevBitmap* bitmaps, uint32_t* fb, int width, int height, uint32_t band_index, uint32_t band_count) {
+void launch_rows(hipStream_t st, const DevEdge* edges, const DevPath* paths, const uint32_t* row_base, const uint32_t* chunk_base,
+                 uint32_t n_paths, RowInfo* rows, Rec* records, uint32_t* counters, uint32_t* overflow_list, uint32_t n_chunks,
+                 uint32_t band_index, uint32_t band_count, int fast_limit) {
+    if (!n_chunks) return;
+    fast_limit = fast_limit < 0 ? 0 : (fast_limit > ROWS_FAST_N ? ROWS_FAST_N : fast_limit);
+    hipLaunchKernelGGL(k_rows, dim3(n_chunks), dim3(64), 0, st, edges, paths, row_base, chunk_base, n_paths, rows, records, counters,
+                       overflow_list, band_index, band_count, fast_limit);
+    // rows that exceeded the per-lane capacity (rare): fixed small grid, every lane loops over the list and exits
+    hipLaunchKernelGGL(k_rows_big, dim3(256), dim3(64), 0, st, edges, paths, row_base, n_paths, rows, records, counters, overflow_list);
+}
+void launch_tiles(hipStream_t st, const swfr_edge* raw, const DevEdge* edges, const DevPath* paths, const uint32_t* band_off,
+                  const uint32_t* band_list, const uint32_t* row_base, const RowInfo* rows, const Rec* records,
+                  const swfr_style* styles, const DevBitmap* bitmaps, uint32_t* fb, int width, int height, uint32_t band_index,
+                  uint32_t band_count) {
     const int tiles_x = (width + TILE_W - 1) / TILE_W, tile_rows = (height + TILE_H - 1) / TILE_H;
     uint32_t local_rows = tile_rows;
     if (band_count > 1) local_rows = (tile_rows > (int)band_index) ? (tile_rows - band_index + band_count - 1) / band_count : 0;
     if (!local_rows) return;
-    hipLaunchKernelGGL(k_tiles, dim3(tiles_x * local_rows), dim3(256), 0, st, raw, edges, paths, n_paths, row_base, rows, records,
-                       styles, bitmaps, fb, width, height, tiles_x, band_index, band_count, local_rows);
+    hipLaunchKernelGGL(k_tiles, dim3(tiles_x * local_rows), dim3(256), 0, st, raw, edges, paths, band_off, band_list, row_base, rows,
+                       records, styles, bitmaps, fb, width, height, tiles_x, band_index, band_count);
 }
 void launch_unpremultiply(hipStream_t st, const uint32_t* in, uint32_t* out, size_t n) {
     if (!n) return;

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -21,10 +22,11 @@
 
 namespace swfr {
 void launch_setup(hipStream_t, const swfr_edge*, const DevPath*, DevEdge*, uint32_t);
-void launch_rows(hipStream_t, const DevEdge*, const DevPath*, const uint32_t*, uint32_t, RowInfo*, uint2*, uint32_t*, uint32_t,
-                 uint32_t, uint32_t);
-void launch_tiles(hipStream_t, const swfr_edge*, const DevEdge*, const DevPath*, uint32_t, const uint32_t*, const RowInfo*,
-                  const uint2*, const swfr_style*, const DevBitmap*, uint32_t*, int, int, uint32_t, uint32_t);
+void launch_bands(hipStream_t, const DevPath*, uint32_t, const uint32_t*, uint32_t*, uint32_t);
+void launch_rows(hipStream_t, const DevEdge*, const DevPath*, const uint32_t*, const uint32_t*, uint32_t, RowInfo*, Rec*, uint32_t*,
+                 uint32_t*, uint32_t, uint32_t, uint32_t, int);
+void launch_tiles(hipStream_t, const swfr_edge*, const DevEdge*, const DevPath*, const uint32_t*, const uint32_t*, const uint32_t*,
+                  const RowInfo*, const Rec*, const swfr_style*, const DevBitmap*, uint32_t*, int, int, uint32_t, uint32_t);
 void launch_unpremultiply(hipStream_t, const uint32_t*, uint32_t*, size_t);
 void launch_pack_band(hipStream_t, const uint32_t*, uint32_t*, int, int, uint32_t, uint32_t, uint32_t);
 }  // namespace swfr
@@ -87,9 +89,9 @@ struct swfr_renderer {
     DevBuf<DevEdge> d_edges;
     DevBuf<DevPath> d_paths;
     DevBuf<swfr_style> d_styles;
-    DevBuf<uint32_t> d_row_base;
+    DevBuf<uint32_t> d_row_base, d_chunk_base, d_band_off, d_band_list, d_overflow;
     DevBuf<RowInfo> d_rows;
-    DevBuf<uint2> d_records;
+    DevBuf<Rec> d_records;
     DevBuf<uint32_t> d_counters;
     DevBuf<DevBitmap> d_bitmap_table;
     DevBuf<uint32_t> d_fb, d_tmp;
@@ -97,15 +99,16 @@ struct swfr_renderer {
     std::vector<DevBitmap> bitmap_table;   // indexed by bitmap id
     bool bitmap_table_dirty = false;
     // resident scene
-    size_t n_edges = 0, n_paths = 0, n_styles = 0, n_tasks = 0, rec_cap = 0;
+    size_t n_edges = 0, n_paths = 0, n_styles = 0, n_tasks = 0, n_chunks = 0, n_bands = 0, rec_cap = 0;
     bool scene_ready = false, fb_valid = false;
     swfr_timing timing{};
+    int fast_limit = 8;                     // rows with more active edges go through k_rows_big (SWFR_FAST_LIMIT: test knob)
 
     ~swfr_renderer() {
         if (has_device) {
             (void)hipSetDevice(cfg.device);
             d_raw.release(); d_edges.release(); d_paths.release(); d_styles.release(); d_row_base.release();
-            d_rows.release(); d_records.release(); d_counters.release(); d_bitmap_table.release(); d_fb.release(); d_tmp.release();
+            d_rows.release(); d_records.release(); d_chunk_base.release(); d_band_off.release(); d_band_list.release(); d_overflow.release(); d_counters.release(); d_bitmap_table.release(); d_fb.release(); d_tmp.release();
             for (auto& kv : bitmaps) if (kv.second.pixels) (void)hipFree(kv.second.pixels);
             for (auto& e : ev) if (e) (void)hipEventDestroy(e);
             if (stream) (void)hipStreamDestroy(stream);
@@ -171,7 +174,9 @@ int upload(swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_
     // stage: edges tagged with their path index; row prefix over tor paths; record capacity bound
     std::vector<swfr_edge> staged(edges, edges + n_edges);
     for (auto& e : staged) e.reserved = 0;            // overwritten below with the owning path's index
-    std::vector<uint32_t> row_base(n_paths + 1, 0);
+    std::vector<uint32_t> row_base(n_paths + 1, 0), chunk_base(n_paths + 1, 0);
+    const size_t n_bands = (r->height + TILE_H - 1) / TILE_H;
+    std::vector<uint32_t> band_off(n_bands + 1, 0);
     size_t rec_cap = 0;
     for (size_t i = 0; i < n_paths; ++i) {
         const swfr_path& p = paths[i];
@@ -187,17 +192,27 @@ int upload(swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_
             }
         }
         row_base[i + 1] = row_base[i] + rows;
+        chunk_base[i + 1] = chunk_base[i] + (rows + ROWS_CHUNK - 1) / ROWS_CHUNK;
+        if (p.y_max > p.y_min)
+            for (int b = p.y_min / TILE_H; b <= (p.y_max - 1) / TILE_H; ++b) ++band_off[size_t(b) + 1];
     }
+    for (size_t b = 0; b < n_bands; ++b) band_off[b + 1] += band_off[b];   // exact sizes; k_bands fills the lists in order
     r->n_edges = n_edges; r->n_paths = n_paths; r->n_styles = n_styles;
     r->n_tasks = row_base[n_paths];
+    r->n_chunks = chunk_base[n_paths];
+    r->n_bands = n_bands;
     r->rec_cap = rec_cap + 64;
     r->d_raw.reserve(n_edges); r->d_edges.reserve(n_edges); r->d_paths.reserve(n_paths); r->d_styles.reserve(n_styles);
     r->d_row_base.reserve(n_paths + 1); r->d_rows.reserve(r->n_tasks); r->d_records.reserve(r->rec_cap);
+    r->d_chunk_base.reserve(n_paths + 1); r->d_band_off.reserve(n_bands + 1); r->d_band_list.reserve(band_off[n_bands]);
+    r->d_overflow.reserve(r->n_tasks);
     r->d_counters.reserve(CNT_WORDS);
     if (n_edges) HIP_CHECK(hipMemcpyAsync(r->d_raw.ptr, staged.data(), n_edges * sizeof(swfr_edge), hipMemcpyHostToDevice, r->stream));
     if (n_paths) HIP_CHECK(hipMemcpyAsync(r->d_paths.ptr, paths, n_paths * sizeof(swfr_path), hipMemcpyHostToDevice, r->stream));
     if (n_styles) HIP_CHECK(hipMemcpyAsync(r->d_styles.ptr, styles, n_styles * sizeof(swfr_style), hipMemcpyHostToDevice, r->stream));
     HIP_CHECK(hipMemcpyAsync(r->d_row_base.ptr, row_base.data(), (n_paths + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, r->stream));
+    HIP_CHECK(hipMemcpyAsync(r->d_chunk_base.ptr, chunk_base.data(), (n_paths + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, r->stream));
+    HIP_CHECK(hipMemcpyAsync(r->d_band_off.ptr, band_off.data(), (n_bands + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, r->stream));
     if (r->bitmap_table_dirty) {
         r->d_bitmap_table.reserve(r->bitmap_table.size());
         if (!r->bitmap_table.empty())
@@ -228,13 +243,17 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
         hipEvent_t* e = &r->ev[size_t(f) * 4];
         HIP_CHECK(hipMemsetAsync(r->d_counters.ptr, 0, CNT_WORDS * sizeof(uint32_t), r->stream));
         HIP_CHECK(hipEventRecord(e[0], r->stream));
-        if (r->n_paths) launch_setup(r->stream, r->d_raw.ptr, r->d_paths.ptr, r->d_edges.ptr, uint32_t(r->n_edges));
+        if (r->n_paths) {
+            launch_setup(r->stream, r->d_raw.ptr, r->d_paths.ptr, r->d_edges.ptr, uint32_t(r->n_edges));
+            launch_bands(r->stream, r->d_paths.ptr, uint32_t(r->n_paths), r->d_band_off.ptr, r->d_band_list.ptr, uint32_t(r->n_bands));
+        }
         HIP_CHECK(hipEventRecord(e[1], r->stream));
-        launch_rows(r->stream, r->d_edges.ptr, r->d_paths.ptr, r->d_row_base.ptr, uint32_t(r->n_paths), r->d_rows.ptr, r->d_records.ptr,
-                    r->d_counters.ptr, uint32_t(r->n_tasks), bi, bc);
+        if (r->n_paths)
+            launch_rows(r->stream, r->d_edges.ptr, r->d_paths.ptr, r->d_row_base.ptr, r->d_chunk_base.ptr, uint32_t(r->n_paths), r->d_rows.ptr,
+                        r->d_records.ptr, r->d_counters.ptr, r->d_overflow.ptr, uint32_t(r->n_chunks), bi, bc, r->fast_limit);
         HIP_CHECK(hipEventRecord(e[2], r->stream));
-        launch_tiles(r->stream, r->d_raw.ptr, r->d_edges.ptr, r->d_paths.ptr, uint32_t(r->n_paths), r->d_row_base.ptr, r->d_rows.ptr,
-                     r->d_records.ptr, r->d_styles.ptr, r->d_bitmap_table.ptr, r->d_fb.ptr, int(r->width), int(r->height), bi, bc);
+        launch_tiles(r->stream, r->d_raw.ptr, r->d_edges.ptr, r->d_paths.ptr, r->d_band_off.ptr, r->d_band_list.ptr, r->d_row_base.ptr,
+                     r->d_rows.ptr, r->d_records.ptr, r->d_styles.ptr, r->d_bitmap_table.ptr, r->d_fb.ptr, int(r->width), int(r->height), bi, bc);
         HIP_CHECK(hipEventRecord(e[3], r->stream));
     }
     HIP_CHECK(hipGetLastError());
@@ -253,7 +272,7 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
     r->fb_valid = true;
     if (counters[CNT_ERROR]) {
         r->fb_valid = false;
-        return fail(r, SWFR_ERR_CAPACITY, "a pixel row has more than 32 active edges of one path (scan converter capacity)");
+        return fail(r, SWFR_ERR_CAPACITY, "a pixel row has more than 64 active edges of one path (scan converter capacity)");
     }
     if (counters[CNT_RECORDS] > r->rec_cap) {
         r->fb_valid = false;
@@ -282,6 +301,7 @@ int swfr_create(uint32_t width, uint32_t height, const swfr_config* cfg, swfr_re
     if (cfg) r->cfg = *cfg;
     if (r->cfg.band_count > 1 && r->cfg.band_index >= r->cfg.band_count) return SWFR_ERR_INVALID;
     r->builder.reset(new FrameBuilder(width, height, (r->cfg.flags & SWFR_FLAG_EVEN_ODD) != 0));
+    if (const char* fl = std::getenv("SWFR_FAST_LIMIT")) r->fast_limit = std::atoi(fl);
     if (r->cfg.device == SWFR_DEVICE_HOST_ONLY) {
         *out = r.release();
         return SWFR_OK;
