@@ -51,6 +51,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = rehearsal of the N>1 path on one GPU: every rank renders on cuda:0, slabs are gathered as CPU tensors")
+    ap.add_argument("--verify", action="store_true", help="rank 0 checks the assembled frame against the S1 known answer")
     args = ap.parse_args()
 
     import numpy as np
@@ -66,10 +69,16 @@ def main():
             raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    rehearsal = args.backend == "gloo"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     cfg = synth.S1
     W, H = cfg["width"], cfg["height"]
@@ -85,9 +94,9 @@ def main():
 
     r = S.Renderer(W, H, device=local_rank, band_index=rank if world > 1 else 0, band_count=world if world > 1 else 0)
     r.upload_edges(edges, paths, styles)                      # inputs resident in HBM before the timed region
-    slab = None
+    pipe = None
     if world > 1:
-        slab = torch.empty(D.slab_shape(W, H, rank, world), dtype=torch.uint8, device="cuda")
+        pipe = D.FramePipeline(r, W, H, rank, world, device="cpu" if rehearsal else "cuda")
 
     def sync_all():
         if world > 1:
@@ -95,9 +104,7 @@ def main():
         torch.cuda.synchronize()
 
     def step_multi():
-        r.render_resident(1)
-        r.copy_band_slab(slab.data_ptr())
-        return D.gather_slabs(slab, W, H, rank, world, dst=0)
+        return pipe.step()
 
     # ---- warmup
     if world == 1:
@@ -111,8 +118,10 @@ def main():
     if world == 1:
         r.render_resident(args.steps)                         # K frames queued back to back on the handle's stream
     else:
+        out = None
         for _ in range(args.steps):
             out = step_multi()
+        out = pipe.finish()
     sync_all()
     dt = time.perf_counter() - t0
     tm = r.timing()
@@ -121,6 +130,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    if args.verify and rank == 0:
+        import hashlib
+        img = out.cpu().numpy() if world > 1 else r.read_image(premultiplied=True)
+        ok = hashlib.sha256(np.ascontiguousarray(img).tobytes()).hexdigest() == synth.S1_SHA256_PREMUL
+        print("verify: assembled frame %s the libcairo known answer" % ("matches" if ok else "DOES NOT match"), file=sys.stderr, flush=True)
+        if not ok:
+            raise SystemExit(3)
     if rank == 0:
         n_edges, n_paths = len(edges), len(paths)
         algo_bytes = 4 * W * H + 16 * n_edges + 16 * n_paths           # SURVEY.md 8(d), per frame = per k_tiles launch

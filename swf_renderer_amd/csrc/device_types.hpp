@@ -35,9 +35,20 @@ struct RowInfo {
 // SUB rows carry 15 two-bit fields, field s = 1 (a span opens at this edge in sub-row s) or 2 (closes).
 // cols = lo | hi << 16: the pixel columns (clamped to [0, 65535]) this record's contributions fall in.
 constexpr uint32_t REC_FULL = 0x80000000u;
+// The record is self-contained (no edge lookup in k_tiles): FULL rows carry the two end points of the edge over
+// the pixel row (x = q + r/dy at the row top and bottom); SUB rows carry x at the edge's first sample row in the
+// pixel row plus the per-sample slope.
 struct Rec {
-    uint32_t eid, roles, cols;
+    uint32_t roles, cols;
+    int32_t q1;              // FULL: x quotient at the row top;    SUB: x quotient at the first sample row
+    int32_t q2;              // FULL: x quotient at the row bottom; SUB: slope quotient per sample row
+    int64_t r1;              // remainder of q1
+    int64_t r2;              // FULL: remainder of q2;              SUB: slope remainder
+    int64_t dy;              // denominator (0: vertical edge)
+    uint32_t span;           // SUB: first | (last+1) << 8, sample rows relative to the pixel row's first
+    uint32_t eid;            // edge index (diagnostics)
 };
+static_assert(sizeof(Rec) == 48, "Rec layout");
 
 enum : uint32_t { CNT_RECORDS = 0, CNT_ERROR = 1, CNT_OVERFLOW = 2, CNT_WORDS = 4 };
 constexpr int ROWS_CHUNK = 64;       // pixel rows per k_rows workgroup (one lane per row)

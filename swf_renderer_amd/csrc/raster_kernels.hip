@@ -66,6 +66,20 @@ __device__ __forceinline__ void full_row_ends(const DevEdge& e, int s0, int32_t&
     }
 }
 __device__ __forceinline__ uint32_t clamp_col(int c) { return (uint32_t)min(max(c, 0), 65535); }
+// self-contained record of edge e for pixel row s0/15 with the given roles / column range
+__device__ __forceinline__ Rec make_record(const DevEdge& e, uint32_t eid, int s0, uint32_t roles, uint32_t cols) {
+    Rec rc;
+    rc.roles = roles; rc.cols = cols; rc.eid = eid; rc.dy = e.dy; rc.span = 0;
+    if (roles & REC_FULL) {
+        full_row_ends(e, s0, rc.q1, rc.r1, rc.q2, rc.r2);
+    } else {
+        const int first = max(e.ytop, s0), last = min(e.ybot, s0 + 15);
+        edge_x_at(e, first, rc.q1, rc.r1);
+        rc.q2 = (int32_t)e.dq; rc.r2 = e.dr;
+        rc.span = (uint32_t)(first - s0) | ((uint32_t)(last - s0) << 8);
+    }
+    return rc;
+}
 
 // wave64 inclusive prefix sum with DPP row shifts + row broadcasts (no LDS traffic)
 __device__ __forceinline__ int wave_scan_incl(int v) {
@@ -513,7 +527,10 @@ __global__ __launch_bounds__(64) void k_rows(const DevEdge* __restrict__ edges, 
         rows[t] = ri;
 #pragma unroll
         for (int s = 0; s < ROWS_FAST_N; ++s) {
-            if (s < n && roles[s] != 0) { Rec rc; rc.eid = P.first_edge + (uint32_t)el[s]; rc.roles = (uint32_t)roles[s]; rc.cols = (uint32_t)cols[s]; records[off++] = rc; }
+            if (s < n && roles[s] != 0) {
+                const DevEdge e = use_lds ? staged[el[s]] : edges[P.first_edge + el[s]];
+                records[off++] = make_record(e, P.first_edge + (uint32_t)el[s], r * 15, (uint32_t)roles[s], (uint32_t)cols[s]);
+            }
         }
     }
 }
@@ -543,7 +560,7 @@ __global__ __launch_bounds__(64) void k_rows_big(const DevEdge* __restrict__ edg
             ri.rec_off = off; ri.n_rec = (uint16_t)n_out; ri.mode = (uint16_t)res.mode;
             for (int k = 0; k < res.n; ++k) {
                 const int32_t roles = L.aux[k][lane];
-                if (roles) { Rec rc; rc.eid = P.first_edge + (uint32_t)L.eid[k][lane]; rc.roles = (uint32_t)roles; rc.cols = (uint32_t)L.cols[k][lane]; records[off++] = rc; }
+                if (roles) records[off++] = make_record(edges[P.first_edge + (uint32_t)L.eid[k][lane]], P.first_edge + (uint32_t)L.eid[k][lane], r * 15, (uint32_t)roles, (uint32_t)L.cols[k][lane]);
             }
         }
         rows[t] = ri;
@@ -692,18 +709,18 @@ __device__ __forceinline__ void cell_add(int* acc, const TileCtx& c, int i, int 
 }
 
 // FULL-row edge (A.5 render_edge): analytic trapezoid coverage of one edge over one pixel row
-__device__ void full_edge(const DevEdge& e, int s0, int sign, int* acc, const TileCtx& c) {
-    int32_t q1, q2; int64_t r1, r2;
-    full_row_ends(e, s0, q1, r1, q2, r2);
+__device__ void full_edge(const Rec& rec, int sign, int* acc, const TileCtx& c) {
+    int32_t q1 = rec.q1, q2 = rec.q2; int64_t r1 = rec.r1, r2 = rec.r2;
+    const int64_t edy = rec.dy;
     int ix1 = q1 >> 8, f1 = q1 & 255, ix2 = q2 >> 8, f2 = q2 & 255;
     if (ix1 == ix2) { cell_add(acc, c, ix1, sign * 15, sign * (f1 + f2) * 15); return; }
     if (ix2 < ix1) { int t = ix1; ix1 = ix2; ix2 = t; t = f1; f1 = f2; f2 = t; int32_t tq = q1; q1 = q2; q2 = tq; int64_t tr = r1; r1 = r2; r2 = tr; }
     const int lo = max(c.tx0, c.xminp);                  // first column whose own area matters to this tile
     const int hi = min(c.tx0 + TILE_W, c.xmaxp);         // one past the last such column
     if (ix1 >= hi) return;                               // entirely to the right: invisible here
-    const int64_t dx = (int64_t)(q2 - q1) * e.dy + (r2 - r1);
-    const int64_t t0 = ((int64_t)((ix1 + 1) * 256 - q1) * e.dy - r1) * 15;
-    const int64_t F = 15ll * 256 * e.dy;
+    const int64_t dx = (int64_t)(q2 - q1) * edy + (r2 - r1);
+    const int64_t t0 = ((int64_t)((ix1 + 1) * 256 - q1) * edy - r1) * 15;
+    const int64_t F = 15ll * 256 * edy;
     // Y(col) = covered sub-rows accumulated over columns ix1..col (ix1 <= col < ix2), exact floor
     const int first = max(ix1, lo);
     int y_prev = 0;
@@ -731,7 +748,7 @@ __device__ void full_edge(const DevEdge& e, int s0, int sign, int* acc, const Ti
 
 // phase 1 of a partial tor path: every (row, record) adds its cells into acc (LDS atomics)
 __device__ __forceinline__ void accumulate_path(const DevPath& P, uint32_t row_base_p, const RowInfo* __restrict__ rows,
-                                                const Rec* __restrict__ records, const DevEdge* __restrict__ edges,
+                                                const Rec* __restrict__ records,
                                                 int (*acc)[ACC_STRIDE], int tx0, int ty0, int tid) {
     const int row = tid >> 4, slot = tid & 15;
     const int y = ty0 + row;
@@ -739,7 +756,6 @@ __device__ __forceinline__ void accumulate_path(const DevPath& P, uint32_t row_b
     const RowInfo ri = rows[row_base_p + (uint32_t)(y - P.y_min)];
     if (!ri.n_rec) return;
     TileCtx c; c.tx0 = tx0; c.xminp = P.x_min; c.xmaxp = P.x_max;
-    const int s0 = y * 15;
     if (slot == 0) acc[row][ACC_TOUCH] = 1;
     for (uint32_t k = slot; k < ri.n_rec; k += 16) {
         const Rec rec = records[ri.rec_off + k];
@@ -749,21 +765,19 @@ __device__ __forceinline__ void accumulate_path(const DevPath& P, uint32_t row_b
             cell_add(acc[row], c, chi, record_height(rec.roles), 0);
             continue;
         }
-        const DevEdge e = edges[rec.eid];
         if (rec.roles & REC_FULL) {
-            full_edge(e, s0, (rec.roles & 1u) ? +1 : -1, acc[row], c);
+            full_edge(rec, (rec.roles & 1u) ? +1 : -1, acc[row], c);
         } else {
-            const int first = max(e.ytop, s0), last = min(e.ybot, s0 + 15);
-            int32_t q; int64_t rm;
-            edge_x_at(e, first, q, rm);
+            const int first = (int)(rec.span & 255u), last = (int)(rec.span >> 8);
+            int32_t q = rec.q1; int64_t rm = rec.r1;
             for (int ss = first; ss < last; ++ss) {
-                const uint32_t role = (rec.roles >> (2 * (ss - s0))) & 3u;
+                const uint32_t role = (rec.roles >> (2 * ss)) & 3u;
                 if (role) {
-                    const int cell = e.dy ? cell_of(q, rm, e.dy) : e.x1;
+                    const int cell = rec.dy ? cell_of(q, rm, rec.dy) : q;
                     const int sgn = role == 1 ? 1 : -1;
                     cell_add(acc[row], c, cell >> 8, sgn, sgn * 2 * (cell & 255));
                 }
-                if (e.dy) step_x(q, rm, e);
+                if (rec.dy) { q += rec.q2; rm += rec.r2; if (rm < 0) { --q; rm += rec.dy; } else if (rm >= rec.dy) { ++q; rm -= rec.dy; } }
             }
         }
     }
@@ -775,7 +789,7 @@ __global__ __launch_bounds__(256) void k_tiles(const swfr_edge* __restrict__ raw
                                                const uint32_t* __restrict__ row_base, const RowInfo* __restrict__ rows,
                                                const Rec* __restrict__ records, const swfr_style* __restrict__ styles,
                                                const DevBitmap* __restrict__ bitmaps, uint32_t* __restrict__ fb,
-                                               int width, int height, int tiles_x, uint32_t band_index, uint32_t band_count) {
+                                               int width, int height, int tiles_x, uint32_t band_index, uint32_t band_count, int dbg) {
     __shared__ int acc[2][TILE_H][ACC_STRIDE];
     __shared__ uint32_t list[LIST_CAP];
     __shared__ uint32_t cls[LIST_CAP];
@@ -822,7 +836,8 @@ __global__ __launch_bounds__(256) void k_tiles(const swfr_edge* __restrict__ raw
             if (tid == 0) list_n += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
             __syncthreads();
         }
-        const int ln = (int)list_n;
+        int ln = (int)list_n;
+        if (dbg == 1) ln = 0;
 
         // ---- classify every (tile, path): 16 paths x 16 rows per pass; no edge arithmetic, records only
         for (int base = 0; base < ln; base += 16) {
@@ -872,15 +887,15 @@ __global__ __launch_bounds__(256) void k_tiles(const swfr_edge* __restrict__ raw
             }
         }
         __syncthreads();
-        const int start = cover_from;
+        const int start = dbg == 2 ? ln : cover_from;
 
         // ---- painter's order walk; tor-partial paths are software pipelined over two accumulator buffers
         int buf = 0;
         int nxt = -1;                                          // next partial tor path at or after `start`
         for (int li = start; li < ln; ++li) if ((cls[li] & (CLS_PARTIAL | CLS_BOX)) == CLS_PARTIAL) { nxt = li; break; }
-        if (nxt >= 0) {
+        if (nxt >= 0 && dbg != 3) {
             const uint32_t pi = list[nxt];
-            accumulate_path(paths[pi], row_base[pi], rows, records, edges, acc[buf], tx0, ty0, tid);
+            accumulate_path(paths[pi], row_base[pi], rows, records, acc[buf], tx0, ty0, tid);
         }
         __syncthreads();
         for (int li = start; li < ln; ++li) {
@@ -890,7 +905,7 @@ __global__ __launch_bounds__(256) void k_tiles(const swfr_edge* __restrict__ raw
             const DevPath P = paths[pi];
             const int row_lo = max(P.y_min, ty0), row_hi = min(P.y_max, ty0 + TILE_H);
             uint32_t alpha[4] = {0u, 0u, 0u, 0u};
-            const bool is_partial_tor = (f & (CLS_PARTIAL | CLS_BOX)) == CLS_PARTIAL;
+            const bool is_partial_tor = (f & (CLS_PARTIAL | CLS_BOX)) == CLS_PARTIAL && dbg != 3;
             if (f & CLS_BOX) {
                 // ---- rectilinear (A.6): exact area of disjoint boxes, alpha = (c>>8) - (c>>16)
                 uint32_t cov[4] = {0u, 0u, 0u, 0u};
@@ -914,7 +929,7 @@ __global__ __launch_bounds__(256) void k_tiles(const swfr_edge* __restrict__ raw
                 for (int lj = li + 1; lj < ln; ++lj) if ((cls[lj] & (CLS_PARTIAL | CLS_BOX)) == CLS_PARTIAL) { nxt = lj; break; }
                 if (nxt >= 0) {
                     const uint32_t pn = list[nxt];
-                    accumulate_path(paths[pn], row_base[pn], rows, records, edges, acc[buf ^ 1], tx0, ty0, tid);
+                    accumulate_path(paths[pn], row_base[pn], rows, records, acc[buf ^ 1], tx0, ty0, tid);
                 }
                 // phase 2: per row, wave64 prefix sum of covered height, coverage -> alpha; clears as it reads
 #pragma unroll
@@ -1032,13 +1047,13 @@ void launch_rows(hipStream_t st, const DevEdge* edges, const DevPath* paths, con
 void launch_tiles(hipStream_t st, const swfr_edge* raw, const DevEdge* edges, const DevPath* paths, const uint32_t* band_off,
                   const uint32_t* band_list, const uint32_t* row_base, const RowInfo* rows, const Rec* records,
                   const swfr_style* styles, const DevBitmap* bitmaps, uint32_t* fb, int width, int height, uint32_t band_index,
-                  uint32_t band_count) {
+                  uint32_t band_count, int dbg) {
     const int tiles_x = (width + TILE_W - 1) / TILE_W, tile_rows = (height + TILE_H - 1) / TILE_H;
     uint32_t local_rows = tile_rows;
     if (band_count > 1) local_rows = (tile_rows > (int)band_index) ? (tile_rows - band_index + band_count - 1) / band_count : 0;
     if (!local_rows) return;
     hipLaunchKernelGGL(k_tiles, dim3(tiles_x * local_rows), dim3(256), 0, st, raw, edges, paths, band_off, band_list, row_base, rows,
-                       records, styles, bitmaps, fb, width, height, tiles_x, band_index, band_count);
+                       records, styles, bitmaps, fb, width, height, tiles_x, band_index, band_count, dbg);
 }
 void launch_unpremultiply(hipStream_t st, const uint32_t* in, uint32_t* out, size_t n) {
     if (!n) return;

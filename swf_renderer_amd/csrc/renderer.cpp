@@ -26,7 +26,7 @@ void launch_bands(hipStream_t, const DevPath*, uint32_t, const uint32_t*, uint32
 void launch_rows(hipStream_t, const DevEdge*, const DevPath*, const uint32_t*, const uint32_t*, uint32_t, RowInfo*, Rec*, uint32_t*,
                  uint32_t*, uint32_t, uint32_t, uint32_t, int);
 void launch_tiles(hipStream_t, const swfr_edge*, const DevEdge*, const DevPath*, const uint32_t*, const uint32_t*, const uint32_t*,
-                  const RowInfo*, const Rec*, const swfr_style*, const DevBitmap*, uint32_t*, int, int, uint32_t, uint32_t);
+                  const RowInfo*, const Rec*, const swfr_style*, const DevBitmap*, uint32_t*, int, int, uint32_t, uint32_t, int);
 void launch_unpremultiply(hipStream_t, const uint32_t*, uint32_t*, size_t);
 void launch_pack_band(hipStream_t, const uint32_t*, uint32_t*, int, int, uint32_t, uint32_t, uint32_t);
 }  // namespace swfr
@@ -102,6 +102,7 @@ struct swfr_renderer {
     size_t n_edges = 0, n_paths = 0, n_styles = 0, n_tasks = 0, n_chunks = 0, n_bands = 0, rec_cap = 0;
     bool scene_ready = false, fb_valid = false;
     swfr_timing timing{};
+    int tiles_dbg = 0;                      // SWFR_TILES_DEBUG: timing-only ablations of k_tiles (wrong pixels)
     int fast_limit = 8;                     // rows with more active edges go through k_rows_big (SWFR_FAST_LIMIT: test knob)
 
     ~swfr_renderer() {
@@ -253,7 +254,7 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
                         r->d_records.ptr, r->d_counters.ptr, r->d_overflow.ptr, uint32_t(r->n_chunks), bi, bc, r->fast_limit);
         HIP_CHECK(hipEventRecord(e[2], r->stream));
         launch_tiles(r->stream, r->d_raw.ptr, r->d_edges.ptr, r->d_paths.ptr, r->d_band_off.ptr, r->d_band_list.ptr, r->d_row_base.ptr,
-                     r->d_rows.ptr, r->d_records.ptr, r->d_styles.ptr, r->d_bitmap_table.ptr, r->d_fb.ptr, int(r->width), int(r->height), bi, bc);
+                     r->d_rows.ptr, r->d_records.ptr, r->d_styles.ptr, r->d_bitmap_table.ptr, r->d_fb.ptr, int(r->width), int(r->height), bi, bc, r->tiles_dbg);
         HIP_CHECK(hipEventRecord(e[3], r->stream));
     }
     HIP_CHECK(hipGetLastError());
@@ -302,6 +303,7 @@ int swfr_create(uint32_t width, uint32_t height, const swfr_config* cfg, swfr_re
     if (r->cfg.band_count > 1 && r->cfg.band_index >= r->cfg.band_count) return SWFR_ERR_INVALID;
     r->builder.reset(new FrameBuilder(width, height, (r->cfg.flags & SWFR_FLAG_EVEN_ODD) != 0));
     if (const char* fl = std::getenv("SWFR_FAST_LIMIT")) r->fast_limit = std::atoi(fl);
+    if (const char* td = std::getenv("SWFR_TILES_DEBUG")) r->tiles_dbg = std::atoi(td);
     if (r->cfg.device == SWFR_DEVICE_HOST_ONLY) {
         *out = r.release();
         return SWFR_OK;

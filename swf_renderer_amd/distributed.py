@@ -84,3 +84,65 @@ def gather_slabs(slab, width: int, height: int, rank: int, world: int, dst: int 
     if rank != dst:
         return None
     return assemble(bufs, width, height)
+
+
+class FramePipeline:
+    """N>1 step = render this rank's bands, pack them, gather to rank 0, assemble -- with the gather and the
+    assembly of frame k overlapping the rasterization of frame k+1.
+
+    The renderer works on its own HIP stream; the collective and the de-interleave run on torch's streams.
+    `depth` slabs rotate; a slab is reused only after the event recorded behind its assembly has completed.
+    """
+
+    def __init__(self, renderer, width, height, rank, world, device="cuda", depth=3, dst=0):
+        import torch
+        self.r, self.w, self.h, self.rank, self.world, self.dst = renderer, width, height, rank, world, dst
+        self.device = device
+        rows = max_slab_rows(height, world)
+        on_gpu = device != "cpu"
+        self.stage = [torch.zeros((rows, width, 4), dtype=torch.uint8, device="cuda") for _ in range(depth)]
+        self.cpu_slabs = None if on_gpu else [torch.zeros((rows, width, 4), dtype=torch.uint8) for _ in range(depth)]
+        self.bufs = None
+        if rank == dst:
+            self.bufs = [[torch.empty((rows, width, 4), dtype=torch.uint8, device=device) for _ in range(world)] for _ in range(depth)]
+        self.events = [None] * depth
+        self.works = [None] * depth
+        self.k = 0
+        self.last = None
+
+    def step(self):
+        import torch
+        import torch.distributed as dist
+        i = self.k % len(self.stage)
+        self.k += 1
+        if self.works[i] is not None:
+            self.works[i].wait()
+            self.works[i] = None
+        if self.events[i] is not None:
+            self.events[i].synchronize()                   # the slab's previous gather + assembly are done
+        self.r.render_resident(1)                          # blocking on the renderer's stream
+        self.r.copy_band_slab(self.stage[i].data_ptr())    # packed tile-rows, zero padded to the common size
+        send = self.stage[i]
+        if self.cpu_slabs is not None:                     # gloo rehearsal: collectives on CPU tensors
+            self.cpu_slabs[i].copy_(send)
+            send = self.cpu_slabs[i]
+        work = dist.gather(send, gather_list=self.bufs[i] if self.rank == self.dst else None, dst=self.dst, async_op=True)
+        if self.cpu_slabs is not None:
+            work.wait()
+        else:
+            work.wait()                                    # NCCL: makes the current stream wait, not the host
+        if self.rank == self.dst:
+            self.last = assemble(self.bufs[i], self.w, self.h)
+        if self.cpu_slabs is None:
+            ev = torch.cuda.Event()
+            ev.record()
+            self.events[i] = ev
+        return self.last
+
+    def finish(self):
+        import torch
+        for w in self.works:
+            if w is not None:
+                w.wait()
+        torch.cuda.synchronize()
+        return self.last
