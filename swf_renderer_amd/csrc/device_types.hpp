@@ -50,7 +50,7 @@ struct Rec {
 };
 static_assert(sizeof(Rec) == 48, "Rec layout");
 
-enum : uint32_t { CNT_RECORDS = 0, CNT_ERROR = 1, CNT_OVERFLOW = 2, CNT_WORDS = 4 };
+enum : uint32_t { CNT_RECORDS = 0, CNT_ERROR = 1, CNT_OVERFLOW = 2, CNT_PAIRS = 3, CNT_PARTIAL = 4, CNT_FULL = 5, CNT_CULLED = 6, CNT_WORDS = 8 };
 constexpr int ROWS_CHUNK = 64;       // pixel rows per k_rows workgroup (one lane per row)
 
 struct DevBitmap {

@@ -681,7 +681,7 @@ __device__ __noinline__ uint32_t shade(const swfr_style& s, const DevBitmap* __r
 #define ACC_STRIDE 66                 // 64 cells + carry slot + touched flag
 #define ACC_CARRY 64
 #define ACC_TOUCH 65
-#define LIST_CAP 512
+#define LIST_CAP 256
 
 // classification of a (tile, path) pair
 #define CLS_PARTIAL 1u                // some row needs the general accumulate + scan path
@@ -746,18 +746,18 @@ __device__ void full_edge(const Rec& rec, int sign, int* acc, const TileCtx& c) 
     }
 }
 
-// phase 1 of a partial tor path: every (row, record) adds its cells into acc (LDS atomics)
+// phase 1 of a partial tor path: lane = (row, slot); every record of the row adds its cells into acc (LDS atomics)
 __device__ __forceinline__ void accumulate_path(const DevPath& P, uint32_t row_base_p, const RowInfo* __restrict__ rows,
                                                 const Rec* __restrict__ records,
-                                                int (*acc)[ACC_STRIDE], int tx0, int ty0, int tid) {
-    const int row = tid >> 4, slot = tid & 15;
+                                                int (*acc)[ACC_STRIDE], int tx0, int ty0, int lane) {
+    const int row = lane >> 2, slot = lane & 3;
     const int y = ty0 + row;
     if (y < P.y_min || y >= P.y_max) return;
     const RowInfo ri = rows[row_base_p + (uint32_t)(y - P.y_min)];
     if (!ri.n_rec) return;
     TileCtx c; c.tx0 = tx0; c.xminp = P.x_min; c.xmaxp = P.x_max;
     if (slot == 0) acc[row][ACC_TOUCH] = 1;
-    for (uint32_t k = slot; k < ri.n_rec; k += 16) {
+    for (uint32_t k = slot; k < ri.n_rec; k += 4) {
         const Rec rec = records[ri.rec_off + k];
         const int clo = (int)(rec.cols & 0xffffu), chi = (int)(rec.cols >> 16);
         if (clo >= tx0 + TILE_W && clo < 65535) continue;           // entirely right of the tile
@@ -783,21 +783,32 @@ __device__ __forceinline__ void accumulate_path(const DevPath& P, uint32_t row_b
     }
 }
 
-__global__ __launch_bounds__(256) void k_tiles(const swfr_edge* __restrict__ raw_edges, const DevEdge* __restrict__ edges,
-                                               const DevPath* __restrict__ paths, const uint32_t* __restrict__ band_off,
-                                               const uint32_t* __restrict__ band_list,
-                                               const uint32_t* __restrict__ row_base, const RowInfo* __restrict__ rows,
-                                               const Rec* __restrict__ records, const swfr_style* __restrict__ styles,
-                                               const DevBitmap* __restrict__ bitmaps, uint32_t* __restrict__ fb,
-                                               int width, int height, int tiles_x, uint32_t band_index, uint32_t band_count, int dbg) {
-    __shared__ int acc[2][TILE_H][ACC_STRIDE];
+__device__ __forceinline__ uint32_t blend_pixel(uint32_t dst, uint32_t a, const DevPath& P, const swfr_style& S, uint32_t kind,
+                                                uint32_t solid, const DevBitmap* __restrict__ bitmaps, int cx, int cy) {
+    if (kind == SWFR_STYLE_SOLID) {
+        if (P.lerp) return a == 255u ? solid : lerp_pixel(solid, a, dst);
+        return over_pixel(a == 255u ? solid : mul_un8(solid, a), dst);
+    }
+    const uint32_t s = mul_un8(shade(S, bitmaps, cx, cy), a);
+    return P.lerp ? s : over_pixel(s, dst);
+}
+
+// One wavefront per 64x16 tile: lane = pixel column, 16 rows of premultiplied pixels live in registers.
+// No workgroup barriers anywhere: LDS traffic of a wave is ordered.
+__global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_edges,
+                                              const DevPath* __restrict__ paths, const uint32_t* __restrict__ band_off,
+                                              const uint32_t* __restrict__ band_list,
+                                              const uint32_t* __restrict__ row_base, const RowInfo* __restrict__ rows,
+                                              const Rec* __restrict__ records, const swfr_style* __restrict__ styles,
+                                              const DevBitmap* __restrict__ bitmaps, uint32_t* __restrict__ fb,
+                                              int width, int height, int tiles_x, uint32_t band_index, uint32_t band_count, int dbg,
+                                              uint32_t* __restrict__ counters) {
+    __shared__ int acc[TILE_H][ACC_STRIDE];
+    __shared__ uint32_t px[TILE_H][TILE_W];
     __shared__ uint32_t list[LIST_CAP];
     __shared__ uint32_t cls[LIST_CAP];
-    __shared__ uint32_t wave_cnt[4];
-    __shared__ uint32_t list_n;
-    __shared__ int cover_from;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane = threadIdx.x;
     // blockIdx -> tile: consecutive workgroups walk along x inside one tile-row, so the 8 tiles that are
     // co-scheduled round-robin over the 8 XCDs read the same band list / path records
     const int tile = blockIdx.x;
@@ -807,18 +818,20 @@ __global__ __launch_bounds__(256) void k_tiles(const swfr_edge* __restrict__ raw
     const int tx0 = tcol * TILE_W, ty0 = trow * TILE_H;
     if (ty0 >= height) return;
     const int tile_x1 = min(tx0 + TILE_W, width), tile_y1 = min(ty0 + TILE_H, height);
+    const int cx = tx0 + lane;
+    const unsigned long long t_start = dbg == 8 ? __builtin_amdgcn_s_memtime() : 0ull;
 
-    uint32_t px[4] = {0u, 0u, 0u, 0u};                    // rows 4*wave .. 4*wave+3, column tx0+lane (premultiplied ARGB)
-    for (int i = tid; i < 2 * TILE_H * ACC_STRIDE; i += 256) (&acc[0][0][0])[i] = 0;
+    // tile-resident pixels (premultiplied ARGB) live in LDS: row loops stay rolled (small code, few VGPRs)
+    for (int rr = 0; rr < TILE_H; ++rr) px[rr][lane] = 0u;
+    for (int i = lane; i < TILE_H * ACC_STRIDE; i += 64) (&acc[0][0])[i] = 0;
 
     const uint32_t band_begin = band_off[trow], band_end = band_off[trow + 1];
     for (uint32_t chunk = band_begin; chunk < band_end; chunk += LIST_CAP) {
-        // ---- bin: paths of the band whose pixel rectangle overlaps the tile, in painter's order
-        if (tid == 0) { list_n = 0; cover_from = 0; }
-        __syncthreads();
+        // ---- bin: paths of the band whose pixel rectangle overlaps the tile, in painter's order (wave-local)
         const uint32_t chunk_end = min(chunk + LIST_CAP, band_end);
-        for (uint32_t base = chunk; base < chunk_end; base += 256) {
-            const uint32_t bi = base + tid;
+        int ln = 0;
+        for (uint32_t base = chunk; base < chunk_end; base += 64) {
+            const uint32_t bi = base + lane;
             bool hit = false;
             uint32_t p = 0;
             if (bi < chunk_end) {
@@ -827,21 +840,15 @@ __global__ __launch_bounds__(256) void k_tiles(const swfr_edge* __restrict__ raw
                 hit = P.x_min < tile_x1 && P.x_max > tx0 && P.y_min < tile_y1 && P.y_max > ty0;
             }
             const unsigned long long b = __ballot(hit);
-            if (lane == 0) wave_cnt[wave] = __popcll(b);
-            __syncthreads();
-            uint32_t off = list_n;
-            for (int w = 0; w < wave; ++w) off += wave_cnt[w];
-            if (hit) { const uint32_t at = off + __popcll(b & ((1ull << lane) - 1ull)); list[at] = p; cls[at] = 0; }
-            __syncthreads();
-            if (tid == 0) list_n += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-            __syncthreads();
+            if (hit) { const int at = ln + __popcll(b & ((1ull << lane) - 1ull)); list[at] = p; cls[at] = 0; }
+            ln += __popcll(b);
         }
-        int ln = (int)list_n;
         if (dbg == 1) ln = 0;
 
-        // ---- classify every (tile, path): 16 paths x 16 rows per pass; no edge arithmetic, records only
-        for (int base = 0; base < ln; base += 16) {
-            const int li = base + (tid >> 4), row = tid & 15;
+        // ---- classify every (tile, path): 4 paths x 16 rows per pass; no edge arithmetic, record headers only
+        for (int it0 = 0; it0 < ln * TILE_H; it0 += 64) {
+            const int it = it0 + lane;
+            const int li = it >> 4, row = it & 15;
             const int y = ty0 + row;
             if (li < ln && y < height) {
                 const uint32_t pi = list[li];
@@ -860,9 +867,10 @@ __global__ __launch_bounds__(256) void k_tiles(const swfr_edge* __restrict__ raw
                     int carry = 0;
                     bool inter = false;
                     for (uint32_t k = 0; k < ri.n_rec; ++k) {
-                        const Rec rec = records[ri.rec_off + k];
-                        const int clo = (int)(rec.cols & 0xffffu), chi = (int)(rec.cols >> 16);
-                        if (chi < tx0 && chi < 65535) carry += record_height(rec.roles);
+                        const Rec* rp = &records[ri.rec_off + k];
+                        const uint32_t rroles = rp->roles, rcols = rp->cols;
+                        const int clo = (int)(rcols & 0xffffu), chi = (int)(rcols >> 16);
+                        if (chi < tx0 && chi < 65535) carry += record_height(rroles);
                         else if (clo >= tx0 + TILE_W && clo < 65535) { /* right of the tile */ }
                         else inter = true;
                     }
@@ -876,121 +884,89 @@ __global__ __launch_bounds__(256) void k_tiles(const swfr_edge* __restrict__ raw
                 if (f) atomicOr(&cls[li], f);
             }
         }
-        __syncthreads();
         // ---- occlusion: everything below the last opaque, lerp-blended full cover is invisible in this tile
-        for (int li = tid; li < ln; li += 256) {
-            const uint32_t f = cls[li];
-            if ((f & (CLS_PARTIAL | CLS_NOTFULL | CLS_BOX)) == 0 && (f & CLS_NONEMPTY)) {
-                const DevPath P = paths[list[li]];
-                const swfr_style& S = styles[P.style];
-                if (P.lerp && S.kind == SWFR_STYLE_SOLID && (S.pixel >> 24) == 0xffu) atomicMax(&cover_from, li);
+        int start = 0;
+        for (int base = 0; base < ln; base += 64) {
+            const int li = base + lane;
+            bool cover = false;
+            if (li < ln) {
+                const uint32_t f = cls[li];
+                if ((f & (CLS_PARTIAL | CLS_NOTFULL | CLS_BOX)) == 0 && (f & CLS_NONEMPTY)) {
+                    const DevPath P = paths[list[li]];
+                    const swfr_style& S = styles[P.style];
+                    cover = P.lerp && S.kind == SWFR_STYLE_SOLID && (S.pixel >> 24) == 0xffu;
+                }
             }
+            const unsigned long long b = __ballot(cover);
+            if (b) start = base + 63 - __clzll((long long)b);
         }
-        __syncthreads();
-        const int start = dbg == 2 ? ln : cover_from;
+        if (dbg == 2) start = ln;
+        if (dbg == 9 && lane == 0) {                          // statistics (SWFR_TILES_DEBUG=9)
+            uint32_t np = 0, nf = 0;
+            for (int li = start; li < ln; ++li) { const uint32_t f = cls[li]; if (f & CLS_NONEMPTY) { if (f & (CLS_PARTIAL | CLS_BOX)) ++np; else ++nf; } }
+            atomicAdd(&counters[CNT_PAIRS], (uint32_t)ln); atomicAdd(&counters[CNT_PARTIAL], np); atomicAdd(&counters[CNT_FULL], nf);
+            atomicAdd(&counters[CNT_CULLED], (uint32_t)start);
+        }
 
-        // ---- painter's order walk; tor-partial paths are software pipelined over two accumulator buffers
-        int buf = 0;
-        int nxt = -1;                                          // next partial tor path at or after `start`
-        for (int li = start; li < ln; ++li) if ((cls[li] & (CLS_PARTIAL | CLS_BOX)) == CLS_PARTIAL) { nxt = li; break; }
-        if (nxt >= 0 && dbg != 3) {
-            const uint32_t pi = list[nxt];
-            accumulate_path(paths[pi], row_base[pi], rows, records, acc[buf], tx0, ty0, tid);
-        }
-        __syncthreads();
+        // ---- painter's order walk
         for (int li = start; li < ln; ++li) {
-            const uint32_t f = cls[li];
+            const uint32_t f = __builtin_amdgcn_readfirstlane(cls[li]);
             if (!(f & CLS_NONEMPTY)) continue;
-            const uint32_t pi = list[li];
+            const uint32_t pi = __builtin_amdgcn_readfirstlane(list[li]);
             const DevPath P = paths[pi];
-            const int row_lo = max(P.y_min, ty0), row_hi = min(P.y_max, ty0 + TILE_H);
-            uint32_t alpha[4] = {0u, 0u, 0u, 0u};
-            const bool is_partial_tor = (f & (CLS_PARTIAL | CLS_BOX)) == CLS_PARTIAL && dbg != 3;
+            const swfr_style& S = styles[P.style];
+            const uint32_t kind = S.kind, solid = S.pixel;
+            const int row_lo = max(P.y_min, ty0) - ty0, row_hi = min(P.y_max, ty0 + TILE_H) - ty0;
             if (f & CLS_BOX) {
                 // ---- rectilinear (A.6): exact area of disjoint boxes, alpha = (c>>8) - (c>>16)
-                uint32_t cov[4] = {0u, 0u, 0u, 0u};
-                const int cx = tx0 + lane;
-                for (uint32_t k = 0; k < P.n_edges; ++k) {
-                    const swfr_edge bx = raw_edges[P.first_edge + k];
-                    const int wx = min(bx.x2, (cx + 1) * 256) - max(bx.x1, cx * 256);
-                    if (wx <= 0) continue;
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) {
-                        const int cy = ty0 + wave * 4 + rr;
+#pragma unroll 1
+                for (int rr = row_lo; rr < row_hi; ++rr) {
+                    const int cy = ty0 + rr;
+                    uint32_t cov = 0u;
+                    for (uint32_t k = 0; k < P.n_edges; ++k) {
+                        const swfr_edge bx = raw_edges[P.first_edge + k];
+                        const int wx = min(bx.x2, (cx + 1) * 256) - max(bx.x1, cx * 256);
                         const int wy = min(bx.y2, (cy + 1) * 256) - max(bx.y1, cy * 256);
-                        if (wy > 0) cov[rr] += (uint32_t)(wx * wy);
+                        if (wx > 0 && wy > 0) cov += (uint32_t)(wx * wy);
                     }
+                    const uint32_t a = ((cov >> 8) - (cov >> 16)) & 255u;
+                    if (a) px[rr][lane] = blend_pixel(px[rr][lane], a, P, S, kind, solid, bitmaps, cx, cy);
                 }
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) alpha[rr] = ((cov[rr] >> 8) - (cov[rr] >> 16)) & 255u;
-            } else if (is_partial_tor) {
-                // phase 1 of the NEXT partial path goes into the other buffer while this one is consumed
-                nxt = -1;
-                for (int lj = li + 1; lj < ln; ++lj) if ((cls[lj] & (CLS_PARTIAL | CLS_BOX)) == CLS_PARTIAL) { nxt = lj; break; }
-                if (nxt >= 0) {
-                    const uint32_t pn = list[nxt];
-                    accumulate_path(paths[pn], row_base[pn], rows, records, acc[buf ^ 1], tx0, ty0, tid);
-                }
-                // phase 2: per row, wave64 prefix sum of covered height, coverage -> alpha; clears as it reads
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const int rw = wave * 4 + rr;
-                    if (!acc[buf][rw][ACC_TOUCH]) continue;            // wave-uniform
-                    const int v = acc[buf][rw][lane];
-                    const int carry = acc[buf][rw][ACC_CARRY];
-                    acc[buf][rw][lane] = 0;
-                    if (lane < 2) acc[buf][rw][ACC_CARRY + lane] = 0;
+            } else if ((f & CLS_PARTIAL) && dbg != 3) {
+                // ---- tor (A.5): records -> covered height / uncovered area per cell, prefix sum, alpha
+                if (dbg != 5) accumulate_path(P, row_base[pi], rows, records, acc, tx0, ty0, lane);
+#pragma unroll 1
+                for (int rr = row_lo; rr < row_hi; ++rr) {
+                    if (dbg == 4) continue;
+                    if (!acc[rr][ACC_TOUCH] && dbg != 5) continue;     // wave-uniform
+                    const int v = acc[rr][lane];
+                    const int carry = acc[rr][ACC_CARRY];
+                    acc[rr][lane] = 0;
+                    if (lane < 2) acc[rr][ACC_CARRY + lane] = 0;
                     const int ua = (v << 12) >> 12;                    // low 20 bits, sign-extended
                     int ch = (v - ua) >> 20;
                     if (lane == 0) ch += carry;
                     const int scan = wave_scan_incl(ch);
                     const int area = scan * 512 - ua;
                     uint32_t a = (uint32_t)((area * 17 + 256) >> 9) & 255u;
-                    const int cx = tx0 + lane;
                     if (cx < P.x_min || cx >= P.x_max) a = 0;
-                    alpha[rr] = a;
+                    if (a) px[rr][lane] = blend_pixel(px[rr][lane], a, P, S, kind, solid, bitmaps, cx, ty0 + rr);
                 }
-            } else {
+            } else if (!(f & CLS_PARTIAL)) {
                 // full cover: every in-frame pixel of the tile has coverage 255
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) alpha[rr] = 255u;
+#pragma unroll 1
+                for (int rr = row_lo; rr < row_hi; ++rr) px[rr][lane] = blend_pixel(px[rr][lane], 255u, P, S, kind, solid, bitmaps, cx, ty0 + rr);
             }
-
-            // ---- shade + blend (A.7) into the tile-resident pixels
-            const swfr_style& S = styles[P.style];
-            const uint32_t kind = S.kind;
-            const uint32_t solid = S.pixel;
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const uint32_t a = alpha[rr];
-                if (!a) continue;
-                const int cy = ty0 + wave * 4 + rr;
-                if (cy < row_lo || cy >= row_hi) continue;
-                if (kind == SWFR_STYLE_SOLID) {
-                    if (P.lerp) {
-                        px[rr] = a == 255u ? solid : lerp_pixel(solid, a, px[rr]);
-                    } else {
-                        const uint32_t s = a == 255u ? solid : mul_un8(solid, a);
-                        px[rr] = over_pixel(s, px[rr]);
-                    }
-                } else {
-                    const uint32_t s = mul_un8(shade(S, bitmaps, tx0 + lane, cy), a);
-                    px[rr] = P.lerp ? s : over_pixel(s, px[rr]);
-                }
-            }
-            if (is_partial_tor) { __syncthreads(); buf ^= 1; }
         }
-        __syncthreads();
     }
 
-    // ---- one store per pixel: premultiplied R,G,B,A bytes; a wave writes 256 contiguous bytes per row
-    const int cx = tx0 + lane;
+    if (dbg == 8 && lane == 0) px[0][0] = (uint32_t)(__builtin_amdgcn_s_memtime() - t_start);   // diagnostics: tile duration in clocks
+    // ---- one store per pixel: premultiplied R,G,B,A bytes; the wave writes 256 contiguous bytes per row
     if (cx < width) {
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int cy = ty0 + wave * 4 + rr;
-            if (cy >= height) continue;
-            const uint32_t p = px[rr];
+        for (int rr = 0; rr < TILE_H; ++rr) {
+            const int cy = ty0 + rr;
+            if (cy >= height) break;
+            const uint32_t p = px[rr][lane];
             const uint32_t rgba = (p & 0xff00ff00u) | ((p >> 16) & 0xffu) | ((p & 0xffu) << 16);
             fb[(size_t)cy * (size_t)width + cx] = rgba;
         }
@@ -1047,13 +1023,14 @@ void launch_rows(hipStream_t st, const DevEdge* edges, const DevPath* paths, con
 void launch_tiles(hipStream_t st, const swfr_edge* raw, const DevEdge* edges, const DevPath* paths, const uint32_t* band_off,
                   const uint32_t* band_list, const uint32_t* row_base, const RowInfo* rows, const Rec* records,
                   const swfr_style* styles, const DevBitmap* bitmaps, uint32_t* fb, int width, int height, uint32_t band_index,
-                  uint32_t band_count, int dbg) {
+                  uint32_t band_count, int dbg, uint32_t* counters) {
+    (void)edges;
     const int tiles_x = (width + TILE_W - 1) / TILE_W, tile_rows = (height + TILE_H - 1) / TILE_H;
     uint32_t local_rows = tile_rows;
     if (band_count > 1) local_rows = (tile_rows > (int)band_index) ? (tile_rows - band_index + band_count - 1) / band_count : 0;
     if (!local_rows) return;
-    hipLaunchKernelGGL(k_tiles, dim3(tiles_x * local_rows), dim3(256), 0, st, raw, edges, paths, band_off, band_list, row_base, rows,
-                       records, styles, bitmaps, fb, width, height, tiles_x, band_index, band_count, dbg);
+    hipLaunchKernelGGL(k_tiles, dim3(tiles_x * local_rows), dim3(64), 0, st, raw, paths, band_off, band_list, row_base, rows,
+                       records, styles, bitmaps, fb, width, height, tiles_x, band_index, band_count, dbg, counters);
 }
 void launch_unpremultiply(hipStream_t st, const uint32_t* in, uint32_t* out, size_t n) {
     if (!n) return;

@@ -26,7 +26,7 @@ void launch_bands(hipStream_t, const DevPath*, uint32_t, const uint32_t*, uint32
 void launch_rows(hipStream_t, const DevEdge*, const DevPath*, const uint32_t*, const uint32_t*, uint32_t, RowInfo*, Rec*, uint32_t*,
                  uint32_t*, uint32_t, uint32_t, uint32_t, int);
 void launch_tiles(hipStream_t, const swfr_edge*, const DevEdge*, const DevPath*, const uint32_t*, const uint32_t*, const uint32_t*,
-                  const RowInfo*, const Rec*, const swfr_style*, const DevBitmap*, uint32_t*, int, int, uint32_t, uint32_t, int);
+                  const RowInfo*, const Rec*, const swfr_style*, const DevBitmap*, uint32_t*, int, int, uint32_t, uint32_t, int, uint32_t*);
 void launch_unpremultiply(hipStream_t, const uint32_t*, uint32_t*, size_t);
 void launch_pack_band(hipStream_t, const uint32_t*, uint32_t*, int, int, uint32_t, uint32_t, uint32_t);
 }  // namespace swfr
@@ -232,7 +232,7 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
     if (frames == 0) frames = 1;
     const uint32_t bc = r->cfg.band_count > 1 ? r->cfg.band_count : 1, bi = r->cfg.band_count > 1 ? r->cfg.band_index : 0;
     float setup_ms = 0, rows_ms = 0, tiles_ms = 0, total_ms = 0;
-    uint32_t counters[CNT_WORDS] = {0, 0, 0, 0};
+    uint32_t counters[CNT_WORDS] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (frames > 4096) frames = 4096;
     while (r->ev.size() < size_t(frames) * 4) {
         hipEvent_t e = nullptr;
@@ -254,7 +254,7 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
                         r->d_records.ptr, r->d_counters.ptr, r->d_overflow.ptr, uint32_t(r->n_chunks), bi, bc, r->fast_limit);
         HIP_CHECK(hipEventRecord(e[2], r->stream));
         launch_tiles(r->stream, r->d_raw.ptr, r->d_edges.ptr, r->d_paths.ptr, r->d_band_off.ptr, r->d_band_list.ptr, r->d_row_base.ptr,
-                     r->d_rows.ptr, r->d_records.ptr, r->d_styles.ptr, r->d_bitmap_table.ptr, r->d_fb.ptr, int(r->width), int(r->height), bi, bc, r->tiles_dbg);
+                     r->d_rows.ptr, r->d_records.ptr, r->d_styles.ptr, r->d_bitmap_table.ptr, r->d_fb.ptr, int(r->width), int(r->height), bi, bc, r->tiles_dbg, r->d_counters.ptr);
         HIP_CHECK(hipEventRecord(e[3], r->stream));
     }
     HIP_CHECK(hipGetLastError());
@@ -270,6 +270,9 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
     HIP_CHECK(hipEventElapsedTime(&total_ms, r->ev[0], r->ev[size_t(frames - 1) * 4 + 3]));
     HIP_CHECK(hipMemcpy(counters, r->d_counters.ptr, sizeof counters, hipMemcpyDeviceToHost));
     r->timing = swfr_timing{total_ms, setup_ms, rows_ms, tiles_ms, frames, r->n_edges, r->n_paths, r->n_tasks, counters[CNT_RECORDS]};
+    if (r->tiles_dbg == 9)
+        std::fprintf(stderr, "[swfr] tile/path pairs %u, partial %u, full %u, culled entries %u, records %u, overflow rows %u\n", counters[CNT_PAIRS],
+                     counters[CNT_PARTIAL], counters[CNT_FULL], counters[CNT_CULLED], counters[CNT_RECORDS], counters[CNT_OVERFLOW]);
     r->fb_valid = true;
     if (counters[CNT_ERROR]) {
         r->fb_valid = false;
