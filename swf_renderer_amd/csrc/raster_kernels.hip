@@ -127,25 +127,44 @@ __global__ __launch_bounds__(256) void k_setup(const swfr_edge* __restrict__ in,
 // k_bands: per tile-row, the paths whose pixel rows intersect it, in painter's order
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_bands(const DevPath* __restrict__ paths, uint32_t n_paths,
-                                               const uint32_t* __restrict__ band_off, uint32_t* __restrict__ band_list) {
+                                               const uint32_t* __restrict__ row_base, const swfr_style* __restrict__ styles,
+                                               const uint32_t* __restrict__ band_off, BandEntry* __restrict__ band_list,
+                                               uint32_t* __restrict__ counters) {
     __shared__ uint32_t wave_cnt[4];
     __shared__ uint32_t total;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int band = blockIdx.x;
     const int y0 = band * TILE_H, y1 = y0 + TILE_H;
-    uint32_t* out = band_list + band_off[band];
+    BandEntry* out = band_list + band_off[band];
     if (tid == 0) total = 0;
     __syncthreads();
     for (uint32_t base = 0; base < n_paths; base += 256) {
         const uint32_t p = base + tid;
         bool hit = false;
-        if (p < n_paths) { const DevPath P = paths[p]; hit = P.y_min < y1 && P.y_max > y0; }
+        DevPath P;
+        if (p < n_paths) { P = paths[p]; hit = P.y_min < y1 && P.y_max > y0 && P.x_max > P.x_min; }
         const unsigned long long b = __ballot(hit);
         if (lane == 0) wave_cnt[wave] = __popcll(b);
         __syncthreads();
         uint32_t off = total;
         for (int w = 0; w < wave; ++w) off += wave_cnt[w];
-        if (hit) out[off + __popcll(b & ((1ull << lane) - 1ull))] = p;
+        if (hit) {
+            BandEntry e;
+            e.path = p;
+            e.x_min = (int16_t)P.x_min; e.x_max = (int16_t)P.x_max; e.y_min = (int16_t)P.y_min; e.y_max = (int16_t)P.y_max;
+            e.row_base = row_base[p];
+            e.style = P.style; e.first_edge = P.first_edge; e.n_edges = P.n_edges;
+            const uint32_t kind = styles[P.style].kind, pixel = styles[P.style].pixel;
+            uint32_t fl = 0;
+            if (P.kind == SWFR_PATH_BOXES) fl |= BE_BOXES;
+            if (P.lerp) fl |= BE_LERP;
+            if (kind == SWFR_STYLE_SOLID) fl |= BE_SOLID;
+            if (kind == SWFR_STYLE_SOLID && P.lerp && (pixel >> 24) == 0xffu) fl |= BE_OPAQUE_COVER;
+            e.flags = fl; e.solid = pixel;
+            e.tc0 = (uint32_t)(P.x_min / TILE_W);
+            e.pair_off = atomicAdd(&counters[CNT_PAIR_ALLOC], (uint32_t)((P.x_max - 1) / TILE_W) - e.tc0 + 1u);
+            out[off + __popcll(b & ((1ull << lane) - 1ull))] = e;
+        }
         __syncthreads();
         if (tid == 0) total += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
         __syncthreads();
@@ -746,27 +765,76 @@ __device__ void full_edge(const Rec& rec, int sign, int* acc, const TileCtx& c) 
     }
 }
 
-// phase 1 of a partial tor path: lane = (row, slot); every record of the row adds its cells into acc (LDS atomics)
-__device__ __forceinline__ void accumulate_path(const DevPath& P, uint32_t row_base_p, const RowInfo* __restrict__ rows,
-                                                const Rec* __restrict__ records,
-                                                int (*acc)[ACC_STRIDE], int tx0, int ty0, int lane) {
-    const int row = lane >> 2, slot = lane & 3;
-    const int y = ty0 + row;
-    if (y < P.y_min || y >= P.y_max) return;
-    const RowInfo ri = rows[row_base_p + (uint32_t)(y - P.y_min)];
-    if (!ri.n_rec) return;
-    TileCtx c; c.tx0 = tx0; c.xminp = P.x_min; c.xmaxp = P.x_max;
-    if (slot == 0) acc[row][ACC_TOUCH] = 1;
-    for (uint32_t k = slot; k < ri.n_rec; k += 4) {
+
+// ---------------------------------------------------------------------------------------------
+// k_class: one wavefront per band entry (path x tile-row); lane = tile column of the path's pixel rectangle.
+// Classifies every (tile, path) pair from the record headers alone (uniform loads, no edge arithmetic):
+// CLS_PARTIAL (a boundary passes through the tile), full cover, or empty.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_class(const BandEntry* __restrict__ band_list, uint32_t n_entries,
+                                              const uint32_t* __restrict__ band_of_entry_off, uint32_t n_bands,
+                                              const swfr_edge* __restrict__ raw_edges, const RowInfo* __restrict__ rows,
+                                              const Rec* __restrict__ records, uint8_t* __restrict__ cls_mat, int width, int height) {
+    const uint32_t ei = blockIdx.x;
+    if (ei >= n_entries) return;
+    const int lane = threadIdx.x;
+    const BandEntry e = band_list[ei];
+    // band of this entry: upper_bound on the band offsets (wave-uniform)
+    uint32_t lo = 0, hi = n_bands;
+    while (lo + 1 < hi) { const uint32_t mid = (lo + hi) >> 1; if (band_of_entry_off[mid] <= ei) lo = mid; else hi = mid; }
+    const int ty0 = (int)lo * TILE_H;
+    const int tc1 = ((int)e.x_max - 1) / TILE_W;
+    for (int tc = (int)e.tc0 + lane; tc <= tc1; tc += 64) {
+        const int tx0 = tc * TILE_W, tile_x1 = min(tx0 + TILE_W, width), tile_y1 = min(ty0 + TILE_H, height);
+        uint32_t flags = 0;
+        if (e.flags & BE_BOXES) {
+            flags = CLS_BOX | CLS_NONEMPTY | CLS_NOTFULL;
+            if (e.n_edges == 1) {                 // one box that contains the whole tile: full cover
+                const swfr_edge bx = raw_edges[e.first_edge];
+                if (bx.x1 <= tx0 * 256 && bx.x2 >= tile_x1 * 256 && bx.y1 <= ty0 * 256 && bx.y2 >= tile_y1 * 256) flags = CLS_NONEMPTY;
+            }
+        } else {
+            const bool inside_x = e.x_min <= tx0 && e.x_max >= tile_x1;
+            for (int y = ty0; y < tile_y1; ++y) {
+                if (y < e.y_min || y >= e.y_max) { flags |= CLS_NOTFULL; continue; }
+                const RowInfo ri = rows[e.row_base + (uint32_t)(y - e.y_min)];
+                int carry = 0;
+                bool inter = false;
+                for (uint32_t k = 0; k < ri.n_rec; ++k) {
+                    const Rec* rp = &records[ri.rec_off + k];
+                    const uint32_t rroles = rp->roles, rcols = rp->cols;
+                    const int clo = (int)(rcols & 0xffffu), chi = (int)(rcols >> 16);
+                    if (chi < tx0 && chi < 65535) carry += record_height(rroles);
+                    else if (clo >= tx0 + TILE_W && clo < 65535) { /* right of the tile */ }
+                    else inter = true;
+                }
+                const uint32_t a = (uint32_t)((carry * 512 * 17 + 256) >> 9) & 255u;
+                if (inter) flags |= CLS_PARTIAL | CLS_NOTFULL | CLS_NONEMPTY;
+                else if (a == 0) flags |= CLS_NOTFULL;
+                else if (a == 255 && inside_x) flags |= CLS_NONEMPTY;
+                else flags |= CLS_PARTIAL | CLS_NOTFULL | CLS_NONEMPTY;   // uniform partial alpha or column masking
+            }
+        }
+        cls_mat[e.pair_off + (uint32_t)(tc - (int)e.tc0)] = (uint8_t)flags;
+    }
+}
+
+#define NACC 2                         // partial paths accumulated concurrently (one acc buffer each)
+#define TLIST 96                       // tile list entries processed per round (scan stops once > TLIST-64 are found)
+
+// records of one (path, row) -> covered height / uncovered area per cell (LDS atomics into `acc`)
+__device__ __forceinline__ void accumulate_row(const RowInfo ri, const Rec* __restrict__ records, int* acc, const TileCtx& c,
+                                               int slot, int nslots) {
+    for (uint32_t k = (uint32_t)slot; k < ri.n_rec; k += (uint32_t)nslots) {
         const Rec rec = records[ri.rec_off + k];
         const int clo = (int)(rec.cols & 0xffffu), chi = (int)(rec.cols >> 16);
-        if (clo >= tx0 + TILE_W && clo < 65535) continue;           // entirely right of the tile
-        if (chi < tx0 && chi < 65535) {                             // entirely left: only its net height reaches us
-            cell_add(acc[row], c, chi, record_height(rec.roles), 0);
+        if (clo >= c.tx0 + TILE_W && clo < 65535) continue;         // entirely right of the tile
+        if (chi < c.tx0 && chi < 65535) {                           // entirely left: only its net height reaches us
+            cell_add(acc, c, chi, record_height(rec.roles), 0);
             continue;
         }
         if (rec.roles & REC_FULL) {
-            full_edge(rec, (rec.roles & 1u) ? +1 : -1, acc[row], c);
+            full_edge(rec, (rec.roles & 1u) ? +1 : -1, acc, c);
         } else {
             const int first = (int)(rec.span & 255u), last = (int)(rec.span >> 8);
             int32_t q = rec.q1; int64_t rm = rec.r1;
@@ -775,7 +843,7 @@ __device__ __forceinline__ void accumulate_path(const DevPath& P, uint32_t row_b
                 if (role) {
                     const int cell = rec.dy ? cell_of(q, rm, rec.dy) : q;
                     const int sgn = role == 1 ? 1 : -1;
-                    cell_add(acc[row], c, cell >> 8, sgn, sgn * 2 * (cell & 255));
+                    cell_add(acc, c, cell >> 8, sgn, sgn * 2 * (cell & 255));
                 }
                 if (rec.dy) { q += rec.q2; rm += rec.r2; if (rm < 0) { --q; rm += rec.dy; } else if (rm >= rec.dy) { ++q; rm -= rec.dy; } }
             }
@@ -783,30 +851,30 @@ __device__ __forceinline__ void accumulate_path(const DevPath& P, uint32_t row_b
     }
 }
 
-__device__ __forceinline__ uint32_t blend_pixel(uint32_t dst, uint32_t a, const DevPath& P, const swfr_style& S, uint32_t kind,
-                                                uint32_t solid, const DevBitmap* __restrict__ bitmaps, int cx, int cy) {
-    if (kind == SWFR_STYLE_SOLID) {
-        if (P.lerp) return a == 255u ? solid : lerp_pixel(solid, a, dst);
+__device__ __forceinline__ uint32_t blend_pixel(uint32_t dst, uint32_t a, uint32_t eflags, uint32_t solid, const swfr_style* __restrict__ styles,
+                                                uint32_t style, const DevBitmap* __restrict__ bitmaps, int cx, int cy) {
+    if (eflags & BE_SOLID) {
+        if (eflags & BE_LERP) return a == 255u ? solid : lerp_pixel(solid, a, dst);
         return over_pixel(a == 255u ? solid : mul_un8(solid, a), dst);
     }
-    const uint32_t s = mul_un8(shade(S, bitmaps, cx, cy), a);
-    return P.lerp ? s : over_pixel(s, dst);
+    const uint32_t s = mul_un8(shade(styles[style], bitmaps, cx, cy), a);
+    return (eflags & BE_LERP) ? s : over_pixel(s, dst);
 }
 
-// One wavefront per 64x16 tile: lane = pixel column, 16 rows of premultiplied pixels live in registers.
-// No workgroup barriers anywhere: LDS traffic of a wave is ordered.
+// One wavefront per 64x16 tile: lane = pixel column, the tile's pixels live in LDS.  No workgroup barriers:
+// LDS traffic of a wave is ordered.  Global memory is touched in few dependent steps per tile:
+// band entries -> row headers -> records, with NACC partial paths' records in flight at once.
 __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_edges,
-                                              const DevPath* __restrict__ paths, const uint32_t* __restrict__ band_off,
-                                              const uint32_t* __restrict__ band_list,
-                                              const uint32_t* __restrict__ row_base, const RowInfo* __restrict__ rows,
+                                              const uint32_t* __restrict__ band_off, const BandEntry* __restrict__ band_list,
+                                              const uint8_t* __restrict__ cls_mat, const RowInfo* __restrict__ rows,
                                               const Rec* __restrict__ records, const swfr_style* __restrict__ styles,
                                               const DevBitmap* __restrict__ bitmaps, uint32_t* __restrict__ fb,
                                               int width, int height, int tiles_x, uint32_t band_index, uint32_t band_count, int dbg,
                                               uint32_t* __restrict__ counters) {
-    __shared__ int acc[TILE_H][ACC_STRIDE];
+    __shared__ int acc[NACC][TILE_H][ACC_STRIDE];
     __shared__ uint32_t px[TILE_H][TILE_W];
-    __shared__ uint32_t list[LIST_CAP];
-    __shared__ uint32_t cls[LIST_CAP];
+    __shared__ BandEntry ent[TLIST];
+    __shared__ uint32_t cls[TLIST];
 
     const int lane = threadIdx.x;
     // blockIdx -> tile: consecutive workgroups walk along x inside one tile-row, so the 8 tiles that are
@@ -820,70 +888,34 @@ __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_
     const int tile_x1 = min(tx0 + TILE_W, width), tile_y1 = min(ty0 + TILE_H, height);
     const int cx = tx0 + lane;
     const unsigned long long t_start = dbg == 8 ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long t_start10 = dbg == 10 ? __builtin_amdgcn_s_memtime() : 0ull;
 
-    // tile-resident pixels (premultiplied ARGB) live in LDS: row loops stay rolled (small code, few VGPRs)
     for (int rr = 0; rr < TILE_H; ++rr) px[rr][lane] = 0u;
-    for (int i = lane; i < TILE_H * ACC_STRIDE; i += 64) (&acc[0][0])[i] = 0;
+    for (int i = lane; i < NACC * TILE_H * ACC_STRIDE; i += 64) (&acc[0][0][0])[i] = 0;
 
     const uint32_t band_begin = band_off[trow], band_end = band_off[trow + 1];
-    for (uint32_t chunk = band_begin; chunk < band_end; chunk += LIST_CAP) {
-        // ---- bin: paths of the band whose pixel rectangle overlaps the tile, in painter's order (wave-local)
-        const uint32_t chunk_end = min(chunk + LIST_CAP, band_end);
+    uint32_t next = band_begin;
+    while (next < band_end) {
+        // ---- bin: up to TLIST entries of the band whose pixel rectangle overlaps the tile, painter's order kept
         int ln = 0;
-        for (uint32_t base = chunk; base < chunk_end; base += 64) {
-            const uint32_t bi = base + lane;
+        while (next < band_end && ln + 64 <= TLIST) {
+            const uint32_t bi = next + lane;
             bool hit = false;
-            uint32_t p = 0;
-            if (bi < chunk_end) {
-                p = band_list[bi];
-                const DevPath P = paths[p];
-                hit = P.x_min < tile_x1 && P.x_max > tx0 && P.y_min < tile_y1 && P.y_max > ty0;
+            BandEntry e;
+            uint32_t f = 0;
+            if (bi < band_end) {
+                e = band_list[bi];
+                hit = e.x_min < tile_x1 && e.x_max > tx0 && e.y_min < tile_y1 && e.y_max > ty0;
+                if (hit) { f = cls_mat[e.pair_off + (uint32_t)tcol - e.tc0]; hit = (f & CLS_NONEMPTY) != 0; }   // empties never enter the list
             }
             const unsigned long long b = __ballot(hit);
-            if (hit) { const int at = ln + __popcll(b & ((1ull << lane) - 1ull)); list[at] = p; cls[at] = 0; }
+            if (hit) { const int at = ln + __popcll(b & ((1ull << lane) - 1ull)); ent[at] = e; cls[at] = f; }
             ln += __popcll(b);
+            next += 64;
         }
         if (dbg == 1) ln = 0;
+        unsigned long long t1 = dbg == 10 ? __builtin_amdgcn_s_memtime() : 0ull;
 
-        // ---- classify every (tile, path): 4 paths x 16 rows per pass; no edge arithmetic, record headers only
-        for (int it0 = 0; it0 < ln * TILE_H; it0 += 64) {
-            const int it = it0 + lane;
-            const int li = it >> 4, row = it & 15;
-            const int y = ty0 + row;
-            if (li < ln && y < height) {
-                const uint32_t pi = list[li];
-                const DevPath P = paths[pi];
-                uint32_t f = 0;
-                if (P.kind == SWFR_PATH_BOXES) {
-                    f = CLS_BOX | CLS_NONEMPTY | CLS_NOTFULL;
-                    if (P.n_edges == 1) {                 // one box that contains the whole tile: full cover
-                        const swfr_edge bx = raw_edges[P.first_edge];
-                        if (bx.x1 <= tx0 * 256 && bx.x2 >= tile_x1 * 256 && bx.y1 <= ty0 * 256 && bx.y2 >= tile_y1 * 256) f = CLS_NONEMPTY;
-                    }
-                } else if (y < P.y_min || y >= P.y_max) {
-                    f = CLS_NOTFULL;
-                } else {
-                    const RowInfo ri = rows[row_base[pi] + (uint32_t)(y - P.y_min)];
-                    int carry = 0;
-                    bool inter = false;
-                    for (uint32_t k = 0; k < ri.n_rec; ++k) {
-                        const Rec* rp = &records[ri.rec_off + k];
-                        const uint32_t rroles = rp->roles, rcols = rp->cols;
-                        const int clo = (int)(rcols & 0xffffu), chi = (int)(rcols >> 16);
-                        if (chi < tx0 && chi < 65535) carry += record_height(rroles);
-                        else if (clo >= tx0 + TILE_W && clo < 65535) { /* right of the tile */ }
-                        else inter = true;
-                    }
-                    const bool inside_x = P.x_min <= tx0 && P.x_max >= tile_x1;
-                    const uint32_t a = (uint32_t)((carry * 512 * 17 + 256) >> 9) & 255u;
-                    if (inter) f = CLS_PARTIAL | CLS_NOTFULL | CLS_NONEMPTY;
-                    else if (a == 0) f = CLS_NOTFULL;
-                    else if (a == 255 && inside_x) f = CLS_NONEMPTY;
-                    else f = CLS_PARTIAL | CLS_NOTFULL | CLS_NONEMPTY;   // uniform partial alpha or column masking
-                }
-                if (f) atomicOr(&cls[li], f);
-            }
-        }
         // ---- occlusion: everything below the last opaque, lerp-blended full cover is invisible in this tile
         int start = 0;
         for (int base = 0; base < ln; base += 64) {
@@ -891,11 +923,7 @@ __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_
             bool cover = false;
             if (li < ln) {
                 const uint32_t f = cls[li];
-                if ((f & (CLS_PARTIAL | CLS_NOTFULL | CLS_BOX)) == 0 && (f & CLS_NONEMPTY)) {
-                    const DevPath P = paths[list[li]];
-                    const swfr_style& S = styles[P.style];
-                    cover = P.lerp && S.kind == SWFR_STYLE_SOLID && (S.pixel >> 24) == 0xffu;
-                }
+                cover = (f & (CLS_PARTIAL | CLS_NOTFULL | CLS_BOX)) == 0 && (f & CLS_NONEMPTY) && (ent[li].flags & BE_OPAQUE_COVER);
             }
             const unsigned long long b = __ballot(cover);
             if (b) start = base + 63 - __clzll((long long)b);
@@ -908,58 +936,117 @@ __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_
             atomicAdd(&counters[CNT_CULLED], (uint32_t)start);
         }
 
-        // ---- painter's order walk
+        unsigned long long t2 = dbg == 10 ? __builtin_amdgcn_s_memtime() : 0ull;
+        unsigned long long t_acc = 0ull;
+        // ---- painter's order walk; the next NACC partial tor paths are accumulated together (one round trip
+        //      to their row headers and one to their records), then consumed in order
+        int pend[NACC];                                       // list indices whose acc buffer is filled
+#pragma unroll
+        for (int j = 0; j < NACC; ++j) pend[j] = -1;
+        int filled_to = start;                                // entries < filled_to have been scanned for accumulation
         for (int li = start; li < ln; ++li) {
-            const uint32_t f = __builtin_amdgcn_readfirstlane(cls[li]);
+            const uint32_t f = cls[li];                        // wave-uniform (LDS broadcast)
             if (!(f & CLS_NONEMPTY)) continue;
-            const uint32_t pi = __builtin_amdgcn_readfirstlane(list[li]);
-            const DevPath P = paths[pi];
-            const swfr_style& S = styles[P.style];
-            const uint32_t kind = S.kind, solid = S.pixel;
-            const int row_lo = max(P.y_min, ty0) - ty0, row_hi = min(P.y_max, ty0 + TILE_H) - ty0;
+            const BandEntry& e = ent[li];
+            const uint32_t eflags = e.flags, solid = e.solid, style = e.style;
+            const int row_lo = max((int)e.y_min, ty0) - ty0, row_hi = min((int)e.y_max, ty0 + TILE_H) - ty0;
             if (f & CLS_BOX) {
                 // ---- rectilinear (A.6): exact area of disjoint boxes, alpha = (c>>8) - (c>>16)
 #pragma unroll 1
                 for (int rr = row_lo; rr < row_hi; ++rr) {
                     const int cy = ty0 + rr;
                     uint32_t cov = 0u;
-                    for (uint32_t k = 0; k < P.n_edges; ++k) {
-                        const swfr_edge bx = raw_edges[P.first_edge + k];
+                    for (uint32_t k = 0; k < e.n_edges; ++k) {
+                        const swfr_edge bx = raw_edges[e.first_edge + k];
                         const int wx = min(bx.x2, (cx + 1) * 256) - max(bx.x1, cx * 256);
                         const int wy = min(bx.y2, (cy + 1) * 256) - max(bx.y1, cy * 256);
                         if (wx > 0 && wy > 0) cov += (uint32_t)(wx * wy);
                     }
                     const uint32_t a = ((cov >> 8) - (cov >> 16)) & 255u;
-                    if (a) px[rr][lane] = blend_pixel(px[rr][lane], a, P, S, kind, solid, bitmaps, cx, cy);
+                    if (a) px[rr][lane] = blend_pixel(px[rr][lane], a, eflags, solid, styles, style, bitmaps, cx, cy);
                 }
-            } else if ((f & CLS_PARTIAL) && dbg != 3) {
-                // ---- tor (A.5): records -> covered height / uncovered area per cell, prefix sum, alpha
-                if (dbg != 5) accumulate_path(P, row_base[pi], rows, records, acc, tx0, ty0, lane);
+            } else if (f & CLS_PARTIAL) {
+                if (dbg == 3) continue;
+                // which acc buffer holds this path?  if none, fill the buffers with the next NACC partial paths
+                int slot_j = -1;
+#pragma unroll
+                for (int j = 0; j < NACC; ++j) if (pend[j] == li) slot_j = j;
+                if (slot_j < 0) {
+                    int cand[NACC];
+                    int nc = 0;
+                    for (int lj = max(li, filled_to); lj < ln && nc < NACC; ++lj)
+                        if ((cls[lj] & (CLS_PARTIAL | CLS_BOX | CLS_NONEMPTY)) == (CLS_PARTIAL | CLS_NONEMPTY)) {
+#pragma unroll
+                            for (int j = 0; j < NACC; ++j) if (j == nc) cand[j] = lj;
+                            ++nc;
+                            filled_to = lj + 1;
+                        }
+#pragma unroll
+                    for (int j = 0; j < NACC; ++j) pend[j] = j < nc ? cand[j] : -1;
+                    // lanes = (buffer j, row, slot): every lane walks the records of its (path, row)
+                    constexpr int NSLOT = 64 / (16 * NACC);
+                    const int j = (lane >> 4) % NACC, row = lane & 15, slot = lane / (16 * NACC);
+                    int mine = -1;
+#pragma unroll
+                    for (int jj = 0; jj < NACC; ++jj) if (jj == j) mine = pend[jj];
+                    const unsigned long long ta0 = dbg == 10 ? __builtin_amdgcn_s_memtime() : 0ull;
+                    if (mine >= 0 && dbg != 5) {
+                        const BandEntry& pe = ent[mine];
+                        const int y = ty0 + row;
+                        if (y >= pe.y_min && y < pe.y_max) {
+                            const RowInfo ri = rows[pe.row_base + (uint32_t)(y - pe.y_min)];
+                            if (ri.n_rec) {
+                                TileCtx c; c.tx0 = tx0; c.xminp = pe.x_min; c.xmaxp = pe.x_max;
+                                if (slot == 0) acc[j][row][ACC_TOUCH] = 1;
+                                accumulate_row(ri, records, acc[j][row], c, slot, NSLOT);
+                            }
+                        }
+                    }
+                    if (dbg == 10) { __builtin_amdgcn_s_waitcnt(0); t_acc += __builtin_amdgcn_s_memtime() - ta0; }
+#pragma unroll
+                    for (int jj = 0; jj < NACC; ++jj) if (pend[jj] == li) slot_j = jj;
+                }
+                // ---- prefix sum, alpha, blend for this path's buffer; clears as it reads
+                int (*A)[ACC_STRIDE] = acc[slot_j];
 #pragma unroll 1
                 for (int rr = row_lo; rr < row_hi; ++rr) {
                     if (dbg == 4) continue;
-                    if (!acc[rr][ACC_TOUCH] && dbg != 5) continue;     // wave-uniform
-                    const int v = acc[rr][lane];
-                    const int carry = acc[rr][ACC_CARRY];
-                    acc[rr][lane] = 0;
-                    if (lane < 2) acc[rr][ACC_CARRY + lane] = 0;
+                    if (!A[rr][ACC_TOUCH] && dbg != 5) continue;       // wave-uniform
+                    const int v = A[rr][lane];
+                    const int carry = A[rr][ACC_CARRY];
+                    A[rr][lane] = 0;
+                    if (lane < 2) A[rr][ACC_CARRY + lane] = 0;
                     const int ua = (v << 12) >> 12;                    // low 20 bits, sign-extended
                     int ch = (v - ua) >> 20;
                     if (lane == 0) ch += carry;
                     const int scan = wave_scan_incl(ch);
                     const int area = scan * 512 - ua;
                     uint32_t a = (uint32_t)((area * 17 + 256) >> 9) & 255u;
-                    if (cx < P.x_min || cx >= P.x_max) a = 0;
-                    if (a) px[rr][lane] = blend_pixel(px[rr][lane], a, P, S, kind, solid, bitmaps, cx, ty0 + rr);
+                    if (cx < e.x_min || cx >= e.x_max) a = 0;
+                    if (a) px[rr][lane] = blend_pixel(px[rr][lane], a, eflags, solid, styles, style, bitmaps, cx, ty0 + rr);
                 }
-            } else if (!(f & CLS_PARTIAL)) {
+#pragma unroll
+                for (int jj = 0; jj < NACC; ++jj) if (jj == slot_j) pend[jj] = -1;
+            } else {
                 // full cover: every in-frame pixel of the tile has coverage 255
 #pragma unroll 1
-                for (int rr = row_lo; rr < row_hi; ++rr) px[rr][lane] = blend_pixel(px[rr][lane], 255u, P, S, kind, solid, bitmaps, cx, ty0 + rr);
+                for (int rr = row_lo; rr < row_hi; ++rr) px[rr][lane] = blend_pixel(px[rr][lane], 255u, eflags, solid, styles, style, bitmaps, cx, ty0 + rr);
             }
+        }
+        if (dbg == 10 && lane == 0) {
+            const unsigned long long t4 = __builtin_amdgcn_s_memtime();
+            atomicAdd((unsigned long long*)&counters[12], t2 - t1);       // classification + occlusion
+            atomicAdd((unsigned long long*)&counters[14], t_acc);         // accumulate (P1) incl. waiting for its loads
+            atomicAdd((unsigned long long*)&counters[16], t4 - t2);       // whole walk
+            atomicAdd((unsigned long long*)&counters[18], t1 - t_start10); // up to end of binning (first round)
         }
     }
 
+    if (dbg == 10 && lane == 0) {
+        const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+        atomicAdd(&counters[8], 1u);
+        atomicAdd((unsigned long long*)&counters[10], t3 - t_start10);
+    }
     if (dbg == 8 && lane == 0) px[0][0] = (uint32_t)(__builtin_amdgcn_s_memtime() - t_start);   // diagnostics: tile duration in clocks
     // ---- one store per pixel: premultiplied R,G,B,A bytes; the wave writes 256 contiguous bytes per row
     if (cx < width) {
@@ -1006,9 +1093,10 @@ void launch_setup(hipStream_t st, const swfr_edge* in, const DevPath* paths, Dev
     if (!n_edges) return;
     hipLaunchKernelGGL(k_setup, dim3((n_edges + 255) / 256), dim3(256), 0, st, in, paths, out, n_edges);
 }
-void launch_bands(hipStream_t st, const DevPath* paths, uint32_t n_paths, const uint32_t* band_off, uint32_t* band_list, uint32_t n_bands) {
+void launch_bands(hipStream_t st, const DevPath* paths, uint32_t n_paths, const uint32_t* row_base, const swfr_style* styles,
+                  const uint32_t* band_off, BandEntry* band_list, uint32_t n_bands, uint32_t* counters) {
     if (!n_bands || !n_paths) return;
-    hipLaunchKernelGGL(k_bands, dim3(n_bands), dim3(256), 0, st, paths, n_paths, band_off, band_list);
+    hipLaunchKernelGGL(k_bands, dim3(n_bands), dim3(256), 0, st, paths, n_paths, row_base, styles, band_off, band_list, counters);
 }
 void launch_rows(hipStream_t st, const DevEdge* edges, const DevPath* paths, const uint32_t* row_base, const uint32_t* chunk_base,
                  uint32_t n_paths, RowInfo* rows, Rec* records, uint32_t* counters, uint32_t* overflow_list, uint32_t n_chunks,
@@ -1020,17 +1108,21 @@ void launch_rows(hipStream_t st, const DevEdge* edges, const DevPath* paths, con
     // rows that exceeded the per-lane capacity (rare): fixed small grid, every lane loops over the list and exits
     hipLaunchKernelGGL(k_rows_big, dim3(256), dim3(64), 0, st, edges, paths, row_base, n_paths, rows, records, counters, overflow_list);
 }
-void launch_tiles(hipStream_t st, const swfr_edge* raw, const DevEdge* edges, const DevPath* paths, const uint32_t* band_off,
-                  const uint32_t* band_list, const uint32_t* row_base, const RowInfo* rows, const Rec* records,
-                  const swfr_style* styles, const DevBitmap* bitmaps, uint32_t* fb, int width, int height, uint32_t band_index,
-                  uint32_t band_count, int dbg, uint32_t* counters) {
-    (void)edges;
+void launch_class(hipStream_t st, const BandEntry* band_list, uint32_t n_entries, const uint32_t* band_off, uint32_t n_bands,
+                  const swfr_edge* raw, const RowInfo* rows, const Rec* records, uint8_t* cls_mat, int width, int height) {
+    if (!n_entries) return;
+    hipLaunchKernelGGL(k_class, dim3(n_entries), dim3(64), 0, st, band_list, n_entries, band_off, n_bands, raw, rows, records, cls_mat,
+                       width, height);
+}
+void launch_tiles(hipStream_t st, const swfr_edge* raw, const uint32_t* band_off, const BandEntry* band_list, const uint8_t* cls_mat,
+                  const RowInfo* rows, const Rec* records, const swfr_style* styles, const DevBitmap* bitmaps, uint32_t* fb, int width, int height,
+                  uint32_t band_index, uint32_t band_count, int dbg, uint32_t* counters) {
     const int tiles_x = (width + TILE_W - 1) / TILE_W, tile_rows = (height + TILE_H - 1) / TILE_H;
     uint32_t local_rows = tile_rows;
     if (band_count > 1) local_rows = (tile_rows > (int)band_index) ? (tile_rows - band_index + band_count - 1) / band_count : 0;
     if (!local_rows) return;
-    hipLaunchKernelGGL(k_tiles, dim3(tiles_x * local_rows), dim3(64), 0, st, raw, paths, band_off, band_list, row_base, rows,
-                       records, styles, bitmaps, fb, width, height, tiles_x, band_index, band_count, dbg, counters);
+    hipLaunchKernelGGL(k_tiles, dim3(tiles_x * local_rows), dim3(64), 0, st, raw, band_off, band_list, cls_mat, rows, records, styles, bitmaps,
+                       fb, width, height, tiles_x, band_index, band_count, dbg, counters);
 }
 void launch_unpremultiply(hipStream_t st, const uint32_t* in, uint32_t* out, size_t n) {
     if (!n) return;

@@ -22,11 +22,12 @@
 
 namespace swfr {
 void launch_setup(hipStream_t, const swfr_edge*, const DevPath*, DevEdge*, uint32_t);
-void launch_bands(hipStream_t, const DevPath*, uint32_t, const uint32_t*, uint32_t*, uint32_t);
+void launch_bands(hipStream_t, const DevPath*, uint32_t, const uint32_t*, const swfr_style*, const uint32_t*, BandEntry*, uint32_t, uint32_t*);
+void launch_class(hipStream_t, const BandEntry*, uint32_t, const uint32_t*, uint32_t, const swfr_edge*, const RowInfo*, const Rec*, uint8_t*, int, int);
 void launch_rows(hipStream_t, const DevEdge*, const DevPath*, const uint32_t*, const uint32_t*, uint32_t, RowInfo*, Rec*, uint32_t*,
                  uint32_t*, uint32_t, uint32_t, uint32_t, int);
-void launch_tiles(hipStream_t, const swfr_edge*, const DevEdge*, const DevPath*, const uint32_t*, const uint32_t*, const uint32_t*,
-                  const RowInfo*, const Rec*, const swfr_style*, const DevBitmap*, uint32_t*, int, int, uint32_t, uint32_t, int, uint32_t*);
+void launch_tiles(hipStream_t, const swfr_edge*, const uint32_t*, const BandEntry*, const uint8_t*, const RowInfo*, const Rec*, const swfr_style*,
+                  const DevBitmap*, uint32_t*, int, int, uint32_t, uint32_t, int, uint32_t*);
 void launch_unpremultiply(hipStream_t, const uint32_t*, uint32_t*, size_t);
 void launch_pack_band(hipStream_t, const uint32_t*, uint32_t*, int, int, uint32_t, uint32_t, uint32_t);
 }  // namespace swfr
@@ -89,7 +90,10 @@ struct swfr_renderer {
     DevBuf<DevEdge> d_edges;
     DevBuf<DevPath> d_paths;
     DevBuf<swfr_style> d_styles;
-    DevBuf<uint32_t> d_row_base, d_chunk_base, d_band_off, d_band_list, d_overflow;
+    DevBuf<uint32_t> d_row_base, d_chunk_base, d_band_off, d_overflow;
+    DevBuf<BandEntry> d_band_list;
+    DevBuf<uint8_t> d_cls;
+    size_t n_band_entries = 0;
     DevBuf<RowInfo> d_rows;
     DevBuf<Rec> d_records;
     DevBuf<uint32_t> d_counters;
@@ -109,7 +113,7 @@ struct swfr_renderer {
         if (has_device) {
             (void)hipSetDevice(cfg.device);
             d_raw.release(); d_edges.release(); d_paths.release(); d_styles.release(); d_row_base.release();
-            d_rows.release(); d_records.release(); d_chunk_base.release(); d_band_off.release(); d_band_list.release(); d_overflow.release(); d_counters.release(); d_bitmap_table.release(); d_fb.release(); d_tmp.release();
+            d_rows.release(); d_records.release(); d_chunk_base.release(); d_band_off.release(); d_band_list.release(); d_overflow.release(); d_cls.release(); d_counters.release(); d_bitmap_table.release(); d_fb.release(); d_tmp.release();
             for (auto& kv : bitmaps) if (kv.second.pixels) (void)hipFree(kv.second.pixels);
             for (auto& e : ev) if (e) (void)hipEventDestroy(e);
             if (stream) (void)hipStreamDestroy(stream);
@@ -178,7 +182,7 @@ int upload(swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_
     std::vector<uint32_t> row_base(n_paths + 1, 0), chunk_base(n_paths + 1, 0);
     const size_t n_bands = (r->height + TILE_H - 1) / TILE_H;
     std::vector<uint32_t> band_off(n_bands + 1, 0);
-    size_t rec_cap = 0;
+    size_t rec_cap = 0, pair_cap = 0;
     for (size_t i = 0; i < n_paths; ++i) {
         const swfr_path& p = paths[i];
         for (uint32_t k = 0; k < p.n_edges; ++k) staged[p.first_edge + k].reserved = int32_t(i);
@@ -194,8 +198,10 @@ int upload(swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_
         }
         row_base[i + 1] = row_base[i] + rows;
         chunk_base[i + 1] = chunk_base[i] + (rows + ROWS_CHUNK - 1) / ROWS_CHUNK;
-        if (p.y_max > p.y_min)
+        if (p.y_max > p.y_min && p.x_max > p.x_min) {
             for (int b = p.y_min / TILE_H; b <= (p.y_max - 1) / TILE_H; ++b) ++band_off[size_t(b) + 1];
+            pair_cap += size_t((p.y_max - 1) / TILE_H - p.y_min / TILE_H + 1) * size_t((p.x_max - 1) / TILE_W - p.x_min / TILE_W + 1);
+        }
     }
     for (size_t b = 0; b < n_bands; ++b) band_off[b + 1] += band_off[b];   // exact sizes; k_bands fills the lists in order
     r->n_edges = n_edges; r->n_paths = n_paths; r->n_styles = n_styles;
@@ -207,6 +213,8 @@ int upload(swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_
     r->d_row_base.reserve(n_paths + 1); r->d_rows.reserve(r->n_tasks); r->d_records.reserve(r->rec_cap);
     r->d_chunk_base.reserve(n_paths + 1); r->d_band_off.reserve(n_bands + 1); r->d_band_list.reserve(band_off[n_bands]);
     r->d_overflow.reserve(r->n_tasks);
+    r->d_cls.reserve(pair_cap + 64);
+    r->n_band_entries = band_off[n_bands];
     r->d_counters.reserve(CNT_WORDS);
     if (n_edges) HIP_CHECK(hipMemcpyAsync(r->d_raw.ptr, staged.data(), n_edges * sizeof(swfr_edge), hipMemcpyHostToDevice, r->stream));
     if (n_paths) HIP_CHECK(hipMemcpyAsync(r->d_paths.ptr, paths, n_paths * sizeof(swfr_path), hipMemcpyHostToDevice, r->stream));
@@ -232,7 +240,7 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
     if (frames == 0) frames = 1;
     const uint32_t bc = r->cfg.band_count > 1 ? r->cfg.band_count : 1, bi = r->cfg.band_count > 1 ? r->cfg.band_index : 0;
     float setup_ms = 0, rows_ms = 0, tiles_ms = 0, total_ms = 0;
-    uint32_t counters[CNT_WORDS] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t counters[CNT_WORDS] = {};
     if (frames > 4096) frames = 4096;
     while (r->ev.size() < size_t(frames) * 4) {
         hipEvent_t e = nullptr;
@@ -246,15 +254,19 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
         HIP_CHECK(hipEventRecord(e[0], r->stream));
         if (r->n_paths) {
             launch_setup(r->stream, r->d_raw.ptr, r->d_paths.ptr, r->d_edges.ptr, uint32_t(r->n_edges));
-            launch_bands(r->stream, r->d_paths.ptr, uint32_t(r->n_paths), r->d_band_off.ptr, r->d_band_list.ptr, uint32_t(r->n_bands));
+            launch_bands(r->stream, r->d_paths.ptr, uint32_t(r->n_paths), r->d_row_base.ptr, r->d_styles.ptr, r->d_band_off.ptr, r->d_band_list.ptr,
+                         uint32_t(r->n_bands), r->d_counters.ptr);
         }
         HIP_CHECK(hipEventRecord(e[1], r->stream));
         if (r->n_paths)
             launch_rows(r->stream, r->d_edges.ptr, r->d_paths.ptr, r->d_row_base.ptr, r->d_chunk_base.ptr, uint32_t(r->n_paths), r->d_rows.ptr,
                         r->d_records.ptr, r->d_counters.ptr, r->d_overflow.ptr, uint32_t(r->n_chunks), bi, bc, r->fast_limit);
+        if (r->n_paths)
+            launch_class(r->stream, r->d_band_list.ptr, uint32_t(r->n_band_entries), r->d_band_off.ptr, uint32_t(r->n_bands), r->d_raw.ptr,
+                         r->d_rows.ptr, r->d_records.ptr, r->d_cls.ptr, int(r->width), int(r->height));
         HIP_CHECK(hipEventRecord(e[2], r->stream));
-        launch_tiles(r->stream, r->d_raw.ptr, r->d_edges.ptr, r->d_paths.ptr, r->d_band_off.ptr, r->d_band_list.ptr, r->d_row_base.ptr,
-                     r->d_rows.ptr, r->d_records.ptr, r->d_styles.ptr, r->d_bitmap_table.ptr, r->d_fb.ptr, int(r->width), int(r->height), bi, bc, r->tiles_dbg, r->d_counters.ptr);
+        launch_tiles(r->stream, r->d_raw.ptr, r->d_band_off.ptr, r->d_band_list.ptr, r->d_cls.ptr, r->d_rows.ptr, r->d_records.ptr, r->d_styles.ptr,
+                     r->d_bitmap_table.ptr, r->d_fb.ptr, int(r->width), int(r->height), bi, bc, r->tiles_dbg, r->d_counters.ptr);
         HIP_CHECK(hipEventRecord(e[3], r->stream));
     }
     HIP_CHECK(hipGetLastError());
@@ -273,6 +285,12 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
     if (r->tiles_dbg == 9)
         std::fprintf(stderr, "[swfr] tile/path pairs %u, partial %u, full %u, culled entries %u, records %u, overflow rows %u\n", counters[CNT_PAIRS],
                      counters[CNT_PARTIAL], counters[CNT_FULL], counters[CNT_CULLED], counters[CNT_RECORDS], counters[CNT_OVERFLOW]);
+    if (r->tiles_dbg == 10) {
+        auto u64 = [&](int i) { return (unsigned long long)counters[i] | ((unsigned long long)counters[i + 1] << 32); };
+        const double n = counters[8] ? counters[8] : 1;
+        std::fprintf(stderr, "[swfr] per tile clocks: total %.0f, bin %.0f, classify %.0f, walk %.0f (accumulate %.0f)\n", u64(10) / n, u64(18) / n,
+                     u64(12) / n, u64(16) / n, u64(14) / n);
+    }
     r->fb_valid = true;
     if (counters[CNT_ERROR]) {
         r->fb_valid = false;
