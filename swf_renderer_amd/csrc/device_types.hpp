@@ -50,7 +50,7 @@ struct Rec {
 };
 static_assert(sizeof(Rec) == 48, "Rec layout");
 
-enum : uint32_t { CNT_RECORDS = 0, CNT_ERROR = 1, CNT_OVERFLOW = 2, CNT_PAIRS = 3, CNT_PARTIAL = 4, CNT_FULL = 5, CNT_CULLED = 6, CNT_PAIR_ALLOC = 7, CNT_WORDS = 24 };
+enum : uint32_t { CNT_RECORDS = 0, CNT_ERROR = 1, CNT_OVERFLOW = 2, CNT_PAIRS = 3, CNT_PARTIAL = 4, CNT_FULL = 5, CNT_CULLED = 6, CNT_WORDS = 24 };
 constexpr int ROWS_CHUNK = 64;       // pixel rows per k_rows workgroup (one lane per row)
 
 // Band list entry: everything a tile needs to bin, classify and cull a path without touching paths[]/styles[].
@@ -62,10 +62,8 @@ struct BandEntry {
     uint32_t first_edge, n_edges;         // boxes paths
     uint32_t flags;                       // BE_*
     uint32_t solid;                       // premultiplied pixel of a solid style
-    uint32_t pair_off;                    // first slot of this entry in the (tile, path) class matrix
-    uint32_t tc0;                         // first tile column of the path's pixel rectangle
 };
-static_assert(sizeof(BandEntry) == 44, "BandEntry layout");
+static_assert(sizeof(BandEntry) == 36, "BandEntry layout");
 enum : uint32_t { BE_BOXES = 1u, BE_LERP = 2u, BE_SOLID = 4u, BE_OPAQUE_COVER = 8u /* solid, alpha 255, lerp blend */ };
 
 struct DevBitmap {

@@ -161,8 +161,6 @@ __global__ __launch_bounds__(256) void k_bands(const DevPath* __restrict__ paths
             if (kind == SWFR_STYLE_SOLID) fl |= BE_SOLID;
             if (kind == SWFR_STYLE_SOLID && P.lerp && (pixel >> 24) == 0xffu) fl |= BE_OPAQUE_COVER;
             e.flags = fl; e.solid = pixel;
-            e.tc0 = (uint32_t)(P.x_min / TILE_W);
-            e.pair_off = atomicAdd(&counters[CNT_PAIR_ALLOC], (uint32_t)((P.x_max - 1) / TILE_W) - e.tc0 + 1u);
             out[off + __popcll(b & ((1ull << lane) - 1ull))] = e;
         }
         __syncthreads();
@@ -439,6 +437,7 @@ __device__ __forceinline__ void fast_rows(EPTR E, const DevPath& P, int r, bool 
             for (int s = 0; s < ROWS_FAST_N; ++s) { F.eid[s][lane] = (uint16_t)el[s]; F.roles[s][lane] = 0; F.clo[s][lane] = 65535; F.chi[s][lane] = 0; }
         }
     }
+    __syncthreads();                                          // F.* written by the row owners, read by the sample lanes
     // ---- phase B: the wave's SUB rows, 4 rows x 15 sub-rows per pass
     unsigned long long pending = __ballot(is_sub);
     const int g = lane / 15, sub = lane - g * 15;
@@ -492,6 +491,7 @@ __device__ __forceinline__ void fast_rows(EPTR E, const DevPath& P, int r, bool 
             }
         }
     }
+    __syncthreads();                                          // role bits OR-ed in by the sample lanes
     if (is_sub) {
 #pragma unroll
         for (int s = 0; s < ROWS_FAST_N; ++s) { roles[s] = F.roles[s][lane]; cols[s] = (int32_t)((uint32_t)F.clo[s][lane] | ((uint32_t)F.chi[s][lane] << 16)); }
@@ -772,19 +772,23 @@ __device__ void full_edge(const Rec& rec, int sign, int* acc, const TileCtx& c) 
 // CLS_PARTIAL (a boundary passes through the tile), full cover, or empty.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_class(const BandEntry* __restrict__ band_list, uint32_t n_entries,
-                                              const uint32_t* __restrict__ band_of_entry_off, uint32_t n_bands,
+                                              const uint32_t* __restrict__ band_off, uint32_t n_bands,
                                               const swfr_edge* __restrict__ raw_edges, const RowInfo* __restrict__ rows,
-                                              const Rec* __restrict__ records, uint8_t* __restrict__ cls_mat, int width, int height) {
+                                              const Rec* __restrict__ records, uint8_t* __restrict__ cls_t, int width, int height,
+                                              int tiles_x, uint32_t band_index, uint32_t band_count) {
     const uint32_t ei = blockIdx.x;
     if (ei >= n_entries) return;
     const int lane = threadIdx.x;
-    const BandEntry e = band_list[ei];
     // band of this entry: upper_bound on the band offsets (wave-uniform)
     uint32_t lo = 0, hi = n_bands;
-    while (lo + 1 < hi) { const uint32_t mid = (lo + hi) >> 1; if (band_of_entry_off[mid] <= ei) lo = mid; else hi = mid; }
+    while (lo + 1 < hi) { const uint32_t mid = (lo + hi) >> 1; if (band_off[mid] <= ei) lo = mid; else hi = mid; }
+    if (band_count > 1 && lo % band_count != band_index) return;        // another rank's tile-row
+    const BandEntry e = band_list[ei];
+    const uint32_t b0 = band_off[lo], n_b = band_off[lo + 1] - b0, e_local = ei - b0;
+    uint8_t* out = cls_t + (size_t)tiles_x * b0 + e_local;              // + tile column * n_b
     const int ty0 = (int)lo * TILE_H;
-    const int tc1 = ((int)e.x_max - 1) / TILE_W;
-    for (int tc = (int)e.tc0 + lane; tc <= tc1; tc += 64) {
+    const int tc0 = (int)e.x_min / TILE_W, tc1 = ((int)e.x_max - 1) / TILE_W;
+    for (int tc = tc0 + lane; tc <= tc1; tc += 64) {
         const int tx0 = tc * TILE_W, tile_x1 = min(tx0 + TILE_W, width), tile_y1 = min(ty0 + TILE_H, height);
         uint32_t flags = 0;
         if (e.flags & BE_BOXES) {
@@ -815,41 +819,12 @@ __global__ __launch_bounds__(64) void k_class(const BandEntry* __restrict__ band
                 else flags |= CLS_PARTIAL | CLS_NOTFULL | CLS_NONEMPTY;   // uniform partial alpha or column masking
             }
         }
-        cls_mat[e.pair_off + (uint32_t)(tc - (int)e.tc0)] = (uint8_t)flags;
+        out[(size_t)tc * n_b] = (uint8_t)flags;
     }
 }
 
-#define NACC 2                         // partial paths accumulated concurrently (one acc buffer each)
-#define TLIST 96                       // tile list entries processed per round (scan stops once > TLIST-64 are found)
-
-// records of one (path, row) -> covered height / uncovered area per cell (LDS atomics into `acc`)
-__device__ __forceinline__ void accumulate_row(const RowInfo ri, const Rec* __restrict__ records, int* acc, const TileCtx& c,
-                                               int slot, int nslots) {
-    for (uint32_t k = (uint32_t)slot; k < ri.n_rec; k += (uint32_t)nslots) {
-        const Rec rec = records[ri.rec_off + k];
-        const int clo = (int)(rec.cols & 0xffffu), chi = (int)(rec.cols >> 16);
-        if (clo >= c.tx0 + TILE_W && clo < 65535) continue;         // entirely right of the tile
-        if (chi < c.tx0 && chi < 65535) {                           // entirely left: only its net height reaches us
-            cell_add(acc, c, chi, record_height(rec.roles), 0);
-            continue;
-        }
-        if (rec.roles & REC_FULL) {
-            full_edge(rec, (rec.roles & 1u) ? +1 : -1, acc, c);
-        } else {
-            const int first = (int)(rec.span & 255u), last = (int)(rec.span >> 8);
-            int32_t q = rec.q1; int64_t rm = rec.r1;
-            for (int ss = first; ss < last; ++ss) {
-                const uint32_t role = (rec.roles >> (2 * ss)) & 3u;
-                if (role) {
-                    const int cell = rec.dy ? cell_of(q, rm, rec.dy) : q;
-                    const int sgn = role == 1 ? 1 : -1;
-                    cell_add(acc, c, cell >> 8, sgn, sgn * 2 * (cell & 255));
-                }
-                if (rec.dy) { q += rec.q2; rm += rec.r2; if (rm < 0) { --q; rm += rec.dy; } else if (rm >= rec.dy) { ++q; rm -= rec.dy; } }
-            }
-        }
-    }
-}
+#define TLIST 64                       // tile list entries per round
+#define REC_STAGE 96                   // records of one (tile, path) staged in LDS per round
 
 __device__ __forceinline__ uint32_t blend_pixel(uint32_t dst, uint32_t a, uint32_t eflags, uint32_t solid, const swfr_style* __restrict__ styles,
                                                 uint32_t style, const DevBitmap* __restrict__ bitmaps, int cx, int cy) {
@@ -861,103 +836,134 @@ __device__ __forceinline__ uint32_t blend_pixel(uint32_t dst, uint32_t a, uint32
     return (eflags & BE_LERP) ? s : over_pixel(s, dst);
 }
 
+// one staged record -> covered height / uncovered area per cell of its row (LDS atomics into `acc`)
+__device__ __forceinline__ void accumulate_record(const Rec& rec, int* acc, const TileCtx& c) {
+    const int clo = (int)(rec.cols & 0xffffu), chi = (int)(rec.cols >> 16);
+    if (clo >= c.tx0 + TILE_W && clo < 65535) return;               // entirely right of the tile
+    if (chi < c.tx0 && chi < 65535) {                               // entirely left: only its net height reaches us
+        cell_add(acc, c, chi, record_height(rec.roles), 0);
+        return;
+    }
+    if (rec.roles & REC_FULL) {
+        full_edge(rec, (rec.roles & 1u) ? +1 : -1, acc, c);
+        return;
+    }
+    const int first = (int)(rec.span & 255u), last = (int)(rec.span >> 8);
+    int32_t q = rec.q1; int64_t rm = rec.r1;
+    for (int ss = first; ss < last; ++ss) {
+        const uint32_t role = (rec.roles >> (2 * ss)) & 3u;
+        if (role) {
+            const int cell = rec.dy ? cell_of(q, rm, rec.dy) : q;
+            const int sgn = role == 1 ? 1 : -1;
+            cell_add(acc, c, cell >> 8, sgn, sgn * 2 * (cell & 255));
+        }
+        if (rec.dy) { q += rec.q2; rm += rec.r2; if (rm < 0) { --q; rm += rec.dy; } else if (rm >= rec.dy) { ++q; rm -= rec.dy; } }
+    }
+}
+
 // One wavefront per 64x16 tile: lane = pixel column, the tile's pixels live in LDS.  No workgroup barriers:
-// LDS traffic of a wave is ordered.  Global memory is touched in few dependent steps per tile:
-// band entries -> row headers -> records, with NACC partial paths' records in flight at once.
+// LDS traffic of a wave is ordered.  Global memory is read in coalesced pieces only: the tile's class bytes
+// (contiguous per tile), the few band entries that survive, 16 row headers per path (one line) and the
+// path's records as a dword stream staged through LDS.
 __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_edges,
                                               const uint32_t* __restrict__ band_off, const BandEntry* __restrict__ band_list,
-                                              const uint8_t* __restrict__ cls_mat, const RowInfo* __restrict__ rows,
+                                              const uint8_t* __restrict__ cls_t, const RowInfo* __restrict__ rows,
                                               const Rec* __restrict__ records, const swfr_style* __restrict__ styles,
                                               const DevBitmap* __restrict__ bitmaps, uint32_t* __restrict__ fb,
                                               int width, int height, int tiles_x, uint32_t band_index, uint32_t band_count, int dbg,
-                                              uint32_t* __restrict__ counters) {
-    __shared__ int acc[NACC][TILE_H][ACC_STRIDE];
+                                              uint32_t* __restrict__ counters, uint32_t n_rows_total, uint32_t n_rec_cap) {
+    __shared__ int acc[TILE_H][ACC_STRIDE];
     __shared__ uint32_t px[TILE_H][TILE_W];
-    __shared__ BandEntry ent[TLIST];
+    __shared__ uint32_t ent[TLIST][9];                    // BandEntry as 9 dwords
     __shared__ uint32_t cls[TLIST];
+    __shared__ __attribute__((aligned(16))) uint32_t stage[REC_STAGE * 12];   // records as dwords
+    __shared__ uint32_t rec_src[REC_STAGE];
+    __shared__ uint32_t row_off[TILE_H], row_start[TILE_H + 1];
+    __shared__ uint8_t rec_row[REC_STAGE];
 
     const int lane = threadIdx.x;
     // blockIdx -> tile: consecutive workgroups walk along x inside one tile-row, so the 8 tiles that are
-    // co-scheduled round-robin over the 8 XCDs read the same band list / path records
+    // co-scheduled round-robin over the 8 XCDs read the same band entries / path records
     const int tile = blockIdx.x;
     const int tcol = tile % tiles_x;
     int trow = tile / tiles_x;
     if (band_count > 1) trow = trow * (int)band_count + (int)band_index;
     const int tx0 = tcol * TILE_W, ty0 = trow * TILE_H;
     if (ty0 >= height) return;
-    const int tile_x1 = min(tx0 + TILE_W, width), tile_y1 = min(ty0 + TILE_H, height);
     const int cx = tx0 + lane;
     const unsigned long long t_start = dbg == 8 ? __builtin_amdgcn_s_memtime() : 0ull;
-    const unsigned long long t_start10 = dbg == 10 ? __builtin_amdgcn_s_memtime() : 0ull;
 
     for (int rr = 0; rr < TILE_H; ++rr) px[rr][lane] = 0u;
-    for (int i = lane; i < NACC * TILE_H * ACC_STRIDE; i += 64) (&acc[0][0][0])[i] = 0;
+    for (int i = lane; i < TILE_H * ACC_STRIDE; i += 64) (&acc[0][0])[i] = 0;
 
     const uint32_t band_begin = band_off[trow], band_end = band_off[trow + 1];
-    uint32_t next = band_begin;
-    while (next < band_end) {
-        // ---- bin: up to TLIST entries of the band whose pixel rectangle overlaps the tile, painter's order kept
+    const uint32_t n_b = band_end - band_begin;
+    const uint8_t* mycls = cls_t + (size_t)tiles_x * band_begin + (size_t)tcol * n_b;   // this tile's class byte per band entry
+    uint32_t next = 0;
+    while (next < n_b) {
+        // ---- bin: band entries with a non-empty class for this tile, painter's order kept (wave-local compaction)
         int ln = 0;
-        while (next < band_end && ln + 64 <= TLIST) {
+        while (next < n_b && ln < TLIST) {
             const uint32_t bi = next + lane;
-            bool hit = false;
-            BandEntry e;
-            uint32_t f = 0;
-            if (bi < band_end) {
-                e = band_list[bi];
-                hit = e.x_min < tile_x1 && e.x_max > tx0 && e.y_min < tile_y1 && e.y_max > ty0;
-                if (hit) { f = cls_mat[e.pair_off + (uint32_t)tcol - e.tc0]; hit = (f & CLS_NONEMPTY) != 0; }   // empties never enter the list
+            const uint32_t f = bi < n_b ? (uint32_t)mycls[bi] : 0u;
+            bool hit = (f & CLS_NONEMPTY) != 0;
+            unsigned long long b = __ballot(hit);
+            const int room = TLIST - ln;
+            int cnt = __popcll(b);
+            if (cnt > room) {                                 // keep the first `room` hits, rescan the rest next round
+                int keep = room; unsigned long long m = b, kept = 0ull; uint32_t last = 0;
+                while (keep--) { const int bit = __ffsll((long long)m) - 1; kept |= 1ull << bit; m &= m - 1; last = (uint32_t)bit; }
+                b = kept; hit = hit && ((kept >> lane) & 1ull); cnt = room;
+                next += last + 1;
+            } else next += 64;
+            if (hit) {
+                const int at = ln + __popcll(b & ((1ull << lane) - 1ull));
+                const uint32_t* src = reinterpret_cast<const uint32_t*>(&band_list[band_begin + bi]);
+#pragma unroll
+                for (int w = 0; w < 9; ++w) ent[at][w] = src[w];
+                cls[at] = f;
             }
-            const unsigned long long b = __ballot(hit);
-            if (hit) { const int at = ln + __popcll(b & ((1ull << lane) - 1ull)); ent[at] = e; cls[at] = f; }
-            ln += __popcll(b);
-            next += 64;
+            ln += cnt;
         }
         if (dbg == 1) ln = 0;
-        unsigned long long t1 = dbg == 10 ? __builtin_amdgcn_s_memtime() : 0ull;
+        __syncthreads();                                      // ent/cls written by other lanes (one-wave workgroup: cheap)
 
         // ---- occlusion: everything below the last opaque, lerp-blended full cover is invisible in this tile
         int start = 0;
-        for (int base = 0; base < ln; base += 64) {
-            const int li = base + lane;
+        {
             bool cover = false;
-            if (li < ln) {
-                const uint32_t f = cls[li];
-                cover = (f & (CLS_PARTIAL | CLS_NOTFULL | CLS_BOX)) == 0 && (f & CLS_NONEMPTY) && (ent[li].flags & BE_OPAQUE_COVER);
+            if (lane < ln) {
+                const uint32_t f = cls[lane];
+                cover = (f & (CLS_PARTIAL | CLS_NOTFULL | CLS_BOX)) == 0 && (ent[lane][7] & BE_OPAQUE_COVER);
             }
             const unsigned long long b = __ballot(cover);
-            if (b) start = base + 63 - __clzll((long long)b);
+            if (b) start = 63 - __clzll((long long)b);
         }
         if (dbg == 2) start = ln;
         if (dbg == 9 && lane == 0) {                          // statistics (SWFR_TILES_DEBUG=9)
             uint32_t np = 0, nf = 0;
-            for (int li = start; li < ln; ++li) { const uint32_t f = cls[li]; if (f & CLS_NONEMPTY) { if (f & (CLS_PARTIAL | CLS_BOX)) ++np; else ++nf; } }
+            for (int li = start; li < ln; ++li) { const uint32_t f = cls[li]; if (f & (CLS_PARTIAL | CLS_BOX)) ++np; else ++nf; }
             atomicAdd(&counters[CNT_PAIRS], (uint32_t)ln); atomicAdd(&counters[CNT_PARTIAL], np); atomicAdd(&counters[CNT_FULL], nf);
             atomicAdd(&counters[CNT_CULLED], (uint32_t)start);
         }
 
-        unsigned long long t2 = dbg == 10 ? __builtin_amdgcn_s_memtime() : 0ull;
-        unsigned long long t_acc = 0ull;
-        // ---- painter's order walk; the next NACC partial tor paths are accumulated together (one round trip
-        //      to their row headers and one to their records), then consumed in order
-        int pend[NACC];                                       // list indices whose acc buffer is filled
-#pragma unroll
-        for (int j = 0; j < NACC; ++j) pend[j] = -1;
-        int filled_to = start;                                // entries < filled_to have been scanned for accumulation
+        // ---- painter's order walk
         for (int li = start; li < ln; ++li) {
             const uint32_t f = cls[li];                        // wave-uniform (LDS broadcast)
-            if (!(f & CLS_NONEMPTY)) continue;
-            const BandEntry& e = ent[li];
-            const uint32_t eflags = e.flags, solid = e.solid, style = e.style;
-            const int row_lo = max((int)e.y_min, ty0) - ty0, row_hi = min((int)e.y_max, ty0 + TILE_H) - ty0;
+            const uint32_t xw = ent[li][1], yw = ent[li][2];
+            const int e_xmin = (int)(int16_t)(xw & 0xffffu), e_xmax = (int)(int16_t)(xw >> 16);
+            const int e_ymin = (int)(int16_t)(yw & 0xffffu), e_ymax = (int)(int16_t)(yw >> 16);
+            const uint32_t e_row_base = ent[li][3], style = ent[li][4], e_first = ent[li][5], e_nedges = ent[li][6];
+            const uint32_t eflags = ent[li][7], solid = ent[li][8];
+            const int row_lo = max(e_ymin, ty0) - ty0, row_hi = min(min(e_ymax, ty0 + TILE_H), height) - ty0;
             if (f & CLS_BOX) {
                 // ---- rectilinear (A.6): exact area of disjoint boxes, alpha = (c>>8) - (c>>16)
 #pragma unroll 1
                 for (int rr = row_lo; rr < row_hi; ++rr) {
                     const int cy = ty0 + rr;
                     uint32_t cov = 0u;
-                    for (uint32_t k = 0; k < e.n_edges; ++k) {
-                        const swfr_edge bx = raw_edges[e.first_edge + k];
+                    for (uint32_t k = 0; k < e_nedges; ++k) {
+                        const swfr_edge bx = raw_edges[e_first + k];
                         const int wx = min(bx.x2, (cx + 1) * 256) - max(bx.x1, cx * 256);
                         const int wy = min(bx.y2, (cy + 1) * 256) - max(bx.y1, cy * 256);
                         if (wx > 0 && wy > 0) cov += (uint32_t)(wx * wy);
@@ -967,86 +973,91 @@ __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_
                 }
             } else if (f & CLS_PARTIAL) {
                 if (dbg == 3) continue;
-                // which acc buffer holds this path?  if none, fill the buffers with the next NACC partial paths
-                int slot_j = -1;
-#pragma unroll
-                for (int j = 0; j < NACC; ++j) if (pend[j] == li) slot_j = j;
-                if (slot_j < 0) {
-                    int cand[NACC];
-                    int nc = 0;
-                    for (int lj = max(li, filled_to); lj < ln && nc < NACC; ++lj)
-                        if ((cls[lj] & (CLS_PARTIAL | CLS_BOX | CLS_NONEMPTY)) == (CLS_PARTIAL | CLS_NONEMPTY)) {
-#pragma unroll
-                            for (int j = 0; j < NACC; ++j) if (j == nc) cand[j] = lj;
-                            ++nc;
-                            filled_to = lj + 1;
-                        }
-#pragma unroll
-                    for (int j = 0; j < NACC; ++j) pend[j] = j < nc ? cand[j] : -1;
-                    // lanes = (buffer j, row, slot): every lane walks the records of its (path, row)
-                    constexpr int NSLOT = 64 / (16 * NACC);
-                    const int j = (lane >> 4) % NACC, row = lane & 15, slot = lane / (16 * NACC);
-                    int mine = -1;
-#pragma unroll
-                    for (int jj = 0; jj < NACC; ++jj) if (jj == j) mine = pend[jj];
-                    const unsigned long long ta0 = dbg == 10 ? __builtin_amdgcn_s_memtime() : 0ull;
-                    if (mine >= 0 && dbg != 5) {
-                        const BandEntry& pe = ent[mine];
-                        const int y = ty0 + row;
-                        if (y >= pe.y_min && y < pe.y_max) {
-                            const RowInfo ri = rows[pe.row_base + (uint32_t)(y - pe.y_min)];
-                            if (ri.n_rec) {
-                                TileCtx c; c.tx0 = tx0; c.xminp = pe.x_min; c.xmaxp = pe.x_max;
-                                if (slot == 0) acc[j][row][ACC_TOUCH] = 1;
-                                accumulate_row(ri, records, acc[j][row], c, slot, NSLOT);
-                            }
-                        }
+                // ---- tor (A.5).  Row headers: 16 consecutive RowInfo = one line, loaded by lanes 0..15
+                uint32_t my_cnt = 0;
+                if (lane < TILE_H) {
+                    uint32_t off = 0;
+                    if (lane >= row_lo && lane < row_hi) {
+                        const uint32_t ridx = e_row_base + (uint32_t)(ty0 + lane - e_ymin);
+                        if (ridx < n_rows_total) {
+                            const RowInfo ri = rows[ridx];
+                            off = ri.rec_off; my_cnt = ri.n_rec;
+                            if ((uint64_t)off + my_cnt > n_rec_cap) { atomicOr(&counters[CNT_ERROR], 4u); my_cnt = 0; }
+                        } else atomicOr(&counters[CNT_ERROR], 2u);      // defensive: never read outside the row table
                     }
-                    if (dbg == 10) { __builtin_amdgcn_s_waitcnt(0); t_acc += __builtin_amdgcn_s_memtime() - ta0; }
-#pragma unroll
-                    for (int jj = 0; jj < NACC; ++jj) if (pend[jj] == li) slot_j = jj;
+                    row_off[lane] = off;
                 }
-                // ---- prefix sum, alpha, blend for this path's buffer; clears as it reads
-                int (*A)[ACC_STRIDE] = acc[slot_j];
+                // exclusive prefix of the per-row record counts (lanes 0..15), total in row_start[16]
+                const int incl = wave_scan_incl((int)my_cnt);
+                if (lane < TILE_H) row_start[lane] = (uint32_t)(incl - (int)my_cnt);
+                int total = __shfl(incl, TILE_H - 1);              // lanes >= 16 contribute 0
+                __syncthreads();                                   // row_off / row_start visible to every lane
+                if (dbg == 11) total = 0;
+                TileCtx c; c.tx0 = tx0; c.xminp = e_xmin; c.xmaxp = e_xmax;
+                const uint32_t* rdw = reinterpret_cast<const uint32_t*>(records);
+                for (int base = 0; base < total; base += REC_STAGE) {
+                    const int n = min(REC_STAGE, total - base);
+                    // which row does each staged record belong to, and where does it live
+                    for (int t = lane; t < n; t += 64) {
+                        const uint32_t g = (uint32_t)(base + t);
+                        int lo = 0, hi = TILE_H;                    // last row with row_start <= g
+                        while (lo + 1 < hi) { const int mid = (lo + hi) >> 1; if (row_start[mid] <= g) lo = mid; else hi = mid; }
+                        rec_row[t] = (uint8_t)lo;
+                        uint32_t src = row_off[lo] + (g - row_start[lo]);
+                        if (src >= n_rec_cap) { atomicOr(&counters[CNT_ERROR], 8u); src = 0; }   // defensive
+                        rec_src[t] = src;
+                    }
+                    __syncthreads();
+                    if (dbg == 12) continue;
+                    // coalesced dword stream of the records into LDS
+                    for (int d = lane; d < n * 12; d += 64) {
+                        const int t = d / 12, w = d - t * 12;
+                        stage[d] = rdw[(size_t)rec_src[t] * 12 + w];
+                    }
+                    __syncthreads();
+                    // lanes = records
+                    if (dbg != 5 && dbg != 13)
+                        for (int t = lane; t < n; t += 64) {
+                            const uint32_t* sw = &stage[t * 12];                 // dword reads only: no alignment assumption
+                            Rec rec;
+                            rec.roles = sw[0]; rec.cols = sw[1]; rec.q1 = (int32_t)sw[2]; rec.q2 = (int32_t)sw[3];
+                            rec.r1 = (int64_t)((uint64_t)sw[4] | ((uint64_t)sw[5] << 32));
+                            rec.r2 = (int64_t)((uint64_t)sw[6] | ((uint64_t)sw[7] << 32));
+                            rec.dy = (int64_t)((uint64_t)sw[8] | ((uint64_t)sw[9] << 32));
+                            rec.span = sw[10]; rec.eid = sw[11];
+                            const int r = rec_row[t];
+                            acc[r][ACC_TOUCH] = 1;
+                            accumulate_record(rec, acc[r], c);
+                        }
+                    __syncthreads();                               // stage / rec_row may be rewritten; acc complete
+                }
+                // ---- prefix sum, alpha, blend; clears as it reads
 #pragma unroll 1
                 for (int rr = row_lo; rr < row_hi; ++rr) {
                     if (dbg == 4) continue;
-                    if (!A[rr][ACC_TOUCH] && dbg != 5) continue;       // wave-uniform
-                    const int v = A[rr][lane];
-                    const int carry = A[rr][ACC_CARRY];
-                    A[rr][lane] = 0;
-                    if (lane < 2) A[rr][ACC_CARRY + lane] = 0;
+                    if (!acc[rr][ACC_TOUCH] && dbg != 5) continue;     // wave-uniform
+                    const int v = acc[rr][lane];
+                    const int carry = acc[rr][ACC_CARRY];
+                    acc[rr][lane] = 0;
+                    if (lane < 2) acc[rr][ACC_CARRY + lane] = 0;
                     const int ua = (v << 12) >> 12;                    // low 20 bits, sign-extended
                     int ch = (v - ua) >> 20;
                     if (lane == 0) ch += carry;
                     const int scan = wave_scan_incl(ch);
                     const int area = scan * 512 - ua;
                     uint32_t a = (uint32_t)((area * 17 + 256) >> 9) & 255u;
-                    if (cx < e.x_min || cx >= e.x_max) a = 0;
+                    if (cx < e_xmin || cx >= e_xmax) a = 0;
                     if (a) px[rr][lane] = blend_pixel(px[rr][lane], a, eflags, solid, styles, style, bitmaps, cx, ty0 + rr);
                 }
-#pragma unroll
-                for (int jj = 0; jj < NACC; ++jj) if (jj == slot_j) pend[jj] = -1;
+                __syncthreads();                                   // acc cleared before the next path accumulates
             } else {
                 // full cover: every in-frame pixel of the tile has coverage 255
 #pragma unroll 1
                 for (int rr = row_lo; rr < row_hi; ++rr) px[rr][lane] = blend_pixel(px[rr][lane], 255u, eflags, solid, styles, style, bitmaps, cx, ty0 + rr);
             }
         }
-        if (dbg == 10 && lane == 0) {
-            const unsigned long long t4 = __builtin_amdgcn_s_memtime();
-            atomicAdd((unsigned long long*)&counters[12], t2 - t1);       // classification + occlusion
-            atomicAdd((unsigned long long*)&counters[14], t_acc);         // accumulate (P1) incl. waiting for its loads
-            atomicAdd((unsigned long long*)&counters[16], t4 - t2);       // whole walk
-            atomicAdd((unsigned long long*)&counters[18], t1 - t_start10); // up to end of binning (first round)
-        }
     }
 
-    if (dbg == 10 && lane == 0) {
-        const unsigned long long t3 = __builtin_amdgcn_s_memtime();
-        atomicAdd(&counters[8], 1u);
-        atomicAdd((unsigned long long*)&counters[10], t3 - t_start10);
-    }
     if (dbg == 8 && lane == 0) px[0][0] = (uint32_t)(__builtin_amdgcn_s_memtime() - t_start);   // diagnostics: tile duration in clocks
     // ---- one store per pixel: premultiplied R,G,B,A bytes; the wave writes 256 contiguous bytes per row
     if (cx < width) {
@@ -1109,20 +1120,22 @@ void launch_rows(hipStream_t st, const DevEdge* edges, const DevPath* paths, con
     hipLaunchKernelGGL(k_rows_big, dim3(256), dim3(64), 0, st, edges, paths, row_base, n_paths, rows, records, counters, overflow_list);
 }
 void launch_class(hipStream_t st, const BandEntry* band_list, uint32_t n_entries, const uint32_t* band_off, uint32_t n_bands,
-                  const swfr_edge* raw, const RowInfo* rows, const Rec* records, uint8_t* cls_mat, int width, int height) {
+                  const swfr_edge* raw, const RowInfo* rows, const Rec* records, uint8_t* cls_t, int width, int height,
+                  uint32_t band_index, uint32_t band_count) {
     if (!n_entries) return;
-    hipLaunchKernelGGL(k_class, dim3(n_entries), dim3(64), 0, st, band_list, n_entries, band_off, n_bands, raw, rows, records, cls_mat,
-                       width, height);
+    const int tiles_x = (width + TILE_W - 1) / TILE_W;
+    hipLaunchKernelGGL(k_class, dim3(n_entries), dim3(64), 0, st, band_list, n_entries, band_off, n_bands, raw, rows, records, cls_t,
+                       width, height, tiles_x, band_index, band_count);
 }
 void launch_tiles(hipStream_t st, const swfr_edge* raw, const uint32_t* band_off, const BandEntry* band_list, const uint8_t* cls_mat,
                   const RowInfo* rows, const Rec* records, const swfr_style* styles, const DevBitmap* bitmaps, uint32_t* fb, int width, int height,
-                  uint32_t band_index, uint32_t band_count, int dbg, uint32_t* counters) {
+                  uint32_t band_index, uint32_t band_count, int dbg, uint32_t* counters, uint32_t n_rows_total, uint32_t n_rec_cap) {
     const int tiles_x = (width + TILE_W - 1) / TILE_W, tile_rows = (height + TILE_H - 1) / TILE_H;
     uint32_t local_rows = tile_rows;
     if (band_count > 1) local_rows = (tile_rows > (int)band_index) ? (tile_rows - band_index + band_count - 1) / band_count : 0;
     if (!local_rows) return;
     hipLaunchKernelGGL(k_tiles, dim3(tiles_x * local_rows), dim3(64), 0, st, raw, band_off, band_list, cls_mat, rows, records, styles, bitmaps,
-                       fb, width, height, tiles_x, band_index, band_count, dbg, counters);
+                       fb, width, height, tiles_x, band_index, band_count, dbg, counters, n_rows_total, n_rec_cap);
 }
 void launch_unpremultiply(hipStream_t st, const uint32_t* in, uint32_t* out, size_t n) {
     if (!n) return;

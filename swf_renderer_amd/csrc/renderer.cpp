@@ -23,11 +23,12 @@
 namespace swfr {
 void launch_setup(hipStream_t, const swfr_edge*, const DevPath*, DevEdge*, uint32_t);
 void launch_bands(hipStream_t, const DevPath*, uint32_t, const uint32_t*, const swfr_style*, const uint32_t*, BandEntry*, uint32_t, uint32_t*);
-void launch_class(hipStream_t, const BandEntry*, uint32_t, const uint32_t*, uint32_t, const swfr_edge*, const RowInfo*, const Rec*, uint8_t*, int, int);
+void launch_class(hipStream_t, const BandEntry*, uint32_t, const uint32_t*, uint32_t, const swfr_edge*, const RowInfo*, const Rec*, uint8_t*, int, int,
+                  uint32_t, uint32_t);
 void launch_rows(hipStream_t, const DevEdge*, const DevPath*, const uint32_t*, const uint32_t*, uint32_t, RowInfo*, Rec*, uint32_t*,
                  uint32_t*, uint32_t, uint32_t, uint32_t, int);
 void launch_tiles(hipStream_t, const swfr_edge*, const uint32_t*, const BandEntry*, const uint8_t*, const RowInfo*, const Rec*, const swfr_style*,
-                  const DevBitmap*, uint32_t*, int, int, uint32_t, uint32_t, int, uint32_t*);
+                  const DevBitmap*, uint32_t*, int, int, uint32_t, uint32_t, int, uint32_t*, uint32_t, uint32_t);
 void launch_unpremultiply(hipStream_t, const uint32_t*, uint32_t*, size_t);
 void launch_pack_band(hipStream_t, const uint32_t*, uint32_t*, int, int, uint32_t, uint32_t, uint32_t);
 }  // namespace swfr
@@ -213,7 +214,8 @@ int upload(swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_
     r->d_row_base.reserve(n_paths + 1); r->d_rows.reserve(r->n_tasks); r->d_records.reserve(r->rec_cap);
     r->d_chunk_base.reserve(n_paths + 1); r->d_band_off.reserve(n_bands + 1); r->d_band_list.reserve(band_off[n_bands]);
     r->d_overflow.reserve(r->n_tasks);
-    r->d_cls.reserve(pair_cap + 64);
+    (void)pair_cap;
+    r->d_cls.reserve(size_t(band_off[n_bands]) * ((r->width + TILE_W - 1) / TILE_W) + 64);   // class byte per (band entry, tile column)
     r->n_band_entries = band_off[n_bands];
     r->d_counters.reserve(CNT_WORDS);
     if (n_edges) HIP_CHECK(hipMemcpyAsync(r->d_raw.ptr, staged.data(), n_edges * sizeof(swfr_edge), hipMemcpyHostToDevice, r->stream));
@@ -262,11 +264,14 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
             launch_rows(r->stream, r->d_edges.ptr, r->d_paths.ptr, r->d_row_base.ptr, r->d_chunk_base.ptr, uint32_t(r->n_paths), r->d_rows.ptr,
                         r->d_records.ptr, r->d_counters.ptr, r->d_overflow.ptr, uint32_t(r->n_chunks), bi, bc, r->fast_limit);
         if (r->n_paths)
+        {
+            HIP_CHECK(hipMemsetAsync(r->d_cls.ptr, 0, r->n_band_entries * ((r->width + TILE_W - 1) / TILE_W), r->stream));
             launch_class(r->stream, r->d_band_list.ptr, uint32_t(r->n_band_entries), r->d_band_off.ptr, uint32_t(r->n_bands), r->d_raw.ptr,
-                         r->d_rows.ptr, r->d_records.ptr, r->d_cls.ptr, int(r->width), int(r->height));
+                         r->d_rows.ptr, r->d_records.ptr, r->d_cls.ptr, int(r->width), int(r->height), bi, bc);
+        }
         HIP_CHECK(hipEventRecord(e[2], r->stream));
         launch_tiles(r->stream, r->d_raw.ptr, r->d_band_off.ptr, r->d_band_list.ptr, r->d_cls.ptr, r->d_rows.ptr, r->d_records.ptr, r->d_styles.ptr,
-                     r->d_bitmap_table.ptr, r->d_fb.ptr, int(r->width), int(r->height), bi, bc, r->tiles_dbg, r->d_counters.ptr);
+                     r->d_bitmap_table.ptr, r->d_fb.ptr, int(r->width), int(r->height), bi, bc, r->tiles_dbg, r->d_counters.ptr, uint32_t(r->n_tasks), uint32_t(r->rec_cap));
         HIP_CHECK(hipEventRecord(e[3], r->stream));
     }
     HIP_CHECK(hipGetLastError());
@@ -292,6 +297,10 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
                      u64(12) / n, u64(16) / n, u64(14) / n);
     }
     r->fb_valid = true;
+    if (counters[CNT_ERROR] & ~1u) {
+        r->fb_valid = false;
+        return fail(r, SWFR_ERR_DEVICE, "internal consistency check failed in k_tiles (code " + std::to_string(counters[CNT_ERROR]) + ")");
+    }
     if (counters[CNT_ERROR]) {
         r->fb_valid = false;
         return fail(r, SWFR_ERR_CAPACITY, "a pixel row has more than 64 active edges of one path (scan converter capacity)");
