@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void k_bands(const DevPath* __restrict__ paths
             if (P.lerp) fl |= BE_LERP;
             if (kind == SWFR_STYLE_SOLID) fl |= BE_SOLID;
             if (kind == SWFR_STYLE_SOLID && P.lerp && (pixel >> 24) == 0xffu) fl |= BE_OPAQUE_COVER;
-            e.flags = fl; e.solid = pixel;
+            e.flags = fl | ((uint32_t)band << 8); e.solid = pixel;   // the band index rides in the upper bits
             out[off + __popcll(b & ((1ull << lane) - 1ull))] = e;
         }
         __syncthreads();
@@ -779,52 +779,84 @@ __global__ __launch_bounds__(64) void k_class(const BandEntry* __restrict__ band
     const uint32_t ei = blockIdx.x;
     if (ei >= n_entries) return;
     const int lane = threadIdx.x;
-    // band of this entry: upper_bound on the band offsets (wave-uniform)
-    uint32_t lo = 0, hi = n_bands;
-    while (lo + 1 < hi) { const uint32_t mid = (lo + hi) >> 1; if (band_off[mid] <= ei) lo = mid; else hi = mid; }
-    if (band_count > 1 && lo % band_count != band_index) return;        // another rank's tile-row
     const BandEntry e = band_list[ei];
-    const uint32_t b0 = band_off[lo], n_b = band_off[lo + 1] - b0, e_local = ei - b0;
+    const uint32_t band = e.flags >> 8;
+    if (band >= n_bands) return;
+    if (band_count > 1 && band % band_count != band_index) return;      // another rank's tile-row
+    const uint32_t b0 = band_off[band], n_b = band_off[band + 1] - b0, e_local = ei - b0;
     uint8_t* out = cls_t + (size_t)tiles_x * b0 + e_local;              // + tile column * n_b
-    const int ty0 = (int)lo * TILE_H;
+    const int ty0 = (int)band * TILE_H, tile_y1 = min(ty0 + TILE_H, height);
     const int tc0 = (int)e.x_min / TILE_W, tc1 = ((int)e.x_max - 1) / TILE_W;
-    for (int tc = tc0 + lane; tc <= tc1; tc += 64) {
-        const int tx0 = tc * TILE_W, tile_x1 = min(tx0 + TILE_W, width), tile_y1 = min(ty0 + TILE_H, height);
-        uint32_t flags = 0;
-        if (e.flags & BE_BOXES) {
-            flags = CLS_BOX | CLS_NONEMPTY | CLS_NOTFULL;
-            if (e.n_edges == 1) {                 // one box that contains the whole tile: full cover
+    if (e.flags & BE_BOXES) {
+        for (int tc = tc0 + lane; tc <= tc1; tc += 64) {
+            const int tx0 = tc * TILE_W, tile_x1 = min(tx0 + TILE_W, width);
+            uint32_t flags = CLS_BOX | CLS_NONEMPTY | CLS_NOTFULL;
+            if (e.n_edges == 1) {                     // one box that contains the whole tile: full cover
                 const swfr_edge bx = raw_edges[e.first_edge];
                 if (bx.x1 <= tx0 * 256 && bx.x2 >= tile_x1 * 256 && bx.y1 <= ty0 * 256 && bx.y2 >= tile_y1 * 256) flags = CLS_NONEMPTY;
             }
-        } else {
-            const bool inside_x = e.x_min <= tx0 && e.x_max >= tile_x1;
-            for (int y = ty0; y < tile_y1; ++y) {
-                if (y < e.y_min || y >= e.y_max) { flags |= CLS_NOTFULL; continue; }
-                const RowInfo ri = rows[e.row_base + (uint32_t)(y - e.y_min)];
+            out[(size_t)tc * n_b] = (uint8_t)flags;
+        }
+        return;
+    }
+    // lane = (tile column within a group of four, pixel row of the band): the 16 rows are read once, in parallel
+    const int row = lane & 15, sub = lane >> 4;
+    const int y = ty0 + row;
+    const bool in_frame = y < tile_y1, in_rows = in_frame && y >= e.y_min && y < e.y_max;
+    uint32_t n_rec = 0, rec_off = 0;
+    if (in_rows) { const RowInfo ri = rows[e.row_base + (uint32_t)(y - e.y_min)]; n_rec = ri.n_rec; rec_off = ri.rec_off; }
+    constexpr int HN = 6;                             // record headers kept in registers; longer rows re-read the rest
+    uint32_t hroles[HN], hcols[HN];
+#pragma unroll
+    for (int k = 0; k < HN; ++k) {
+        hroles[k] = 0; hcols[k] = 0;
+        if ((uint32_t)k < n_rec) { const Rec* rp = &records[rec_off + k]; hroles[k] = rp->roles; hcols[k] = rp->cols; }
+    }
+    for (int tcb = tc0; tcb <= tc1; tcb += 4) {
+        const int tc = tcb + sub;
+        const int tx0 = tc * TILE_W, tile_x1 = min(tx0 + TILE_W, width);
+        uint32_t f = 0;
+        if (in_frame && tc <= tc1) {
+            if (!in_rows) f = CLS_NOTFULL;
+            else {
                 int carry = 0;
                 bool inter = false;
-                for (uint32_t k = 0; k < ri.n_rec; ++k) {
-                    const Rec* rp = &records[ri.rec_off + k];
+#pragma unroll
+                for (int k = 0; k < HN; ++k) {
+                    if ((uint32_t)k >= n_rec) continue;
+                    const int clo = (int)(hcols[k] & 0xffffu), chi = (int)(hcols[k] >> 16);
+                    if (chi < tx0 && chi < 65535) carry += record_height(hroles[k]);
+                    else if (clo >= tx0 + TILE_W && clo < 65535) { /* right of the tile */ }
+                    else inter = true;
+                }
+                for (uint32_t k = HN; k < n_rec; ++k) {
+                    const Rec* rp = &records[rec_off + k];
                     const uint32_t rroles = rp->roles, rcols = rp->cols;
                     const int clo = (int)(rcols & 0xffffu), chi = (int)(rcols >> 16);
                     if (chi < tx0 && chi < 65535) carry += record_height(rroles);
                     else if (clo >= tx0 + TILE_W && clo < 65535) { /* right of the tile */ }
                     else inter = true;
                 }
+                const bool inside_x = e.x_min <= tx0 && e.x_max >= tile_x1;
                 const uint32_t a = (uint32_t)((carry * 512 * 17 + 256) >> 9) & 255u;
-                if (inter) flags |= CLS_PARTIAL | CLS_NOTFULL | CLS_NONEMPTY;
-                else if (a == 0) flags |= CLS_NOTFULL;
-                else if (a == 255 && inside_x) flags |= CLS_NONEMPTY;
-                else flags |= CLS_PARTIAL | CLS_NOTFULL | CLS_NONEMPTY;   // uniform partial alpha or column masking
+                if (inter) f = CLS_PARTIAL | CLS_NOTFULL | CLS_NONEMPTY;
+                else if (a == 0) f = CLS_NOTFULL;
+                else if (a == 255 && inside_x) f = CLS_NONEMPTY;
+                else f = CLS_PARTIAL | CLS_NOTFULL | CLS_NONEMPTY;       // uniform partial alpha or column masking
             }
         }
-        out[(size_t)tc * n_b] = (uint8_t)flags;
+        // OR over the 16 rows of the tile (lanes of one 16-lane group); every lane active
+        f |= (uint32_t)__shfl_xor((int)f, 8);
+        f |= (uint32_t)__shfl_xor((int)f, 4);
+        f |= (uint32_t)__shfl_xor((int)f, 2);
+        f |= (uint32_t)__shfl_xor((int)f, 1);
+        if (row == 0 && tc <= tc1) out[(size_t)tc * n_b] = (uint8_t)f;
     }
 }
 
 #define TLIST 64                       // tile list entries per round
-#define REC_STAGE 96                   // records of one (tile, path) staged in LDS per round
+#define REC_STAGE 96                   // records staged in LDS per round
+#define NB 2                           // partial paths whose records are fetched and accumulated together
 
 __device__ __forceinline__ uint32_t blend_pixel(uint32_t dst, uint32_t a, uint32_t eflags, uint32_t solid, const swfr_style* __restrict__ styles,
                                                 uint32_t style, const DevBitmap* __restrict__ bitmaps, int cx, int cy) {
@@ -872,13 +904,13 @@ __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_
                                               const DevBitmap* __restrict__ bitmaps, uint32_t* __restrict__ fb,
                                               int width, int height, int tiles_x, uint32_t band_index, uint32_t band_count, int dbg,
                                               uint32_t* __restrict__ counters, uint32_t n_rows_total, uint32_t n_rec_cap) {
-    __shared__ int acc[TILE_H][ACC_STRIDE];
+    __shared__ int acc[NB][TILE_H][ACC_STRIDE];
     __shared__ uint32_t px[TILE_H][TILE_W];
     __shared__ uint32_t ent[TLIST][9];                    // BandEntry as 9 dwords
     __shared__ uint32_t cls[TLIST];
     __shared__ __attribute__((aligned(16))) uint32_t stage[REC_STAGE * 12];   // records as dwords
     __shared__ uint32_t rec_src[REC_STAGE];
-    __shared__ uint32_t row_off[TILE_H], row_start[TILE_H + 1];
+    __shared__ uint32_t row_off[NB * TILE_H], row_start[NB * TILE_H + 1];
     __shared__ uint8_t rec_row[REC_STAGE];
 
     const int lane = threadIdx.x;
@@ -892,9 +924,10 @@ __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_
     if (ty0 >= height) return;
     const int cx = tx0 + lane;
     const unsigned long long t_start = dbg == 8 ? __builtin_amdgcn_s_memtime() : 0ull;
+    uint32_t dbg_pairs = 0, dbg_recs = 0;
 
     for (int rr = 0; rr < TILE_H; ++rr) px[rr][lane] = 0u;
-    for (int i = lane; i < TILE_H * ACC_STRIDE; i += 64) (&acc[0][0])[i] = 0;
+    for (int i = lane; i < NB * TILE_H * ACC_STRIDE; i += 64) (&acc[0][0][0])[i] = 0;
 
     const uint32_t band_begin = band_off[trow], band_end = band_off[trow + 1];
     const uint32_t n_b = band_end - band_begin;
@@ -947,13 +980,18 @@ __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_
             atomicAdd(&counters[CNT_CULLED], (uint32_t)start);
         }
 
-        // ---- painter's order walk
+        // ---- painter's order walk.  Partial tor paths are fetched + accumulated NB at a time (one round trip to
+        //      their row headers, one to their records), then consumed in order from their own accumulator.
+        int pend[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) pend[j] = -1;
+        int filled_to = start;
         for (int li = start; li < ln; ++li) {
             const uint32_t f = cls[li];                        // wave-uniform (LDS broadcast)
             const uint32_t xw = ent[li][1], yw = ent[li][2];
             const int e_xmin = (int)(int16_t)(xw & 0xffffu), e_xmax = (int)(int16_t)(xw >> 16);
             const int e_ymin = (int)(int16_t)(yw & 0xffffu), e_ymax = (int)(int16_t)(yw >> 16);
-            const uint32_t e_row_base = ent[li][3], style = ent[li][4], e_first = ent[li][5], e_nedges = ent[li][6];
+            const uint32_t style = ent[li][4], e_first = ent[li][5], e_nedges = ent[li][6];
             const uint32_t eflags = ent[li][7], solid = ent[li][8];
             const int row_lo = max(e_ymin, ty0) - ty0, row_hi = min(min(e_ymax, ty0 + TILE_H), height) - ty0;
             if (f & CLS_BOX) {
@@ -973,82 +1011,140 @@ __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_
                 }
             } else if (f & CLS_PARTIAL) {
                 if (dbg == 3) continue;
-                // ---- tor (A.5).  Row headers: 16 consecutive RowInfo = one line, loaded by lanes 0..15
-                uint32_t my_cnt = 0;
-                if (lane < TILE_H) {
-                    uint32_t off = 0;
-                    if (lane >= row_lo && lane < row_hi) {
-                        const uint32_t ridx = e_row_base + (uint32_t)(ty0 + lane - e_ymin);
-                        if (ridx < n_rows_total) {
-                            const RowInfo ri = rows[ridx];
-                            off = ri.rec_off; my_cnt = ri.n_rec;
-                            if ((uint64_t)off + my_cnt > n_rec_cap) { atomicOr(&counters[CNT_ERROR], 4u); my_cnt = 0; }
-                        } else atomicOr(&counters[CNT_ERROR], 2u);      // defensive: never read outside the row table
-                    }
-                    row_off[lane] = off;
-                }
-                // exclusive prefix of the per-row record counts (lanes 0..15), total in row_start[16]
-                const int incl = wave_scan_incl((int)my_cnt);
-                if (lane < TILE_H) row_start[lane] = (uint32_t)(incl - (int)my_cnt);
-                int total = __shfl(incl, TILE_H - 1);              // lanes >= 16 contribute 0
-                __syncthreads();                                   // row_off / row_start visible to every lane
-                if (dbg == 11) total = 0;
-                TileCtx c; c.tx0 = tx0; c.xminp = e_xmin; c.xmaxp = e_xmax;
-                const uint32_t* rdw = reinterpret_cast<const uint32_t*>(records);
-                for (int base = 0; base < total; base += REC_STAGE) {
-                    const int n = min(REC_STAGE, total - base);
-                    // which row does each staged record belong to, and where does it live
-                    for (int t = lane; t < n; t += 64) {
-                        const uint32_t g = (uint32_t)(base + t);
-                        int lo = 0, hi = TILE_H;                    // last row with row_start <= g
-                        while (lo + 1 < hi) { const int mid = (lo + hi) >> 1; if (row_start[mid] <= g) lo = mid; else hi = mid; }
-                        rec_row[t] = (uint8_t)lo;
-                        uint32_t src = row_off[lo] + (g - row_start[lo]);
-                        if (src >= n_rec_cap) { atomicOr(&counters[CNT_ERROR], 8u); src = 0; }   // defensive
-                        rec_src[t] = src;
-                    }
-                    __syncthreads();
-                    if (dbg == 12) continue;
-                    // coalesced dword stream of the records into LDS
-                    for (int d = lane; d < n * 12; d += 64) {
-                        const int t = d / 12, w = d - t * 12;
-                        stage[d] = rdw[(size_t)rec_src[t] * 12 + w];
-                    }
-                    __syncthreads();
-                    // lanes = records
-                    if (dbg != 5 && dbg != 13)
-                        for (int t = lane; t < n; t += 64) {
-                            const uint32_t* sw = &stage[t * 12];                 // dword reads only: no alignment assumption
-                            Rec rec;
-                            rec.roles = sw[0]; rec.cols = sw[1]; rec.q1 = (int32_t)sw[2]; rec.q2 = (int32_t)sw[3];
-                            rec.r1 = (int64_t)((uint64_t)sw[4] | ((uint64_t)sw[5] << 32));
-                            rec.r2 = (int64_t)((uint64_t)sw[6] | ((uint64_t)sw[7] << 32));
-                            rec.dy = (int64_t)((uint64_t)sw[8] | ((uint64_t)sw[9] << 32));
-                            rec.span = sw[10]; rec.eid = sw[11];
-                            const int r = rec_row[t];
-                            acc[r][ACC_TOUCH] = 1;
-                            accumulate_record(rec, acc[r], c);
+                // ---- tor (A.5)
+                int slot_j = -1;
+#pragma unroll
+                for (int j = 0; j < NB; ++j) if (pend[j] == li) slot_j = j;
+                if (slot_j < 0) {
+                    // the next NB partial tor paths of the list (this one included)
+                    int nc = 0;
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) pend[j] = -1;
+                    for (int lj = max(li, filled_to); lj < ln && nc < NB; ++lj)
+                        if ((cls[lj] & (CLS_PARTIAL | CLS_BOX)) == CLS_PARTIAL) {
+#pragma unroll
+                            for (int j = 0; j < NB; ++j) if (j == nc) pend[j] = lj;
+                            ++nc;
+                            filled_to = lj + 1;
                         }
-                    __syncthreads();                               // stage / rec_row may be rewritten; acc complete
+                    // row headers: lane = (path j, row); 16 consecutive RowInfo per path = one line each
+                    uint32_t my_cnt = 0;
+                    if (lane < NB * TILE_H) {
+                        const int j = lane >> 4, row = lane & 15;
+                        int mine = -1;
+#pragma unroll
+                        for (int jj = 0; jj < NB; ++jj) if (jj == j) mine = pend[jj];
+                        uint32_t off = 0;
+                        if (mine >= 0) {
+                            const uint32_t myw = ent[mine][2];
+                            const int p_ymin = (int)(int16_t)(myw & 0xffffu), p_ymax = (int)(int16_t)(myw >> 16);
+                            const int y = ty0 + row;
+                            if (y >= p_ymin && y < p_ymax && y < height) {
+                                const uint32_t ridx = ent[mine][3] + (uint32_t)(y - p_ymin);
+                                if (ridx < n_rows_total) {
+                                    const RowInfo ri = rows[ridx];
+                                    off = ri.rec_off; my_cnt = ri.n_rec;
+                                    if ((uint64_t)off + my_cnt > n_rec_cap) { atomicOr(&counters[CNT_ERROR], 4u); my_cnt = 0; }
+                                } else atomicOr(&counters[CNT_ERROR], 2u);  // defensive: never read outside the row table
+                            }
+                        }
+                        row_off[lane] = off;
+                    }
+                    // exclusive prefix of the per-row record counts
+                    const int incl = wave_scan_incl((int)my_cnt);
+                    if (lane < NB * TILE_H) row_start[lane] = (uint32_t)(incl - (int)my_cnt);
+                    int total = __shfl(incl, NB * TILE_H - 1);         // lanes beyond contribute 0
+                    ++dbg_pairs; dbg_recs += (uint32_t)total;
+                    __syncthreads();                                   // row_off / row_start visible to every lane
+                    if (dbg == 11) total = 0;
+                    const uint32_t* rdw = reinterpret_cast<const uint32_t*>(records);
+                    for (int base = 0; base < total; base += REC_STAGE) {
+                        const int n = min(REC_STAGE, total - base);
+                        // which (path, row) does each staged record belong to, and where does it live
+                        for (int t = lane; t < n; t += 64) {
+                            const uint32_t g = (uint32_t)(base + t);
+                            int lo = 0, hi = NB * TILE_H;               // last virtual row with row_start <= g
+                            while (lo + 1 < hi) { const int mid = (lo + hi) >> 1; if (row_start[mid] <= g) lo = mid; else hi = mid; }
+                            rec_row[t] = (uint8_t)lo;
+                            uint32_t src = row_off[lo] + (g - row_start[lo]);
+                            if (src >= n_rec_cap) { atomicOr(&counters[CNT_ERROR], 8u); src = 0; }   // defensive
+                            rec_src[t] = src;
+                        }
+                        __syncthreads();
+                        if (dbg == 12) continue;
+                        // coalesced dword stream of the records into LDS, six independent loads in flight per lane
+                        for (int d0 = 0; d0 < n * 12; d0 += 64 * 6) {
+                            uint32_t tmp[6];
+#pragma unroll
+                            for (int u = 0; u < 6; ++u) {
+                                const int d = d0 + u * 64 + lane;
+                                tmp[u] = 0u;
+                                if (d < n * 12) { const int t = d / 12, w = d - t * 12; tmp[u] = rdw[(size_t)rec_src[t] * 12 + w]; }
+                            }
+#pragma unroll
+                            for (int u = 0; u < 6; ++u) {
+                                const int d = d0 + u * 64 + lane;
+                                if (d < n * 12) stage[d] = tmp[u];
+                            }
+                        }
+                        __syncthreads();
+                        // lanes = records
+                        if (dbg != 5 && dbg != 13)
+                            for (int t = lane; t < n; t += 64) {
+                                const uint32_t* sw = &stage[t * 12];                 // dword reads only: no alignment assumption
+                                Rec rec;
+                                rec.roles = sw[0]; rec.cols = sw[1]; rec.q1 = (int32_t)sw[2]; rec.q2 = (int32_t)sw[3];
+                                rec.r1 = (int64_t)((uint64_t)sw[4] | ((uint64_t)sw[5] << 32));
+                                rec.r2 = (int64_t)((uint64_t)sw[6] | ((uint64_t)sw[7] << 32));
+                                rec.dy = (int64_t)((uint64_t)sw[8] | ((uint64_t)sw[9] << 32));
+                                rec.span = sw[10]; rec.eid = sw[11];
+                                const int vr = rec_row[t], j = vr >> 4, r = vr & 15;
+                                int mine = 0;
+#pragma unroll
+                                for (int jj = 0; jj < NB; ++jj) if (jj == j) mine = pend[jj];
+                                const uint32_t mxw = ent[mine][1];
+                                TileCtx c; c.tx0 = tx0; c.xminp = (int)(int16_t)(mxw & 0xffffu); c.xmaxp = (int)(int16_t)(mxw >> 16);
+                                acc[j][r][ACC_TOUCH] = 1;
+                                accumulate_record(rec, acc[j][r], c);
+                            }
+                        __syncthreads();                               // stage / rec_row may be rewritten; acc complete
+                    }
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) if (pend[j] == li) slot_j = j;
                 }
-                // ---- prefix sum, alpha, blend; clears as it reads
+                int (*A)[ACC_STRIDE] = acc[slot_j];
+                // ---- prefix sum, alpha, blend; clears as it reads.  Four rows per step so their LDS round trips overlap
 #pragma unroll 1
-                for (int rr = row_lo; rr < row_hi; ++rr) {
+                for (int r4 = row_lo; r4 < row_hi; r4 += 4) {
                     if (dbg == 4) continue;
-                    if (!acc[rr][ACC_TOUCH] && dbg != 5) continue;     // wave-uniform
-                    const int v = acc[rr][lane];
-                    const int carry = acc[rr][ACC_CARRY];
-                    acc[rr][lane] = 0;
-                    if (lane < 2) acc[rr][ACC_CARRY + lane] = 0;
-                    const int ua = (v << 12) >> 12;                    // low 20 bits, sign-extended
-                    int ch = (v - ua) >> 20;
-                    if (lane == 0) ch += carry;
-                    const int scan = wave_scan_incl(ch);
-                    const int area = scan * 512 - ua;
-                    uint32_t a = (uint32_t)((area * 17 + 256) >> 9) & 255u;
-                    if (cx < e_xmin || cx >= e_xmax) a = 0;
-                    if (a) px[rr][lane] = blend_pixel(px[rr][lane], a, eflags, solid, styles, style, bitmaps, cx, ty0 + rr);
+                    int v[4], carry[4], touch[4];
+                    uint32_t old_px[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int rr = min(r4 + u, TILE_H - 1);
+                        touch[u] = (r4 + u < row_hi) ? A[rr][ACC_TOUCH] : 0;
+                        v[u] = A[rr][lane];
+                        carry[u] = A[rr][ACC_CARRY];
+                        old_px[u] = px[rr][lane];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int rr = r4 + u;
+                        if (!touch[u]) continue;                       // wave-uniform
+                        A[rr][lane] = 0;
+                        if (lane < 2) A[rr][ACC_CARRY + lane] = 0;
+                        const int ua = (v[u] << 12) >> 12;             // low 20 bits, sign-extended
+                        int ch = (v[u] - ua) >> 20;
+                        if (lane == 0) ch += carry[u];
+                        const int scan = wave_scan_incl(ch);
+                        const int area = scan * 512 - ua;
+                        uint32_t a = (uint32_t)((area * 17 + 256) >> 9) & 255u;
+                        if (cx < e_xmin || cx >= e_xmax) a = 0;
+                        if (a) px[rr][lane] = blend_pixel(old_px[u], a, eflags, solid, styles, style, bitmaps, cx, ty0 + rr);
+                    }
                 }
+#pragma unroll
+                for (int j = 0; j < NB; ++j) if (j == slot_j) pend[j] = -1;
                 __syncthreads();                                   // acc cleared before the next path accumulates
             } else {
                 // full cover: every in-frame pixel of the tile has coverage 255
@@ -1058,7 +1154,7 @@ __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_
         }
     }
 
-    if (dbg == 8 && lane == 0) px[0][0] = (uint32_t)(__builtin_amdgcn_s_memtime() - t_start);   // diagnostics: tile duration in clocks
+    if (dbg == 8 && lane == 0) { px[0][0] = (uint32_t)(__builtin_amdgcn_s_memtime() - t_start); px[0][1] = dbg_pairs; px[0][2] = dbg_recs; }   // diagnostics
     // ---- one store per pixel: premultiplied R,G,B,A bytes; the wave writes 256 contiguous bytes per row
     if (cx < width) {
         for (int rr = 0; rr < TILE_H; ++rr) {
