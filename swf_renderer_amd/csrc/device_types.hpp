@@ -35,6 +35,10 @@ struct RowInfo {
 // SUB rows carry 15 two-bit fields, field s = 1 (a span opens at this edge in sub-row s) or 2 (closes).
 // cols = lo | hi << 16: the pixel columns (clamped to [0, 65535]) this record's contributions fall in.
 constexpr uint32_t REC_FULL = 0x80000000u;
+// REC_CELLS: the contributions were precomputed by k_rows: roles = REC_CELLS | n_cells | (int8 net height) << 8, and the
+// 40 bytes after `cols` hold up to 10 cells {column - lo : 8, covered height : int8, uncovered area : int16}.
+constexpr uint32_t REC_CELLS = 0x40000000u;
+constexpr int REC_MAX_CELLS = 10;
 // The record is self-contained (no edge lookup in k_tiles): FULL rows carry the two end points of the edge over
 // the pixel row (x = q + r/dy at the row top and bottom); SUB rows carry x at the edge's first sample row in the
 // pixel row plus the per-sample slope.

@@ -66,6 +66,12 @@ __device__ __forceinline__ void full_row_ends(const DevEdge& e, int s0, int32_t&
     }
 }
 __device__ __forceinline__ uint32_t clamp_col(int c) { return (uint32_t)min(max(c, 0), 65535); }
+// net covered height a record adds to everything right of it
+__device__ __forceinline__ int record_height(uint32_t roles) {
+    if (roles & REC_CELLS) return (int)(int8_t)(roles >> 8);
+    if (roles & REC_FULL) return (roles & 1u) ? 15 : -15;
+    return __popc(roles & 0x15555555u) - __popc(roles & 0x2aaaaaaau);
+}
 // self-contained record of edge e for pixel row s0/15 with the given roles / column range
 __device__ __forceinline__ Rec make_record(const DevEdge& e, uint32_t eid, int s0, uint32_t roles, uint32_t cols) {
     Rec rc;
@@ -79,6 +85,39 @@ __device__ __forceinline__ Rec make_record(const DevEdge& e, uint32_t eid, int s
         rc.span = (uint32_t)(first - s0) | ((uint32_t)(last - s0) << 8);
     }
     return rc;
+}
+
+__device__ __forceinline__ uint32_t pack_cell(int col_rel, int ch, int ua) {
+    return (uint32_t)(col_rel & 255) | ((uint32_t)(ch & 255) << 8) | ((uint32_t)(ua & 0xffff) << 16);
+}
+// Cells of a FULL-row edge (A.5 render_edge) as a cell record; false when the edge spans more than REC_MAX_CELLS columns
+__device__ __forceinline__ bool full_cells(const DevEdge& e, int s0, int sign, Rec& rc) {
+    int32_t q1, q2; int64_t r1, r2;
+    full_row_ends(e, s0, q1, r1, q2, r2);
+    int ix1 = q1 >> 8, f1 = q1 & 255, ix2 = q2 >> 8, f2 = q2 & 255;
+    uint32_t* cells = reinterpret_cast<uint32_t*>(&rc.q1);
+    if (ix2 < ix1) { int t = ix1; ix1 = ix2; ix2 = t; t = f1; f1 = f2; f2 = t; int32_t tq = q1; q1 = q2; q2 = tq; int64_t tr = r1; r1 = r2; r2 = tr; }
+    const int n = ix2 - ix1 + 1;
+    if (n > REC_MAX_CELLS || ix1 < 0 || ix2 > 65534) return false;
+    rc.cols = clamp_col(ix1) | (clamp_col(ix2) << 16);
+    rc.roles = REC_CELLS | (uint32_t)n | ((uint32_t)((sign * 15) & 255) << 8);
+    if (n == 1) { cells[0] = pack_cell(0, sign * 15, sign * (f1 + f2) * 15); return true; }
+    const int64_t dx = (int64_t)(q2 - q1) * e.dy + (r2 - r1);
+    const int64_t t0 = ((int64_t)((ix1 + 1) * 256 - q1) * e.dy - r1) * 15;
+    const int64_t F = 15ll * 256 * e.dy;
+    int64_t yq, yr, fq = 0, fr = 0;
+    floor_div(t0, dx, yq, yr);
+    if (n > 2) floor_div(F, dx, fq, fr);
+    int y_prev = 0;
+#pragma unroll 1
+    for (int k = 0; k < n - 1; ++k) {
+        if (k > 0) { yq += fq; yr += fr; if (yr >= dx) { ++yq; yr -= dx; } }
+        const int h = (int)yq - y_prev;
+        cells[k] = pack_cell(k, sign * h, sign * h * (k == 0 ? 256 + f1 : 256));
+        y_prev = (int)yq;
+    }
+    cells[n - 1] = pack_cell(n - 1, sign * (15 - y_prev), sign * (15 - y_prev) * f2);
+    return true;
 }
 
 // wave64 inclusive prefix sum with DPP row shifts + row broadcasts (no LDS traffic)
@@ -503,7 +542,7 @@ __global__ __launch_bounds__(64) void k_rows(const DevEdge* __restrict__ edges, 
                                              const uint32_t* __restrict__ row_base, const uint32_t* __restrict__ chunk_base,
                                              uint32_t n_paths, RowInfo* __restrict__ rows, Rec* __restrict__ records,
                                              uint32_t* __restrict__ counters, uint32_t* __restrict__ overflow_list,
-                                             uint32_t band_index, uint32_t band_count, int fast_limit) {
+                                             uint32_t band_index, uint32_t band_count, int fast_limit, int cell_mode) {
     __shared__ FastLds F;
     __shared__ DevEdge staged[ROWS_STAGE];
     const int lane = threadIdx.x;
@@ -548,7 +587,13 @@ __global__ __launch_bounds__(64) void k_rows(const DevEdge* __restrict__ edges, 
         for (int s = 0; s < ROWS_FAST_N; ++s) {
             if (s < n && roles[s] != 0) {
                 const DevEdge e = use_lds ? staged[el[s]] : edges[P.first_edge + el[s]];
-                records[off++] = make_record(e, P.first_edge + (uint32_t)el[s], r * 15, (uint32_t)roles[s], (uint32_t)cols[s]);
+                Rec rc;
+                bool as_cells = false;
+                if ((uint32_t)roles[s] & REC_FULL) {
+                    if (cell_mode & 1) as_cells = full_cells(e, r * 15, ((uint32_t)roles[s] & 1u) ? +1 : -1, rc);
+                }
+                if (!as_cells) rc = make_record(e, P.first_edge + (uint32_t)el[s], r * 15, (uint32_t)roles[s], (uint32_t)cols[s]);
+                records[off++] = rc;
             }
         }
     }
@@ -712,11 +757,6 @@ struct TileCtx {
     int tx0, xminp, xmaxp;
 };
 
-// net covered height a record adds to everything right of it
-__device__ __forceinline__ int record_height(uint32_t roles) {
-    if (roles & REC_FULL) return (roles & 1u) ? 15 : -15;
-    return __popc(roles & 0x15555555u) - __popc(roles & 0x2aaaaaaau);
-}
 
 // accumulate one cell contribution (covered height dch, uncovered area dua) of row `acc`
 __device__ __forceinline__ void cell_add(int* acc, const TileCtx& c, int i, int dch, int dua) {
@@ -855,8 +895,8 @@ __global__ __launch_bounds__(64) void k_class(const BandEntry* __restrict__ band
 }
 
 #define TLIST 64                       // tile list entries per round
-#define REC_STAGE 96                   // records staged in LDS per round
-#define NB 2                           // partial paths whose records are fetched and accumulated together
+#define REC_STAGE 64                   // records staged in LDS per round
+#define NB 1                           // partial paths whose records are fetched and accumulated together
 
 __device__ __forceinline__ uint32_t blend_pixel(uint32_t dst, uint32_t a, uint32_t eflags, uint32_t solid, const swfr_style* __restrict__ styles,
                                                 uint32_t style, const DevBitmap* __restrict__ bitmaps, int cx, int cy) {
@@ -869,11 +909,19 @@ __device__ __forceinline__ uint32_t blend_pixel(uint32_t dst, uint32_t a, uint32
 }
 
 // one staged record -> covered height / uncovered area per cell of its row (LDS atomics into `acc`)
-__device__ __forceinline__ void accumulate_record(const Rec& rec, int* acc, const TileCtx& c) {
+__device__ __forceinline__ void accumulate_record(const Rec& rec, const uint32_t* sw, int* acc, const TileCtx& c) {
     const int clo = (int)(rec.cols & 0xffffu), chi = (int)(rec.cols >> 16);
     if (clo >= c.tx0 + TILE_W && clo < 65535) return;               // entirely right of the tile
     if (chi < c.tx0 && chi < 65535) {                               // entirely left: only its net height reaches us
         cell_add(acc, c, chi, record_height(rec.roles), 0);
+        return;
+    }
+    if (rec.roles & REC_CELLS) {                                    // precomputed by k_rows: no arithmetic left
+        const int n = (int)(rec.roles & 15u);
+        for (int k = 0; k < n; ++k) {
+            const uint32_t w = sw[2 + k];
+            cell_add(acc, c, clo + (int)(w & 255u), (int)(int8_t)(w >> 8), (int)(int16_t)(w >> 16));
+        }
         return;
     }
     if (rec.roles & REC_FULL) {
@@ -1105,7 +1153,7 @@ __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_
                                 const uint32_t mxw = ent[mine][1];
                                 TileCtx c; c.tx0 = tx0; c.xminp = (int)(int16_t)(mxw & 0xffffu); c.xmaxp = (int)(int16_t)(mxw >> 16);
                                 acc[j][r][ACC_TOUCH] = 1;
-                                accumulate_record(rec, acc[j][r], c);
+                                accumulate_record(rec, sw, acc[j][r], c);
                             }
                         __syncthreads();                               // stage / rec_row may be rewritten; acc complete
                     }
@@ -1207,11 +1255,11 @@ void launch_bands(hipStream_t st, const DevPath* paths, uint32_t n_paths, const 
 }
 void launch_rows(hipStream_t st, const DevEdge* edges, const DevPath* paths, const uint32_t* row_base, const uint32_t* chunk_base,
                  uint32_t n_paths, RowInfo* rows, Rec* records, uint32_t* counters, uint32_t* overflow_list, uint32_t n_chunks,
-                 uint32_t band_index, uint32_t band_count, int fast_limit) {
+                 uint32_t band_index, uint32_t band_count, int fast_limit, int cell_mode) {
     if (!n_chunks) return;
     fast_limit = fast_limit < 0 ? 0 : (fast_limit > ROWS_FAST_N ? ROWS_FAST_N : fast_limit);
     hipLaunchKernelGGL(k_rows, dim3(n_chunks), dim3(64), 0, st, edges, paths, row_base, chunk_base, n_paths, rows, records, counters,
-                       overflow_list, band_index, band_count, fast_limit);
+                       overflow_list, band_index, band_count, fast_limit, cell_mode);
     // rows that exceeded the per-lane capacity (rare): fixed small grid, every lane loops over the list and exits
     hipLaunchKernelGGL(k_rows_big, dim3(256), dim3(64), 0, st, edges, paths, row_base, n_paths, rows, records, counters, overflow_list);
 }

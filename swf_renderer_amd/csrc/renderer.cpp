@@ -26,7 +26,7 @@ void launch_bands(hipStream_t, const DevPath*, uint32_t, const uint32_t*, const 
 void launch_class(hipStream_t, const BandEntry*, uint32_t, const uint32_t*, uint32_t, const swfr_edge*, const RowInfo*, const Rec*, uint8_t*, int, int,
                   uint32_t, uint32_t);
 void launch_rows(hipStream_t, const DevEdge*, const DevPath*, const uint32_t*, const uint32_t*, uint32_t, RowInfo*, Rec*, uint32_t*,
-                 uint32_t*, uint32_t, uint32_t, uint32_t, int);
+                 uint32_t*, uint32_t, uint32_t, uint32_t, int, int);
 void launch_tiles(hipStream_t, const swfr_edge*, const uint32_t*, const BandEntry*, const uint8_t*, const RowInfo*, const Rec*, const swfr_style*,
                   const DevBitmap*, uint32_t*, int, int, uint32_t, uint32_t, int, uint32_t*, uint32_t, uint32_t);
 void launch_unpremultiply(hipStream_t, const uint32_t*, uint32_t*, size_t);
@@ -108,6 +108,7 @@ struct swfr_renderer {
     bool scene_ready = false, fb_valid = false;
     swfr_timing timing{};
     int tiles_dbg = 0;                      // SWFR_TILES_DEBUG: timing-only ablations of k_tiles (wrong pixels)
+    int cell_mode = 3;                      // SWFR_CELL_MODE: 1 = FULL rows as precomputed cells, 2 = SUB rows (test knob)
     int fast_limit = 8;                     // rows with more active edges go through k_rows_big (SWFR_FAST_LIMIT: test knob)
 
     ~swfr_renderer() {
@@ -262,7 +263,7 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
         HIP_CHECK(hipEventRecord(e[1], r->stream));
         if (r->n_paths)
             launch_rows(r->stream, r->d_edges.ptr, r->d_paths.ptr, r->d_row_base.ptr, r->d_chunk_base.ptr, uint32_t(r->n_paths), r->d_rows.ptr,
-                        r->d_records.ptr, r->d_counters.ptr, r->d_overflow.ptr, uint32_t(r->n_chunks), bi, bc, r->fast_limit);
+                        r->d_records.ptr, r->d_counters.ptr, r->d_overflow.ptr, uint32_t(r->n_chunks), bi, bc, r->fast_limit, r->cell_mode);
         if (r->n_paths)
         {
             HIP_CHECK(hipMemsetAsync(r->d_cls.ptr, 0, r->n_band_entries * ((r->width + TILE_W - 1) / TILE_W), r->stream));
@@ -334,6 +335,7 @@ int swfr_create(uint32_t width, uint32_t height, const swfr_config* cfg, swfr_re
     r->builder.reset(new FrameBuilder(width, height, (r->cfg.flags & SWFR_FLAG_EVEN_ODD) != 0));
     if (const char* fl = std::getenv("SWFR_FAST_LIMIT")) r->fast_limit = std::atoi(fl);
     if (const char* td = std::getenv("SWFR_TILES_DEBUG")) r->tiles_dbg = std::atoi(td);
+    if (const char* cm = std::getenv("SWFR_CELL_MODE")) r->cell_mode = std::atoi(cm);
     if (r->cfg.device == SWFR_DEVICE_HOST_ONLY) {
         *out = r.release();
         return SWFR_OK;
