@@ -124,6 +124,44 @@ def test_fuzz_layered_translucent_vs_oracle():
         assert diff_stats(product_render(sc), oracle_render(sc)) == (0, 0), it
 
 
+# ---- every internal route of the row/tile kernels gives the same pixels
+@pytest.mark.parametrize("env", [{"SWFR_FAST_LIMIT": "0"}, {"SWFR_FAST_LIMIT": "3"}, {"SWFR_CELL_MODE": "0"}])
+def test_kernel_route_knobs_are_pixel_identical(env, monkeypatch):
+    """SWFR_FAST_LIMIT routes rows with more active edges than the limit through k_rows_big (the generic LDS-list
+    routine); SWFR_CELL_MODE=0 keeps analytic records instead of precomputed cells.  Same bytes either way."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for name in ("config2_homestuck-beta-1", "translucent_stack", "evenodd_pentagram", "offframe_fill_stroke", "morph_128"):
+        sc = SC[name]
+        assert diff_stats(product_render(sc), oracle_render(sc)) == (0, 0), (env, name)
+
+
+# ---- BASELINE configs 3 and 4 at their full frame sizes (a few frames; the oracle needs seconds)
+def test_config3_morph_1080p_vs_oracle():
+    tag = fixture("homestuck-beta-29")
+    b, mb = tag["bounds"], tag["morph_bounds"]
+    x0, x1 = min(b["x_min"], mb["x_min"]), max(b["x_max"], mb["x_max"])
+    y0, y1 = min(b["y_min"], mb["y_min"]), max(b["y_max"], mb["y_max"])
+    sx, sy = 1920 * 20 / (x1 - x0), 1080 * 20 / (y1 - y0)
+    for k in (0, 77, 255):
+        sc = dict(width=1920, height=1080, stage={"children": [
+            {"type": "morph-shape", "definition": tag, "ratio": k / 255, "matrix": scenarios._m(sx, sy, -x0 * sx, -y0 * sy)}]})
+        assert diff_stats(product_render(sc), oracle_render(sc)) == (0, 0), k
+
+
+def test_config4_textured_4k_vs_oracle():
+    """Bitmap fill magnified to 3840x2160 (bilinear region of FILTER_GOOD): the HIP shader and the oracle share the
+    float64 sampling model, so they agree to +-1; against libcairo the model is pinned at reduced size
+    (cairo_bitmap_magnified.npz)."""
+    tag = fixture("homestuck-beta-4")
+    b = tag["bounds"]
+    sx, sy = 3840 * 20 / (b["x_max"] - b["x_min"]), 2160 * 20 / (b["y_max"] - b["y_min"])
+    sc = dict(width=3840, height=2160, bitmaps=[fixture("homestuck-beta-3.bitmap")], stage={"children": [
+        {"type": "shape", "definition": tag, "matrix": scenarios._m(sx, sy, -b["x_min"] * sx, -b["y_min"] * sy)}]})
+    n, mx = diff_stats(product_render(sc), oracle_render(sc))
+    assert mx <= 1, (n, mx)
+
+
 # ---- full BASELINE sizes
 def _s_scene(cfg):
     from swf_renderer_amd import api, synth
