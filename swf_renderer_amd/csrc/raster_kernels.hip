@@ -895,18 +895,22 @@ __global__ __launch_bounds__(64) void k_class(const BandEntry* __restrict__ band
 }
 
 #define TLIST 64                       // tile list entries per round
+#define STRIP_H 4                      // pixel rows per wavefront: a 64x16 tile is rasterized as four independent 64x4 strips
+#define STRIPS_PER_TILE (TILE_H / STRIP_H)
 #define REC_STAGE 64                   // records staged in LDS per round
 #define NB 1                           // partial paths whose records are fetched and accumulated together
 
-__device__ __forceinline__ uint32_t blend_pixel(uint32_t dst, uint32_t a, uint32_t eflags, uint32_t solid, const swfr_style* __restrict__ styles,
-                                                uint32_t style, const DevBitmap* __restrict__ bitmaps, int cx, int cy) {
-    if (eflags & BE_SOLID) {
+template <bool SHADERS>
+__device__ __forceinline__ uint32_t blend_pixel_t(uint32_t dst, uint32_t a, uint32_t eflags, uint32_t solid, const swfr_style* __restrict__ styles,
+                                                  uint32_t style, const DevBitmap* __restrict__ bitmaps, int cx, int cy) {
+    if (!SHADERS || (eflags & BE_SOLID)) {
         if (eflags & BE_LERP) return a == 255u ? solid : lerp_pixel(solid, a, dst);
         return over_pixel(a == 255u ? solid : mul_un8(solid, a), dst);
     }
     const uint32_t s = mul_un8(shade(styles[style], bitmaps, cx, cy), a);
     return (eflags & BE_LERP) ? s : over_pixel(s, dst);
 }
+#define blend_pixel blend_pixel_t<SHADERS>
 
 // one staged record -> covered height / uncovered area per cell of its row (LDS atomics into `acc`)
 __device__ __forceinline__ void accumulate_record(const Rec& rec, const uint32_t* sw, int* acc, const TileCtx& c) {
@@ -945,6 +949,8 @@ __device__ __forceinline__ void accumulate_record(const Rec& rec, const uint32_t
 // LDS traffic of a wave is ordered.  Global memory is read in coalesced pieces only: the tile's class bytes
 // (contiguous per tile), the few band entries that survive, 16 row headers per path (one line) and the
 // path's records as a dword stream staged through LDS.
+// SHADERS = false is the solid-colour specialisation (no call into the f64 gradient/bitmap shader, fewer VGPRs)
+template <bool SHADERS>
 __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_edges,
                                               const uint32_t* __restrict__ band_off, const BandEntry* __restrict__ band_list,
                                               const uint8_t* __restrict__ cls_t, const RowInfo* __restrict__ rows,
@@ -952,30 +958,30 @@ __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_
                                               const DevBitmap* __restrict__ bitmaps, uint32_t* __restrict__ fb,
                                               int width, int height, int tiles_x, uint32_t band_index, uint32_t band_count, int dbg,
                                               uint32_t* __restrict__ counters, uint32_t n_rows_total, uint32_t n_rec_cap) {
-    __shared__ int acc[NB][TILE_H][ACC_STRIDE];
-    __shared__ uint32_t px[TILE_H][TILE_W];
+    __shared__ int acc[NB][STRIP_H][ACC_STRIDE];
+    __shared__ uint32_t px[STRIP_H][TILE_W];
     __shared__ uint32_t ent[TLIST][9];                    // BandEntry as 9 dwords
     __shared__ uint32_t cls[TLIST];
     __shared__ __attribute__((aligned(16))) uint32_t stage[REC_STAGE * 12];   // records as dwords
     __shared__ uint32_t rec_src[REC_STAGE];
-    __shared__ uint32_t row_off[NB * TILE_H], row_start[NB * TILE_H + 1];
+    __shared__ uint32_t row_off[NB * STRIP_H], row_start[NB * STRIP_H + 1];
     __shared__ uint8_t rec_row[REC_STAGE];
 
     const int lane = threadIdx.x;
     // blockIdx -> tile: consecutive workgroups walk along x inside one tile-row, so the 8 tiles that are
     // co-scheduled round-robin over the 8 XCDs read the same band entries / path records
-    const int tile = blockIdx.x;
+    const int tile = blockIdx.x / STRIPS_PER_TILE, strip = blockIdx.x % STRIPS_PER_TILE;
     const int tcol = tile % tiles_x;
     int trow = tile / tiles_x;
     if (band_count > 1) trow = trow * (int)band_count + (int)band_index;
-    const int tx0 = tcol * TILE_W, ty0 = trow * TILE_H;
+    const int tx0 = tcol * TILE_W, ty0 = trow * TILE_H + strip * STRIP_H;   // ty0: first pixel row of this wave's strip
     if (ty0 >= height) return;
     const int cx = tx0 + lane;
     const unsigned long long t_start = dbg == 8 ? __builtin_amdgcn_s_memtime() : 0ull;
     uint32_t dbg_pairs = 0, dbg_recs = 0;
 
-    for (int rr = 0; rr < TILE_H; ++rr) px[rr][lane] = 0u;
-    for (int i = lane; i < NB * TILE_H * ACC_STRIDE; i += 64) (&acc[0][0][0])[i] = 0;
+    for (int rr = 0; rr < STRIP_H; ++rr) px[rr][lane] = 0u;
+    for (int i = lane; i < NB * STRIP_H * ACC_STRIDE; i += 64) (&acc[0][0][0])[i] = 0;
 
     const uint32_t band_begin = band_off[trow], band_end = band_off[trow + 1];
     const uint32_t n_b = band_end - band_begin;
@@ -1041,7 +1047,8 @@ __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_
             const int e_ymin = (int)(int16_t)(yw & 0xffffu), e_ymax = (int)(int16_t)(yw >> 16);
             const uint32_t style = ent[li][4], e_first = ent[li][5], e_nedges = ent[li][6];
             const uint32_t eflags = ent[li][7], solid = ent[li][8];
-            const int row_lo = max(e_ymin, ty0) - ty0, row_hi = min(min(e_ymax, ty0 + TILE_H), height) - ty0;
+            const int row_lo = max(e_ymin, ty0) - ty0, row_hi = min(min(e_ymax, ty0 + STRIP_H), height) - ty0;
+            if (row_hi <= row_lo) continue;                    // the path misses this strip of the tile
             if (f & CLS_BOX) {
                 // ---- rectilinear (A.6): exact area of disjoint boxes, alpha = (c>>8) - (c>>16)
 #pragma unroll 1
@@ -1077,8 +1084,8 @@ __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_
                         }
                     // row headers: lane = (path j, row); 16 consecutive RowInfo per path = one line each
                     uint32_t my_cnt = 0;
-                    if (lane < NB * TILE_H) {
-                        const int j = lane >> 4, row = lane & 15;
+                    if (lane < NB * STRIP_H) {
+                        const int j = lane / STRIP_H, row = lane % STRIP_H;
                         int mine = -1;
 #pragma unroll
                         for (int jj = 0; jj < NB; ++jj) if (jj == j) mine = pend[jj];
@@ -1100,8 +1107,8 @@ __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_
                     }
                     // exclusive prefix of the per-row record counts
                     const int incl = wave_scan_incl((int)my_cnt);
-                    if (lane < NB * TILE_H) row_start[lane] = (uint32_t)(incl - (int)my_cnt);
-                    int total = __shfl(incl, NB * TILE_H - 1);         // lanes beyond contribute 0
+                    if (lane < NB * STRIP_H) row_start[lane] = (uint32_t)(incl - (int)my_cnt);
+                    int total = __shfl(incl, NB * STRIP_H - 1);        // lanes beyond contribute 0
                     ++dbg_pairs; dbg_recs += (uint32_t)total;
                     __syncthreads();                                   // row_off / row_start visible to every lane
                     if (dbg == 11) total = 0;
@@ -1111,7 +1118,7 @@ __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_
                         // which (path, row) does each staged record belong to, and where does it live
                         for (int t = lane; t < n; t += 64) {
                             const uint32_t g = (uint32_t)(base + t);
-                            int lo = 0, hi = NB * TILE_H;               // last virtual row with row_start <= g
+                            int lo = 0, hi = NB * STRIP_H;              // last virtual row with row_start <= g
                             while (lo + 1 < hi) { const int mid = (lo + hi) >> 1; if (row_start[mid] <= g) lo = mid; else hi = mid; }
                             rec_row[t] = (uint8_t)lo;
                             uint32_t src = row_off[lo] + (g - row_start[lo]);
@@ -1146,7 +1153,7 @@ __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_
                                 rec.r2 = (int64_t)((uint64_t)sw[6] | ((uint64_t)sw[7] << 32));
                                 rec.dy = (int64_t)((uint64_t)sw[8] | ((uint64_t)sw[9] << 32));
                                 rec.span = sw[10]; rec.eid = sw[11];
-                                const int vr = rec_row[t], j = vr >> 4, r = vr & 15;
+                                const int vr = rec_row[t], j = vr / STRIP_H, r = vr % STRIP_H;
                                 int mine = 0;
 #pragma unroll
                                 for (int jj = 0; jj < NB; ++jj) if (jj == j) mine = pend[jj];
@@ -1169,7 +1176,7 @@ __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_
                     uint32_t old_px[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        const int rr = min(r4 + u, TILE_H - 1);
+                        const int rr = min(r4 + u, STRIP_H - 1);
                         touch[u] = (r4 + u < row_hi) ? A[rr][ACC_TOUCH] : 0;
                         v[u] = A[rr][lane];
                         carry[u] = A[rr][ACC_CARRY];
@@ -1205,7 +1212,7 @@ __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_
     if (dbg == 8 && lane == 0) { px[0][0] = (uint32_t)(__builtin_amdgcn_s_memtime() - t_start); px[0][1] = dbg_pairs; px[0][2] = dbg_recs; }   // diagnostics
     // ---- one store per pixel: premultiplied R,G,B,A bytes; the wave writes 256 contiguous bytes per row
     if (cx < width) {
-        for (int rr = 0; rr < TILE_H; ++rr) {
+        for (int rr = 0; rr < STRIP_H; ++rr) {
             const int cy = ty0 + rr;
             if (cy >= height) break;
             const uint32_t p = px[rr][lane];
@@ -1214,6 +1221,8 @@ __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_
         }
     }
 }
+
+#undef blend_pixel
 
 // ---------------------------------------------------------------------------------------------
 // auxiliary kernels
@@ -1273,13 +1282,18 @@ void launch_class(hipStream_t st, const BandEntry* band_list, uint32_t n_entries
 }
 void launch_tiles(hipStream_t st, const swfr_edge* raw, const uint32_t* band_off, const BandEntry* band_list, const uint8_t* cls_mat,
                   const RowInfo* rows, const Rec* records, const swfr_style* styles, const DevBitmap* bitmaps, uint32_t* fb, int width, int height,
-                  uint32_t band_index, uint32_t band_count, int dbg, uint32_t* counters, uint32_t n_rows_total, uint32_t n_rec_cap) {
+                  uint32_t band_index, uint32_t band_count, int dbg, uint32_t* counters, uint32_t n_rows_total, uint32_t n_rec_cap,
+                  bool any_shader) {
     const int tiles_x = (width + TILE_W - 1) / TILE_W, tile_rows = (height + TILE_H - 1) / TILE_H;
     uint32_t local_rows = tile_rows;
     if (band_count > 1) local_rows = (tile_rows > (int)band_index) ? (tile_rows - band_index + band_count - 1) / band_count : 0;
     if (!local_rows) return;
-    hipLaunchKernelGGL(k_tiles, dim3(tiles_x * local_rows), dim3(64), 0, st, raw, band_off, band_list, cls_mat, rows, records, styles, bitmaps,
-                       fb, width, height, tiles_x, band_index, band_count, dbg, counters, n_rows_total, n_rec_cap);
+    if (any_shader)
+        hipLaunchKernelGGL(k_tiles<true>, dim3(tiles_x * local_rows * STRIPS_PER_TILE), dim3(64), 0, st, raw, band_off, band_list, cls_mat, rows,
+                           records, styles, bitmaps, fb, width, height, tiles_x, band_index, band_count, dbg, counters, n_rows_total, n_rec_cap);
+    else
+        hipLaunchKernelGGL(k_tiles<false>, dim3(tiles_x * local_rows * STRIPS_PER_TILE), dim3(64), 0, st, raw, band_off, band_list, cls_mat, rows,
+                           records, styles, bitmaps, fb, width, height, tiles_x, band_index, band_count, dbg, counters, n_rows_total, n_rec_cap);
 }
 void launch_unpremultiply(hipStream_t st, const uint32_t* in, uint32_t* out, size_t n) {
     if (!n) return;

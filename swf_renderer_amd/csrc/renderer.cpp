@@ -28,7 +28,7 @@ void launch_class(hipStream_t, const BandEntry*, uint32_t, const uint32_t*, uint
 void launch_rows(hipStream_t, const DevEdge*, const DevPath*, const uint32_t*, const uint32_t*, uint32_t, RowInfo*, Rec*, uint32_t*,
                  uint32_t*, uint32_t, uint32_t, uint32_t, int, int);
 void launch_tiles(hipStream_t, const swfr_edge*, const uint32_t*, const BandEntry*, const uint8_t*, const RowInfo*, const Rec*, const swfr_style*,
-                  const DevBitmap*, uint32_t*, int, int, uint32_t, uint32_t, int, uint32_t*, uint32_t, uint32_t);
+                  const DevBitmap*, uint32_t*, int, int, uint32_t, uint32_t, int, uint32_t*, uint32_t, uint32_t, bool);
 void launch_unpremultiply(hipStream_t, const uint32_t*, uint32_t*, size_t);
 void launch_pack_band(hipStream_t, const uint32_t*, uint32_t*, int, int, uint32_t, uint32_t, uint32_t);
 }  // namespace swfr
@@ -105,7 +105,7 @@ struct swfr_renderer {
     bool bitmap_table_dirty = false;
     // resident scene
     size_t n_edges = 0, n_paths = 0, n_styles = 0, n_tasks = 0, n_chunks = 0, n_bands = 0, rec_cap = 0;
-    bool scene_ready = false, fb_valid = false;
+    bool scene_ready = false, fb_valid = false, any_shader = false;
     swfr_timing timing{};
     int tiles_dbg = 0;                      // SWFR_TILES_DEBUG: timing-only ablations of k_tiles (wrong pixels)
     int cell_mode = 3;                      // SWFR_CELL_MODE: 1 = FULL rows as precomputed cells, 2 = SUB rows (test knob)
@@ -207,6 +207,8 @@ int upload(swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_
     }
     for (size_t b = 0; b < n_bands; ++b) band_off[b + 1] += band_off[b];   // exact sizes; k_bands fills the lists in order
     r->n_edges = n_edges; r->n_paths = n_paths; r->n_styles = n_styles;
+    r->any_shader = false;
+    for (size_t i = 0; i < n_styles; ++i) r->any_shader = r->any_shader || styles[i].kind != SWFR_STYLE_SOLID;
     r->n_tasks = row_base[n_paths];
     r->n_chunks = chunk_base[n_paths];
     r->n_bands = n_bands;
@@ -272,7 +274,7 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
         }
         HIP_CHECK(hipEventRecord(e[2], r->stream));
         launch_tiles(r->stream, r->d_raw.ptr, r->d_band_off.ptr, r->d_band_list.ptr, r->d_cls.ptr, r->d_rows.ptr, r->d_records.ptr, r->d_styles.ptr,
-                     r->d_bitmap_table.ptr, r->d_fb.ptr, int(r->width), int(r->height), bi, bc, r->tiles_dbg, r->d_counters.ptr, uint32_t(r->n_tasks), uint32_t(r->rec_cap));
+                     r->d_bitmap_table.ptr, r->d_fb.ptr, int(r->width), int(r->height), bi, bc, r->tiles_dbg, r->d_counters.ptr, uint32_t(r->n_tasks), uint32_t(r->rec_cap), r->any_shader);
         HIP_CHECK(hipEventRecord(e[3], r->stream));
     }
     HIP_CHECK(hipGetLastError());
