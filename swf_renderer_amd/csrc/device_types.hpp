@@ -70,6 +70,12 @@ struct BandEntry {
 static_assert(sizeof(BandEntry) == 36, "BandEntry layout");
 enum : uint32_t { BE_BOXES = 1u, BE_LERP = 2u, BE_SOLID = 4u, BE_OPAQUE_COVER = 8u /* solid, alpha 255, lerp blend */ };
 
+// One k_rows workgroup: 64 consecutive pixel rows of one path.  rec_base is the first record slot reserved for the
+// chunk (host-computed upper bound), so record allocation needs no global atomics.
+struct ChunkInfo {
+    uint32_t path, first_row, rec_base, pad;
+};
+
 struct DevBitmap {
     const uint32_t* pixels;  // premultiplied ARGB, tight rows
     uint32_t width, height;

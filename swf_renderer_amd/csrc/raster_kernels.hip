@@ -539,19 +539,19 @@ __device__ __forceinline__ void fast_rows(EPTR E, const DevPath& P, int r, bool 
 }
 
 __global__ __launch_bounds__(64) void k_rows(const DevEdge* __restrict__ edges, const DevPath* __restrict__ paths,
-                                             const uint32_t* __restrict__ row_base, const uint32_t* __restrict__ chunk_base,
+                                             const uint32_t* __restrict__ row_base, const ChunkInfo* __restrict__ chunks,
                                              uint32_t n_paths, RowInfo* __restrict__ rows, Rec* __restrict__ records,
                                              uint32_t* __restrict__ counters, uint32_t* __restrict__ overflow_list,
                                              uint32_t band_index, uint32_t band_count, int fast_limit, int cell_mode) {
     __shared__ FastLds F;
     __shared__ DevEdge staged[ROWS_STAGE];
     const int lane = threadIdx.x;
-    // workgroup -> (path, chunk of 64 rows): wave-uniform, so path and edge reads are scalar
-    uint32_t lo = 0, hi = n_paths;
-    const uint32_t chunk = blockIdx.x;
-    while (lo + 1 < hi) { const uint32_t mid = (lo + hi) >> 1; if (chunk_base[mid] <= chunk) lo = mid; else hi = mid; }
+    // workgroup -> (path, 64 rows): one wave-uniform descriptor load, so path and edge reads are scalar
+    const ChunkInfo ck = chunks[blockIdx.x];
+    const uint32_t lo = ck.path;
+    (void)n_paths;
     const DevPath P = paths[lo];
-    const int r = P.y_min + (int)(chunk - chunk_base[lo]) * ROWS_CHUNK + lane;
+    const int r = (int)ck.first_row + lane;
     const bool in_path = P.kind == SWFR_PATH_TOR && r < P.y_max;
     bool live = in_path;
     if (live && band_count > 1 && (uint32_t)((r / TILE_H) % band_count) != band_index) live = false;
@@ -573,12 +573,9 @@ __global__ __launch_bounds__(64) void k_rows(const DevEdge* __restrict__ edges, 
         const uint32_t slot = atomicAdd(&counters[CNT_OVERFLOW], 1u);
         overflow_list[slot] = t;
     }
-    // ---- wave-level allocation of record slots: one atomic per wave
+    // ---- record slots: the chunk owns [rec_base, rec_base + bound); lanes take consecutive pieces (no atomics)
     const uint32_t incl = (uint32_t)wave_scan_incl((int)n_out);
-    const uint32_t total = __shfl(incl, 63);
-    uint32_t base = 0;
-    if (lane == 0 && total) base = atomicAdd(&counters[CNT_RECORDS], total);
-    base = __shfl(base, 0);
+    const uint32_t base = ck.rec_base;
     if (in_path && !overflow) {
         uint32_t off = base + incl - n_out;
         RowInfo ri; ri.rec_off = off; ri.n_rec = (uint16_t)n_out; ri.mode = (uint16_t)mode;
@@ -603,7 +600,8 @@ __global__ __launch_bounds__(64) void k_rows(const DevEdge* __restrict__ edges, 
 __global__ __launch_bounds__(64) void k_rows_big(const DevEdge* __restrict__ edges, const DevPath* __restrict__ paths,
                                                  const uint32_t* __restrict__ row_base, uint32_t n_paths,
                                                  RowInfo* __restrict__ rows, Rec* __restrict__ records,
-                                                 uint32_t* __restrict__ counters, const uint32_t* __restrict__ overflow_list) {
+                                                 uint32_t* __restrict__ counters, const uint32_t* __restrict__ overflow_list,
+                                                 uint32_t rec_overflow_base) {
     __shared__ RowLds<ROWS_BIG_MAXA> L;
     const int lane = threadIdx.x;
     const uint32_t count = counters[CNT_OVERFLOW];
@@ -620,7 +618,7 @@ __global__ __launch_bounds__(64) void k_rows_big(const DevEdge* __restrict__ edg
         } else {
             uint32_t n_out = 0;
             for (int k = 0; k < res.n; ++k) n_out += L.aux[k][lane] != 0;
-            uint32_t off = n_out ? atomicAdd(&counters[CNT_RECORDS], n_out) : 0u;
+            uint32_t off = n_out ? rec_overflow_base + atomicAdd(&counters[CNT_RECORDS], n_out) : 0u;
             ri.rec_off = off; ri.n_rec = (uint16_t)n_out; ri.mode = (uint16_t)res.mode;
             for (int k = 0; k < res.n; ++k) {
                 const int32_t roles = L.aux[k][lane];
@@ -1262,15 +1260,16 @@ void launch_bands(hipStream_t st, const DevPath* paths, uint32_t n_paths, const 
     if (!n_bands || !n_paths) return;
     hipLaunchKernelGGL(k_bands, dim3(n_bands), dim3(256), 0, st, paths, n_paths, row_base, styles, band_off, band_list, counters);
 }
-void launch_rows(hipStream_t st, const DevEdge* edges, const DevPath* paths, const uint32_t* row_base, const uint32_t* chunk_base,
+void launch_rows(hipStream_t st, const DevEdge* edges, const DevPath* paths, const uint32_t* row_base, const ChunkInfo* chunk_base,
                  uint32_t n_paths, RowInfo* rows, Rec* records, uint32_t* counters, uint32_t* overflow_list, uint32_t n_chunks,
-                 uint32_t band_index, uint32_t band_count, int fast_limit, int cell_mode) {
+                 uint32_t band_index, uint32_t band_count, int fast_limit, int cell_mode, uint32_t rec_overflow_base) {
     if (!n_chunks) return;
     fast_limit = fast_limit < 0 ? 0 : (fast_limit > ROWS_FAST_N ? ROWS_FAST_N : fast_limit);
     hipLaunchKernelGGL(k_rows, dim3(n_chunks), dim3(64), 0, st, edges, paths, row_base, chunk_base, n_paths, rows, records, counters,
                        overflow_list, band_index, band_count, fast_limit, cell_mode);
     // rows that exceeded the per-lane capacity (rare): fixed small grid, every lane loops over the list and exits
-    hipLaunchKernelGGL(k_rows_big, dim3(256), dim3(64), 0, st, edges, paths, row_base, n_paths, rows, records, counters, overflow_list);
+    hipLaunchKernelGGL(k_rows_big, dim3(256), dim3(64), 0, st, edges, paths, row_base, n_paths, rows, records, counters, overflow_list,
+                       rec_overflow_base);
 }
 void launch_class(hipStream_t st, const BandEntry* band_list, uint32_t n_entries, const uint32_t* band_off, uint32_t n_bands,
                   const swfr_edge* raw, const RowInfo* rows, const Rec* records, uint8_t* cls_t, int width, int height,

@@ -25,8 +25,8 @@ void launch_setup(hipStream_t, const swfr_edge*, const DevPath*, DevEdge*, uint3
 void launch_bands(hipStream_t, const DevPath*, uint32_t, const uint32_t*, const swfr_style*, const uint32_t*, BandEntry*, uint32_t, uint32_t*);
 void launch_class(hipStream_t, const BandEntry*, uint32_t, const uint32_t*, uint32_t, const swfr_edge*, const RowInfo*, const Rec*, uint8_t*, int, int,
                   uint32_t, uint32_t);
-void launch_rows(hipStream_t, const DevEdge*, const DevPath*, const uint32_t*, const uint32_t*, uint32_t, RowInfo*, Rec*, uint32_t*,
-                 uint32_t*, uint32_t, uint32_t, uint32_t, int, int);
+void launch_rows(hipStream_t, const DevEdge*, const DevPath*, const uint32_t*, const ChunkInfo*, uint32_t, RowInfo*, Rec*, uint32_t*,
+                 uint32_t*, uint32_t, uint32_t, uint32_t, int, int, uint32_t);
 void launch_tiles(hipStream_t, const swfr_edge*, const uint32_t*, const BandEntry*, const uint8_t*, const RowInfo*, const Rec*, const swfr_style*,
                   const DevBitmap*, uint32_t*, int, int, uint32_t, uint32_t, int, uint32_t*, uint32_t, uint32_t, bool);
 void launch_unpremultiply(hipStream_t, const uint32_t*, uint32_t*, size_t);
@@ -91,7 +91,8 @@ struct swfr_renderer {
     DevBuf<DevEdge> d_edges;
     DevBuf<DevPath> d_paths;
     DevBuf<swfr_style> d_styles;
-    DevBuf<uint32_t> d_row_base, d_chunk_base, d_band_off, d_overflow;
+    DevBuf<uint32_t> d_row_base, d_band_off, d_overflow;
+    DevBuf<ChunkInfo> d_chunk_base;
     DevBuf<BandEntry> d_band_list;
     DevBuf<uint8_t> d_cls;
     size_t n_band_entries = 0;
@@ -104,7 +105,7 @@ struct swfr_renderer {
     std::vector<DevBitmap> bitmap_table;   // indexed by bitmap id
     bool bitmap_table_dirty = false;
     // resident scene
-    size_t n_edges = 0, n_paths = 0, n_styles = 0, n_tasks = 0, n_chunks = 0, n_bands = 0, rec_cap = 0;
+    size_t n_edges = 0, n_paths = 0, n_styles = 0, n_tasks = 0, n_chunks = 0, n_bands = 0, rec_cap = 0, rec_main = 0;
     bool scene_ready = false, fb_valid = false, any_shader = false;
     swfr_timing timing{};
     int tiles_dbg = 0;                      // SWFR_TILES_DEBUG: timing-only ablations of k_tiles (wrong pixels)
@@ -181,7 +182,9 @@ int upload(swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_
     // stage: edges tagged with their path index; row prefix over tor paths; record capacity bound
     std::vector<swfr_edge> staged(edges, edges + n_edges);
     for (auto& e : staged) e.reserved = 0;            // overwritten below with the owning path's index
-    std::vector<uint32_t> row_base(n_paths + 1, 0), chunk_base(n_paths + 1, 0);
+    std::vector<uint32_t> row_base(n_paths + 1, 0);
+    std::vector<ChunkInfo> chunks;                    // one k_rows workgroup each
+    std::vector<uint32_t> chunk_cap;
     const size_t n_bands = (r->height + TILE_H - 1) / TILE_H;
     std::vector<uint32_t> band_off(n_bands + 1, 0);
     size_t rec_cap = 0, pair_cap = 0;
@@ -191,15 +194,23 @@ int upload(swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_
         uint32_t rows = 0;
         if (p.kind == SWFR_PATH_TOR) {
             rows = uint32_t(p.y_max - p.y_min);
+            const size_t c0 = chunks.size(), nc = (rows + ROWS_CHUNK - 1) / ROWS_CHUNK;
+            for (size_t c = 0; c < nc; ++c) chunks.push_back(ChunkInfo{uint32_t(i), uint32_t(p.y_min) + uint32_t(c) * ROWS_CHUNK, 0, 0});
+            chunk_cap.resize(chunks.size(), 0);
             for (uint32_t k = 0; k < p.n_edges; ++k) {
                 const swfr_edge& e = edges[p.first_edge + k];
-                // rows an edge can be active in: [top, bottom) in pixels, clamped to the path
-                const int64_t top = std::max<int64_t>(e.top, int64_t(p.y_min) * 256), bot = std::min<int64_t>(e.bottom, int64_t(p.y_max) * 256);
-                if (bot > top) rec_cap += size_t((bot + 255) / 256 - top / 256 + 1);
+                // pixel rows an edge can be active in (one row of slack at the bottom), clamped to the path:
+                // each contributes at most one record to its row
+                const int64_t rt = std::max<int64_t>(e.top >> 8, p.y_min), rb = std::min<int64_t>(((int64_t(e.bottom) + 255) >> 8) + 1, p.y_max);
+                for (int64_t y = rt; y < rb;) {
+                    const size_t c = size_t(y - p.y_min) / ROWS_CHUNK;
+                    const int64_t cend = std::min<int64_t>(rb, int64_t(p.y_min) + int64_t(c + 1) * ROWS_CHUNK);
+                    chunk_cap[c0 + c] += uint32_t(cend - y);
+                    y = cend;
+                }
             }
         }
         row_base[i + 1] = row_base[i] + rows;
-        chunk_base[i + 1] = chunk_base[i] + (rows + ROWS_CHUNK - 1) / ROWS_CHUNK;
         if (p.y_max > p.y_min && p.x_max > p.x_min) {
             for (int b = p.y_min / TILE_H; b <= (p.y_max - 1) / TILE_H; ++b) ++band_off[size_t(b) + 1];
             pair_cap += size_t((p.y_max - 1) / TILE_H - p.y_min / TILE_H + 1) * size_t((p.x_max - 1) / TILE_W - p.x_min / TILE_W + 1);
@@ -209,13 +220,15 @@ int upload(swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_
     r->n_edges = n_edges; r->n_paths = n_paths; r->n_styles = n_styles;
     r->any_shader = false;
     for (size_t i = 0; i < n_styles; ++i) r->any_shader = r->any_shader || styles[i].kind != SWFR_STYLE_SOLID;
+    for (size_t c = 0; c < chunks.size(); ++c) { chunks[c].rec_base = uint32_t(rec_cap); rec_cap += chunk_cap[c]; }
     r->n_tasks = row_base[n_paths];
-    r->n_chunks = chunk_base[n_paths];
+    r->n_chunks = chunks.size();
     r->n_bands = n_bands;
-    r->rec_cap = rec_cap + 64;
+    r->rec_main = rec_cap;                            // chunk-owned region; rows handled by k_rows_big allocate behind it
+    r->rec_cap = 2 * rec_cap + 64;
     r->d_raw.reserve(n_edges); r->d_edges.reserve(n_edges); r->d_paths.reserve(n_paths); r->d_styles.reserve(n_styles);
     r->d_row_base.reserve(n_paths + 1); r->d_rows.reserve(r->n_tasks); r->d_records.reserve(r->rec_cap);
-    r->d_chunk_base.reserve(n_paths + 1); r->d_band_off.reserve(n_bands + 1); r->d_band_list.reserve(band_off[n_bands]);
+    r->d_chunk_base.reserve(chunks.size()); r->d_band_off.reserve(n_bands + 1); r->d_band_list.reserve(band_off[n_bands]);
     r->d_overflow.reserve(r->n_tasks);
     (void)pair_cap;
     r->d_cls.reserve(size_t(band_off[n_bands]) * ((r->width + TILE_W - 1) / TILE_W) + 64);   // class byte per (band entry, tile column)
@@ -225,7 +238,8 @@ int upload(swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_
     if (n_paths) HIP_CHECK(hipMemcpyAsync(r->d_paths.ptr, paths, n_paths * sizeof(swfr_path), hipMemcpyHostToDevice, r->stream));
     if (n_styles) HIP_CHECK(hipMemcpyAsync(r->d_styles.ptr, styles, n_styles * sizeof(swfr_style), hipMemcpyHostToDevice, r->stream));
     HIP_CHECK(hipMemcpyAsync(r->d_row_base.ptr, row_base.data(), (n_paths + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, r->stream));
-    HIP_CHECK(hipMemcpyAsync(r->d_chunk_base.ptr, chunk_base.data(), (n_paths + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, r->stream));
+    if (!chunks.empty())
+        HIP_CHECK(hipMemcpyAsync(r->d_chunk_base.ptr, chunks.data(), chunks.size() * sizeof(ChunkInfo), hipMemcpyHostToDevice, r->stream));
     HIP_CHECK(hipMemcpyAsync(r->d_band_off.ptr, band_off.data(), (n_bands + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, r->stream));
     if (r->bitmap_table_dirty) {
         r->d_bitmap_table.reserve(r->bitmap_table.size());
@@ -265,7 +279,8 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
         HIP_CHECK(hipEventRecord(e[1], r->stream));
         if (r->n_paths)
             launch_rows(r->stream, r->d_edges.ptr, r->d_paths.ptr, r->d_row_base.ptr, r->d_chunk_base.ptr, uint32_t(r->n_paths), r->d_rows.ptr,
-                        r->d_records.ptr, r->d_counters.ptr, r->d_overflow.ptr, uint32_t(r->n_chunks), bi, bc, r->fast_limit, r->cell_mode);
+                        r->d_records.ptr, r->d_counters.ptr, r->d_overflow.ptr, uint32_t(r->n_chunks), bi, bc, r->fast_limit, r->cell_mode,
+                        uint32_t(r->rec_main));
         if (r->n_paths)
         {
             HIP_CHECK(hipMemsetAsync(r->d_cls.ptr, 0, r->n_band_entries * ((r->width + TILE_W - 1) / TILE_W), r->stream));
@@ -289,7 +304,7 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
     }
     HIP_CHECK(hipEventElapsedTime(&total_ms, r->ev[0], r->ev[size_t(frames - 1) * 4 + 3]));
     HIP_CHECK(hipMemcpy(counters, r->d_counters.ptr, sizeof counters, hipMemcpyDeviceToHost));
-    r->timing = swfr_timing{total_ms, setup_ms, rows_ms, tiles_ms, frames, r->n_edges, r->n_paths, r->n_tasks, counters[CNT_RECORDS]};
+    r->timing = swfr_timing{total_ms, setup_ms, rows_ms, tiles_ms, frames, r->n_edges, r->n_paths, r->n_tasks, r->rec_main};
     if (r->tiles_dbg == 9)
         std::fprintf(stderr, "[swfr] tile/path pairs %u, partial %u, full %u, culled entries %u, records %u, overflow rows %u\n", counters[CNT_PAIRS],
                      counters[CNT_PARTIAL], counters[CNT_FULL], counters[CNT_CULLED], counters[CNT_RECORDS], counters[CNT_OVERFLOW]);
@@ -308,7 +323,7 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
         r->fb_valid = false;
         return fail(r, SWFR_ERR_CAPACITY, "a pixel row has more than 64 active edges of one path (scan converter capacity)");
     }
-    if (counters[CNT_RECORDS] > r->rec_cap) {
+    if (size_t(counters[CNT_RECORDS]) + r->rec_main > r->rec_cap) {
         r->fb_valid = false;
         return fail(r, SWFR_ERR_CAPACITY, "row record buffer overflow");
     }
