@@ -142,7 +142,7 @@ def main():
         algo_bytes = 4 * W * H + 16 * n_edges + 16 * n_paths           # SURVEY.md 8(d), per frame = per k_tiles launch
         if world > 1:
             algo_bytes = 4 * W * D.local_tile_rows(H, 0, world) * D.TILE_H + 16 * n_edges + 16 * n_paths
-        tiles_ms = tm["tiles_ms"] / max(tm["frames"], 1)
+        tiles_ms = tm["tiles_ms"] / max(tm["timed_frames"], 1)
         achieved = algo_bytes / (tiles_ms * 1e-3) / 1e9 if tiles_ms > 0 else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01b_pmc_k_tiles.json")
@@ -164,7 +164,7 @@ def main():
                        "n_edges": n_edges, "n_paths": n_paths,
                        "sharding": "tile-row bands interleaved over %d rank(s)%s" % (world, ", one RCCL gather per frame" if world > 1 else ""),
                        "host_edge_list_build_ms": round(t_host * 1e3, 2)},
-            "kernel_ms_per_frame": {"k_setup": round(tm["setup_ms"] / tm["frames"], 4), "k_rows": round(tm["rows_ms"] / tm["frames"], 4),
+            "kernel_ms_per_frame": {"k_setup": round(tm["setup_ms"] / max(tm["timed_frames"], 1), 4), "k_rows": round(tm["rows_ms"] / max(tm["timed_frames"], 1), 4),
                                     "k_tiles": round(tiles_ms, 4)},
             "roofline": {"bound": "hbm", "kernel": "k_tiles", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,

@@ -210,9 +210,10 @@ int  swfr_shape_json(swfr_renderer *r, uint32_t id, int morph, const char **json
 /* Timing of the last swfr_render / swfr_render_resident, from HIP events on the handle's stream. */
 typedef struct {
     float total_ms;                      /* first kernel start -> last kernel end, all frames */
-    float setup_ms, rows_ms, tiles_ms;   /* per-kernel sums over all frames */
+    float setup_ms, rows_ms, tiles_ms;   /* per-kernel sums over the timed_frames frames that carried events */
     uint32_t frames;
     uint64_t n_edges, n_paths, n_row_tasks, n_records;
+    uint32_t timed_frames;               /* frames / SWFR_EVENT_STRIDE (default: every frame) */
 } swfr_timing;
 int  swfr_last_timing(swfr_renderer *r, swfr_timing *out);
 

@@ -123,7 +123,7 @@ class Style(C.Structure):
 class Timing(C.Structure):
     _fields_ = [("total_ms", C.c_float), ("setup_ms", C.c_float), ("rows_ms", C.c_float), ("tiles_ms", C.c_float),
                 ("frames", C.c_uint32), ("n_edges", C.c_uint64), ("n_paths", C.c_uint64), ("n_row_tasks", C.c_uint64),
-                ("n_records", C.c_uint64)]
+                ("n_records", C.c_uint64), ("timed_frames", C.c_uint32)]
 
 
 EDGE_DTYPE = np.dtype([(n, "<i4") for n in ("x1", "y1", "x2", "y2", "top", "bottom", "dir", "reserved")])

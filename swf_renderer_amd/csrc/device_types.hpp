@@ -76,6 +76,14 @@ struct ChunkInfo {
     uint32_t path, first_row, rec_base, pad;
 };
 
+// A pixel row with more active edges than k_rows keeps in registers: handled by k_rows_big, one lane each.
+struct BigRow {
+    uint32_t path;
+    int32_t row;             // absolute pixel row
+    uint32_t rec_base;       // first of the row's record slots (one per active edge)
+    uint32_t pad;
+};
+
 struct DevBitmap {
     const uint32_t* pixels;  // premultiplied ARGB, tight rows
     uint32_t width, height;

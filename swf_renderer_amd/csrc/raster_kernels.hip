@@ -134,9 +134,9 @@ __device__ __forceinline__ int wave_scan_incl(int v) {
 // ---------------------------------------------------------------------------------------------
 // k_setup
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_setup(const swfr_edge* __restrict__ in, const DevPath* __restrict__ paths,
-                                               DevEdge* __restrict__ out, uint32_t n_edges) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void setup_block(uint32_t block, const swfr_edge* __restrict__ in, const DevPath* __restrict__ paths,
+                                            DevEdge* __restrict__ out, uint32_t n_edges) {
+    const uint32_t i = block * 256 + threadIdx.x;
     if (i >= n_edges) return;
     const swfr_edge e = in[i];
     const DevPath p = paths[e.reserved];
@@ -165,14 +165,12 @@ __global__ __launch_bounds__(256) void k_setup(const swfr_edge* __restrict__ in,
 // ---------------------------------------------------------------------------------------------
 // k_bands: per tile-row, the paths whose pixel rows intersect it, in painter's order
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_bands(const DevPath* __restrict__ paths, uint32_t n_paths,
-                                               const uint32_t* __restrict__ row_base, const swfr_style* __restrict__ styles,
-                                               const uint32_t* __restrict__ band_off, BandEntry* __restrict__ band_list,
-                                               uint32_t* __restrict__ counters) {
+__device__ __forceinline__ void bands_block(int band, const DevPath* __restrict__ paths, uint32_t n_paths,
+                                            const uint32_t* __restrict__ row_base, const swfr_style* __restrict__ styles,
+                                            const uint32_t* __restrict__ band_off, BandEntry* __restrict__ band_list) {
     __shared__ uint32_t wave_cnt[4];
     __shared__ uint32_t total;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int band = blockIdx.x;
     const int y0 = band * TILE_H, y1 = y0 + TILE_H;
     BandEntry* out = band_list + band_off[band];
     if (tid == 0) total = 0;
@@ -206,6 +204,17 @@ __global__ __launch_bounds__(256) void k_bands(const DevPath* __restrict__ paths
         if (tid == 0) total += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
         __syncthreads();
     }
+}
+
+// k_front: one launch for the per-frame front end.  Blocks [0, n_setup) convert edges (k_setup), the next n_bands
+// blocks build the band lists (k_bands); block 0 also clears the frame's counters.
+__global__ __launch_bounds__(256) void k_front(const swfr_edge* __restrict__ in, const DevPath* __restrict__ paths, DevEdge* __restrict__ out,
+                                               uint32_t n_edges, uint32_t n_setup, uint32_t n_paths, const uint32_t* __restrict__ row_base,
+                                               const swfr_style* __restrict__ styles, const uint32_t* __restrict__ band_off,
+                                               BandEntry* __restrict__ band_list, uint32_t* __restrict__ counters) {
+    if (blockIdx.x == 0 && threadIdx.x < CNT_WORDS) counters[threadIdx.x] = 0;
+    if (blockIdx.x < n_setup) setup_block(blockIdx.x, in, paths, out, n_edges);
+    else bands_block((int)(blockIdx.x - n_setup), paths, n_paths, row_base, styles, band_off, band_list);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -541,7 +550,6 @@ __device__ __forceinline__ void fast_rows(EPTR E, const DevPath& P, int r, bool 
 __global__ __launch_bounds__(64) void k_rows(const DevEdge* __restrict__ edges, const DevPath* __restrict__ paths,
                                              const uint32_t* __restrict__ row_base, const ChunkInfo* __restrict__ chunks,
                                              uint32_t n_paths, RowInfo* __restrict__ rows, Rec* __restrict__ records,
-                                             uint32_t* __restrict__ counters, uint32_t* __restrict__ overflow_list,
                                              uint32_t band_index, uint32_t band_count, int fast_limit, int cell_mode) {
     __shared__ FastLds F;
     __shared__ DevEdge staged[ROWS_STAGE];
@@ -569,10 +577,6 @@ __global__ __launch_bounds__(64) void k_rows(const DevEdge* __restrict__ edges, 
     uint32_t n_out = 0;
 #pragma unroll
     for (int s = 0; s < ROWS_FAST_N; ++s) n_out += (s < n && roles[s] != 0) ? 1u : 0u;
-    if (overflow) {                                                     // handled by k_rows_big
-        const uint32_t slot = atomicAdd(&counters[CNT_OVERFLOW], 1u);
-        overflow_list[slot] = t;
-    }
     // ---- record slots: the chunk owns [rec_base, rec_base + bound); lanes take consecutive pieces (no atomics)
     const uint32_t incl = (uint32_t)wave_scan_incl((int)n_out);
     const uint32_t base = ck.rec_base;
@@ -596,37 +600,34 @@ __global__ __launch_bounds__(64) void k_rows(const DevEdge* __restrict__ edges, 
     }
 }
 
-// Rows with more than ROWS_MAXA active edges: one lane per overflowed row, 4x the capacity.
+// Rows with more than ROWS_FAST_N active edges of one path (the host lists them at upload, with their record slots):
+// one lane per listed row, generic LDS-list routine with ROWS_BIG_MAXA capacity.
 __global__ __launch_bounds__(64) void k_rows_big(const DevEdge* __restrict__ edges, const DevPath* __restrict__ paths,
-                                                 const uint32_t* __restrict__ row_base, uint32_t n_paths,
-                                                 RowInfo* __restrict__ rows, Rec* __restrict__ records,
-                                                 uint32_t* __restrict__ counters, const uint32_t* __restrict__ overflow_list,
-                                                 uint32_t rec_overflow_base) {
+                                                 const uint32_t* __restrict__ row_base, const BigRow* __restrict__ big_rows, uint32_t n_big,
+                                                 RowInfo* __restrict__ rows, Rec* __restrict__ records, uint32_t* __restrict__ counters) {
     __shared__ RowLds<ROWS_BIG_MAXA> L;
     const int lane = threadIdx.x;
-    const uint32_t count = counters[CNT_OVERFLOW];
-    for (uint32_t i = blockIdx.x * 64 + lane; i < count; i += gridDim.x * 64) {
-        const uint32_t t = overflow_list[i];
-        uint32_t lo = 0, hi = n_paths;
-        while (lo + 1 < hi) { const uint32_t mid = (lo + hi) >> 1; if (row_base[mid] <= t) lo = mid; else hi = mid; }
-        const DevPath P = paths[lo];
-        const int r = P.y_min + (int)(t - row_base[lo]);
-        const RowResult res = process_row<ROWS_BIG_MAXA>(edges + P.first_edge, P, r, L, lane);
-        RowInfo ri; ri.rec_off = 0; ri.n_rec = 0; ri.mode = ROW_EMPTY;
-        if (res.overflow) {
-            atomicOr(&counters[CNT_ERROR], 1u);
-        } else {
-            uint32_t n_out = 0;
-            for (int k = 0; k < res.n; ++k) n_out += L.aux[k][lane] != 0;
-            uint32_t off = n_out ? rec_overflow_base + atomicAdd(&counters[CNT_RECORDS], n_out) : 0u;
-            ri.rec_off = off; ri.n_rec = (uint16_t)n_out; ri.mode = (uint16_t)res.mode;
-            for (int k = 0; k < res.n; ++k) {
-                const int32_t roles = L.aux[k][lane];
-                if (roles) records[off++] = make_record(edges[P.first_edge + (uint32_t)L.eid[k][lane]], P.first_edge + (uint32_t)L.eid[k][lane], r * 15, (uint32_t)roles, (uint32_t)L.cols[k][lane]);
-            }
+    const uint32_t i = blockIdx.x * 64 + lane;
+    if (i >= n_big) return;                       // process_row has no workgroup barriers: lanes are independent
+    const BigRow br = big_rows[i];
+    const DevPath P = paths[br.path];
+    const int r = br.row;
+    const uint32_t t = row_base[br.path] + (uint32_t)(r - P.y_min);
+    const RowResult res = process_row<ROWS_BIG_MAXA>(edges + P.first_edge, P, r, L, lane);
+    RowInfo ri; ri.rec_off = 0; ri.n_rec = 0; ri.mode = ROW_EMPTY;
+    if (res.overflow) {
+        atomicOr(&counters[CNT_ERROR], 1u);
+    } else {
+        uint32_t n_out = 0;
+        for (int k = 0; k < res.n; ++k) n_out += L.aux[k][lane] != 0;
+        uint32_t off = br.rec_base;               // the row owns as many slots as it has active edges
+        ri.rec_off = off; ri.n_rec = (uint16_t)n_out; ri.mode = (uint16_t)res.mode;
+        for (int k = 0; k < res.n; ++k) {
+            const int32_t roles = L.aux[k][lane];
+            if (roles) records[off++] = make_record(edges[P.first_edge + (uint32_t)L.eid[k][lane]], P.first_edge + (uint32_t)L.eid[k][lane], r * 15, (uint32_t)roles, (uint32_t)L.cols[k][lane]);
         }
-        rows[t] = ri;
     }
+    rows[t] = ri;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -825,6 +826,8 @@ __global__ __launch_bounds__(64) void k_class(const BandEntry* __restrict__ band
     uint8_t* out = cls_t + (size_t)tiles_x * b0 + e_local;              // + tile column * n_b
     const int ty0 = (int)band * TILE_H, tile_y1 = min(ty0 + TILE_H, height);
     const int tc0 = (int)e.x_min / TILE_W, tc1 = ((int)e.x_max - 1) / TILE_W;
+    for (int tc = lane; tc < tiles_x; tc += 64)                          // columns the path's rectangle does not reach: empty
+        if (tc < tc0 || tc > tc1) out[(size_t)tc * n_b] = 0;
     if (e.flags & BE_BOXES) {
         for (int tc = tc0 + lane; tc <= tc1; tc += 64) {
             const int tx0 = tc * TILE_W, tile_x1 = min(tx0 + TILE_W, width);
@@ -1251,25 +1254,24 @@ __global__ __launch_bounds__(256) void k_pack_band(const uint32_t* __restrict__ 
 // ---------------------------------------------------------------------------------------------
 // launchers (called from renderer.cpp, which is compiled as plain C++ by the same hipcc)
 // ---------------------------------------------------------------------------------------------
-void launch_setup(hipStream_t st, const swfr_edge* in, const DevPath* paths, DevEdge* out, uint32_t n_edges) {
-    if (!n_edges) return;
-    hipLaunchKernelGGL(k_setup, dim3((n_edges + 255) / 256), dim3(256), 0, st, in, paths, out, n_edges);
-}
-void launch_bands(hipStream_t st, const DevPath* paths, uint32_t n_paths, const uint32_t* row_base, const swfr_style* styles,
-                  const uint32_t* band_off, BandEntry* band_list, uint32_t n_bands, uint32_t* counters) {
-    if (!n_bands || !n_paths) return;
-    hipLaunchKernelGGL(k_bands, dim3(n_bands), dim3(256), 0, st, paths, n_paths, row_base, styles, band_off, band_list, counters);
+void launch_front(hipStream_t st, const swfr_edge* in, const DevPath* paths, DevEdge* out, uint32_t n_edges, uint32_t n_paths,
+                  const uint32_t* row_base, const swfr_style* styles, const uint32_t* band_off, BandEntry* band_list, uint32_t n_bands,
+                  uint32_t* counters) {
+    uint32_t n_setup = (n_edges + 255) / 256;
+    const uint32_t n_b = n_paths ? n_bands : 0;
+    if (n_setup + n_b == 0) n_setup = 1;          // counters are still cleared
+    hipLaunchKernelGGL(k_front, dim3(n_setup + n_b), dim3(256), 0, st, in, paths, out, n_edges, n_setup, n_paths, row_base, styles, band_off,
+                       band_list, counters);
 }
 void launch_rows(hipStream_t st, const DevEdge* edges, const DevPath* paths, const uint32_t* row_base, const ChunkInfo* chunk_base,
-                 uint32_t n_paths, RowInfo* rows, Rec* records, uint32_t* counters, uint32_t* overflow_list, uint32_t n_chunks,
-                 uint32_t band_index, uint32_t band_count, int fast_limit, int cell_mode, uint32_t rec_overflow_base) {
+                 uint32_t n_paths, RowInfo* rows, Rec* records, uint32_t* counters, const BigRow* big_rows, uint32_t n_big, uint32_t n_chunks,
+                 uint32_t band_index, uint32_t band_count, int fast_limit, int cell_mode) {
     if (!n_chunks) return;
     fast_limit = fast_limit < 0 ? 0 : (fast_limit > ROWS_FAST_N ? ROWS_FAST_N : fast_limit);
-    hipLaunchKernelGGL(k_rows, dim3(n_chunks), dim3(64), 0, st, edges, paths, row_base, chunk_base, n_paths, rows, records, counters,
-                       overflow_list, band_index, band_count, fast_limit, cell_mode);
-    // rows that exceeded the per-lane capacity (rare): fixed small grid, every lane loops over the list and exits
-    hipLaunchKernelGGL(k_rows_big, dim3(256), dim3(64), 0, st, edges, paths, row_base, n_paths, rows, records, counters, overflow_list,
-                       rec_overflow_base);
+    hipLaunchKernelGGL(k_rows, dim3(n_chunks), dim3(64), 0, st, edges, paths, row_base, chunk_base, n_paths, rows, records,
+                       band_index, band_count, fast_limit, cell_mode);
+    if (n_big)
+        hipLaunchKernelGGL(k_rows_big, dim3((n_big + 63) / 64), dim3(64), 0, st, edges, paths, row_base, big_rows, n_big, rows, records, counters);
 }
 void launch_class(hipStream_t st, const BandEntry* band_list, uint32_t n_entries, const uint32_t* band_off, uint32_t n_bands,
                   const swfr_edge* raw, const RowInfo* rows, const Rec* records, uint8_t* cls_t, int width, int height,

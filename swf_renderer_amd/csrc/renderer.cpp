@@ -21,12 +21,12 @@
 #include "shape_decoder.hpp"
 
 namespace swfr {
-void launch_setup(hipStream_t, const swfr_edge*, const DevPath*, DevEdge*, uint32_t);
-void launch_bands(hipStream_t, const DevPath*, uint32_t, const uint32_t*, const swfr_style*, const uint32_t*, BandEntry*, uint32_t, uint32_t*);
+void launch_front(hipStream_t, const swfr_edge*, const DevPath*, DevEdge*, uint32_t, uint32_t, const uint32_t*, const swfr_style*, const uint32_t*,
+                  BandEntry*, uint32_t, uint32_t*);
 void launch_class(hipStream_t, const BandEntry*, uint32_t, const uint32_t*, uint32_t, const swfr_edge*, const RowInfo*, const Rec*, uint8_t*, int, int,
                   uint32_t, uint32_t);
-void launch_rows(hipStream_t, const DevEdge*, const DevPath*, const uint32_t*, const ChunkInfo*, uint32_t, RowInfo*, Rec*, uint32_t*,
-                 uint32_t*, uint32_t, uint32_t, uint32_t, int, int, uint32_t);
+void launch_rows(hipStream_t, const DevEdge*, const DevPath*, const uint32_t*, const ChunkInfo*, uint32_t, RowInfo*, Rec*, uint32_t*, const BigRow*,
+                 uint32_t, uint32_t, uint32_t, uint32_t, int, int);
 void launch_tiles(hipStream_t, const swfr_edge*, const uint32_t*, const BandEntry*, const uint8_t*, const RowInfo*, const Rec*, const swfr_style*,
                   const DevBitmap*, uint32_t*, int, int, uint32_t, uint32_t, int, uint32_t*, uint32_t, uint32_t, bool);
 void launch_unpremultiply(hipStream_t, const uint32_t*, uint32_t*, size_t);
@@ -91,7 +91,8 @@ struct swfr_renderer {
     DevBuf<DevEdge> d_edges;
     DevBuf<DevPath> d_paths;
     DevBuf<swfr_style> d_styles;
-    DevBuf<uint32_t> d_row_base, d_band_off, d_overflow;
+    DevBuf<uint32_t> d_row_base, d_band_off;
+    DevBuf<BigRow> d_big_rows;
     DevBuf<ChunkInfo> d_chunk_base;
     DevBuf<BandEntry> d_band_list;
     DevBuf<uint8_t> d_cls;
@@ -105,9 +106,10 @@ struct swfr_renderer {
     std::vector<DevBitmap> bitmap_table;   // indexed by bitmap id
     bool bitmap_table_dirty = false;
     // resident scene
-    size_t n_edges = 0, n_paths = 0, n_styles = 0, n_tasks = 0, n_chunks = 0, n_bands = 0, rec_cap = 0, rec_main = 0;
+    size_t n_edges = 0, n_paths = 0, n_styles = 0, n_tasks = 0, n_chunks = 0, n_bands = 0, rec_cap = 0, rec_main = 0, n_big = 0;
     bool scene_ready = false, fb_valid = false, any_shader = false;
     swfr_timing timing{};
+    int event_stride = 8;                   // SWFR_EVENT_STRIDE: per-kernel HIP events on every n-th resident frame
     int tiles_dbg = 0;                      // SWFR_TILES_DEBUG: timing-only ablations of k_tiles (wrong pixels)
     int cell_mode = 3;                      // SWFR_CELL_MODE: 1 = FULL rows as precomputed cells, 2 = SUB rows (test knob)
     int fast_limit = 8;                     // rows with more active edges go through k_rows_big (SWFR_FAST_LIMIT: test knob)
@@ -116,7 +118,7 @@ struct swfr_renderer {
         if (has_device) {
             (void)hipSetDevice(cfg.device);
             d_raw.release(); d_edges.release(); d_paths.release(); d_styles.release(); d_row_base.release();
-            d_rows.release(); d_records.release(); d_chunk_base.release(); d_band_off.release(); d_band_list.release(); d_overflow.release(); d_cls.release(); d_counters.release(); d_bitmap_table.release(); d_fb.release(); d_tmp.release();
+            d_rows.release(); d_records.release(); d_chunk_base.release(); d_band_off.release(); d_band_list.release(); d_big_rows.release(); d_cls.release(); d_counters.release(); d_bitmap_table.release(); d_fb.release(); d_tmp.release();
             for (auto& kv : bitmaps) if (kv.second.pixels) (void)hipFree(kv.second.pixels);
             for (auto& e : ev) if (e) (void)hipEventDestroy(e);
             if (stream) (void)hipStreamDestroy(stream);
@@ -185,6 +187,9 @@ int upload(swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_
     std::vector<uint32_t> row_base(n_paths + 1, 0);
     std::vector<ChunkInfo> chunks;                    // one k_rows workgroup each
     std::vector<uint32_t> chunk_cap;
+    std::vector<BigRow> big_rows;                     // rec_base holds the row's slot count until the prefix pass below
+    std::vector<int32_t> active;
+    const uint32_t bc = r->cfg.band_count > 1 ? r->cfg.band_count : 1, bi = r->cfg.band_count > 1 ? r->cfg.band_index : 0;
     const size_t n_bands = (r->height + TILE_H - 1) / TILE_H;
     std::vector<uint32_t> band_off(n_bands + 1, 0);
     size_t rec_cap = 0, pair_cap = 0;
@@ -197,17 +202,27 @@ int upload(swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_
             const size_t c0 = chunks.size(), nc = (rows + ROWS_CHUNK - 1) / ROWS_CHUNK;
             for (size_t c = 0; c < nc; ++c) chunks.push_back(ChunkInfo{uint32_t(i), uint32_t(p.y_min) + uint32_t(c) * ROWS_CHUNK, 0, 0});
             chunk_cap.resize(chunks.size(), 0);
+            // active edges per pixel row, exactly as k_setup / k_rows count them (sample rows [ytop, ybot) clamped to the
+            // path): a row yields at most one record per active edge, so these counts size the record slots; rows
+            // with more than the register capacity of k_rows are listed for k_rows_big
+            active.assign(size_t(rows) + 1, 0);
             for (uint32_t k = 0; k < p.n_edges; ++k) {
                 const swfr_edge& e = edges[p.first_edge + k];
-                // pixel rows an edge can be active in (one row of slack at the bottom), clamped to the path:
-                // each contributes at most one record to its row
-                const int64_t rt = std::max<int64_t>(e.top >> 8, p.y_min), rb = std::min<int64_t>(((int64_t(e.bottom) + 255) >> 8) + 1, p.y_max);
-                for (int64_t y = rt; y < rb;) {
-                    const size_t c = size_t(y - p.y_min) / ROWS_CHUNK;
-                    const int64_t cend = std::min<int64_t>(rb, int64_t(p.y_min) + int64_t(c + 1) * ROWS_CHUNK);
-                    chunk_cap[c0 + c] += uint32_t(cend - y);
-                    y = cend;
-                }
+                int64_t ytop = (15ll * e.top + 128) >> 8, ybot = (15ll * e.bottom + 128) >> 8;
+                ytop = std::max<int64_t>(ytop, int64_t(p.y_min) * 15);
+                ybot = std::min<int64_t>(ybot, int64_t(p.y_max) * 15);
+                if (ybot <= ytop) continue;
+                ++active[size_t(ytop / 15 - p.y_min)];
+                --active[size_t((ybot - 1) / 15 - p.y_min) + 1];
+            }
+            const int limit = p.n_edges > 65535u ? 0 : std::min(std::max(r->fast_limit, 0), 8);
+            int32_t run = 0;
+            for (uint32_t y = 0; y < rows; ++y) {
+                run += active[y];
+                const uint32_t band = (uint32_t(p.y_min) + y) / TILE_H;
+                if (bc > 1 && band % bc != bi) continue;          // another rank's tile-row: k_rows leaves it empty
+                if (run > limit) { big_rows.push_back(BigRow{uint32_t(i), int32_t(p.y_min) + int32_t(y), uint32_t(run), 0}); }
+                else chunk_cap[c0 + y / ROWS_CHUNK] += uint32_t(run);
             }
         }
         row_base[i + 1] = row_base[i] + rows;
@@ -224,12 +239,14 @@ int upload(swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_
     r->n_tasks = row_base[n_paths];
     r->n_chunks = chunks.size();
     r->n_bands = n_bands;
-    r->rec_main = rec_cap;                            // chunk-owned region; rows handled by k_rows_big allocate behind it
-    r->rec_cap = 2 * rec_cap + 64;
+    r->rec_main = rec_cap;                            // chunk-owned region; the rows of k_rows_big own slots behind it
+    for (auto& b : big_rows) { const uint32_t n = b.rec_base; b.rec_base = uint32_t(rec_cap); rec_cap += n; }
+    r->rec_cap = rec_cap + 64;
+    r->n_big = big_rows.size();
     r->d_raw.reserve(n_edges); r->d_edges.reserve(n_edges); r->d_paths.reserve(n_paths); r->d_styles.reserve(n_styles);
     r->d_row_base.reserve(n_paths + 1); r->d_rows.reserve(r->n_tasks); r->d_records.reserve(r->rec_cap);
     r->d_chunk_base.reserve(chunks.size()); r->d_band_off.reserve(n_bands + 1); r->d_band_list.reserve(band_off[n_bands]);
-    r->d_overflow.reserve(r->n_tasks);
+    r->d_big_rows.reserve(big_rows.size());
     (void)pair_cap;
     r->d_cls.reserve(size_t(band_off[n_bands]) * ((r->width + TILE_W - 1) / TILE_W) + 64);   // class byte per (band entry, tile column)
     r->n_band_entries = band_off[n_bands];
@@ -238,6 +255,8 @@ int upload(swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_
     if (n_paths) HIP_CHECK(hipMemcpyAsync(r->d_paths.ptr, paths, n_paths * sizeof(swfr_path), hipMemcpyHostToDevice, r->stream));
     if (n_styles) HIP_CHECK(hipMemcpyAsync(r->d_styles.ptr, styles, n_styles * sizeof(swfr_style), hipMemcpyHostToDevice, r->stream));
     HIP_CHECK(hipMemcpyAsync(r->d_row_base.ptr, row_base.data(), (n_paths + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, r->stream));
+    if (!big_rows.empty())
+        HIP_CHECK(hipMemcpyAsync(r->d_big_rows.ptr, big_rows.data(), big_rows.size() * sizeof(BigRow), hipMemcpyHostToDevice, r->stream));
     if (!chunks.empty())
         HIP_CHECK(hipMemcpyAsync(r->d_chunk_base.ptr, chunks.data(), chunks.size() * sizeof(ChunkInfo), hipMemcpyHostToDevice, r->stream));
     HIP_CHECK(hipMemcpyAsync(r->d_band_off.ptr, band_off.data(), (n_bands + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, r->stream));
@@ -261,40 +280,41 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
     float setup_ms = 0, rows_ms = 0, tiles_ms = 0, total_ms = 0;
     uint32_t counters[CNT_WORDS] = {};
     if (frames > 4096) frames = 4096;
-    while (r->ev.size() < size_t(frames) * 4) {
+    while (r->ev.size() < size_t(frames) * 4 + 2) {
         hipEvent_t e = nullptr;
         HIP_CHECK(hipEventCreate(&e));
         r->ev.push_back(e);
     }
     // all frames are queued back to back; events bracket every kernel on the handle's own stream
+    HIP_CHECK(hipMemsetAsync(r->d_counters.ptr, 0, CNT_WORDS * sizeof(uint32_t), r->stream));
+    const uint32_t stride = r->event_stride < 1 ? 1u : uint32_t(r->event_stride);
+    hipEvent_t ev_begin = r->ev[size_t(frames) * 4], ev_end = r->ev[size_t(frames) * 4 + 1];
+    HIP_CHECK(hipEventRecord(ev_begin, r->stream));
     for (uint32_t f = 0; f < frames; ++f) {
         hipEvent_t* e = &r->ev[size_t(f) * 4];
-        HIP_CHECK(hipMemsetAsync(r->d_counters.ptr, 0, CNT_WORDS * sizeof(uint32_t), r->stream));
-        HIP_CHECK(hipEventRecord(e[0], r->stream));
+        const bool timed = f % stride == 0;        // per-kernel events on every stride-th frame (each costs a queue packet)
+        if (timed) HIP_CHECK(hipEventRecord(e[0], r->stream));
+        if (r->n_paths)     // edge constants + band lists; also clears the counters for this frame
+            launch_front(r->stream, r->d_raw.ptr, r->d_paths.ptr, r->d_edges.ptr, uint32_t(r->n_edges), uint32_t(r->n_paths), r->d_row_base.ptr,
+                         r->d_styles.ptr, r->d_band_off.ptr, r->d_band_list.ptr, uint32_t(r->n_bands), r->d_counters.ptr);
+        if (timed) HIP_CHECK(hipEventRecord(e[1], r->stream));
         if (r->n_paths) {
-            launch_setup(r->stream, r->d_raw.ptr, r->d_paths.ptr, r->d_edges.ptr, uint32_t(r->n_edges));
-            launch_bands(r->stream, r->d_paths.ptr, uint32_t(r->n_paths), r->d_row_base.ptr, r->d_styles.ptr, r->d_band_off.ptr, r->d_band_list.ptr,
-                         uint32_t(r->n_bands), r->d_counters.ptr);
-        }
-        HIP_CHECK(hipEventRecord(e[1], r->stream));
-        if (r->n_paths)
             launch_rows(r->stream, r->d_edges.ptr, r->d_paths.ptr, r->d_row_base.ptr, r->d_chunk_base.ptr, uint32_t(r->n_paths), r->d_rows.ptr,
-                        r->d_records.ptr, r->d_counters.ptr, r->d_overflow.ptr, uint32_t(r->n_chunks), bi, bc, r->fast_limit, r->cell_mode,
-                        uint32_t(r->rec_main));
-        if (r->n_paths)
-        {
-            HIP_CHECK(hipMemsetAsync(r->d_cls.ptr, 0, r->n_band_entries * ((r->width + TILE_W - 1) / TILE_W), r->stream));
+                        r->d_records.ptr, r->d_counters.ptr, r->d_big_rows.ptr, uint32_t(r->n_big), uint32_t(r->n_chunks), bi, bc, r->fast_limit,
+                        r->cell_mode);
             launch_class(r->stream, r->d_band_list.ptr, uint32_t(r->n_band_entries), r->d_band_off.ptr, uint32_t(r->n_bands), r->d_raw.ptr,
                          r->d_rows.ptr, r->d_records.ptr, r->d_cls.ptr, int(r->width), int(r->height), bi, bc);
         }
-        HIP_CHECK(hipEventRecord(e[2], r->stream));
+        if (timed) HIP_CHECK(hipEventRecord(e[2], r->stream));
         launch_tiles(r->stream, r->d_raw.ptr, r->d_band_off.ptr, r->d_band_list.ptr, r->d_cls.ptr, r->d_rows.ptr, r->d_records.ptr, r->d_styles.ptr,
                      r->d_bitmap_table.ptr, r->d_fb.ptr, int(r->width), int(r->height), bi, bc, r->tiles_dbg, r->d_counters.ptr, uint32_t(r->n_tasks), uint32_t(r->rec_cap), r->any_shader);
-        HIP_CHECK(hipEventRecord(e[3], r->stream));
+        if (timed) HIP_CHECK(hipEventRecord(e[3], r->stream));
     }
+    HIP_CHECK(hipEventRecord(ev_end, r->stream));
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(r->stream));
-    for (uint32_t f = 0; f < frames; ++f) {
+    uint32_t timed_frames = 0;
+    for (uint32_t f = 0; f < frames; f += stride, ++timed_frames) {
         hipEvent_t* e = &r->ev[size_t(f) * 4];
         float a = 0, b = 0, c = 0;
         HIP_CHECK(hipEventElapsedTime(&a, e[0], e[1]));
@@ -302,9 +322,9 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
         HIP_CHECK(hipEventElapsedTime(&c, e[2], e[3]));
         setup_ms += a; rows_ms += b; tiles_ms += c;
     }
-    HIP_CHECK(hipEventElapsedTime(&total_ms, r->ev[0], r->ev[size_t(frames - 1) * 4 + 3]));
+    HIP_CHECK(hipEventElapsedTime(&total_ms, ev_begin, ev_end));
     HIP_CHECK(hipMemcpy(counters, r->d_counters.ptr, sizeof counters, hipMemcpyDeviceToHost));
-    r->timing = swfr_timing{total_ms, setup_ms, rows_ms, tiles_ms, frames, r->n_edges, r->n_paths, r->n_tasks, r->rec_main};
+    r->timing = swfr_timing{total_ms, setup_ms, rows_ms, tiles_ms, frames, r->n_edges, r->n_paths, r->n_tasks, r->rec_main, timed_frames};
     if (r->tiles_dbg == 9)
         std::fprintf(stderr, "[swfr] tile/path pairs %u, partial %u, full %u, culled entries %u, records %u, overflow rows %u\n", counters[CNT_PAIRS],
                      counters[CNT_PARTIAL], counters[CNT_FULL], counters[CNT_CULLED], counters[CNT_RECORDS], counters[CNT_OVERFLOW]);
@@ -322,10 +342,6 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
     if (counters[CNT_ERROR]) {
         r->fb_valid = false;
         return fail(r, SWFR_ERR_CAPACITY, "a pixel row has more than 64 active edges of one path (scan converter capacity)");
-    }
-    if (size_t(counters[CNT_RECORDS]) + r->rec_main > r->rec_cap) {
-        r->fb_valid = false;
-        return fail(r, SWFR_ERR_CAPACITY, "row record buffer overflow");
     }
     return SWFR_OK;
 }
@@ -352,6 +368,7 @@ int swfr_create(uint32_t width, uint32_t height, const swfr_config* cfg, swfr_re
     r->builder.reset(new FrameBuilder(width, height, (r->cfg.flags & SWFR_FLAG_EVEN_ODD) != 0));
     if (const char* fl = std::getenv("SWFR_FAST_LIMIT")) r->fast_limit = std::atoi(fl);
     if (const char* td = std::getenv("SWFR_TILES_DEBUG")) r->tiles_dbg = std::atoi(td);
+    if (const char* es = std::getenv("SWFR_EVENT_STRIDE")) r->event_stride = std::atoi(es);
     if (const char* cm = std::getenv("SWFR_CELL_MODE")) r->cell_mode = std::atoi(cm);
     if (r->cfg.device == SWFR_DEVICE_HOST_ONLY) {
         *out = r.release();
