@@ -21,7 +21,10 @@ def per_kernel(path, counter):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == counter:
-            agg[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+            name = r["Kernel_Name"].split("(")[0]
+            if name.startswith("void "):           # template instances are reported with their return type
+                name = name[5:]
+            agg[name].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in agg.items()}
 
 
@@ -39,7 +42,8 @@ def main():
         summary[k] = {"FETCH_SIZE_KiB_raw": fk, "WRITE_SIZE_KiB": wk, "fetch_bytes_corrected_x2": int(fk * 2 * 1024),
                       "write_bytes": int(wk * 1024), "hbm_bytes_per_launch": int(fk * 2 * 1024 + wk * 1024)}
     json.dump(summary, open(os.path.join(out, "%s_pmc_summary.json" % tag), "w"), indent=1)
-    kt = summary.get("swfr::k_tiles")
+    kt = [v for k, v in summary.items() if k.startswith("swfr::k_tiles")]
+    kt = max(kt, key=lambda v: v["hbm_bytes_per_launch"]) if kt else None
     if kt:
         json.dump(kt, open(os.path.join(out, "%s_pmc_k_tiles.json" % tag), "w"), indent=1)
     print(json.dumps(summary, indent=1))
