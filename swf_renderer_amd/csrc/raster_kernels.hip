@@ -896,10 +896,10 @@ __global__ __launch_bounds__(64) void k_class(const BandEntry* __restrict__ band
 }
 
 #define TLIST 64                       // tile list entries per round
-#define STRIP_H 4                      // pixel rows per wavefront: a 64x16 tile is rasterized as four independent 64x4 strips
+#define STRIP_H 8                      // pixel rows per wavefront: a 64x16 tile is rasterized as four independent 64x4 strips
 #define STRIPS_PER_TILE (TILE_H / STRIP_H)
 #define REC_STAGE 64                   // records staged in LDS per round
-#define NB 1                           // partial paths whose records are fetched and accumulated together
+#define PBATCH (64 / STRIP_H)           // partial paths whose row headers and records are fetched in one round trip each
 
 template <bool SHADERS>
 __device__ __forceinline__ uint32_t blend_pixel_t(uint32_t dst, uint32_t a, uint32_t eflags, uint32_t solid, const swfr_style* __restrict__ styles,
@@ -959,13 +959,14 @@ __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_
                                               const DevBitmap* __restrict__ bitmaps, uint32_t* __restrict__ fb,
                                               int width, int height, int tiles_x, uint32_t band_index, uint32_t band_count, int dbg,
                                               uint32_t* __restrict__ counters, uint32_t n_rows_total, uint32_t n_rec_cap) {
-    __shared__ int acc[NB][STRIP_H][ACC_STRIDE];
+    __shared__ int acc[STRIP_H][ACC_STRIDE];
     __shared__ uint32_t px[STRIP_H][TILE_W];
+    __shared__ int plist[PBATCH];
     __shared__ uint32_t ent[TLIST][9];                    // BandEntry as 9 dwords
     __shared__ uint32_t cls[TLIST];
     __shared__ __attribute__((aligned(16))) uint32_t stage[REC_STAGE * 12];   // records as dwords
     __shared__ uint32_t rec_src[REC_STAGE];
-    __shared__ uint32_t row_off[NB * STRIP_H], row_start[NB * STRIP_H + 1];
+    __shared__ uint32_t row_off[64], row_start[64 + 1];   // per (batch path, strip row): first record, exclusive prefix of counts
     __shared__ uint8_t rec_row[REC_STAGE];
 
     const int lane = threadIdx.x;
@@ -982,7 +983,7 @@ __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_
     uint32_t dbg_pairs = 0, dbg_recs = 0;
 
     for (int rr = 0; rr < STRIP_H; ++rr) px[rr][lane] = 0u;
-    for (int i = lane; i < NB * STRIP_H * ACC_STRIDE; i += 64) (&acc[0][0][0])[i] = 0;
+    for (int i = lane; i < STRIP_H * ACC_STRIDE; i += 64) (&acc[0][0])[i] = 0;
 
     const uint32_t band_begin = band_off[trow], band_end = band_off[trow + 1];
     const uint32_t n_b = band_end - band_begin;
@@ -1035,12 +1036,11 @@ __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_
             atomicAdd(&counters[CNT_CULLED], (uint32_t)start);
         }
 
-        // ---- painter's order walk.  Partial tor paths are fetched + accumulated NB at a time (one round trip to
-        //      their row headers, one to their records), then consumed in order from their own accumulator.
-        int pend[NB];
-#pragma unroll
-        for (int j = 0; j < NB; ++j) pend[j] = -1;
-        int filled_to = start;
+        // ---- painter's order walk.  The row headers of up to PBATCH partial tor paths are fetched in one round trip and
+        //      their records form one sequence that is staged through LDS in windows of REC_STAGE (usually a single one);
+        //      each path is then accumulated and blended in order from the staged records.
+        int batch_n = 0, batch_i = 0;                          // paths in the batch, next one to consume
+        int total = 0, wbase = 0, wn = 0;                      // records of the batch; staged window [wbase, wbase + wn)
         for (int li = start; li < ln; ++li) {
             const uint32_t f = cls[li];                        // wave-uniform (LDS broadcast)
             const uint32_t xw = ent[li][1], yw = ent[li][2];
@@ -1068,30 +1068,26 @@ __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_
             } else if (f & CLS_PARTIAL) {
                 if (dbg == 3) continue;
                 // ---- tor (A.5)
-                int slot_j = -1;
-#pragma unroll
-                for (int j = 0; j < NB; ++j) if (pend[j] == li) slot_j = j;
-                if (slot_j < 0) {
-                    // the next NB partial tor paths of the list (this one included)
-                    int nc = 0;
-#pragma unroll
-                    for (int j = 0; j < NB; ++j) pend[j] = -1;
-                    for (int lj = max(li, filled_to); lj < ln && nc < NB; ++lj)
-                        if ((cls[lj] & (CLS_PARTIAL | CLS_BOX)) == CLS_PARTIAL) {
-#pragma unroll
-                            for (int j = 0; j < NB; ++j) if (j == nc) pend[j] = lj;
-                            ++nc;
-                            filled_to = lj + 1;
-                        }
-                    // row headers: lane = (path j, row); 16 consecutive RowInfo per path = one line each
-                    uint32_t my_cnt = 0;
-                    if (lane < NB * STRIP_H) {
-                        const int j = lane / STRIP_H, row = lane % STRIP_H;
-                        int mine = -1;
-#pragma unroll
-                        for (int jj = 0; jj < NB; ++jj) if (jj == j) mine = pend[jj];
-                        uint32_t off = 0;
-                        if (mine >= 0) {
+                if (batch_i == batch_n) {
+                    // the next PBATCH partial tor paths of the list, this one first (lane = list position)
+                    //   (same visibility test as the walk: entries that miss this strip's rows are skipped there)
+                    bool isp = lane >= li && lane < ln && (cls[lane] & (CLS_PARTIAL | CLS_BOX)) == CLS_PARTIAL;
+                    if (isp) {
+                        const uint32_t lyw = ent[lane][2];
+                        const int l_ymin = (int)(int16_t)(lyw & 0xffffu), l_ymax = (int)(int16_t)(lyw >> 16);
+                        isp = min(min(l_ymax, ty0 + STRIP_H), height) > max(l_ymin, ty0);
+                    }
+                    const unsigned long long pm = __ballot(isp);
+                    const int rank = __popcll(pm & ((1ull << lane) - 1ull));
+                    if (isp && rank < PBATCH) plist[rank] = lane;
+                    batch_n = min((int)__popcll(pm), PBATCH); batch_i = 0;
+                    __syncthreads();                                   // plist visible
+                    // row headers: lane = (path of the batch, row of the strip)
+                    uint32_t my_cnt = 0, off = 0;
+                    {
+                        const int bp = lane / STRIP_H, row = lane % STRIP_H;
+                        if (bp < batch_n) {
+                            const int mine = plist[bp];
                             const uint32_t myw = ent[mine][2];
                             const int p_ymin = (int)(int16_t)(myw & 0xffffu), p_ymax = (int)(int16_t)(myw >> 16);
                             const int y = ty0 + row;
@@ -1104,22 +1100,31 @@ __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_
                                 } else atomicOr(&counters[CNT_ERROR], 2u);  // defensive: never read outside the row table
                             }
                         }
-                        row_off[lane] = off;
                     }
-                    // exclusive prefix of the per-row record counts
-                    const int incl = wave_scan_incl((int)my_cnt);
-                    if (lane < NB * STRIP_H) row_start[lane] = (uint32_t)(incl - (int)my_cnt);
-                    int total = __shfl(incl, NB * STRIP_H - 1);        // lanes beyond contribute 0
-                    ++dbg_pairs; dbg_recs += (uint32_t)total;
+                    const int incl = wave_scan_incl((int)my_cnt);       // every lane active
+                    total = __shfl(incl, 63);
+                    row_off[lane] = off;
+                    row_start[lane] = (uint32_t)(incl - (int)my_cnt);
+                    row_start[64] = (uint32_t)total;                    // same value from every lane
+                    wbase = 0; wn = 0;
+                    dbg_recs += (uint32_t)total;
+                    if (dbg == 11) { row_start[lane] = 0; row_start[64] = 0; total = 0; }
                     __syncthreads();                                   // row_off / row_start visible to every lane
-                    if (dbg == 11) total = 0;
-                    const uint32_t* rdw = reinterpret_cast<const uint32_t*>(records);
-                    for (int base = 0; base < total; base += REC_STAGE) {
-                        const int n = min(REC_STAGE, total - base);
+                }
+                const int bp = batch_i++;
+                ++dbg_pairs;
+                TileCtx c; c.tx0 = tx0; c.xminp = e_xmin; c.xmaxp = e_xmax;
+                int g0 = (int)row_start[bp * STRIP_H];
+                const int g1 = (int)row_start[(bp + 1) * STRIP_H];      // this path's records [g0, g1) of the batch sequence
+                const uint32_t* rdw = reinterpret_cast<const uint32_t*>(records);
+                while (g0 < g1) {
+                    if (g0 >= wbase + wn) {
+                        // ---- stage the window that starts at this path's next record
+                        wbase = g0; wn = min(REC_STAGE, total - wbase);
                         // which (path, row) does each staged record belong to, and where does it live
-                        for (int t = lane; t < n; t += 64) {
-                            const uint32_t g = (uint32_t)(base + t);
-                            int lo = 0, hi = NB * STRIP_H;              // last virtual row with row_start <= g
+                        for (int t = lane; t < wn; t += 64) {
+                            const uint32_t g = (uint32_t)(wbase + t);
+                            int lo = 0, hi = 64;                        // last virtual row with row_start <= g
                             while (lo + 1 < hi) { const int mid = (lo + hi) >> 1; if (row_start[mid] <= g) lo = mid; else hi = mid; }
                             rec_row[t] = (uint8_t)lo;
                             uint32_t src = row_off[lo] + (g - row_start[lo]);
@@ -1127,48 +1132,43 @@ __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_
                             rec_src[t] = src;
                         }
                         __syncthreads();
-                        if (dbg == 12) continue;
                         // coalesced dword stream of the records into LDS, six independent loads in flight per lane
-                        for (int d0 = 0; d0 < n * 12; d0 += 64 * 6) {
+                        if (dbg != 12)
+                        for (int d0 = 0; d0 < wn * 12; d0 += 64 * 6) {
                             uint32_t tmp[6];
 #pragma unroll
                             for (int u = 0; u < 6; ++u) {
                                 const int d = d0 + u * 64 + lane;
                                 tmp[u] = 0u;
-                                if (d < n * 12) { const int t = d / 12, w = d - t * 12; tmp[u] = rdw[(size_t)rec_src[t] * 12 + w]; }
+                                if (d < wn * 12) { const int t = d / 12, w = d - t * 12; tmp[u] = rdw[(size_t)rec_src[t] * 12 + w]; }
                             }
 #pragma unroll
                             for (int u = 0; u < 6; ++u) {
                                 const int d = d0 + u * 64 + lane;
-                                if (d < n * 12) stage[d] = tmp[u];
+                                if (d < wn * 12) stage[d] = tmp[u];
                             }
                         }
                         __syncthreads();
-                        // lanes = records
-                        if (dbg != 5 && dbg != 13)
-                            for (int t = lane; t < n; t += 64) {
-                                const uint32_t* sw = &stage[t * 12];                 // dword reads only: no alignment assumption
-                                Rec rec;
-                                rec.roles = sw[0]; rec.cols = sw[1]; rec.q1 = (int32_t)sw[2]; rec.q2 = (int32_t)sw[3];
-                                rec.r1 = (int64_t)((uint64_t)sw[4] | ((uint64_t)sw[5] << 32));
-                                rec.r2 = (int64_t)((uint64_t)sw[6] | ((uint64_t)sw[7] << 32));
-                                rec.dy = (int64_t)((uint64_t)sw[8] | ((uint64_t)sw[9] << 32));
-                                rec.span = sw[10]; rec.eid = sw[11];
-                                const int vr = rec_row[t], j = vr / STRIP_H, r = vr % STRIP_H;
-                                int mine = 0;
-#pragma unroll
-                                for (int jj = 0; jj < NB; ++jj) if (jj == j) mine = pend[jj];
-                                const uint32_t mxw = ent[mine][1];
-                                TileCtx c; c.tx0 = tx0; c.xminp = (int)(int16_t)(mxw & 0xffffu); c.xmaxp = (int)(int16_t)(mxw >> 16);
-                                acc[j][r][ACC_TOUCH] = 1;
-                                accumulate_record(rec, sw, acc[j][r], c);
-                            }
-                        __syncthreads();                               // stage / rec_row may be rewritten; acc complete
                     }
-#pragma unroll
-                    for (int j = 0; j < NB; ++j) if (pend[j] == li) slot_j = j;
+                    const int hi_g = min(g1, wbase + wn);
+                    // lanes = this path's staged records
+                    if (dbg != 12 && dbg != 13)
+                        for (int t = g0 - wbase + lane; t < hi_g - wbase; t += 64) {
+                            const uint32_t* sw = &stage[t * 12];                 // dword reads only: no alignment assumption
+                            Rec rec;
+                            rec.roles = sw[0]; rec.cols = sw[1]; rec.q1 = (int32_t)sw[2]; rec.q2 = (int32_t)sw[3];
+                            rec.r1 = (int64_t)((uint64_t)sw[4] | ((uint64_t)sw[5] << 32));
+                            rec.r2 = (int64_t)((uint64_t)sw[6] | ((uint64_t)sw[7] << 32));
+                            rec.dy = (int64_t)((uint64_t)sw[8] | ((uint64_t)sw[9] << 32));
+                            rec.span = sw[10]; rec.eid = sw[11];
+                            const int r = rec_row[t] % STRIP_H;
+                            acc[r][ACC_TOUCH] = 1;
+                            accumulate_record(rec, sw, acc[r], c);
+                        }
+                    g0 = hi_g;
+                    __syncthreads();                                   // acc complete; the window may be restaged
                 }
-                int (*A)[ACC_STRIDE] = acc[slot_j];
+                int (*A)[ACC_STRIDE] = acc;
                 // ---- prefix sum, alpha, blend; clears as it reads.  Four rows per step so their LDS round trips overlap
 #pragma unroll 1
                 for (int r4 = row_lo; r4 < row_hi; r4 += 4) {
@@ -1199,8 +1199,6 @@ __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_
                         if (a) px[rr][lane] = blend_pixel(old_px[u], a, eflags, solid, styles, style, bitmaps, cx, ty0 + rr);
                     }
                 }
-#pragma unroll
-                for (int j = 0; j < NB; ++j) if (j == slot_j) pend[j] = -1;
                 __syncthreads();                                   // acc cleared before the next path accumulates
             } else {
                 // full cover: every in-frame pixel of the tile has coverage 255
