@@ -8,7 +8,9 @@
 namespace swfr {
 
 constexpr int TILE_W = 64;   // one wavefront lane per pixel column
-constexpr int TILE_H = 16;   // 4 waves x 4 rows
+constexpr int TILE_H = 16;   // tile-rows ("bands") are the unit of band lists and of multi-GPU sharding
+constexpr int STRIP_H = 8;   // pixel rows per k_tiles wavefront: a 64x16 tile is rasterized as two independent 64x8 strips
+constexpr int STRIPS_PER_TILE = TILE_H / STRIP_H;
 
 // Per-edge constants of the tor scan converter (SURVEY.md A.5 make_edge), 64 bytes.
 struct DevEdge {

@@ -895,10 +895,8 @@ __global__ __launch_bounds__(64) void k_class(const BandEntry* __restrict__ band
     }
 }
 
-#define TLIST 64                       // tile list entries per round
-#define STRIP_H 8                      // pixel rows per wavefront: a 64x16 tile is rasterized as four independent 64x4 strips
-#define STRIPS_PER_TILE (TILE_H / STRIP_H)
-#define REC_STAGE 64                   // records staged in LDS per round
+#define TLIST 32                       // tile list entries per round
+#define REC_STAGE 32                   // records staged in LDS per round
 #define PBATCH (64 / STRIP_H)           // partial paths whose row headers and records are fetched in one round trip each
 
 template <bool SHADERS>
@@ -958,7 +956,8 @@ __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_
                                               const Rec* __restrict__ records, const swfr_style* __restrict__ styles,
                                               const DevBitmap* __restrict__ bitmaps, uint32_t* __restrict__ fb,
                                               int width, int height, int tiles_x, uint32_t band_index, uint32_t band_count, int dbg,
-                                              uint32_t* __restrict__ counters, uint32_t n_rows_total, uint32_t n_rec_cap) {
+                                              uint32_t* __restrict__ counters, uint32_t n_rows_total, uint32_t n_rec_cap,
+                                              const uint32_t* __restrict__ order) {
     __shared__ int acc[STRIP_H][ACC_STRIDE];
     __shared__ uint32_t px[STRIP_H][TILE_W];
     __shared__ int plist[PBATCH];
@@ -972,7 +971,10 @@ __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_
     const int lane = threadIdx.x;
     // blockIdx -> tile: consecutive workgroups walk along x inside one tile-row, so the 8 tiles that are
     // co-scheduled round-robin over the 8 XCDs read the same band entries / path records
-    const int tile = blockIdx.x / STRIPS_PER_TILE, strip = blockIdx.x % STRIPS_PER_TILE;
+    // (`order`, when given, is the host's launch order: strips with the most edges first, so that the heaviest
+    //  wavefronts do not start last)
+    const uint32_t wg = order ? order[blockIdx.x] : blockIdx.x;
+    const int tile = (int)(wg / STRIPS_PER_TILE), strip = (int)(wg % STRIPS_PER_TILE);
     const int tcol = tile % tiles_x;
     int trow = tile / tiles_x;
     if (band_count > 1) trow = trow * (int)band_count + (int)band_index;
@@ -1282,17 +1284,17 @@ void launch_class(hipStream_t st, const BandEntry* band_list, uint32_t n_entries
 void launch_tiles(hipStream_t st, const swfr_edge* raw, const uint32_t* band_off, const BandEntry* band_list, const uint8_t* cls_mat,
                   const RowInfo* rows, const Rec* records, const swfr_style* styles, const DevBitmap* bitmaps, uint32_t* fb, int width, int height,
                   uint32_t band_index, uint32_t band_count, int dbg, uint32_t* counters, uint32_t n_rows_total, uint32_t n_rec_cap,
-                  bool any_shader) {
+                  bool any_shader, const uint32_t* order) {
     const int tiles_x = (width + TILE_W - 1) / TILE_W, tile_rows = (height + TILE_H - 1) / TILE_H;
     uint32_t local_rows = tile_rows;
     if (band_count > 1) local_rows = (tile_rows > (int)band_index) ? (tile_rows - band_index + band_count - 1) / band_count : 0;
     if (!local_rows) return;
     if (any_shader)
         hipLaunchKernelGGL(k_tiles<true>, dim3(tiles_x * local_rows * STRIPS_PER_TILE), dim3(64), 0, st, raw, band_off, band_list, cls_mat, rows,
-                           records, styles, bitmaps, fb, width, height, tiles_x, band_index, band_count, dbg, counters, n_rows_total, n_rec_cap);
+                           records, styles, bitmaps, fb, width, height, tiles_x, band_index, band_count, dbg, counters, n_rows_total, n_rec_cap, order);
     else
         hipLaunchKernelGGL(k_tiles<false>, dim3(tiles_x * local_rows * STRIPS_PER_TILE), dim3(64), 0, st, raw, band_off, band_list, cls_mat, rows,
-                           records, styles, bitmaps, fb, width, height, tiles_x, band_index, band_count, dbg, counters, n_rows_total, n_rec_cap);
+                           records, styles, bitmaps, fb, width, height, tiles_x, band_index, band_count, dbg, counters, n_rows_total, n_rec_cap, order);
 }
 void launch_unpremultiply(hipStream_t st, const uint32_t* in, uint32_t* out, size_t n) {
     if (!n) return;

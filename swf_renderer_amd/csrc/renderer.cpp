@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -28,7 +29,7 @@ void launch_class(hipStream_t, const BandEntry*, uint32_t, const uint32_t*, uint
 void launch_rows(hipStream_t, const DevEdge*, const DevPath*, const uint32_t*, const ChunkInfo*, uint32_t, RowInfo*, Rec*, uint32_t*, const BigRow*,
                  uint32_t, uint32_t, uint32_t, uint32_t, int, int);
 void launch_tiles(hipStream_t, const swfr_edge*, const uint32_t*, const BandEntry*, const uint8_t*, const RowInfo*, const Rec*, const swfr_style*,
-                  const DevBitmap*, uint32_t*, int, int, uint32_t, uint32_t, int, uint32_t*, uint32_t, uint32_t, bool);
+                  const DevBitmap*, uint32_t*, int, int, uint32_t, uint32_t, int, uint32_t*, uint32_t, uint32_t, bool, const uint32_t*);
 void launch_unpremultiply(hipStream_t, const uint32_t*, uint32_t*, size_t);
 void launch_pack_band(hipStream_t, const uint32_t*, uint32_t*, int, int, uint32_t, uint32_t, uint32_t);
 }  // namespace swfr
@@ -91,7 +92,7 @@ struct swfr_renderer {
     DevBuf<DevEdge> d_edges;
     DevBuf<DevPath> d_paths;
     DevBuf<swfr_style> d_styles;
-    DevBuf<uint32_t> d_row_base, d_band_off;
+    DevBuf<uint32_t> d_row_base, d_band_off, d_order;
     DevBuf<BigRow> d_big_rows;
     DevBuf<ChunkInfo> d_chunk_base;
     DevBuf<BandEntry> d_band_list;
@@ -109,6 +110,8 @@ struct swfr_renderer {
     size_t n_edges = 0, n_paths = 0, n_styles = 0, n_tasks = 0, n_chunks = 0, n_bands = 0, rec_cap = 0, rec_main = 0, n_big = 0;
     bool scene_ready = false, fb_valid = false, any_shader = false;
     swfr_timing timing{};
+    int strip_order = 1;                    // SWFR_STRIP_ORDER=0: launch the k_tiles wavefronts in row-major order
+    bool has_order = false;
     int event_stride = 8;                   // SWFR_EVENT_STRIDE: per-kernel HIP events on every n-th resident frame
     int tiles_dbg = 0;                      // SWFR_TILES_DEBUG: timing-only ablations of k_tiles (wrong pixels)
     int cell_mode = 3;                      // SWFR_CELL_MODE: 1 = FULL rows as precomputed cells, 2 = SUB rows (test knob)
@@ -118,7 +121,7 @@ struct swfr_renderer {
         if (has_device) {
             (void)hipSetDevice(cfg.device);
             d_raw.release(); d_edges.release(); d_paths.release(); d_styles.release(); d_row_base.release();
-            d_rows.release(); d_records.release(); d_chunk_base.release(); d_band_off.release(); d_band_list.release(); d_big_rows.release(); d_cls.release(); d_counters.release(); d_bitmap_table.release(); d_fb.release(); d_tmp.release();
+            d_rows.release(); d_records.release(); d_chunk_base.release(); d_band_off.release(); d_band_list.release(); d_big_rows.release(); d_order.release(); d_cls.release(); d_counters.release(); d_bitmap_table.release(); d_fb.release(); d_tmp.release();
             for (auto& kv : bitmaps) if (kv.second.pixels) (void)hipFree(kv.second.pixels);
             for (auto& e : ev) if (e) (void)hipEventDestroy(e);
             if (stream) (void)hipStreamDestroy(stream);
@@ -232,6 +235,44 @@ int upload(swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_
         }
     }
     for (size_t b = 0; b < n_bands; ++b) band_off[b + 1] += band_off[b];   // exact sizes; k_bands fills the lists in order
+    // ---- launch order of the k_tiles wavefronts: strips crossed by many edges first (a scheduling hint from edge
+    //      end points only: x of the edge at the strip's top and bottom by linear interpolation, one column of slack)
+    std::vector<uint32_t> order;
+    if (r->strip_order) {
+        const uint32_t tiles_x = (r->width + TILE_W - 1) / TILE_W, n_local = local_tile_rows(r);
+        const uint32_t strip_rows = uint32_t(n_bands) * STRIPS_PER_TILE;
+        std::vector<uint32_t> cost(size_t(strip_rows) * tiles_x, 0);
+        for (size_t i = 0; i < n_paths; ++i) {
+            const swfr_path& p = paths[i];
+            if (p.kind != SWFR_PATH_TOR) continue;
+            for (uint32_t k = 0; k < p.n_edges; ++k) {
+                const swfr_edge& e = edges[p.first_edge + k];
+                const int64_t top = std::max<int64_t>(e.top, int64_t(p.y_min) * 256), bot = std::min<int64_t>(e.bottom, int64_t(p.y_max) * 256);
+                if (bot <= top || e.y2 == e.y1) continue;
+                const double slope = double(e.x2 - e.x1) / double(e.y2 - e.y1);
+                for (int64_t sr = (top >> 8) / STRIP_H; sr <= ((bot - 1) >> 8) / STRIP_H && sr < int64_t(strip_rows); ++sr) {
+                    const int64_t ya = std::max<int64_t>(top, sr * STRIP_H * 256), yb = std::min<int64_t>(bot, (sr + 1) * STRIP_H * 256);
+                    const double xa = e.x1 + slope * double(ya - e.y1), xb = e.x1 + slope * double(yb - e.y1);
+                    int64_t ca = int64_t(std::floor(std::min(xa, xb) / 256.0)) - 1, cb = int64_t(std::floor(std::max(xa, xb) / 256.0)) + 1;
+                    ca = std::max<int64_t>(ca, p.x_min); cb = std::min<int64_t>(cb, int64_t(p.x_max) - 1);
+                    const uint32_t w = uint32_t((yb - ya + 255) >> 8);
+                    for (int64_t tc = ca / TILE_W; tc <= cb / TILE_W && tc < int64_t(tiles_x); ++tc) cost[size_t(sr) * tiles_x + size_t(tc)] += w;
+                }
+            }
+        }
+        constexpr uint32_t NBUCKET = 32;
+        std::vector<uint32_t> bucket_n(NBUCKET + 1, 0);
+        auto bucket_of = [&](uint32_t c) { return NBUCKET - 1 - std::min<uint32_t>(c / 8, NBUCKET - 1); };   // bucket 0 = heaviest
+        const uint32_t n_wg = n_local * tiles_x * STRIPS_PER_TILE;
+        auto cost_of = [&](uint32_t wg) {
+            const uint32_t tile = wg / STRIPS_PER_TILE, strip = wg % STRIPS_PER_TILE, tcol = tile % tiles_x, trow = (tile / tiles_x) * bc + bi;
+            return cost[size_t(trow * STRIPS_PER_TILE + strip) * tiles_x + tcol];
+        };
+        for (uint32_t wg = 0; wg < n_wg; ++wg) ++bucket_n[bucket_of(cost_of(wg)) + 1];
+        for (uint32_t b = 0; b < NBUCKET; ++b) bucket_n[b + 1] += bucket_n[b];
+        order.resize(n_wg);
+        for (uint32_t wg = 0; wg < n_wg; ++wg) order[bucket_n[bucket_of(cost_of(wg))]++] = wg;   // row-major inside a bucket
+    }
     r->n_edges = n_edges; r->n_paths = n_paths; r->n_styles = n_styles;
     r->any_shader = false;
     for (size_t i = 0; i < n_styles; ++i) r->any_shader = r->any_shader || styles[i].kind != SWFR_STYLE_SOLID;
@@ -255,6 +296,10 @@ int upload(swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_
     if (n_paths) HIP_CHECK(hipMemcpyAsync(r->d_paths.ptr, paths, n_paths * sizeof(swfr_path), hipMemcpyHostToDevice, r->stream));
     if (n_styles) HIP_CHECK(hipMemcpyAsync(r->d_styles.ptr, styles, n_styles * sizeof(swfr_style), hipMemcpyHostToDevice, r->stream));
     HIP_CHECK(hipMemcpyAsync(r->d_row_base.ptr, row_base.data(), (n_paths + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, r->stream));
+    r->d_order.reserve(order.size());
+    r->has_order = !order.empty();
+    if (!order.empty())
+        HIP_CHECK(hipMemcpyAsync(r->d_order.ptr, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice, r->stream));
     if (!big_rows.empty())
         HIP_CHECK(hipMemcpyAsync(r->d_big_rows.ptr, big_rows.data(), big_rows.size() * sizeof(BigRow), hipMemcpyHostToDevice, r->stream));
     if (!chunks.empty())
@@ -307,7 +352,8 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
         }
         if (timed) HIP_CHECK(hipEventRecord(e[2], r->stream));
         launch_tiles(r->stream, r->d_raw.ptr, r->d_band_off.ptr, r->d_band_list.ptr, r->d_cls.ptr, r->d_rows.ptr, r->d_records.ptr, r->d_styles.ptr,
-                     r->d_bitmap_table.ptr, r->d_fb.ptr, int(r->width), int(r->height), bi, bc, r->tiles_dbg, r->d_counters.ptr, uint32_t(r->n_tasks), uint32_t(r->rec_cap), r->any_shader);
+                     r->d_bitmap_table.ptr, r->d_fb.ptr, int(r->width), int(r->height), bi, bc, r->tiles_dbg, r->d_counters.ptr, uint32_t(r->n_tasks), uint32_t(r->rec_cap), r->any_shader,
+                     r->has_order ? r->d_order.ptr : nullptr);
         if (timed) HIP_CHECK(hipEventRecord(e[3], r->stream));
     }
     HIP_CHECK(hipEventRecord(ev_end, r->stream));
@@ -368,6 +414,7 @@ int swfr_create(uint32_t width, uint32_t height, const swfr_config* cfg, swfr_re
     r->builder.reset(new FrameBuilder(width, height, (r->cfg.flags & SWFR_FLAG_EVEN_ODD) != 0));
     if (const char* fl = std::getenv("SWFR_FAST_LIMIT")) r->fast_limit = std::atoi(fl);
     if (const char* td = std::getenv("SWFR_TILES_DEBUG")) r->tiles_dbg = std::atoi(td);
+    if (const char* so = std::getenv("SWFR_STRIP_ORDER")) r->strip_order = std::atoi(so);
     if (const char* es = std::getenv("SWFR_EVENT_STRIDE")) r->event_stride = std::atoi(es);
     if (const char* cm = std::getenv("SWFR_CELL_MODE")) r->cell_mode = std::atoi(cm);
     if (r->cfg.device == SWFR_DEVICE_HOST_ONLY) {
