@@ -983,6 +983,14 @@ __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_
     const int cx = tx0 + lane;
     const unsigned long long t_start = dbg == 8 ? __builtin_amdgcn_s_memtime() : 0ull;
     uint32_t dbg_pairs = 0, dbg_recs = 0;
+#ifdef SWFR_PHASES                         // build with -DSWFR_PHASES for tools/strip_times.py: clocks per phase (costs VGPRs)
+    const unsigned long long w_start = __builtin_amdgcn_s_memrealtime();
+    uint32_t ph_bin = 0, ph_batch = 0, ph_stage = 0, ph_acc = 0, ph_p2 = 0;
+    unsigned long long ph_t = t_start;
+#define PHASE(var) do { if (dbg == 8) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); var += (uint32_t)(now_ - ph_t); ph_t = now_; } } while (0)
+#else
+#define PHASE(var) do { } while (0)
+#endif
 
     for (int rr = 0; rr < STRIP_H; ++rr) px[rr][lane] = 0u;
     for (int i = lane; i < STRIP_H * ACC_STRIDE; i += 64) (&acc[0][0])[i] = 0;
@@ -1031,6 +1039,7 @@ __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_
             if (b) start = 63 - __clzll((long long)b);
         }
         if (dbg == 2) start = ln;
+        PHASE(ph_bin);
         if (dbg == 9 && lane == 0) {                          // statistics (SWFR_TILES_DEBUG=9)
             uint32_t np = 0, nf = 0;
             for (int li = start; li < ln; ++li) { const uint32_t f = cls[li]; if (f & (CLS_PARTIAL | CLS_BOX)) ++np; else ++nf; }
@@ -1070,6 +1079,7 @@ __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_
             } else if (f & CLS_PARTIAL) {
                 if (dbg == 3) continue;
                 // ---- tor (A.5)
+                PHASE(ph_bin);
                 if (batch_i == batch_n) {
                     // the next PBATCH partial tor paths of the list, this one first (lane = list position)
                     //   (same visibility test as the walk: entries that miss this strip's rows are skipped there)
@@ -1112,6 +1122,7 @@ __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_
                     dbg_recs += (uint32_t)total;
                     if (dbg == 11) { row_start[lane] = 0; row_start[64] = 0; total = 0; }
                     __syncthreads();                                   // row_off / row_start visible to every lane
+                    PHASE(ph_batch);
                 }
                 const int bp = batch_i++;
                 ++dbg_pairs;
@@ -1151,6 +1162,7 @@ __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_
                             }
                         }
                         __syncthreads();
+                        PHASE(ph_stage);
                     }
                     const int hi_g = min(g1, wbase + wn);
                     // lanes = this path's staged records
@@ -1169,6 +1181,7 @@ __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_
                         }
                     g0 = hi_g;
                     __syncthreads();                                   // acc complete; the window may be restaged
+                    PHASE(ph_acc);
                 }
                 int (*A)[ACC_STRIDE] = acc;
                 // ---- prefix sum, alpha, blend; clears as it reads.  Four rows per step so their LDS round trips overlap
@@ -1202,6 +1215,7 @@ __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_
                     }
                 }
                 __syncthreads();                                   // acc cleared before the next path accumulates
+                PHASE(ph_p2);
             } else {
                 // full cover: every in-frame pixel of the tile has coverage 255
 #pragma unroll 1
@@ -1210,7 +1224,13 @@ __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_
         }
     }
 
-    if (dbg == 8 && lane == 0) { px[0][0] = (uint32_t)(__builtin_amdgcn_s_memtime() - t_start); px[0][1] = dbg_pairs; px[0][2] = dbg_recs; }   // diagnostics
+    if (dbg == 8 && lane == 0) {                              // diagnostics (tools/strip_times.py)
+        px[0][0] = (uint32_t)(__builtin_amdgcn_s_memtime() - t_start); px[0][1] = dbg_pairs; px[0][2] = dbg_recs;
+#ifdef SWFR_PHASES
+        px[0][3] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - w_start); px[0][4] = (uint32_t)w_start; px[0][5] = (uint32_t)(w_start >> 32);
+        px[0][8] = ph_bin; px[0][9] = ph_batch; px[0][10] = ph_stage; px[0][11] = ph_acc; px[0][12] = ph_p2;
+#endif
+    }
     // ---- one store per pixel: premultiplied R,G,B,A bytes; the wave writes 256 contiguous bytes per row
     if (cx < width) {
         for (int rr = 0; rr < STRIP_H; ++rr) {
@@ -1224,6 +1244,7 @@ __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_
 }
 
 #undef blend_pixel
+#undef PHASE
 
 // ---------------------------------------------------------------------------------------------
 // auxiliary kernels

@@ -260,9 +260,9 @@ int upload(swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_
                 }
             }
         }
-        constexpr uint32_t NBUCKET = 32;
+        constexpr uint32_t NBUCKET = 128;
         std::vector<uint32_t> bucket_n(NBUCKET + 1, 0);
-        auto bucket_of = [&](uint32_t c) { return NBUCKET - 1 - std::min<uint32_t>(c / 8, NBUCKET - 1); };   // bucket 0 = heaviest
+        auto bucket_of = [&](uint32_t c) { return NBUCKET - 1 - std::min<uint32_t>(c / 2, NBUCKET - 1); };   // bucket 0 = heaviest
         const uint32_t n_wg = n_local * tiles_x * STRIPS_PER_TILE;
         auto cost_of = [&](uint32_t wg) {
             const uint32_t tile = wg / STRIPS_PER_TILE, strip = wg % STRIPS_PER_TILE, tcol = tile % tiles_x, trow = (tile / tiles_x) * bc + bi;
