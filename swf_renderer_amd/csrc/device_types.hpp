@@ -20,7 +20,7 @@ struct DevEdge {
     int64_t ex;              // (x2 - x1) * 256
     int64_t dy;              // (y2 - y1) * 15 * 512, 0 for vertical edges
     int64_t dq, dr;          // per-sub-row slope: truncated quotient / remainder of ex*512 / dy
-    int64_t pad2;
+    double inv_dy;           // 1.0 / dy (correctly rounded): quotient estimates need one multiply, the integer fix-up makes them exact
 };
 static_assert(sizeof(DevEdge) == 64, "DevEdge layout");
 

@@ -36,6 +36,13 @@ __device__ __forceinline__ void floor_div(int64_t a, int64_t b, int64_t& q, int6
     while (r < 0) { --q; r += b; }
     while (r >= b) { ++q; r -= b; }
 }
+// Same with a precomputed reciprocal of b (|a / b| < 2^31, so the estimate is off by at most one before the fix-up).
+__device__ __forceinline__ void floor_div_inv(int64_t a, int64_t b, double inv_b, int64_t& q, int64_t& r) {
+    q = (int64_t)(int32_t)floor((double)a * inv_b);
+    r = a - q * b;
+    while (r < 0) { --q; r += b; }
+    while (r >= b) { ++q; r -= b; }
+}
 // C (truncating) division, b > 0.
 __device__ __forceinline__ void trunc_div(int64_t a, int64_t b, int64_t& q, int64_t& r) {
     floor_div(a, b, q, r);
@@ -46,7 +53,7 @@ __device__ __forceinline__ void edge_x_at(const DevEdge& e, int s, int32_t& quo,
     if (e.dy == 0) { quo = e.x1; rem = 0; return; }
     const int64_t a = ((int64_t)(2 * s + 1) << 8) - 30 * (int64_t)e.y1;
     int64_t q, r;
-    floor_div(a * e.ex, e.dy, q, r);
+    floor_div_inv(a * e.ex, e.dy, e.inv_dy, q, r);
     quo = e.x1 + (int32_t)q;
     rem = r;
 }
@@ -90,10 +97,9 @@ __device__ __forceinline__ Rec make_record(const DevEdge& e, uint32_t eid, int s
 __device__ __forceinline__ uint32_t pack_cell(int col_rel, int ch, int ua) {
     return (uint32_t)(col_rel & 255) | ((uint32_t)(ch & 255) << 8) | ((uint32_t)(ua & 0xffff) << 16);
 }
-// Cells of a FULL-row edge (A.5 render_edge) as a cell record; false when the edge spans more than REC_MAX_CELLS columns
-__device__ __forceinline__ bool full_cells(const DevEdge& e, int s0, int sign, Rec& rc) {
-    int32_t q1, q2; int64_t r1, r2;
-    full_row_ends(e, s0, q1, r1, q2, r2);
+// Cells of a FULL-row edge (A.5 render_edge) as a cell record, from the edge's exact x at the row top (q1 + r1/dy) and
+// bottom (q2 + r2/dy); false when the edge spans more than REC_MAX_CELLS columns
+__device__ __forceinline__ bool full_cells_ends(int32_t q1, int64_t r1, int32_t q2, int64_t r2, int64_t edy, int sign, Rec& rc) {
     int ix1 = q1 >> 8, f1 = q1 & 255, ix2 = q2 >> 8, f2 = q2 & 255;
     uint32_t* cells = reinterpret_cast<uint32_t*>(&rc.q1);
     if (ix2 < ix1) { int t = ix1; ix1 = ix2; ix2 = t; t = f1; f1 = f2; f2 = t; int32_t tq = q1; q1 = q2; q2 = tq; int64_t tr = r1; r1 = r2; r2 = tr; }
@@ -102,9 +108,9 @@ __device__ __forceinline__ bool full_cells(const DevEdge& e, int s0, int sign, R
     rc.cols = clamp_col(ix1) | (clamp_col(ix2) << 16);
     rc.roles = REC_CELLS | (uint32_t)n | ((uint32_t)((sign * 15) & 255) << 8);
     if (n == 1) { cells[0] = pack_cell(0, sign * 15, sign * (f1 + f2) * 15); return true; }
-    const int64_t dx = (int64_t)(q2 - q1) * e.dy + (r2 - r1);
-    const int64_t t0 = ((int64_t)((ix1 + 1) * 256 - q1) * e.dy - r1) * 15;
-    const int64_t F = 15ll * 256 * e.dy;
+    const int64_t dx = (int64_t)(q2 - q1) * edy + (r2 - r1);
+    const int64_t t0 = ((int64_t)((ix1 + 1) * 256 - q1) * edy - r1) * 15;
+    const int64_t F = 15ll * 256 * edy;
     int64_t yq, yr, fq = 0, fr = 0;
     floor_div(t0, dx, yq, yr);
     if (n > 2) floor_div(F, dx, fq, fr);
@@ -118,6 +124,11 @@ __device__ __forceinline__ bool full_cells(const DevEdge& e, int s0, int sign, R
     }
     cells[n - 1] = pack_cell(n - 1, sign * (15 - y_prev), sign * (15 - y_prev) * f2);
     return true;
+}
+__device__ __forceinline__ bool full_cells(const DevEdge& e, int s0, int sign, Rec& rc) {
+    int32_t q1, q2; int64_t r1, r2;
+    full_row_ends(e, s0, q1, r1, q2, r2);
+    return full_cells_ends(q1, r1, q2, r2, e.dy, sign, rc);
 }
 
 // wave64 inclusive prefix sum with DPP row shifts + row broadcasts (no LDS traffic)
@@ -141,7 +152,7 @@ __device__ __forceinline__ void setup_block(uint32_t block, const swfr_edge* __r
     const swfr_edge e = in[i];
     const DevPath p = paths[e.reserved];
     DevEdge d;
-    d.x1 = e.x1; d.y1 = e.y1; d.dir = e.dir; d.pad = 0; d.pad2 = 0;
+    d.x1 = e.x1; d.y1 = e.y1; d.dir = e.dir; d.pad = 0; d.inv_dy = 0.0;
     if (p.kind != SWFR_PATH_TOR) {          // boxes are consumed raw by k_tiles
         d.ytop = d.ybot = 0; d.dy = 0; d.ex = 0; d.dq = d.dr = 0;
         out[i] = d;
@@ -157,6 +168,7 @@ __device__ __forceinline__ void setup_block(uint32_t block, const swfr_edge* __r
     } else {
         d.ex = (int64_t)(e.x2 - e.x1) * 256;
         d.dy = (int64_t)(e.y2 - e.y1) * 15 * 512;
+        d.inv_dy = 1.0 / (double)d.dy;
         trunc_div(d.ex * 512, d.dy, d.dq, d.dr);
     }
     out[i] = d;
@@ -401,35 +413,54 @@ struct FastLds {
 template <class EPTR>
 __device__ __forceinline__ void fast_rows(EPTR E, const DevPath& P, int r, bool live, int fast_limit, FastLds& F, int lane,
                                           uint32_t& mode_out, int& n_out_edges, bool& overflow_out,
-                                          int32_t (&roles)[ROWS_FAST_N], int32_t (&cols)[ROWS_FAST_N], int (&el)[ROWS_FAST_N]) {
+                                          int32_t (&roles)[ROWS_FAST_N], int32_t (&cols)[ROWS_FAST_N], int (&el)[ROWS_FAST_N],
+                                          int32_t (&Q1)[ROWS_FAST_N], int64_t (&R1)[ROWS_FAST_N], int32_t (&Q2)[ROWS_FAST_N], int64_t (&R2)[ROWS_FAST_N]) {
     const int s0 = r * 15;
     const unsigned mask = P.fill_rule ? 1u : ~0u;
     int n = 0;
     bool mid_row = false, overflow = false;
     int cs[ROWS_FAST_N], ce[ROWS_FAST_N], cp[ROWS_FAST_N], dr[ROWS_FAST_N], nw[ROWS_FAST_N];
 #pragma unroll
-    for (int s = 0; s < ROWS_FAST_N; ++s) { cs[s] = ce[s] = cp[s] = dr[s] = nw[s] = 0; el[s] = 0; roles[s] = 0; cols[s] = 0; }
+    for (int s = 0; s < ROWS_FAST_N; ++s) { cs[s] = ce[s] = cp[s] = dr[s] = nw[s] = 0; el[s] = 0; roles[s] = 0; cols[s] = 0; Q1[s] = Q2[s] = 0; R1[s] = R2[s] = 0; }
+    // ---- gather: which edges are active in this row (sample rows [ytop, ybot) against the row's fifteen); no arithmetic yet
     if (live) {
         for (uint32_t k = 0; k < P.n_edges; ++k) {
             const int ytop = E[k].ytop, ybot = E[k].ybot;
             if (ybot <= s0 || ytop >= s0 + 15) continue;
             if (n >= fast_limit) { overflow = true; break; }
             mid_row |= (ytop > s0) | (ybot < s0 + 15);
-            const DevEdge e = E[k];
-            int32_t q; int64_t rm;
-            int c0 = e.x1, c1 = e.x1, cpv = e.x1;
-            if (e.dy && !mid_row) {                       // keys are only needed while the row can still be FULL
-                edge_x_at(e, s0, q, rm);
-                c0 = cell_of(q, rm, e.dy);
-                int32_t q2; int64_t r2;
-                edge_x_at(e, s0 + 15, q2, r2);
-                c1 = cell_of(q2, r2, e.dy);
-                cpv = c0;
-                if (e.ytop < s0) { q -= (int32_t)e.dq; rm -= e.dr; if (rm < 0) { --q; rm += e.dy; } else if (rm >= e.dy) { ++q; rm -= e.dy; } cpv = cell_of(q, rm, e.dy); }
-            }
 #pragma unroll
-            for (int s = 0; s < ROWS_FAST_N; ++s) if (s == n) { el[s] = (int)k; cs[s] = c0; ce[s] = c1; cp[s] = cpv; dr[s] = e.dir; nw[s] = (e.ytop == s0) ? 1 : 0; }
+            for (int s = 0; s < ROWS_FAST_N; ++s) if (s == n) el[s] = (int)k;
             ++n;
+        }
+    }
+    if (overflow) n = 0;
+    // ---- rows that can still be FULL: x of every active edge at the first sample row of this pixel row and of the next
+    //      (one reciprocal multiply + integer fix-up each); kept as the exact row-top / row-bottom end points for the records
+    if (n > 0 && !mid_row) {
+#pragma unroll
+        for (int s = 0; s < ROWS_FAST_N; ++s) {
+            if (s >= n) continue;
+            const DevEdge e = E[el[s]];
+            int32_t qa = e.x1, qb = e.x1; int64_t ra = 0, rb = 0;
+            int c0 = e.x1, c1 = e.x1, cpv = e.x1;
+            if (e.dy) {
+                edge_x_at(e, s0, qa, ra);
+                edge_x_at(e, s0 + 15, qb, rb);
+                c0 = cell_of(qa, ra, e.dy);
+                c1 = cell_of(qb, rb, e.dy);
+                cpv = c0;
+                if (e.ytop < s0) {                        // cell one sample row earlier (tie-break of the sorted list)
+                    int32_t q = qa - (int32_t)e.dq; int64_t rm = ra - e.dr;
+                    if (rm < 0) { --q; rm += e.dy; } else if (rm >= e.dy) { ++q; rm -= e.dy; }
+                    cpv = cell_of(q, rm, e.dy);
+                }
+                const int32_t hq = (int32_t)(e.dq / 2); const int64_t hr = e.dr / 2;   // half a sample row back: row top / bottom
+                qa -= hq; ra -= hr; if (ra < 0) { --qa; ra += e.dy; } else if (ra >= e.dy) { ++qa; ra -= e.dy; }
+                qb -= hq; rb -= hr; if (rb < 0) { --qb; rb += e.dy; } else if (rb >= e.dy) { ++qb; rb -= e.dy; }
+            }
+            cs[s] = c0; ce[s] = c1; cp[s] = cpv; dr[s] = e.dir; nw[s] = (e.ytop == s0) ? 1 : 0;
+            Q1[s] = qa; R1[s] = ra; Q2[s] = qb; R2[s] = rb;
         }
     }
     if (overflow) n = 0;
@@ -470,10 +501,7 @@ __device__ __forceinline__ void fast_rows(EPTR E, const DevPath& P, int r, bool 
                 if (!in_b && ((firstg >> j) & 1u)) role = REC_FULL | 1u;          // left edge of a span
                 else if (!in_a && ((lastg >> j) & 1u)) role = REC_FULL | 2u;      // right edge
                 if (role) {
-                    const DevEdge e = E[el[j]];
-                    int32_t q1, q2; int64_t r1, r2;
-                    full_row_ends(e, s0, q1, r1, q2, r2);
-                    const int a = q1 >> 8, b = q2 >> 8;
+                    const int a = Q1[j] >> 8, b = Q2[j] >> 8;
                     cols[j] = (int32_t)(clamp_col(min(a, b)) | (clamp_col(max(a, b)) << 16));
                 }
                 roles[j] = (int32_t)role;
@@ -572,8 +600,9 @@ __global__ __launch_bounds__(64) void k_rows(const DevEdge* __restrict__ edges, 
     }
     uint32_t mode; int n; bool overflow;
     int32_t roles[ROWS_FAST_N], cols[ROWS_FAST_N]; int el[ROWS_FAST_N];
-    if (use_lds) fast_rows((const DevEdge*)staged, P, r, live, fast_limit, F, lane, mode, n, overflow, roles, cols, el);
-    else fast_rows(edges + P.first_edge, P, r, live, fast_limit, F, lane, mode, n, overflow, roles, cols, el);
+    int32_t Q1[ROWS_FAST_N], Q2[ROWS_FAST_N]; int64_t R1[ROWS_FAST_N], R2[ROWS_FAST_N];
+    if (use_lds) fast_rows((const DevEdge*)staged, P, r, live, fast_limit, F, lane, mode, n, overflow, roles, cols, el, Q1, R1, Q2, R2);
+    else fast_rows(edges + P.first_edge, P, r, live, fast_limit, F, lane, mode, n, overflow, roles, cols, el, Q1, R1, Q2, R2);
     uint32_t n_out = 0;
 #pragma unroll
     for (int s = 0; s < ROWS_FAST_N; ++s) n_out += (s < n && roles[s] != 0) ? 1u : 0u;
@@ -587,13 +616,19 @@ __global__ __launch_bounds__(64) void k_rows(const DevEdge* __restrict__ edges, 
 #pragma unroll
         for (int s = 0; s < ROWS_FAST_N; ++s) {
             if (s < n && roles[s] != 0) {
-                const DevEdge e = use_lds ? staged[el[s]] : edges[P.first_edge + el[s]];
                 Rec rc;
-                bool as_cells = false;
-                if ((uint32_t)roles[s] & REC_FULL) {
-                    if (cell_mode & 1) as_cells = full_cells(e, r * 15, ((uint32_t)roles[s] & 1u) ? +1 : -1, rc);
+                if ((uint32_t)roles[s] & REC_FULL) {     // end points are already known: cells, or the generic FULL record
+                    const int64_t edy = use_lds ? staged[el[s]].dy : edges[P.first_edge + el[s]].dy;
+                    bool as_cells = false;
+                    if (cell_mode & 1) as_cells = full_cells_ends(Q1[s], R1[s], Q2[s], R2[s], edy, ((uint32_t)roles[s] & 1u) ? +1 : -1, rc);
+                    if (!as_cells) {
+                        rc.roles = (uint32_t)roles[s]; rc.cols = (uint32_t)cols[s]; rc.eid = P.first_edge + (uint32_t)el[s]; rc.dy = edy; rc.span = 0;
+                        rc.q1 = Q1[s]; rc.r1 = R1[s]; rc.q2 = Q2[s]; rc.r2 = R2[s];
+                    }
+                } else {
+                    const DevEdge e = use_lds ? staged[el[s]] : edges[P.first_edge + el[s]];
+                    rc = make_record(e, P.first_edge + (uint32_t)el[s], r * 15, (uint32_t)roles[s], (uint32_t)cols[s]);
                 }
-                if (!as_cells) rc = make_record(e, P.first_edge + (uint32_t)el[s], r * 15, (uint32_t)roles[s], (uint32_t)cols[s]);
                 records[off++] = rc;
             }
         }
