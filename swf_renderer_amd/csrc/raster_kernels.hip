@@ -435,6 +435,8 @@ __device__ __forceinline__ void fast_rows(EPTR E, const DevPath& P, int r, bool 
         }
     }
     if (overflow) n = 0;
+    // wave-uniform bound on the active edges of any row of this wave: the unrolled slot loops stop there
+    const int nmax = __ballot(n > 6) ? 8 : __ballot(n > 4) ? 6 : __ballot(n > 2) ? 4 : 2;
     // ---- rows that can still be FULL: x of every active edge at the first sample row of this pixel row and of the next
     //      (one reciprocal multiply + integer fix-up each); kept as the exact row-top / row-bottom end points for the records
     if (n > 0 && !mid_row) {
@@ -470,13 +472,16 @@ __device__ __forceinline__ void fast_rows(EPTR E, const DevPath& P, int r, bool 
         bool full = !mid_row;
         int wb[ROWS_FAST_N];
         unsigned firstg = 0, lastg = 0;
+#pragma unroll
+        for (int j = 0; j < ROWS_FAST_N; ++j) wb[j] = 0;
         if (full) {
 #pragma unroll
             for (int j = 0; j < ROWS_FAST_N; ++j) {
+                if (j >= nmax) continue;                  // wave-uniform: no row of this wave has that many edges
                 int w = 0; bool fg = true, lg = true;
 #pragma unroll
                 for (int i = 0; i < ROWS_FAST_N; ++i) {
-                    if (i == j) continue;
+                    if (i == j || i >= nmax) continue;
                     const bool valid = i < n && j < n;
                     // does edge i sort before edge j?  (cell, active-before-new, previous cell, path order)
                     const bool tie = cs[i] == cs[j];
@@ -537,6 +542,7 @@ __device__ __forceinline__ void fast_rows(EPTR E, const DevPath& P, int r, bool 
 #pragma unroll
             for (int s = 0; s < ROWS_FAST_N; ++s) {
                 cc[s] = 0; dd[s] = 0;
+                if (s >= nmax) continue;
                 if (s < nR) {
                     const DevEdge e = E[F.eid[s][R]];
                     if (e.ytop <= ss && ss < e.ybot) {
@@ -548,10 +554,12 @@ __device__ __forceinline__ void fast_rows(EPTR E, const DevPath& P, int r, bool 
             }
 #pragma unroll
             for (int j = 0; j < ROWS_FAST_N; ++j) {
+                if (j >= nmax) continue;
                 if (!((act >> j) & 1u)) continue;
                 int wbj = 0, gsum = dd[j]; bool rep = true;
 #pragma unroll
                 for (int i = 0; i < ROWS_FAST_N; ++i) {
+                    if (i >= nmax) continue;
                     if (i == j || !((act >> i) & 1u)) continue;
                     if (cc[i] < cc[j]) wbj += dd[i];
                     else if (cc[i] == cc[j]) { gsum += dd[i]; if (i < j) rep = false; }
