@@ -596,7 +596,7 @@ __global__ __launch_bounds__(64) void k_rows(const DevEdge* __restrict__ edges, 
     (void)n_paths;
     const DevPath P = paths[lo];
     const int r = (int)ck.first_row + lane;
-    const bool in_path = P.kind == SWFR_PATH_TOR && r < P.y_max;
+    const bool in_path = P.kind == SWFR_PATH_TOR && lane < ROWS_CHUNK && r < P.y_max;
     bool live = in_path;
     if (live && band_count > 1 && (uint32_t)((r / TILE_H) % band_count) != band_index) live = false;
     const uint32_t t = row_base[lo] + (uint32_t)(r - P.y_min);          // row task index (valid when in_path)
@@ -1002,7 +1002,6 @@ __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_
                                               uint32_t* __restrict__ counters, uint32_t n_rows_total, uint32_t n_rec_cap,
                                               const uint32_t* __restrict__ order) {
     __shared__ int acc[STRIP_H][ACC_STRIDE];
-    __shared__ uint32_t px[STRIP_H][TILE_W];
     __shared__ int plist[PBATCH];
     __shared__ uint32_t ent[TLIST][9];                    // BandEntry as 9 dwords
     __shared__ uint32_t cls[TLIST];
@@ -1035,7 +1034,9 @@ __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_
 #define PHASE(var) do { } while (0)
 #endif
 
-    for (int rr = 0; rr < STRIP_H; ++rr) px[rr][lane] = 0u;
+    uint32_t px[STRIP_H];                                 // this lane's column of the strip, in registers (row loops are unrolled)
+#pragma unroll
+    for (int rr = 0; rr < STRIP_H; ++rr) px[rr] = 0u;
     for (int i = lane; i < STRIP_H * ACC_STRIDE; i += 64) (&acc[0][0])[i] = 0;
 
     const uint32_t band_begin = band_off[trow], band_end = band_off[trow + 1];
@@ -1106,8 +1107,9 @@ __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_
             if (row_hi <= row_lo) continue;                    // the path misses this strip of the tile
             if (f & CLS_BOX) {
                 // ---- rectilinear (A.6): exact area of disjoint boxes, alpha = (c>>8) - (c>>16)
-#pragma unroll 1
-                for (int rr = row_lo; rr < row_hi; ++rr) {
+#pragma unroll
+                for (int rr = 0; rr < STRIP_H; ++rr) {
+                    if (rr < row_lo || rr >= row_hi) continue;         // wave-uniform
                     const int cy = ty0 + rr;
                     uint32_t cov = 0u;
                     for (uint32_t k = 0; k < e_nedges; ++k) {
@@ -1117,7 +1119,7 @@ __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_
                         if (wx > 0 && wy > 0) cov += (uint32_t)(wx * wy);
                     }
                     const uint32_t a = ((cov >> 8) - (cov >> 16)) & 255u;
-                    if (a) px[rr][lane] = blend_pixel(px[rr][lane], a, eflags, solid, styles, style, bitmaps, cx, cy);
+                    if (a) px[rr] = blend_pixel(px[rr], a, eflags, solid, styles, style, bitmaps, cx, cy);
                 }
             } else if (f & CLS_PARTIAL) {
                 if (dbg == 3) continue;
@@ -1228,18 +1230,17 @@ __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_
                 }
                 int (*A)[ACC_STRIDE] = acc;
                 // ---- prefix sum, alpha, blend; clears as it reads.  Four rows per step so their LDS round trips overlap
-#pragma unroll 1
-                for (int r4 = row_lo; r4 < row_hi; r4 += 4) {
+#pragma unroll
+                for (int r4 = 0; r4 < STRIP_H; r4 += 4) {
+                    if (r4 + 4 <= row_lo || r4 >= row_hi) continue;    // wave-uniform
                     if (dbg == 4) continue;
                     int v[4], carry[4], touch[4];
-                    uint32_t old_px[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        const int rr = min(r4 + u, STRIP_H - 1);
-                        touch[u] = (r4 + u < row_hi) ? A[rr][ACC_TOUCH] : 0;
+                        const int rr = r4 + u;
+                        touch[u] = (rr >= row_lo && rr < row_hi) ? A[rr][ACC_TOUCH] : 0;
                         v[u] = A[rr][lane];
                         carry[u] = A[rr][ACC_CARRY];
-                        old_px[u] = px[rr][lane];
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
@@ -1254,32 +1255,37 @@ __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_
                         const int area = scan * 512 - ua;
                         uint32_t a = (uint32_t)((area * 17 + 256) >> 9) & 255u;
                         if (cx < e_xmin || cx >= e_xmax) a = 0;
-                        if (a) px[rr][lane] = blend_pixel(old_px[u], a, eflags, solid, styles, style, bitmaps, cx, ty0 + rr);
+                        if (a) px[rr] = blend_pixel(px[rr], a, eflags, solid, styles, style, bitmaps, cx, ty0 + rr);
                     }
                 }
                 __syncthreads();                                   // acc cleared before the next path accumulates
                 PHASE(ph_p2);
             } else {
                 // full cover: every in-frame pixel of the tile has coverage 255
-#pragma unroll 1
-                for (int rr = row_lo; rr < row_hi; ++rr) px[rr][lane] = blend_pixel(px[rr][lane], 255u, eflags, solid, styles, style, bitmaps, cx, ty0 + rr);
+#pragma unroll
+                for (int rr = 0; rr < STRIP_H; ++rr)
+                    if (rr >= row_lo && rr < row_hi) px[rr] = blend_pixel(px[rr], 255u, eflags, solid, styles, style, bitmaps, cx, ty0 + rr);
             }
         }
     }
 
-    if (dbg == 8 && lane == 0) {                              // diagnostics (tools/strip_times.py)
-        px[0][0] = (uint32_t)(__builtin_amdgcn_s_memtime() - t_start); px[0][1] = dbg_pairs; px[0][2] = dbg_recs;
+    if (dbg == 8) {                                           // diagnostics (tools/strip_times.py): first pixels of the strip's first row
+        uint32_t d[16] = {};
+        d[0] = (uint32_t)(__builtin_amdgcn_s_memtime() - t_start); d[1] = dbg_pairs; d[2] = dbg_recs;
 #ifdef SWFR_PHASES
-        px[0][3] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - w_start); px[0][4] = (uint32_t)w_start; px[0][5] = (uint32_t)(w_start >> 32);
-        px[0][8] = ph_bin; px[0][9] = ph_batch; px[0][10] = ph_stage; px[0][11] = ph_acc; px[0][12] = ph_p2;
+        d[3] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - w_start); d[4] = (uint32_t)w_start; d[5] = (uint32_t)(w_start >> 32);
+        d[8] = ph_bin; d[9] = ph_batch; d[10] = ph_stage; d[11] = ph_acc; d[12] = ph_p2;
 #endif
+#pragma unroll
+        for (int k = 0; k < 16; ++k) if (lane == k) px[0] = d[k];
     }
     // ---- one store per pixel: premultiplied R,G,B,A bytes; the wave writes 256 contiguous bytes per row
     if (cx < width) {
+#pragma unroll
         for (int rr = 0; rr < STRIP_H; ++rr) {
             const int cy = ty0 + rr;
-            if (cy >= height) break;
-            const uint32_t p = px[rr][lane];
+            if (cy >= height) continue;
+            const uint32_t p = px[rr];
             const uint32_t rgba = (p & 0xff00ff00u) | ((p >> 16) & 0xffu) | ((p & 0xffu) << 16);
             fb[(size_t)cy * (size_t)width + cx] = rgba;
         }
