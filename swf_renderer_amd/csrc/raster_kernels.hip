@@ -955,21 +955,29 @@ __device__ __forceinline__ uint32_t blend_pixel_t(uint32_t dst, uint32_t a, uint
 #define blend_pixel blend_pixel_t<SHADERS>
 
 // one staged record -> covered height / uncovered area per cell of its row (LDS atomics into `acc`)
-__device__ __forceinline__ void accumulate_record(const Rec& rec, const uint32_t* sw, int* acc, const TileCtx& c) {
-    const int clo = (int)(rec.cols & 0xffffu), chi = (int)(rec.cols >> 16);
+__device__ __forceinline__ void accumulate_record(const uint32_t* sw, int* acc, const TileCtx& c) {
+    const uint32_t roles = sw[0], rcols = sw[1];
+    const int clo = (int)(rcols & 0xffffu), chi = (int)(rcols >> 16);
     if (clo >= c.tx0 + TILE_W && clo < 65535) return;               // entirely right of the tile
     if (chi < c.tx0 && chi < 65535) {                               // entirely left: only its net height reaches us
-        cell_add(acc, c, chi, record_height(rec.roles), 0);
+        cell_add(acc, c, chi, record_height(roles), 0);
         return;
     }
-    if (rec.roles & REC_CELLS) {                                    // precomputed by k_rows: no arithmetic left
-        const int n = (int)(rec.roles & 15u);
+    if (roles & REC_CELLS) {                                        // precomputed by k_rows: no arithmetic left
+        const int n = (int)(roles & 15u);
         for (int k = 0; k < n; ++k) {
             const uint32_t w = sw[2 + k];
             cell_add(acc, c, clo + (int)(w & 255u), (int)(int8_t)(w >> 8), (int)(int16_t)(w >> 16));
         }
         return;
     }
+    // the remaining kinds need the whole record (dword reads only: no alignment assumption)
+    Rec rec;
+    rec.roles = roles; rec.cols = rcols; rec.q1 = (int32_t)sw[2]; rec.q2 = (int32_t)sw[3];
+    rec.r1 = (int64_t)((uint64_t)sw[4] | ((uint64_t)sw[5] << 32));
+    rec.r2 = (int64_t)((uint64_t)sw[6] | ((uint64_t)sw[7] << 32));
+    rec.dy = (int64_t)((uint64_t)sw[8] | ((uint64_t)sw[9] << 32));
+    rec.span = sw[10]; rec.eid = sw[11];
     if (rec.roles & REC_FULL) {
         full_edge(rec, (rec.roles & 1u) ? +1 : -1, acc, c);
         return;
@@ -1213,16 +1221,9 @@ __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_
                     // lanes = this path's staged records
                     if (dbg != 12 && dbg != 13)
                         for (int t = g0 - wbase + lane; t < hi_g - wbase; t += 64) {
-                            const uint32_t* sw = &stage[t * 12];                 // dword reads only: no alignment assumption
-                            Rec rec;
-                            rec.roles = sw[0]; rec.cols = sw[1]; rec.q1 = (int32_t)sw[2]; rec.q2 = (int32_t)sw[3];
-                            rec.r1 = (int64_t)((uint64_t)sw[4] | ((uint64_t)sw[5] << 32));
-                            rec.r2 = (int64_t)((uint64_t)sw[6] | ((uint64_t)sw[7] << 32));
-                            rec.dy = (int64_t)((uint64_t)sw[8] | ((uint64_t)sw[9] << 32));
-                            rec.span = sw[10]; rec.eid = sw[11];
+                            const uint32_t* sw = &stage[t * 12];
                             const int r = rec_row[t] % STRIP_H;
-                            acc[r][ACC_TOUCH] = 1;
-                            accumulate_record(rec, sw, acc[r], c);
+                            accumulate_record(sw, acc[r], c);
                         }
                     g0 = hi_g;
                     __syncthreads();                                   // acc complete; the window may be restaged
@@ -1234,28 +1235,37 @@ __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_
                 for (int r4 = 0; r4 < STRIP_H; r4 += 4) {
                     if (r4 + 4 <= row_lo || r4 >= row_hi) continue;    // wave-uniform
                     if (dbg == 4) continue;
-                    int v[4], carry[4], touch[4];
+                    // straight-line over the four rows (no per-row branches) so that their LDS round trips and DPP scan
+                    // chains interleave; a row nothing was accumulated into scans zeros and leaves its pixels unchanged
+                    int v[4], carry[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int rr = r4 + u;
-                        touch[u] = (rr >= row_lo && rr < row_hi) ? A[rr][ACC_TOUCH] : 0;
                         v[u] = A[rr][lane];
                         carry[u] = A[rr][ACC_CARRY];
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int rr = r4 + u;
-                        if (!touch[u]) continue;                       // wave-uniform
                         A[rr][lane] = 0;
-                        if (lane < 2) A[rr][ACC_CARRY + lane] = 0;
+                        if (lane == 0) A[rr][ACC_CARRY] = 0;
+                    }
+                    uint32_t al[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
                         const int ua = (v[u] << 12) >> 12;             // low 20 bits, sign-extended
                         int ch = (v[u] - ua) >> 20;
                         if (lane == 0) ch += carry[u];
                         const int scan = wave_scan_incl(ch);
                         const int area = scan * 512 - ua;
-                        uint32_t a = (uint32_t)((area * 17 + 256) >> 9) & 255u;
-                        if (cx < e_xmin || cx >= e_xmax) a = 0;
-                        if (a) px[rr] = blend_pixel(px[rr], a, eflags, solid, styles, style, bitmaps, cx, ty0 + rr);
+                        al[u] = (uint32_t)((area * 17 + 256) >> 9) & 255u;
+                        if (cx < e_xmin || cx >= e_xmax) al[u] = 0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int rr = r4 + u;
+                        if (SHADERS) { if (al[u]) px[rr] = blend_pixel(px[rr], al[u], eflags, solid, styles, style, bitmaps, cx, ty0 + rr); }
+                        else { const uint32_t b = blend_pixel(px[rr], al[u], eflags, solid, styles, style, bitmaps, cx, ty0 + rr); px[rr] = al[u] ? b : px[rr]; }
                     }
                 }
                 __syncthreads();                                   // acc cleared before the next path accumulates
