@@ -940,6 +940,7 @@ __global__ __launch_bounds__(64) void k_class(const BandEntry* __restrict__ band
 
 #define TLIST 32                       // tile list entries per round
 #define REC_STAGE 32                   // records staged in LDS per round
+#define P2B 8                          // rows scanned + blended per straight-line step
 #define PBATCH (64 / STRIP_H)           // partial paths whose row headers and records are fetched in one round trip each
 
 template <bool SHADERS>
@@ -956,7 +957,10 @@ __device__ __forceinline__ uint32_t blend_pixel_t(uint32_t dst, uint32_t a, uint
 
 // one staged record -> covered height / uncovered area per cell of its row (LDS atomics into `acc`)
 __device__ __forceinline__ void accumulate_record(const uint32_t* sw, int* acc, const TileCtx& c) {
-    const uint32_t roles = sw[0], rcols = sw[1];
+    // the whole 48-byte record in three 16-byte LDS reads (staged records start on 16-byte boundaries)
+    const uint4* s4 = reinterpret_cast<const uint4*>(sw);
+    const uint4 w0 = s4[0], w1 = s4[1], w2 = s4[2];
+    const uint32_t roles = w0.x, rcols = w0.y;
     const int clo = (int)(rcols & 0xffffu), chi = (int)(rcols >> 16);
     if (clo >= c.tx0 + TILE_W && clo < 65535) return;               // entirely right of the tile
     if (chi < c.tx0 && chi < 65535) {                               // entirely left: only its net height reaches us
@@ -965,19 +969,19 @@ __device__ __forceinline__ void accumulate_record(const uint32_t* sw, int* acc, 
     }
     if (roles & REC_CELLS) {                                        // precomputed by k_rows: no arithmetic left
         const int n = (int)(roles & 15u);
-        for (int k = 0; k < n; ++k) {
-            const uint32_t w = sw[2 + k];
-            cell_add(acc, c, clo + (int)(w & 255u), (int)(int8_t)(w >> 8), (int)(int16_t)(w >> 16));
+        const uint32_t cw[REC_MAX_CELLS] = {w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
+#pragma unroll
+        for (int k = 0; k < REC_MAX_CELLS; ++k) {
+            if (k < n) cell_add(acc, c, clo + (int)(cw[k] & 255u), (int)(int8_t)(cw[k] >> 8), (int)(int16_t)(cw[k] >> 16));
         }
         return;
     }
-    // the remaining kinds need the whole record (dword reads only: no alignment assumption)
     Rec rec;
-    rec.roles = roles; rec.cols = rcols; rec.q1 = (int32_t)sw[2]; rec.q2 = (int32_t)sw[3];
-    rec.r1 = (int64_t)((uint64_t)sw[4] | ((uint64_t)sw[5] << 32));
-    rec.r2 = (int64_t)((uint64_t)sw[6] | ((uint64_t)sw[7] << 32));
-    rec.dy = (int64_t)((uint64_t)sw[8] | ((uint64_t)sw[9] << 32));
-    rec.span = sw[10]; rec.eid = sw[11];
+    rec.roles = roles; rec.cols = rcols; rec.q1 = (int32_t)w0.z; rec.q2 = (int32_t)w0.w;
+    rec.r1 = (int64_t)((uint64_t)w1.x | ((uint64_t)w1.y << 32));
+    rec.r2 = (int64_t)((uint64_t)w1.z | ((uint64_t)w1.w << 32));
+    rec.dy = (int64_t)((uint64_t)w2.x | ((uint64_t)w2.y << 32));
+    rec.span = w2.z; rec.eid = w2.w;
     if (rec.roles & REC_FULL) {
         full_edge(rec, (rec.roles & 1u) ? +1 : -1, acc, c);
         return;
@@ -1232,27 +1236,27 @@ __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_
                 int (*A)[ACC_STRIDE] = acc;
                 // ---- prefix sum, alpha, blend; clears as it reads.  Four rows per step so their LDS round trips overlap
 #pragma unroll
-                for (int r4 = 0; r4 < STRIP_H; r4 += 4) {
-                    if (r4 + 4 <= row_lo || r4 >= row_hi) continue;    // wave-uniform
+                for (int r4 = 0; r4 < STRIP_H; r4 += P2B) {
+                    if (r4 + P2B <= row_lo || r4 >= row_hi) continue;    // wave-uniform
                     if (dbg == 4) continue;
                     // straight-line over the four rows (no per-row branches) so that their LDS round trips and DPP scan
                     // chains interleave; a row nothing was accumulated into scans zeros and leaves its pixels unchanged
-                    int v[4], carry[4];
+                    int v[P2B], carry[P2B];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 0; u < P2B; ++u) {
                         const int rr = r4 + u;
                         v[u] = A[rr][lane];
                         carry[u] = A[rr][ACC_CARRY];
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 0; u < P2B; ++u) {
                         const int rr = r4 + u;
                         A[rr][lane] = 0;
                         if (lane == 0) A[rr][ACC_CARRY] = 0;
                     }
-                    uint32_t al[4];
+                    uint32_t al[P2B];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 0; u < P2B; ++u) {
                         const int ua = (v[u] << 12) >> 12;             // low 20 bits, sign-extended
                         int ch = (v[u] - ua) >> 20;
                         if (lane == 0) ch += carry[u];
@@ -1262,7 +1266,7 @@ __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_
                         if (cx < e_xmin || cx >= e_xmax) al[u] = 0;
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 0; u < P2B; ++u) {
                         const int rr = r4 + u;
                         if (SHADERS) { if (al[u]) px[rr] = blend_pixel(px[rr], al[u], eflags, solid, styles, style, bitmaps, cx, ty0 + rr); }
                         else { const uint32_t b = blend_pixel(px[rr], al[u], eflags, solid, styles, style, bitmaps, cx, ty0 + rr); px[rr] = al[u] ? b : px[rr]; }
