@@ -956,16 +956,17 @@ __device__ __forceinline__ uint32_t blend_pixel_t(uint32_t dst, uint32_t a, uint
 #define blend_pixel blend_pixel_t<SHADERS>
 
 // one staged record -> covered height / uncovered area per cell of its row (LDS atomics into `acc`)
-__device__ __forceinline__ void accumulate_record(const uint32_t* sw, int* acc, const TileCtx& c) {
+// returns true for a SUB-row record that reaches into the tile: its fifteen sample rows are spread over lanes by the caller
+__device__ __forceinline__ bool accumulate_record(const uint32_t* sw, int* acc, const TileCtx& c) {
     // the whole 48-byte record in three 16-byte LDS reads (staged records start on 16-byte boundaries)
     const uint4* s4 = reinterpret_cast<const uint4*>(sw);
     const uint4 w0 = s4[0], w1 = s4[1], w2 = s4[2];
     const uint32_t roles = w0.x, rcols = w0.y;
     const int clo = (int)(rcols & 0xffffu), chi = (int)(rcols >> 16);
-    if (clo >= c.tx0 + TILE_W && clo < 65535) return;               // entirely right of the tile
+    if (clo >= c.tx0 + TILE_W && clo < 65535) return false;         // entirely right of the tile
     if (chi < c.tx0 && chi < 65535) {                               // entirely left: only its net height reaches us
         cell_add(acc, c, chi, record_height(roles), 0);
-        return;
+        return false;
     }
     if (roles & REC_CELLS) {                                        // precomputed by k_rows: no arithmetic left
         const int n = (int)(roles & 15u);
@@ -974,29 +975,39 @@ __device__ __forceinline__ void accumulate_record(const uint32_t* sw, int* acc, 
         for (int k = 0; k < REC_MAX_CELLS; ++k) {
             if (k < n) cell_add(acc, c, clo + (int)(cw[k] & 255u), (int)(int8_t)(cw[k] >> 8), (int)(int16_t)(cw[k] >> 16));
         }
-        return;
+        return false;
     }
+    if (!(roles & REC_FULL)) return true;
     Rec rec;
     rec.roles = roles; rec.cols = rcols; rec.q1 = (int32_t)w0.z; rec.q2 = (int32_t)w0.w;
     rec.r1 = (int64_t)((uint64_t)w1.x | ((uint64_t)w1.y << 32));
     rec.r2 = (int64_t)((uint64_t)w1.z | ((uint64_t)w1.w << 32));
     rec.dy = (int64_t)((uint64_t)w2.x | ((uint64_t)w2.y << 32));
     rec.span = w2.z; rec.eid = w2.w;
-    if (rec.roles & REC_FULL) {
-        full_edge(rec, (rec.roles & 1u) ? +1 : -1, acc, c);
-        return;
+    full_edge(rec, (rec.roles & 1u) ? +1 : -1, acc, c);
+    return false;
+}
+
+// One sample row of a SUB-row record (lane = sample): x at sample ss in closed form from the record's first sample and slope
+__device__ __forceinline__ void accumulate_sub_sample(const uint32_t* sw, int ss, int* acc, const TileCtx& c) {
+    const uint4* s4 = reinterpret_cast<const uint4*>(sw);
+    const uint4 w0 = s4[0], w1 = s4[1], w2 = s4[2];
+    const uint32_t roles = w0.x, span = w2.z;
+    const int first = (int)(span & 255u), last = (int)(span >> 8);
+    if (ss < first || ss >= last) return;
+    const uint32_t role = (roles >> (2 * ss)) & 3u;
+    if (!role) return;
+    const int64_t r1 = (int64_t)((uint64_t)w1.x | ((uint64_t)w1.y << 32)), r2 = (int64_t)((uint64_t)w1.z | ((uint64_t)w1.w << 32));
+    const int64_t dy = (int64_t)((uint64_t)w2.x | ((uint64_t)w2.y << 32));
+    int cell = (int32_t)w0.z;
+    if (dy) {
+        const int k = ss - first;
+        int64_t dq, rm;
+        floor_div(r1 + (int64_t)k * r2, dy, dq, rm);          // |quotient| <= 15
+        cell = cell_of((int32_t)w0.z + k * (int32_t)w0.w + (int32_t)dq, rm, dy);
     }
-    const int first = (int)(rec.span & 255u), last = (int)(rec.span >> 8);
-    int32_t q = rec.q1; int64_t rm = rec.r1;
-    for (int ss = first; ss < last; ++ss) {
-        const uint32_t role = (rec.roles >> (2 * ss)) & 3u;
-        if (role) {
-            const int cell = rec.dy ? cell_of(q, rm, rec.dy) : q;
-            const int sgn = role == 1 ? 1 : -1;
-            cell_add(acc, c, cell >> 8, sgn, sgn * 2 * (cell & 255));
-        }
-        if (rec.dy) { q += rec.q2; rm += rec.r2; if (rm < 0) { --q; rm += rec.dy; } else if (rm >= rec.dy) { ++q; rm -= rec.dy; } }
-    }
+    const int sgn = role == 1 ? 1 : -1;
+    cell_add(acc, c, cell >> 8, sgn, sgn * 2 * (cell & 255));
 }
 
 // One wavefront per 64x16 tile: lane = pixel column, the tile's pixels live in LDS.  No workgroup barriers:
@@ -1223,12 +1234,32 @@ __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_
                     }
                     const int hi_g = min(g1, wbase + wn);
                     // lanes = this path's staged records
-                    if (dbg != 12 && dbg != 13)
-                        for (int t = g0 - wbase + lane; t < hi_g - wbase; t += 64) {
+                    if (dbg != 12 && dbg != 13) {
+                        bool sub_pending = false;
+                        const int t = g0 - wbase + lane;               // a window holds at most REC_STAGE <= 64 records: one pass
+                        if (t < hi_g - wbase) {
                             const uint32_t* sw = &stage[t * 12];
                             const int r = rec_row[t] % STRIP_H;
-                            accumulate_record(sw, acc[r], c);
+                            sub_pending = accumulate_record(sw, acc[r], c);
                         }
+                        // SUB-row records: four at a time, lane = (record, sample row)
+                        unsigned long long pend = __ballot(sub_pending);
+                        while (pend) {
+                            const int g = lane / 15, ss = lane - g * 15;
+                            unsigned long long m = pend;
+                            int src = -1;
+                            for (int q = 0; q < 4; ++q) {
+                                const int bit = m ? __ffsll((long long)m) - 1 : -1;
+                                if (q == g) src = bit;
+                                m &= m - 1;
+                            }
+                            pend = m;
+                            if (g < 4 && src >= 0) {
+                                const int t = g0 - wbase + src;
+                                accumulate_sub_sample(&stage[t * 12], ss, acc[rec_row[t] % STRIP_H], c);
+                            }
+                        }
+                    }
                     g0 = hi_g;
                     __syncthreads();                                   // acc complete; the window may be restaged
                     PHASE(ph_acc);
