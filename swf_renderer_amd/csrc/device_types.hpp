@@ -78,6 +78,15 @@ struct ChunkInfo {
     uint32_t path, first_row, rec_base, pad;
 };
 
+// One (path, tile-row) pair: where its BandEntry goes.  The host assigns the slots (painter's order inside every
+// tile-row) from the paths' pixel rectangles while it sizes the band lists.
+struct BandSlot {
+    uint32_t path;
+    uint32_t slot;           // index into band_list; the tile-row is recovered from band_off
+    uint32_t band;
+    uint32_t pad;
+};
+
 // A pixel row with more active edges than k_rows keeps in registers: handled by k_rows_big, one lane each.
 struct BigRow {
     uint32_t path;

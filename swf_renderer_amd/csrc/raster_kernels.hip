@@ -177,56 +177,38 @@ __device__ __forceinline__ void setup_block(uint32_t block, const swfr_edge* __r
 // ---------------------------------------------------------------------------------------------
 // k_bands: per tile-row, the paths whose pixel rows intersect it, in painter's order
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void bands_block(int band, const DevPath* __restrict__ paths, uint32_t n_paths,
-                                            const uint32_t* __restrict__ row_base, const swfr_style* __restrict__ styles,
-                                            const uint32_t* __restrict__ band_off, BandEntry* __restrict__ band_list) {
-    __shared__ uint32_t wave_cnt[4];
-    __shared__ uint32_t total;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int y0 = band * TILE_H, y1 = y0 + TILE_H;
-    BandEntry* out = band_list + band_off[band];
-    if (tid == 0) total = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < n_paths; base += 256) {
-        const uint32_t p = base + tid;
-        bool hit = false;
-        DevPath P;
-        if (p < n_paths) { P = paths[p]; hit = P.y_min < y1 && P.y_max > y0 && P.x_max > P.x_min; }
-        const unsigned long long b = __ballot(hit);
-        if (lane == 0) wave_cnt[wave] = __popcll(b);
-        __syncthreads();
-        uint32_t off = total;
-        for (int w = 0; w < wave; ++w) off += wave_cnt[w];
-        if (hit) {
-            BandEntry e;
-            e.path = p;
-            e.x_min = (int16_t)P.x_min; e.x_max = (int16_t)P.x_max; e.y_min = (int16_t)P.y_min; e.y_max = (int16_t)P.y_max;
-            e.row_base = row_base[p];
-            e.style = P.style; e.first_edge = P.first_edge; e.n_edges = P.n_edges;
-            const uint32_t kind = styles[P.style].kind, pixel = styles[P.style].pixel;
-            uint32_t fl = 0;
-            if (P.kind == SWFR_PATH_BOXES) fl |= BE_BOXES;
-            if (P.lerp) fl |= BE_LERP;
-            if (kind == SWFR_STYLE_SOLID) fl |= BE_SOLID;
-            if (kind == SWFR_STYLE_SOLID && P.lerp && (pixel >> 24) == 0xffu) fl |= BE_OPAQUE_COVER;
-            e.flags = fl | ((uint32_t)band << 8); e.solid = pixel;   // the band index rides in the upper bits
-            out[off + __popcll(b & ((1ull << lane) - 1ull))] = e;
-        }
-        __syncthreads();
-        if (tid == 0) total += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-        __syncthreads();
-    }
+__device__ __forceinline__ void bands_block(uint32_t block, const DevPath* __restrict__ paths, const BandSlot* __restrict__ slots,
+                                            uint32_t n_slots, const uint32_t* __restrict__ row_base,
+                                            const swfr_style* __restrict__ styles, BandEntry* __restrict__ band_list) {
+    const uint32_t g = block * 256 + threadIdx.x;
+    if (g >= n_slots) return;
+    const BandSlot bs = slots[g];
+    const uint32_t p = bs.path;
+    const DevPath P = paths[p];
+    BandEntry e;
+    e.path = p;
+    e.x_min = (int16_t)P.x_min; e.x_max = (int16_t)P.x_max; e.y_min = (int16_t)P.y_min; e.y_max = (int16_t)P.y_max;
+    e.row_base = row_base[p];
+    e.style = P.style; e.first_edge = P.first_edge; e.n_edges = P.n_edges;
+    const uint32_t kind = styles[P.style].kind, pixel = styles[P.style].pixel;
+    uint32_t fl = 0;
+    if (P.kind == SWFR_PATH_BOXES) fl |= BE_BOXES;
+    if (P.lerp) fl |= BE_LERP;
+    if (kind == SWFR_STYLE_SOLID) fl |= BE_SOLID;
+    if (kind == SWFR_STYLE_SOLID && P.lerp && (pixel >> 24) == 0xffu) fl |= BE_OPAQUE_COVER;
+    e.flags = fl | (bs.band << 8); e.solid = pixel;          // the tile-row index rides in the upper bits
+    band_list[bs.slot] = e;
 }
 
-// k_front: one launch for the per-frame front end.  Blocks [0, n_setup) convert edges (k_setup), the next n_bands
-// blocks build the band lists (k_bands); block 0 also clears the frame's counters.
+// k_front: one launch for the per-frame front end.  Blocks [0, n_setup) convert edges (one thread per edge), the rest
+// write the band entries (one thread per (path, tile-row) pair, slots assigned by the host); block 0 clears the counters.
 __global__ __launch_bounds__(256) void k_front(const swfr_edge* __restrict__ in, const DevPath* __restrict__ paths, DevEdge* __restrict__ out,
-                                               uint32_t n_edges, uint32_t n_setup, uint32_t n_paths, const uint32_t* __restrict__ row_base,
-                                               const swfr_style* __restrict__ styles, const uint32_t* __restrict__ band_off,
+                                               uint32_t n_edges, uint32_t n_setup, const BandSlot* __restrict__ slots, uint32_t n_slots,
+                                               const uint32_t* __restrict__ row_base, const swfr_style* __restrict__ styles,
                                                BandEntry* __restrict__ band_list, uint32_t* __restrict__ counters) {
     if (blockIdx.x == 0 && threadIdx.x < CNT_WORDS) counters[threadIdx.x] = 0;
     if (blockIdx.x < n_setup) setup_block(blockIdx.x, in, paths, out, n_edges);
-    else bands_block((int)(blockIdx.x - n_setup), paths, n_paths, row_base, styles, band_off, band_list);
+    else bands_block(blockIdx.x - n_setup, paths, slots, n_slots, row_base, styles, band_list);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1369,13 +1351,12 @@ __global__ __launch_bounds__(256) void k_pack_band(const uint32_t* __restrict__ 
 // ---------------------------------------------------------------------------------------------
 // launchers (called from renderer.cpp, which is compiled as plain C++ by the same hipcc)
 // ---------------------------------------------------------------------------------------------
-void launch_front(hipStream_t st, const swfr_edge* in, const DevPath* paths, DevEdge* out, uint32_t n_edges, uint32_t n_paths,
-                  const uint32_t* row_base, const swfr_style* styles, const uint32_t* band_off, BandEntry* band_list, uint32_t n_bands,
-                  uint32_t* counters) {
+void launch_front(hipStream_t st, const swfr_edge* in, const DevPath* paths, DevEdge* out, uint32_t n_edges, const BandSlot* slots,
+                  uint32_t n_slots, const uint32_t* row_base, const swfr_style* styles, BandEntry* band_list, uint32_t* counters) {
     uint32_t n_setup = (n_edges + 255) / 256;
-    const uint32_t n_b = n_paths ? n_bands : 0;
+    const uint32_t n_b = (n_slots + 255) / 256;
     if (n_setup + n_b == 0) n_setup = 1;          // counters are still cleared
-    hipLaunchKernelGGL(k_front, dim3(n_setup + n_b), dim3(256), 0, st, in, paths, out, n_edges, n_setup, n_paths, row_base, styles, band_off,
+    hipLaunchKernelGGL(k_front, dim3(n_setup + n_b), dim3(256), 0, st, in, paths, out, n_edges, n_setup, slots, n_slots, row_base, styles,
                        band_list, counters);
 }
 void launch_rows(hipStream_t st, const DevEdge* edges, const DevPath* paths, const uint32_t* row_base, const ChunkInfo* chunk_base,

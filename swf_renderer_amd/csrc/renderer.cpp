@@ -22,8 +22,8 @@
 #include "shape_decoder.hpp"
 
 namespace swfr {
-void launch_front(hipStream_t, const swfr_edge*, const DevPath*, DevEdge*, uint32_t, uint32_t, const uint32_t*, const swfr_style*, const uint32_t*,
-                  BandEntry*, uint32_t, uint32_t*);
+void launch_front(hipStream_t, const swfr_edge*, const DevPath*, DevEdge*, uint32_t, const BandSlot*, uint32_t, const uint32_t*, const swfr_style*,
+                  BandEntry*, uint32_t*);
 void launch_class(hipStream_t, const BandEntry*, uint32_t, const uint32_t*, uint32_t, const swfr_edge*, const RowInfo*, const Rec*, uint8_t*, int, int,
                   uint32_t, uint32_t);
 void launch_rows(hipStream_t, const DevEdge*, const DevPath*, const uint32_t*, const ChunkInfo*, uint32_t, RowInfo*, Rec*, uint32_t*, const BigRow*,
@@ -94,6 +94,7 @@ struct swfr_renderer {
     DevBuf<swfr_style> d_styles;
     DevBuf<uint32_t> d_row_base, d_band_off, d_order;
     DevBuf<BigRow> d_big_rows;
+    DevBuf<BandSlot> d_band_slots;
     DevBuf<ChunkInfo> d_chunk_base;
     DevBuf<BandEntry> d_band_list;
     DevBuf<uint8_t> d_cls;
@@ -121,7 +122,7 @@ struct swfr_renderer {
         if (has_device) {
             (void)hipSetDevice(cfg.device);
             d_raw.release(); d_edges.release(); d_paths.release(); d_styles.release(); d_row_base.release();
-            d_rows.release(); d_records.release(); d_chunk_base.release(); d_band_off.release(); d_band_list.release(); d_big_rows.release(); d_order.release(); d_cls.release(); d_counters.release(); d_bitmap_table.release(); d_fb.release(); d_tmp.release();
+            d_rows.release(); d_records.release(); d_chunk_base.release(); d_band_off.release(); d_band_list.release(); d_big_rows.release(); d_band_slots.release(); d_order.release(); d_cls.release(); d_counters.release(); d_bitmap_table.release(); d_fb.release(); d_tmp.release();
             for (auto& kv : bitmaps) if (kv.second.pixels) (void)hipFree(kv.second.pixels);
             for (auto& e : ev) if (e) (void)hipEventDestroy(e);
             if (stream) (void)hipStreamDestroy(stream);
@@ -190,6 +191,7 @@ int upload(swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_
     std::vector<uint32_t> row_base(n_paths + 1, 0);
     std::vector<ChunkInfo> chunks;                    // one k_rows workgroup each
     std::vector<uint32_t> chunk_cap;
+    std::vector<BandSlot> band_slots;
     std::vector<BigRow> big_rows;                     // rec_base holds the row's slot count until the prefix pass below
     std::vector<int32_t> active;
     const uint32_t bc = r->cfg.band_count > 1 ? r->cfg.band_count : 1, bi = r->cfg.band_count > 1 ? r->cfg.band_index : 0;
@@ -230,11 +232,14 @@ int upload(swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_
         }
         row_base[i + 1] = row_base[i] + rows;
         if (p.y_max > p.y_min && p.x_max > p.x_min) {
-            for (int b = p.y_min / TILE_H; b <= (p.y_max - 1) / TILE_H; ++b) ++band_off[size_t(b) + 1];
+            // slot of this path in every tile-row list it touches: its rank among the paths seen so far (painter's order)
+            for (int b = p.y_min / TILE_H; b <= (p.y_max - 1) / TILE_H; ++b)
+                band_slots.push_back(BandSlot{uint32_t(i), band_off[size_t(b) + 1]++, uint32_t(b), 0});
             pair_cap += size_t((p.y_max - 1) / TILE_H - p.y_min / TILE_H + 1) * size_t((p.x_max - 1) / TILE_W - p.x_min / TILE_W + 1);
         }
     }
-    for (size_t b = 0; b < n_bands; ++b) band_off[b + 1] += band_off[b];   // exact sizes; k_bands fills the lists in order
+    for (size_t b = 0; b < n_bands; ++b) band_off[b + 1] += band_off[b];   // exact sizes
+    for (BandSlot& bs : band_slots) bs.slot += band_off[bs.band];
     // ---- launch order of the k_tiles wavefronts: strips crossed by many edges first (a scheduling hint from edge
     //      end points only: x of the edge at the strip's top and bottom by linear interpolation, one column of slack)
     std::vector<uint32_t> order;
@@ -296,6 +301,9 @@ int upload(swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_
     if (n_paths) HIP_CHECK(hipMemcpyAsync(r->d_paths.ptr, paths, n_paths * sizeof(swfr_path), hipMemcpyHostToDevice, r->stream));
     if (n_styles) HIP_CHECK(hipMemcpyAsync(r->d_styles.ptr, styles, n_styles * sizeof(swfr_style), hipMemcpyHostToDevice, r->stream));
     HIP_CHECK(hipMemcpyAsync(r->d_row_base.ptr, row_base.data(), (n_paths + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, r->stream));
+    r->d_band_slots.reserve(band_slots.size());
+    if (!band_slots.empty())
+        HIP_CHECK(hipMemcpyAsync(r->d_band_slots.ptr, band_slots.data(), band_slots.size() * sizeof(BandSlot), hipMemcpyHostToDevice, r->stream));
     r->d_order.reserve(order.size());
     r->has_order = !order.empty();
     if (!order.empty())
@@ -340,8 +348,8 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
         const bool timed = f % stride == 0;        // per-kernel events on every stride-th frame (each costs a queue packet)
         if (timed) HIP_CHECK(hipEventRecord(e[0], r->stream));
         if (r->n_paths)     // edge constants + band lists; also clears the counters for this frame
-            launch_front(r->stream, r->d_raw.ptr, r->d_paths.ptr, r->d_edges.ptr, uint32_t(r->n_edges), uint32_t(r->n_paths), r->d_row_base.ptr,
-                         r->d_styles.ptr, r->d_band_off.ptr, r->d_band_list.ptr, uint32_t(r->n_bands), r->d_counters.ptr);
+            launch_front(r->stream, r->d_raw.ptr, r->d_paths.ptr, r->d_edges.ptr, uint32_t(r->n_edges), r->d_band_slots.ptr, uint32_t(r->n_band_entries),
+                         r->d_row_base.ptr, r->d_styles.ptr, r->d_band_list.ptr, r->d_counters.ptr);
         if (timed) HIP_CHECK(hipEventRecord(e[1], r->stream));
         if (r->n_paths) {
             launch_rows(r->stream, r->d_edges.ptr, r->d_paths.ptr, r->d_row_base.ptr, r->d_chunk_base.ptr, uint32_t(r->n_paths), r->d_rows.ptr,
