@@ -104,6 +104,20 @@ struct swfr_renderer {
     DevBuf<uint32_t> d_counters;
     DevBuf<DevBitmap> d_bitmap_table;
     DevBuf<uint32_t> d_fb, d_tmp;
+    // further sets of per-frame buffers + streams: with SWFR_FRAMES_IN_FLIGHT = n consecutive resident frames rotate over n
+    // sets, so the front of frame f+1 overlaps the tail of frame f (every frame still recomputes everything)
+    struct ExtraSet {
+        hipStream_t stream = nullptr;
+        DevBuf<DevEdge> d_edges;
+        DevBuf<BandEntry> d_band_list;
+        DevBuf<uint8_t> d_cls;
+        DevBuf<RowInfo> d_rows;
+        DevBuf<Rec> d_records;
+        DevBuf<uint32_t> d_counters, d_fb;
+    };
+    ExtraSet extra[3];
+    int in_flight = 2;
+    uint32_t* fb_cur = nullptr;             // framebuffer of the last completed frame
     std::map<uint32_t, DeviceBitmap> bitmaps;
     std::vector<DevBitmap> bitmap_table;   // indexed by bitmap id
     bool bitmap_table_dirty = false;
@@ -123,6 +137,10 @@ struct swfr_renderer {
             (void)hipSetDevice(cfg.device);
             d_raw.release(); d_edges.release(); d_paths.release(); d_styles.release(); d_row_base.release();
             d_rows.release(); d_records.release(); d_chunk_base.release(); d_band_off.release(); d_band_list.release(); d_big_rows.release(); d_band_slots.release(); d_order.release(); d_cls.release(); d_counters.release(); d_bitmap_table.release(); d_fb.release(); d_tmp.release();
+            for (ExtraSet& x : extra) {
+                x.d_edges.release(); x.d_band_list.release(); x.d_cls.release(); x.d_rows.release(); x.d_records.release(); x.d_counters.release(); x.d_fb.release();
+                if (x.stream) (void)hipStreamDestroy(x.stream);
+            }
             for (auto& kv : bitmaps) if (kv.second.pixels) (void)hipFree(kv.second.pixels);
             for (auto& e : ev) if (e) (void)hipEventDestroy(e);
             if (stream) (void)hipStreamDestroy(stream);
@@ -297,6 +315,17 @@ int upload(swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_
     r->d_cls.reserve(size_t(band_off[n_bands]) * ((r->width + TILE_W - 1) / TILE_W) + 64);   // class byte per (band entry, tile column)
     r->n_band_entries = band_off[n_bands];
     r->d_counters.reserve(CNT_WORDS);
+    for (int k = 0; k + 1 < std::min(r->in_flight, 4); ++k) {
+        auto& x = r->extra[k];
+        x.d_edges.reserve(n_edges); x.d_rows.reserve(r->n_tasks); x.d_records.reserve(r->rec_cap); x.d_band_list.reserve(band_off[n_bands]);
+        x.d_cls.reserve(size_t(band_off[n_bands]) * ((r->width + TILE_W - 1) / TILE_W) + 64);
+        x.d_counters.reserve(CNT_WORDS);
+        if (!x.d_fb.ptr) {
+            x.d_fb.reserve(size_t(r->width) * r->height);
+            HIP_CHECK(hipMemsetAsync(x.d_fb.ptr, 0, size_t(r->width) * r->height * 4, r->stream));
+        }
+        if (!x.stream) HIP_CHECK(hipStreamCreateWithFlags(&x.stream, hipStreamNonBlocking));
+    }
     if (n_edges) HIP_CHECK(hipMemcpyAsync(r->d_raw.ptr, staged.data(), n_edges * sizeof(swfr_edge), hipMemcpyHostToDevice, r->stream));
     if (n_paths) HIP_CHECK(hipMemcpyAsync(r->d_paths.ptr, paths, n_paths * sizeof(swfr_path), hipMemcpyHostToDevice, r->stream));
     if (n_styles) HIP_CHECK(hipMemcpyAsync(r->d_styles.ptr, styles, n_styles * sizeof(swfr_style), hipMemcpyHostToDevice, r->stream));
@@ -333,40 +362,59 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
     float setup_ms = 0, rows_ms = 0, tiles_ms = 0, total_ms = 0;
     uint32_t counters[CNT_WORDS] = {};
     if (frames > 4096) frames = 4096;
-    while (r->ev.size() < size_t(frames) * 4 + 2) {
+    // all frames are queued back to back; events bracket every kernel on the stream the frame runs on
+    struct Set { hipStream_t st; DevEdge* edges; BandEntry* band_list; uint8_t* cls; RowInfo* rows; Rec* records; uint32_t* counters; uint32_t* fb; };
+    Set sets[4] = {{r->stream, r->d_edges.ptr, r->d_band_list.ptr, r->d_cls.ptr, r->d_rows.ptr, r->d_records.ptr, r->d_counters.ptr, r->d_fb.ptr}};
+    uint32_t n_sets = 1;
+    if (frames > 1)
+        for (int k = 0; k + 1 < std::min(r->in_flight, 4) && r->extra[k].stream; ++k) {
+            auto& x = r->extra[k];
+            sets[n_sets++] = Set{x.stream, x.d_edges.ptr, x.d_band_list.ptr, x.d_cls.ptr, x.d_rows.ptr, x.d_records.ptr, x.d_counters.ptr, x.d_fb.ptr};
+        }
+    while (r->ev.size() < size_t(frames) * 4 + 5) {
         hipEvent_t e = nullptr;
         HIP_CHECK(hipEventCreate(&e));
         r->ev.push_back(e);
     }
-    // all frames are queued back to back; events bracket every kernel on the handle's own stream
-    HIP_CHECK(hipMemsetAsync(r->d_counters.ptr, 0, CNT_WORDS * sizeof(uint32_t), r->stream));
     const uint32_t stride = r->event_stride < 1 ? 1u : uint32_t(r->event_stride);
     hipEvent_t ev_begin = r->ev[size_t(frames) * 4], ev_end = r->ev[size_t(frames) * 4 + 1];
+    hipEvent_t* ev_join = &r->ev[size_t(frames) * 4 + 2];
+    HIP_CHECK(hipMemsetAsync(r->d_counters.ptr, 0, CNT_WORDS * sizeof(uint32_t), r->stream));
     HIP_CHECK(hipEventRecord(ev_begin, r->stream));
+    for (uint32_t k = 1; k < n_sets; ++k) {
+        HIP_CHECK(hipStreamWaitEvent(sets[k].st, ev_begin, 0));
+        HIP_CHECK(hipMemsetAsync(sets[k].counters, 0, CNT_WORDS * sizeof(uint32_t), sets[k].st));
+    }
     for (uint32_t f = 0; f < frames; ++f) {
+        const Set& S = sets[f % n_sets];
         hipEvent_t* e = &r->ev[size_t(f) * 4];
         const bool timed = f % stride == 0;        // per-kernel events on every stride-th frame (each costs a queue packet)
-        if (timed) HIP_CHECK(hipEventRecord(e[0], r->stream));
+        if (timed) HIP_CHECK(hipEventRecord(e[0], S.st));
         if (r->n_paths)     // edge constants + band lists; also clears the counters for this frame
-            launch_front(r->stream, r->d_raw.ptr, r->d_paths.ptr, r->d_edges.ptr, uint32_t(r->n_edges), r->d_band_slots.ptr, uint32_t(r->n_band_entries),
-                         r->d_row_base.ptr, r->d_styles.ptr, r->d_band_list.ptr, r->d_counters.ptr);
-        if (timed) HIP_CHECK(hipEventRecord(e[1], r->stream));
+            launch_front(S.st, r->d_raw.ptr, r->d_paths.ptr, S.edges, uint32_t(r->n_edges), r->d_band_slots.ptr, uint32_t(r->n_band_entries),
+                         r->d_row_base.ptr, r->d_styles.ptr, S.band_list, S.counters);
+        if (timed) HIP_CHECK(hipEventRecord(e[1], S.st));
         if (r->n_paths) {
-            launch_rows(r->stream, r->d_edges.ptr, r->d_paths.ptr, r->d_row_base.ptr, r->d_chunk_base.ptr, uint32_t(r->n_paths), r->d_rows.ptr,
-                        r->d_records.ptr, r->d_counters.ptr, r->d_big_rows.ptr, uint32_t(r->n_big), uint32_t(r->n_chunks), bi, bc, r->fast_limit,
+            launch_rows(S.st, S.edges, r->d_paths.ptr, r->d_row_base.ptr, r->d_chunk_base.ptr, uint32_t(r->n_paths), S.rows,
+                        S.records, S.counters, r->d_big_rows.ptr, uint32_t(r->n_big), uint32_t(r->n_chunks), bi, bc, r->fast_limit,
                         r->cell_mode);
-            launch_class(r->stream, r->d_band_list.ptr, uint32_t(r->n_band_entries), r->d_band_off.ptr, uint32_t(r->n_bands), r->d_raw.ptr,
-                         r->d_rows.ptr, r->d_records.ptr, r->d_cls.ptr, int(r->width), int(r->height), bi, bc);
+            launch_class(S.st, S.band_list, uint32_t(r->n_band_entries), r->d_band_off.ptr, uint32_t(r->n_bands), r->d_raw.ptr,
+                         S.rows, S.records, S.cls, int(r->width), int(r->height), bi, bc);
         }
-        if (timed) HIP_CHECK(hipEventRecord(e[2], r->stream));
-        launch_tiles(r->stream, r->d_raw.ptr, r->d_band_off.ptr, r->d_band_list.ptr, r->d_cls.ptr, r->d_rows.ptr, r->d_records.ptr, r->d_styles.ptr,
-                     r->d_bitmap_table.ptr, r->d_fb.ptr, int(r->width), int(r->height), bi, bc, r->tiles_dbg, r->d_counters.ptr, uint32_t(r->n_tasks), uint32_t(r->rec_cap), r->any_shader,
+        if (timed) HIP_CHECK(hipEventRecord(e[2], S.st));
+        launch_tiles(S.st, r->d_raw.ptr, r->d_band_off.ptr, S.band_list, S.cls, S.rows, S.records, r->d_styles.ptr,
+                     r->d_bitmap_table.ptr, S.fb, int(r->width), int(r->height), bi, bc, r->tiles_dbg, S.counters, uint32_t(r->n_tasks), uint32_t(r->rec_cap), r->any_shader,
                      r->has_order ? r->d_order.ptr : nullptr);
-        if (timed) HIP_CHECK(hipEventRecord(e[3], r->stream));
+        if (timed) HIP_CHECK(hipEventRecord(e[3], S.st));
+    }
+    for (uint32_t k = 1; k < n_sets; ++k) {
+        HIP_CHECK(hipEventRecord(ev_join[k - 1], sets[k].st));
+        HIP_CHECK(hipStreamWaitEvent(r->stream, ev_join[k - 1], 0));
     }
     HIP_CHECK(hipEventRecord(ev_end, r->stream));
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(r->stream));
+    r->fb_cur = sets[(frames - 1) % n_sets].fb;
     uint32_t timed_frames = 0;
     for (uint32_t f = 0; f < frames; f += stride, ++timed_frames) {
         hipEvent_t* e = &r->ev[size_t(f) * 4];
@@ -378,6 +426,11 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
     }
     HIP_CHECK(hipEventElapsedTime(&total_ms, ev_begin, ev_end));
     HIP_CHECK(hipMemcpy(counters, r->d_counters.ptr, sizeof counters, hipMemcpyDeviceToHost));
+    for (uint32_t k = 1; k < n_sets; ++k) {
+        uint32_t c2[CNT_WORDS] = {};
+        HIP_CHECK(hipMemcpy(c2, sets[k].counters, sizeof c2, hipMemcpyDeviceToHost));
+        counters[CNT_ERROR] |= c2[CNT_ERROR];
+    }
     r->timing = swfr_timing{total_ms, setup_ms, rows_ms, tiles_ms, frames, r->n_edges, r->n_paths, r->n_tasks, r->rec_main, timed_frames};
     if (r->tiles_dbg == 9)
         std::fprintf(stderr, "[swfr] tile/path pairs %u, partial %u, full %u, culled entries %u, records %u, overflow rows %u\n", counters[CNT_PAIRS],
@@ -423,6 +476,7 @@ int swfr_create(uint32_t width, uint32_t height, const swfr_config* cfg, swfr_re
     if (const char* fl = std::getenv("SWFR_FAST_LIMIT")) r->fast_limit = std::atoi(fl);
     if (const char* td = std::getenv("SWFR_TILES_DEBUG")) r->tiles_dbg = std::atoi(td);
     if (const char* so = std::getenv("SWFR_STRIP_ORDER")) r->strip_order = std::atoi(so);
+    if (const char* fi = std::getenv("SWFR_FRAMES_IN_FLIGHT")) r->in_flight = std::atoi(fi);
     if (const char* es = std::getenv("SWFR_EVENT_STRIDE")) r->event_stride = std::atoi(es);
     if (const char* cm = std::getenv("SWFR_CELL_MODE")) r->cell_mode = std::atoi(cm);
     if (r->cfg.device == SWFR_DEVICE_HOST_ONLY) {
@@ -548,10 +602,10 @@ int swfr_read_image(swfr_renderer* r, uint8_t* dst, size_t dst_stride, int premu
     if (!r->fb_valid) return fail(r, SWFR_ERR_INVALID, "nothing rendered yet");
     return guarded(r, [&]() {
         const size_t n = size_t(r->width) * r->height;
-        const uint32_t* src = r->d_fb.ptr;
+        const uint32_t* src = r->fb_cur ? r->fb_cur : r->d_fb.ptr;
         if (!premultiplied) {
             r->d_tmp.reserve(n);
-            launch_unpremultiply(r->stream, r->d_fb.ptr, r->d_tmp.ptr, n);
+            launch_unpremultiply(r->stream, src, r->d_tmp.ptr, n);
             src = r->d_tmp.ptr;
         }
         HIP_CHECK(hipMemcpy2DAsync(dst, dst_stride, src, size_t(r->width) * 4, size_t(r->width) * 4, r->height, hipMemcpyDeviceToHost,
@@ -588,14 +642,14 @@ int swfr_copy_band_slab(swfr_renderer* r, void* device_dst) {
     if (!r->has_device) return fail(r, SWFR_ERR_NO_DEVICE, "host-only handle");
     return guarded(r, [&]() {
         const uint32_t bc = r->cfg.band_count > 1 ? r->cfg.band_count : 1, bi = r->cfg.band_count > 1 ? r->cfg.band_index : 0;
-        launch_pack_band(r->stream, r->d_fb.ptr, static_cast<uint32_t*>(device_dst), int(r->width), int(r->height), bi, bc, local_tile_rows(r));
+        launch_pack_band(r->stream, r->fb_cur ? r->fb_cur : r->d_fb.ptr, static_cast<uint32_t*>(device_dst), int(r->width), int(r->height), bi, bc, local_tile_rows(r));
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipStreamSynchronize(r->stream));
         return int(SWFR_OK);
     });
 }
 
-void* swfr_device_framebuffer(swfr_renderer* r) { return (r && r->has_device) ? r->d_fb.ptr : nullptr; }
+void* swfr_device_framebuffer(swfr_renderer* r) { return (r && r->has_device) ? (r->fb_cur ? r->fb_cur : r->d_fb.ptr) : nullptr; }
 
 #pragma GCC visibility pop
 }  // extern "C"
