@@ -166,7 +166,7 @@ def main():
         tiles_ms = tm["tiles_ms"] / max(tm["timed_frames"], 1)
         achieved = algo_bytes / (tiles_ms * 1e-3) / 1e9 if tiles_ms > 0 else 0.0
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01c_pmc_k_tiles.json")
+        pmc = os.path.join(ROOT, "profiles", "r01d_pmc_k_tiles.json")
         if os.path.exists(pmc) and world == 1 and args.workload == "s1":
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
         line = {
@@ -191,6 +191,21 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": algo_bytes},
         }
+        line["config"]["frames_in_flight"] = int(os.environ.get("SWFR_FRAMES_IN_FLIGHT", "2")) if world == 1 else 1
+        if world == 1 and line["config"]["frames_in_flight"] > 1:
+            # the timed region overlaps consecutive frames on two streams, which stretches every kernel's own duration;
+            # the same kernel timed with one frame in flight (a second handle, outside the timed region) is reported beside it
+            os.environ["SWFR_FRAMES_IN_FLIGHT"] = "1"
+            r1 = S.Renderer(W, H, device=local_rank)
+            r1.upload_edges(edges, paths, styles)
+            r1.render_resident(16)
+            r1.render_resident(64)
+            t1 = r1.timing()
+            r1.close()
+            iso_ms = t1["tiles_ms"] / max(t1["timed_frames"], 1)
+            iso = algo_bytes / (iso_ms * 1e-3) / 1e9 if iso_ms > 0 else 0.0
+            line["roofline"]["one_frame_in_flight"] = {"k_tiles_ms": round(iso_ms, 4), "achieved": round(iso, 2), "frac": round(iso / HBM_PEAK_GBS, 5),
+                                                       "value": round(W * H * 64 / (t1["total_ms"] * 1e-3) / 1e6, 2)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(fx, cols, W, H, name=args.workload.upper())
         print(json.dumps(line), flush=True)
