@@ -70,6 +70,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 path on one GPU: every rank renders on cuda:0, slabs are gathered as CPU tensors")
     ap.add_argument("--verify", action="store_true", help="rank 0 checks the assembled frame against the S1 known answer (S2: against the oracle)")
+    ap.add_argument("--sharding", default="frames", choices=["frames", "bands"],
+                    help="N>1: frames = every rank rasterizes whole frames of the batch, no data-path collective (weak scaling, default); "
+                         "bands = one frame's tile-rows interleaved over the ranks + one RCCL gather per frame to rank 0 (strong scaling)")
     ap.add_argument("--workload", default="s1", choices=["s1", "s2"],
                     help="s1 = BASELINE.json's metric configuration (4K, 10k edges; the default and the judged line); s2 = 8K, 100k edges")
     args = ap.parse_args()
@@ -110,10 +113,11 @@ def main():
     t_host = time.perf_counter() - t0
     host.close()
 
-    r = S.Renderer(W, H, device=local_rank, band_index=rank if world > 1 else 0, band_count=world if world > 1 else 0)
+    bands = world > 1 and args.sharding == "bands"
+    r = S.Renderer(W, H, device=local_rank, band_index=rank if bands else 0, band_count=world if bands else 0)
     r.upload_edges(edges, paths, styles)                      # inputs resident in HBM before the timed region
     pipe = None
-    if world > 1:
+    if bands:
         pipe = D.FramePipeline(r, W, H, rank, world, device="cpu" if rehearsal else "cuda")
 
     def sync_all():
@@ -125,7 +129,7 @@ def main():
         return pipe.step()
 
     # ---- warmup
-    if world == 1:
+    if not bands:
         r.render_resident(max(args.warmup, 1))
     else:
         for _ in range(max(args.warmup, 1)):
@@ -133,8 +137,8 @@ def main():
     sync_all()
     # ---- timed region: exactly K steps
     t0 = time.perf_counter()
-    if world == 1:
-        r.render_resident(args.steps)                         # K frames queued back to back on the handle's stream
+    if not bands:
+        r.render_resident(args.steps)                         # K frames queued back to back on the handle's streams
     else:
         out = None
         for _ in range(args.steps):
@@ -150,7 +154,7 @@ def main():
 
     if args.verify and rank == 0:
         import hashlib
-        img = out.cpu().numpy() if world > 1 else r.read_image(premultiplied=True)
+        img = out.cpu().numpy() if bands else r.read_image(premultiplied=True)
         if args.workload == "s1":
             ok = hashlib.sha256(np.ascontiguousarray(img).tobytes()).hexdigest() == synth.S1_SHA256_PREMUL
         else:
@@ -161,29 +165,31 @@ def main():
     if rank == 0:
         n_edges, n_paths = len(edges), len(paths)
         algo_bytes = 4 * W * H + 16 * n_edges + 16 * n_paths           # SURVEY.md 8(d), per frame = per k_tiles launch
-        if world > 1:
+        if bands:
             algo_bytes = 4 * W * D.local_tile_rows(H, 0, world) * D.TILE_H + 16 * n_edges + 16 * n_paths
         tiles_ms = tm["tiles_ms"] / max(tm["timed_frames"], 1)
         achieved = algo_bytes / (tiles_ms * 1e-3) / 1e9 if tiles_ms > 0 else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01d_pmc_k_tiles.json")
-        if os.path.exists(pmc) and world == 1 and args.workload == "s1":
+        if os.path.exists(pmc) and not bands and args.workload == "s1":
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
         line = {
             "metric": "Mpixels/sec rasterized @ 4K, 10k-edge synthetic shape set" if args.workload == "s1" else "Mpixels/sec rasterized @ 8K, 100k-edge synthetic shape set",
-            "value": round(W * H * args.steps / dt / 1e6, 2),
+            # frames sharding: a step is one frame on every rank (N frames); bands sharding: one frame over all ranks
+            "value": round(W * H * args.steps * (1 if bands or world == 1 else world) / dt / 1e6, 2),
             "unit": "Mpixels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "frames_per_sec": round(args.steps / dt, 1),
+            "frames_per_sec": round(args.steps * (1 if bands or world == 1 else world) / dt, 1),
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": "strong" if bands else "weak",
             "vs_baseline": None,
             "dtype": "int64/u8",
             "data": "synthetic",
             "config": {"workload": "%s: %dx%d, %d ten-vertex stars, opaque solid, nonzero, seed 0xC0FFEE" % (args.workload.upper(), W, H, len(fx)),
                        "n_edges": n_edges, "n_paths": n_paths,
-                       "sharding": "tile-row bands interleaved over %d rank(s)%s" % (world, ", one RCCL gather per frame" if world > 1 else ""),
+                       "sharding": ("tile-row bands interleaved over %d ranks, one RCCL gather per frame" % world) if bands else
+                                   ("whole frames, one per rank and step, no data-path collective" if world > 1 else "single GPU"),
                        "host_edge_list_build_ms": round(t_host * 1e3, 2)},
             "kernel_ms_per_frame": {"k_setup": round(tm["setup_ms"] / max(tm["timed_frames"], 1), 4), "k_rows": round(tm["rows_ms"] / max(tm["timed_frames"], 1), 4),
                                     "k_tiles": round(tiles_ms, 4)},
@@ -191,7 +197,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": algo_bytes},
         }
-        line["config"]["frames_in_flight"] = int(os.environ.get("SWFR_FRAMES_IN_FLIGHT", "2")) if world == 1 else 1
+        line["config"]["frames_in_flight"] = int(os.environ.get("SWFR_FRAMES_IN_FLIGHT", "2")) if not bands else 1
         if world == 1 and line["config"]["frames_in_flight"] > 1:
             # the timed region overlaps consecutive frames on two streams, which stretches every kernel's own duration;
             # the same kernel timed with one frame in flight (a second handle, outside the timed region) is reported beside it
