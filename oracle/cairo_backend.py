@@ -246,6 +246,14 @@ class CairoBackend:
     def set_line_join_round(self):
         self.lib.cairo_set_line_join(self.cr, 1)
 
+    def set_line_cap(self, k):
+        """0 butt, 1 round, 2 square (cairo_line_cap_t)."""
+        self.lib.cairo_set_line_cap(self.cr, int(k))
+
+    def set_line_join(self, k):
+        """0 miter, 1 round, 2 bevel (cairo_line_join_t)."""
+        self.lib.cairo_set_line_join(self.cr, int(k))
+
     def stroke(self):
         self._apply_source(self._stroke)
         self.lib.cairo_stroke_preserve(self.cr)

@@ -168,6 +168,12 @@ class OracleBackend:
     def set_line_join_round(self):
         self.L.swfo_set_line_join(self.ctx, 1)
 
+    def set_line_cap(self, k):
+        self.L.swfo_set_line_cap(self.ctx, int(k))
+
+    def set_line_join(self, k):
+        self.L.swfo_set_line_join(self.ctx, int(k))
+
     def stroke(self):
         self._apply(self._stroke)
         self.unsupported |= self.L.swfo_stroke_preserve(self.ctx)

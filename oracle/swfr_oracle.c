@@ -419,21 +419,28 @@ static void path_fill_to_polygon(const path_t *p, double tol, polygon_t *g)
 }
 
 /* ------------------------------------------------------------------ [A.8] stroker */
+/* Restates cairo 1.16 cairo-path-stroke-polygon.c (+ cairo-pen.c, cairo-spline.c's tangent decomposition and the
+   rectilinear stroker of cairo-path-stroke-boxes.c).  Pinned by fuzzing against libcairo (tests/test_oracle_vs_cairo.py). */
 typedef struct { pt_t *p; int n, cap; int dir; } contour_t;
 typedef struct {
     pt_t ccw, point, cw;
     int64_t dvx, dvy;                       /* dev_vector (fixed deltas) */
     double dsx, dsy;                        /* unit device slope */
+    double usx, usy;                        /* unit user-space slope (square caps) */
     double length;
 } face_t;
+typedef struct { pt_t pt; int64_t cw_dx, cw_dy, ccw_dx, ccw_dy; } pen_vertex_t;
+typedef struct { int n; pen_vertex_t *v; } pen_t;
 typedef struct {
     contour_t cw, ccw;
     polygon_t *g;
     const mat_t *ctm, *inv;
     int ctm_det_positive, ctm_identity;
-    double half_width, miter_limit, tol;
-    int join, cap;
+    double half_width, miter_limit, tol, spline_cusp_tol;
+    int join, cap;                          /* join: 0 miter 1 round 2 bevel; cap: 0 butt 1 round 2 square */
     int64_t contour_tol;
+    pen_t pen;
+    int has_bounds; pt_t b1, b2;
     pt_t first_point;
     int has_initial_sub_path, has_current_face, has_first_face;
     face_t current_face, first_face;
@@ -487,6 +494,7 @@ static void compute_face(const pt_t *point, int64_t ddx, int64_t ddy, stroker_t 
     f->ccw.x = point->x + ox; f->ccw.y = point->y + oy;
     f->point = *point;
     f->cw.x = point->x - ox; f->cw.y = point->y - oy;
+    f->usx = sdx; f->usy = sdy;
     f->dvx = ddx; f->dvy = ddy;
 }
 static int slope_compare(int64_t adx, int64_t ady, int64_t bdx, int64_t bdy)
@@ -504,6 +512,124 @@ static int slope_compare_sgn(double dx1, double dy1, double dx2, double dy2)
     double c = dx1 * dy2 - dx2 * dy1;
     return c > 0 ? 1 : c < 0 ? -1 : 0;
 }
+
+/* ---- pen (cairo-pen.c): a polygonal circle of radius half_width under the CTM, fine enough for `tolerance` */
+static int mat_has_unity_scale(const mat_t *m)
+{
+    const double eps = 1.0 / 256.0;
+    double det = mat_det(m);
+    if (fabs(det * det - 1.0) < eps) {
+        if (fabs(m->xy) < eps && fabs(m->yx) < eps) return 1;
+        if (fabs(m->xx) < eps && fabs(m->yy) < eps) return 1;
+    }
+    return 0;
+}
+static double mat_circle_major_axis(const mat_t *m, double radius)
+{
+    if (mat_has_unity_scale(m)) return radius;
+    double a = m->xx, b = m->yx, c = m->xy, d = m->yy;
+    double i = a * a + b * b, j = c * c + d * d;
+    double f = 0.5 * (i + j), g = 0.5 * (i - j), h = a * c + b * d;
+    return radius * sqrt(f + hypot(g, h));
+}
+static int pen_vertices_needed(double tolerance, double radius, const mat_t *m)
+{
+    double major_axis = mat_circle_major_axis(m, radius);
+    int n;
+    if (tolerance >= 4 * major_axis) n = 1;
+    else if (tolerance >= major_axis) n = 4;
+    else {
+        n = (int)ceil(2 * M_PI / acos(1 - tolerance / major_axis));
+        if (n % 2) n++;
+        if (n < 4) n = 4;
+    }
+    return n;
+}
+static void pen_init(pen_t *pen, double radius, double tolerance, const mat_t *ctm)
+{
+    int reflect = mat_det(ctm) < 0.0;
+    pen->n = pen_vertices_needed(tolerance, radius, ctm);
+    pen->v = malloc(sizeof(pen_vertex_t) * pen->n);
+    for (int i = 0; i < pen->n; i++) {
+        double theta = 2 * M_PI * i / (double)pen->n, dx, dy;
+        dx = radius * cos(reflect ? -theta : theta);
+        dy = radius * sin(reflect ? -theta : theta);
+        mat_distance(ctm, &dx, &dy);
+        pen->v[i].pt.x = fx_from_double(dx);
+        pen->v[i].pt.y = fx_from_double(dy);
+    }
+    for (int i = 0; i < pen->n; i++) {
+        const pen_vertex_t *prev = &pen->v[(i + pen->n - 1) % pen->n], *next = &pen->v[(i + 1) % pen->n];
+        pen_vertex_t *v = &pen->v[i];
+        v->cw_dx = (int64_t)v->pt.x - prev->pt.x; v->cw_dy = (int64_t)v->pt.y - prev->pt.y;
+        v->ccw_dx = (int64_t)next->pt.x - v->pt.x; v->ccw_dy = (int64_t)next->pt.y - v->pt.y;
+    }
+}
+static void pen_find_active_cw(const pen_t *pen, int64_t idx, int64_t idy, int64_t odx, int64_t ody, int *start, int *stop)
+{
+    int lo = 0, hi = pen->n, i = (lo + hi) >> 1;
+    do {
+        if (slope_compare(pen->v[i].cw_dx, pen->v[i].cw_dy, idx, idy) < 0) lo = i; else hi = i;
+        i = (lo + hi) >> 1;
+    } while (hi - lo > 1);
+    if (slope_compare(pen->v[i].cw_dx, pen->v[i].cw_dy, idx, idy) < 0)
+        if (++i == pen->n) i = 0;
+    *start = i;
+    if (slope_compare(odx, ody, pen->v[i].ccw_dx, pen->v[i].ccw_dy) >= 0) {
+        lo = i; hi = i + pen->n; i = (lo + hi) >> 1;
+        do {
+            int j = i; if (j >= pen->n) j -= pen->n;
+            if (slope_compare(pen->v[j].cw_dx, pen->v[j].cw_dy, odx, ody) > 0) hi = i; else lo = i;
+            i = (lo + hi) >> 1;
+        } while (hi - lo > 1);
+        if (i >= pen->n) i -= pen->n;
+    }
+    *stop = i;
+}
+static void pen_find_active_ccw(const pen_t *pen, int64_t idx, int64_t idy, int64_t odx, int64_t ody, int *start, int *stop)
+{
+    int lo = 0, hi = pen->n, i = (lo + hi) >> 1;
+    do {
+        if (slope_compare(idx, idy, pen->v[i].ccw_dx, pen->v[i].ccw_dy) < 0) lo = i; else hi = i;
+        i = (lo + hi) >> 1;
+    } while (hi - lo > 1);
+    if (slope_compare(idx, idy, pen->v[i].ccw_dx, pen->v[i].ccw_dy) < 0)
+        if (++i == pen->n) i = 0;
+    *start = i;
+    if (slope_compare(pen->v[i].cw_dx, pen->v[i].cw_dy, odx, ody) <= 0) {
+        lo = i; hi = i + pen->n; i = (lo + hi) >> 1;
+        do {
+            int j = i; if (j >= pen->n) j -= pen->n;
+            if (slope_compare(odx, ody, pen->v[j].ccw_dx, pen->v[j].ccw_dy) > 0) hi = i; else lo = i;
+            i = (lo + hi) >> 1;
+        } while (hi - lo > 1);
+        if (i >= pen->n) i -= pen->n;
+    }
+    *stop = i;
+}
+static void add_fan(stroker_t *s, int64_t idx, int64_t idy, int64_t odx, int64_t ody, const pt_t *mid, int clockwise, contour_t *c)
+{
+    const pen_t *pen = &s->pen;
+    int start, stop;
+    if (s->has_bounds && !(s->b1.x <= mid->x && mid->x <= s->b2.x && s->b1.y <= mid->y && mid->y <= s->b2.y)) return;
+    if (clockwise) {
+        pen_find_active_cw(pen, idx, idy, odx, ody, &start, &stop);
+        while (start != stop) {
+            pt_t p = { mid->x + pen->v[start].pt.x, mid->y + pen->v[start].pt.y };
+            contour_add_point(s, c, &p);
+            if (++start == pen->n) start = 0;
+        }
+    } else {
+        pen_find_active_ccw(pen, idx, idy, odx, ody, &start, &stop);
+        while (start != stop) {
+            pt_t p = { mid->x + pen->v[start].pt.x, mid->y + pen->v[start].pt.y };
+            contour_add_point(s, c, &p);
+            if (start-- == 0) start += pen->n;
+        }
+    }
+}
+static int join_is_clockwise(const face_t *in, const face_t *out) { return slope_compare(in->dvx, in->dvy, out->dvx, out->dvy) < 0; }
+
 static void inner_join(stroker_t *s, const face_t *in, const face_t *out, int clockwise)
 {
     contour_t *inner = clockwise ? &s->ccw : &s->cw;
@@ -511,58 +637,118 @@ static void inner_join(stroker_t *s, const face_t *in, const face_t *out, int cl
     contour_add_point(s, inner, &in->point);
     contour_add_point(s, inner, outpt);
 }
+static void inner_close(stroker_t *s, const face_t *in, const face_t *out)
+{
+    int clockwise = join_is_clockwise(in, out);
+    contour_t *inner = clockwise ? &s->ccw : &s->cw;
+    const pt_t *inpt = clockwise ? &out->ccw : &out->cw;
+    contour_add_point(s, inner, &in->point);
+    contour_add_point(s, inner, inpt);
+    inner->p[0] = inner->p[inner->n - 1];
+}
+/* the miter point when the limit allows it and it lies between the two faces; 0 otherwise */
+static int miter_point(stroker_t *s, const face_t *in, const face_t *out, const pt_t *inpt, const pt_t *outpt, pt_t *res)
+{
+    double in_dot_out = in->dsx * out->dsx + in->dsy * out->dsy, ml = s->miter_limit;
+    if (2 <= ml * ml * (1 + in_dot_out)) {
+        double x1 = fx_to_double(inpt->x), y1 = fx_to_double(inpt->y), dx1 = in->dsx, dy1 = in->dsy;
+        double x2 = fx_to_double(outpt->x), y2 = fx_to_double(outpt->y), dx2 = out->dsx, dy2 = out->dsy;
+        double my = (((x2 - x1) * dy1 * dy2 - y2 * dx2 * dy1 + y1 * dx1 * dy2) / (dx1 * dy2 - dx2 * dy1));
+        double mx = fabs(dy1) >= fabs(dy2) ? (my - y1) * dx1 / dy1 + x1 : (my - y2) * dx2 / dy2 + x2;
+        double ix = fx_to_double(in->point.x), iy = fx_to_double(in->point.y);
+        double fdx1 = x1 - ix, fdy1 = y1 - iy, fdx2 = x2 - ix, fdy2 = y2 - iy, mdx = mx - ix, mdy = my - iy;
+        if (slope_compare_sgn(fdx1, fdy1, mdx, mdy) != slope_compare_sgn(fdx2, fdy2, mdx, mdy)) {
+            res->x = fx_from_double(mx); res->y = fx_from_double(my);
+            return 1;
+        }
+    }
+    return 0;
+}
+static void outer_close(stroker_t *s, const face_t *in, const face_t *out)
+{
+    if (in->cw.x == out->cw.x && in->cw.y == out->cw.y && in->ccw.x == out->ccw.x && in->ccw.y == out->ccw.y) return;
+    int clockwise = join_is_clockwise(in, out);
+    const pt_t *inpt = clockwise ? &in->cw : &in->ccw, *outpt = clockwise ? &out->cw : &out->ccw;
+    contour_t *outer = clockwise ? &s->cw : &s->ccw;
+    if (within_tolerance(inpt, outpt, s->contour_tol)) { outer->p[0] = outer->p[outer->n - 1]; return; }
+    if (s->join == 1 && (in->dsx * out->dsx + in->dsy * out->dsy) < s->spline_cusp_tol) {
+        add_fan(s, in->dvx, in->dvy, out->dvx, out->dvy, &in->point, clockwise, outer);
+    } else if (s->join != 2) {                           /* MITER, or a ROUND join too flat for a fan: cairo falls through to the
+                                                            miter code; its tip may leave the approximate extents (see op_bounds) */
+        pt_t p;
+        if (miter_point(s, in, out, inpt, outpt, &p)) {
+            outer->p[outer->n - 1] = p;
+            outer->p[0] = p;
+            return;
+        }
+    }
+    contour_add_point(s, outer, outpt);
+}
 static void outer_join(stroker_t *s, const face_t *in, const face_t *out, int clockwise)
 {
     if (in->cw.x == out->cw.x && in->cw.y == out->cw.y && in->ccw.x == out->ccw.x && in->ccw.y == out->ccw.y) return;
     const pt_t *inpt = clockwise ? &in->cw : &in->ccw, *outpt = clockwise ? &out->cw : &out->ccw;
     contour_t *outer = clockwise ? &s->cw : &s->ccw;
-    if (s->join == 1) { s->unsupported = 1; }           /* ROUND joins: pen not restated */
-    if (s->join == 0) {                                  /* MITER */
-        double in_dot_out = in->dsx * out->dsx + in->dsy * out->dsy, ml = s->miter_limit;
-        if (2 <= ml * ml * (1 + in_dot_out)) {
-            double x1 = fx_to_double(inpt->x), y1 = fx_to_double(inpt->y), dx1 = in->dsx, dy1 = in->dsy;
-            double x2 = fx_to_double(outpt->x), y2 = fx_to_double(outpt->y), dx2 = out->dsx, dy2 = out->dsy;
-            double my = (((x2 - x1) * dy1 * dy2 - y2 * dx2 * dy1 + y1 * dx1 * dy2) / (dx1 * dy2 - dx2 * dy1));
-            double mx = fabs(dy1) >= fabs(dy2) ? (my - y1) * dx1 / dy1 + x1 : (my - y2) * dx2 / dy2 + x2;
-            double ix = fx_to_double(in->point.x), iy = fx_to_double(in->point.y);
-            double fdx1 = x1 - ix, fdy1 = y1 - iy, fdx2 = x2 - ix, fdy2 = y2 - iy, mdx = mx - ix, mdy = my - iy;
-            if (slope_compare_sgn(fdx1, fdy1, mdx, mdy) != slope_compare_sgn(fdx2, fdy2, mdx, mdy)) {
-                pt_t p = { fx_from_double(mx), fx_from_double(my) };
-                outer->p[outer->n - 1] = p;
-                return;
-            }
-        }
+    if (s->join == 1) {                                  /* ROUND: fan around the common midpoint */
+        add_fan(s, in->dvx, in->dvy, out->dvx, out->dvy, &in->point, clockwise, outer);
+    } else if (s->join == 0) {                           /* MITER */
+        pt_t p;
+        if (miter_point(s, in, out, inpt, outpt, &p)) { outer->p[outer->n - 1] = p; return; }
     }
-    contour_add_point(s, outer, outpt);                  /* BEVEL, or a rejected miter */
+    contour_add_point(s, outer, outpt);                  /* BEVEL, a rejected miter, or the end of the fan */
 }
 static void add_cap(stroker_t *s, const face_t *f, contour_t *c)
 {
-    if (s->cap != 0) s->unsupported = 1;                 /* only BUTT is restated */
+    if (s->cap == 1) {                                   /* ROUND */
+        add_fan(s, f->dvx, f->dvy, -f->dvx, -f->dvy, &f->point, 0, c);
+    } else if (s->cap == 2) {                            /* SQUARE */
+        double dx = f->usx * s->half_width, dy = f->usy * s->half_width;
+        mat_distance(s->ctm, &dx, &dy);
+        fx_t vx = fx_from_double(dx), vy = fx_from_double(dy);
+        pt_t p = { f->ccw.x + vx, f->ccw.y + vy };
+        contour_add_point(s, c, &p);
+        p.x = f->cw.x + vx; p.y = f->cw.y + vy;
+        contour_add_point(s, c, &p);
+    }
     contour_add_point(s, c, &f->cw);
+}
+static void add_leading_cap(stroker_t *s, const face_t *face, contour_t *c)
+{
+    face_t r = *face;
+    r.usx = -r.usx; r.usy = -r.usy; r.dvx = -r.dvx; r.dvy = -r.dvy;
+    pt_t t = r.cw; r.cw = r.ccw; r.ccw = t;
+    add_cap(s, &r, c);
 }
 static void add_caps(stroker_t *s)
 {
-    if (s->has_initial_sub_path && !s->has_first_face && !s->has_current_face && s->cap == 1) { s->unsupported = 1; return; }
-    if (s->has_current_face) add_cap(s, &s->current_face, &s->ccw);
-    polygon_add_contour(s->g, &s->ccw);
-    contour_reset(&s->ccw);
-    if (s->has_first_face) {
-        face_t r = s->first_face;
-        contour_push(&s->ccw, &s->first_face.cw);
-        r.dvx = -r.dvx; r.dvy = -r.dvy; r.dsx = -r.dsx; r.dsy = -r.dsy;
-        pt_t t = r.cw; r.cw = r.ccw; r.ccw = t;
-        add_cap(s, &r, &s->ccw);
+    if (s->has_initial_sub_path && !s->has_first_face && !s->has_current_face && s->cap == 1) {
+        /* degenerate sub-path with round caps: a dot */
+        face_t face;
+        compute_face(&s->first_point, 256, 0, s, &face);
+        add_leading_cap(s, &face, &s->ccw);
+        add_cap(s, &face, &s->ccw);
+        if (s->ccw.n) { pt_t first = s->ccw.p[0]; contour_push(&s->ccw, &first); }
         polygon_add_contour(s->g, &s->ccw);
         contour_reset(&s->ccw);
+    } else {
+        if (s->has_current_face) add_cap(s, &s->current_face, &s->ccw);
+        polygon_add_contour(s->g, &s->ccw);
+        contour_reset(&s->ccw);
+        if (s->has_first_face) {
+            contour_push(&s->ccw, &s->first_face.cw);
+            add_leading_cap(s, &s->first_face, &s->ccw);
+            polygon_add_contour(s->g, &s->ccw);
+            contour_reset(&s->ccw);
+        }
+        polygon_add_contour(s->g, &s->cw);
+        contour_reset(&s->cw);
     }
-    polygon_add_contour(s->g, &s->cw);
 }
 static void stroker_move_to(stroker_t *s, const pt_t *p)
 {
     add_caps(s);
     s->has_first_face = s->has_current_face = s->has_initial_sub_path = 0;
     s->first_point = *p;
-    contour_reset(&s->cw); contour_reset(&s->ccw);
     s->current_face.point = *p;
 }
 static void stroker_line_to(void *closure, const pt_t *point)
@@ -597,25 +783,198 @@ static void stroker_line_to(void *closure, const pt_t *point)
     contour_add_point(s, &s->cw, &s->current_face.cw);
     contour_add_point(s, &s->ccw, &s->current_face.ccw);
 }
-/* closed sub-paths and curves inside strokes are outside the validated subset:
-   curves are flattened with the fill flattener (cairo adds pen-based cusp handling) */
+/* one point of a flattened curve with the curve's tangent there (cairo spline_to) */
+static void stroker_spline_to(stroker_t *s, const pt_t *point, int64_t tdx, int64_t tdy)
+{
+    face_t face;
+    if ((tdx | tdy) == 0) {                              /* cusp: turn around with a fan */
+        face = s->current_face;
+        face.usx = -face.usx; face.usy = -face.usy; face.dvx = -face.dvx; face.dvy = -face.dvy;
+        pt_t t = face.cw; face.cw = face.ccw; face.ccw = t;
+        int clockwise = join_is_clockwise(&s->current_face, &face);
+        contour_t *outer = clockwise ? &s->cw : &s->ccw;
+        add_fan(s, s->current_face.dvx, s->current_face.dvy, face.dvx, face.dvy, &s->current_face.point, clockwise, outer);
+    } else {
+        compute_face(point, tdx, tdy, s, &face);
+        if ((face.dsx * s->current_face.dsx + face.dsy * s->current_face.dsy) < s->spline_cusp_tol) {
+            int clockwise = join_is_clockwise(&s->current_face, &face);
+            s->current_face.cw.x += face.point.x - s->current_face.point.x;
+            s->current_face.cw.y += face.point.y - s->current_face.point.y;
+            contour_add_point(s, &s->cw, &s->current_face.cw);
+            s->current_face.ccw.x += face.point.x - s->current_face.point.x;
+            s->current_face.ccw.y += face.point.y - s->current_face.point.y;
+            contour_add_point(s, &s->ccw, &s->current_face.ccw);
+            contour_t *outer = clockwise ? &s->cw : &s->ccw;
+            add_fan(s, s->current_face.dvx, s->current_face.dvy, face.dvx, face.dvy, &s->current_face.point, clockwise, outer);
+        }
+        contour_add_point(s, &s->cw, &face.cw);
+        contour_add_point(s, &s->ccw, &face.ccw);
+    }
+    s->current_face = face;
+}
+typedef struct { stroker_t *s; pt_t last; } spline_tan_t;
+static void spline_tan_add(spline_tan_t *sp, const pt_t *p, const pt_t *knot)
+{
+    if (p->x == sp->last.x && p->y == sp->last.y) return;
+    sp->last = *p;
+    stroker_spline_to(sp->s, p, (int64_t)knot->x - p->x, (int64_t)knot->y - p->y);
+}
+static void spline_tan_decompose_into(knots_t *s1, double tol2, spline_tan_t *out)
+{
+    if (spline_error_squared(s1) < tol2) { spline_tan_add(out, &s1->a, &s1->b); return; }
+    knots_t s2;
+    pt_t ab, bc, cd, abbc, bccd, fin;
+    lerp_half(&s1->a, &s1->b, &ab); lerp_half(&s1->b, &s1->c, &bc); lerp_half(&s1->c, &s1->d, &cd);
+    lerp_half(&ab, &bc, &abbc); lerp_half(&bc, &cd, &bccd); lerp_half(&abbc, &bccd, &fin);
+    s2.a = fin; s2.b = bccd; s2.c = cd; s2.d = s1->d;
+    s1->b = ab; s1->c = abbc; s1->d = fin;
+    spline_tan_decompose_into(s1, tol2, out);
+    spline_tan_decompose_into(&s2, tol2, out);
+}
+static void stroker_curve_to(stroker_t *s, const pt_t *b, const pt_t *c, const pt_t *d)
+{
+    const pt_t a = s->current_face.point;
+    if (s->has_bounds && !spline_intersects(&a, b, c, d, &s->b1, &s->b2)) { stroker_line_to(s, d); return; }
+    /* _cairo_spline_init: initial / final slopes; degenerate splines are lines */
+    if (a.x == b->x && a.y == b->y && c->x == d->x && c->y == d->y) { stroker_line_to(s, d); return; }
+    int64_t isx, isy, fsx, fsy;
+    if (a.x != b->x || a.y != b->y) { isx = (int64_t)b->x - a.x; isy = (int64_t)b->y - a.y; }
+    else if (a.x != c->x || a.y != c->y) { isx = (int64_t)c->x - a.x; isy = (int64_t)c->y - a.y; }
+    else if (a.x != d->x || a.y != d->y) { isx = (int64_t)d->x - a.x; isy = (int64_t)d->y - a.y; }
+    else { stroker_line_to(s, d); return; }
+    if (c->x != d->x || c->y != d->y) { fsx = (int64_t)d->x - c->x; fsy = (int64_t)d->y - c->y; }
+    else if (b->x != d->x || b->y != d->y) { fsx = (int64_t)d->x - b->x; fsy = (int64_t)d->y - b->y; }
+    else { stroker_line_to(s, d); return; }
+    face_t face;
+    compute_face(&a, isx, isy, s, &face);
+    if (s->has_current_face) {
+        int clockwise = join_is_clockwise(&s->current_face, &face);
+        outer_join(s, &s->current_face, &face, clockwise);
+        inner_join(s, &s->current_face, &face, clockwise);
+    } else {
+        if (!s->has_first_face) { s->first_face = face; s->has_first_face = 1; }
+        s->has_current_face = 1;
+        contour_add_point(s, &s->cw, &face.cw);
+        contour_add_point(s, &s->ccw, &face.ccw);
+    }
+    s->current_face = face;
+    spline_tan_t sp = { s, a };
+    knots_t k = { a, *b, *c, *d };
+    spline_tan_decompose_into(&k, s->tol * s->tol, &sp);
+    stroker_spline_to(s, d, fsx, fsy);
+}
+static void stroker_close_path(stroker_t *s)
+{
+    stroker_line_to(s, &s->first_point);
+    if (s->has_first_face && s->has_current_face) {
+        outer_close(s, &s->current_face, &s->first_face);
+        inner_close(s, &s->current_face, &s->first_face);
+        polygon_add_contour(s->g, &s->cw);
+        polygon_add_contour(s->g, &s->ccw);
+        contour_reset(&s->cw); contour_reset(&s->ccw);
+    } else
+        add_caps(s);
+    s->has_initial_sub_path = 0;
+    s->has_first_face = 0;
+    s->has_current_face = 0;
+}
 static int path_stroke_to_polygon(const path_t *p, stroker_t *s)
 {
     const pt_t *pts = p->pts;
+    s->spline_cusp_tol = 1 - s->tol / s->half_width;
+    s->spline_cusp_tol *= s->spline_cusp_tol;
+    s->spline_cusp_tol *= 2;
+    s->spline_cusp_tol -= 1;
+    s->pen.n = 0; s->pen.v = NULL;
+    pen_init(&s->pen, s->half_width, s->tol, s->ctm);    /* >= 4 vertices: the caller dropped strokes whose pen degenerates */
     for (int i = 0; i < p->nops; i++) {
         switch (p->ops[i]) {
         case OP_MOVE: stroker_move_to(s, &pts[0]); pts += 1; break;
         case OP_LINE: stroker_line_to(s, &pts[0]); pts += 1; break;
-        case OP_CURVE:
-            s->unsupported = 1;
-            if (!spline_flatten(&s->current_face.point, &pts[0], &pts[1], &pts[2], s->tol, stroker_line_to, s))
-                stroker_line_to(s, &pts[2]);
-            pts += 3; break;
-        case OP_CLOSE: s->unsupported = 1; stroker_line_to(s, &s->first_point); break;
+        case OP_CURVE: stroker_curve_to(s, &pts[0], &pts[1], &pts[2]); pts += 3; break;
+        case OP_CLOSE: stroker_close_path(s); break;
         }
     }
     add_caps(s);
+    free(s->pen.v); s->pen.v = NULL;
     return s->unsupported;
+}
+
+/* ---- rectilinear strokes (cairo-path-stroke-boxes.c, undashed): one box per segment, lengthened for joins / square caps;
+        the union of the boxes is what gets painted (cairo tessellates them into disjoint boxes, A.6 sums exact areas) */
+typedef struct { pt_t p1, p2; int horizontal; } rseg_t;
+typedef struct {
+    polygon_t *g; fx_t hx, hy; int cap;
+    rseg_t *seg; int n, capn;
+    pt_t cur, first; int open_sub_path;
+} rstroker_t;
+static void rs_add_box(polygon_t *g, fx_t x1, fx_t y1, fx_t x2, fx_t y2)
+{
+    if (x1 == x2 || y1 == y2) return;
+    pt_t a = { x1, y1 }, b = { x1, y2 }, c2 = { x2, y1 }, d = { x2, y2 };
+    polygon_add_edge(g, &a, &b, 1);
+    polygon_add_edge(g, &c2, &d, -1);
+}
+static void rs_emit_segments(rstroker_t *r)
+{
+    for (int i = 0; i < r->n; i++) {
+        pt_t a = r->seg[i].p1, b = r->seg[i].p2;
+        int j = i == 0 ? r->n - 1 : i - 1;
+        int lengthen_initial = r->seg[i].horizontal != r->seg[j].horizontal;
+        j = i == r->n - 1 ? 0 : i + 1;
+        int lengthen_final = r->seg[i].horizontal != r->seg[j].horizontal;
+        if (r->open_sub_path) {
+            if (i == 0) lengthen_initial = r->cap != 0;
+            if (i == r->n - 1) lengthen_final = r->cap != 0;
+        }
+        if (lengthen_initial | lengthen_final) {
+            if (a.y == b.y) {
+                if (a.x < b.x) { if (lengthen_initial) a.x -= r->hx; if (lengthen_final) b.x += r->hx; }
+                else { if (lengthen_initial) a.x += r->hx; if (lengthen_final) b.x -= r->hx; }
+            } else {
+                if (a.y < b.y) { if (lengthen_initial) a.y -= r->hy; if (lengthen_final) b.y += r->hy; }
+                else { if (lengthen_initial) a.y += r->hy; if (lengthen_final) b.y -= r->hy; }
+            }
+        }
+        if (a.y == b.y) { a.y -= r->hy; b.y += r->hy; } else { a.x -= r->hx; b.x += r->hx; }
+        rs_add_box(r->g, a.x < b.x ? a.x : b.x, a.y < b.y ? a.y : b.y, a.x < b.x ? b.x : a.x, a.y < b.y ? b.y : a.y);
+    }
+    r->n = 0;
+}
+static void rs_line_to(rstroker_t *r, const pt_t *b)
+{
+    const pt_t a = r->cur;
+    if (a.x == b->x && a.y == b->y) return;
+    if (r->n == r->capn) { r->capn = r->capn ? 2 * r->capn : 16; r->seg = realloc(r->seg, sizeof(rseg_t) * r->capn); }
+    r->seg[r->n].p1 = a; r->seg[r->n].p2 = *b; r->seg[r->n].horizontal = a.y == b->y; r->n++;
+    r->cur = *b;
+    r->open_sub_path = 1;
+}
+/* returns 0 when cairo's rectilinear stroker declines (the caller then uses the polygon stroker) */
+static int path_stroke_rectilinear(const path_t *p, const mat_t *ctm, double line_width, int join, int cap, double miter_limit, polygon_t *g)
+{
+    if (join != 0) return 0;
+    if (miter_limit < M_SQRT2) return 0;
+    if (!(cap == 0 || cap == 2)) return 0;
+    if (!(ctm->xy == 0.0 && ctm->yx == 0.0)) return 0;   /* _cairo_matrix_is_scale */
+    rstroker_t r; memset(&r, 0, sizeof(r));
+    r.g = g; r.cap = cap;
+    r.hx = fx_from_double(fabs(ctm->xx) * line_width / 2.0);
+    r.hy = fx_from_double(fabs(ctm->yy) * line_width / 2.0);
+    const pt_t *pts = p->pts;
+    for (int i = 0; i < p->nops; i++) {
+        switch (p->ops[i]) {
+        case OP_MOVE: rs_emit_segments(&r); r.cur = r.first = pts[0]; r.open_sub_path = 0; pts += 1; break;
+        case OP_LINE: rs_line_to(&r, &pts[0]); pts += 1; break;
+        case OP_CURVE: pts += 3; break;                 /* cannot happen: the path is rectilinear */
+        case OP_CLOSE:
+            if (r.open_sub_path) { rs_line_to(&r, &r.first); r.open_sub_path = 0; rs_emit_segments(&r); }
+            break;
+        }
+    }
+    rs_emit_segments(&r);
+    free(r.seg);
+    return 1;
 }
 
 /* ------------------------------------------------------------------ sources + surface */
@@ -636,6 +995,7 @@ typedef struct {
 
 typedef struct swfo_ctx {
     int w, h; uint32_t *px; int is_clear;
+    int bx0, by0, bx1, by1;                 /* bounded rectangle of the current operation (op_bounds) */
     gstate_t gs[64]; int ngs;
     path_t path;
     source_t src;
@@ -1146,6 +1506,9 @@ static int op_bounds(swfo_ctx *c, pt_t e1, pt_t e2, int *needs_limits)
     int x0 = fx_floor_i(e1.x), y0 = fx_floor_i(e1.y), x1 = fx_ceil_i(e2.x), y1 = fx_ceil_i(e2.y);
     *needs_limits = !(x0 >= 0 && y0 >= 0 && x1 <= c->w && y1 <= c->h);
     if (x0 < 0) x0 = 0; if (y0 < 0) y0 = 0; if (x1 > c->w) x1 = c->w; if (y1 > c->h) y1 = c->h;
+    /* the operation is bounded by this rectangle: geometry the stroker produces outside it (a round join that fell
+       through to a miter at a closing corner) is not painted */
+    c->bx0 = x0; c->by0 = y0; c->bx1 = x1; c->by1 = y1;
     return x0 < x1 && y0 < y1;
 }
 static int source_is_clear(const source_t *s) { return s->kind == SRC_SOLID && (s->pixel >> 24) == 0; }
@@ -1173,7 +1536,8 @@ static void render_polygon(swfo_ctx *c, polygon_t *g, int even_odd)
     if (!g->n) return;
     int lerp_mode = source_is_opaque_solid(&c->src) || c->is_clear;
     int xmin = fx_floor_i(g->x1.x), xmax = fx_ceil_i(g->x2.x), ymin = fx_floor_i(g->x1.y), ymax = fx_ceil_i(g->x2.y);
-    if (xmin < 0) xmin = 0; if (ymin < 0) ymin = 0; if (xmax > c->w) xmax = c->w; if (ymax > c->h) ymax = c->h;
+    if (xmin < c->bx0) xmin = c->bx0; if (ymin < c->by0) ymin = c->by0; if (xmax > c->bx1) xmax = c->bx1; if (ymax > c->by1) ymax = c->by1;
+    if (xmin >= xmax || ymin >= ymax) return;
     tor_render(c, g, even_odd, lerp_mode, xmin, ymin, xmax, ymax);
 }
 
@@ -1211,12 +1575,15 @@ EXPORT int swfo_stroke_preserve(swfo_ctx *c)
     mat_t inv = gs->ctm;
     if (!mat_invert(&inv)) return 0;
     double hw = gs->line_width / 2.0;
+    /* _cairo_compositor_stroke: a pen that degenerates to one vertex (line width <= tolerance / 2 = 0.05 device pixels under
+       the CTM) means NOTHING_TO_DO for every stroker, rectilinear included; the surface stays untouched (probe-validated) */
+    if (pen_vertices_needed(0.1, hw, &gs->ctm) <= 1) return 0;
     /* _cairo_stroke_style_max_distance_from_path + _cairo_path_fixed_approximate_stroke_extents */
     double expansion = 0.5;
+    if (gs->cap == 2) expansion = M_SQRT1_2;
     if (gs->join == 0 && !p->stroke_is_rect && expansion < M_SQRT2 * gs->miter_limit) expansion = M_SQRT2 * gs->miter_limit;
     expansion *= gs->line_width;
-    int unity = (fabs(gs->ctm.xx) == 1.0 && fabs(gs->ctm.yy) == 1.0 && gs->ctm.xy == 0.0 && gs->ctm.yx == 0.0) ||
-                (fabs(gs->ctm.xy) == 1.0 && fabs(gs->ctm.yx) == 1.0 && gs->ctm.xx == 0.0 && gs->ctm.yy == 0.0);
+    int unity = mat_has_unity_scale(&gs->ctm);
     double gx = unity ? expansion : expansion * hypot(gs->ctm.xx, gs->ctm.xy);
     double gy = unity ? expansion : expansion * hypot(gs->ctm.yy, gs->ctm.yx);
     pt_t e1 = { p->e1.x - fx_from_double(gx), p->e1.y - fx_from_double(gy) };
@@ -1225,6 +1592,19 @@ EXPORT int swfo_stroke_preserve(swfo_ctx *c)
     if (!op_bounds(c, e1, e2, &needs_limits)) return 0;
     polygon_t g; memset(&g, 0, sizeof(g));
     pt_t l1 = { 0, 0 }, l2 = { c->w * 256, c->h * 256 };
+    if (p->stroke_is_rect) {
+        /* rectilinear path: cairo's box stroker, when it accepts the style; painted like a rectilinear fill (A.6) */
+        polygon_init(&g, 0, l1, l2);
+        if (path_stroke_rectilinear(p, &gs->ctm, gs->line_width, gs->join, gs->cap, gs->miter_limit, &g)) {
+            remember_polygon(c, &g, 1);
+            int lerp_mode = source_is_opaque_solid(&c->src) || c->is_clear;
+            boxes_render(c, &g, 0, lerp_mode);
+            free(g.e);
+            c->is_clear = 0;
+            return 0;
+        }
+        g.n = 0;
+    }
     polygon_init(&g, needs_limits, l1, l2);
     stroker_t s; memset(&s, 0, sizeof(s));
     s.cw.dir = 1; s.ccw.dir = -1;
@@ -1234,7 +1614,11 @@ EXPORT int swfo_stroke_preserve(swfo_ctx *c)
     s.half_width = hw; s.miter_limit = gs->miter_limit; s.tol = 0.1;
     s.join = gs->join; s.cap = gs->cap;
     { double t = 0.1 * 256.0; s.contour_tol = (int64_t)(t * t); }
-    if (p->stroke_is_rect) s.unsupported = 1;             /* rectilinear stroker not restated (A.4) */
+    if (needs_limits) {                                   /* stroker bounds: the limits grown by the style's reach */
+        s.has_bounds = 1;
+        s.b1.x = l1.x - fx_from_double(gx); s.b1.y = l1.y - fx_from_double(gy);
+        s.b2.x = l2.x + fx_from_double(gx); s.b2.y = l2.y + fx_from_double(gy);
+    }
     c->last_unsupported = path_stroke_to_polygon(p, &s);
     remember_polygon(c, &g, 0);
     render_polygon(c, &g, 0);
