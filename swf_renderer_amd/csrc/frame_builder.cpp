@@ -161,7 +161,7 @@ uint32_t FrameBuilder::push_solid(uint32_t pixel) {
     return uint32_t(styles_.size() - 1);
 }
 
-void FrameBuilder::emit_polygon(Polygon& poly, bool rectilinear, uint32_t style, bool opaque_solid) {
+void FrameBuilder::emit_polygon(Polygon& poly, bool rectilinear, uint32_t style, bool opaque_solid, int bx0, int by0, int bx1, int by1) {
     const bool lerp_blend = opaque_solid || surface_clear_;
     surface_clear_ = false;  // any drawing op that was not "nothing to do" dirties the surface
     if (poly.empty()) return;
@@ -171,10 +171,11 @@ void FrameBuilder::emit_polygon(Polygon& poly, bool rectilinear, uint32_t style,
     p.fill_rule = even_odd_ ? 1 : 0;
     p.style = style;
     p.lerp = lerp_blend ? 1 : 0;
-    p.x_min = std::max(floor_px(poly.ext_min().x), 0);
-    p.y_min = std::max(floor_px(poly.ext_min().y), 0);
-    p.x_max = std::min(ceil_px(poly.ext_max().x), int(w_));
-    p.y_max = std::min(ceil_px(poly.ext_max().y), int(h_));
+    // converter rectangle: the polygon's extents inside the operation's bounded rectangle (the frame for fills)
+    p.x_min = std::max(floor_px(poly.ext_min().x), std::max(bx0, 0));
+    p.y_min = std::max(floor_px(poly.ext_min().y), std::max(by0, 0));
+    p.x_max = std::min(ceil_px(poly.ext_max().x), std::min(bx1, int(w_)));
+    p.y_max = std::min(ceil_px(poly.ext_max().y), std::min(by1, int(h_)));
     if (p.x_min >= p.x_max || p.y_min >= p.y_max) return;
     if (rectilinear) {
         p.kind = SWFR_PATH_BOXES;
@@ -267,13 +268,18 @@ void FrameBuilder::emit_stroke(const StyledPath& p, bool morph, double ratio) {
     if (morph) st.cap = st.join = 1;  // lineCap = lineJoin = "round" (canvas-renderer.ts:263-264)
     if ((px >> 24) == 0) return;
     if (path_.empty_extents()) return;
+    // _cairo_compositor_stroke: a pen that degenerates to one vertex (line width <= tolerance/2 = 0.05 device pixels under the CTM)
+    // paints nothing, whatever the stroker; the surface stays untouched
+    if (stroke_pen_vertices(st.line_width, st.ctm) <= 1) return;
     // approximate stroke extents: path box grown by the style's maximum distance from the path
     double expansion = 0.5;
+    if (st.cap == 2) expansion = M_SQRT1_2;
     if (st.join == 0 && !path_.stroke_is_rectilinear() && expansion < M_SQRT2 * 10.0) expansion = M_SQRT2 * 10.0;
     expansion *= st.line_width;
     const Affine& c = st.ctm;
-    const bool unity = (std::fabs(c.xx) == 1.0 && std::fabs(c.yy) == 1.0 && c.xy == 0.0 && c.yx == 0.0) ||
-                       (std::fabs(c.xy) == 1.0 && std::fabs(c.yx) == 1.0 && c.xx == 0.0 && c.yy == 0.0);
+    const double eps = 1.0 / 256.0, det = c.det();
+    const bool unity = std::fabs(det * det - 1.0) < eps &&
+                       ((std::fabs(c.xy) < eps && std::fabs(c.yx) < eps) || (std::fabs(c.xx) < eps && std::fabs(c.yy) < eps));
     const double gx = unity ? expansion : expansion * std::hypot(c.xx, c.xy);
     const double gy = unity ? expansion : expansion * std::hypot(c.yy, c.yx);
     Pt lo = path_.box_min(), hi = path_.box_max();
@@ -281,20 +287,41 @@ void FrameBuilder::emit_stroke(const StyledPath& p, bool morph, double ratio) {
     hi.x += to_fixed(gx); hi.y += to_fixed(gy);
     bool needs_clip = false;
     if (!frame_bounds(lo, hi, needs_clip)) return;
-    Polygon poly;
-    poly.reset(needs_clip, Pt{0, 0}, Pt{fixed_t(w_) * 256, fixed_t(h_) * 256});
+    // the operation is bounded by these extents (rounded out, inside the frame): what the stroker produces beyond them is not painted
+    const int bx0 = std::max(floor_px(lo.x), 0), by0 = std::max(floor_px(lo.y), 0);
+    const int bx1 = std::min(ceil_px(hi.x), int(w_)), by1 = std::min(ceil_px(hi.y), int(h_));
+    const Pt frame_lo{0, 0}, frame_hi{fixed_t(w_) * 256, fixed_t(h_) * 256};
     StrokeParams sp;
     sp.line_width = st.line_width;
     sp.cap = st.cap;
     sp.join = st.join;
-    if (!stroke_to_polygon(path_, sp, st.ctm, poly))
-        throw StatusError{SWFR_ERR_NOT_IMPLEMENTED, "stroke needs round joins/caps, closed sub-paths, curves or the rectilinear stroker"};
     const bool opaque = (px >> 24) == 0xff;
-    const uint32_t style_index = push_solid(px);
     // strokes are filled non-zero regardless of the configured fill rule
     const bool saved = even_odd_;
     even_odd_ = false;
-    emit_polygon(poly, false, style_index, opaque);
+    Polygon poly;
+    bool done = false;
+    if (path_.stroke_is_rectilinear()) {
+        // Cairo's box stroker when it accepts the style: the union of one box per segment, painted like a rectilinear fill
+        poly.reset(needs_clip, frame_lo, frame_hi);
+        if (stroke_rectilinear_to_boxes(path_, sp, st.ctm, poly)) {
+            emit_polygon(poly, true, push_solid(px), opaque, bx0, by0, bx1, by1);
+            done = true;
+        }
+    }
+    if (!done) {
+        poly.reset(needs_clip, frame_lo, frame_hi);
+        if (needs_clip) {
+            sp.has_bounds = true;
+            sp.bounds_lo = Pt{frame_lo.x - to_fixed(gx), frame_lo.y - to_fixed(gy)};
+            sp.bounds_hi = Pt{frame_hi.x + to_fixed(gx), frame_hi.y + to_fixed(gy)};
+        }
+        if (!stroke_to_polygon(path_, sp, st.ctm, poly)) {
+            even_odd_ = saved;
+            return;                                            // singular CTM: nothing can be stroked
+        }
+        emit_polygon(poly, false, push_solid(px), opaque, bx0, by0, bx1, by1);
+    }
     even_odd_ = saved;
 }
 

@@ -50,7 +50,7 @@ private:
     void trace(const StyledPath& p, bool morph, double ratio);
     void emit_fill(const OwnedFill& f, bool morph, double ratio);
     void emit_stroke(const StyledPath& p, bool morph, double ratio);
-    void emit_polygon(Polygon& poly, bool rectilinear, uint32_t style, bool opaque_solid);
+    void emit_polygon(Polygon& poly, bool rectilinear, uint32_t style, bool opaque_solid, int bx0 = 0, int by0 = 0, int bx1 = INT32_MAX, int by1 = INT32_MAX);
     uint32_t push_solid(uint32_t pixel);
     bool frame_bounds(Pt lo, Pt hi, bool& needs_clip) const;
     static Affine matrix_of(const swfr_matrix& m);

@@ -2,8 +2,9 @@
 //
 // Everything the reference's Canvas2D backend does to a path before scan conversion happens here
 // on the CPU (north star: "decodes shape records to an edge list on CPU"): CTM application and
-// 24.8 quantisation, collinear merge, cubic flattening, stroke expansion (miter/bevel joins, butt
-// caps), clipping of edges against the frame, and tessellation of rectilinear paths into boxes.
+// 24.8 quantisation, collinear merge, cubic flattening, stroke expansion (pen, all joins and caps,
+// closed sub-paths, curves, rectilinear strokes), clipping of edges against the frame, and
+// tessellation of rectilinear paths into boxes.
 // The arithmetic follows SURVEY.md Appendix A.1-A.4, A.5b, A.6, A.8 (Cairo 1.16 as used through
 // ts/src/lib/renderers/canvas-renderer.ts:207-350); results feed swfr_edge/swfr_path arrays.
 #pragma once
@@ -97,8 +98,12 @@ private:
 struct StrokeParams {
     double line_width = 1.0;
     double miter_limit = 10.0;
-    int cap = 0;   // 0 butt (only butt is implemented; reference static shapes use the Canvas default)
-    int join = 0;  // 0 miter, 1 round (not implemented), 2 bevel
+    int cap = 0;   // 0 butt, 1 round, 2 square (cairo_line_cap_t)
+    int join = 0;  // 0 miter, 1 round, 2 bevel (cairo_line_join_t)
+    // Stroker bounds (Cairo sets them when the stroke may leave the surface: the limits grown by the style's reach):
+    // fans whose centre lies outside are skipped, curves that cannot touch the box become chords.
+    bool has_bounds = false;
+    Pt bounds_lo{}, bounds_hi{};
 };
 
 constexpr double kTolerance = 0.1;  // Cairo's default flattening tolerance (device pixels)
@@ -107,9 +112,16 @@ constexpr double kTolerance = 0.1;  // Cairo's default flattening tolerance (dev
 void fill_to_polygon(const DevicePath& path, Polygon& out);
 // Same, for a polygon that is being clipped to [lo,hi]: curves that cannot touch the box become chords.
 void fill_to_polygon_clipped(const DevicePath& path, Polygon& out, Pt lo, Pt hi);
-// Stroke: open sub-paths -> outline polygon (filled non-zero).  Returns false when the path needs
-// features outside the implemented subset (round joins/caps, closed sub-paths, curves).
+// Stroke -> outline polygon (filled non-zero): Cairo 1.16's polygon stroker with its pen (round joins and caps, fans inside
+// curves), miter / bevel joins, butt / square caps, closed sub-paths and tangent-following curve decomposition.
+// Returns false only for a singular CTM.
 bool stroke_to_polygon(const DevicePath& path, const StrokeParams& sp, const Affine& ctm, Polygon& out);
+// Vertices of the stroking pen for this width under the CTM (cairo-pen.c); <= 1 means the stroke paints nothing at all.
+int stroke_pen_vertices(double line_width, const Affine& ctm);
+// Cairo's rectilinear stroker (axis-aligned paths, miter joins, butt/square caps, scale-only CTM): one box per segment as
+// left/right edges in `out`; the union (non-zero) is the stroke.  Returns false when Cairo would decline (the polygon
+// stroker is used then).
+bool stroke_rectilinear_to_boxes(const DevicePath& path, const StrokeParams& sp, const Affine& ctm, Polygon& out);
 // Rectilinear fill region -> disjoint boxes (x1,y1)-(x2,y2), stored in swfr_edge records.
 void rectilinear_to_boxes(const Polygon& poly, bool even_odd, std::vector<swfr_edge>& boxes);
 

@@ -121,6 +121,56 @@ def scenarios():
     big = [(-700, 300), (1500, -500), (2900, 900), (1200, 2600), (-300, 1800)]
     out["offframe_fill_stroke"] = dict(width=100, height=100, exact=True, stage={"children": [
         {"type": "shape", "definition": _poly_shape(big, {"type": "solid", "color": _rgba(200, 180, 40)}, line=_rgba(0, 0, 0), line_width=70)}]})
+    # --- strokes beyond open miter/butt polylines: curves, the rectilinear box stroker, round caps + joins
+    #     (morph shapes), hairlines that cairo drops, and round strokes leaving the frame
+    def _path_shape(start, segs, fill=None, line=None, line_width=0):
+        """segs: (dx, dy) straight or (dx, dy, cdx, cdy) quadratic with control delta; twips."""
+        sc = {"type": "style-change", "move_to": {"x": int(start[0]), "y": int(start[1])}}
+        if fill is not None:
+            sc["left_fill"] = 1
+        if line is not None:
+            sc["line_style"] = 1
+        recs = [sc]
+        x, y = start
+        xs, ys = [x], [y]
+        for sg in segs:
+            e = {"type": "edge", "delta": {"x": int(sg[0]), "y": int(sg[1])}}
+            if len(sg) == 4:
+                e["control_delta"] = {"x": int(sg[2]), "y": int(sg[3])}
+                xs.append(x + sg[2]); ys.append(y + sg[3])
+            x += sg[0]; y += sg[1]
+            xs.append(x); ys.append(y)
+            recs.append(e)
+        lines = [] if line is None else [{"width": line_width, "fill": {"type": "solid", "color": line}}]
+        return {"id": 1, "bounds": {"x_min": int(min(xs)), "x_max": int(max(xs)), "y_min": int(min(ys)), "y_max": int(max(ys))},
+                "shape": {"initial_styles": {"fill": [] if fill is None else [fill], "line": lines}, "records": recs}}
+
+    blob = _path_shape((300, 900), [(700, -600, 100, -500), (600, 500, 500, -100), (-300, 600, 200, 500), (-1000, -500, -600, 300)],
+                       fill={"type": "solid", "color": _rgba(250, 220, 90)}, line=_rgba(30, 30, 120), line_width=90)
+    out["stroke_curves"] = dict(width=100, height=90, exact=True, stage={"children": [{"type": "shape", "definition": blob}]})
+    thin_curve = _path_shape((200, 300), [(900, 300, 800, -250), (400, 900, -500, 300), (-1100, -200, -300, 500)],
+                             line=_rgba(0, 0, 0, 160), line_width=14)
+    out["stroke_curves_thin_translucent"] = dict(width=100, height=90, exact=True, stage={"children": [{"type": "shape", "definition": thin_curve}]})
+    stairs = _path_shape((205, 310), [(400, 0), (0, 300), (350, 0), (0, -450), (500, 0), (0, 900), (-1100, 0)], line=_rgba(200, 30, 30), line_width=50)
+    out["stroke_rectilinear_open"] = dict(width=90, height=70, exact=True, stage={"children": [{"type": "shape", "definition": stairs}]})
+    frame_loop = _path_shape((300, 300), [(1000, 0), (0, 700), (-1000, 0), (0, -700)], fill={"type": "solid", "color": _rgba(20, 160, 90, 200)},
+                             line=_rgba(0, 0, 0, 128), line_width=65)
+    out["stroke_rectilinear_loop_scaled"] = dict(width=120, height=80, exact=True, stage={"children": [
+        {"type": "shape", "definition": frame_loop, "matrix": _m(1.3, 0.9, 137, 55)}]})
+    hair = {"children": [
+        {"type": "shape", "definition": _path_shape((100, 100), [(1500, 900), (-700, 400)], line=_rgba(0, 0, 0), line_width=1)},      # 0.05 px: dropped
+        {"type": "shape", "definition": _path_shape((100, 1300), [(1500, -900), (-200, -300)], line=_rgba(0, 0, 0), line_width=2)},   # 0.1 px: drawn
+        {"type": "shape", "definition": _path_shape((200, 200), [(0, 1200), (1300, 0)], line=_rgba(0, 0, 0), line_width=1)}]}          # rectilinear, dropped too
+    out["stroke_hairlines"] = dict(width=90, height=80, exact=True, stage=hair)
+    mtag = json.loads(json.dumps(load_fixture("homestuck-beta-29")))
+    for ln in mtag["shape"]["initial_styles"]["line"]:
+        ln["width"], ln["morph_width"] = 60, 160
+        ln["fill"]["color"], ln["fill"]["morph_color"] = _rgba(200, 40, 40, 255), _rgba(40, 40, 220, 140)
+    for k in (0, 90, 255):
+        out["morph_round_stroke_%03d" % k] = dict(width=w, height=h, exact=True, stage={"children": [
+            {"type": "morph-shape", "definition": mtag, "ratio": k / 255, "matrix": _m(tx=-x0, ty=-y0)}]})
+    out["morph_round_stroke_offframe"] = dict(width=w, height=h, exact=True, stage={"children": [
+        {"type": "morph-shape", "definition": mtag, "ratio": 0.6, "matrix": _m(1.4, 1.2, -x0 * 1.4 - 400, -y0 * 1.2 + 300)}]})
     # --- bitmap fill, magnified (BASELINE config 4 at reduced size; bilinear region of FILTER_GOOD)
     tag4 = load_fixture("homestuck-beta-4")
     b = tag4["bounds"]
