@@ -987,7 +987,95 @@ typedef struct {
     double cx0, cy0, r0, cx1, cy1, r1;       /* RADIAL / LINEAR (x0,y0,x1,y1) */
     stop_t *stops; int nstops;
     const uint32_t *tex; int tw, th, extend; /* SURFACE: premultiplied ARGB, extend 0 none / 1 repeat */
+    /* SURFACE, CAIRO_FILTER_GOOD when it is not downgraded to bilinear: pixman separable convolution tables */
+    int good, cw, ch, xbits, ybits;
+    int32_t *xpar, *ypar;                    /* (1 << bits) phases x width taps, 16.16 */
 } source_t;
+
+/* ---- CAIRO_FILTER_GOOD for surface patterns (cairo-pattern.c _cairo_pattern_analyze_filter, cairo-image-source.c
+        create_separable_convolution, pixman bits_image_fetch_pixel_separable_convolution).  The sample position is taken
+        from the double-precision pattern matrix (pixman rounds its matrix to 16.16 first), so single pixels can differ from
+        libcairo by an LSB or two where a phase boundary is hit; the tables and the accumulation are pixman's integers. */
+static double good_box_kernel(double x, double r) { return fmax(0.0, fmin(fmin(r, 1.0), fmin((r + 1) / 2 - x, (r + 1) / 2 + x))); }
+static int good_box_width(double r) { return r < 1.0 ? 2 : (int)ceil(r + 1); }
+static void good_get_filter(double r, int width, int subsample, int32_t *out)
+{
+    int n_phases = 1 << subsample;
+    double step = 1.0 / n_phases;
+    int32_t *p = out;
+    if (width <= 1) { for (int i = 0; i < n_phases; i++) *p++ = 65536; return; }
+    for (int i = 0; i < n_phases; i++) {
+        double frac = (i + .5) * step;
+        double x1 = ceil(frac - width / 2.0 - 0.5) - frac + 0.5;      /* centre of the left-most pixel */
+        double total = 0;
+        int32_t new_total = 0;
+        for (int j = 0; j < width; j++) { double v = good_box_kernel(x1 + j, r); total += v; p[j] = (int32_t)(v * 65536.0); }
+        total = 1 / total;
+        for (int j = 0; j < width; j++) new_total += (p[j] = (int32_t)(p[j] * total));
+        p[width / 2] += 65536 - new_total;                           /* any error goes on the centre pixel */
+        p += width;
+    }
+}
+static int good_use_bilinear(double x, double y, double t)
+{
+    double h = x * x + y * y;                                        /* this is the inverse (device -> pattern) matrix */
+    if (h < 1.0 / (0.75 * 0.75)) return 1;                           /* scale > .75 */
+    if ((h > 3.99 && h < 4.01) && !fx_from_double(x * y) && (fx_from_double(t) & 255) == 0) return 1;   /* exactly 1/2, axis-parallel, integer offset */
+    return 0;
+}
+static void source_setup_filter(source_t *s)
+{
+    free(s->xpar); free(s->ypar); s->xpar = s->ypar = NULL; s->good = 0;
+    if (s->kind != SRC_SURFACE) return;
+    const mat_t *m = &s->inv;
+    if (good_use_bilinear(m->xx, m->xy, m->x0) && good_use_bilinear(m->yx, m->yy, m->y0)) return;
+    double dx = hypot(m->xx, m->xy), dy = hypot(m->yx, m->yy);
+    if (dx > 16.0) dx = 16.0;
+    if (dy > 16.0) dy = 16.0;
+    if (dx < 1.0 / 0.75) dx = 1.0;                                   /* match the bilinear filter for scales > .75 */
+    if (dy < 1.0 / 0.75) dy = 1.0;
+    s->cw = good_box_width(dx); s->xbits = 0;
+    if (s->cw > 1) while (dx * (1 << s->xbits) <= 128.0) s->xbits++;
+    s->ch = good_box_width(dy); s->ybits = 0;
+    if (s->ch > 1) while (dy * (1 << s->ybits) <= 128.0) s->ybits++;
+    s->xpar = malloc(sizeof(int32_t) * (size_t)(s->cw << s->xbits));
+    s->ypar = malloc(sizeof(int32_t) * (size_t)(s->ch << s->ybits));
+    good_get_filter(dx, s->cw, s->xbits, s->xpar);
+    good_get_filter(dy, s->ch, s->ybits, s->ypar);
+    s->good = 1;
+}
+static uint32_t sample_good(const source_t *s, double u, double v)
+{
+    int64_t x = (int64_t)floor(u * 65536.0), y = (int64_t)floor(v * 65536.0);
+    const int xsh = 16 - s->xbits, ysh = 16 - s->ybits;
+    const int64_t x_off = (((int64_t)s->cw << 16) - 65536) >> 1, y_off = (((int64_t)s->ch << 16) - 65536) >> 1;
+    /* round to the middle of the closest phase */
+    x = ((x >> xsh) << xsh) + ((1 << xsh) >> 1);
+    y = ((y >> ysh) << ysh) + ((1 << ysh) >> 1);
+    const int px = (int)((x & 0xffff) >> xsh), py = (int)((y & 0xffff) >> ysh);
+    const int32_t *yp = s->ypar + py * s->ch;
+    const int x1 = (int)((x - 1 - x_off) >> 16), y1 = (int)((y - 1 - y_off) >> 16);
+    int64_t sr = 0, sg = 0, sb = 0, sa = 0;
+    for (int i = y1; i < y1 + s->ch; i++) {
+        int64_t fy = *yp++;
+        const int32_t *xp = s->xpar + px * s->cw;
+        if (!fy) continue;
+        for (int j = x1; j < x1 + s->cw; j++) {
+            int32_t fx = *xp++;
+            if (!fx) continue;
+            int rx = j, ry = i;
+            uint32_t pixel;
+            if (s->extend == 1) { rx = ((rx % s->tw) + s->tw) % s->tw; ry = ((ry % s->th) + s->th) % s->th; pixel = s->tex[ry * s->tw + rx]; }
+            else pixel = (rx < 0 || ry < 0 || rx >= s->tw || ry >= s->th) ? 0 : s->tex[ry * s->tw + rx];
+            int32_t f = (int32_t)((fy * fx + 0x8000) >> 16);
+            sr += (int)((pixel >> 16) & 255) * f; sg += (int)((pixel >> 8) & 255) * f; sb += (int)(pixel & 255) * f; sa += (int)(pixel >> 24) * f;
+        }
+    }
+    sa = (sa + 0x8000) >> 16; sr = (sr + 0x8000) >> 16; sg = (sg + 0x8000) >> 16; sb = (sb + 0x8000) >> 16;
+    if (sa < 0) sa = 0; if (sa > 255) sa = 255; if (sr < 0) sr = 0; if (sr > 255) sr = 255;
+    if (sg < 0) sg = 0; if (sg > 255) sg = 255; if (sb < 0) sb = 0; if (sb > 255) sb = 255;
+    return ((uint32_t)sa << 24) | ((uint32_t)sr << 16) | ((uint32_t)sg << 8) | (uint32_t)sb;
+}
 
 typedef struct {
     mat_t ctm; double line_width; int cap, join; double miter_limit; int fill_rule;
@@ -1100,7 +1188,8 @@ static uint32_t sample_source(const source_t *s, int px, int py)
         if (t < 0) t = 0; if (t > 1) t = 1;
         return gradient_color(s, t);
     }
-    /* SRC_SURFACE: bilinear (7-bit weights) -- matches CAIRO_FILTER_GOOD only for magnification */
+    if (s->good) return sample_good(s, x, y);
+    /* SRC_SURFACE: bilinear (7-bit weights) -- what CAIRO_FILTER_GOOD becomes for scales > .75 */
     double u = x - 0.5, v = y - 0.5;
     int x0 = (int)floor(u), y0 = (int)floor(v);
     int wx = (int)floor((u - x0) * 128.0), wy = (int)floor((v - y0) * 128.0);
@@ -1641,7 +1730,7 @@ EXPORT swfo_ctx *swfo_create(int w, int h)
 EXPORT void swfo_destroy(swfo_ctx *c)
 {
     if (!c) return;
-    free(c->px); free(c->path.ops); free(c->path.pts); free(c->src.stops);
+    free(c->px); free(c->path.ops); free(c->path.pts); free(c->src.stops); free(c->src.xpar); free(c->src.ypar);
     free(c->ch); free(c->ua); free(c->touched); free(c->tmark); free(c->last_poly);
     free(c);
 }
@@ -1722,6 +1811,7 @@ EXPORT void swfo_set_source_surface(swfo_ctx *c, const uint32_t *argb_premul, in
 {
     c->src.kind = SRC_SURFACE; c->src.tex = argb_premul; c->src.tw = tw; c->src.th = th; c->src.extend = extend;
     lock_pattern_matrix(c);
+    source_setup_filter(&c->src);
 }
 EXPORT void swfo_set_line_width(swfo_ctx *c, double w) { c->gs[c->ngs - 1].line_width = w; }
 EXPORT void swfo_set_line_cap(swfo_ctx *c, int cap) { c->gs[c->ngs - 1].cap = cap; }

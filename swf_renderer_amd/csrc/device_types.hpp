@@ -100,4 +100,18 @@ struct DevBitmap {
     uint32_t width, height;
 };
 
+// CAIRO_FILTER_GOOD of a bitmap style when Cairo does not downgrade it to bilinear (minification below 0.75): pixman's
+// separable convolution.  x_off / y_off index the handle's table of 16.16 weights: (1 << bits) phases x width taps.
+struct DevFilter {
+    int32_t on, cw, ch, xbits, ybits;
+    uint32_t x_off, y_off, pad;
+};
+
+// what the shader needs besides the style itself
+struct Sources {
+    const DevBitmap* bitmaps;
+    const DevFilter* filters;    // per style index
+    const int32_t* fparams;
+};
+
 }  // namespace swfr

@@ -709,7 +709,7 @@ __device__ uint32_t gradient_color(const swfr_style& s, double t) {
 
 // premultiplied ARGB source colour at pixel centre (px+0.5, py+0.5): float64 model of pixman's
 // general path (gradients within +-1 LSB of Cairo)
-__device__ __noinline__ uint32_t shade(const swfr_style& s, const DevBitmap* __restrict__ bitmaps, int px, int py) {
+__device__ __noinline__ uint32_t shade(const swfr_style& s, uint32_t style_index, const Sources bitmaps, int px, int py) {
     double x = px + 0.5, y = py + 0.5;
     const double ux = s.inv[0] * x + s.inv[2] * y + s.inv[4];
     const double uy = s.inv[1] * x + s.inv[3] * y + s.inv[5];
@@ -736,8 +736,42 @@ __device__ __noinline__ uint32_t shade(const swfr_style& s, const DevBitmap* __r
         t = fmin(fmax(t, 0.0), 1.0);
         return gradient_color(s, t);
     }
-    // bitmap: bilinear with 7-bit weights
-    const DevBitmap bm = bitmaps[s.bitmap];
+    const DevBitmap bm = bitmaps.bitmaps[s.bitmap];
+    const DevFilter flt = bitmaps.filters[style_index];
+    if (flt.on) {
+        // CAIRO_FILTER_GOOD below scale 0.75: pixman's separable convolution (integer tables and accumulation; the sample
+        // position comes from the f64 pattern matrix)
+        long long x = (long long)floor(ux * 65536.0), y = (long long)floor(uy * 65536.0);
+        const int xsh = 16 - flt.xbits, ysh = 16 - flt.ybits;
+        const long long x_off = (((long long)flt.cw << 16) - 65536) >> 1, y_off = (((long long)flt.ch << 16) - 65536) >> 1;
+        x = ((x >> xsh) << xsh) + ((1 << xsh) >> 1);          // the middle of the closest phase
+        y = ((y >> ysh) << ysh) + ((1 << ysh) >> 1);
+        const int phx = (int)((x & 0xffff) >> xsh), phy = (int)((y & 0xffff) >> ysh);
+        const int32_t* yp = bitmaps.fparams + flt.y_off + phy * flt.ch;
+        const int32_t* xp0 = bitmaps.fparams + flt.x_off + phx * flt.cw;
+        const int x1 = (int)((x - 1 - x_off) >> 16), y1 = (int)((y - 1 - y_off) >> 16);
+        long long sr = 0, sg = 0, sb = 0, sa = 0;
+        for (int i = 0; i < flt.ch; ++i) {
+            const long long fy = yp[i];
+            if (!fy) continue;
+            int ry = y1 + i;
+            if (s.extend == 1) ry = ((ry % (int)bm.height) + (int)bm.height) % (int)bm.height;
+            for (int j = 0; j < flt.cw; ++j) {
+                const int32_t fx = xp0[j];
+                if (!fx) continue;
+                int rx = x1 + j;
+                uint32_t pixel;
+                if (s.extend == 1) { rx = ((rx % (int)bm.width) + (int)bm.width) % (int)bm.width; pixel = bm.pixels[(size_t)ry * bm.width + rx]; }
+                else pixel = (rx < 0 || ry < 0 || rx >= (int)bm.width || ry >= (int)bm.height) ? 0u : bm.pixels[(size_t)ry * bm.width + rx];
+                const int f = (int)((fy * fx + 0x8000) >> 16);
+                sr += (int)((pixel >> 16) & 255u) * f; sg += (int)((pixel >> 8) & 255u) * f; sb += (int)(pixel & 255u) * f; sa += (int)(pixel >> 24) * f;
+            }
+        }
+        sa = (sa + 0x8000) >> 16; sr = (sr + 0x8000) >> 16; sg = (sg + 0x8000) >> 16; sb = (sb + 0x8000) >> 16;
+        sa = min(max(sa, 0ll), 255ll); sr = min(max(sr, 0ll), 255ll); sg = min(max(sg, 0ll), 255ll); sb = min(max(sb, 0ll), 255ll);
+        return ((uint32_t)sa << 24) | ((uint32_t)sr << 16) | ((uint32_t)sg << 8) | (uint32_t)sb;
+    }
+    // bilinear with 7-bit weights (what CAIRO_FILTER_GOOD becomes for scales > .75)
     const double u = ux - 0.5, v = uy - 0.5;
     const int x0 = (int)floor(u), y0 = (int)floor(v);
     const int wx = (int)floor((u - x0) * 128.0), wy = (int)floor((v - y0) * 128.0);
@@ -927,12 +961,12 @@ __global__ __launch_bounds__(64) void k_class(const BandEntry* __restrict__ band
 
 template <bool SHADERS>
 __device__ __forceinline__ uint32_t blend_pixel_t(uint32_t dst, uint32_t a, uint32_t eflags, uint32_t solid, const swfr_style* __restrict__ styles,
-                                                  uint32_t style, const DevBitmap* __restrict__ bitmaps, int cx, int cy) {
+                                                  uint32_t style, const Sources bitmaps, int cx, int cy) {
     if (!SHADERS || (eflags & BE_SOLID)) {
         if (eflags & BE_LERP) return a == 255u ? solid : lerp_pixel(solid, a, dst);
         return over_pixel(a == 255u ? solid : mul_un8(solid, a), dst);
     }
-    const uint32_t s = mul_un8(shade(styles[style], bitmaps, cx, cy), a);
+    const uint32_t s = mul_un8(shade(styles[style], style, bitmaps, cx, cy), a);
     return (eflags & BE_LERP) ? s : over_pixel(s, dst);
 }
 #define blend_pixel blend_pixel_t<SHADERS>
@@ -1002,7 +1036,7 @@ __global__ __launch_bounds__(64) void k_tiles(const swfr_edge* __restrict__ raw_
                                               const uint32_t* __restrict__ band_off, const BandEntry* __restrict__ band_list,
                                               const uint8_t* __restrict__ cls_t, const RowInfo* __restrict__ rows,
                                               const Rec* __restrict__ records, const swfr_style* __restrict__ styles,
-                                              const DevBitmap* __restrict__ bitmaps, uint32_t* __restrict__ fb,
+                                              const Sources bitmaps, uint32_t* __restrict__ fb,
                                               int width, int height, int tiles_x, uint32_t band_index, uint32_t band_count, int dbg,
                                               uint32_t* __restrict__ counters, uint32_t n_rows_total, uint32_t n_rec_cap,
                                               const uint32_t* __restrict__ order) {
@@ -1378,7 +1412,7 @@ void launch_class(hipStream_t st, const BandEntry* band_list, uint32_t n_entries
                        width, height, tiles_x, band_index, band_count);
 }
 void launch_tiles(hipStream_t st, const swfr_edge* raw, const uint32_t* band_off, const BandEntry* band_list, const uint8_t* cls_mat,
-                  const RowInfo* rows, const Rec* records, const swfr_style* styles, const DevBitmap* bitmaps, uint32_t* fb, int width, int height,
+                  const RowInfo* rows, const Rec* records, const swfr_style* styles, const Sources bitmaps, uint32_t* fb, int width, int height,
                   uint32_t band_index, uint32_t band_count, int dbg, uint32_t* counters, uint32_t n_rows_total, uint32_t n_rec_cap,
                   bool any_shader, const uint32_t* order) {
     const int tiles_x = (width + TILE_W - 1) / TILE_W, tile_rows = (height + TILE_H - 1) / TILE_H;

@@ -29,7 +29,7 @@ void launch_class(hipStream_t, const BandEntry*, uint32_t, const uint32_t*, uint
 void launch_rows(hipStream_t, const DevEdge*, const DevPath*, const uint32_t*, const ChunkInfo*, uint32_t, RowInfo*, Rec*, uint32_t*, const BigRow*,
                  uint32_t, uint32_t, uint32_t, uint32_t, int, int);
 void launch_tiles(hipStream_t, const swfr_edge*, const uint32_t*, const BandEntry*, const uint8_t*, const RowInfo*, const Rec*, const swfr_style*,
-                  const DevBitmap*, uint32_t*, int, int, uint32_t, uint32_t, int, uint32_t*, uint32_t, uint32_t, bool, const uint32_t*);
+                  Sources, uint32_t*, int, int, uint32_t, uint32_t, int, uint32_t*, uint32_t, uint32_t, bool, const uint32_t*);
 void launch_unpremultiply(hipStream_t, const uint32_t*, uint32_t*, size_t);
 void launch_pack_band(hipStream_t, const uint32_t*, uint32_t*, int, int, uint32_t, uint32_t, uint32_t);
 }  // namespace swfr
@@ -103,6 +103,8 @@ struct swfr_renderer {
     DevBuf<Rec> d_records;
     DevBuf<uint32_t> d_counters;
     DevBuf<DevBitmap> d_bitmap_table;
+    DevBuf<DevFilter> d_filters;            // per style: CAIRO_FILTER_GOOD tables of bitmap styles (see good_filter)
+    DevBuf<int32_t> d_filter_params;
     DevBuf<uint32_t> d_fb, d_tmp;
     // further sets of per-frame buffers + streams: with SWFR_FRAMES_IN_FLIGHT = n consecutive resident frames rotate over n
     // sets, so the front of frame f+1 overlaps the tail of frame f (every frame still recomputes everything)
@@ -136,7 +138,7 @@ struct swfr_renderer {
         if (has_device) {
             (void)hipSetDevice(cfg.device);
             d_raw.release(); d_edges.release(); d_paths.release(); d_styles.release(); d_row_base.release();
-            d_rows.release(); d_records.release(); d_chunk_base.release(); d_band_off.release(); d_band_list.release(); d_big_rows.release(); d_band_slots.release(); d_order.release(); d_cls.release(); d_counters.release(); d_bitmap_table.release(); d_fb.release(); d_tmp.release();
+            d_rows.release(); d_records.release(); d_chunk_base.release(); d_band_off.release(); d_band_list.release(); d_big_rows.release(); d_band_slots.release(); d_order.release(); d_cls.release(); d_counters.release(); d_bitmap_table.release(); d_filters.release(); d_filter_params.release(); d_fb.release(); d_tmp.release();
             for (ExtraSet& x : extra) {
                 x.d_edges.release(); x.d_band_list.release(); x.d_cls.release(); x.d_rows.release(); x.d_records.release(); x.d_counters.release(); x.d_fb.release();
                 if (x.stream) (void)hipStreamDestroy(x.stream);
@@ -196,6 +198,52 @@ void validate_scene(const swfr_renderer* r, const swfr_edge* edges, size_t n_edg
         if (s.n_stops > SWFR_MAX_STOPS) throw StatusError{SWFR_ERR_INVALID, "too many gradient stops"};
         if (s.kind == SWFR_STYLE_BITMAP && !r->bitmaps.count(s.bitmap)) throw StatusError{SWFR_ERR_NOT_FOUND, "BitmapNotFound"};
     }
+}
+
+// CAIRO_FILTER_GOOD for a surface pattern (cairo-pattern.c _cairo_pattern_analyze_filter, cairo-image-source.c
+// create_separable_convolution): bilinear unless an axis is minified below 0.75; then a box (x) tent kernel per axis,
+// sampled at 2^bits phases, weights in 16.16, normalised with the rounding error put on the centre tap.
+double good_box_kernel(double x, double r) { return std::max(0.0, std::min(std::min(r, 1.0), std::min((r + 1) / 2 - x, (r + 1) / 2 + x))); }
+void good_axis(double r, int& width, int& bits, std::vector<int32_t>& out) {
+    width = r < 1.0 ? 2 : int(std::ceil(r + 1));
+    bits = 0;
+    if (width > 1) while (r * double(1 << bits) <= 128.0) ++bits;
+    const int n_phases = 1 << bits;
+    const double step = 1.0 / n_phases;
+    for (int i = 0; i < n_phases; ++i) {
+        const size_t base = out.size();
+        if (width <= 1) { out.push_back(65536); continue; }
+        const double frac = (i + .5) * step;
+        const double x1 = std::ceil(frac - width / 2.0 - 0.5) - frac + 0.5;   // centre of the left-most tap
+        double total = 0;
+        for (int j = 0; j < width; ++j) { const double v = good_box_kernel(x1 + j, r); total += v; out.push_back(int32_t(v * 65536.0)); }
+        total = 1 / total;
+        int32_t new_total = 0;
+        for (int j = 0; j < width; ++j) new_total += (out[base + size_t(j)] = int32_t(out[base + size_t(j)] * total));
+        out[base + size_t(width / 2)] += 65536 - new_total;
+    }
+}
+bool good_use_bilinear(double x, double y, double t) {
+    const double h = x * x + y * y;                                   // device -> pattern matrix row
+    if (h < 1.0 / (0.75 * 0.75)) return true;
+    if (h > 3.99 && h < 4.01 && to_fixed(x * y) == 0 && (to_fixed(t) & 255) == 0) return true;   // exactly 1/2, axis-parallel, integer offset
+    return false;
+}
+DevFilter good_filter(const swfr_style& st, std::vector<int32_t>& params) {
+    DevFilter f{};
+    if (st.kind != SWFR_STYLE_BITMAP) return f;
+    const double xx = st.inv[0], yx = st.inv[1], xy = st.inv[2], yy = st.inv[3], x0 = st.inv[4], y0 = st.inv[5];
+    if (good_use_bilinear(xx, xy, x0) && good_use_bilinear(yx, yy, y0)) return f;
+    double dx = std::hypot(xx, xy), dy = std::hypot(yx, yy);
+    dx = std::min(dx, 16.0); dy = std::min(dy, 16.0);
+    if (dx < 1.0 / 0.75) dx = 1.0;
+    if (dy < 1.0 / 0.75) dy = 1.0;
+    f.on = 1;
+    f.x_off = uint32_t(params.size());
+    good_axis(dx, f.cw, f.xbits, params);
+    f.y_off = uint32_t(params.size());
+    good_axis(dy, f.ch, f.ybits, params);
+    return f;
 }
 
 int upload(swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_path* paths, size_t n_paths,
@@ -342,6 +390,16 @@ int upload(swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_
     if (!chunks.empty())
         HIP_CHECK(hipMemcpyAsync(r->d_chunk_base.ptr, chunks.data(), chunks.size() * sizeof(ChunkInfo), hipMemcpyHostToDevice, r->stream));
     HIP_CHECK(hipMemcpyAsync(r->d_band_off.ptr, band_off.data(), (n_bands + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, r->stream));
+    {   // per-style sampling filters of bitmap styles
+        std::vector<DevFilter> filters(n_styles);
+        std::vector<int32_t> fparams;
+        for (size_t i = 0; i < n_styles; ++i) filters[i] = good_filter(styles[i], fparams);
+        r->d_filters.reserve(std::max<size_t>(n_styles, 1));
+        r->d_filter_params.reserve(std::max<size_t>(fparams.size(), 1));
+        if (n_styles) HIP_CHECK(hipMemcpyAsync(r->d_filters.ptr, filters.data(), n_styles * sizeof(DevFilter), hipMemcpyHostToDevice, r->stream));
+        if (!fparams.empty()) HIP_CHECK(hipMemcpyAsync(r->d_filter_params.ptr, fparams.data(), fparams.size() * sizeof(int32_t), hipMemcpyHostToDevice, r->stream));
+        HIP_CHECK(hipStreamSynchronize(r->stream));   // the staging vectors die here
+    }
     if (r->bitmap_table_dirty) {
         r->d_bitmap_table.reserve(r->bitmap_table.size());
         if (!r->bitmap_table.empty())
@@ -403,7 +461,7 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
         }
         if (timed) HIP_CHECK(hipEventRecord(e[2], S.st));
         launch_tiles(S.st, r->d_raw.ptr, r->d_band_off.ptr, S.band_list, S.cls, S.rows, S.records, r->d_styles.ptr,
-                     r->d_bitmap_table.ptr, S.fb, int(r->width), int(r->height), bi, bc, r->tiles_dbg, S.counters, uint32_t(r->n_tasks), uint32_t(r->rec_cap), r->any_shader,
+                     Sources{r->d_bitmap_table.ptr, r->d_filters.ptr, r->d_filter_params.ptr}, S.fb, int(r->width), int(r->height), bi, bc, r->tiles_dbg, S.counters, uint32_t(r->n_tasks), uint32_t(r->rec_cap), r->any_shader,
                      r->has_order ? r->d_order.ptr : nullptr);
         if (timed) HIP_CHECK(hipEventRecord(e[3], S.st));
     }

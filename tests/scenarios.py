@@ -179,4 +179,12 @@ def scenarios():
     out["bitmap_magnified"] = dict(width=math.ceil((b["x_max"] - b["x_min"]) / 20 * sc), height=math.ceil((b["y_max"] - b["y_min"]) / 20 * sc),
                                    exact=False, bitmaps=[bmp], tolerance=4, stage={"children": [
         {"type": "shape", "definition": tag4, "matrix": _m(sc, sc, -b["x_min"] * sc, -b["y_min"] * sc)}]})
+    # --- the reference's textured fixture at its own size: the bitmap is minified 2.58x, i.e. CAIRO_FILTER_GOOD's separable
+    #     convolution (pixman) rather than bilinear; and a rotated, strongly minified repeat fill
+    out["fixture_homestuck-beta-4"] = dict(width=math.ceil((b["x_max"] - b["x_min"]) / 20), height=math.ceil((b["y_max"] - b["y_min"]) / 20),
+                                           exact=False, bitmaps=[bmp], tolerance=2, stage={"children": [
+        {"type": "shape", "definition": tag4, "matrix": _m(tx=-b["x_min"], ty=-b["y_min"])}]})
+    out["bitmap_minified_rotated"] = dict(width=120, height=90, exact=False, bitmaps=[bmp], tolerance=2, stage={"children": [
+        {"type": "shape", "definition": tag4, "matrix": _m(0.55, 0.4, 500 - (0.55 * b["x_min"] - 0.15 * b["y_min"]),
+                                                                 150 - (0.2 * b["x_min"] + 0.4 * b["y_min"]), 0.2, -0.15)}]})
     return out

@@ -62,6 +62,21 @@ def test_reference_golden_png(name):
     r.close()
 
 
+def test_reference_textured_golden_png():
+    """The 7th golden of the reference: bitmap fill minified 2.58x (CAIRO_FILTER_GOOD = pixman separable convolution)."""
+    import swf_renderer_amd as S
+    sc = SC["fixture_homestuck-beta-4"]
+    r = S.Renderer(sc["width"], sc["height"])
+    for bm in sc["bitmaps"]:
+        r.add_bitmap(bm)
+    r.render(sc["stage"])
+    out = r.read_image(premultiplied=False)
+    r.close()
+    ref = golden("ref_homestuck-beta-4", "rgba_straight")
+    n, mx = diff_stats(out, ref)
+    assert mx <= 1 and n <= 0.005 * out.shape[0] * out.shape[1], (n, mx)   # sample positions from the f64 matrix: a few px one LSB off
+
+
 @pytest.mark.parametrize("ratio,fname,allowed", [(0, "0", 0), (0.5, "32768", 4), (1, "65536", 0)])
 def test_reference_morph_golden_png(ratio, fname, allowed):
     import swf_renderer_amd as S

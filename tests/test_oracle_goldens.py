@@ -49,15 +49,16 @@ def test_render_morph_golden_png(ratio, fname, allowed):
     assert n <= allowed and mx <= (1 if allowed else 0)
 
 
-def test_render_textured_golden_png_reference_metric():
-    """homestuck-beta-4 is minified 2.58x with Cairo's FILTER_GOOD (pixman separable convolution), which
-    is not restated: the bilinear model is checked only for frame/extent agreement here."""
+def test_render_textured_golden_png():
+    """homestuck-beta-4 is minified 2.58x: Cairo's FILTER_GOOD = pixman's separable convolution (restated in the oracle;
+    the sample position comes from the double-precision matrix, so a few pixels sit one LSB off the reference's PNG)."""
     sc = dict(width=54, height=81, bitmaps=[fixture("homestuck-beta-3.bitmap")],
               stage=cr.stage_for_shape(fixture("homestuck-beta-4"))[2])
     out = cr.unpremultiply(oracle_render(sc))
     ref = golden("ref_homestuck-beta-4", "rgba_straight")
     assert out.shape == ref.shape
-    assert ((out[..., 3] > 0) == (ref[..., 3] > 0)).mean() > 0.999
+    n, mx = diff_stats(out, ref)
+    assert mx <= 1 and n <= 0.005 * out.shape[0] * out.shape[1], (n, mx)
 
 
 # ---- committed libcairo goldens for everything else
