@@ -292,6 +292,16 @@ def _define_shape(arena, tag):
     return d
 
 
+def image_to_pam(width: int, height: int, rgba: bytes) -> bytes:
+    """Straight RGBA8 -> Netpbm PAM (`P7`, `TUPLTYPE RGB_ALPHA`), byte for byte what the reference's writers emit
+    (rs/src/pam.rs:3-34, ts/src/lib/image-data-to-pam.ts:8-28)."""
+    rgba = bytes(rgba)
+    if len(rgba) != width * height * 4:
+        raise ValueError("image_to_pam: data length does not match the dimensions")
+    header = "P7\nWIDTH %d\nHEIGHT %d\nDEPTH 4\nMAXVAL 255\nTUPLTYPE RGB_ALPHA\nENDHDR\n" % (width, height)
+    return header.encode("ascii") + rgba
+
+
 def decode_x_swf_bmp(data: bytes):
     """`image/x-swf-bmp` format 3 (zlib colour-mapped) -> (width, height, straight RGBA bytes).
 
@@ -454,6 +464,12 @@ class Renderer:
         t = Timing()
         self.L.swfr_last_timing(self.h, C.byref(t))
         return {n: getattr(t, n) for n, _ in Timing._fields_}
+
+    def write_pam(self, path: str) -> None:
+        """Dumps the last frame (straight RGBA) as PAM, like the reference's headless renderer does for its tests."""
+        img = self.read_image(premultiplied=False)
+        with open(path, "wb") as f:
+            f.write(image_to_pam(self.width, self.height, np.ascontiguousarray(img).tobytes()))
 
     def read_image(self, premultiplied=False) -> np.ndarray:
         """HxWx4 uint8 RGBA; straight (as the reference's PNG/getImageData) unless premultiplied=True."""

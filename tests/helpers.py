@@ -57,3 +57,71 @@ def diff_stats(a, b):
     d = (a != b).any(-1)
     mx = int(np.abs(a.astype(int) - b.astype(int)).max()) if d.any() else 0
     return int(d.sum()), mx
+
+
+# ---- the reference's own acceptance metric (ts/src/test/node-canvas-renderer.spec.ts:54-65: pixelmatch, threshold 0.05,
+#      anti-aliased pixels skipped, at most 1e-4 of the pixels may differ) restated for reporting
+def _pm_delta(p1, p2, y_only=False):
+    r1, g1, b1, a1 = (float(v) for v in p1)
+    r2, g2, b2, a2 = (float(v) for v in p2)
+    if (r1, g1, b1, a1) == (r2, g2, b2, a2):
+        return 0.0
+    if a1 < 255:
+        a1 /= 255; r1, g1, b1 = 255 + (r1 - 255) * a1, 255 + (g1 - 255) * a1, 255 + (b1 - 255) * a1
+    if a2 < 255:
+        a2 /= 255; r2, g2, b2 = 255 + (r2 - 255) * a2, 255 + (g2 - 255) * a2, 255 + (b2 - 255) * a2
+    y = (r1 * 0.29889531 + g1 * 0.58662247 + b1 * 0.11448223) - (r2 * 0.29889531 + g2 * 0.58662247 + b2 * 0.11448223)
+    if y_only:
+        return y
+    i = (r1 * 0.59597799 - g1 * 0.27417610 - b1 * 0.32180189) - (r2 * 0.59597799 - g2 * 0.27417610 - b2 * 0.32180189)
+    q = (r1 * 0.21147017 - g1 * 0.52261711 + b1 * 0.31113672) - (r2 * 0.21147017 - g2 * 0.52261711 + b2 * 0.31113672)
+    return 0.5053 * y * y + 0.299 * i * i + 0.1957 * q * q
+
+
+def _pm_many_siblings(img, x1, y1):
+    h, w = img.shape[:2]
+    zeroes = 1 if (x1 == 0 or y1 == 0 or x1 == w - 1 or y1 == h - 1) else 0
+    for x in range(max(x1 - 1, 0), min(x1 + 1, w - 1) + 1):
+        for y in range(max(y1 - 1, 0), min(y1 + 1, h - 1) + 1):
+            if (x, y) != (x1, y1) and (img[y, x] == img[y1, x1]).all():
+                zeroes += 1
+                if zeroes > 2:
+                    return True
+    return False
+
+
+def _pm_antialiased(img, x1, y1, img2):
+    h, w = img.shape[:2]
+    zeroes = 1 if (x1 == 0 or y1 == 0 or x1 == w - 1 or y1 == h - 1) else 0
+    mn = mx = 0.0
+    mnp = mxp = None
+    for x in range(max(x1 - 1, 0), min(x1 + 1, w - 1) + 1):
+        for y in range(max(y1 - 1, 0), min(y1 + 1, h - 1) + 1):
+            if (x, y) == (x1, y1):
+                continue
+            d = _pm_delta(img[y1, x1], img[y, x], True)
+            if d == 0:
+                zeroes += 1
+                if zeroes > 2:
+                    return False
+            elif d < mn:
+                mn, mnp = d, (x, y)
+            elif d > mx:
+                mx, mxp = d, (x, y)
+    if mn == 0 or mx == 0:
+        return False
+    return ((_pm_many_siblings(img, *mnp) and _pm_many_siblings(img2, *mnp)) or
+            (_pm_many_siblings(img, *mxp) and _pm_many_siblings(img2, *mxp)))
+
+
+def pixelmatch_count(a, b, threshold=0.05):
+    """Number of mismatched pixels as the reference's spec counts them (straight RGBA8 images of equal shape)."""
+    assert a.shape == b.shape
+    max_delta = 35215 * threshold * threshold
+    ys, xs = np.nonzero((a != b).any(-1))
+    n = 0
+    for y, x in zip(ys.tolist(), xs.tolist()):
+        if _pm_delta(a[y, x], b[y, x]) > max_delta:
+            if not (_pm_antialiased(a, x, y, b) or _pm_antialiased(b, x, y, a)):
+                n += 1
+    return n

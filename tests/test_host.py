@@ -58,7 +58,9 @@ def test_bitmap_decode_matches_reference_pam():
     tag = fixture("homestuck-beta-3.bitmap")
     w, h, rgba = api.decode_x_swf_bmp(bytes.fromhex(tag["data"]))
     with open(os.path.join(ROOT, "tests", "golden", "fixtures", "homestuck-beta-3.pam"), "rb") as f:
-        assert cr.image_to_pam(w, h, rgba) == f.read()
+        want = f.read()
+    assert cr.image_to_pam(w, h, rgba) == want
+    assert api.image_to_pam(w, h, rgba) == want        # the product's own PAM writer (rs/src/pam.rs format)
 
 
 class _Tap(ob.OracleBackend):

@@ -61,6 +61,20 @@ def test_render_textured_golden_png():
     assert mx <= 1 and n <= 0.005 * out.shape[0] * out.shape[1], (n, mx)
 
 
+def test_reference_spec_metric_on_all_seven_goldens():
+    """The reference's own criterion (pixelmatch 0.05, <= 1e-4 of the pixels): every golden PNG passes with zero counted pixels."""
+    from helpers import pixelmatch_count
+    cases = [(cr.stage_for_shape(fixture(n)), [], "ref_" + n) for n in ("squares", "triangle", "homestuck-beta-1")]
+    cases.append((cr.stage_for_shape(fixture("homestuck-beta-4")), [fixture("homestuck-beta-3.bitmap")], "ref_homestuck-beta-4"))
+    for ratio, fname in ((0, "0"), (0.5, "32768"), (1, "65536")):
+        cases.append((cr.stage_for_morph_shape(fixture("homestuck-beta-29"), ratio), [], "ref_homestuck-beta-29_" + fname))
+    for (w, h, stage), bitmaps, gname in cases:
+        out = cr.unpremultiply(oracle_render(dict(width=w, height=h, stage=stage, bitmaps=bitmaps)))
+        ref = golden(gname, "rgba_straight")
+        assert pixelmatch_count(out, ref) <= 1e-4 * w * h, gname
+        assert pixelmatch_count(out, ref) == 0, gname
+
+
 # ---- committed libcairo goldens for everything else
 @pytest.mark.parametrize("name", sorted(SC))
 def test_oracle_vs_cairo_golden(name):
