@@ -181,3 +181,36 @@ def test_stroker_styles(kind):
         else:
             op = _pen_case(rng, W, H, curves=True, margin=-12, scale=True, subs=int(rng.integers(1, 4)))
         assert _same(W, H, [op]), op
+
+
+# ---- bitmap fills: CAIRO_FILTER_GOOD = bilinear above scale 0.75, pixman's separable convolution below.  Tables and accumulation
+#      are pixman's integers; the sample position comes from the double matrix (pixman rounds its matrix to 16.16 first), so a small
+#      share of the pixels may sit an LSB or two off.  EXTEND_REPEAT keeps the bitmap's own border out of the picture.
+@pytest.mark.parametrize("kind", ["minify_rotated", "minify_axis", "mixed", "magnify"])
+def test_bitmap_fill_filters(kind):
+    rng = np.random.default_rng(zlib.crc32(kind.encode()) % 991)
+    W, H = 64, 48
+    total = differing = 0
+    worst = 0
+    for _ in range(40):
+        tw, th = int(rng.integers(8, 40)), int(rng.integers(8, 40))
+        bmp = rng.integers(0, 256, (th, tw, 4)).astype(np.uint8)
+        if rng.integers(0, 2):
+            bmp[..., 3] = 255
+        lo, hi, rot = {"minify_rotated": (0.1, 0.7, True), "minify_axis": (0.05, 0.74, False), "mixed": (0.3, 3.0, True), "magnify": (0.76, 6.0, True)}[kind]
+        sx, sy = rng.uniform(lo, hi), rng.uniform(lo, hi)
+        th_ = rng.uniform(-0.6, 0.6) if rot else 0.0
+        c, s_ = np.cos(th_), np.sin(th_)
+        m = (sx * c, sx * s_, -sy * s_, sy * c, float(rng.uniform(-5, 20)), float(rng.uniform(-5, 20)))
+        imgs = []
+        for be in (cb.CairoBackend(W, H), ob.OracleBackend(W, H)):
+            be.set_transform_identity(); be.clear_all()
+            b = be.create_bitmap(tw, th, bmp.tobytes())
+            be.begin_path(); be.move_to(2, 2); be.line_to(W - 3, 3); be.line_to(W - 2, H - 2); be.line_to(3, H - 4); be.line_to(2, 2)
+            be.save(); be.transform(*m)
+            be.set_fill_pattern(b, True); be.fill(); be.restore()
+            imgs.append(be.premultiplied_rgba().astype(int)); be.close()
+        d = np.abs(imgs[0] - imgs[1]).max(-1)
+        total += d.size; differing += int((d > 0).sum()); worst = max(worst, int(d.max()))
+    # bilinear weights are 7-bit functions of the position, so the position rounding shows a little more there
+    assert worst <= (3 if kind in ("magnify", "mixed") else 2) and differing <= 0.02 * total, (kind, worst, differing, total)
