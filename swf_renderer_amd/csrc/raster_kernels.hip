@@ -214,169 +214,6 @@ __global__ __launch_bounds__(256) void k_front(const swfr_edge* __restrict__ in,
 // ---------------------------------------------------------------------------------------------
 // k_rows
 // ---------------------------------------------------------------------------------------------
-template <int MAXA>
-struct RowLds {
-    int32_t eid[MAXA][64];      // edge index relative to the path's first edge
-    int32_t quo[MAXA][64];      // SUB: x quotient;  FULL check: cell one sub-row earlier
-    int32_t rem_lo[MAXA][64];   // SUB: x remainder; FULL check: "starts in this row" flag
-    int32_t rem_hi[MAXA][64];
-    int32_t cell[MAXA][64];
-    int32_t aux[MAXA][64];      // FULL check: cell after a full step; then the role bits
-    int32_t cols[MAXA][64];     // lo | hi << 16 column range of the contributions
-    uint8_t ord[MAXA][64];
-};
-
-struct RowResult {
-    uint32_t mode;
-    int n;              // active edges gathered (<= MAXA)
-    bool overflow;
-};
-
-// One pixel row r of path P for this lane.  E points at the path's edges (LDS copy or global).
-template <int MAXA, class LDS>
-__device__ __forceinline__ RowResult process_row(const DevEdge* E, const DevPath& P, int r, LDS& L, int lane) {
-    RowResult res; res.mode = ROW_EMPTY; res.n = 0; res.overflow = false;
-    const int s0 = r * 15;
-    int n = 0;
-    bool mid_row = false;
-    for (uint32_t k = 0; k < P.n_edges; ++k) {
-        const int ytop = E[k].ytop, ybot = E[k].ybot;
-        if (ybot <= s0 || ytop >= s0 + 15) continue;
-        if (n < MAXA) { L.eid[n][lane] = (int32_t)k; ++n; } else res.overflow = true;
-        mid_row |= (ytop > s0) | (ybot < s0 + 15);
-    }
-    if (res.overflow) return res;
-    res.n = n;
-    if (n == 0) return res;
-    const unsigned mask = P.fill_rule ? 1u : ~0u;
-    bool full = false;
-    if (!mid_row) {
-        // ---- candidate FULL row: order by cell at the row start, check the order after a full step
-        for (int k = 0; k < n; ++k) {
-            const DevEdge e = E[L.eid[k][lane]];
-            int32_t q; int64_t rm;
-            edge_x_at(e, s0, q, rm);
-            L.cell[k][lane] = e.dy ? cell_of(q, rm, e.dy) : e.x1;
-            int32_t q2; int64_t r2;
-            edge_x_at(e, s0 + 15, q2, r2);
-            L.aux[k][lane] = e.dy ? cell_of(q2, r2, e.dy) : e.x1;
-            // tie-break key among edges already active: the cell one sub-row earlier
-            int32_t qp = q; int64_t rp = rm;
-            if (e.dy && e.ytop < s0) { qp -= (int32_t)e.dq; rp -= e.dr; if (rp < 0) { --qp; rp += e.dy; } else if (rp >= e.dy) { ++qp; rp -= e.dy; } }
-            L.quo[k][lane] = e.dy ? cell_of(qp, rp, e.dy) : e.x1;
-            L.rem_lo[k][lane] = (e.ytop == s0) ? 1 : 0;   // new in this row: sorts after active edges on ties
-            L.ord[k][lane] = (uint8_t)k;
-        }
-        for (int i = 1; i < n; ++i) {          // stable insertion sort on (cell, is_new, previous cell)
-            const uint8_t ki = L.ord[i][lane];
-            const int ci = L.cell[ki][lane], ni = L.rem_lo[ki][lane], pi = L.quo[ki][lane];
-            int j = i - 1;
-            while (j >= 0) {
-                const uint8_t kj = L.ord[j][lane];
-                const int cj = L.cell[kj][lane], nj = L.rem_lo[kj][lane], pj = L.quo[kj][lane];
-                const bool greater = cj > ci || (cj == ci && (nj > ni || (nj == ni && ni == 0 && pj > pi)));
-                if (!greater) break;
-                L.ord[j + 1][lane] = kj; --j;
-            }
-            L.ord[j + 1][lane] = ki;
-        }
-        full = true;
-        int prev = INT32_MIN;
-        for (int i = 0; i < n; ++i) { const int c = L.aux[L.ord[i][lane]][lane]; if (c < prev) { full = false; break; } prev = c; }
-    }
-    if (full) {
-        res.mode = ROW_FULL;
-        for (int k = 0; k < n; ++k) L.aux[k][lane] = 0;
-        int i = 0;
-        while (i < n) {
-            const int kl = L.ord[i][lane];
-            int w = E[L.eid[kl][lane]].dir;
-            int j = i + 1;
-            while (j < n) {
-                const int kj = L.ord[j][lane];
-                w += E[L.eid[kj][lane]].dir;
-                const bool last_of_group = (j + 1 == n) || (L.cell[L.ord[j + 1][lane]][lane] != L.cell[kj][lane]);
-                if (((unsigned)w & mask) == 0 && last_of_group) break;
-                ++j;
-            }
-            if (j >= n) break;                 // unbalanced winding: no span
-            const int kr = L.ord[j][lane];
-            L.aux[kl][lane] = (int32_t)(REC_FULL | 1u);    // left edge, sign +1
-            L.aux[kr][lane] = (int32_t)(REC_FULL | 2u);    // right edge, sign -1
-            i = j + 1;
-        }
-        for (int k = 0; k < n; ++k) {          // column range of the analytic contribution
-            if (!L.aux[k][lane]) continue;
-            const DevEdge e = E[L.eid[k][lane]];
-            int32_t q1, q2; int64_t r1, r2;
-            full_row_ends(e, s0, q1, r1, q2, r2);
-            const int a = q1 >> 8, b = q2 >> 8;
-            L.cols[k][lane] = (int32_t)(clamp_col(min(a, b)) | (clamp_col(max(a, b)) << 16));
-        }
-    } else {
-        // ---- SUB row: 15 sample rows, edges sorted by cell, spans between winding transitions
-        res.mode = ROW_SUB;
-        int na = 0;
-        for (int k = 0; k < n; ++k) { L.aux[k][lane] = 0; L.cols[k][lane] = 0x0000ffff; }   // lo = 65535, hi = 0
-        for (int s = 0; s < 15; ++s) {
-            const int ss = s0 + s;
-            for (int k = 0; k < n; ++k) {       // activate edges whose first sub-row is ss
-                const DevEdge& er = E[L.eid[k][lane]];
-                const int first = max(er.ytop, s0);
-                if (first != ss) continue;
-                const DevEdge e = er;
-                int32_t q; int64_t rm;
-                edge_x_at(e, ss, q, rm);
-                L.quo[k][lane] = q; L.rem_lo[k][lane] = (int32_t)(uint32_t)rm; L.rem_hi[k][lane] = (int32_t)(rm >> 32);
-                L.cell[k][lane] = e.dy ? cell_of(q, rm, e.dy) : e.x1;
-                L.ord[na][lane] = (uint8_t)k; ++na;
-            }
-            for (int i = 1; i < na; ++i) {      // stable insertion sort by cell
-                const uint8_t ki = L.ord[i][lane];
-                const int ci = L.cell[ki][lane];
-                int j = i - 1;
-                while (j >= 0 && L.cell[L.ord[j][lane]][lane] > ci) { L.ord[j + 1][lane] = L.ord[j][lane]; --j; }
-                L.ord[j + 1][lane] = ki;
-            }
-            // winding walk over groups of equal cell: a group opens a span when the winding enters
-            // "inside" across it, closes one when it leaves
-            int w = 0, i = 0;
-            while (i < na) {
-                const int kf = L.ord[i][lane];
-                const int c = L.cell[kf][lane];
-                const bool in_before = ((unsigned)w & mask) != 0;
-                int j = i;
-                while (j < na && L.cell[L.ord[j][lane]][lane] == c) { w += E[L.eid[L.ord[j][lane]][lane]].dir; ++j; }
-                const bool in_after = ((unsigned)w & mask) != 0;
-                if (in_after != in_before) {
-                    L.aux[kf][lane] |= (in_after ? 1 : 2) << (2 * s);
-                    const uint32_t col = clamp_col(c >> 8), old = (uint32_t)L.cols[kf][lane];
-                    L.cols[kf][lane] = (int32_t)(min(old & 0xffffu, col) | (max(old >> 16, col) << 16));
-                }
-                i = j;
-            }
-            // retire edges whose last sub-row was ss, step the others
-            int keep = 0;
-            for (int i2 = 0; i2 < na; ++i2) {
-                const int k = L.ord[i2][lane];
-                const DevEdge& er = E[L.eid[k][lane]];
-                if (er.ybot == ss + 1) continue;
-                if (er.dy) {
-                    const DevEdge e = er;
-                    int32_t q = L.quo[k][lane];
-                    int64_t rm = ((int64_t)L.rem_hi[k][lane] << 32) | (uint32_t)L.rem_lo[k][lane];
-                    step_x(q, rm, e);
-                    L.quo[k][lane] = q; L.rem_lo[k][lane] = (int32_t)(uint32_t)rm; L.rem_hi[k][lane] = (int32_t)(rm >> 32);
-                    L.cell[k][lane] = cell_of(q, rm, e.dy);
-                }
-                L.ord[keep][lane] = (uint8_t)k; ++keep;
-            }
-            na = keep;
-        }
-    }
-    return res;
-}
-
 #define ROWS_FAST_N 8            // active edges per row handled in registers by k_rows
 #define ROWS_BIG_MAXA 64         // capacity of the generic (LDS list) routine in k_rows_big
 #define ROWS_STAGE 64            // paths with at most this many edges are staged into LDS
@@ -626,33 +463,137 @@ __global__ __launch_bounds__(64) void k_rows(const DevEdge* __restrict__ edges, 
 }
 
 // Rows with more than ROWS_FAST_N active edges of one path (the host lists them at upload, with their record slots):
-// one lane per listed row, generic LDS-list routine with ROWS_BIG_MAXA capacity.
+// one wavefront per row, lane = active edge (up to 64).  Same decisions as fast_rows, but the "edge i sorts before edge j"
+// sums run over lanes with v_readlane broadcasts instead of over register slots, and the fifteen sample rows are a loop.
 __global__ __launch_bounds__(64) void k_rows_big(const DevEdge* __restrict__ edges, const DevPath* __restrict__ paths,
                                                  const uint32_t* __restrict__ row_base, const BigRow* __restrict__ big_rows, uint32_t n_big,
-                                                 RowInfo* __restrict__ rows, Rec* __restrict__ records, uint32_t* __restrict__ counters) {
-    __shared__ RowLds<ROWS_BIG_MAXA> L;
+                                                 RowInfo* __restrict__ rows, Rec* __restrict__ records, uint32_t* __restrict__ counters,
+                                                 int cell_mode) {
+    __shared__ uint32_t active[ROWS_BIG_MAXA];
     const int lane = threadIdx.x;
-    const uint32_t i = blockIdx.x * 64 + lane;
-    if (i >= n_big) return;                       // process_row has no workgroup barriers: lanes are independent
-    const BigRow br = big_rows[i];
+    if (blockIdx.x >= n_big) return;
+    const BigRow br = big_rows[blockIdx.x];
     const DevPath P = paths[br.path];
-    const int r = br.row;
+    const int r = br.row, s0 = r * 15;
     const uint32_t t = row_base[br.path] + (uint32_t)(r - P.y_min);
-    const RowResult res = process_row<ROWS_BIG_MAXA>(edges + P.first_edge, P, r, L, lane);
-    RowInfo ri; ri.rec_off = 0; ri.n_rec = 0; ri.mode = ROW_EMPTY;
-    if (res.overflow) {
-        atomicOr(&counters[CNT_ERROR], 1u);
-    } else {
-        uint32_t n_out = 0;
-        for (int k = 0; k < res.n; ++k) n_out += L.aux[k][lane] != 0;
-        uint32_t off = br.rec_base;               // the row owns as many slots as it has active edges
-        ri.rec_off = off; ri.n_rec = (uint16_t)n_out; ri.mode = (uint16_t)res.mode;
-        for (int k = 0; k < res.n; ++k) {
-            const int32_t roles = L.aux[k][lane];
-            if (roles) records[off++] = make_record(edges[P.first_edge + (uint32_t)L.eid[k][lane]], P.first_edge + (uint32_t)L.eid[k][lane], r * 15, (uint32_t)roles, (uint32_t)L.cols[k][lane]);
+    const unsigned mask = P.fill_rule ? 1u : ~0u;
+    const DevEdge* E = edges + P.first_edge;
+    // ---- gather: compact the indices of the active edges, 64 candidates per pass (path order is kept)
+    int n = 0;
+    bool too_many = false;
+    for (uint32_t base = 0; base < P.n_edges; base += 64) {
+        const uint32_t k = base + (uint32_t)lane;
+        bool act = false;
+        if (k < P.n_edges) { const int ytop = E[k].ytop, ybot = E[k].ybot; act = !(ybot <= s0 || ytop >= s0 + 15); }
+        const unsigned long long b = __ballot(act);
+        const int at = n + __popcll(b & ((1ull << lane) - 1ull));
+        if (act && at < ROWS_BIG_MAXA) active[at] = k;
+        n += __popcll(b);
+        if (n > ROWS_BIG_MAXA) { too_many = true; break; }
+    }
+    __syncthreads();
+    RowInfo ri; ri.rec_off = br.rec_base; ri.n_rec = 0; ri.mode = ROW_EMPTY;
+    if (too_many) {
+        if (lane == 0) { atomicOr(&counters[CNT_ERROR], 1u); rows[t] = ri; }
+        return;
+    }
+    const bool mine = lane < n;
+    const uint32_t k_mine = mine ? active[lane] : active[0];
+    const DevEdge e = E[n ? k_mine : 0];                      // lanes past the list compute on a valid edge and are ignored
+    const bool slanted = e.dy != 0;
+    const bool mid_row = __ballot(mine && ((e.ytop > s0) | (e.ybot < s0 + 15))) != 0ull;
+    uint32_t role = 0, cols = 0;
+    int32_t q1 = e.x1, q2 = e.x1; int64_t r1 = 0, r2 = 0;
+    bool full = !mid_row && n > 0;
+    if (full) {
+        // ---- FULL candidate: keys at the first sample row of this pixel row and of the next; exact row-top / bottom end points
+        int c0 = e.x1, c1 = e.x1, cpv = e.x1;
+        if (slanted) {
+            int32_t qa, qb; int64_t ra, rb;
+            edge_x_at(e, s0, qa, ra);
+            edge_x_at(e, s0 + 15, qb, rb);
+            c0 = cell_of(qa, ra, e.dy);
+            c1 = cell_of(qb, rb, e.dy);
+            cpv = c0;
+            if (e.ytop < s0) {
+                int32_t q = qa - (int32_t)e.dq; int64_t rm = ra - e.dr;
+                if (rm < 0) { --q; rm += e.dy; } else if (rm >= e.dy) { ++q; rm -= e.dy; }
+                cpv = cell_of(q, rm, e.dy);
+            }
+            const int32_t hq = (int32_t)(e.dq / 2); const int64_t hr = e.dr / 2;
+            qa -= hq; ra -= hr; if (ra < 0) { --qa; ra += e.dy; } else if (ra >= e.dy) { ++qa; ra -= e.dy; }
+            qb -= hq; rb -= hr; if (rb < 0) { --qb; rb += e.dy; } else if (rb >= e.dy) { ++qb; rb -= e.dy; }
+            q1 = qa; r1 = ra; q2 = qb; r2 = rb;
+        }
+        const int nw = (e.ytop == s0) ? 1 : 0, dr = e.dir;
+        int w = 0; bool fg = true, lg = true, ok = true;
+        for (int i = 0; i < n; ++i) {                         // wave-uniform loop: lane i's keys broadcast to every lane
+            const int ci = __builtin_amdgcn_readlane(c0, i), ei = __builtin_amdgcn_readlane(c1, i), pi = __builtin_amdgcn_readlane(cpv, i);
+            const int ni = __builtin_amdgcn_readlane(nw, i), di = __builtin_amdgcn_readlane(dr, i);
+            if (i == lane) continue;
+            // does edge i sort before this lane's edge?  (cell, active-before-new, previous cell, path order)
+            const bool tie = ci == c0, tie2 = ni == nw;
+            const bool t3 = ni == 0 ? (pi < cpv || (pi == cpv && i < lane)) : (i < lane);
+            const bool before = ci < c0 || (tie && (ni < nw || (tie2 && t3)));
+            if (before) { w += di; if (ei > c1) ok = false; if (tie) fg = false; }
+            else if (tie) lg = false;
+        }
+        full = __ballot(mine && !ok) == 0ull;
+        if (full && mine) {
+            const bool in_b = ((unsigned)w & mask) != 0, in_a = ((unsigned)(w + dr) & mask) != 0;
+            if (!in_b && fg) role = REC_FULL | 1u;            // left edge of a span
+            else if (!in_a && lg) role = REC_FULL | 2u;       // right edge
+            if (role) { const int a = q1 >> 8, b = q2 >> 8; cols = clamp_col(min(a, b)) | (clamp_col(max(a, b)) << 16); }
         }
     }
-    rows[t] = ri;
+    uint32_t mode = n == 0 ? ROW_EMPTY : (full ? ROW_FULL : ROW_SUB);
+    if (n > 0 && !full) {
+        // ---- SUB row: fifteen sample rows; per sample the lanes rank their cells against each other
+        int clo = 65535, chi = 0;
+        for (int sub = 0; sub < 15; ++sub) {
+            const int ss = s0 + sub;
+            const bool act = mine && e.ytop <= ss && ss < e.ybot;
+            int cc = e.x1;
+            if (act && slanted) { int32_t q; int64_t rm; edge_x_at(e, ss, q, rm); cc = cell_of(q, rm, e.dy); }
+            const int dd = act ? e.dir : 0;
+            const unsigned long long am = __ballot(act);
+            int wb = 0, gsum = dd; bool rep = true;
+            unsigned long long m = am;
+            while (m) {                                       // wave-uniform: the active lanes of this sample row
+                const int i = __ffsll((long long)m) - 1; m &= m - 1;
+                const int ci = __builtin_amdgcn_readlane(cc, i), di = __builtin_amdgcn_readlane(dd, i);
+                if (i == lane) continue;
+                if (ci < cc) wb += di;
+                else if (ci == cc) { gsum += di; if (i < lane) rep = false; }
+            }
+            if (act && rep) {
+                const bool in_b = ((unsigned)wb & mask) != 0, in_a = ((unsigned)(wb + gsum) & mask) != 0;
+                if (in_a != in_b) {
+                    role |= (uint32_t)(in_a ? 1 : 2) << (2 * sub);
+                    const int col = (int)clamp_col(cc >> 8);
+                    clo = min(clo, col); chi = max(chi, col);
+                }
+            }
+        }
+        cols = (uint32_t)clo | ((uint32_t)chi << 16);
+    }
+    // ---- records: one per edge that carries a role, in path order
+    const bool has = mine && role != 0;
+    const unsigned long long hm = __ballot(has);
+    if (has) {
+        const uint32_t off = br.rec_base + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
+        Rec rc;
+        if (role & REC_FULL) {
+            bool as_cells = false;
+            if (cell_mode & 1) as_cells = full_cells_ends(q1, r1, q2, r2, e.dy, (role & 1u) ? +1 : -1, rc);
+            if (!as_cells) {
+                rc.roles = role; rc.cols = cols; rc.eid = P.first_edge + k_mine; rc.dy = e.dy; rc.span = 0;
+                rc.q1 = q1; rc.r1 = r1; rc.q2 = q2; rc.r2 = r2;
+            }
+        } else rc = make_record(e, P.first_edge + k_mine, s0, role, cols);
+        records[off] = rc;
+    }
+    if (lane == 0) { ri.n_rec = (uint16_t)__popcll(hm); ri.mode = (uint16_t)mode; rows[t] = ri; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1401,7 +1342,7 @@ void launch_rows(hipStream_t st, const DevEdge* edges, const DevPath* paths, con
     hipLaunchKernelGGL(k_rows, dim3(n_chunks), dim3(64), 0, st, edges, paths, row_base, chunk_base, n_paths, rows, records,
                        band_index, band_count, fast_limit, cell_mode);
     if (n_big)
-        hipLaunchKernelGGL(k_rows_big, dim3((n_big + 63) / 64), dim3(64), 0, st, edges, paths, row_base, big_rows, n_big, rows, records, counters);
+        hipLaunchKernelGGL(k_rows_big, dim3(n_big), dim3(64), 0, st, edges, paths, row_base, big_rows, n_big, rows, records, counters, cell_mode);
 }
 void launch_class(hipStream_t st, const BandEntry* band_list, uint32_t n_entries, const uint32_t* band_off, uint32_t n_bands,
                   const swfr_edge* raw, const RowInfo* rows, const Rec* records, uint8_t* cls_t, int width, int height,
