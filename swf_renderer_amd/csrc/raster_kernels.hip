@@ -230,7 +230,7 @@ struct FastLds {
 //   phase B (lane = (SUB row, sub-row)): four SUB rows x 15 sample rows per pass; closed-form x per sample,
 //                         open/close role per group of equal cells, OR-ed into the row's role words in LDS
 template <class EPTR>
-__device__ __forceinline__ void fast_rows(EPTR E, const DevPath& P, int r, bool live, int fast_limit, FastLds& F, int lane,
+__device__ __forceinline__ void fast_rows(EPTR E, uint32_t n_list, const DevPath& P, int r, bool live, int fast_limit, FastLds& F, int lane,
                                           uint32_t& mode_out, int& n_out_edges, bool& overflow_out,
                                           int32_t (&roles)[ROWS_FAST_N], int32_t (&cols)[ROWS_FAST_N], int (&el)[ROWS_FAST_N],
                                           int32_t (&Q1)[ROWS_FAST_N], int64_t (&R1)[ROWS_FAST_N], int32_t (&Q2)[ROWS_FAST_N], int64_t (&R2)[ROWS_FAST_N]) {
@@ -243,7 +243,7 @@ __device__ __forceinline__ void fast_rows(EPTR E, const DevPath& P, int r, bool 
     for (int s = 0; s < ROWS_FAST_N; ++s) { cs[s] = ce[s] = cp[s] = dr[s] = nw[s] = 0; el[s] = 0; roles[s] = 0; cols[s] = 0; Q1[s] = Q2[s] = 0; R1[s] = R2[s] = 0; }
     // ---- gather: which edges are active in this row (sample rows [ytop, ybot) against the row's fifteen); no arithmetic yet
     if (live) {
-        for (uint32_t k = 0; k < P.n_edges; ++k) {
+        for (uint32_t k = 0; k < n_list; ++k) {
             const int ytop = E[k].ytop, ybot = E[k].ybot;
             if (ybot <= s0 || ytop >= s0 + 15) continue;
             if (n >= fast_limit) { overflow = true; break; }
@@ -408,6 +408,7 @@ __global__ __launch_bounds__(64) void k_rows(const DevEdge* __restrict__ edges, 
                                              uint32_t band_index, uint32_t band_count, int fast_limit, int cell_mode) {
     __shared__ FastLds F;
     __shared__ DevEdge staged[ROWS_STAGE];
+    __shared__ uint16_t staged_id[ROWS_STAGE], staged_hi[ROWS_STAGE];   // path-relative index of a staged edge (diagnostic eid)
     const int lane = threadIdx.x;
     // workgroup -> (path, 64 rows): one wave-uniform descriptor load, so path and edge reads are scalar
     const ChunkInfo ck = chunks[blockIdx.x];
@@ -420,16 +421,28 @@ __global__ __launch_bounds__(64) void k_rows(const DevEdge* __restrict__ edges, 
     if (live && band_count > 1 && (uint32_t)((r / TILE_H) % band_count) != band_index) live = false;
     const uint32_t t = row_base[lo] + (uint32_t)(r - P.y_min);          // row task index (valid when in_path)
     if (P.n_edges > 65535u) fast_limit = 0;                             // 16-bit local edge indices in the fast path
-    const bool use_lds = P.n_edges <= ROWS_STAGE;
-    if (use_lds) {
-        if ((uint32_t)lane < P.n_edges) staged[lane] = edges[P.first_edge + lane];
-        __syncthreads();
+    // ---- stage the edges that can be active in this chunk's 64 rows (path order kept): the row loops then run over that
+    //      short list in LDS instead of over every edge of the path; only if more than ROWS_STAGE overlap do they read L2
+    const int lo_s = (int)ck.first_row * 15, hi_s = lo_s + ROWS_CHUNK * 15;
+    uint32_t n_list = 0;
+    bool use_lds = true;
+    for (uint32_t eb = 0; eb < P.n_edges; eb += 64) {
+        const uint32_t k = eb + (uint32_t)lane;
+        DevEdge ek;
+        bool hit = false;
+        if (k < P.n_edges) { ek = edges[P.first_edge + k]; hit = ek.ytop < hi_s && ek.ybot > lo_s; }
+        const unsigned long long hb = __ballot(hit);
+        const uint32_t at = n_list + (uint32_t)__popcll(hb & ((1ull << lane) - 1ull));
+        if (hit && at < ROWS_STAGE) { staged[at] = ek; staged_id[at] = (uint16_t)(k & 0xffffu); staged_hi[at] = (uint16_t)(k >> 16); }
+        n_list += (uint32_t)__popcll(hb);
+        if (n_list > ROWS_STAGE) { use_lds = false; break; }
     }
+    __syncthreads();
     uint32_t mode; int n; bool overflow;
     int32_t roles[ROWS_FAST_N], cols[ROWS_FAST_N]; int el[ROWS_FAST_N];
     int32_t Q1[ROWS_FAST_N], Q2[ROWS_FAST_N]; int64_t R1[ROWS_FAST_N], R2[ROWS_FAST_N];
-    if (use_lds) fast_rows((const DevEdge*)staged, P, r, live, fast_limit, F, lane, mode, n, overflow, roles, cols, el, Q1, R1, Q2, R2);
-    else fast_rows(edges + P.first_edge, P, r, live, fast_limit, F, lane, mode, n, overflow, roles, cols, el, Q1, R1, Q2, R2);
+    if (use_lds) fast_rows((const DevEdge*)staged, n_list, P, r, live, fast_limit, F, lane, mode, n, overflow, roles, cols, el, Q1, R1, Q2, R2);
+    else fast_rows(edges + P.first_edge, P.n_edges, P, r, live, fast_limit, F, lane, mode, n, overflow, roles, cols, el, Q1, R1, Q2, R2);
     uint32_t n_out = 0;
 #pragma unroll
     for (int s = 0; s < ROWS_FAST_N; ++s) n_out += (s < n && roles[s] != 0) ? 1u : 0u;
@@ -444,17 +457,18 @@ __global__ __launch_bounds__(64) void k_rows(const DevEdge* __restrict__ edges, 
         for (int s = 0; s < ROWS_FAST_N; ++s) {
             if (s < n && roles[s] != 0) {
                 Rec rc;
+                const uint32_t eidx = use_lds ? ((uint32_t)staged_id[el[s]] | ((uint32_t)staged_hi[el[s]] << 16)) : (uint32_t)el[s];
                 if ((uint32_t)roles[s] & REC_FULL) {     // end points are already known: cells, or the generic FULL record
                     const int64_t edy = use_lds ? staged[el[s]].dy : edges[P.first_edge + el[s]].dy;
                     bool as_cells = false;
                     if (cell_mode & 1) as_cells = full_cells_ends(Q1[s], R1[s], Q2[s], R2[s], edy, ((uint32_t)roles[s] & 1u) ? +1 : -1, rc);
                     if (!as_cells) {
-                        rc.roles = (uint32_t)roles[s]; rc.cols = (uint32_t)cols[s]; rc.eid = P.first_edge + (uint32_t)el[s]; rc.dy = edy; rc.span = 0;
+                        rc.roles = (uint32_t)roles[s]; rc.cols = (uint32_t)cols[s]; rc.eid = P.first_edge + eidx; rc.dy = edy; rc.span = 0;
                         rc.q1 = Q1[s]; rc.r1 = R1[s]; rc.q2 = Q2[s]; rc.r2 = R2[s];
                     }
                 } else {
                     const DevEdge e = use_lds ? staged[el[s]] : edges[P.first_edge + el[s]];
-                    rc = make_record(e, P.first_edge + (uint32_t)el[s], r * 15, (uint32_t)roles[s], (uint32_t)cols[s]);
+                    rc = make_record(e, P.first_edge + eidx, r * 15, (uint32_t)roles[s], (uint32_t)cols[s]);
                 }
                 records[off++] = rc;
             }
