@@ -57,7 +57,7 @@ struct Rec {
 static_assert(sizeof(Rec) == 48, "Rec layout");
 
 enum : uint32_t { CNT_RECORDS = 0, CNT_ERROR = 1, CNT_OVERFLOW = 2, CNT_PAIRS = 3, CNT_PARTIAL = 4, CNT_FULL = 5, CNT_CULLED = 6, CNT_WORDS = 24 };
-constexpr int ROWS_CHUNK = 64;       // pixel rows per k_rows workgroup (one lane per row)
+constexpr int ROWS_CHUNK = 64;       // most pixel rows per k_rows workgroup (one lane per row)
 
 // Band list entry: everything a tile needs to bin, classify and cull a path without touching paths[]/styles[].
 struct BandEntry {
@@ -72,10 +72,10 @@ struct BandEntry {
 static_assert(sizeof(BandEntry) == 36, "BandEntry layout");
 enum : uint32_t { BE_BOXES = 1u, BE_LERP = 2u, BE_SOLID = 4u, BE_OPAQUE_COVER = 8u /* solid, alpha 255, lerp blend */ };
 
-// One k_rows workgroup: 64 consecutive pixel rows of one path.  rec_base is the first record slot reserved for the
+// One k_rows workgroup: `rows` (<= 64) consecutive pixel rows of one path.  rec_base is the first record slot reserved for the
 // chunk (host-computed upper bound), so record allocation needs no global atomics.
 struct ChunkInfo {
-    uint32_t path, first_row, rec_base, pad;
+    uint32_t path, first_row, rec_base, rows;
 };
 
 // One (path, tile-row) pair: where its BandEntry goes.  The host assigns the slots (painter's order inside every

@@ -416,14 +416,15 @@ __global__ __launch_bounds__(64) void k_rows(const DevEdge* __restrict__ edges, 
     (void)n_paths;
     const DevPath P = paths[lo];
     const int r = (int)ck.first_row + lane;
-    const bool in_path = P.kind == SWFR_PATH_TOR && lane < ROWS_CHUNK && r < P.y_max;
+    const int chunk_rows = (int)ck.rows;                                // 64, or fewer for scenes of a few tall paths
+    const bool in_path = P.kind == SWFR_PATH_TOR && lane < chunk_rows && r < P.y_max;
     bool live = in_path;
     if (live && band_count > 1 && (uint32_t)((r / TILE_H) % band_count) != band_index) live = false;
     const uint32_t t = row_base[lo] + (uint32_t)(r - P.y_min);          // row task index (valid when in_path)
     if (P.n_edges > 65535u) fast_limit = 0;                             // 16-bit local edge indices in the fast path
     // ---- stage the edges that can be active in this chunk's 64 rows (path order kept): the row loops then run over that
     //      short list in LDS instead of over every edge of the path; only if more than ROWS_STAGE overlap do they read L2
-    const int lo_s = (int)ck.first_row * 15, hi_s = lo_s + ROWS_CHUNK * 15;
+    const int lo_s = (int)ck.first_row * 15, hi_s = lo_s + chunk_rows * 15;
     uint32_t n_list = 0;
     bool use_lds = true;
     for (uint32_t eb = 0; eb < P.n_edges; eb += 64) {

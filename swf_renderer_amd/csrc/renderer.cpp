@@ -264,14 +264,26 @@ int upload(swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_
     const size_t n_bands = (r->height + TILE_H - 1) / TILE_H;
     std::vector<uint32_t> band_off(n_bands + 1, 0);
     size_t rec_cap = 0, pair_cap = 0;
+    // rows per k_rows workgroup: 64 when that already gives the GPU a thousand wavefronts, fewer for scenes made of a few tall
+    // paths (a wavefront's run time is set by its longest row loop, so those scenes want more, shorter wavefronts)
+    uint32_t chunk_rows = ROWS_CHUNK;
+    {
+        for (;;) {
+            size_t n = 0;
+            for (size_t i = 0; i < n_paths; ++i)
+                if (paths[i].kind == SWFR_PATH_TOR) n += size_t(paths[i].y_max - paths[i].y_min + int(chunk_rows) - 1) / chunk_rows;
+            if (n >= 1024 || chunk_rows <= 8) break;
+            chunk_rows >>= 1;
+        }
+    }
     for (size_t i = 0; i < n_paths; ++i) {
         const swfr_path& p = paths[i];
         for (uint32_t k = 0; k < p.n_edges; ++k) staged[p.first_edge + k].reserved = int32_t(i);
         uint32_t rows = 0;
         if (p.kind == SWFR_PATH_TOR) {
             rows = uint32_t(p.y_max - p.y_min);
-            const size_t c0 = chunks.size(), nc = (rows + ROWS_CHUNK - 1) / ROWS_CHUNK;
-            for (size_t c = 0; c < nc; ++c) chunks.push_back(ChunkInfo{uint32_t(i), uint32_t(p.y_min) + uint32_t(c) * ROWS_CHUNK, 0, 0});
+            const size_t c0 = chunks.size(), nc = (rows + chunk_rows - 1) / chunk_rows;
+            for (size_t c = 0; c < nc; ++c) chunks.push_back(ChunkInfo{uint32_t(i), uint32_t(p.y_min) + uint32_t(c) * chunk_rows, 0, chunk_rows});
             chunk_cap.resize(chunks.size(), 0);
             // active edges per pixel row, exactly as k_setup / k_rows count them (sample rows [ytop, ybot) clamped to the
             // path): a row yields at most one record per active edge, so these counts size the record slots; rows
@@ -293,7 +305,7 @@ int upload(swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_
                 const uint32_t band = (uint32_t(p.y_min) + y) / TILE_H;
                 if (bc > 1 && band % bc != bi) continue;          // another rank's tile-row: k_rows leaves it empty
                 if (run > limit) { big_rows.push_back(BigRow{uint32_t(i), int32_t(p.y_min) + int32_t(y), uint32_t(run), 0}); }
-                else chunk_cap[c0 + y / ROWS_CHUNK] += uint32_t(run);
+                else chunk_cap[c0 + y / chunk_rows] += uint32_t(run);
             }
         }
         row_base[i + 1] = row_base[i] + rows;
