@@ -477,6 +477,166 @@ __global__ __launch_bounds__(64) void k_rows(const DevEdge* __restrict__ edges, 
     }
 }
 
+// k_rows for scenes made of a few tall paths (the host then cuts the paths into 8-row chunks): lane = (row of the chunk, slot
+// of that row's active-edge list), so the per-edge evaluation is one step instead of a loop over slots and the "edge i sorts
+// before edge j" sums are eight shuffles inside the row's 8-lane group.  Same decisions and records as k_rows.
+template <class EPTR>
+__device__ __forceinline__ void rows_by_slot(EPTR E, uint32_t n_list, const uint32_t* staged_k, const DevPath& P, const ChunkInfo& ck,
+                                             const uint32_t* __restrict__ row_base, RowInfo* __restrict__ rows, Rec* __restrict__ records,
+                                             uint32_t band_index, uint32_t band_count, int fast_limit, int cell_mode, int lane) {
+    const int g = lane >> 3, slot = lane & 7, gbase = lane & ~7;
+    const int r = (int)ck.first_row + g, s0 = r * 15;
+    const bool in_path = P.kind == SWFR_PATH_TOR && g < (int)ck.rows && r < P.y_max;
+    bool live = in_path;
+    if (live && band_count > 1 && (uint32_t)((r / TILE_H) % band_count) != band_index) live = false;
+    const uint32_t t = row_base[ck.path] + (uint32_t)(r - P.y_min);
+    const unsigned mask = P.fill_rule ? 1u : ~0u;
+    // ---- gather: the eight lanes of a row walk the list together; lane `slot` keeps the slot-th active edge
+    int n = 0, my_k = 0;
+    bool mid_row = false, overflow = false;
+    if (live) {
+        for (uint32_t k = 0; k < n_list; ++k) {
+            const int ytop = E[k].ytop, ybot = E[k].ybot;
+            if (ybot <= s0 || ytop >= s0 + 15) continue;
+            if (n >= fast_limit) { overflow = true; break; }
+            mid_row |= (ytop > s0) | (ybot < s0 + 15);
+            if (n == slot) my_k = (int)k;
+            ++n;
+        }
+    }
+    if (overflow) n = 0;
+    const bool mine = slot < n;
+    const DevEdge e = E[n_list ? (uint32_t)my_k : 0u];
+    const bool slanted = e.dy != 0;
+    const bool cand = n > 0 && !mid_row;
+    int c0 = e.x1, c1 = e.x1, cpv = e.x1;
+    int32_t q1 = e.x1, q2 = e.x1; int64_t r1 = 0, r2 = 0;
+    if (mine && cand && slanted) {
+        int32_t qa, qb; int64_t ra, rb;
+        edge_x_at(e, s0, qa, ra);
+        edge_x_at(e, s0 + 15, qb, rb);
+        c0 = cell_of(qa, ra, e.dy);
+        c1 = cell_of(qb, rb, e.dy);
+        cpv = c0;
+        if (e.ytop < s0) {
+            int32_t q = qa - (int32_t)e.dq; int64_t rm = ra - e.dr;
+            if (rm < 0) { --q; rm += e.dy; } else if (rm >= e.dy) { ++q; rm -= e.dy; }
+            cpv = cell_of(q, rm, e.dy);
+        }
+        const int32_t hq = (int32_t)(e.dq / 2); const int64_t hr = e.dr / 2;
+        qa -= hq; ra -= hr; if (ra < 0) { --qa; ra += e.dy; } else if (ra >= e.dy) { ++qa; ra -= e.dy; }
+        qb -= hq; rb -= hr; if (rb < 0) { --qb; rb += e.dy; } else if (rb >= e.dy) { ++qb; rb -= e.dy; }
+        q1 = qa; r1 = ra; q2 = qb; r2 = rb;
+    }
+    const int nw = (e.ytop == s0) ? 1 : 0, dr = e.dir;
+    // ---- FULL test: keys of the other slots of this row by shuffles (every lane takes part: bpermute reads 0 from idle lanes)
+    int w = 0; bool fg = true, lg = true, ok = true;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int src = gbase | i;
+        const int ci = __shfl(c0, src), ei = __shfl(c1, src), pi = __shfl(cpv, src), ni = __shfl(nw, src), di = __shfl(dr, src);
+        if (!(mine && cand) || i >= n || i == slot) continue;
+        const bool tie = ci == c0, tie2 = ni == nw;
+        const bool t3 = ni == 0 ? (pi < cpv || (pi == cpv && i < slot)) : (i < slot);
+        const bool before = ci < c0 || (tie && (ni < nw || (tie2 && t3)));
+        if (before) { w += di; if (ei > c1) ok = false; if (tie) fg = false; }
+        else if (tie) lg = false;
+    }
+    const unsigned long long bad = __ballot(mine && cand && !ok);
+    const bool full = cand && ((bad >> gbase) & 0xffull) == 0ull;
+    uint32_t role = 0, cols = 0;
+    if (full && mine) {
+        const bool in_b = ((unsigned)w & mask) != 0, in_a = ((unsigned)(w + dr) & mask) != 0;
+        if (!in_b && fg) role = REC_FULL | 1u;
+        else if (!in_a && lg) role = REC_FULL | 2u;
+        if (role) { const int a = q1 >> 8, b = q2 >> 8; cols = clamp_col(min(a, b)) | (clamp_col(max(a, b)) << 16); }
+    }
+    // ---- SUB rows: fifteen sample rows, ranked inside the row's lane group
+    const bool is_sub = n > 0 && !full;
+    if (__ballot(is_sub) != 0ull) {
+        int clo = 65535, chi = 0;
+        for (int sub = 0; sub < 15; ++sub) {
+            const int ss = s0 + sub;
+            const bool act = mine && is_sub && e.ytop <= ss && ss < e.ybot;
+            int cc = e.x1;
+            if (act && slanted) { int32_t q; int64_t rm; edge_x_at(e, ss, q, rm); cc = cell_of(q, rm, e.dy); }
+            const int dd = act ? e.dir : 0;
+            const unsigned long long am = __ballot(act);
+            int wb = 0, gsum = dd; bool rep = true;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int src = gbase | i;
+                const int ci = __shfl(cc, src), di = __shfl(dd, src);
+                if (!act || i == slot || !((am >> src) & 1ull)) continue;
+                if (ci < cc) wb += di;
+                else if (ci == cc) { gsum += di; if (i < slot) rep = false; }
+            }
+            if (act && rep) {
+                const bool in_b = ((unsigned)wb & mask) != 0, in_a = ((unsigned)(wb + gsum) & mask) != 0;
+                if (in_a != in_b) {
+                    role |= (uint32_t)(in_a ? 1 : 2) << (2 * sub);
+                    const int col = (int)clamp_col(cc >> 8);
+                    clo = min(clo, col); chi = max(chi, col);
+                }
+            }
+        }
+        if (is_sub) cols = (uint32_t)clo | ((uint32_t)chi << 16);
+    }
+    // ---- records in (row, slot) order: the chunk owns consecutive slots from rec_base
+    const bool has = mine && role != 0 && in_path && !overflow;
+    const unsigned long long hm = __ballot(has);
+    if (has) {
+        const uint32_t off = ck.rec_base + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
+        const uint32_t eidx = staged_k ? staged_k[my_k] : (uint32_t)my_k;
+        Rec rc;
+        if (role & REC_FULL) {
+            bool as_cells = false;
+            if (cell_mode & 1) as_cells = full_cells_ends(q1, r1, q2, r2, e.dy, (role & 1u) ? +1 : -1, rc);
+            if (!as_cells) {
+                rc.roles = role; rc.cols = cols; rc.eid = P.first_edge + eidx; rc.dy = e.dy; rc.span = 0;
+                rc.q1 = q1; rc.r1 = r1; rc.q2 = q2; rc.r2 = r2;
+            }
+        } else rc = make_record(e, P.first_edge + eidx, s0, role, cols);
+        records[off] = rc;
+    }
+    if (slot == 0 && in_path && !overflow) {
+        RowInfo ri;
+        ri.rec_off = ck.rec_base + (uint32_t)__popcll(hm & ((1ull << gbase) - 1ull));
+        ri.n_rec = (uint16_t)__popcll((hm >> gbase) & 0xffull);
+        ri.mode = (uint16_t)(n == 0 ? ROW_EMPTY : (full ? ROW_FULL : ROW_SUB));
+        rows[t] = ri;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_rows_rs(const DevEdge* __restrict__ edges, const DevPath* __restrict__ paths,
+                                                const uint32_t* __restrict__ row_base, const ChunkInfo* __restrict__ chunks,
+                                                RowInfo* __restrict__ rows, Rec* __restrict__ records,
+                                                uint32_t band_index, uint32_t band_count, int fast_limit, int cell_mode) {
+    __shared__ DevEdge staged[ROWS_STAGE];
+    __shared__ uint32_t staged_k[ROWS_STAGE];
+    const int lane = threadIdx.x;
+    const ChunkInfo ck = chunks[blockIdx.x];
+    const DevPath P = paths[ck.path];
+    if (P.n_edges > 65535u) fast_limit = 0;                  // same rule as k_rows: the host lists those rows for k_rows_big
+    const int lo_s = (int)ck.first_row * 15, hi_s = lo_s + (int)ck.rows * 15;
+    uint32_t n_list = 0;
+    bool use_lds = true;
+    for (uint32_t eb = 0; eb < P.n_edges; eb += 64) {
+        const uint32_t k = eb + (uint32_t)lane;
+        DevEdge ek;
+        bool hit = false;
+        if (k < P.n_edges) { ek = edges[P.first_edge + k]; hit = ek.ytop < hi_s && ek.ybot > lo_s; }
+        const unsigned long long hb = __ballot(hit);
+        const uint32_t at = n_list + (uint32_t)__popcll(hb & ((1ull << lane) - 1ull));
+        if (hit && at < ROWS_STAGE) { staged[at] = ek; staged_k[at] = k; }
+        n_list += (uint32_t)__popcll(hb);
+        if (n_list > ROWS_STAGE) { use_lds = false; break; }
+    }
+    __syncthreads();
+    if (use_lds) rows_by_slot((const DevEdge*)staged, n_list, (const uint32_t*)staged_k, P, ck, row_base, rows, records, band_index, band_count, fast_limit, cell_mode, lane);
+    else rows_by_slot(edges + P.first_edge, P.n_edges, (const uint32_t*)nullptr, P, ck, row_base, rows, records, band_index, band_count, fast_limit, cell_mode, lane);
+}
+
 // Rows with more than ROWS_FAST_N active edges of one path (the host lists them at upload, with their record slots):
 // one wavefront per row, lane = active edge (up to 64).  Same decisions as fast_rows, but the "edge i sorts before edge j"
 // sums run over lanes with v_readlane broadcasts instead of over register slots, and the fifteen sample rows are a loop.
@@ -1351,11 +1511,15 @@ void launch_front(hipStream_t st, const swfr_edge* in, const DevPath* paths, Dev
 }
 void launch_rows(hipStream_t st, const DevEdge* edges, const DevPath* paths, const uint32_t* row_base, const ChunkInfo* chunk_base,
                  uint32_t n_paths, RowInfo* rows, Rec* records, uint32_t* counters, const BigRow* big_rows, uint32_t n_big, uint32_t n_chunks,
-                 uint32_t band_index, uint32_t band_count, int fast_limit, int cell_mode) {
+                 uint32_t band_index, uint32_t band_count, int fast_limit, int cell_mode, uint32_t chunk_rows) {
     if (!n_chunks) return;
     fast_limit = fast_limit < 0 ? 0 : (fast_limit > ROWS_FAST_N ? ROWS_FAST_N : fast_limit);
-    hipLaunchKernelGGL(k_rows, dim3(n_chunks), dim3(64), 0, st, edges, paths, row_base, chunk_base, n_paths, rows, records,
-                       band_index, band_count, fast_limit, cell_mode);
+    if (chunk_rows <= 8)
+        hipLaunchKernelGGL(k_rows_rs, dim3(n_chunks), dim3(64), 0, st, edges, paths, row_base, chunk_base, rows, records, band_index, band_count,
+                           fast_limit, cell_mode);
+    else
+        hipLaunchKernelGGL(k_rows, dim3(n_chunks), dim3(64), 0, st, edges, paths, row_base, chunk_base, n_paths, rows, records,
+                           band_index, band_count, fast_limit, cell_mode);
     if (n_big)
         hipLaunchKernelGGL(k_rows_big, dim3(n_big), dim3(64), 0, st, edges, paths, row_base, big_rows, n_big, rows, records, counters, cell_mode);
 }

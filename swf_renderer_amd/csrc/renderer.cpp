@@ -27,7 +27,7 @@ void launch_front(hipStream_t, const swfr_edge*, const DevPath*, DevEdge*, uint3
 void launch_class(hipStream_t, const BandEntry*, uint32_t, const uint32_t*, uint32_t, const swfr_edge*, const RowInfo*, const Rec*, uint8_t*, int, int,
                   uint32_t, uint32_t);
 void launch_rows(hipStream_t, const DevEdge*, const DevPath*, const uint32_t*, const ChunkInfo*, uint32_t, RowInfo*, Rec*, uint32_t*, const BigRow*,
-                 uint32_t, uint32_t, uint32_t, uint32_t, int, int);
+                 uint32_t, uint32_t, uint32_t, uint32_t, int, int, uint32_t);
 void launch_tiles(hipStream_t, const swfr_edge*, const uint32_t*, const BandEntry*, const uint8_t*, const RowInfo*, const Rec*, const swfr_style*,
                   Sources, uint32_t*, int, int, uint32_t, uint32_t, int, uint32_t*, uint32_t, uint32_t, bool, const uint32_t*);
 void launch_unpremultiply(hipStream_t, const uint32_t*, uint32_t*, size_t);
@@ -124,9 +124,10 @@ struct swfr_renderer {
     std::vector<DevBitmap> bitmap_table;   // indexed by bitmap id
     bool bitmap_table_dirty = false;
     // resident scene
-    size_t n_edges = 0, n_paths = 0, n_styles = 0, n_tasks = 0, n_chunks = 0, n_bands = 0, rec_cap = 0, rec_main = 0, n_big = 0;
+    size_t n_edges = 0, n_paths = 0, n_styles = 0, n_tasks = 0, n_chunks = 0, n_bands = 0, rec_cap = 0, rec_main = 0, n_big = 0, chunk_rows = 64;
     bool scene_ready = false, fb_valid = false, any_shader = false;
     swfr_timing timing{};
+    int force_chunk_rows = 0;               // SWFR_CHUNK_ROWS: test knob
     int strip_order = 1;                    // SWFR_STRIP_ORDER=0: launch the k_tiles wavefronts in row-major order
     bool has_order = false;
     int event_stride = 8;                   // SWFR_EVENT_STRIDE: per-kernel HIP events on every n-th resident frame
@@ -267,7 +268,9 @@ int upload(swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_
     // rows per k_rows workgroup: 64 when that already gives the GPU a thousand wavefronts, fewer for scenes made of a few tall
     // paths (a wavefront's run time is set by its longest row loop, so those scenes want more, shorter wavefronts)
     uint32_t chunk_rows = ROWS_CHUNK;
-    {
+    if (r->force_chunk_rows == 8 || r->force_chunk_rows == 16 || r->force_chunk_rows == 32 || r->force_chunk_rows == 64) {
+        chunk_rows = uint32_t(r->force_chunk_rows);           // SWFR_CHUNK_ROWS: test knob (8 selects the row x slot kernel)
+    } else {
         for (;;) {
             size_t n = 0;
             for (size_t i = 0; i < n_paths; ++i)
@@ -362,6 +365,7 @@ int upload(swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_
     for (size_t c = 0; c < chunks.size(); ++c) { chunks[c].rec_base = uint32_t(rec_cap); rec_cap += chunk_cap[c]; }
     r->n_tasks = row_base[n_paths];
     r->n_chunks = chunks.size();
+    r->chunk_rows = chunk_rows;
     r->n_bands = n_bands;
     r->rec_main = rec_cap;                            // chunk-owned region; the rows of k_rows_big own slots behind it
     for (auto& b : big_rows) { const uint32_t n = b.rec_base; b.rec_base = uint32_t(rec_cap); rec_cap += n; }
@@ -467,7 +471,7 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
         if (r->n_paths) {
             launch_rows(S.st, S.edges, r->d_paths.ptr, r->d_row_base.ptr, r->d_chunk_base.ptr, uint32_t(r->n_paths), S.rows,
                         S.records, S.counters, r->d_big_rows.ptr, uint32_t(r->n_big), uint32_t(r->n_chunks), bi, bc, r->fast_limit,
-                        r->cell_mode);
+                        r->cell_mode, uint32_t(r->chunk_rows));
             launch_class(S.st, S.band_list, uint32_t(r->n_band_entries), r->d_band_off.ptr, uint32_t(r->n_bands), r->d_raw.ptr,
                          S.rows, S.records, S.cls, int(r->width), int(r->height), bi, bc);
         }
@@ -545,6 +549,7 @@ int swfr_create(uint32_t width, uint32_t height, const swfr_config* cfg, swfr_re
     r->builder.reset(new FrameBuilder(width, height, (r->cfg.flags & SWFR_FLAG_EVEN_ODD) != 0));
     if (const char* fl = std::getenv("SWFR_FAST_LIMIT")) r->fast_limit = std::atoi(fl);
     if (const char* td = std::getenv("SWFR_TILES_DEBUG")) r->tiles_dbg = std::atoi(td);
+    if (const char* cr = std::getenv("SWFR_CHUNK_ROWS")) r->force_chunk_rows = std::atoi(cr);
     if (const char* so = std::getenv("SWFR_STRIP_ORDER")) r->strip_order = std::atoi(so);
     if (const char* fi = std::getenv("SWFR_FRAMES_IN_FLIGHT")) r->in_flight = std::atoi(fi);
     if (const char* es = std::getenv("SWFR_EVENT_STRIDE")) r->event_stride = std::atoi(es);
