@@ -402,16 +402,16 @@ __device__ __forceinline__ void fast_rows(EPTR E, uint32_t n_list, const DevPath
     mode_out = mode; n_out_edges = n; overflow_out = overflow;
 }
 
-__global__ __launch_bounds__(64) void k_rows(const DevEdge* __restrict__ edges, const DevPath* __restrict__ paths,
-                                             const uint32_t* __restrict__ row_base, const ChunkInfo* __restrict__ chunks,
-                                             uint32_t n_paths, RowInfo* __restrict__ rows, Rec* __restrict__ records,
-                                             uint32_t band_index, uint32_t band_count, int fast_limit, int cell_mode) {
+__device__ __forceinline__ void rows_chunk_body(uint32_t block, const DevEdge* __restrict__ edges, const DevPath* __restrict__ paths,
+                                                const uint32_t* __restrict__ row_base, const ChunkInfo* __restrict__ chunks,
+                                                uint32_t n_paths, RowInfo* __restrict__ rows, Rec* __restrict__ records,
+                                                uint32_t band_index, uint32_t band_count, int fast_limit, int cell_mode) {
     __shared__ FastLds F;
     __shared__ DevEdge staged[ROWS_STAGE];
     __shared__ uint16_t staged_id[ROWS_STAGE], staged_hi[ROWS_STAGE];   // path-relative index of a staged edge (diagnostic eid)
     const int lane = threadIdx.x;
     // workgroup -> (path, 64 rows): one wave-uniform descriptor load, so path and edge reads are scalar
-    const ChunkInfo ck = chunks[blockIdx.x];
+    const ChunkInfo ck = chunks[block];
     const uint32_t lo = ck.path;
     (void)n_paths;
     const DevPath P = paths[lo];
@@ -608,14 +608,14 @@ __device__ __forceinline__ void rows_by_slot(EPTR E, uint32_t n_list, const uint
     }
 }
 
-__global__ __launch_bounds__(64) void k_rows_rs(const DevEdge* __restrict__ edges, const DevPath* __restrict__ paths,
-                                                const uint32_t* __restrict__ row_base, const ChunkInfo* __restrict__ chunks,
-                                                RowInfo* __restrict__ rows, Rec* __restrict__ records,
-                                                uint32_t band_index, uint32_t band_count, int fast_limit, int cell_mode) {
+__device__ __forceinline__ void rows_rs_body(uint32_t block, const DevEdge* __restrict__ edges, const DevPath* __restrict__ paths,
+                                             const uint32_t* __restrict__ row_base, const ChunkInfo* __restrict__ chunks,
+                                             RowInfo* __restrict__ rows, Rec* __restrict__ records,
+                                             uint32_t band_index, uint32_t band_count, int fast_limit, int cell_mode) {
     __shared__ DevEdge staged[ROWS_STAGE];
     __shared__ uint32_t staged_k[ROWS_STAGE];
     const int lane = threadIdx.x;
-    const ChunkInfo ck = chunks[blockIdx.x];
+    const ChunkInfo ck = chunks[block];
     const DevPath P = paths[ck.path];
     if (P.n_edges > 65535u) fast_limit = 0;                  // same rule as k_rows: the host lists those rows for k_rows_big
     const int lo_s = (int)ck.first_row * 15, hi_s = lo_s + (int)ck.rows * 15;
@@ -640,14 +640,14 @@ __global__ __launch_bounds__(64) void k_rows_rs(const DevEdge* __restrict__ edge
 // Rows with more than ROWS_FAST_N active edges of one path (the host lists them at upload, with their record slots):
 // one wavefront per row, lane = active edge (up to 64).  Same decisions as fast_rows, but the "edge i sorts before edge j"
 // sums run over lanes with v_readlane broadcasts instead of over register slots, and the fifteen sample rows are a loop.
-__global__ __launch_bounds__(64) void k_rows_big(const DevEdge* __restrict__ edges, const DevPath* __restrict__ paths,
-                                                 const uint32_t* __restrict__ row_base, const BigRow* __restrict__ big_rows, uint32_t n_big,
-                                                 RowInfo* __restrict__ rows, Rec* __restrict__ records, uint32_t* __restrict__ counters,
-                                                 int cell_mode) {
+__device__ __forceinline__ void big_row_body(uint32_t block, const DevEdge* __restrict__ edges, const DevPath* __restrict__ paths,
+                                             const uint32_t* __restrict__ row_base, const BigRow* __restrict__ big_rows, uint32_t n_big,
+                                             RowInfo* __restrict__ rows, Rec* __restrict__ records, uint32_t* __restrict__ counters,
+                                             int cell_mode) {
     __shared__ uint32_t active[ROWS_BIG_MAXA];
     const int lane = threadIdx.x;
-    if (blockIdx.x >= n_big) return;
-    const BigRow br = big_rows[blockIdx.x];
+    if (block >= n_big) return;
+    const BigRow br = big_rows[block];
     const DevPath P = paths[br.path];
     const int r = br.row, s0 = r * 15;
     const uint32_t t = row_base[br.path] + (uint32_t)(r - P.y_min);
@@ -769,6 +769,25 @@ __global__ __launch_bounds__(64) void k_rows_big(const DevEdge* __restrict__ edg
         records[off] = rc;
     }
     if (lane == 0) { ri.n_rec = (uint16_t)__popcll(hm); ri.mode = (uint16_t)mode; rows[t] = ri; }
+}
+
+// The row pass is one launch: the first n_big workgroups take the crowded rows (the longest wavefronts start first), the rest
+// take the chunks -- lane = row for crowded scenes (k_rows), lane = (row, slot) for scenes of a few tall paths (k_rows_rs).
+__global__ __launch_bounds__(64) void k_rows(const DevEdge* __restrict__ edges, const DevPath* __restrict__ paths,
+                                             const uint32_t* __restrict__ row_base, const ChunkInfo* __restrict__ chunks,
+                                             uint32_t n_paths, RowInfo* __restrict__ rows, Rec* __restrict__ records,
+                                             uint32_t band_index, uint32_t band_count, int fast_limit, int cell_mode,
+                                             const BigRow* __restrict__ big_rows, uint32_t n_big, uint32_t* __restrict__ counters) {
+    if (blockIdx.x < n_big) big_row_body(blockIdx.x, edges, paths, row_base, big_rows, n_big, rows, records, counters, cell_mode);
+    else rows_chunk_body(blockIdx.x - n_big, edges, paths, row_base, chunks, n_paths, rows, records, band_index, band_count, fast_limit, cell_mode);
+}
+__global__ __launch_bounds__(64) void k_rows_rs(const DevEdge* __restrict__ edges, const DevPath* __restrict__ paths,
+                                                const uint32_t* __restrict__ row_base, const ChunkInfo* __restrict__ chunks,
+                                                RowInfo* __restrict__ rows, Rec* __restrict__ records,
+                                                uint32_t band_index, uint32_t band_count, int fast_limit, int cell_mode,
+                                                const BigRow* __restrict__ big_rows, uint32_t n_big, uint32_t* __restrict__ counters) {
+    if (blockIdx.x < n_big) big_row_body(blockIdx.x, edges, paths, row_base, big_rows, n_big, rows, records, counters, cell_mode);
+    else rows_rs_body(blockIdx.x - n_big, edges, paths, row_base, chunks, rows, records, band_index, band_count, fast_limit, cell_mode);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1515,13 +1534,11 @@ void launch_rows(hipStream_t st, const DevEdge* edges, const DevPath* paths, con
     if (!n_chunks) return;
     fast_limit = fast_limit < 0 ? 0 : (fast_limit > ROWS_FAST_N ? ROWS_FAST_N : fast_limit);
     if (chunk_rows <= 8)
-        hipLaunchKernelGGL(k_rows_rs, dim3(n_chunks), dim3(64), 0, st, edges, paths, row_base, chunk_base, rows, records, band_index, band_count,
-                           fast_limit, cell_mode);
+        hipLaunchKernelGGL(k_rows_rs, dim3(n_chunks + n_big), dim3(64), 0, st, edges, paths, row_base, chunk_base, rows, records, band_index, band_count,
+                           fast_limit, cell_mode, big_rows, n_big, counters);
     else
-        hipLaunchKernelGGL(k_rows, dim3(n_chunks), dim3(64), 0, st, edges, paths, row_base, chunk_base, n_paths, rows, records,
-                           band_index, band_count, fast_limit, cell_mode);
-    if (n_big)
-        hipLaunchKernelGGL(k_rows_big, dim3(n_big), dim3(64), 0, st, edges, paths, row_base, big_rows, n_big, rows, records, counters, cell_mode);
+        hipLaunchKernelGGL(k_rows, dim3(n_chunks + n_big), dim3(64), 0, st, edges, paths, row_base, chunk_base, n_paths, rows, records,
+                           band_index, band_count, fast_limit, cell_mode, big_rows, n_big, counters);
 }
 void launch_class(hipStream_t st, const BandEntry* band_list, uint32_t n_entries, const uint32_t* band_off, uint32_t n_bands,
                   const swfr_edge* raw, const RowInfo* rows, const Rec* records, uint8_t* cls_t, int width, int height,
