@@ -130,7 +130,7 @@ def main():
 
     # ---- warmup
     if not bands:
-        r.render_resident(max(args.warmup, 1))
+        r.render_resident(min(max(args.warmup, 1), 2048))
     else:
         for _ in range(max(args.warmup, 1)):
             step_multi()
@@ -138,7 +138,11 @@ def main():
     # ---- timed region: exactly K steps
     t0 = time.perf_counter()
     if not bands:
-        r.render_resident(args.steps)                         # K frames queued back to back on the handle's streams
+        left = args.steps                                     # K frames queued back to back on the handle's streams
+        while left > 0:                                       # (the library takes at most 4096 frames per call)
+            n = min(left, 2048)
+            r.render_resident(n)
+            left -= n
     else:
         out = None
         for _ in range(args.steps):
