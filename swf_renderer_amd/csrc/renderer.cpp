@@ -53,7 +53,15 @@ template <class T>
 struct DevBuf {
     T* ptr = nullptr;
     size_t cap = 0;
+    bool view = false;                       // points into the handle's scene arena: not owned
+    void set_view(void* p) {
+        if (ptr && !view) (void)hipFree(ptr);
+        ptr = static_cast<T*>(p);
+        cap = 0;
+        view = true;
+    }
     void reserve(size_t n) {
+        if (view) { ptr = nullptr; view = false; cap = 0; }
         if (n <= cap) return;
         if (ptr) HIP_CHECK(hipFree(ptr));
         ptr = nullptr;
@@ -64,9 +72,51 @@ struct DevBuf {
         cap = want;
     }
     void release() {
-        if (ptr) (void)hipFree(ptr);
+        if (ptr && !view) (void)hipFree(ptr);
         ptr = nullptr;
         cap = 0;
+        view = false;
+    }
+};
+
+// The read-only arrays of an uploaded scene live in one device allocation and are filled by one H2D copy from one pinned
+// staging buffer (nine small pageable copies cost ~70 us of host time per frame; one pinned copy a fraction of that).
+struct SceneArena {
+    uint8_t* dev = nullptr;
+    uint8_t* host = nullptr;
+    size_t cap = 0, used = 0;
+    hipEvent_t copied = nullptr;             // recorded behind the H2D: the staging buffer may be rewritten after it
+    void begin(size_t bytes) {
+        if (copied) HIP_CHECK(hipEventSynchronize(copied));
+        if (bytes > cap) {
+            if (dev) (void)hipFree(dev);
+            if (host) (void)hipHostFree(host);
+            dev = host = nullptr;
+            const size_t want = bytes + bytes / 2 + 4096;
+            HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&dev), want));
+            HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&host), want, hipHostMallocDefault));
+            cap = want;
+        }
+        used = 0;
+    }
+    static size_t padded(size_t bytes) { return (bytes + 255) & ~size_t(255); }
+    // copies `bytes` into the staging buffer and returns the device address they will land at
+    void* push(const void* src, size_t bytes) {
+        void* d = dev + used;
+        if (bytes) std::memcpy(host + used, src, bytes);
+        used += padded(bytes);
+        return d;
+    }
+    void flush(hipStream_t st) {
+        if (used) HIP_CHECK(hipMemcpyAsync(dev, host, used, hipMemcpyHostToDevice, st));
+        if (!copied) HIP_CHECK(hipEventCreateWithFlags(&copied, hipEventDisableTiming));
+        HIP_CHECK(hipEventRecord(copied, st));
+    }
+    void release() {
+        if (copied) (void)hipEventDestroy(copied);
+        if (dev) (void)hipFree(dev);
+        if (host) (void)hipHostFree(host);
+        dev = host = nullptr; copied = nullptr; cap = used = 0;
     }
 };
 
@@ -87,6 +137,8 @@ struct swfr_renderer {
 
     // device state
     hipStream_t stream = nullptr;
+    SceneArena arena;
+    uint32_t* h_counters = nullptr;         // pinned: the kernels' counters of up to four frame sets
     std::vector<hipEvent_t> ev;             // 4 per frame of the last swfr_render_resident call
     DevBuf<swfr_edge> d_raw;
     DevBuf<DevEdge> d_edges;
@@ -122,7 +174,7 @@ struct swfr_renderer {
     uint32_t* fb_cur = nullptr;             // framebuffer of the last completed frame
     std::map<uint32_t, DeviceBitmap> bitmaps;
     std::vector<DevBitmap> bitmap_table;   // indexed by bitmap id
-    bool bitmap_table_dirty = false;
+    bool bitmap_table_dirty = false, bitmap_table_dirty_copied = false;
     // resident scene
     size_t n_edges = 0, n_paths = 0, n_styles = 0, n_tasks = 0, n_chunks = 0, n_bands = 0, rec_cap = 0, rec_main = 0, n_big = 0, chunk_rows = 64;
     bool scene_ready = false, fb_valid = false, any_shader = false;
@@ -144,6 +196,8 @@ struct swfr_renderer {
                 x.d_edges.release(); x.d_band_list.release(); x.d_cls.release(); x.d_rows.release(); x.d_records.release(); x.d_counters.release(); x.d_fb.release();
                 if (x.stream) (void)hipStreamDestroy(x.stream);
             }
+            arena.release();
+            if (h_counters) (void)hipHostFree(h_counters);
             for (auto& kv : bitmaps) if (kv.second.pixels) (void)hipFree(kv.second.pixels);
             for (auto& e : ev) if (e) (void)hipEventDestroy(e);
             if (stream) (void)hipStreamDestroy(stream);
@@ -371,10 +425,8 @@ int upload(swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_
     for (auto& b : big_rows) { const uint32_t n = b.rec_base; b.rec_base = uint32_t(rec_cap); rec_cap += n; }
     r->rec_cap = rec_cap + 64;
     r->n_big = big_rows.size();
-    r->d_raw.reserve(n_edges); r->d_edges.reserve(n_edges); r->d_paths.reserve(n_paths); r->d_styles.reserve(n_styles);
-    r->d_row_base.reserve(n_paths + 1); r->d_rows.reserve(r->n_tasks); r->d_records.reserve(r->rec_cap);
-    r->d_chunk_base.reserve(chunks.size()); r->d_band_off.reserve(n_bands + 1); r->d_band_list.reserve(band_off[n_bands]);
-    r->d_big_rows.reserve(big_rows.size());
+    // per-frame (kernel-written) buffers: grow-only allocations
+    r->d_edges.reserve(n_edges); r->d_rows.reserve(r->n_tasks); r->d_records.reserve(r->rec_cap); r->d_band_list.reserve(band_off[n_bands]);
     (void)pair_cap;
     r->d_cls.reserve(size_t(band_off[n_bands]) * ((r->width + TILE_W - 1) / TILE_W) + 64);   // class byte per (band entry, tile column)
     r->n_band_entries = band_off[n_bands];
@@ -390,31 +442,30 @@ int upload(swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_
         }
         if (!x.stream) HIP_CHECK(hipStreamCreateWithFlags(&x.stream, hipStreamNonBlocking));
     }
-    if (n_edges) HIP_CHECK(hipMemcpyAsync(r->d_raw.ptr, staged.data(), n_edges * sizeof(swfr_edge), hipMemcpyHostToDevice, r->stream));
-    if (n_paths) HIP_CHECK(hipMemcpyAsync(r->d_paths.ptr, paths, n_paths * sizeof(swfr_path), hipMemcpyHostToDevice, r->stream));
-    if (n_styles) HIP_CHECK(hipMemcpyAsync(r->d_styles.ptr, styles, n_styles * sizeof(swfr_style), hipMemcpyHostToDevice, r->stream));
-    HIP_CHECK(hipMemcpyAsync(r->d_row_base.ptr, row_base.data(), (n_paths + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, r->stream));
-    r->d_band_slots.reserve(band_slots.size());
-    if (!band_slots.empty())
-        HIP_CHECK(hipMemcpyAsync(r->d_band_slots.ptr, band_slots.data(), band_slots.size() * sizeof(BandSlot), hipMemcpyHostToDevice, r->stream));
-    r->d_order.reserve(order.size());
+    // the scene's read-only arrays: one pinned staging buffer, one H2D copy, views into one device arena
+    std::vector<DevFilter> filters(n_styles);
+    std::vector<int32_t> fparams;
+    for (size_t i = 0; i < n_styles; ++i) filters[i] = good_filter(styles[i], fparams);
     r->has_order = !order.empty();
-    if (!order.empty())
-        HIP_CHECK(hipMemcpyAsync(r->d_order.ptr, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice, r->stream));
-    if (!big_rows.empty())
-        HIP_CHECK(hipMemcpyAsync(r->d_big_rows.ptr, big_rows.data(), big_rows.size() * sizeof(BigRow), hipMemcpyHostToDevice, r->stream));
-    if (!chunks.empty())
-        HIP_CHECK(hipMemcpyAsync(r->d_chunk_base.ptr, chunks.data(), chunks.size() * sizeof(ChunkInfo), hipMemcpyHostToDevice, r->stream));
-    HIP_CHECK(hipMemcpyAsync(r->d_band_off.ptr, band_off.data(), (n_bands + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, r->stream));
-    {   // per-style sampling filters of bitmap styles
-        std::vector<DevFilter> filters(n_styles);
-        std::vector<int32_t> fparams;
-        for (size_t i = 0; i < n_styles; ++i) filters[i] = good_filter(styles[i], fparams);
-        r->d_filters.reserve(std::max<size_t>(n_styles, 1));
-        r->d_filter_params.reserve(std::max<size_t>(fparams.size(), 1));
-        if (n_styles) HIP_CHECK(hipMemcpyAsync(r->d_filters.ptr, filters.data(), n_styles * sizeof(DevFilter), hipMemcpyHostToDevice, r->stream));
-        if (!fparams.empty()) HIP_CHECK(hipMemcpyAsync(r->d_filter_params.ptr, fparams.data(), fparams.size() * sizeof(int32_t), hipMemcpyHostToDevice, r->stream));
-        HIP_CHECK(hipStreamSynchronize(r->stream));   // the staging vectors die here
+    {
+        SceneArena& A = r->arena;
+        auto P = SceneArena::padded;
+        A.begin(P(n_edges * sizeof(swfr_edge)) + P(n_paths * sizeof(swfr_path)) + P(n_styles * sizeof(swfr_style)) +
+                P((n_paths + 1) * sizeof(uint32_t)) + P(band_slots.size() * sizeof(BandSlot)) + P(order.size() * sizeof(uint32_t)) +
+                P(big_rows.size() * sizeof(BigRow)) + P(chunks.size() * sizeof(ChunkInfo)) + P((n_bands + 1) * sizeof(uint32_t)) +
+                P(n_styles * sizeof(DevFilter)) + P(fparams.size() * sizeof(int32_t)) + 4096);
+        r->d_raw.set_view(A.push(staged.data(), n_edges * sizeof(swfr_edge)));
+        r->d_paths.set_view(A.push(paths, n_paths * sizeof(swfr_path)));
+        r->d_styles.set_view(A.push(styles, n_styles * sizeof(swfr_style)));
+        r->d_row_base.set_view(A.push(row_base.data(), (n_paths + 1) * sizeof(uint32_t)));
+        r->d_band_slots.set_view(A.push(band_slots.data(), band_slots.size() * sizeof(BandSlot)));
+        r->d_order.set_view(A.push(order.data(), order.size() * sizeof(uint32_t)));
+        r->d_big_rows.set_view(A.push(big_rows.data(), big_rows.size() * sizeof(BigRow)));
+        r->d_chunk_base.set_view(A.push(chunks.data(), chunks.size() * sizeof(ChunkInfo)));
+        r->d_band_off.set_view(A.push(band_off.data(), (n_bands + 1) * sizeof(uint32_t)));
+        r->d_filters.set_view(A.push(filters.data(), n_styles * sizeof(DevFilter)));
+        r->d_filter_params.set_view(A.push(fparams.data(), fparams.size() * sizeof(int32_t)));
+        A.flush(r->stream);
     }
     if (r->bitmap_table_dirty) {
         r->d_bitmap_table.reserve(r->bitmap_table.size());
@@ -422,8 +473,9 @@ int upload(swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_
             HIP_CHECK(hipMemcpyAsync(r->d_bitmap_table.ptr, r->bitmap_table.data(), r->bitmap_table.size() * sizeof(DevBitmap),
                                      hipMemcpyHostToDevice, r->stream));
         r->bitmap_table_dirty = false;
+        r->bitmap_table_dirty_copied = true;
     }
-    HIP_CHECK(hipStreamSynchronize(r->stream));   // staging vectors die at scope exit
+    if (r->bitmap_table_dirty_copied) { HIP_CHECK(hipStreamSynchronize(r->stream)); r->bitmap_table_dirty_copied = false; }   // bitmap_table may be edited next
     r->scene_ready = true;
     return SWFR_OK;
 }
@@ -487,6 +539,10 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
     }
     HIP_CHECK(hipEventRecord(ev_end, r->stream));
     HIP_CHECK(hipGetLastError());
+    // the counters of every set come back through pinned memory behind the last kernel: one synchronisation for everything
+    if (!r->h_counters) HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&r->h_counters), 4 * CNT_WORDS * sizeof(uint32_t), hipHostMallocDefault));
+    for (uint32_t k = 0; k < n_sets; ++k)
+        HIP_CHECK(hipMemcpyAsync(r->h_counters + k * CNT_WORDS, sets[k].counters, CNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
     HIP_CHECK(hipStreamSynchronize(r->stream));
     r->fb_cur = sets[(frames - 1) % n_sets].fb;
     uint32_t timed_frames = 0;
@@ -499,12 +555,8 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
         setup_ms += a; rows_ms += b; tiles_ms += c;
     }
     HIP_CHECK(hipEventElapsedTime(&total_ms, ev_begin, ev_end));
-    HIP_CHECK(hipMemcpy(counters, r->d_counters.ptr, sizeof counters, hipMemcpyDeviceToHost));
-    for (uint32_t k = 1; k < n_sets; ++k) {
-        uint32_t c2[CNT_WORDS] = {};
-        HIP_CHECK(hipMemcpy(c2, sets[k].counters, sizeof c2, hipMemcpyDeviceToHost));
-        counters[CNT_ERROR] |= c2[CNT_ERROR];
-    }
+    std::memcpy(counters, r->h_counters, sizeof counters);
+    for (uint32_t k = 1; k < n_sets; ++k) counters[CNT_ERROR] |= r->h_counters[k * CNT_WORDS + CNT_ERROR];
     r->timing = swfr_timing{total_ms, setup_ms, rows_ms, tiles_ms, frames, r->n_edges, r->n_paths, r->n_tasks, r->rec_main, timed_frames};
     if (r->tiles_dbg == 9)
         std::fprintf(stderr, "[swfr] tile/path pairs %u, partial %u, full %u, culled entries %u, records %u, overflow rows %u\n", counters[CNT_PAIRS],
