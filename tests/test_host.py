@@ -153,3 +153,86 @@ def test_empty_and_degenerate_inputs():
     tag = scenarios._poly_shape([(-5000, -5000), (-4000, -5000), (-4500, -4000)], {"type": "solid", "color": scenarios._rgba(1, 2, 3)})
     e, p, s = r.build_frame({"children": [{"type": "shape", "definition": tag}]})
     assert len(p) == 0
+
+
+def _rand_path_shape(rng, line_width, morph=False):
+    """A random open path of straight / quadratic / axis-aligned segments with a solid line style (and sometimes a fill)."""
+    kind = rng.choice(["straight", "curved", "rectilinear", "mixed"])
+    x, y = int(rng.integers(200, 1500)), int(rng.integers(200, 1200))
+    sc = {"type": "style-change", "move_to": {"x": x, "y": y}, "line_style": 1}
+    if morph:
+        sc["morph_move_to"] = {"x": x + int(rng.integers(-100, 100)), "y": y + int(rng.integers(-100, 100))}
+    fill = None
+    if rng.integers(0, 3) == 0:
+        fill = {"type": "solid", "color": {"r": 10, "g": 200, "b": 90, "a": int(rng.choice([255, 120]))}}
+        if morph:
+            fill["morph_color"] = fill["color"]
+        sc["left_fill"] = 1
+    recs = [sc]
+    xs, ys = [x], [y]
+    for k in range(int(rng.integers(1, 8))):
+        if kind == "rectilinear":
+            d = (int(rng.integers(-600, 600)), 0) if k % 2 == 0 else (0, int(rng.integers(-600, 600)))
+        else:
+            d = (int(rng.integers(-700, 700)), int(rng.integers(-700, 700)))
+        e = {"type": "edge", "delta": {"x": d[0], "y": d[1]}}
+        if kind == "curved" or (kind == "mixed" and rng.integers(0, 2)):
+            e["control_delta"] = {"x": int(rng.integers(-500, 500)), "y": int(rng.integers(-500, 500))}
+        if morph:
+            e["morph_delta"] = {"x": d[0] + int(rng.integers(-150, 150)), "y": d[1] + int(rng.integers(-150, 150))}
+            if "control_delta" in e:
+                e["morph_control_delta"] = {"x": e["control_delta"]["x"] + int(rng.integers(-80, 80)), "y": e["control_delta"]["y"] + int(rng.integers(-80, 80))}
+        x += d[0]; y += d[1]
+        xs.append(x); ys.append(y)
+        recs.append(e)
+    col = {"r": int(rng.integers(0, 256)), "g": 30, "b": 60, "a": int(rng.choice([255, 255, 100]))}
+    line = {"width": line_width, "fill": {"type": "solid", "color": col}}
+    if morph:
+        line["morph_width"] = int(line_width * rng.uniform(0.5, 2.0)) + 1
+        line["fill"]["morph_color"] = col
+    b = {"x_min": min(xs) - 400, "x_max": max(xs) + 400, "y_min": min(ys) - 400, "y_max": max(ys) + 400}
+    tag = {"id": 1, "bounds": b, "shape": {"initial_styles": {"fill": [fill] if fill else [], "line": [line]}, "records": recs}}
+    if morph:
+        tag["morph_bounds"] = b
+        tag["type"] = "define-morph-shape"
+    return tag
+
+
+def test_fuzz_stroked_shapes_edges_equal_oracle():
+    """Host stroker vs the oracle's, edge for edge, over random open paths (straight, curved, rectilinear), line widths down to
+    hairlines, reflecting / scaling placement matrices that push parts off the frame, and morph shapes (round caps and joins)."""
+    import scenarios
+    rng = np.random.default_rng(77)
+    W, H = 120, 100
+    for it in range(800):
+        morph = bool(rng.integers(0, 3) == 0)
+        tag = _rand_path_shape(rng, int(rng.choice([1, 2, 5, 20, 45, 90, 200])), morph)
+        sx, sy = float(rng.choice([1, 1, 0.6, 1.7, -1])), float(rng.choice([1, 1, 0.8, 1.3]))
+        mat = scenarios._m(sx, sy, int(rng.integers(-300, 900)) + (2000 if sx < 0 else 0), int(rng.integers(-300, 500)),
+                           float(rng.choice([0, 0, 0.2])), float(rng.choice([0, 0, -0.15])))
+        child = {"type": "morph-shape", "definition": tag, "ratio": float(rng.uniform(0, 1)), "matrix": mat} if morph else \
+                {"type": "shape", "definition": tag, "matrix": mat}
+        stage = {"children": [child]}
+        r = S.Renderer(W, H, device=api.DEVICE_HOST_ONLY)
+        edges, paths, styles = r.build_frame(stage)
+        r.close()
+        tap = _Tap(W, H)
+        cr.CanvasReplay(tap, linear_extension=True).render(stage)
+        assert not tap.unsupported
+
+        def visible(pe):        # the host drops polygons whose pixel rectangle inside the frame is empty (nothing would be painted)
+            x0 = min(pe[:, 0].min(), pe[:, 2].min()) >> 8
+            x1 = (max(pe[:, 0].max(), pe[:, 2].max()) + 255) >> 8
+            y0, y1 = pe[:, 4].min() >> 8, (pe[:, 5].max() + 255) >> 8
+            return max(x0, 0) < min(x1, W) and max(y0, 0) < min(y1, H)
+
+        polys = [(pe, rect) for pe, rect in tap.polys if visible(pe)]
+        assert len(paths) == len(polys), it
+        for pth, (pe, rect) in zip(paths, polys):
+            e = edges[pth["first_edge"]: pth["first_edge"] + pth["n_edges"]]
+            assert (pth["kind"] == api.PATH_BOXES) == bool(rect), it
+            if rect:
+                continue
+            got = np.stack([e[k] for k in ("x1", "y1", "x2", "y2", "top", "bottom", "dir")], 1)
+            assert got.shape == pe.shape and (got == pe).all(), it
+        tap.close()
