@@ -139,6 +139,26 @@ def test_fuzz_layered_translucent_vs_oracle():
         assert diff_stats(product_render(sc), oracle_render(sc)) == (0, 0), it
 
 
+def test_fuzz_stroked_shapes_vs_oracle():
+    """Random stroked (morph) shapes -- curves, rectilinear box strokes, round caps / joins, hairlines, reflected and off-frame
+    placements -- through the whole product path against the oracle's pixels."""
+    from test_host import _rand_path_shape
+    rng = np.random.default_rng(78)
+    W, H = 120, 100
+    for it in range(120):
+        kids = []
+        for _ in range(int(rng.integers(1, 4))):
+            morph = bool(rng.integers(0, 3) == 0)
+            tag = _rand_path_shape(rng, int(rng.choice([1, 2, 5, 20, 45, 90, 200])), morph)
+            sx, sy = float(rng.choice([1, 1, 0.6, 1.7, -1])), float(rng.choice([1, 1, 0.8, 1.3]))
+            mat = scenarios._m(sx, sy, int(rng.integers(-300, 900)) + (2000 if sx < 0 else 0), int(rng.integers(-300, 500)),
+                               float(rng.choice([0, 0, 0.2])), float(rng.choice([0, 0, -0.15])))
+            kids.append({"type": "morph-shape", "definition": tag, "ratio": float(rng.uniform(0, 1)), "matrix": mat} if morph else
+                        {"type": "shape", "definition": tag, "matrix": mat})
+        sc = dict(width=W, height=H, stage={"children": kids})
+        assert diff_stats(product_render(sc), oracle_render(sc)) == (0, 0), it
+
+
 # ---- every internal route of the row/tile kernels gives the same pixels
 @pytest.mark.parametrize("env", [{"SWFR_FAST_LIMIT": "0"}, {"SWFR_FAST_LIMIT": "3"}, {"SWFR_CELL_MODE": "0"}, {"SWFR_CHUNK_ROWS": "64"},
                                  {"SWFR_CHUNK_ROWS": "8"}, {"SWFR_CHUNK_ROWS": "8", "SWFR_FAST_LIMIT": "3"}, {"SWFR_CHUNK_ROWS": "16", "SWFR_CELL_MODE": "0"}])
