@@ -76,6 +76,8 @@ enum : uint32_t { BE_BOXES = 1u, BE_LERP = 2u, BE_SOLID = 4u, BE_OPAQUE_COVER = 
 // chunk (host-computed upper bound), so record allocation needs no global atomics.
 struct ChunkInfo {
     uint32_t path, first_row, rec_base, rows;
+    uint32_t slot0;          // index into band_slots of the (path, tile-row) pair of the chunk's first tile-row; ~0u if none
+    uint32_t pad[3];
 };
 
 // One (path, tile-row) pair: where its BandEntry goes.  The host assigns the slots (painter's order inside every

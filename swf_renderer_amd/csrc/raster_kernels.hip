@@ -214,6 +214,12 @@ __global__ __launch_bounds__(256) void k_front(const swfr_edge* __restrict__ in,
 // ---------------------------------------------------------------------------------------------
 // k_rows
 // ---------------------------------------------------------------------------------------------
+// classification of a (tile, path) pair
+#define CLS_PARTIAL 1u                // some row needs the general accumulate + scan path
+#define CLS_NOTFULL 2u                // some in-frame row of the tile is not uniformly alpha 255
+#define CLS_NONEMPTY 4u               // some row has coverage
+#define CLS_BOX 8u                    // rectilinear path evaluated per pixel from its boxes
+
 #define ROWS_FAST_N 8            // active edges per row handled in registers by k_rows
 #define ROWS_BIG_MAXA 64         // capacity of the generic (LDS list) routine in k_rows_big
 #define ROWS_STAGE 64            // paths with at most this many edges are staged into LDS
@@ -405,7 +411,9 @@ __device__ __forceinline__ void fast_rows(EPTR E, uint32_t n_list, const DevPath
 __device__ __forceinline__ void rows_chunk_body(uint32_t block, const DevEdge* __restrict__ edges, const DevPath* __restrict__ paths,
                                                 const uint32_t* __restrict__ row_base, const ChunkInfo* __restrict__ chunks,
                                                 uint32_t n_paths, RowInfo* __restrict__ rows, Rec* __restrict__ records,
-                                                uint32_t band_index, uint32_t band_count, int fast_limit, int cell_mode) {
+                                                uint32_t band_index, uint32_t band_count, int fast_limit, int cell_mode,
+                                                const BandSlot* __restrict__ band_slots, const uint32_t* __restrict__ band_off,
+                                                uint8_t* __restrict__ cls_t, int width, int height, int fused) {
     __shared__ FastLds F;
     __shared__ DevEdge staged[ROWS_STAGE];
     __shared__ uint16_t staged_id[ROWS_STAGE], staged_hi[ROWS_STAGE];   // path-relative index of a staged edge (diagnostic eid)
@@ -417,7 +425,7 @@ __device__ __forceinline__ void rows_chunk_body(uint32_t block, const DevEdge* _
     const DevPath P = paths[lo];
     const int r = (int)ck.first_row + lane;
     const int chunk_rows = (int)ck.rows;                                // 64, or fewer for scenes of a few tall paths
-    const bool in_path = P.kind == SWFR_PATH_TOR && lane < chunk_rows && r < P.y_max;
+    const bool in_path = P.kind == SWFR_PATH_TOR && lane < chunk_rows && r >= P.y_min && r < P.y_max;   // chunks start on tile-row boundaries
     bool live = in_path;
     if (live && band_count > 1 && (uint32_t)((r / TILE_H) % band_count) != band_index) live = false;
     const uint32_t t = row_base[lo] + (uint32_t)(r - P.y_min);          // row task index (valid when in_path)
@@ -473,6 +481,60 @@ __device__ __forceinline__ void rows_chunk_body(uint32_t block, const DevEdge* _
                 }
                 records[off++] = rc;
             }
+        }
+    }
+    // ---- classification of this chunk's (tile, path) pairs (what k_class does, from the record headers still in registers):
+    //      a chunk holds whole tile-rows of its path, lanes 16g..16g+15 are the pixel rows of tile-row g
+    if (fused && ck.slot0 != ~0u && P.kind == SWFR_PATH_TOR) {
+        const int tiles_x = (width + TILE_W - 1) / TILE_W;
+        const int g = lane >> 4;
+        const int band = (int)ck.first_row / TILE_H + g;
+        const int band_lo = P.y_min / TILE_H, band_hi = (P.y_max - 1) / TILE_H;
+        const bool band_ok = g < chunk_rows / TILE_H && band >= band_lo && band <= band_hi;
+        uint8_t* out = cls_t;                                 // + tile column * n_b
+        uint32_t n_b = 0;
+        if (band_ok) {
+            const BandSlot bs = band_slots[ck.slot0 + (uint32_t)(band - (int)ck.first_row / TILE_H)];
+            const uint32_t b0 = band_off[band];
+            n_b = band_off[band + 1] - b0;
+            out = cls_t + (size_t)tiles_x * b0 + (bs.slot - b0);
+        }
+        const int tc0 = P.x_min / TILE_W, tc1 = (P.x_max - 1) / TILE_W;
+        // columns the path's rectangle does not reach: empty (sixteen lanes share a tile-row and stride over the columns)
+        if (band_ok)
+            for (int tc = lane & 15; tc < tiles_x; tc += 16)
+                if (tc < tc0 || tc > tc1) out[(size_t)tc * n_b] = 0;
+        const int y = r;
+        const bool in_frame = y < height && band_ok, in_rows = in_frame && in_path;
+        for (int tc = tc0; tc <= tc1; ++tc) {                 // wave-uniform
+            const int tx0 = tc * TILE_W, tile_x1 = min(tx0 + TILE_W, width);
+            uint32_t f = 0;
+            if (in_frame) {
+                if (!in_rows) f = CLS_NOTFULL;
+                else {
+                    int carry = 0;
+                    bool inter = false;
+#pragma unroll
+                    for (int s2 = 0; s2 < ROWS_FAST_N; ++s2) {
+                        if (s2 >= n || roles[s2] == 0) continue;
+                        const int clo = (int)((uint32_t)cols[s2] & 0xffffu), chi = (int)((uint32_t)cols[s2] >> 16);
+                        if (chi < tx0 && chi < 65535) carry += record_height((uint32_t)roles[s2]);
+                        else if (clo >= tx0 + TILE_W && clo < 65535) { /* right of the tile */ }
+                        else inter = true;
+                    }
+                    const bool inside_x = P.x_min <= tx0 && P.x_max >= tile_x1;
+                    const uint32_t a = (uint32_t)((carry * 512 * 17 + 256) >> 9) & 255u;
+                    if (inter) f = CLS_PARTIAL | CLS_NOTFULL | CLS_NONEMPTY;
+                    else if (a == 0) f = CLS_NOTFULL;
+                    else if (a == 255 && inside_x) f = CLS_NONEMPTY;
+                    else f = CLS_PARTIAL | CLS_NOTFULL | CLS_NONEMPTY;
+                }
+            }
+            f |= (uint32_t)__shfl_xor((int)f, 8);             // OR over the tile-row's sixteen lanes; every lane active
+            f |= (uint32_t)__shfl_xor((int)f, 4);
+            f |= (uint32_t)__shfl_xor((int)f, 2);
+            f |= (uint32_t)__shfl_xor((int)f, 1);
+            if ((lane & 15) == 0 && band_ok) out[(size_t)tc * n_b] = (uint8_t)f;
         }
     }
 }
@@ -777,9 +839,12 @@ __global__ __launch_bounds__(64) void k_rows(const DevEdge* __restrict__ edges, 
                                              const uint32_t* __restrict__ row_base, const ChunkInfo* __restrict__ chunks,
                                              uint32_t n_paths, RowInfo* __restrict__ rows, Rec* __restrict__ records,
                                              uint32_t band_index, uint32_t band_count, int fast_limit, int cell_mode,
-                                             const BigRow* __restrict__ big_rows, uint32_t n_big, uint32_t* __restrict__ counters) {
+                                             const BigRow* __restrict__ big_rows, uint32_t n_big, uint32_t* __restrict__ counters,
+                                             const BandSlot* __restrict__ band_slots, const uint32_t* __restrict__ band_off,
+                                             uint8_t* __restrict__ cls_t, int width, int height, int fused) {
     if (blockIdx.x < n_big) big_row_body(blockIdx.x, edges, paths, row_base, big_rows, n_big, rows, records, counters, cell_mode);
-    else rows_chunk_body(blockIdx.x - n_big, edges, paths, row_base, chunks, n_paths, rows, records, band_index, band_count, fast_limit, cell_mode);
+    else rows_chunk_body(blockIdx.x - n_big, edges, paths, row_base, chunks, n_paths, rows, records, band_index, band_count, fast_limit, cell_mode,
+                         band_slots, band_off, cls_t, width, height, fused);
 }
 __global__ __launch_bounds__(64) void k_rows_rs(const DevEdge* __restrict__ edges, const DevPath* __restrict__ paths,
                                                 const uint32_t* __restrict__ row_base, const ChunkInfo* __restrict__ chunks,
@@ -940,11 +1005,6 @@ __device__ __noinline__ uint32_t shade(const swfr_style& s, uint32_t style_index
 #define ACC_TOUCH 65
 #define LIST_CAP 256
 
-// classification of a (tile, path) pair
-#define CLS_PARTIAL 1u                // some row needs the general accumulate + scan path
-#define CLS_NOTFULL 2u                // some in-frame row of the tile is not uniformly alpha 255
-#define CLS_NONEMPTY 4u               // some row has coverage
-#define CLS_BOX 8u                    // rectilinear path evaluated per pixel from its boxes
 
 struct TileCtx {
     int tx0, xminp, xmaxp;
@@ -1551,7 +1611,8 @@ void launch_front(hipStream_t st, const swfr_edge* in, const DevPath* paths, Dev
 }
 void launch_rows(hipStream_t st, const DevEdge* edges, const DevPath* paths, const uint32_t* row_base, const ChunkInfo* chunk_base,
                  uint32_t n_paths, RowInfo* rows, Rec* records, uint32_t* counters, const BigRow* big_rows, uint32_t n_big, uint32_t n_chunks,
-                 uint32_t band_index, uint32_t band_count, int fast_limit, int cell_mode, uint32_t chunk_rows) {
+                 uint32_t band_index, uint32_t band_count, int fast_limit, int cell_mode, uint32_t chunk_rows,
+                 const BandSlot* band_slots, const uint32_t* band_off, uint8_t* cls_t, int width, int height, int fused) {
     if (!n_chunks) return;
     fast_limit = fast_limit < 0 ? 0 : (fast_limit > ROWS_FAST_N ? ROWS_FAST_N : fast_limit);
     if (chunk_rows <= 8)
@@ -1559,7 +1620,7 @@ void launch_rows(hipStream_t st, const DevEdge* edges, const DevPath* paths, con
                            fast_limit, cell_mode, big_rows, n_big, counters);
     else
         hipLaunchKernelGGL(k_rows, dim3(n_chunks + n_big), dim3(64), 0, st, edges, paths, row_base, chunk_base, n_paths, rows, records,
-                           band_index, band_count, fast_limit, cell_mode, big_rows, n_big, counters);
+                           band_index, band_count, fast_limit, cell_mode, big_rows, n_big, counters, band_slots, band_off, cls_t, width, height, fused);
 }
 void launch_class(hipStream_t st, const BandEntry* band_list, uint32_t n_entries, const uint32_t* band_off, uint32_t n_bands,
                   const swfr_edge* raw, const RowInfo* rows, const Rec* records, uint8_t* cls_t, int width, int height,

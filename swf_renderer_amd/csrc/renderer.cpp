@@ -27,7 +27,7 @@ void launch_front(hipStream_t, const swfr_edge*, const DevPath*, DevEdge*, uint3
 void launch_class(hipStream_t, const BandEntry*, uint32_t, const uint32_t*, uint32_t, const swfr_edge*, const RowInfo*, const Rec*, uint8_t*, int, int,
                   uint32_t, uint32_t);
 void launch_rows(hipStream_t, const DevEdge*, const DevPath*, const uint32_t*, const ChunkInfo*, uint32_t, RowInfo*, Rec*, uint32_t*, const BigRow*,
-                 uint32_t, uint32_t, uint32_t, uint32_t, int, int, uint32_t);
+                 uint32_t, uint32_t, uint32_t, uint32_t, int, int, uint32_t, const BandSlot*, const uint32_t*, uint8_t*, int, int, int);
 void launch_tiles(hipStream_t, const swfr_edge*, const uint32_t*, const BandEntry*, const uint8_t*, const RowInfo*, const Rec*, const swfr_style*,
                   Sources, uint32_t*, int, int, uint32_t, uint32_t, int, uint32_t*, uint32_t, uint32_t, bool, const uint32_t*);
 void launch_unpremultiply(hipStream_t, const uint32_t*, uint32_t*, size_t);
@@ -179,6 +179,8 @@ struct swfr_renderer {
     size_t n_edges = 0, n_paths = 0, n_styles = 0, n_tasks = 0, n_chunks = 0, n_bands = 0, rec_cap = 0, rec_main = 0, n_big = 0, chunk_rows = 64;
     bool scene_ready = false, fb_valid = false, any_shader = false;
     swfr_timing timing{};
+    bool fused_class = false;
+    int allow_fused = 1;                    // SWFR_FUSED_CLASS=0: always launch k_class (test knob)
     int force_chunk_rows = 0;               // SWFR_CHUNK_ROWS: test knob
     int strip_order = 1;                    // SWFR_STRIP_ORDER=0: launch the k_tiles wavefronts in row-major order
     bool has_order = false;
@@ -333,14 +335,25 @@ int upload(swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_
             chunk_rows >>= 1;
         }
     }
+    bool any_boxes = false;
     for (size_t i = 0; i < n_paths; ++i) {
         const swfr_path& p = paths[i];
         for (uint32_t k = 0; k < p.n_edges; ++k) staged[p.first_edge + k].reserved = int32_t(i);
-        uint32_t rows = 0;
+        uint32_t rows = 0, chunk_a0 = 0;
+        if (p.kind != SWFR_PATH_TOR) any_boxes = true;
         if (p.kind == SWFR_PATH_TOR) {
             rows = uint32_t(p.y_max - p.y_min);
-            const size_t c0 = chunks.size(), nc = (rows + chunk_rows - 1) / chunk_rows;
-            for (size_t c = 0; c < nc; ++c) chunks.push_back(ChunkInfo{uint32_t(i), uint32_t(p.y_min) + uint32_t(c) * chunk_rows, 0, chunk_rows});
+            // chunks of 16+ rows start on tile-row boundaries, so that a chunk holds whole tile-rows of the path and can
+            // classify its (tile, path) pairs itself (see fused_class)
+            const uint32_t a0 = chunk_rows >= uint32_t(TILE_H) ? uint32_t(p.y_min) / TILE_H * TILE_H : uint32_t(p.y_min);
+            const bool has_area = p.y_max > p.y_min && p.x_max > p.x_min;
+            const size_t c0 = chunks.size(), nc = (uint32_t(p.y_max) - a0 + chunk_rows - 1) / chunk_rows;
+            for (size_t c = 0; c < nc; ++c) {
+                const uint32_t first = a0 + uint32_t(c) * chunk_rows;
+                const uint32_t slot0 = has_area ? uint32_t(band_slots.size()) + (first / TILE_H - uint32_t(p.y_min) / TILE_H) : ~0u;
+                chunks.push_back(ChunkInfo{uint32_t(i), first, 0, chunk_rows, slot0, {0, 0, 0}});
+            }
+            chunk_a0 = a0;
             chunk_cap.resize(chunks.size(), 0);
             // active edges per pixel row, exactly as k_setup / k_rows count them (sample rows [ytop, ybot) clamped to the
             // path): a row yields at most one record per active edge, so these counts size the record slots; rows
@@ -362,7 +375,7 @@ int upload(swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_
                 const uint32_t band = (uint32_t(p.y_min) + y) / TILE_H;
                 if (bc > 1 && band % bc != bi) continue;          // another rank's tile-row: k_rows leaves it empty
                 if (run > limit) { big_rows.push_back(BigRow{uint32_t(i), int32_t(p.y_min) + int32_t(y), uint32_t(run), 0}); }
-                else chunk_cap[c0 + y / chunk_rows] += uint32_t(run);
+                else chunk_cap[c0 + (uint32_t(p.y_min) + y - chunk_a0) / chunk_rows] += uint32_t(run);
             }
         }
         row_base[i + 1] = row_base[i] + rows;
@@ -425,6 +438,9 @@ int upload(swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_
     for (auto& b : big_rows) { const uint32_t n = b.rec_base; b.rec_base = uint32_t(rec_cap); rec_cap += n; }
     r->rec_cap = rec_cap + 64;
     r->n_big = big_rows.size();
+    // the chunk workgroups of k_rows classify their own (tile, path) pairs when every row of the scene is theirs (no crowded
+    // rows, no box paths, no other rank's tile-rows): k_class is then not launched at all
+    r->fused_class = r->allow_fused && chunk_rows >= uint32_t(TILE_H) && big_rows.empty() && !any_boxes && bc == 1;
     // per-frame (kernel-written) buffers: grow-only allocations
     r->d_edges.reserve(n_edges); r->d_rows.reserve(r->n_tasks); r->d_records.reserve(r->rec_cap); r->d_band_list.reserve(band_off[n_bands]);
     (void)pair_cap;
@@ -523,9 +539,11 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
         if (r->n_paths) {
             launch_rows(S.st, S.edges, r->d_paths.ptr, r->d_row_base.ptr, r->d_chunk_base.ptr, uint32_t(r->n_paths), S.rows,
                         S.records, S.counters, r->d_big_rows.ptr, uint32_t(r->n_big), uint32_t(r->n_chunks), bi, bc, r->fast_limit,
-                        r->cell_mode, uint32_t(r->chunk_rows));
-            launch_class(S.st, S.band_list, uint32_t(r->n_band_entries), r->d_band_off.ptr, uint32_t(r->n_bands), r->d_raw.ptr,
-                         S.rows, S.records, S.cls, int(r->width), int(r->height), bi, bc);
+                        r->cell_mode, uint32_t(r->chunk_rows), r->d_band_slots.ptr, r->d_band_off.ptr, S.cls, int(r->width), int(r->height),
+                        r->fused_class ? 1 : 0);
+            if (!r->fused_class)
+                launch_class(S.st, S.band_list, uint32_t(r->n_band_entries), r->d_band_off.ptr, uint32_t(r->n_bands), r->d_raw.ptr,
+                             S.rows, S.records, S.cls, int(r->width), int(r->height), bi, bc);
         }
         if (timed) HIP_CHECK(hipEventRecord(e[2], S.st));
         launch_tiles(S.st, r->d_raw.ptr, r->d_band_off.ptr, S.band_list, S.cls, S.rows, S.records, r->d_styles.ptr,
@@ -601,6 +619,7 @@ int swfr_create(uint32_t width, uint32_t height, const swfr_config* cfg, swfr_re
     r->builder.reset(new FrameBuilder(width, height, (r->cfg.flags & SWFR_FLAG_EVEN_ODD) != 0));
     if (const char* fl = std::getenv("SWFR_FAST_LIMIT")) r->fast_limit = std::atoi(fl);
     if (const char* td = std::getenv("SWFR_TILES_DEBUG")) r->tiles_dbg = std::atoi(td);
+    if (const char* fc = std::getenv("SWFR_FUSED_CLASS")) r->allow_fused = std::atoi(fc);
     if (const char* cr = std::getenv("SWFR_CHUNK_ROWS")) r->force_chunk_rows = std::atoi(cr);
     if (const char* so = std::getenv("SWFR_STRIP_ORDER")) r->strip_order = std::atoi(so);
     if (const char* fi = std::getenv("SWFR_FRAMES_IN_FLIGHT")) r->in_flight = std::atoi(fi);
