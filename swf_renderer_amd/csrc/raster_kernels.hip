@@ -145,18 +145,13 @@ __device__ __forceinline__ int wave_scan_incl(int v) {
 // ---------------------------------------------------------------------------------------------
 // k_setup
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void setup_block(uint32_t block, const swfr_edge* __restrict__ in, const DevPath* __restrict__ paths,
-                                            DevEdge* __restrict__ out, uint32_t n_edges) {
-    const uint32_t i = block * 256 + threadIdx.x;
-    if (i >= n_edges) return;
-    const swfr_edge e = in[i];
-    const DevPath p = paths[e.reserved];
+// per-edge constants of a tor path's edge (A.5 make_edge): sample-row span clamped to the path, slope quotient / remainder, 1/dy
+__device__ __forceinline__ DevEdge make_dev_edge(const swfr_edge& e, const DevPath& p) {
     DevEdge d;
     d.x1 = e.x1; d.y1 = e.y1; d.dir = e.dir; d.pad = 0; d.inv_dy = 0.0;
     if (p.kind != SWFR_PATH_TOR) {          // boxes are consumed raw by k_tiles
         d.ytop = d.ybot = 0; d.dy = 0; d.ex = 0; d.dq = d.dr = 0;
-        out[i] = d;
-        return;
+        return d;
     }
     int ytop = (int)((15ll * e.top + 128) >> 8), ybot = (int)((15ll * e.bottom + 128) >> 8);
     ytop = max(ytop, p.y_min * 15);
@@ -171,24 +166,25 @@ __device__ __forceinline__ void setup_block(uint32_t block, const swfr_edge* __r
         d.inv_dy = 1.0 / (double)d.dy;
         trunc_div(d.ex * 512, d.dy, d.dq, d.dr);
     }
-    out[i] = d;
+    return d;
+}
+__device__ __forceinline__ void setup_block(uint32_t block, const swfr_edge* __restrict__ in, const DevPath* __restrict__ paths,
+                                            DevEdge* __restrict__ out, uint32_t n_edges) {
+    const uint32_t i = block * 256 + threadIdx.x;
+    if (i >= n_edges) return;
+    const swfr_edge e = in[i];
+    out[i] = make_dev_edge(e, paths[e.reserved]);
 }
 
 // ---------------------------------------------------------------------------------------------
 // k_bands: per tile-row, the paths whose pixel rows intersect it, in painter's order
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void bands_block(uint32_t block, const DevPath* __restrict__ paths, const BandSlot* __restrict__ slots,
-                                            uint32_t n_slots, const uint32_t* __restrict__ row_base,
-                                            const swfr_style* __restrict__ styles, BandEntry* __restrict__ band_list) {
-    const uint32_t g = block * 256 + threadIdx.x;
-    if (g >= n_slots) return;
-    const BandSlot bs = slots[g];
-    const uint32_t p = bs.path;
-    const DevPath P = paths[p];
+// everything a tile needs to bin, classify and cull a path without touching paths[] / styles[]
+__device__ __forceinline__ BandEntry make_band_entry(const DevPath& P, uint32_t p, uint32_t band, uint32_t row_base_p, const swfr_style* __restrict__ styles) {
     BandEntry e;
     e.path = p;
     e.x_min = (int16_t)P.x_min; e.x_max = (int16_t)P.x_max; e.y_min = (int16_t)P.y_min; e.y_max = (int16_t)P.y_max;
-    e.row_base = row_base[p];
+    e.row_base = row_base_p;
     e.style = P.style; e.first_edge = P.first_edge; e.n_edges = P.n_edges;
     const uint32_t kind = styles[P.style].kind, pixel = styles[P.style].pixel;
     uint32_t fl = 0;
@@ -196,7 +192,17 @@ __device__ __forceinline__ void bands_block(uint32_t block, const DevPath* __res
     if (P.lerp) fl |= BE_LERP;
     if (kind == SWFR_STYLE_SOLID) fl |= BE_SOLID;
     if (kind == SWFR_STYLE_SOLID && P.lerp && (pixel >> 24) == 0xffu) fl |= BE_OPAQUE_COVER;
-    e.flags = fl | (bs.band << 8); e.solid = pixel;          // the tile-row index rides in the upper bits
+    e.flags = fl | (band << 8); e.solid = pixel;             // the tile-row index rides in the upper bits
+    return e;
+}
+__device__ __forceinline__ void bands_block(uint32_t block, const DevPath* __restrict__ paths, const BandSlot* __restrict__ slots,
+                                            uint32_t n_slots, const uint32_t* __restrict__ row_base,
+                                            const swfr_style* __restrict__ styles, BandEntry* __restrict__ band_list) {
+    const uint32_t g = block * 256 + threadIdx.x;
+    if (g >= n_slots) return;
+    const BandSlot bs = slots[g];
+    const uint32_t p = bs.path;
+    const BandEntry e = make_band_entry(paths[p], p, bs.band, row_base[p], styles);
     band_list[bs.slot] = e;
 }
 
@@ -413,7 +419,9 @@ __device__ __forceinline__ void rows_chunk_body(uint32_t block, const DevEdge* _
                                                 uint32_t n_paths, RowInfo* __restrict__ rows, Rec* __restrict__ records,
                                                 uint32_t band_index, uint32_t band_count, int fast_limit, int cell_mode,
                                                 const BandSlot* __restrict__ band_slots, const uint32_t* __restrict__ band_off,
-                                                uint8_t* __restrict__ cls_t, int width, int height, int fused) {
+                                                uint8_t* __restrict__ cls_t, int width, int height, int fused,
+                                                const swfr_edge* __restrict__ raw, const swfr_style* __restrict__ styles,
+                                                BandEntry* __restrict__ band_list) {
     __shared__ FastLds F;
     __shared__ DevEdge staged[ROWS_STAGE];
     __shared__ uint16_t staged_id[ROWS_STAGE], staged_hi[ROWS_STAGE];   // path-relative index of a staged edge (diagnostic eid)
@@ -439,7 +447,11 @@ __device__ __forceinline__ void rows_chunk_body(uint32_t block, const DevEdge* _
         const uint32_t k = eb + (uint32_t)lane;
         DevEdge ek;
         bool hit = false;
-        if (k < P.n_edges) { ek = edges[P.first_edge + k]; hit = ek.ytop < hi_s && ek.ybot > lo_s; }
+        if (k < P.n_edges) {
+            // (fused front end: the edge constants are computed here from the raw edge instead of being read from k_front's array)
+            ek = (fused & 2) ? make_dev_edge(raw[P.first_edge + k], P) : edges[P.first_edge + k];
+            hit = ek.ytop < hi_s && ek.ybot > lo_s;
+        }
         const unsigned long long hb = __ballot(hit);
         const uint32_t at = n_list + (uint32_t)__popcll(hb & ((1ull << lane) - 1ull));
         if (hit && at < ROWS_STAGE) { staged[at] = ek; staged_id[at] = (uint16_t)(k & 0xffffu); staged_hi[at] = (uint16_t)(k >> 16); }
@@ -485,7 +497,15 @@ __device__ __forceinline__ void rows_chunk_body(uint32_t block, const DevEdge* _
     }
     // ---- classification of this chunk's (tile, path) pairs (what k_class does, from the record headers still in registers):
     //      a chunk holds whole tile-rows of its path, lanes 16g..16g+15 are the pixel rows of tile-row g
-    if (fused && ck.slot0 != ~0u && P.kind == SWFR_PATH_TOR) {
+    if ((fused & 2) && ck.slot0 != ~0u && lane < chunk_rows / TILE_H) {
+        // fused front end: this chunk writes the band entries of its tile-rows (what k_front's band blocks do)
+        const int band = (int)ck.first_row / TILE_H + lane;
+        if (band >= P.y_min / TILE_H && band <= (P.y_max - 1) / TILE_H) {
+            const BandSlot bs = band_slots[ck.slot0 + (uint32_t)lane];
+            band_list[bs.slot] = make_band_entry(P, lo, (uint32_t)band, row_base[lo], styles);
+        }
+    }
+    if ((fused & 1) && ck.slot0 != ~0u && P.kind == SWFR_PATH_TOR) {
         const int tiles_x = (width + TILE_W - 1) / TILE_W;
         const int g = lane >> 4;
         const int band = (int)ck.first_row / TILE_H + g;
@@ -841,10 +861,12 @@ __global__ __launch_bounds__(64) void k_rows(const DevEdge* __restrict__ edges, 
                                              uint32_t band_index, uint32_t band_count, int fast_limit, int cell_mode,
                                              const BigRow* __restrict__ big_rows, uint32_t n_big, uint32_t* __restrict__ counters,
                                              const BandSlot* __restrict__ band_slots, const uint32_t* __restrict__ band_off,
-                                             uint8_t* __restrict__ cls_t, int width, int height, int fused) {
+                                             uint8_t* __restrict__ cls_t, int width, int height, int fused,
+                                             const swfr_edge* __restrict__ raw, const swfr_style* __restrict__ styles,
+                                             BandEntry* __restrict__ band_list) {
     if (blockIdx.x < n_big) big_row_body(blockIdx.x, edges, paths, row_base, big_rows, n_big, rows, records, counters, cell_mode);
     else rows_chunk_body(blockIdx.x - n_big, edges, paths, row_base, chunks, n_paths, rows, records, band_index, band_count, fast_limit, cell_mode,
-                         band_slots, band_off, cls_t, width, height, fused);
+                         band_slots, band_off, cls_t, width, height, fused, raw, styles, band_list);
 }
 __global__ __launch_bounds__(64) void k_rows_rs(const DevEdge* __restrict__ edges, const DevPath* __restrict__ paths,
                                                 const uint32_t* __restrict__ row_base, const ChunkInfo* __restrict__ chunks,
@@ -1612,7 +1634,8 @@ void launch_front(hipStream_t st, const swfr_edge* in, const DevPath* paths, Dev
 void launch_rows(hipStream_t st, const DevEdge* edges, const DevPath* paths, const uint32_t* row_base, const ChunkInfo* chunk_base,
                  uint32_t n_paths, RowInfo* rows, Rec* records, uint32_t* counters, const BigRow* big_rows, uint32_t n_big, uint32_t n_chunks,
                  uint32_t band_index, uint32_t band_count, int fast_limit, int cell_mode, uint32_t chunk_rows,
-                 const BandSlot* band_slots, const uint32_t* band_off, uint8_t* cls_t, int width, int height, int fused) {
+                 const BandSlot* band_slots, const uint32_t* band_off, uint8_t* cls_t, int width, int height, int fused,
+                 const swfr_edge* raw, const swfr_style* styles, BandEntry* band_list) {
     if (!n_chunks) return;
     fast_limit = fast_limit < 0 ? 0 : (fast_limit > ROWS_FAST_N ? ROWS_FAST_N : fast_limit);
     if (chunk_rows <= 8)
@@ -1620,7 +1643,8 @@ void launch_rows(hipStream_t st, const DevEdge* edges, const DevPath* paths, con
                            fast_limit, cell_mode, big_rows, n_big, counters);
     else
         hipLaunchKernelGGL(k_rows, dim3(n_chunks + n_big), dim3(64), 0, st, edges, paths, row_base, chunk_base, n_paths, rows, records,
-                           band_index, band_count, fast_limit, cell_mode, big_rows, n_big, counters, band_slots, band_off, cls_t, width, height, fused);
+                           band_index, band_count, fast_limit, cell_mode, big_rows, n_big, counters, band_slots, band_off, cls_t, width, height, fused,
+                           raw, styles, band_list);
 }
 void launch_class(hipStream_t st, const BandEntry* band_list, uint32_t n_entries, const uint32_t* band_off, uint32_t n_bands,
                   const swfr_edge* raw, const RowInfo* rows, const Rec* records, uint8_t* cls_t, int width, int height,

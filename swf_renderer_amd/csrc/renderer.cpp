@@ -27,7 +27,8 @@ void launch_front(hipStream_t, const swfr_edge*, const DevPath*, DevEdge*, uint3
 void launch_class(hipStream_t, const BandEntry*, uint32_t, const uint32_t*, uint32_t, const swfr_edge*, const RowInfo*, const Rec*, uint8_t*, int, int,
                   uint32_t, uint32_t);
 void launch_rows(hipStream_t, const DevEdge*, const DevPath*, const uint32_t*, const ChunkInfo*, uint32_t, RowInfo*, Rec*, uint32_t*, const BigRow*,
-                 uint32_t, uint32_t, uint32_t, uint32_t, int, int, uint32_t, const BandSlot*, const uint32_t*, uint8_t*, int, int, int);
+                 uint32_t, uint32_t, uint32_t, uint32_t, int, int, uint32_t, const BandSlot*, const uint32_t*, uint8_t*, int, int, int,
+                 const swfr_edge*, const swfr_style*, BandEntry*);
 void launch_tiles(hipStream_t, const swfr_edge*, const uint32_t*, const BandEntry*, const uint8_t*, const RowInfo*, const Rec*, const swfr_style*,
                   Sources, uint32_t*, int, int, uint32_t, uint32_t, int, uint32_t*, uint32_t, uint32_t, bool, const uint32_t*);
 void launch_unpremultiply(hipStream_t, const uint32_t*, uint32_t*, size_t);
@@ -179,8 +180,8 @@ struct swfr_renderer {
     size_t n_edges = 0, n_paths = 0, n_styles = 0, n_tasks = 0, n_chunks = 0, n_bands = 0, rec_cap = 0, rec_main = 0, n_big = 0, chunk_rows = 64;
     bool scene_ready = false, fb_valid = false, any_shader = false;
     swfr_timing timing{};
-    bool fused_class = false;
-    int allow_fused = 1;                    // SWFR_FUSED_CLASS=0: always launch k_class (test knob)
+    bool fused_class = false, fused_front = false;
+    int allow_fused = 2;                    // SWFR_FUSED_CLASS=0: always launch k_class (test knob)
     int force_chunk_rows = 0;               // SWFR_CHUNK_ROWS: test knob
     int strip_order = 1;                    // SWFR_STRIP_ORDER=0: launch the k_tiles wavefronts in row-major order
     bool has_order = false;
@@ -335,12 +336,15 @@ int upload(swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_
             chunk_rows >>= 1;
         }
     }
-    bool any_boxes = false;
+    bool any_boxes = false, any_flat = false;
+    size_t max_path_edges = 0;
     for (size_t i = 0; i < n_paths; ++i) {
         const swfr_path& p = paths[i];
         for (uint32_t k = 0; k < p.n_edges; ++k) staged[p.first_edge + k].reserved = int32_t(i);
         uint32_t rows = 0, chunk_a0 = 0;
         if (p.kind != SWFR_PATH_TOR) any_boxes = true;
+        max_path_edges = std::max<size_t>(max_path_edges, p.n_edges);
+        if (!(p.y_max > p.y_min && p.x_max > p.x_min)) any_flat = true;
         if (p.kind == SWFR_PATH_TOR) {
             rows = uint32_t(p.y_max - p.y_min);
             // chunks of 16+ rows start on tile-row boundaries, so that a chunk holds whole tile-rows of the path and can
@@ -441,6 +445,9 @@ int upload(swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_
     // the chunk workgroups of k_rows classify their own (tile, path) pairs when every row of the scene is theirs (no crowded
     // rows, no box paths, no other rank's tile-rows): k_class is then not launched at all
     r->fused_class = r->allow_fused && chunk_rows >= uint32_t(TILE_H) && big_rows.empty() && !any_boxes && bc == 1;
+    // ... and when, besides, every path's edges fit the chunk staging area and every path has an area (so that every band entry
+    // belongs to a chunk), the chunks also compute their edges' constants and write their band entries: k_front is not launched
+    r->fused_front = r->fused_class && r->allow_fused > 1 && max_path_edges <= 64 && !any_flat;
     // per-frame (kernel-written) buffers: grow-only allocations
     r->d_edges.reserve(n_edges); r->d_rows.reserve(r->n_tasks); r->d_records.reserve(r->rec_cap); r->d_band_list.reserve(band_off[n_bands]);
     (void)pair_cap;
@@ -532,7 +539,7 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
         hipEvent_t* e = &r->ev[size_t(f) * 4];
         const bool timed = f % stride == 0;        // per-kernel events on every stride-th frame (each costs a queue packet)
         if (timed) HIP_CHECK(hipEventRecord(e[0], S.st));
-        if (r->n_paths)     // edge constants + band lists; also clears the counters for this frame
+        if (r->n_paths && !r->fused_front)   // edge constants + band lists (the row kernel does both itself when fused_front)
             launch_front(S.st, r->d_raw.ptr, r->d_paths.ptr, S.edges, uint32_t(r->n_edges), r->d_band_slots.ptr, uint32_t(r->n_band_entries),
                          r->d_row_base.ptr, r->d_styles.ptr, S.band_list, S.counters);
         if (timed) HIP_CHECK(hipEventRecord(e[1], S.st));
@@ -540,7 +547,7 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
             launch_rows(S.st, S.edges, r->d_paths.ptr, r->d_row_base.ptr, r->d_chunk_base.ptr, uint32_t(r->n_paths), S.rows,
                         S.records, S.counters, r->d_big_rows.ptr, uint32_t(r->n_big), uint32_t(r->n_chunks), bi, bc, r->fast_limit,
                         r->cell_mode, uint32_t(r->chunk_rows), r->d_band_slots.ptr, r->d_band_off.ptr, S.cls, int(r->width), int(r->height),
-                        r->fused_class ? 1 : 0);
+                        (r->fused_class ? 1 : 0) | (r->fused_front ? 2 : 0), r->d_raw.ptr, r->d_styles.ptr, S.band_list);
             if (!r->fused_class)
                 launch_class(S.st, S.band_list, uint32_t(r->n_band_entries), r->d_band_off.ptr, uint32_t(r->n_bands), r->d_raw.ptr,
                              S.rows, S.records, S.cls, int(r->width), int(r->height), bi, bc);

@@ -162,7 +162,7 @@ def test_fuzz_stroked_shapes_vs_oracle():
 # ---- every internal route of the row/tile kernels gives the same pixels
 @pytest.mark.parametrize("env", [{"SWFR_FAST_LIMIT": "0"}, {"SWFR_FAST_LIMIT": "3"}, {"SWFR_CELL_MODE": "0"}, {"SWFR_CHUNK_ROWS": "64"},
                                  {"SWFR_CHUNK_ROWS": "8"}, {"SWFR_CHUNK_ROWS": "8", "SWFR_FAST_LIMIT": "3"}, {"SWFR_CHUNK_ROWS": "16", "SWFR_CELL_MODE": "0"},
-                                 {"SWFR_FUSED_CLASS": "0"}, {"SWFR_CHUNK_ROWS": "32", "SWFR_FAST_LIMIT": "8"}])
+                                 {"SWFR_FUSED_CLASS": "0"}, {"SWFR_FUSED_CLASS": "1"}, {"SWFR_CHUNK_ROWS": "32", "SWFR_FAST_LIMIT": "8"}])
 def test_kernel_route_knobs_are_pixel_identical(env, monkeypatch):
     """SWFR_FAST_LIMIT routes rows with more active edges than the limit through k_rows_big (the generic LDS-list
     routine); SWFR_CELL_MODE=0 keeps analytic records instead of precomputed cells; SWFR_CHUNK_ROWS picks the rows per k_rows
