@@ -213,7 +213,7 @@ typedef struct {
     float setup_ms, rows_ms, tiles_ms;   /* per-kernel sums over the timed_frames frames that carried events */
     uint32_t frames;
     uint64_t n_edges, n_paths, n_row_tasks, n_records;
-    uint32_t timed_frames;               /* frames / SWFR_EVENT_STRIDE (default: every frame) */
+    uint32_t timed_frames;               /* frames / SWFR_EVENT_STRIDE (default 16) */
 } swfr_timing;
 int  swfr_last_timing(swfr_renderer *r, swfr_timing *out);
 

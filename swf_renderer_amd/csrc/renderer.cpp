@@ -185,7 +185,7 @@ struct swfr_renderer {
     int force_chunk_rows = 0;               // SWFR_CHUNK_ROWS: test knob
     int strip_order = 1;                    // SWFR_STRIP_ORDER=0: launch the k_tiles wavefronts in row-major order
     bool has_order = false;
-    int event_stride = 8;                   // SWFR_EVENT_STRIDE: per-kernel HIP events on every n-th resident frame
+    int event_stride = 16;                  // SWFR_EVENT_STRIDE: per-kernel HIP events on every n-th resident frame
     int tiles_dbg = 0;                      // SWFR_TILES_DEBUG: timing-only ablations of k_tiles (wrong pixels)
     int cell_mode = 3;                      // SWFR_CELL_MODE: 1 = FULL rows as precomputed cells, 2 = SUB rows (test knob)
     int fast_limit = 8;                     // rows with more active edges go through k_rows_big (SWFR_FAST_LIMIT: test knob)
