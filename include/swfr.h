@@ -207,6 +207,13 @@ int  swfr_build_frame(swfr_renderer *r, const swfr_stage *stage,
    decode goldens (tests/<set>/<name>/shape.ts.json).  String owned by the handle. */
 int  swfr_shape_json(swfr_renderer *r, uint32_t id, int morph, const char **json);
 
+/* A batch of different frames in one call (the reference renders its 256 morph ratios by calling render 256 times,
+   ts/src/test/node-canvas-renderer.spec.ts:86-113; rs/src/lib.rs:116-130): frame i is built on the host, uploaded and
+   rasterized on one of SWFR_FRAMES_IN_FLIGHT streams while the host builds frame i+1.  Frame i lands, premultiplied RGBA8
+   with tight rows, at device_dst + i * frame_stride (DEVICE memory, e.g. a torch tensor); with device_dst == NULL only the
+   last frame is kept for swfr_read_image.  Blocking: returns when every frame is finished. */
+int  swfr_render_batch(swfr_renderer *r, const swfr_stage *stages, uint32_t n_stages, void *device_dst, size_t frame_stride);
+
 /* Timing of the last swfr_render / swfr_render_resident, from HIP events on the handle's stream. */
 typedef struct {
     float total_ms;                      /* first kernel start -> last kernel end, all frames */

@@ -24,7 +24,7 @@ MAX_STOPS = 16
 
 EXPORTS = [
     "swfr_abi_version", "swfr_create", "swfr_destroy", "swfr_last_error", "swfr_register_shape",
-    "swfr_register_morph_shape", "swfr_register_bitmap", "swfr_render", "swfr_read_image", "swfr_upload_edges",
+    "swfr_register_morph_shape", "swfr_register_bitmap", "swfr_render", "swfr_render_batch", "swfr_read_image", "swfr_upload_edges",
     "swfr_render_resident", "swfr_render_edges", "swfr_build_frame", "swfr_shape_json", "swfr_last_timing",
     "swfr_band_slab_bytes", "swfr_copy_band_slab", "swfr_device_framebuffer",
 ]
@@ -161,6 +161,8 @@ def load_library():
     L.swfr_register_bitmap.argtypes = [P, U, U, U, P, C.c_size_t]
     L.swfr_render.restype = I
     L.swfr_render.argtypes = [P, C.POINTER(Stage)]
+    L.swfr_render_batch.restype = I
+    L.swfr_render_batch.argtypes = [P, C.POINTER(Stage), C.c_uint32, C.c_void_p, C.c_size_t]
     L.swfr_read_image.restype = I
     L.swfr_read_image.argtypes = [P, P, C.c_size_t, I]
     for fn in ("swfr_upload_edges", "swfr_render_edges"):
@@ -423,6 +425,15 @@ class Renderer:
         arena = _Arena()
         s = self._stage(arena, stage)
         self._check(self.L.swfr_render(self.h, C.byref(s)))
+
+    def render_batch(self, stages, device_ptr=None, frame_stride=0):
+        """A batch of different frames in one call (e.g. the 256 ratios of a morph shape), pipelined over the handle's streams.
+        Frame i lands at device_ptr + i * frame_stride (device memory: pass tensor.data_ptr()); without a destination only the
+        last frame is kept for read_image().  Blocking."""
+        arena = _Arena()
+        arr = (Stage * max(len(stages), 1))(*[self._stage(arena, st) for st in stages])
+        self._check(self.L.swfr_render_batch(self.h, arr, len(stages), C.c_void_p(device_ptr) if device_ptr else None,
+                                             int(frame_stride) if device_ptr else 0))
 
     def build_frame(self, stage):
         """Host half only: (edges, paths, styles) exactly as render() would upload them."""

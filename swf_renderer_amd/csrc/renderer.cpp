@@ -137,31 +137,25 @@ struct swfr_renderer {
     std::string json_scratch;
 
     // device state
-    hipStream_t stream = nullptr;
-    SceneArena arena;
+    hipStream_t stream = nullptr;           // == fs[0].stream
     uint32_t* h_counters = nullptr;         // pinned: the kernels' counters of up to four frame sets
     std::vector<hipEvent_t> ev;             // 4 per frame of the last swfr_render_resident call
-    DevBuf<swfr_edge> d_raw;
-    DevBuf<DevEdge> d_edges;
-    DevBuf<DevPath> d_paths;
-    DevBuf<swfr_style> d_styles;
-    DevBuf<uint32_t> d_row_base, d_band_off, d_order;
-    DevBuf<BigRow> d_big_rows;
-    DevBuf<BandSlot> d_band_slots;
-    DevBuf<ChunkInfo> d_chunk_base;
-    DevBuf<BandEntry> d_band_list;
-    DevBuf<uint8_t> d_cls;
-    size_t n_band_entries = 0;
-    DevBuf<RowInfo> d_rows;
-    DevBuf<Rec> d_records;
-    DevBuf<uint32_t> d_counters;
-    DevBuf<DevBitmap> d_bitmap_table;
-    DevBuf<DevFilter> d_filters;            // per style: CAIRO_FILTER_GOOD tables of bitmap styles (see good_filter)
-    DevBuf<int32_t> d_filter_params;
-    DevBuf<uint32_t> d_fb, d_tmp;
-    // further sets of per-frame buffers + streams: with SWFR_FRAMES_IN_FLIGHT = n consecutive resident frames rotate over n
-    // sets, so the front of frame f+1 overlaps the tail of frame f (every frame still recomputes everything)
-    struct ExtraSet {
+    // The read-only arrays of one uploaded scene (views into its arena) and what the launches need to know about it.
+    // Resident rendering uses scene 0; swfr_render_batch keeps one scene per frame in flight.
+    struct Scene {
+        SceneArena arena;
+        swfr_edge* raw = nullptr; DevPath* paths = nullptr; swfr_style* styles = nullptr;
+        uint32_t *row_base = nullptr, *band_off = nullptr, *order = nullptr;
+        BigRow* big_rows = nullptr; BandSlot* band_slots = nullptr; ChunkInfo* chunk_base = nullptr;
+        DevFilter* filters = nullptr; int32_t* filter_params = nullptr;
+        size_t n_edges = 0, n_paths = 0, n_styles = 0, n_tasks = 0, n_chunks = 0, n_bands = 0, rec_cap = 0, rec_main = 0, n_big = 0,
+               chunk_rows = 64, n_band_entries = 0;
+        bool any_shader = false, fused_class = false, fused_front = false, has_order = false;
+    };
+    Scene scn[4];
+    // One set of kernel-written per-frame buffers and the stream they are used on.  With SWFR_FRAMES_IN_FLIGHT = n consecutive
+    // frames rotate over n sets, so the front of frame f+1 overlaps the tail of frame f (every frame recomputes everything).
+    struct FrameSet {
         hipStream_t stream = nullptr;
         DevBuf<DevEdge> d_edges;
         DevBuf<BandEntry> d_band_list;
@@ -170,21 +164,19 @@ struct swfr_renderer {
         DevBuf<Rec> d_records;
         DevBuf<uint32_t> d_counters, d_fb;
     };
-    ExtraSet extra[3];
+    FrameSet fs[4];
+    DevBuf<DevBitmap> d_bitmap_table;
+    DevBuf<uint32_t> d_tmp;
     int in_flight = 2;
     uint32_t* fb_cur = nullptr;             // framebuffer of the last completed frame
     std::map<uint32_t, DeviceBitmap> bitmaps;
     std::vector<DevBitmap> bitmap_table;   // indexed by bitmap id
     bool bitmap_table_dirty = false, bitmap_table_dirty_copied = false;
-    // resident scene
-    size_t n_edges = 0, n_paths = 0, n_styles = 0, n_tasks = 0, n_chunks = 0, n_bands = 0, rec_cap = 0, rec_main = 0, n_big = 0, chunk_rows = 64;
-    bool scene_ready = false, fb_valid = false, any_shader = false;
+    bool scene_ready = false, fb_valid = false;
     swfr_timing timing{};
-    bool fused_class = false, fused_front = false;
     int allow_fused = 2;                    // SWFR_FUSED_CLASS=0: always launch k_class (test knob)
     int force_chunk_rows = 0;               // SWFR_CHUNK_ROWS: test knob
     int strip_order = 1;                    // SWFR_STRIP_ORDER=0: launch the k_tiles wavefronts in row-major order
-    bool has_order = false;
     int event_stride = 16;                  // SWFR_EVENT_STRIDE: per-kernel HIP events on every n-th resident frame
     int tiles_dbg = 0;                      // SWFR_TILES_DEBUG: timing-only ablations of k_tiles (wrong pixels)
     int cell_mode = 3;                      // SWFR_CELL_MODE: 1 = FULL rows as precomputed cells, 2 = SUB rows (test knob)
@@ -193,13 +185,13 @@ struct swfr_renderer {
     ~swfr_renderer() {
         if (has_device) {
             (void)hipSetDevice(cfg.device);
-            d_raw.release(); d_edges.release(); d_paths.release(); d_styles.release(); d_row_base.release();
-            d_rows.release(); d_records.release(); d_chunk_base.release(); d_band_off.release(); d_band_list.release(); d_big_rows.release(); d_band_slots.release(); d_order.release(); d_cls.release(); d_counters.release(); d_bitmap_table.release(); d_filters.release(); d_filter_params.release(); d_fb.release(); d_tmp.release();
-            for (ExtraSet& x : extra) {
+            d_bitmap_table.release(); d_tmp.release();
+            for (int k = 0; k < 4; ++k) {
+                FrameSet& x = fs[k];
                 x.d_edges.release(); x.d_band_list.release(); x.d_cls.release(); x.d_rows.release(); x.d_records.release(); x.d_counters.release(); x.d_fb.release();
-                if (x.stream) (void)hipStreamDestroy(x.stream);
+                if (k > 0 && x.stream) (void)hipStreamDestroy(x.stream);
+                scn[k].arena.release();
             }
-            arena.release();
             if (h_counters) (void)hipHostFree(h_counters);
             for (auto& kv : bitmaps) if (kv.second.pixels) (void)hipFree(kv.second.pixels);
             for (auto& e : ev) if (e) (void)hipEventDestroy(e);
@@ -304,11 +296,16 @@ DevFilter good_filter(const swfr_style& st, std::vector<int32_t>& params) {
     return f;
 }
 
-int upload(swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_path* paths, size_t n_paths,
+// Uploads a scene into scene slot `si` (H2D on frame set `si`'s stream) and sizes the kernel-written buffers: of every frame
+// set in flight (`all_sets`, resident rendering: the sets share scene 0) or of set `si` only (batch rendering: one scene per set).
+int upload(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, size_t n_edges, const swfr_path* paths, size_t n_paths,
            const swfr_style* styles, size_t n_styles) {
     if (!r->has_device) return fail(r, SWFR_ERR_NO_DEVICE, "host-only handle cannot rasterize");
     validate_scene(r, edges, n_edges, paths, n_paths, styles, n_styles);
-    r->scene_ready = false;
+    swfr_renderer::Scene& sc = r->scn[si];
+    if (si == 0) r->scene_ready = false;
+    if (si > 0 && !r->fs[si].stream) HIP_CHECK(hipStreamCreateWithFlags(&r->fs[si].stream, hipStreamNonBlocking));
+    const hipStream_t up_stream = r->fs[si].stream;
     // stage: edges tagged with their path index; row prefix over tor paths; record capacity bound
     std::vector<swfr_edge> staged(edges, edges + n_edges);
     for (auto& e : staged) e.reserved = 0;            // overwritten below with the owning path's index
@@ -430,38 +427,37 @@ int upload(swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_
         order.resize(n_wg);
         for (uint32_t wg = 0; wg < n_wg; ++wg) order[bucket_n[bucket_of(cost_of(wg))]++] = wg;   // row-major inside a bucket
     }
-    r->n_edges = n_edges; r->n_paths = n_paths; r->n_styles = n_styles;
-    r->any_shader = false;
-    for (size_t i = 0; i < n_styles; ++i) r->any_shader = r->any_shader || styles[i].kind != SWFR_STYLE_SOLID;
+    sc.n_edges = n_edges; sc.n_paths = n_paths; sc.n_styles = n_styles;
+    sc.any_shader = false;
+    for (size_t i = 0; i < n_styles; ++i) sc.any_shader = sc.any_shader || styles[i].kind != SWFR_STYLE_SOLID;
     for (size_t c = 0; c < chunks.size(); ++c) { chunks[c].rec_base = uint32_t(rec_cap); rec_cap += chunk_cap[c]; }
-    r->n_tasks = row_base[n_paths];
-    r->n_chunks = chunks.size();
-    r->chunk_rows = chunk_rows;
-    r->n_bands = n_bands;
-    r->rec_main = rec_cap;                            // chunk-owned region; the rows of k_rows_big own slots behind it
+    sc.n_tasks = row_base[n_paths];
+    sc.n_chunks = chunks.size();
+    sc.chunk_rows = chunk_rows;
+    sc.n_bands = n_bands;
+    sc.rec_main = rec_cap;                            // chunk-owned region; the rows of k_rows_big own slots behind it
     for (auto& b : big_rows) { const uint32_t n = b.rec_base; b.rec_base = uint32_t(rec_cap); rec_cap += n; }
-    r->rec_cap = rec_cap + 64;
-    r->n_big = big_rows.size();
+    sc.rec_cap = rec_cap + 64;
+    sc.n_big = big_rows.size();
     // the chunk workgroups of k_rows classify their own (tile, path) pairs when every row of the scene is theirs (no crowded
     // rows, no box paths, no other rank's tile-rows): k_class is then not launched at all
-    r->fused_class = r->allow_fused && chunk_rows >= uint32_t(TILE_H) && big_rows.empty() && !any_boxes && bc == 1;
+    sc.fused_class = r->allow_fused && chunk_rows >= uint32_t(TILE_H) && big_rows.empty() && !any_boxes && bc == 1;
     // ... and when, besides, every path's edges fit the chunk staging area and every path has an area (so that every band entry
     // belongs to a chunk), the chunks also compute their edges' constants and write their band entries: k_front is not launched
-    r->fused_front = r->fused_class && r->allow_fused > 1 && max_path_edges <= 64 && !any_flat;
-    // per-frame (kernel-written) buffers: grow-only allocations
-    r->d_edges.reserve(n_edges); r->d_rows.reserve(r->n_tasks); r->d_records.reserve(r->rec_cap); r->d_band_list.reserve(band_off[n_bands]);
+    sc.fused_front = sc.fused_class && r->allow_fused > 1 && max_path_edges <= 64 && !any_flat;
+    sc.n_band_entries = band_off[n_bands];
     (void)pair_cap;
-    r->d_cls.reserve(size_t(band_off[n_bands]) * ((r->width + TILE_W - 1) / TILE_W) + 64);   // class byte per (band entry, tile column)
-    r->n_band_entries = band_off[n_bands];
-    r->d_counters.reserve(CNT_WORDS);
-    for (int k = 0; k + 1 < std::min(r->in_flight, 4); ++k) {
-        auto& x = r->extra[k];
-        x.d_edges.reserve(n_edges); x.d_rows.reserve(r->n_tasks); x.d_records.reserve(r->rec_cap); x.d_band_list.reserve(band_off[n_bands]);
-        x.d_cls.reserve(size_t(band_off[n_bands]) * ((r->width + TILE_W - 1) / TILE_W) + 64);
+    // per-frame (kernel-written) buffers: grow-only allocations
+    const int n_sets = std::max(1, std::min(r->in_flight, 4));
+    for (int k = 0; k < 4; ++k) {
+        if (all_sets ? k >= n_sets : k != si) continue;
+        auto& x = r->fs[k];
+        x.d_edges.reserve(n_edges); x.d_rows.reserve(sc.n_tasks); x.d_records.reserve(sc.rec_cap); x.d_band_list.reserve(sc.n_band_entries);
+        x.d_cls.reserve(sc.n_band_entries * ((r->width + TILE_W - 1) / TILE_W) + 64);   // class byte per (band entry, tile column)
         x.d_counters.reserve(CNT_WORDS);
         if (!x.d_fb.ptr) {
             x.d_fb.reserve(size_t(r->width) * r->height);
-            HIP_CHECK(hipMemsetAsync(x.d_fb.ptr, 0, size_t(r->width) * r->height * 4, r->stream));
+            HIP_CHECK(hipMemsetAsync(x.d_fb.ptr, 0, size_t(r->width) * r->height * 4, up_stream));
         }
         if (!x.stream) HIP_CHECK(hipStreamCreateWithFlags(&x.stream, hipStreamNonBlocking));
     }
@@ -469,26 +465,26 @@ int upload(swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_
     std::vector<DevFilter> filters(n_styles);
     std::vector<int32_t> fparams;
     for (size_t i = 0; i < n_styles; ++i) filters[i] = good_filter(styles[i], fparams);
-    r->has_order = !order.empty();
+    sc.has_order = !order.empty();
     {
-        SceneArena& A = r->arena;
+        SceneArena& A = sc.arena;
         auto P = SceneArena::padded;
         A.begin(P(n_edges * sizeof(swfr_edge)) + P(n_paths * sizeof(swfr_path)) + P(n_styles * sizeof(swfr_style)) +
                 P((n_paths + 1) * sizeof(uint32_t)) + P(band_slots.size() * sizeof(BandSlot)) + P(order.size() * sizeof(uint32_t)) +
                 P(big_rows.size() * sizeof(BigRow)) + P(chunks.size() * sizeof(ChunkInfo)) + P((n_bands + 1) * sizeof(uint32_t)) +
                 P(n_styles * sizeof(DevFilter)) + P(fparams.size() * sizeof(int32_t)) + 4096);
-        r->d_raw.set_view(A.push(staged.data(), n_edges * sizeof(swfr_edge)));
-        r->d_paths.set_view(A.push(paths, n_paths * sizeof(swfr_path)));
-        r->d_styles.set_view(A.push(styles, n_styles * sizeof(swfr_style)));
-        r->d_row_base.set_view(A.push(row_base.data(), (n_paths + 1) * sizeof(uint32_t)));
-        r->d_band_slots.set_view(A.push(band_slots.data(), band_slots.size() * sizeof(BandSlot)));
-        r->d_order.set_view(A.push(order.data(), order.size() * sizeof(uint32_t)));
-        r->d_big_rows.set_view(A.push(big_rows.data(), big_rows.size() * sizeof(BigRow)));
-        r->d_chunk_base.set_view(A.push(chunks.data(), chunks.size() * sizeof(ChunkInfo)));
-        r->d_band_off.set_view(A.push(band_off.data(), (n_bands + 1) * sizeof(uint32_t)));
-        r->d_filters.set_view(A.push(filters.data(), n_styles * sizeof(DevFilter)));
-        r->d_filter_params.set_view(A.push(fparams.data(), fparams.size() * sizeof(int32_t)));
-        A.flush(r->stream);
+        sc.raw = static_cast<swfr_edge*>(A.push(staged.data(), n_edges * sizeof(swfr_edge)));
+        sc.paths = static_cast<DevPath*>(A.push(paths, n_paths * sizeof(swfr_path)));
+        sc.styles = static_cast<swfr_style*>(A.push(styles, n_styles * sizeof(swfr_style)));
+        sc.row_base = static_cast<uint32_t*>(A.push(row_base.data(), (n_paths + 1) * sizeof(uint32_t)));
+        sc.band_slots = static_cast<BandSlot*>(A.push(band_slots.data(), band_slots.size() * sizeof(BandSlot)));
+        sc.order = static_cast<uint32_t*>(A.push(order.data(), order.size() * sizeof(uint32_t)));
+        sc.big_rows = static_cast<BigRow*>(A.push(big_rows.data(), big_rows.size() * sizeof(BigRow)));
+        sc.chunk_base = static_cast<ChunkInfo*>(A.push(chunks.data(), chunks.size() * sizeof(ChunkInfo)));
+        sc.band_off = static_cast<uint32_t*>(A.push(band_off.data(), (n_bands + 1) * sizeof(uint32_t)));
+        sc.filters = static_cast<DevFilter*>(A.push(filters.data(), n_styles * sizeof(DevFilter)));
+        sc.filter_params = static_cast<int32_t*>(A.push(fparams.data(), fparams.size() * sizeof(int32_t)));
+        A.flush(up_stream);
     }
     if (r->bitmap_table_dirty) {
         r->d_bitmap_table.reserve(r->bitmap_table.size());
@@ -499,7 +495,44 @@ int upload(swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_
         r->bitmap_table_dirty_copied = true;
     }
     if (r->bitmap_table_dirty_copied) { HIP_CHECK(hipStreamSynchronize(r->stream)); r->bitmap_table_dirty_copied = false; }   // bitmap_table may be edited next
-    r->scene_ready = true;
+    if (si == 0) r->scene_ready = true;
+    return SWFR_OK;
+}
+
+// the kernels of one frame of scene `sc` on frame set `F`, writing the framebuffer `fb`; e (optional): four events around them
+void launch_frame(swfr_renderer* r, const swfr_renderer::Scene& sc, swfr_renderer::FrameSet& F, uint32_t* fb, hipEvent_t* e) {
+    const uint32_t bc = r->cfg.band_count > 1 ? r->cfg.band_count : 1, bi = r->cfg.band_count > 1 ? r->cfg.band_index : 0;
+    const hipStream_t st = F.stream;
+    if (e) HIP_CHECK(hipEventRecord(e[0], st));
+    if (sc.n_paths && !sc.fused_front)   // edge constants + band lists (the row kernel does both itself when fused_front)
+        launch_front(st, sc.raw, sc.paths, F.d_edges.ptr, uint32_t(sc.n_edges), sc.band_slots, uint32_t(sc.n_band_entries),
+                     sc.row_base, sc.styles, F.d_band_list.ptr, F.d_counters.ptr);
+    if (e) HIP_CHECK(hipEventRecord(e[1], st));
+    if (sc.n_paths) {
+        launch_rows(st, F.d_edges.ptr, sc.paths, sc.row_base, sc.chunk_base, uint32_t(sc.n_paths), F.d_rows.ptr,
+                    F.d_records.ptr, F.d_counters.ptr, sc.big_rows, uint32_t(sc.n_big), uint32_t(sc.n_chunks), bi, bc, r->fast_limit,
+                    r->cell_mode, uint32_t(sc.chunk_rows), sc.band_slots, sc.band_off, F.d_cls.ptr, int(r->width), int(r->height),
+                    (sc.fused_class ? 1 : 0) | (sc.fused_front ? 2 : 0), sc.raw, sc.styles, F.d_band_list.ptr);
+        if (!sc.fused_class)
+            launch_class(st, F.d_band_list.ptr, uint32_t(sc.n_band_entries), sc.band_off, uint32_t(sc.n_bands), sc.raw,
+                         F.d_rows.ptr, F.d_records.ptr, F.d_cls.ptr, int(r->width), int(r->height), bi, bc);
+    }
+    if (e) HIP_CHECK(hipEventRecord(e[2], st));
+    launch_tiles(st, sc.raw, sc.band_off, F.d_band_list.ptr, F.d_cls.ptr, F.d_rows.ptr, F.d_records.ptr, sc.styles,
+                 Sources{r->d_bitmap_table.ptr, sc.filters, sc.filter_params}, fb, int(r->width), int(r->height), bi, bc, r->tiles_dbg,
+                 F.d_counters.ptr, uint32_t(sc.n_tasks), uint32_t(sc.rec_cap), sc.any_shader, sc.has_order ? sc.order : nullptr);
+    if (e) HIP_CHECK(hipEventRecord(e[3], st));
+}
+
+int check_counters(swfr_renderer* r, const uint32_t* counters) {
+    if (counters[CNT_ERROR] & ~1u) {
+        r->fb_valid = false;
+        return fail(r, SWFR_ERR_DEVICE, "internal consistency check failed in k_tiles (code " + std::to_string(counters[CNT_ERROR]) + ")");
+    }
+    if (counters[CNT_ERROR]) {
+        r->fb_valid = false;
+        return fail(r, SWFR_ERR_CAPACITY, "a pixel row has more than 64 active edges of one path (scan converter capacity)");
+    }
     return SWFR_OK;
 }
 
@@ -507,19 +540,14 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
     if (!r->has_device) return fail(r, SWFR_ERR_NO_DEVICE, "host-only handle cannot rasterize");
     if (!r->scene_ready) return fail(r, SWFR_ERR_INVALID, "no scene uploaded");
     if (frames == 0) frames = 1;
-    const uint32_t bc = r->cfg.band_count > 1 ? r->cfg.band_count : 1, bi = r->cfg.band_count > 1 ? r->cfg.band_index : 0;
+    const swfr_renderer::Scene& sc = r->scn[0];
     float setup_ms = 0, rows_ms = 0, tiles_ms = 0, total_ms = 0;
     uint32_t counters[CNT_WORDS] = {};
     if (frames > 4096) frames = 4096;
-    // all frames are queued back to back; events bracket every kernel on the stream the frame runs on
-    struct Set { hipStream_t st; DevEdge* edges; BandEntry* band_list; uint8_t* cls; RowInfo* rows; Rec* records; uint32_t* counters; uint32_t* fb; };
-    Set sets[4] = {{r->stream, r->d_edges.ptr, r->d_band_list.ptr, r->d_cls.ptr, r->d_rows.ptr, r->d_records.ptr, r->d_counters.ptr, r->d_fb.ptr}};
+    // all frames are queued back to back, rotating over the frame sets; events bracket every kernel on the stream the frame runs on
     uint32_t n_sets = 1;
     if (frames > 1)
-        for (int k = 0; k + 1 < std::min(r->in_flight, 4) && r->extra[k].stream; ++k) {
-            auto& x = r->extra[k];
-            sets[n_sets++] = Set{x.stream, x.d_edges.ptr, x.d_band_list.ptr, x.d_cls.ptr, x.d_rows.ptr, x.d_records.ptr, x.d_counters.ptr, x.d_fb.ptr};
-        }
+        while (n_sets < uint32_t(std::min(r->in_flight, 4)) && r->fs[n_sets].stream && r->fs[n_sets].d_fb.ptr) ++n_sets;
     while (r->ev.size() < size_t(frames) * 4 + 5) {
         hipEvent_t e = nullptr;
         HIP_CHECK(hipEventCreate(&e));
@@ -528,38 +556,19 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
     const uint32_t stride = r->event_stride < 1 ? 1u : uint32_t(r->event_stride);
     hipEvent_t ev_begin = r->ev[size_t(frames) * 4], ev_end = r->ev[size_t(frames) * 4 + 1];
     hipEvent_t* ev_join = &r->ev[size_t(frames) * 4 + 2];
-    HIP_CHECK(hipMemsetAsync(r->d_counters.ptr, 0, CNT_WORDS * sizeof(uint32_t), r->stream));
+    HIP_CHECK(hipMemsetAsync(r->fs[0].d_counters.ptr, 0, CNT_WORDS * sizeof(uint32_t), r->stream));
     HIP_CHECK(hipEventRecord(ev_begin, r->stream));
     for (uint32_t k = 1; k < n_sets; ++k) {
-        HIP_CHECK(hipStreamWaitEvent(sets[k].st, ev_begin, 0));
-        HIP_CHECK(hipMemsetAsync(sets[k].counters, 0, CNT_WORDS * sizeof(uint32_t), sets[k].st));
+        HIP_CHECK(hipStreamWaitEvent(r->fs[k].stream, ev_begin, 0));
+        HIP_CHECK(hipMemsetAsync(r->fs[k].d_counters.ptr, 0, CNT_WORDS * sizeof(uint32_t), r->fs[k].stream));
     }
     for (uint32_t f = 0; f < frames; ++f) {
-        const Set& S = sets[f % n_sets];
-        hipEvent_t* e = &r->ev[size_t(f) * 4];
+        swfr_renderer::FrameSet& F = r->fs[f % n_sets];
         const bool timed = f % stride == 0;        // per-kernel events on every stride-th frame (each costs a queue packet)
-        if (timed) HIP_CHECK(hipEventRecord(e[0], S.st));
-        if (r->n_paths && !r->fused_front)   // edge constants + band lists (the row kernel does both itself when fused_front)
-            launch_front(S.st, r->d_raw.ptr, r->d_paths.ptr, S.edges, uint32_t(r->n_edges), r->d_band_slots.ptr, uint32_t(r->n_band_entries),
-                         r->d_row_base.ptr, r->d_styles.ptr, S.band_list, S.counters);
-        if (timed) HIP_CHECK(hipEventRecord(e[1], S.st));
-        if (r->n_paths) {
-            launch_rows(S.st, S.edges, r->d_paths.ptr, r->d_row_base.ptr, r->d_chunk_base.ptr, uint32_t(r->n_paths), S.rows,
-                        S.records, S.counters, r->d_big_rows.ptr, uint32_t(r->n_big), uint32_t(r->n_chunks), bi, bc, r->fast_limit,
-                        r->cell_mode, uint32_t(r->chunk_rows), r->d_band_slots.ptr, r->d_band_off.ptr, S.cls, int(r->width), int(r->height),
-                        (r->fused_class ? 1 : 0) | (r->fused_front ? 2 : 0), r->d_raw.ptr, r->d_styles.ptr, S.band_list);
-            if (!r->fused_class)
-                launch_class(S.st, S.band_list, uint32_t(r->n_band_entries), r->d_band_off.ptr, uint32_t(r->n_bands), r->d_raw.ptr,
-                             S.rows, S.records, S.cls, int(r->width), int(r->height), bi, bc);
-        }
-        if (timed) HIP_CHECK(hipEventRecord(e[2], S.st));
-        launch_tiles(S.st, r->d_raw.ptr, r->d_band_off.ptr, S.band_list, S.cls, S.rows, S.records, r->d_styles.ptr,
-                     Sources{r->d_bitmap_table.ptr, r->d_filters.ptr, r->d_filter_params.ptr}, S.fb, int(r->width), int(r->height), bi, bc, r->tiles_dbg, S.counters, uint32_t(r->n_tasks), uint32_t(r->rec_cap), r->any_shader,
-                     r->has_order ? r->d_order.ptr : nullptr);
-        if (timed) HIP_CHECK(hipEventRecord(e[3], S.st));
+        launch_frame(r, sc, F, F.d_fb.ptr, timed ? &r->ev[size_t(f) * 4] : nullptr);
     }
     for (uint32_t k = 1; k < n_sets; ++k) {
-        HIP_CHECK(hipEventRecord(ev_join[k - 1], sets[k].st));
+        HIP_CHECK(hipEventRecord(ev_join[k - 1], r->fs[k].stream));
         HIP_CHECK(hipStreamWaitEvent(r->stream, ev_join[k - 1], 0));
     }
     HIP_CHECK(hipEventRecord(ev_end, r->stream));
@@ -567,9 +576,9 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
     // the counters of every set come back through pinned memory behind the last kernel: one synchronisation for everything
     if (!r->h_counters) HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&r->h_counters), 4 * CNT_WORDS * sizeof(uint32_t), hipHostMallocDefault));
     for (uint32_t k = 0; k < n_sets; ++k)
-        HIP_CHECK(hipMemcpyAsync(r->h_counters + k * CNT_WORDS, sets[k].counters, CNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
+        HIP_CHECK(hipMemcpyAsync(r->h_counters + k * CNT_WORDS, r->fs[k].d_counters.ptr, CNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
     HIP_CHECK(hipStreamSynchronize(r->stream));
-    r->fb_cur = sets[(frames - 1) % n_sets].fb;
+    r->fb_cur = r->fs[(frames - 1) % n_sets].d_fb.ptr;
     uint32_t timed_frames = 0;
     for (uint32_t f = 0; f < frames; f += stride, ++timed_frames) {
         hipEvent_t* e = &r->ev[size_t(f) * 4];
@@ -582,26 +591,57 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
     HIP_CHECK(hipEventElapsedTime(&total_ms, ev_begin, ev_end));
     std::memcpy(counters, r->h_counters, sizeof counters);
     for (uint32_t k = 1; k < n_sets; ++k) counters[CNT_ERROR] |= r->h_counters[k * CNT_WORDS + CNT_ERROR];
-    r->timing = swfr_timing{total_ms, setup_ms, rows_ms, tiles_ms, frames, r->n_edges, r->n_paths, r->n_tasks, r->rec_main, timed_frames};
+    r->timing = swfr_timing{total_ms, setup_ms, rows_ms, tiles_ms, frames, sc.n_edges, sc.n_paths, sc.n_tasks, sc.rec_main, timed_frames};
     if (r->tiles_dbg == 9)
-        std::fprintf(stderr, "[swfr] tile/path pairs %u, partial %u, full %u, culled entries %u, records %u, overflow rows %u\n", counters[CNT_PAIRS],
-                     counters[CNT_PARTIAL], counters[CNT_FULL], counters[CNT_CULLED], counters[CNT_RECORDS], counters[CNT_OVERFLOW]);
-    if (r->tiles_dbg == 10) {
-        auto u64 = [&](int i) { return (unsigned long long)counters[i] | ((unsigned long long)counters[i + 1] << 32); };
-        const double n = counters[8] ? counters[8] : 1;
-        std::fprintf(stderr, "[swfr] per tile clocks: total %.0f, bin %.0f, classify %.0f, walk %.0f (accumulate %.0f)\n", u64(10) / n, u64(18) / n,
-                     u64(12) / n, u64(16) / n, u64(14) / n);
-    }
+        std::fprintf(stderr, "[swfr] tile/path pairs %u, partial %u, full %u, culled entries %u\n", counters[CNT_PAIRS],
+                     counters[CNT_PARTIAL], counters[CNT_FULL], counters[CNT_CULLED]);
     r->fb_valid = true;
-    if (counters[CNT_ERROR] & ~1u) {
-        r->fb_valid = false;
-        return fail(r, SWFR_ERR_DEVICE, "internal consistency check failed in k_tiles (code " + std::to_string(counters[CNT_ERROR]) + ")");
+    return check_counters(r, counters);
+}
+
+// A batch of different frames (BASELINE config 3: 256 morph ratios): frame i is built on the host, uploaded into the scene slot
+// of frame set i mod n and rasterized on that set's stream straight into device_dst + i * frame_stride, while the host already
+// builds frame i+1.  Nothing waits for the GPU until the end (a scene slot's pinned staging buffer is reused only after its
+// previous H2D copy has completed).
+int render_batch(swfr_renderer* r, const swfr_stage* stages, uint32_t n, void* device_dst, size_t frame_stride) {
+    if (!r->has_device) return fail(r, SWFR_ERR_NO_DEVICE, "host-only handle cannot rasterize");
+    if (n == 0) return SWFR_OK;
+    if (device_dst && frame_stride < size_t(r->width) * r->height * 4) return fail(r, SWFR_ERR_INVALID, "frame stride smaller than a frame");
+    const uint32_t n_sets = uint32_t(std::max(1, std::min(r->in_flight, 4)));
+    std::vector<uint32_t*> pinned_counters;
+    uint32_t* hc = nullptr;
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&hc), size_t(n) * CNT_WORDS * sizeof(uint32_t), hipHostMallocDefault));
+    int rc = SWFR_OK;
+    try {
+        for (uint32_t i = 0; i < n; ++i) {
+            const int k = int(i % n_sets);
+            r->builder->build(stages[i]);
+            const auto& e = r->builder->edges();
+            const auto& p = r->builder->paths();
+            const auto& s = r->builder->styles();
+            rc = upload(r, k, false, e.data(), e.size(), p.data(), p.size(), s.data(), s.size());
+            if (rc != SWFR_OK) break;
+            swfr_renderer::FrameSet& F = r->fs[k];
+            if (k > 0 && i < n_sets) HIP_CHECK(hipStreamSynchronize(r->stream));   // first use of the set: bitmap table etc. are in place
+            HIP_CHECK(hipMemsetAsync(F.d_counters.ptr, 0, CNT_WORDS * sizeof(uint32_t), F.stream));
+            uint32_t* fb = device_dst ? reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(device_dst) + size_t(i) * frame_stride) : F.d_fb.ptr;
+            launch_frame(r, r->scn[k], F, fb, nullptr);
+            HIP_CHECK(hipMemcpyAsync(hc + size_t(i) * CNT_WORDS, F.d_counters.ptr, CNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, F.stream));
+            r->fb_cur = fb;
+        }
+        HIP_CHECK(hipGetLastError());
+        for (uint32_t k = 0; k < n_sets; ++k)
+            if (r->fs[k].stream) HIP_CHECK(hipStreamSynchronize(r->fs[k].stream));
+    } catch (...) {
+        (void)hipHostFree(hc);
+        throw;
     }
-    if (counters[CNT_ERROR]) {
-        r->fb_valid = false;
-        return fail(r, SWFR_ERR_CAPACITY, "a pixel row has more than 64 active edges of one path (scan converter capacity)");
-    }
-    return SWFR_OK;
+    r->scene_ready = false;                 // scene 0 now holds some frame of the batch, not a scene the caller uploaded
+    r->fb_valid = true;
+    if (rc == SWFR_OK)
+        for (uint32_t i = 0; i < n && rc == SWFR_OK; ++i) rc = check_counters(r, hc + size_t(i) * CNT_WORDS);
+    (void)hipHostFree(hc);
+    return rc;
 }
 
 }  // namespace
@@ -643,9 +683,10 @@ int swfr_create(uint32_t width, uint32_t height, const swfr_config* cfg, swfr_re
     swfr_renderer* raw = r.get();
     const int rc = guarded(raw, [&]() {
         HIP_CHECK(hipStreamCreateWithFlags(&raw->stream, hipStreamNonBlocking));
-        raw->d_fb.reserve(size_t(width) * height);
-        HIP_CHECK(hipMemsetAsync(raw->d_fb.ptr, 0, size_t(width) * height * 4, raw->stream));
-        raw->d_counters.reserve(CNT_WORDS);
+        raw->fs[0].stream = raw->stream;
+        raw->fs[0].d_fb.reserve(size_t(width) * height);
+        HIP_CHECK(hipMemsetAsync(raw->fs[0].d_fb.ptr, 0, size_t(width) * height * 4, raw->stream));
+        raw->fs[0].d_counters.reserve(CNT_WORDS);
         HIP_CHECK(hipStreamSynchronize(raw->stream));
         return int(SWFR_OK);
     });
@@ -720,7 +761,7 @@ int swfr_build_frame(swfr_renderer* r, const swfr_stage* stage, const swfr_edge*
 int swfr_upload_edges(swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_path* paths, size_t n_paths,
                       const swfr_style* styles, size_t n_styles) {
     if (!r || (n_edges && !edges) || (n_paths && !paths) || (n_styles && !styles)) return fail(r, SWFR_ERR_INVALID, "null argument");
-    return guarded(r, [&]() { return upload(r, edges, n_edges, paths, n_paths, styles, n_styles); });
+    return guarded(r, [&]() { return upload(r, 0, true, edges, n_edges, paths, n_paths, styles, n_styles); });
 }
 
 int swfr_render_resident(swfr_renderer* r, uint32_t frames) {
@@ -743,10 +784,16 @@ int swfr_render(swfr_renderer* r, const swfr_stage* stage) {
         const auto& e = r->builder->edges();
         const auto& p = r->builder->paths();
         const auto& s = r->builder->styles();
-        const int rc = upload(r, e.data(), e.size(), p.data(), p.size(), s.data(), s.size());
+        const int rc = upload(r, 0, true, e.data(), e.size(), p.data(), p.size(), s.data(), s.size());
         if (rc != SWFR_OK) return rc;
         return render_resident(r, 1);
     });
+}
+
+int swfr_render_batch(swfr_renderer* r, const swfr_stage* stages, uint32_t n_stages, void* device_dst, size_t frame_stride) {
+    if (!r || (!stages && n_stages)) return fail(r, SWFR_ERR_INVALID, "null argument");
+    if (!r->has_device) return fail(r, SWFR_ERR_NO_DEVICE, "host-only handle cannot rasterize");
+    return guarded(r, [&]() { return render_batch(r, stages, n_stages, device_dst, frame_stride); });
 }
 
 int swfr_read_image(swfr_renderer* r, uint8_t* dst, size_t dst_stride, int premultiplied) {
@@ -755,7 +802,7 @@ int swfr_read_image(swfr_renderer* r, uint8_t* dst, size_t dst_stride, int premu
     if (!r->fb_valid) return fail(r, SWFR_ERR_INVALID, "nothing rendered yet");
     return guarded(r, [&]() {
         const size_t n = size_t(r->width) * r->height;
-        const uint32_t* src = r->fb_cur ? r->fb_cur : r->d_fb.ptr;
+        const uint32_t* src = r->fb_cur ? r->fb_cur : r->fs[0].d_fb.ptr;
         if (!premultiplied) {
             r->d_tmp.reserve(n);
             launch_unpremultiply(r->stream, src, r->d_tmp.ptr, n);
@@ -795,14 +842,14 @@ int swfr_copy_band_slab(swfr_renderer* r, void* device_dst) {
     if (!r->has_device) return fail(r, SWFR_ERR_NO_DEVICE, "host-only handle");
     return guarded(r, [&]() {
         const uint32_t bc = r->cfg.band_count > 1 ? r->cfg.band_count : 1, bi = r->cfg.band_count > 1 ? r->cfg.band_index : 0;
-        launch_pack_band(r->stream, r->fb_cur ? r->fb_cur : r->d_fb.ptr, static_cast<uint32_t*>(device_dst), int(r->width), int(r->height), bi, bc, local_tile_rows(r));
+        launch_pack_band(r->stream, r->fb_cur ? r->fb_cur : r->fs[0].d_fb.ptr, static_cast<uint32_t*>(device_dst), int(r->width), int(r->height), bi, bc, local_tile_rows(r));
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipStreamSynchronize(r->stream));
         return int(SWFR_OK);
     });
 }
 
-void* swfr_device_framebuffer(swfr_renderer* r) { return (r && r->has_device) ? (r->fb_cur ? r->fb_cur : r->d_fb.ptr) : nullptr; }
+void* swfr_device_framebuffer(swfr_renderer* r) { return (r && r->has_device) ? (r->fb_cur ? r->fb_cur : r->fs[0].d_fb.ptr) : nullptr; }
 
 #pragma GCC visibility pop
 }  // extern "C"

@@ -88,6 +88,37 @@ def test_reference_morph_golden_png(ratio, fname, allowed):
     assert n <= allowed and mx <= (1 if allowed else 0)    # 4 px / 1 LSB at ratio 0.5
 
 
+def test_render_batch_morph_ratios_vs_sequential_and_oracle():
+    """swfr_render_batch: different frames pipelined over the streams, each written straight into its slot of a device tensor."""
+    import torch
+    import swf_renderer_amd as S
+    tag = fixture("homestuck-beta-29")
+    ratios = [k / 40 for k in range(41)]
+    stages = [cr.stage_for_morph_shape(tag, q)[2] for q in ratios]
+    w, h, _ = cr.stage_for_morph_shape(tag, 0.0)
+    r = S.Renderer(w, h)
+    out = torch.zeros((len(stages), h, w, 4), dtype=torch.uint8, device="cuda")
+    r.render_batch(stages, out.data_ptr(), h * w * 4)
+    got = out.cpu().numpy()
+    last = r.read_image(premultiplied=True)
+    assert (last == got[-1]).all()
+    for i, st in enumerate(stages):
+        r.render(st)
+        assert (r.read_image(premultiplied=True) == got[i]).all(), i
+    r.close()
+    for i in (0, 13, 40):
+        assert diff_stats(got[i], oracle_render(dict(width=w, height=h, stage=stages[i]))) == (0, 0), i
+    # textured + stroked frames in one batch, no destination: the last frame is readable
+    sc_a, sc_b = SC["fixture_homestuck-beta-4"], SC["stroke_curves"]
+    r = S.Renderer(sc_a["width"], sc_a["height"])
+    for bm in sc_a["bitmaps"]:
+        r.add_bitmap(bm)
+    r.render_batch([sc_a["stage"], sc_a["stage"], sc_a["stage"]])
+    n, mx = diff_stats(r.read_image(premultiplied=True), oracle_render(sc_a))
+    r.close()
+    assert mx <= 2, (n, mx)
+
+
 # ---- BASELINE config 3: 256 morph ratios through one handle (reduced frame; oracle finishes in seconds)
 def test_morph_256_ratios_vs_oracle():
     import swf_renderer_amd as S

@@ -28,6 +28,14 @@ def run(name, W, H, stages, bitmaps=(), resident_frames=200):
     for st in stages:
         r.render(st)
     dt_full = (time.perf_counter() - t0) / len(stages)
+    # the same frames as one pipelined batch into a device tensor (swfr_render_batch)
+    import torch
+    out_t = torch.empty((len(stages), H, W, 4), dtype=torch.uint8, device="cuda")
+    r.render_batch(stages[:2], out_t.data_ptr(), H * W * 4)
+    t0 = time.perf_counter()
+    r.render_batch(stages, out_t.data_ptr(), H * W * 4)
+    dt_batch = (time.perf_counter() - t0) / len(stages)
+    del out_t
     # device path alone: the last stage's edge list, resident
     edges, paths, styles = r.build_frame(stages[-1])
     r.upload_edges(edges, paths, styles)
@@ -38,6 +46,7 @@ def run(name, W, H, stages, bitmaps=(), resident_frames=200):
     r.close()
     out = {"config": name, "frame": "%dx%d" % (W, H), "frames": len(stages), "edges": int(len(edges)), "paths": int(len(paths)),
            "full_path_frames_per_s": round(1 / dt_full, 1), "full_path_Mpx_per_s": round(W * H / dt_full / 1e6, 1),
+           "batch_frames_per_s": round(1 / dt_batch, 1), "batch_Mpx_per_s": round(W * H / dt_batch / 1e6, 1),
            "device_frames_per_s": round(1 / dt_dev, 1), "device_Mpx_per_s": round(W * H / dt_dev / 1e6, 1),
            "kernel_us": {k: round(tm[k + "_ms"] * 1e3 / max(tm["timed_frames"], 1), 1) for k in ("setup", "rows", "tiles")}}
     print(json.dumps(out), flush=True)
