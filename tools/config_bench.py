@@ -54,6 +54,8 @@ def run(name, W, H, stages, bitmaps=(), resident_frames=200):
 
 
 def main():
+    import torch
+    assert torch.cuda.is_available()                 # torch initialises HIP first (it does not find the GPU after another HIP user did)
     m = scenarios._m
     # config 2: the flat shapes (+ gradient variants) at 1024x1024
     SC = scenarios.scenarios()
