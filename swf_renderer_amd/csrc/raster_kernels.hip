@@ -891,8 +891,10 @@ __device__ __forceinline__ uint32_t add8x2_sat(uint32_t a, uint32_t b) {
 }
 // Cairo's span lerp for SOURCE with 8-bit coverage (0x7f rounding)
 __device__ __forceinline__ uint32_t lerp_pixel(uint32_t src, uint32_t a, uint32_t dst) {
+    // Cairo adds the two products with a saturating add; they cannot exceed 255 per channel (a + (255 - a) = 255 and both
+    // products round down from src*a/255 + 1/2), so a plain add gives the same bits
     const uint32_t ia = 255u - a;
-    return add8x2_sat(mul8x2_7f(src, a), mul8x2_7f(dst, ia)) | (add8x2_sat(mul8x2_7f(src >> 8, a), mul8x2_7f(dst >> 8, ia)) << 8);
+    return (mul8x2_7f(src, a) + mul8x2_7f(dst, ia)) | ((mul8x2_7f(src >> 8, a) + mul8x2_7f(dst >> 8, ia)) << 8);
 }
 // pixman UN8x4_MUL_UN8 (0x80 rounding) and OVER
 __device__ __forceinline__ uint32_t mul_un8(uint32_t x, uint32_t a) {
@@ -1353,12 +1355,14 @@ __device__ __forceinline__ void tiles_body(const swfr_edge* __restrict__ raw_edg
         int batch_n = 0, batch_i = 0;                          // paths in the batch, next one to consume
         int total = 0, wbase = 0, wn = 0;                      // records of the batch; staged window [wbase, wbase + wn)
         for (int li = start; li < ln; ++li) {
-            const uint32_t f = cls[li];                        // wave-uniform (LDS broadcast)
-            const uint32_t xw = ent[li][1], yw = ent[li][2];
+            // per-entry fields are wave-uniform: readfirstlane moves them (and everything computed from them) to the scalar unit
+            const uint32_t f = __builtin_amdgcn_readfirstlane(cls[li]);
+            const uint32_t xw = __builtin_amdgcn_readfirstlane(ent[li][1]), yw = __builtin_amdgcn_readfirstlane(ent[li][2]);
             const int e_xmin = (int)(int16_t)(xw & 0xffffu), e_xmax = (int)(int16_t)(xw >> 16);
             const int e_ymin = (int)(int16_t)(yw & 0xffffu), e_ymax = (int)(int16_t)(yw >> 16);
-            const uint32_t style = ent[li][4], e_first = ent[li][5], e_nedges = ent[li][6];
-            const uint32_t eflags = ent[li][7], solid = ent[li][8];
+            const uint32_t style = __builtin_amdgcn_readfirstlane(ent[li][4]), e_first = __builtin_amdgcn_readfirstlane(ent[li][5]),
+                           e_nedges = __builtin_amdgcn_readfirstlane(ent[li][6]);
+            const uint32_t eflags = __builtin_amdgcn_readfirstlane(ent[li][7]), solid = __builtin_amdgcn_readfirstlane(ent[li][8]);
             const int row_lo = max(e_ymin, ty0) - ty0, row_hi = min(min(e_ymax, ty0 + STRIP_H), height) - ty0;
             if (row_hi <= row_lo) continue;                    // the path misses this strip of the tile
             if (f & CLS_BOX) {
