@@ -1419,7 +1419,7 @@ __device__ __forceinline__ void tiles_body(const swfr_edge* __restrict__ raw_edg
                         }
                     }
                     const int incl = wave_scan_incl((int)my_cnt);       // every lane active
-                    total = __shfl(incl, 63);
+                    total = __builtin_amdgcn_readlane(incl, 63);       // wave-uniform, on the scalar unit
                     row_off[lane] = off;
                     row_start[lane] = (uint32_t)(incl - (int)my_cnt);
                     row_start[64] = (uint32_t)total;                    // same value from every lane
@@ -1432,8 +1432,8 @@ __device__ __forceinline__ void tiles_body(const swfr_edge* __restrict__ raw_edg
                 const int bp = batch_i++;
                 ++dbg_pairs;
                 TileCtx c; c.tx0 = tx0; c.xminp = e_xmin; c.xmaxp = e_xmax;
-                int g0 = (int)row_start[bp * STRIP_H];
-                const int g1 = (int)row_start[(bp + 1) * STRIP_H];      // this path's records [g0, g1) of the batch sequence
+                int g0 = (int)__builtin_amdgcn_readfirstlane(row_start[bp * STRIP_H]);
+                const int g1 = (int)__builtin_amdgcn_readfirstlane(row_start[(bp + 1) * STRIP_H]);   // this path's records [g0, g1) of the batch sequence
                 const uint32_t* rdw = reinterpret_cast<const uint32_t*>(records);
                 while (g0 < g1) {
                     if (g0 >= wbase + wn) {
