@@ -1292,6 +1292,7 @@ __device__ __forceinline__ void tiles_body(const swfr_edge* __restrict__ raw_edg
 #define PHASE(var) do { } while (0)
 #endif
 
+    const int lane_t = lane / 12, lane_w = lane - lane_t * 12;   // record / word of dword `lane` in a stream of 12-dword records
     uint32_t px[STRIP_H];                                 // this lane's column of the strip, in registers (row loops are unrolled)
 #pragma unroll
     for (int rr = 0; rr < STRIP_H; ++rr) px[rr] = 0u;
@@ -1454,11 +1455,15 @@ __device__ __forceinline__ void tiles_body(const swfr_edge* __restrict__ raw_edg
                         if (dbg != 12)
                         for (int d0 = 0; d0 < wn * 12; d0 += 64 * 6) {
                             uint32_t tmp[6];
+                            // dword d = d0 + 64 u + lane is word w of staged record t: (t, w) advance by (5, 4) per u, no divisions
+                            int t = d0 / 12 + lane_t, w = lane_w;          // d0 is a multiple of 384 = 32 records
 #pragma unroll
                             for (int u = 0; u < 6; ++u) {
                                 const int d = d0 + u * 64 + lane;
                                 tmp[u] = 0u;
-                                if (d < wn * 12) { const int t = d / 12, w = d - t * 12; tmp[u] = rdw[(size_t)rec_src[t] * 12 + w]; }
+                                if (d < wn * 12) tmp[u] = rdw[(size_t)rec_src[t] * 12 + w];
+                                w += 4; t += 5;
+                                if (w >= 12) { w -= 12; ++t; }
                             }
 #pragma unroll
                             for (int u = 0; u < 6; ++u) {
@@ -1530,7 +1535,7 @@ __device__ __forceinline__ void tiles_body(const swfr_edge* __restrict__ raw_edg
                         if (lane == 0) ch += carry[u];
                         const int scan = wave_scan_incl(ch);
                         const int area = scan * 512 - ua;
-                        al[u] = (uint32_t)((area * 17 + 256) >> 9) & 255u;
+                        al[u] = (uint32_t)((((area << 4) + area) + 256) >> 9) & 255u;   // area * 17 without a 64-bit multiply-add
                         if (cx < e_xmin || cx >= e_xmax) al[u] = 0;
                     }
 #pragma unroll
@@ -1563,13 +1568,14 @@ __device__ __forceinline__ void tiles_body(const swfr_edge* __restrict__ raw_edg
     }
     // ---- one store per pixel: premultiplied R,G,B,A bytes; the wave writes 256 contiguous bytes per row
     if (cx < width) {
+        uint32_t* rowp = fb + (size_t)ty0 * (size_t)width + cx;   // one 64-bit multiply per strip, then pointer steps
 #pragma unroll
         for (int rr = 0; rr < STRIP_H; ++rr) {
-            const int cy = ty0 + rr;
-            if (cy >= height) continue;
-            const uint32_t p = px[rr];
-            const uint32_t rgba = (p & 0xff00ff00u) | ((p >> 16) & 0xffu) | ((p & 0xffu) << 16);
-            fb[(size_t)cy * (size_t)width + cx] = rgba;
+            if (ty0 + rr < height) {
+                const uint32_t p = px[rr];
+                *rowp = (p & 0xff00ff00u) | ((p >> 16) & 0xffu) | ((p & 0xffu) << 16);
+            }
+            rowp += width;
         }
     }
 }
