@@ -1261,7 +1261,7 @@ __device__ __forceinline__ void tiles_body(const swfr_edge* __restrict__ raw_edg
                                               const uint32_t* __restrict__ order) {
     __shared__ int acc[STRIP_H][ACC_STRIDE];
     __shared__ int plist[PBATCH];
-    __shared__ uint32_t ent[TLIST][9];                    // BandEntry as 9 dwords
+    __shared__ __attribute__((aligned(16))) uint32_t ent[TLIST][12];   // BandEntry as 9 dwords in a 48-byte slot (16-byte LDS writes)
     __shared__ uint32_t cls[TLIST];
     __shared__ __attribute__((aligned(16))) uint32_t stage[REC_STAGE * 12];   // records as dwords
     __shared__ uint32_t rec_src[REC_STAGE];
@@ -1321,8 +1321,13 @@ __device__ __forceinline__ void tiles_body(const swfr_edge* __restrict__ raw_edg
             if (hit) {
                 const int at = ln + __popcll(b & ((1ull << lane) - 1ull));
                 const uint32_t* src = reinterpret_cast<const uint32_t*>(&band_list[band_begin + bi]);
-#pragma unroll
-                for (int w = 0; w < 9; ++w) ent[at][w] = src[w];
+                // 36-byte entry: two 16-byte global loads + one dword (the entries are only 4-byte aligned: dword-aligned vector type)
+                typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+                const u32x4_a4 q0 = *reinterpret_cast<const u32x4_a4*>(src), q1 = *reinterpret_cast<const u32x4_a4*>(src + 4);
+                const uint32_t q2 = src[8];
+                *reinterpret_cast<uint4*>(&ent[at][0]) = make_uint4(q0.x, q0.y, q0.z, q0.w);
+                *reinterpret_cast<uint4*>(&ent[at][4]) = make_uint4(q1.x, q1.y, q1.z, q1.w);
+                ent[at][8] = q2;
                 cls[at] = f;
             }
             ln += cnt;
