@@ -1588,9 +1588,10 @@ __device__ __forceinline__ void tiles_body(const swfr_edge* __restrict__ raw_edg
 #undef blend_pixel
 #undef PHASE
 
-// Two instances: solid-colour scenes (no shader call; the register budget is capped so that five wavefronts fit a SIMD --
-// measured +4 % on S1 with six spilled registers) and scenes with gradient / bitmap styles (uncapped: the f64 shader would spill).
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_tiles_solid(
+// Two instances: solid-colour scenes (no shader call; the register budget is capped so that six wavefronts fit a SIMD --
+// measured best on S1, +5 % with two spilled registers; five or seven are slower) and scenes with gradient / bitmap
+// styles (uncapped: the f64 shader would spill).
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_tiles_solid(
     const swfr_edge* __restrict__ raw_edges, const uint32_t* __restrict__ band_off, const BandEntry* __restrict__ band_list,
     const uint8_t* __restrict__ cls_t, const RowInfo* __restrict__ rows, const Rec* __restrict__ records,
     const swfr_style* __restrict__ styles, const Sources bitmaps, uint32_t* __restrict__ fb, int width, int height, int tiles_x,
