@@ -6,9 +6,12 @@ synthetic shape set (scene S1).
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A step is one pass of the hot path over one frame: edge setup -> per-row winding -> tile raster/shade/blend
--> RGBA8 framebuffer in HBM, with the edge list already resident in HBM.  With N > 1 the frame's tile-rows
-are sharded over the ranks (strong scaling: the frame is fixed) and every step ends with one RCCL gather of
-the band slabs to rank 0, where the frame is assembled.  Rank 0 prints ONE JSON line.
+-> RGBA8 framebuffer in HBM, with the edge list already resident in HBM; consecutive frames alternate between two
+sets of per-frame buffers on two HIP streams (SWFR_FRAMES_IN_FLIGHT).  With N > 1 every rank rasterizes whole frames
+of the batch (a step is one frame per rank, weak scaling, no data-path collective); `--sharding bands` instead
+shards one frame's tile-rows over the ranks and ends every step with one RCCL gather to rank 0 (strong scaling).
+Rank 0 prints ONE JSON line: the BASELINE metric, the HBM roofline of k_tiles from HIP events in the timed region
+(and the same kernel with one frame in flight beside it), and the CPU oracle timed on this box.
 """
 import argparse
 import ctypes
