@@ -853,6 +853,155 @@ __device__ __forceinline__ void big_row_body(uint32_t block, const DevEdge* __re
     if (lane == 0) { ri.n_rec = (uint16_t)__popcll(hm); ri.mode = (uint16_t)mode; rows[t] = ri; }
 }
 
+// Rows with more than ROWS_BIG_MAXA (64) and up to ROWS_HUGE_MAXA (256) active edges of one path: one 256-thread workgroup per
+// row, thread = active edge, sort keys in LDS.  Same decisions as big_row_body; launched only when the host listed such rows.
+#define ROWS_HUGE_MAXA 256
+__global__ __launch_bounds__(256) void k_rows_huge(const DevEdge* __restrict__ edges, const DevPath* __restrict__ paths,
+                                                   const uint32_t* __restrict__ row_base, const BigRow* __restrict__ huge_rows, uint32_t n_huge,
+                                                   RowInfo* __restrict__ rows, Rec* __restrict__ records, uint32_t* __restrict__ counters,
+                                                   int cell_mode) {
+    __shared__ uint32_t active[ROWS_HUGE_MAXA];
+    __shared__ int k_c0[ROWS_HUGE_MAXA], k_c1[ROWS_HUGE_MAXA], k_cp[ROWS_HUGE_MAXA], k_nw[ROWS_HUGE_MAXA], k_dr[ROWS_HUGE_MAXA];
+    __shared__ int k_cc[ROWS_HUGE_MAXA], k_dd[ROWS_HUGE_MAXA];       // per sample row: cell and direction (0 = inactive there)
+    __shared__ uint32_t wave_cnt[4];
+    __shared__ int flags;                                            // bit 0: some edge starts / ends inside the row, bit 1: FULL test failed
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (blockIdx.x >= n_huge) return;
+    const BigRow br = huge_rows[blockIdx.x];
+    const DevPath P = paths[br.path];
+    const int r = br.row, s0 = r * 15;
+    const uint32_t t = row_base[br.path] + (uint32_t)(r - P.y_min);
+    const unsigned mask = P.fill_rule ? 1u : ~0u;
+    const DevEdge* E = edges + P.first_edge;
+    if (tid == 0) flags = 0;
+    // ---- gather the active edges in path order: ballot per wavefront, wavefront totals through LDS
+    int n = 0;
+    for (uint32_t base = 0; base < P.n_edges; base += 256) {
+        const uint32_t k = base + (uint32_t)tid;
+        bool act = false;
+        if (k < P.n_edges) { const int ytop = E[k].ytop, ybot = E[k].ybot; act = !(ybot <= s0 || ytop >= s0 + 15); }
+        const unsigned long long b = __ballot(act);
+        if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(b);
+        __syncthreads();
+        int at = n;
+        for (int w = 0; w < wave; ++w) at += (int)wave_cnt[w];
+        at += __popcll(b & ((1ull << lane) - 1ull));
+        if (act && at < ROWS_HUGE_MAXA) active[at] = k;
+        n += (int)(wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3]);
+        __syncthreads();
+    }
+    RowInfo ri; ri.rec_off = br.rec_base; ri.n_rec = 0; ri.mode = ROW_EMPTY;
+    if (n > ROWS_HUGE_MAXA) {                                        // workgroup-uniform
+        if (tid == 0) { atomicOr(&counters[CNT_ERROR], 1u); rows[t] = ri; }
+        return;
+    }
+    const bool mine = tid < n;
+    const uint32_t k_mine = active[mine ? tid : 0];
+    const DevEdge e = E[k_mine];
+    const bool slanted = e.dy != 0;
+    if (mine && ((e.ytop > s0) | (e.ybot < s0 + 15))) atomicOr(&flags, 1);
+    __syncthreads();
+    uint32_t role = 0, cols = 0;
+    int32_t q1 = e.x1, q2 = e.x1; int64_t r1 = 0, r2 = 0;
+    bool full = (flags & 1) == 0;
+    if (full) {
+        int c0 = e.x1, c1 = e.x1, cpv = e.x1;
+        if (slanted) {
+            int32_t qa, qb; int64_t ra, rb;
+            edge_x_at(e, s0, qa, ra);
+            edge_x_at(e, s0 + 15, qb, rb);
+            c0 = cell_of(qa, ra, e.dy);
+            c1 = cell_of(qb, rb, e.dy);
+            cpv = c0;
+            if (e.ytop < s0) {
+                int32_t q = qa - (int32_t)e.dq; int64_t rm = ra - e.dr;
+                if (rm < 0) { --q; rm += e.dy; } else if (rm >= e.dy) { ++q; rm -= e.dy; }
+                cpv = cell_of(q, rm, e.dy);
+            }
+            const int32_t hq = (int32_t)(e.dq / 2); const int64_t hr = e.dr / 2;
+            qa -= hq; ra -= hr; if (ra < 0) { --qa; ra += e.dy; } else if (ra >= e.dy) { ++qa; ra -= e.dy; }
+            qb -= hq; rb -= hr; if (rb < 0) { --qb; rb += e.dy; } else if (rb >= e.dy) { ++qb; rb -= e.dy; }
+            q1 = qa; r1 = ra; q2 = qb; r2 = rb;
+        }
+        const int nw = (e.ytop == s0) ? 1 : 0, dr = e.dir;
+        if (mine) { k_c0[tid] = c0; k_c1[tid] = c1; k_cp[tid] = cpv; k_nw[tid] = nw; k_dr[tid] = dr; }
+        __syncthreads();
+        int w = 0; bool fg = true, lg = true, ok = true;
+        if (mine)
+            for (int i = 0; i < n; ++i) {                            // LDS broadcast reads
+                if (i == tid) continue;
+                const int ci = k_c0[i], ei = k_c1[i], pi = k_cp[i], ni = k_nw[i], di = k_dr[i];
+                const bool tie = ci == c0, tie2 = ni == nw;
+                const bool t3 = ni == 0 ? (pi < cpv || (pi == cpv && i < tid)) : (i < tid);
+                const bool before = ci < c0 || (tie && (ni < nw || (tie2 && t3)));
+                if (before) { w += di; if (ei > c1) ok = false; if (tie) fg = false; }
+                else if (tie) lg = false;
+            }
+        if (mine && !ok) atomicOr(&flags, 2);
+        __syncthreads();
+        full = (flags & 2) == 0;
+        if (full && mine) {
+            const bool in_b = ((unsigned)w & mask) != 0, in_a = ((unsigned)(w + dr) & mask) != 0;
+            if (!in_b && fg) role = REC_FULL | 1u;
+            else if (!in_a && lg) role = REC_FULL | 2u;
+            if (role) { const int a = q1 >> 8, b = q2 >> 8; cols = clamp_col(min(a, b)) | (clamp_col(max(a, b)) << 16); }
+        }
+    }
+    const uint32_t mode = full ? ROW_FULL : ROW_SUB;
+    if (!full) {
+        int clo = 65535, chi = 0;
+        for (int sub = 0; sub < 15; ++sub) {
+            const int ss = s0 + sub;
+            const bool act = mine && e.ytop <= ss && ss < e.ybot;
+            int cc = e.x1;
+            if (act && slanted) { int32_t q; int64_t rm; edge_x_at(e, ss, q, rm); cc = cell_of(q, rm, e.dy); }
+            const int dd = act ? e.dir : 0;
+            if (mine) { k_cc[tid] = cc; k_dd[tid] = dd; }
+            __syncthreads();
+            if (act) {
+                int wb = 0, gsum = dd; bool rep = true;
+                for (int i = 0; i < n; ++i) {
+                    const int di = k_dd[i];
+                    if (i == tid || di == 0) continue;           // dir is +-1 for an active edge
+                    const int ci = k_cc[i];
+                    if (ci < cc) wb += di;
+                    else if (ci == cc) { gsum += di; if (i < tid) rep = false; }
+                }
+                if (rep) {
+                    const bool in_b = ((unsigned)wb & mask) != 0, in_a = ((unsigned)(wb + gsum) & mask) != 0;
+                    if (in_a != in_b) {
+                        role |= (uint32_t)(in_a ? 1 : 2) << (2 * sub);
+                        const int col = (int)clamp_col(cc >> 8);
+                        clo = min(clo, col); chi = max(chi, col);
+                    }
+                }
+            }
+            __syncthreads();                                         // k_cc / k_dd are rewritten for the next sample row
+        }
+        cols = (uint32_t)clo | ((uint32_t)chi << 16);
+    }
+    // ---- records in path order: rank among the edges that carry a role
+    const bool has = mine && role != 0;
+    const unsigned long long hm = __ballot(has);
+    if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(hm);
+    __syncthreads();
+    if (has) {
+        uint32_t off = br.rec_base + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+        Rec rc;
+        if (role & REC_FULL) {
+            bool as_cells = false;
+            if (cell_mode & 1) as_cells = full_cells_ends(q1, r1, q2, r2, e.dy, (role & 1u) ? +1 : -1, rc);
+            if (!as_cells) {
+                rc.roles = role; rc.cols = cols; rc.eid = P.first_edge + k_mine; rc.dy = e.dy; rc.span = 0;
+                rc.q1 = q1; rc.r1 = r1; rc.q2 = q2; rc.r2 = r2;
+            }
+        } else rc = make_record(e, P.first_edge + k_mine, s0, role, cols);
+        records[off] = rc;
+    }
+    if (tid == 0) { ri.n_rec = (uint16_t)(wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3]); ri.mode = (uint16_t)mode; rows[t] = ri; }
+}
+
 // The row pass is one launch: the first n_big workgroups take the crowded rows (the longest wavefronts start first), the rest
 // take the chunks -- lane = row for crowded scenes (k_rows), lane = (row, slot) for scenes of a few tall paths (k_rows_rs).
 __global__ __launch_bounds__(64) void k_rows(const DevEdge* __restrict__ edges, const DevPath* __restrict__ paths,
@@ -1651,8 +1800,10 @@ void launch_rows(hipStream_t st, const DevEdge* edges, const DevPath* paths, con
                  uint32_t n_paths, RowInfo* rows, Rec* records, uint32_t* counters, const BigRow* big_rows, uint32_t n_big, uint32_t n_chunks,
                  uint32_t band_index, uint32_t band_count, int fast_limit, int cell_mode, uint32_t chunk_rows,
                  const BandSlot* band_slots, const uint32_t* band_off, uint8_t* cls_t, int width, int height, int fused,
-                 const swfr_edge* raw, const swfr_style* styles, BandEntry* band_list) {
+                 const swfr_edge* raw, const swfr_style* styles, BandEntry* band_list, const BigRow* huge_rows, uint32_t n_huge) {
     if (!n_chunks) return;
+    if (n_huge)
+        hipLaunchKernelGGL(k_rows_huge, dim3(n_huge), dim3(256), 0, st, edges, paths, row_base, huge_rows, n_huge, rows, records, counters, cell_mode);
     fast_limit = fast_limit < 0 ? 0 : (fast_limit > ROWS_FAST_N ? ROWS_FAST_N : fast_limit);
     if (chunk_rows <= 8)
         hipLaunchKernelGGL(k_rows_rs, dim3(n_chunks + n_big), dim3(64), 0, st, edges, paths, row_base, chunk_base, rows, records, band_index, band_count,

@@ -28,7 +28,7 @@ void launch_class(hipStream_t, const BandEntry*, uint32_t, const uint32_t*, uint
                   uint32_t, uint32_t);
 void launch_rows(hipStream_t, const DevEdge*, const DevPath*, const uint32_t*, const ChunkInfo*, uint32_t, RowInfo*, Rec*, uint32_t*, const BigRow*,
                  uint32_t, uint32_t, uint32_t, uint32_t, int, int, uint32_t, const BandSlot*, const uint32_t*, uint8_t*, int, int, int,
-                 const swfr_edge*, const swfr_style*, BandEntry*);
+                 const swfr_edge*, const swfr_style*, BandEntry*, const BigRow*, uint32_t);
 void launch_tiles(hipStream_t, const swfr_edge*, const uint32_t*, const BandEntry*, const uint8_t*, const RowInfo*, const Rec*, const swfr_style*,
                   Sources, uint32_t*, int, int, uint32_t, uint32_t, int, uint32_t*, uint32_t, uint32_t, bool, const uint32_t*);
 void launch_unpremultiply(hipStream_t, const uint32_t*, uint32_t*, size_t);
@@ -146,9 +146,9 @@ struct swfr_renderer {
         SceneArena arena;
         swfr_edge* raw = nullptr; DevPath* paths = nullptr; swfr_style* styles = nullptr;
         uint32_t *row_base = nullptr, *band_off = nullptr, *order = nullptr;
-        BigRow* big_rows = nullptr; BandSlot* band_slots = nullptr; ChunkInfo* chunk_base = nullptr;
+        BigRow *big_rows = nullptr, *huge_rows = nullptr; BandSlot* band_slots = nullptr; ChunkInfo* chunk_base = nullptr;
         DevFilter* filters = nullptr; int32_t* filter_params = nullptr;
-        size_t n_edges = 0, n_paths = 0, n_styles = 0, n_tasks = 0, n_chunks = 0, n_bands = 0, rec_cap = 0, rec_main = 0, n_big = 0,
+        size_t n_edges = 0, n_paths = 0, n_styles = 0, n_tasks = 0, n_chunks = 0, n_bands = 0, rec_cap = 0, rec_main = 0, n_big = 0, n_huge = 0,
                chunk_rows = 64, n_band_entries = 0;
         bool any_shader = false, fused_class = false, fused_front = false, has_order = false;
     };
@@ -313,6 +313,7 @@ int upload(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, size
     std::vector<ChunkInfo> chunks;                    // one k_rows workgroup each
     std::vector<uint32_t> chunk_cap;
     std::vector<BandSlot> band_slots;
+    std::vector<BigRow> huge_rows;                    // rows with more than 64 active edges: one 256-thread workgroup each
     std::vector<BigRow> big_rows;                     // rec_base holds the row's slot count until the prefix pass below
     std::vector<int32_t> active;
     const uint32_t bc = r->cfg.band_count > 1 ? r->cfg.band_count : 1, bi = r->cfg.band_count > 1 ? r->cfg.band_index : 0;
@@ -375,7 +376,8 @@ int upload(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, size
                 run += active[y];
                 const uint32_t band = (uint32_t(p.y_min) + y) / TILE_H;
                 if (bc > 1 && band % bc != bi) continue;          // another rank's tile-row: k_rows leaves it empty
-                if (run > limit) { big_rows.push_back(BigRow{uint32_t(i), int32_t(p.y_min) + int32_t(y), uint32_t(run), 0}); }
+                if (run > 64) huge_rows.push_back(BigRow{uint32_t(i), int32_t(p.y_min) + int32_t(y), uint32_t(run), 0});   // k_rows_huge (<= 256)
+                else if (run > limit) big_rows.push_back(BigRow{uint32_t(i), int32_t(p.y_min) + int32_t(y), uint32_t(run), 0});
                 else chunk_cap[c0 + (uint32_t(p.y_min) + y - chunk_a0) / chunk_rows] += uint32_t(run);
             }
         }
@@ -437,11 +439,13 @@ int upload(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, size
     sc.n_bands = n_bands;
     sc.rec_main = rec_cap;                            // chunk-owned region; the rows of k_rows_big own slots behind it
     for (auto& b : big_rows) { const uint32_t n = b.rec_base; b.rec_base = uint32_t(rec_cap); rec_cap += n; }
+    for (auto& b : huge_rows) { const uint32_t n = b.rec_base; b.rec_base = uint32_t(rec_cap); rec_cap += n; }
+    sc.n_huge = huge_rows.size();
     sc.rec_cap = rec_cap + 64;
     sc.n_big = big_rows.size();
     // the chunk workgroups of k_rows classify their own (tile, path) pairs when every row of the scene is theirs (no crowded
     // rows, no box paths, no other rank's tile-rows): k_class is then not launched at all
-    sc.fused_class = r->allow_fused && chunk_rows >= uint32_t(TILE_H) && big_rows.empty() && !any_boxes && bc == 1;
+    sc.fused_class = r->allow_fused && chunk_rows >= uint32_t(TILE_H) && big_rows.empty() && huge_rows.empty() && !any_boxes && bc == 1;
     // ... and when, besides, every path's edges fit the chunk staging area and every path has an area (so that every band entry
     // belongs to a chunk), the chunks also compute their edges' constants and write their band entries: k_front is not launched
     sc.fused_front = sc.fused_class && r->allow_fused > 1 && max_path_edges <= 64 && !any_flat;
@@ -471,7 +475,7 @@ int upload(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, size
         auto P = SceneArena::padded;
         A.begin(P(n_edges * sizeof(swfr_edge)) + P(n_paths * sizeof(swfr_path)) + P(n_styles * sizeof(swfr_style)) +
                 P((n_paths + 1) * sizeof(uint32_t)) + P(band_slots.size() * sizeof(BandSlot)) + P(order.size() * sizeof(uint32_t)) +
-                P(big_rows.size() * sizeof(BigRow)) + P(chunks.size() * sizeof(ChunkInfo)) + P((n_bands + 1) * sizeof(uint32_t)) +
+                P(big_rows.size() * sizeof(BigRow)) + P(huge_rows.size() * sizeof(BigRow)) + P(chunks.size() * sizeof(ChunkInfo)) + P((n_bands + 1) * sizeof(uint32_t)) +
                 P(n_styles * sizeof(DevFilter)) + P(fparams.size() * sizeof(int32_t)) + 4096);
         sc.raw = static_cast<swfr_edge*>(A.push(staged.data(), n_edges * sizeof(swfr_edge)));
         sc.paths = static_cast<DevPath*>(A.push(paths, n_paths * sizeof(swfr_path)));
@@ -480,6 +484,7 @@ int upload(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, size
         sc.band_slots = static_cast<BandSlot*>(A.push(band_slots.data(), band_slots.size() * sizeof(BandSlot)));
         sc.order = static_cast<uint32_t*>(A.push(order.data(), order.size() * sizeof(uint32_t)));
         sc.big_rows = static_cast<BigRow*>(A.push(big_rows.data(), big_rows.size() * sizeof(BigRow)));
+        sc.huge_rows = static_cast<BigRow*>(A.push(huge_rows.data(), huge_rows.size() * sizeof(BigRow)));
         sc.chunk_base = static_cast<ChunkInfo*>(A.push(chunks.data(), chunks.size() * sizeof(ChunkInfo)));
         sc.band_off = static_cast<uint32_t*>(A.push(band_off.data(), (n_bands + 1) * sizeof(uint32_t)));
         sc.filters = static_cast<DevFilter*>(A.push(filters.data(), n_styles * sizeof(DevFilter)));
@@ -512,7 +517,7 @@ void launch_frame(swfr_renderer* r, const swfr_renderer::Scene& sc, swfr_rendere
         launch_rows(st, F.d_edges.ptr, sc.paths, sc.row_base, sc.chunk_base, uint32_t(sc.n_paths), F.d_rows.ptr,
                     F.d_records.ptr, F.d_counters.ptr, sc.big_rows, uint32_t(sc.n_big), uint32_t(sc.n_chunks), bi, bc, r->fast_limit,
                     r->cell_mode, uint32_t(sc.chunk_rows), sc.band_slots, sc.band_off, F.d_cls.ptr, int(r->width), int(r->height),
-                    (sc.fused_class ? 1 : 0) | (sc.fused_front ? 2 : 0), sc.raw, sc.styles, F.d_band_list.ptr);
+                    (sc.fused_class ? 1 : 0) | (sc.fused_front ? 2 : 0), sc.raw, sc.styles, F.d_band_list.ptr, sc.huge_rows, uint32_t(sc.n_huge));
         if (!sc.fused_class)
             launch_class(st, F.d_band_list.ptr, uint32_t(sc.n_band_entries), sc.band_off, uint32_t(sc.n_bands), sc.raw,
                          F.d_rows.ptr, F.d_records.ptr, F.d_cls.ptr, int(r->width), int(r->height), bi, bc);
@@ -531,7 +536,7 @@ int check_counters(swfr_renderer* r, const uint32_t* counters) {
     }
     if (counters[CNT_ERROR]) {
         r->fb_valid = false;
-        return fail(r, SWFR_ERR_CAPACITY, "a pixel row has more than 64 active edges of one path (scan converter capacity)");
+        return fail(r, SWFR_ERR_CAPACITY, "a pixel row has more than 256 active edges of one path (scan converter capacity)");
     }
     return SWFR_OK;
 }

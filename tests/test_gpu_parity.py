@@ -307,15 +307,30 @@ def test_empty_ragged_and_tiny_frames():
         r.close()
 
 
+def _comb(teeth, width_twips):
+    pts = []
+    step = width_twips / teeth
+    for k in range(teeth):
+        pts += [(100 + step * k, 100), (100 + step * k + step / 2, 1900)]
+    pts += [(100 + width_twips + 100, 1950), (50, 1950)]
+    return scenarios._poly_shape(pts, {"type": "solid", "color": scenarios._rgba(1, 2, 3)})
+
+
+@pytest.mark.parametrize("teeth", [12, 40, 100])
+def test_crowded_rows_vs_oracle(teeth):
+    """Rows with 24, 80 and 200 active edges of one path: the crowded-row wavefronts (9..64 edges) and the 256-thread
+    workgroups of k_rows_huge (65..256) against the oracle, both fill rules."""
+    tag = _comb(teeth, 2000)
+    for eo in (False, True):
+        sc = dict(width=120, height=100, even_odd=eo, stage={"children": [{"type": "shape", "definition": tag}]})
+        assert diff_stats(product_render(sc), oracle_render(sc)) == (0, 0), (teeth, eo)
+
+
 def test_many_active_edges_fails_loudly_not_silently():
     import swf_renderer_amd as S
     from swf_renderer_amd import api
-    # a comb with 40 teeth: 80 edges are active in every row, beyond the per-row capacity of 32
-    pts = []
-    for k in range(40):
-        pts += [(100 + 50 * k, 100), (100 + 50 * k + 25, 1900)]
-    pts += [(2200, 1950), (50, 1950)]
-    tag = scenarios._poly_shape(pts, {"type": "solid", "color": scenarios._rgba(1, 2, 3)})
+    # a comb with 140 teeth: 280 edges are active in every row, beyond the per-row capacity of 256
+    tag = _comb(140, 2200)
     r = S.Renderer(120, 100)
     with pytest.raises(S.SwfrError) as e:
         r.render({"children": [{"type": "shape", "definition": tag}]})
