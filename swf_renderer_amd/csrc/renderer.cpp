@@ -233,7 +233,13 @@ uint32_t local_tile_rows(const swfr_renderer* r) {
 // Validate a caller-supplied scene so that no kernel can index out of bounds.
 void validate_scene(const swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_path* paths, size_t n_paths,
                     const swfr_style* styles, size_t n_styles) {
-    (void)edges;
+    // end points within +-32768 px (2^23 in 24.8): inside that range the int64 products of the closed-form edge evaluation cannot overflow
+    for (size_t i = 0; i < n_edges; ++i) {
+        const swfr_edge& e = edges[i];
+        const int32_t lim = 1 << 23;
+        if (e.x1 < -lim || e.x1 > lim || e.x2 < -lim || e.x2 > lim || e.y1 < -lim || e.y1 > lim || e.y2 < -lim || e.y2 > lim)
+            throw StatusError{SWFR_ERR_INVALID, "edge end point outside +-32768 px"};
+    }
     for (size_t i = 0; i < n_paths; ++i) {
         const swfr_path& p = paths[i];
         if (size_t(p.first_edge) + p.n_edges > n_edges) throw StatusError{SWFR_ERR_INVALID, "path edge range out of bounds"};
