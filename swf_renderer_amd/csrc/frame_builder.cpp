@@ -100,6 +100,8 @@ void FrameBuilder::trace(const StyledPath& p, bool morph, double ratio) {
     auto val = [&](const Coord& c) { return morph ? lerp(c.s, c.e, ratio) : c.s; };
     auto dev = [&](double x, double y) {
         ctm.apply(x, y);
+        // 24.8 device coordinates within +-32768 px: beyond that neither Cairo's fixed point nor the kernels' int64 products hold
+        if (!(std::fabs(x) <= 32768.0 && std::fabs(y) <= 32768.0)) throw StatusError{SWFR_ERR_INVALID, "geometry outside +-32768 device pixels"};
         return Pt{to_fixed(x), to_fixed(y)};
     };
     path_.clear();
