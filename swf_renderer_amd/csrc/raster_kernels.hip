@@ -805,23 +805,27 @@ __device__ __forceinline__ void big_row_body(uint32_t block, const DevEdge* __re
     }
     uint32_t mode = n == 0 ? ROW_EMPTY : (full ? ROW_FULL : ROW_SUB);
     if (n > 0 && !full) {
-        // ---- SUB row: fifteen sample rows; per sample the lanes rank their cells against each other
+        // ---- SUB row: fifteen sample rows.  With at most 16 (32) active edges the wavefront works on four (two) sample rows at
+        //      a time: lane = (sample row group g, edge je); the cells of a sample row are ranked inside its lane group by shuffles
+        const int W = n <= 16 ? 16 : (n <= 32 ? 32 : 64), G = 64 / W;      // wave-uniform
+        const int g = lane / W, je = lane - g * W;
+        const bool mine_s = je < n;
+        const DevEdge es = E[active[mine_s ? je : 0]];
+        const bool slanted_s = es.dy != 0;
         int clo = 65535, chi = 0;
-        for (int sub = 0; sub < 15; ++sub) {
-            const int ss = s0 + sub;
-            const bool act = mine && e.ytop <= ss && ss < e.ybot;
-            int cc = e.x1;
-            if (act && slanted) { int32_t q; int64_t rm; edge_x_at(e, ss, q, rm); cc = cell_of(q, rm, e.dy); }
-            const int dd = act ? e.dir : 0;
-            const unsigned long long am = __ballot(act);
+        for (int p = 0; p * G < 15; ++p) {
+            const int sub = p * G + g, ss = s0 + sub;
+            const bool act = mine_s && sub < 15 && es.ytop <= ss && ss < es.ybot;
+            int cc = es.x1;
+            if (act && slanted_s) { int32_t q; int64_t rm; edge_x_at(es, ss, q, rm); cc = cell_of(q, rm, es.dy); }
+            const int dd = act ? es.dir : 0;                            // +-1 on an active edge, 0 otherwise
             int wb = 0, gsum = dd; bool rep = true;
-            unsigned long long m = am;
-            while (m) {                                       // wave-uniform: the active lanes of this sample row
-                const int i = __ffsll((long long)m) - 1; m &= m - 1;
-                const int ci = __builtin_amdgcn_readlane(cc, i), di = __builtin_amdgcn_readlane(dd, i);
-                if (i == lane) continue;
+            for (int i = 0; i < n; ++i) {                               // wave-uniform; every lane takes part in the shuffles
+                const int src = g * W + i;
+                const int ci = __shfl(cc, src), di = __shfl(dd, src);
+                if (!act || i == je || di == 0) continue;
                 if (ci < cc) wb += di;
-                else if (ci == cc) { gsum += di; if (i < lane) rep = false; }
+                else if (ci == cc) { gsum += di; if (i < je) rep = false; }
             }
             if (act && rep) {
                 const bool in_b = ((unsigned)wb & mask) != 0, in_a = ((unsigned)(wb + gsum) & mask) != 0;
@@ -831,6 +835,12 @@ __device__ __forceinline__ void big_row_body(uint32_t block, const DevEdge* __re
                     clo = min(clo, col); chi = max(chi, col);
                 }
             }
+        }
+        // the sample rows of an edge were spread over the lane groups: OR / min / max them back together (lane je of group 0 == lane je)
+        for (int off = W; off < 64; off <<= 1) {
+            role |= (uint32_t)__shfl_xor((int)role, off);
+            clo = min(clo, __shfl_xor(clo, off));
+            chi = max(chi, __shfl_xor(chi, off));
         }
         cols = (uint32_t)clo | ((uint32_t)chi << 16);
     }
