@@ -125,3 +125,52 @@ def pixelmatch_count(a, b, threshold=0.05):
             if not (_pm_antialiased(a, x, y, b) or _pm_antialiased(b, x, y, a)):
                 n += 1
     return n
+
+
+# ---- the Rust decoder's golden format (rs/src/decoder/shape_decoder.rs: `format!("{:#?}\n", shape)` of Shape { paths:
+#      Vec<StyledPath { path: lyon Path, fill: Option<FillStyle>, line: Option<LineStyle> }> }, rs/src/lib.rs:26-71)
+def shape_to_rs_log(decoded: dict, ast: dict) -> str:
+    """Pretty Debug text of the Rust `Shape` for a decoded shape (the product's swfr_shape_json output, straight lines and
+    solid styles only, as in the three fixtures the Rust test holds); line-style attributes the TS form drops come from the AST."""
+    def ind(n):
+        return "    " * n
+
+    def solid(color, n):
+        c = [int(round(color[k] * 255)) for k in "rgba"]
+        return [ind(n) + "Solid(", ind(n + 1) + "Solid {", ind(n + 2) + "color: StraightSRgba8 {",
+                ind(n + 3) + "r: %d," % c[0], ind(n + 3) + "g: %d," % c[1], ind(n + 3) + "b: %d," % c[2], ind(n + 3) + "a: %d," % c[3],
+                ind(n + 2) + "},", ind(n + 1) + "},", ind(n) + "),"]
+
+    out = ["Shape {", ind(1) + "paths: ["]
+    for p in decoded["paths"]:
+        pts, verbs = [], []
+        for c in p["commands"]:
+            if c["type"] == 2:
+                pts.append((c["x"], c["y"])); verbs.append("MoveTo")
+            elif c["type"] == 0:
+                pts.append((c["endX"], c["endY"])); verbs.append("LineTo")
+            else:
+                raise ValueError("the Rust decoder of the reference handles straight edges only")
+        out += [ind(2) + "StyledPath {", ind(3) + "path: Path {", ind(4) + "points: ["]
+        out += [ind(5) + "(%.1f,%.1f)," % (x, y) for x, y in pts]
+        out += [ind(4) + "],", ind(4) + "verbs: ["]
+        out += [ind(5) + v + "," for v in verbs]
+        out += [ind(4) + "],", ind(3) + "},"]
+        if "fill" in p:
+            out += [ind(3) + "fill: Some("] + solid(p["fill"]["color"], 4) + [ind(3) + "),"]
+        else:
+            out.append(ind(3) + "fill: None,")
+        if "line" in p:
+            ls = next(l for l in ast["shape"]["initial_styles"]["line"] if l["width"] == p["line"]["width"])
+            cap = lambda v: v.capitalize()
+            out += [ind(3) + "line: Some(", ind(4) + "LineStyle {", ind(5) + "width: %d," % ls["width"],
+                    ind(5) + "start_cap: %s," % cap(ls["start_cap"]), ind(5) + "end_cap: %s," % cap(ls["end_cap"]),
+                    ind(5) + "join: %s," % cap(ls["join"]["type"])]
+            out += [ind(5) + "%s: %s," % (k, "true" if ls[k] else "false") for k in ("no_h_scale", "no_v_scale", "no_close", "pixel_hinting")]
+            out += [ind(5) + "fill: " + solid(p["line"]["fill"]["color"], 5)[0].strip()] + solid(p["line"]["fill"]["color"], 5)[1:]
+            out += [ind(4) + "},", ind(3) + "),"]
+        else:
+            out.append(ind(3) + "line: None,")
+        out.append(ind(2) + "},")
+    out += [ind(1) + "],", "}"]
+    return "\n".join(out) + "\n"

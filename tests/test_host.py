@@ -48,6 +48,16 @@ def test_decode_shape_json_golden(name):
     assert r.shape_json(sid) == fixture_text(name + ".shape.ts.json")
 
 
+@pytest.mark.parametrize("name", ["squares", "triangle", "homestuck-beta-1"])
+def test_decode_shape_rust_golden(name):
+    """The reference's Rust decoder golden (tests/flat-shapes/*/shape.rs.log, rs/src/lib.rs:26-71), string-exact."""
+    import json
+    from helpers import shape_to_rs_log
+    r = S.Renderer(8, 8, device=api.DEVICE_HOST_ONLY)
+    sid = r.register_shape(fixture(name))
+    assert shape_to_rs_log(json.loads(r.shape_json(sid)), fixture(name)) == fixture_text(name + ".shape.rs.log")
+
+
 def test_decode_morph_shape_json_golden():
     r = S.Renderer(8, 8, device=api.DEVICE_HOST_ONLY)
     sid = r.register_morph_shape(fixture("homestuck-beta-29"))

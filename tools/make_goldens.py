@@ -42,6 +42,8 @@ def ref_pngs():
     for d, n in (("flat-shapes", "squares"), ("flat-shapes", "triangle"), ("flat-shapes", "homestuck-beta-1"),
                  ("textured-shapes", "homestuck-beta-4"), ("flat-morph-shapes", "homestuck-beta-29")):
         shutil.copyfile(os.path.join(REF, d, n, "shape.ts.json"), os.path.join(fx, n + ".shape.ts.json"))
+    for n in ("squares", "triangle", "homestuck-beta-1"):     # the Rust decoder's goldens (rs/src/lib.rs:26-71)
+        shutil.copyfile(os.path.join(REF, "flat-shapes", n, "shape.rs.log"), os.path.join(fx, n + ".shape.rs.log"))
     shutil.copyfile(os.path.join(REF, "bitmap", "homestuck-beta-3.pam"), os.path.join(fx, "homestuck-beta-3.pam"))
     for f in os.listdir(fx):
         os.chmod(os.path.join(fx, f), 0o644)
