@@ -178,7 +178,9 @@ enum { SWFR_STYLE_SOLID = 0, SWFR_STYLE_RADIAL = 1, SWFR_STYLE_LINEAR = 2, SWFR_
 typedef struct {
     uint32_t kind;                       /* SWFR_STYLE_* */
     uint32_t pixel;                      /* solid: premultiplied 0xAARRGGBB */
-    double inv[6];                       /* device -> pattern space (xx, yx, xy, yy, x0, y0) */
+    double inv[6];                       /* device -> pattern space (xx, yx, xy, yy, x0, y0): Cairo's pattern matrix.  A bitmap
+                                            style belongs to one drawing operation: pixman's 16.16 transform is anchored at the
+                                            centre of the operation's pixel rectangle, so paths sharing it must share x_min..y_max */
     double c0x, c0y, r0, c1x, c1y, r1;   /* radial (linear: c0 -> c1) */
     uint32_t n_stops;
     float stop_offset[SWFR_MAX_STOPS];

@@ -24,6 +24,7 @@
 #include <string.h>
 #include <math.h>
 #include <limits.h>
+#include <float.h>
 
 #define EXPORT __attribute__((visibility("default")))
 
@@ -77,6 +78,21 @@ static int mat_invert(mat_t *m)
     r.x0 = (m->xy * m->y0 - m->yy * m->x0) / det;
     r.y0 = (m->yx * m->x0 - m->xx * m->y0) / det;
     *m = r;
+    return 1;
+}
+/* cairo_matrix_invert, operation by operation (the pattern matrix is rounded to 16.16 afterwards, so the order matters in principle) */
+static int mat_invert_cairo(mat_t *m)
+{
+    if (m->xy == 0. && m->yx == 0.) {
+        m->x0 = -m->x0; m->y0 = -m->y0;
+        if (m->xx != 1.) { if (m->xx == 0.) return 0; m->xx = 1. / m->xx; m->x0 *= m->xx; }
+        if (m->yy != 1.) { if (m->yy == 0.) return 0; m->yy = 1. / m->yy; m->y0 *= m->yy; }
+        return 1;
+    }
+    double det = mat_det(m);
+    if (det == 0 || !isfinite(det)) return 0;
+    const double a = m->xx, b = m->yx, cc = m->xy, d = m->yy, tx = m->x0, ty = m->y0, k = 1 / det;
+    m->xx = d * k; m->yx = -b * k; m->xy = -cc * k; m->yy = a * k; m->x0 = (cc * ty - d * tx) * k; m->y0 = (b * tx - a * ty) * k;
     return 1;
 }
 static int mat_is_identity(const mat_t *m)
@@ -990,12 +1006,66 @@ typedef struct {
     /* SURFACE, CAIRO_FILTER_GOOD when it is not downgraded to bilinear: pixman separable convolution tables */
     int good, cw, ch, xbits, ybits;
     int32_t *xpar, *ypar;                    /* (1 << bits) phases x width taps, 16.16 */
+    /* SURFACE: what pixman is given for one drawing operation (source_prepare_pixman): 16.16 transform + integer offset */
+    int64_t pm[2][3]; int pox, poy;
 } source_t;
 
+/* ---- the pattern matrix as pixman gets it (cairo-matrix.c _cairo_matrix_to_pixman_matrix_offset, cairo-image-source.c
+        _pixman_image_set_properties): an integer translation is split off so that what remains is small, the matrix is rounded
+        to 16.16 (ties to even) and its translation is then corrected so that the centre of the operation's rectangle maps where
+        the double matrix would put it.  x0..y1 is that rectangle (bounded extents of the fill / stroke, in pixels). */
+static int32_t f16_from_double(double d) { return (int32_t)(int64_t)nearbyint(d * 65536.0); }
+static void source_prepare_pixman(source_t *s, int x0, int y0, int x1, int y1)
+{
+    mat_t m = s->inv;
+    const double xc = x0 + (x1 - x0) / 2., yc = y0 + (y1 - y0) / 2.;
+    s->pox = s->poy = 0;
+    if (m.x0 != 0.0 || m.y0 != 0.0) {
+        /* spread the offset between the integer part and the matrix: solutions of |x| = |x*xx + y*xy + x0|, |y| = |...| */
+        double tx = m.x0, ty = m.y0, norm = fmax(fabs(tx), fabs(ty));
+        for (int i = -1; i < 2; i += 2)
+            for (int j = -1; j < 2; j += 2) {
+                double den = (m.xx + i) * (m.yy + j) - m.xy * m.yx;
+                if (fabs(den) < DBL_EPSILON) continue;
+                double x = m.y0 * m.xy - m.x0 * (m.yy + j), y = m.x0 * m.yx - m.y0 * (m.xx + i);
+                den = 1 / den; x *= den; y *= den;
+                double new_norm = fmax(fabs(x), fabs(y));
+                if (norm > new_norm) { norm = new_norm; tx = x; ty = y; }
+            }
+        tx = floor(tx); ty = floor(ty);
+        s->pox = (int)-tx; s->poy = (int)-ty;
+        mat_t t = { 1, 0, 0, 1, tx, ty };
+        mat_multiply(&m, &t, &m);                                   /* cairo_matrix_translate */
+    }
+    s->pm[0][0] = f16_from_double(m.xx); s->pm[0][1] = f16_from_double(m.xy); s->pm[0][2] = f16_from_double(m.x0);
+    s->pm[1][0] = f16_from_double(m.yx); s->pm[1][1] = f16_from_double(m.yy); s->pm[1][2] = f16_from_double(m.y0);
+    if (mat_has_unity_scale(&m)) return;
+    mat_t inv = m;
+    if (!mat_invert_cairo(&inv)) return;
+    for (int it = 0; it < 5; it++) {
+        const int64_t vx = f16_from_double(xc), vy = f16_from_double(yc);
+        double x = (double)((s->pm[0][0] * vx + s->pm[0][1] * vy + s->pm[0][2] * 65536 + 0x8000) >> 16) / 65536.0;
+        double y = (double)((s->pm[1][0] * vx + s->pm[1][1] * vy + s->pm[1][2] * 65536 + 0x8000) >> 16) / 65536.0;
+        mat_point(&inv, &x, &y);
+        x -= xc; y -= yc;
+        mat_distance(&m, &x, &y);
+        const int32_t dx = f16_from_double(x), dy = f16_from_double(y);
+        s->pm[0][2] -= dx; s->pm[1][2] -= dy;
+        if (dx == 0 && dy == 0) break;
+    }
+}
+/* pixman's sample position of destination pixel (px, py), 16.16 (pixman_transform_point_3d of the pixel centre; stepping along
+   the scanline by the matrix column is exact, so every pixel can be evaluated by itself) */
+static void source_pixman_position(const source_t *s, int px, int py, int64_t *vx, int64_t *vy)
+{
+    const int64_t X = ((int64_t)(px + s->pox) << 16) + 0x8000, Y = ((int64_t)(py + s->poy) << 16) + 0x8000;
+    *vx = (s->pm[0][0] * X + s->pm[0][1] * Y + s->pm[0][2] * 65536 + 0x8000) >> 16;
+    *vy = (s->pm[1][0] * X + s->pm[1][1] * Y + s->pm[1][2] * 65536 + 0x8000) >> 16;
+}
+
 /* ---- CAIRO_FILTER_GOOD for surface patterns (cairo-pattern.c _cairo_pattern_analyze_filter, cairo-image-source.c
-        create_separable_convolution, pixman bits_image_fetch_pixel_separable_convolution).  The sample position is taken
-        from the double-precision pattern matrix (pixman rounds its matrix to 16.16 first), so single pixels can differ from
-        libcairo by an LSB or two where a phase boundary is hit; the tables and the accumulation are pixman's integers. */
+        create_separable_convolution, pixman bits_image_fetch_pixel_separable_convolution): pixman's integer tables and
+        accumulation at pixman's own 16.16 sample positions. */
 static double good_box_kernel(double x, double r) { return fmax(0.0, fmin(fmin(r, 1.0), fmin((r + 1) / 2 - x, (r + 1) / 2 + x))); }
 static int good_box_width(double r) { return r < 1.0 ? 2 : (int)ceil(r + 1); }
 static void good_get_filter(double r, int width, int subsample, int32_t *out)
@@ -1044,9 +1114,8 @@ static void source_setup_filter(source_t *s)
     good_get_filter(dy, s->ch, s->ybits, s->ypar);
     s->good = 1;
 }
-static uint32_t sample_good(const source_t *s, double u, double v)
+static uint32_t sample_good(const source_t *s, int64_t x, int64_t y)
 {
-    int64_t x = (int64_t)floor(u * 65536.0), y = (int64_t)floor(v * 65536.0);
     const int xsh = 16 - s->xbits, ysh = 16 - s->ybits;
     const int64_t x_off = (((int64_t)s->cw << 16) - 65536) >> 1, y_off = (((int64_t)s->ch << 16) - 65536) >> 1;
     /* round to the middle of the closest phase */
@@ -1078,7 +1147,7 @@ static uint32_t sample_good(const source_t *s, double u, double v)
 }
 
 typedef struct {
-    mat_t ctm; double line_width; int cap, join; double miter_limit; int fill_rule;
+    mat_t ctm, ctm_inverse; double line_width; int cap, join; double miter_limit; int fill_rule;
 } gstate_t;
 
 typedef struct swfo_ctx {
@@ -1163,7 +1232,7 @@ static uint32_t gradient_color(const source_t *s, double t)
 static uint32_t sample_source(const source_t *s, int px, int py)
 {
     double x = px + 0.5, y = py + 0.5;
-    mat_point(&s->inv, &x, &y);
+    if (s->kind != SRC_SURFACE) mat_point(&s->inv, &x, &y);
     if (s->kind == SRC_RADIAL) {
         /* |p - c(t)| = r(t), larger root, PAD extend */
         double cdx = s->cx1 - s->cx0, cdy = s->cy1 - s->cy0, dr = s->r1 - s->r0;
@@ -1188,11 +1257,13 @@ static uint32_t sample_source(const source_t *s, int px, int py)
         if (t < 0) t = 0; if (t > 1) t = 1;
         return gradient_color(s, t);
     }
-    if (s->good) return sample_good(s, x, y);
+    int64_t fxp, fyp;
+    source_pixman_position(s, px, py, &fxp, &fyp);
+    if (s->good) return sample_good(s, fxp, fyp);
     /* SRC_SURFACE: bilinear (7-bit weights) -- what CAIRO_FILTER_GOOD becomes for scales > .75 */
-    double u = x - 0.5, v = y - 0.5;
-    int x0 = (int)floor(u), y0 = (int)floor(v);
-    int wx = (int)floor((u - x0) * 128.0), wy = (int)floor((v - y0) * 128.0);
+    fxp -= 0x8000; fyp -= 0x8000;
+    int x0 = (int)(fxp >> 16), y0 = (int)(fyp >> 16);
+    int wx = (int)((fxp >> 9) & 0x7f), wy = (int)((fyp >> 9) & 0x7f);
     uint32_t c[4];
     for (int k = 0; k < 4; k++) {
         int xx = x0 + (k & 1), yy = y0 + (k >> 1);
@@ -1537,9 +1608,10 @@ static void boxes_render(swfo_ctx *c, const polygon_t *g, int even_odd, int lerp
     qsort(ys, 2 * n, sizeof(fx_t), cmp_fx);
     qsort(ve, n, sizeof(vedge_t), cmp_vedge);
     int px0 = fx_floor_i(g->x1.x), px1 = fx_ceil_i(g->x2.x), py0 = fx_floor_i(g->x1.y), py1 = fx_ceil_i(g->x2.y);
-    if (px0 < 0) px0 = 0; if (py0 < 0) py0 = 0; if (px1 > c->w) px1 = c->w; if (py1 > c->h) py1 = c->h;
+    if (px0 < c->bx0) px0 = c->bx0; if (py0 < c->by0) py0 = c->by0; if (px1 > c->bx1) px1 = c->bx1; if (py1 > c->by1) py1 = c->by1;
     int bw = px1 - px0, bh = py1 - py0;
     if (bw <= 0 || bh <= 0) { free(ve); free(ys); return; }
+    if (c->src.kind == SRC_SURFACE) source_prepare_pixman(&c->src, px0, py0, px1, py1);
     uint32_t *acc = calloc((size_t)bw * bh, sizeof(uint32_t));
     unsigned mask = even_odd ? 1u : ~0u;
     for (int s = 0; s + 1 < 2 * n; s++) {
@@ -1593,8 +1665,34 @@ static int op_bounds(swfo_ctx *c, pt_t e1, pt_t e2, int *needs_limits)
         return 0;
     }
     int x0 = fx_floor_i(e1.x), y0 = fx_floor_i(e1.y), x1 = fx_ceil_i(e2.x), y1 = fx_ceil_i(e2.y);
-    *needs_limits = !(x0 >= 0 && y0 >= 0 && x1 <= c->w && y1 <= c->h);
+    const int mw = x1 - x0, mh = y1 - y0;                  /* the mask extents */
     if (x0 < 0) x0 = 0; if (y0 < 0) y0 = 0; if (x1 > c->w) x1 = c->w; if (y1 > c->h) y1 = c->h;
+    if (c->src.kind == SRC_SURFACE && c->src.extend == 0) {
+        /* OVER is bounded by its source: _cairo_pattern_get_extents of an EXTEND_NONE surface pattern -- the surface rectangle,
+           mapped to device space; an axis the filter magnifies is padded by half a source pixel and rounded to the nearest
+           pixel edge, the others are rounded out (probe-validated against libcairo 1.16.0) */
+        const mat_t *pm = &c->src.inv;
+        double sx0 = 0, sy0 = 0, sx1 = c->src.tw, sy1 = c->src.th;
+        int round_x = 0, round_y = 0;
+        if (hypot(pm->xx, pm->yx) < 1.0) { sx0 -= 0.5; sx1 += 0.5; round_x = 1; }
+        if (hypot(pm->xy, pm->yy) < 1.0) { sy0 -= 0.5; sy1 += 0.5; round_y = 1; }
+        mat_t im = *pm;
+        if (mat_invert_cairo(&im)) {
+            double bx0 = 0, by0 = 0, bx1 = 0, by1 = 0;
+            for (int k = 0; k < 4; k++) {
+                double x = (k & 1) ? sx1 : sx0, y = (k & 2) ? sy1 : sy0;
+                mat_point(&im, &x, &y);
+                if (!k || x < bx0) bx0 = x; if (!k || x > bx1) bx1 = x;
+                if (!k || y < by0) by0 = y; if (!k || y > by1) by1 = y;
+            }
+            if (!round_x) { bx0 -= 0.5; bx1 += 0.5; }
+            if (!round_y) { by0 -= 0.5; by1 += 0.5; }
+            bx0 = floor(bx0 + 0.5); by0 = floor(by0 + 0.5); bx1 = floor(bx1 + 0.5); by1 = floor(by1 + 0.5);
+            if (x0 < bx0) x0 = (int)bx0; if (y0 < by0) y0 = (int)by0;
+            if (x1 > bx1) x1 = (int)bx1; if (y1 > by1) y1 = (int)by1;
+        }
+    }
+    *needs_limits = mw > x1 - x0 || mh > y1 - y0;
     /* the operation is bounded by this rectangle: geometry the stroker produces outside it (a round join that fell
        through to a miter at a closing corner) is not painted */
     c->bx0 = x0; c->by0 = y0; c->bx1 = x1; c->by1 = y1;
@@ -1627,6 +1725,7 @@ static void render_polygon(swfo_ctx *c, polygon_t *g, int even_odd)
     int xmin = fx_floor_i(g->x1.x), xmax = fx_ceil_i(g->x2.x), ymin = fx_floor_i(g->x1.y), ymax = fx_ceil_i(g->x2.y);
     if (xmin < c->bx0) xmin = c->bx0; if (ymin < c->by0) ymin = c->by0; if (xmax > c->bx1) xmax = c->bx1; if (ymax > c->by1) ymax = c->by1;
     if (xmin >= xmax || ymin >= ymax) return;
+    if (c->src.kind == SRC_SURFACE) source_prepare_pixman(&c->src, xmin, ymin, xmax, ymax);
     tor_render(c, g, even_odd, lerp_mode, xmin, ymin, xmax, ymax);
 }
 
@@ -1639,7 +1738,7 @@ EXPORT int swfo_fill_preserve(swfo_ctx *c)
     if (source_is_clear(&c->src)) return 0;               /* OVER with a clear source: no-op */
     if (!p->has_extents || !op_bounds(c, p->e1, p->e2, &needs_limits)) return 0;   /* NOTHING_TO_DO */
     polygon_t g; memset(&g, 0, sizeof(g));
-    pt_t l1 = { 0, 0 }, l2 = { c->w * 256, c->h * 256 };
+    pt_t l1 = { c->bx0 * 256, c->by0 * 256 }, l2 = { c->bx1 * 256, c->by1 * 256 };   /* the limits are the unbounded rectangle */
     polygon_init(&g, needs_limits, l1, l2);
     path_fill_to_polygon(p, 0.1, &g);
     remember_polygon(c, &g, path_fill_is_rectilinear(p));
@@ -1721,7 +1820,7 @@ EXPORT swfo_ctx *swfo_create(int w, int h)
 {
     swfo_ctx *c = calloc(1, sizeof(*c));
     c->w = w; c->h = h; c->px = calloc((size_t)w * h, 4); c->is_clear = 1;
-    c->ngs = 1; mat_identity(&c->gs[0].ctm);
+    c->ngs = 1; mat_identity(&c->gs[0].ctm); mat_identity(&c->gs[0].ctm_inverse);
     c->gs[0].line_width = 2.0; c->gs[0].miter_limit = 10.0; c->gs[0].cap = 0; c->gs[0].join = 0; c->gs[0].fill_rule = 0;
     path_reset(&c->path);
     c->src.kind = SRC_SOLID; c->src.pixel = 0xff000000u;
@@ -1736,13 +1835,24 @@ EXPORT void swfo_destroy(swfo_ctx *c)
 }
 EXPORT void swfo_save(swfo_ctx *c) { if (c->ngs < 64) { c->gs[c->ngs] = c->gs[c->ngs - 1]; c->ngs++; } }
 EXPORT void swfo_restore(swfo_ctx *c) { if (c->ngs > 1) c->ngs--; }
-EXPORT void swfo_identity_matrix(swfo_ctx *c) { mat_identity(&c->gs[c->ngs - 1].ctm); }
+EXPORT void swfo_identity_matrix(swfo_ctx *c) { mat_identity(&c->gs[c->ngs - 1].ctm); mat_identity(&c->gs[c->ngs - 1].ctm_inverse); }
+/* _cairo_gstate_transform / _cairo_gstate_scale: the inverse is kept beside the CTM and updated factor by factor */
 EXPORT void swfo_transform(swfo_ctx *c, double xx, double yx, double xy, double yy, double x0, double y0)
 {
-    mat_t m = { xx, yx, xy, yy, x0, y0 };
-    mat_multiply(&c->gs[c->ngs - 1].ctm, &m, &c->gs[c->ngs - 1].ctm);
+    gstate_t *gs = &c->gs[c->ngs - 1];
+    mat_t m = { xx, yx, xy, yy, x0, y0 }, t = m;
+    if (!mat_invert_cairo(&t)) return;                      /* CAIRO_STATUS_INVALID_MATRIX: the call is ignored */
+    mat_multiply(&gs->ctm, &m, &gs->ctm);
+    mat_multiply(&gs->ctm_inverse, &gs->ctm_inverse, &t);
 }
-EXPORT void swfo_scale(swfo_ctx *c, double sx, double sy) { swfo_transform(c, sx, 0, 0, sy, 0, 0); }
+EXPORT void swfo_scale(swfo_ctx *c, double sx, double sy)
+{
+    gstate_t *gs = &c->gs[c->ngs - 1];
+    if (sx * sy == 0. || !isfinite(sx) || !isfinite(sy)) return;
+    mat_t m = { sx, 0, 0, sy, 0, 0 }, t = { 1 / sx, 0, 0, 1 / sy, 0, 0 };
+    mat_multiply(&gs->ctm, &m, &gs->ctm);
+    mat_multiply(&gs->ctm_inverse, &gs->ctm_inverse, &t);
+}
 EXPORT void swfo_clear_all(swfo_ctx *c) { memset(c->px, 0, (size_t)c->w * c->h * 4); c->is_clear = 1; }
 EXPORT void swfo_new_path(swfo_ctx *c) { path_reset(&c->path); }
 EXPORT void swfo_move_to(swfo_ctx *c, double x, double y)
@@ -1788,8 +1898,7 @@ EXPORT void swfo_set_source_rgba(swfo_ctx *c, double r, double g, double b, doub
 static void lock_pattern_matrix(swfo_ctx *c)
 {
     /* the pattern space is the user space at set_source time: device -> pattern = CTM^-1 */
-    c->src.inv = c->gs[c->ngs - 1].ctm;
-    if (!mat_invert(&c->src.inv)) mat_identity(&c->src.inv);
+    c->src.inv = c->gs[c->ngs - 1].ctm_inverse;
 }
 EXPORT void swfo_set_source_gradient(swfo_ctx *c, int linear, double x0, double y0, double r0, double x1, double y1, double r1,
                                      int nstops, const double *offsets, const double *rgba)

@@ -104,10 +104,17 @@ struct DevBitmap {
 
 // CAIRO_FILTER_GOOD of a bitmap style when Cairo does not downgrade it to bilinear (minification below 0.75): pixman's
 // separable convolution.  x_off / y_off index the handle's table of 16.16 weights: (1 << bits) phases x width taps.
+// Every bitmap style also carries pixman's sample position: the pattern matrix rounded to 16.16 and anchored at the centre of the
+// drawing operation's rectangle (host: pixman_transform_of).  Position of destination pixel (px, py), 16.16:
+// base + px * (m00, m10) + py * (m01, m11) -- exactly what pixman_transform_point_3d gives for the pixel centre.
 struct DevFilter {
     int32_t on, cw, ch, xbits, ybits;
-    uint32_t x_off, y_off, pad;
+    uint32_t x_off, y_off;
+    int32_t m00, m01, m10, m11;
+    int32_t pad;
+    int64_t base_x, base_y;
 };
+static_assert(sizeof(DevFilter) == 64, "DevFilter layout");
 
 // what the shader needs besides the style itself
 struct Sources {

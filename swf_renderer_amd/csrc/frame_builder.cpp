@@ -62,6 +62,7 @@ void FrameBuilder::build(const swfr_stage& stage) {
     surface_clear_ = true;  // clearRect over the whole canvas (canvas-renderer.ts:70-71)
     State s;
     s.ctm = Affine::scale(1.0 / 20.0, 1.0 / 20.0);  // twips -> px (:74)
+    s.inv = Affine::scale(1.0 / (1.0 / 20.0), 1.0 / (1.0 / 20.0));  // cairo_scale: ctm_inverse *= scale(1/sx, 1/sy)
     stack_.push_back(s);
     for (uint32_t i = 0; i < stage.n_children; ++i) draw(stage.children[i], 0);
 }
@@ -73,7 +74,7 @@ void FrameBuilder::draw(const swfr_display_object& obj, int depth) {
         std::vector<State>& s;
         ~Pop() { s.pop_back(); }
     } pop{stack_};
-    if (obj.has_matrix) stack_.back().ctm = matrix_of(obj.matrix).then(stack_.back().ctm);
+    if (obj.has_matrix) transform(matrix_of(obj.matrix));  // a singular matrix puts Cairo's context in an error state; here it is ignored
     switch (obj.type) {
         case SWFR_OBJECT_CONTAINER:
             for (uint32_t i = 0; i < obj.n_children; ++i) draw(obj.children[i], depth + 1);
@@ -93,6 +94,15 @@ void FrameBuilder::draw(const swfr_display_object& obj, int depth) {
         default:
             throw StatusError{SWFR_ERR_INVALID, "UnexpectedDisplayObjectType"};
     }
+}
+
+bool FrameBuilder::transform(const Affine& m) {
+    Affine t = m;
+    if (!t.invert_cairo()) return false;
+    State& st = stack_.back();
+    st.ctm = m.then(st.ctm);
+    st.inv = st.inv.then(t);
+    return true;
 }
 
 void FrameBuilder::trace(const StyledPath& p, bool morph, double ratio) {
@@ -206,8 +216,10 @@ void FrameBuilder::emit_fill(const OwnedFill& f, bool morph, double ratio) {
         swfr_style st;
         std::memset(&st, 0, sizeof st);
         st.kind = SWFR_STYLE_BITMAP;
-        Affine inv = matrix_of(s.matrix).then(stack_.back().ctm);
-        if (!inv.invert()) return;
+        // context.save(); transform(fill.matrix): the pattern matrix is the inverse CTM at fill() time
+        Affine fm = matrix_of(s.matrix);
+        if (!fm.invert_cairo()) return;
+        const Affine inv = stack_.back().inv.then(fm);
         const double m[6] = {inv.xx, inv.yx, inv.xy, inv.yy, inv.x0, inv.y0};
         std::memcpy(st.inv, m, sizeof m);
         st.bitmap = s.bitmap_id;
@@ -222,8 +234,9 @@ void FrameBuilder::emit_fill(const OwnedFill& f, bool morph, double ratio) {
         if (f.stops.size() > SWFR_MAX_STOPS) throw StatusError{SWFR_ERR_CAPACITY, "too many gradient stops"};
         swfr_style st;
         std::memset(&st, 0, sizeof st);
-        Affine inv = matrix_of(s.matrix).then(stack_.back().ctm);
-        if (!inv.invert()) return;
+        Affine fm = matrix_of(s.matrix);
+        if (!fm.invert_cairo()) return;
+        const Affine inv = stack_.back().inv.then(fm);
         const double m[6] = {inv.xx, inv.yx, inv.xy, inv.yy, inv.x0, inv.y0};
         std::memcpy(st.inv, m, sizeof m);
         const double R = 16384.0;
@@ -252,13 +265,54 @@ void FrameBuilder::emit_fill(const OwnedFill& f, bool morph, double ratio) {
         style_index = uint32_t(styles_.size() - 1);
     }
     if (path_.empty_extents()) return;
-    bool needs_clip = false;
-    if (!frame_bounds(path_.box_min(), path_.box_max(), needs_clip)) return;  // nothing to do: surface stays clear
+    // the operation's bounded rectangle: path extents rounded out (the mask), inside the frame, inside the source's extents
+    const Pt plo = path_.box_min(), phi = path_.box_max();
+    if (!(plo.x < phi.x && plo.y < phi.y)) return;  // nothing to do: surface stays clear
+    int x0 = floor_px(plo.x), y0 = floor_px(plo.y), x1 = ceil_px(phi.x), y1 = ceil_px(phi.y);
+    const int mask_w = x1 - x0, mask_h = y1 - y0;
+    x0 = std::max(x0, 0);
+    y0 = std::max(y0, 0);
+    x1 = std::min(x1, int(w_));
+    y1 = std::min(y1, int(h_));
+    if (s.type == SWFR_FILL_BITMAP && !s.repeating) {
+        // OVER is bounded by its source (_cairo_pattern_get_extents of an EXTEND_NONE surface pattern): the bitmap's rectangle in
+        // device space; an axis the filter magnifies is padded by half a source pixel and rounded to the nearest pixel edge,
+        // the others are rounded out
+        const swfr_style& st = styles_[style_index];
+        Affine pm;
+        pm.xx = st.inv[0]; pm.yx = st.inv[1]; pm.xy = st.inv[2]; pm.yy = st.inv[3]; pm.x0 = st.inv[4]; pm.y0 = st.inv[5];
+        const BitmapInfo& bi = bitmaps_.find(s.bitmap_id)->second;
+        double sx0 = 0, sy0 = 0, sx1 = bi.width, sy1 = bi.height;
+        bool round_x = false, round_y = false;
+        if (std::hypot(pm.xx, pm.yx) < 1.0) { sx0 -= 0.5; sx1 += 0.5; round_x = true; }
+        if (std::hypot(pm.xy, pm.yy) < 1.0) { sy0 -= 0.5; sy1 += 0.5; round_y = true; }
+        Affine im = pm;
+        if (im.invert_cairo()) {
+            double bx0 = 0, by0 = 0, bx1 = 0, by1 = 0;
+            for (int k = 0; k < 4; ++k) {
+                double x = (k & 1) ? sx1 : sx0, y = (k & 2) ? sy1 : sy0;
+                im.apply(x, y);
+                if (!k || x < bx0) bx0 = x;
+                if (!k || x > bx1) bx1 = x;
+                if (!k || y < by0) by0 = y;
+                if (!k || y > by1) by1 = y;
+            }
+            if (!round_x) { bx0 -= 0.5; bx1 += 0.5; }
+            if (!round_y) { by0 -= 0.5; by1 += 0.5; }
+            bx0 = std::floor(bx0 + 0.5); by0 = std::floor(by0 + 0.5); bx1 = std::floor(bx1 + 0.5); by1 = std::floor(by1 + 0.5);
+            if (x0 < bx0) x0 = int(bx0);
+            if (y0 < by0) y0 = int(by0);
+            if (x1 > bx1) x1 = int(bx1);
+            if (y1 > by1) y1 = int(by1);
+        }
+    }
+    if (x0 >= x1 || y0 >= y1) return;                   // nothing to do: surface stays clear
+    const bool needs_clip = mask_w > x1 - x0 || mask_h > y1 - y0;
     Polygon poly;
-    const Pt lo{0, 0}, hi{fixed_t(w_) * 256, fixed_t(h_) * 256};
+    const Pt lo{fixed_t(x0) * 256, fixed_t(y0) * 256}, hi{fixed_t(x1) * 256, fixed_t(y1) * 256};  // the limits are the bounded rectangle
     poly.reset(needs_clip, lo, hi);
     if (needs_clip) fill_to_polygon_clipped(path_, poly, lo, hi); else fill_to_polygon(path_, poly);
-    emit_polygon(poly, path_.fill_is_rectilinear(), style_index, opaque_solid);
+    emit_polygon(poly, path_.fill_is_rectilinear(), style_index, opaque_solid, x0, y0, x1, y1);
 }
 
 void FrameBuilder::emit_stroke(const StyledPath& p, bool morph, double ratio) {

@@ -42,6 +42,7 @@ public:
 private:
     struct State {
         Affine ctm;
+        Affine inv;               // Cairo keeps the inverse beside the CTM and updates it factor by factor (_cairo_gstate_transform)
         double line_width = 1.0;  // node-canvas creates its context with line width 1
         int cap = 0, join = 0;
     };
@@ -53,6 +54,7 @@ private:
     void emit_polygon(Polygon& poly, bool rectilinear, uint32_t style, bool opaque_solid, int bx0 = 0, int by0 = 0, int bx1 = INT32_MAX, int by1 = INT32_MAX);
     uint32_t push_solid(uint32_t pixel);
     bool frame_bounds(Pt lo, Pt hi, bool& needs_clip) const;
+    bool transform(const Affine& m);  // context.transform(m); false: singular
     static Affine matrix_of(const swfr_matrix& m);
 
     uint32_t w_, h_;

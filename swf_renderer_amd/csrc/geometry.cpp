@@ -43,6 +43,34 @@ bool Affine::invert() {
     return true;
 }
 
+bool Affine::invert_cairo() {
+    if (xy == 0. && yx == 0.) {
+        x0 = -x0;
+        y0 = -y0;
+        if (xx != 1.) {
+            if (xx == 0.) return false;
+            xx = 1. / xx;
+            x0 *= xx;
+        }
+        if (yy != 1.) {
+            if (yy == 0.) return false;
+            yy = 1. / yy;
+            y0 *= yy;
+        }
+        return true;
+    }
+    const double d = det();
+    if (d == 0 || !std::isfinite(d)) return false;
+    const double a = xx, b = yx, c = xy, e = yy, tx = x0, ty = y0, k = 1 / d;
+    xx = e * k;
+    yx = -b * k;
+    xy = -c * k;
+    yy = a * k;
+    x0 = (c * ty - e * tx) * k;
+    y0 = (b * tx - a * ty) * k;
+    return true;
+}
+
 // ---------------------------------------------------------------------------------------------
 // DevicePath (A.2)
 // ---------------------------------------------------------------------------------------------

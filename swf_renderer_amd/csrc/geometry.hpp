@@ -40,6 +40,9 @@ struct Affine {
     void apply_distance(double& dx, double& dy) const;
     double det() const { return xx * yy - yx * xy; }
     bool invert();
+    // cairo_matrix_invert operation by operation (scale-only shortcut; otherwise adjoint times 1/det): pattern matrices are
+    // rounded to 16.16 for pixman afterwards, so they are derived exactly as Cairo derives them
+    bool invert_cairo();
     bool is_identity() const { return xx == 1 && yx == 0 && xy == 0 && yy == 1 && x0 == 0 && y0 == 0; }
 };
 

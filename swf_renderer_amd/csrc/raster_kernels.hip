@@ -1090,8 +1090,8 @@ __device__ uint32_t gradient_color(const swfr_style& s, double t) {
     return (A << 24) | (R << 16) | (G << 8) | B;
 }
 
-// premultiplied ARGB source colour at pixel centre (px+0.5, py+0.5): float64 model of pixman's
-// general path (gradients within +-1 LSB of Cairo)
+// premultiplied ARGB source colour at pixel centre (px+0.5, py+0.5): gradients are a float64 model of pixman's general path
+// (within +-1 LSB of Cairo); bitmaps use pixman's integer positions, weights and accumulation (bit-exact)
 __device__ __noinline__ uint32_t shade(const swfr_style& s, uint32_t style_index, const Sources bitmaps, int px, int py) {
     double x = px + 0.5, y = py + 0.5;
     const double ux = s.inv[0] * x + s.inv[2] * y + s.inv[4];
@@ -1121,10 +1121,12 @@ __device__ __noinline__ uint32_t shade(const swfr_style& s, uint32_t style_index
     }
     const DevBitmap bm = bitmaps.bitmaps[s.bitmap];
     const DevFilter flt = bitmaps.filters[style_index];
+    // pixman's own 16.16 sample position of this pixel's centre
+    const long long fxp = flt.base_x + (long long)px * flt.m00 + (long long)py * flt.m01;
+    const long long fyp = flt.base_y + (long long)px * flt.m10 + (long long)py * flt.m11;
     if (flt.on) {
-        // CAIRO_FILTER_GOOD below scale 0.75: pixman's separable convolution (integer tables and accumulation; the sample
-        // position comes from the f64 pattern matrix)
-        long long x = (long long)floor(ux * 65536.0), y = (long long)floor(uy * 65536.0);
+        // CAIRO_FILTER_GOOD below scale 0.75: pixman's separable convolution (integer tables and accumulation)
+        long long x = fxp, y = fyp;
         const int xsh = 16 - flt.xbits, ysh = 16 - flt.ybits;
         const long long x_off = (((long long)flt.cw << 16) - 65536) >> 1, y_off = (((long long)flt.ch << 16) - 65536) >> 1;
         x = ((x >> xsh) << xsh) + ((1 << xsh) >> 1);          // the middle of the closest phase
@@ -1155,9 +1157,9 @@ __device__ __noinline__ uint32_t shade(const swfr_style& s, uint32_t style_index
         return ((uint32_t)sa << 24) | ((uint32_t)sr << 16) | ((uint32_t)sg << 8) | (uint32_t)sb;
     }
     // bilinear with 7-bit weights (what CAIRO_FILTER_GOOD becomes for scales > .75)
-    const double u = ux - 0.5, v = uy - 0.5;
-    const int x0 = (int)floor(u), y0 = (int)floor(v);
-    const int wx = (int)floor((u - x0) * 128.0), wy = (int)floor((v - y0) * 128.0);
+    const long long bxp = fxp - 0x8000, byp = fyp - 0x8000;
+    const int x0 = (int)(bxp >> 16), y0 = (int)(byp >> 16);
+    const int wx = (int)((bxp >> 9) & 0x7f), wy = (int)((byp >> 9) & 0x7f);
     uint32_t c[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {

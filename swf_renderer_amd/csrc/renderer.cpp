@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cfloat>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -285,9 +286,69 @@ bool good_use_bilinear(double x, double y, double t) {
     if (h > 3.99 && h < 4.01 && to_fixed(x * y) == 0 && (to_fixed(t) & 255) == 0) return true;   // exactly 1/2, axis-parallel, integer offset
     return false;
 }
-DevFilter good_filter(const swfr_style& st, std::vector<int32_t>& params) {
+int64_t fixed_16_16(double d) { return int64_t(std::nearbyint(d * 65536.0)); }   // _cairo_fixed_16_16_from_double: ties to even
+
+// The pattern matrix as pixman gets it (cairo-matrix.c _cairo_matrix_to_pixman_matrix_offset, cairo-image-source.c
+// _pixman_image_set_properties): an integer translation is split off so that what remains is small, the matrix is rounded to
+// 16.16 and its translation is corrected until the centre of the operation's rectangle maps where the double matrix puts it.
+void pixman_transform_of(const swfr_style& st, const int rect[4], DevFilter& f) {
+    Affine m;
+    m.xx = st.inv[0]; m.yx = st.inv[1]; m.xy = st.inv[2]; m.yy = st.inv[3]; m.x0 = st.inv[4]; m.y0 = st.inv[5];
+    const double xc = rect[0] + (rect[2] - rect[0]) / 2., yc = rect[1] + (rect[3] - rect[1]) / 2.;
+    int64_t ox = 0, oy = 0;
+    if (m.x0 != 0.0 || m.y0 != 0.0) {
+        double tx = m.x0, ty = m.y0, norm = std::max(std::fabs(tx), std::fabs(ty));
+        for (int i = -1; i < 2; i += 2)
+            for (int j = -1; j < 2; j += 2) {
+                double den = (m.xx + i) * (m.yy + j) - m.xy * m.yx;
+                if (std::fabs(den) < DBL_EPSILON) continue;
+                double x = m.y0 * m.xy - m.x0 * (m.yy + j), y = m.x0 * m.yx - m.y0 * (m.xx + i);
+                den = 1 / den;
+                x *= den;
+                y *= den;
+                const double new_norm = std::max(std::fabs(x), std::fabs(y));
+                if (norm > new_norm) { norm = new_norm; tx = x; ty = y; }
+            }
+        tx = std::floor(tx);
+        ty = std::floor(ty);
+        ox = int64_t(-tx);
+        oy = int64_t(-ty);
+        Affine t;
+        t.x0 = tx; t.y0 = ty;
+        m = t.then(m);                                              // cairo_matrix_translate
+    }
+    int64_t p[2][3] = {{fixed_16_16(m.xx), fixed_16_16(m.xy), fixed_16_16(m.x0)}, {fixed_16_16(m.yx), fixed_16_16(m.yy), fixed_16_16(m.y0)}};
+    const double eps = 1.0 / 256.0, det = m.det();
+    const bool unity = std::fabs(det * det - 1.0) < eps &&
+                       ((std::fabs(m.xy) < eps && std::fabs(m.yx) < eps) || (std::fabs(m.xx) < eps && std::fabs(m.yy) < eps));
+    Affine inv = m;
+    if (!unity && inv.invert_cairo()) {
+        for (int it = 0; it < 5; ++it) {
+            const int64_t vx = fixed_16_16(xc), vy = fixed_16_16(yc);
+            double x = double((p[0][0] * vx + p[0][1] * vy + p[0][2] * 65536 + 0x8000) >> 16) / 65536.0;
+            double y = double((p[1][0] * vx + p[1][1] * vy + p[1][2] * 65536 + 0x8000) >> 16) / 65536.0;
+            inv.apply(x, y);
+            x -= xc;
+            y -= yc;
+            m.apply_distance(x, y);
+            const int64_t dx = fixed_16_16(x), dy = fixed_16_16(y);
+            p[0][2] -= dx;
+            p[1][2] -= dy;
+            if (dx == 0 && dy == 0) break;
+        }
+    }
+    // pixman_transform_point_3d of pixel (px, py)'s centre: (p·(X, Y, 1) + 0x8000) >> 16 with X = (px + ox + .5) in 16.16; the
+    // per-pixel and per-row steps are whole multiples of 65536 inside the sum, so they come out of the shift exactly
+    const int64_t X0 = (ox << 16) + 0x8000, Y0 = (oy << 16) + 0x8000;
+    f.base_x = (p[0][0] * X0 + p[0][1] * Y0 + p[0][2] * 65536 + 0x8000) >> 16;
+    f.base_y = (p[1][0] * X0 + p[1][1] * Y0 + p[1][2] * 65536 + 0x8000) >> 16;
+    f.m00 = int32_t(p[0][0]); f.m01 = int32_t(p[0][1]); f.m10 = int32_t(p[1][0]); f.m11 = int32_t(p[1][1]);
+}
+
+DevFilter good_filter(const swfr_style& st, const int rect[4], std::vector<int32_t>& params) {
     DevFilter f{};
     if (st.kind != SWFR_STYLE_BITMAP) return f;
+    pixman_transform_of(st, rect, f);
     const double xx = st.inv[0], yx = st.inv[1], xy = st.inv[2], yy = st.inv[3], x0 = st.inv[4], y0 = st.inv[5];
     if (good_use_bilinear(xx, xy, x0) && good_use_bilinear(yx, yy, y0)) return f;
     double dx = std::hypot(xx, xy), dy = std::hypot(yx, yy);
@@ -474,7 +535,21 @@ int upload(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, size
     // the scene's read-only arrays: one pinned staging buffer, one H2D copy, views into one device arena
     std::vector<DevFilter> filters(n_styles);
     std::vector<int32_t> fparams;
-    for (size_t i = 0; i < n_styles; ++i) filters[i] = good_filter(styles[i], fparams);
+    {
+        // a bitmap style belongs to one drawing operation: pixman's transform is anchored at the centre of that operation's rectangle
+        std::vector<int> rect(4 * n_styles, 0);
+        std::vector<uint8_t> seen(n_styles, 0);
+        for (size_t i = 0; i < n_paths; ++i) {
+            const swfr_path& p = paths[i];
+            if (styles[p.style].kind != SWFR_STYLE_BITMAP) continue;
+            int* q = &rect[4 * size_t(p.style)];
+            if (seen[p.style] && (q[0] != p.x_min || q[1] != p.y_min || q[2] != p.x_max || q[3] != p.y_max))
+                throw StatusError{SWFR_ERR_INVALID, "paths that share a bitmap style must share the pixel rectangle (one drawing operation)"};
+            seen[p.style] = 1;
+            q[0] = p.x_min; q[1] = p.y_min; q[2] = p.x_max; q[3] = p.y_max;
+        }
+        for (size_t i = 0; i < n_styles; ++i) filters[i] = good_filter(styles[i], &rect[4 * i], fparams);
+    }
     sc.has_order = !order.empty();
     {
         SceneArena& A = sc.arena;

@@ -174,3 +174,51 @@ def shape_to_rs_log(decoded: dict, ast: dict) -> str:
         out.append(ind(2) + "},")
     out += [ind(1) + "],", "}"]
     return "\n".join(out) + "\n"
+
+
+def make_bitmap_tag(bitmap_id, width, height, rng, colors=64):
+    """A random DefineBitmap in the only format the reference decodes (image/x-swf-bmp, format 3: zlib-compressed colour table +
+    8-bit indices, rows padded to 4; decode-x-swf-bmp.ts:9-41)."""
+    import zlib
+    table = rng.integers(0, 256, (colors, 3)).astype(np.uint8)
+    padded = width + ((4 - (width % 4)) % 4)
+    idx = np.zeros((height, padded), np.uint8)
+    idx[:, :width] = rng.integers(0, colors, (height, width))
+    body = zlib.compress(table.tobytes() + idx.tobytes())
+    data = bytes([3, width & 255, width >> 8, height & 255, height >> 8, colors - 1]) + body
+    return {"type": "define-bitmap", "id": bitmap_id, "width": width, "height": height, "media_type": "image/x-swf-bmp", "data": data.hex()}
+
+
+def rand_bitmap_scene(rng):
+    """One random frame of bitmap-filled shapes as the renderer draws them: repeat / no-repeat fills from 20x minified to 30x
+    magnified, rotated, reflected, partly off-frame, polygons and (un)aligned rectangles, with translucent solids in between."""
+    import scenarios
+    W, H = int(rng.integers(40, 200)), int(rng.integers(40, 140))
+    bmp = make_bitmap_tag(3, int(rng.integers(1, 48)), int(rng.integers(1, 48)), rng)
+    kids = []
+    for _ in range(int(rng.integers(1, 4))):
+        if rng.integers(0, 4) == 0:
+            pts = rng.uniform(0, 1, (4, 2)) * [W, H]
+            kids.append({"type": "shape", "definition": scenarios._poly_shape(np.rint(pts * 20), {"type": "solid", "color": scenarios._rgba(30, 200, 90, int(rng.choice([255, 140])))})})
+            continue
+        lo, hi = [(0.05, 0.74), (0.3, 3.0), (0.76, 8.0), (10, 30)][int(rng.integers(0, 4))]
+        k = float(rng.uniform(lo, hi))
+        t = float(rng.uniform(-3.2, 3.2)) if rng.integers(0, 3) else 0.0
+        c, sn = np.cos(t), np.sin(t)
+        flip = -1.0 if rng.integers(0, 5) == 0 else 1.0
+        fill = {"type": "bitmap", "bitmap_id": 3, "repeating": bool(rng.integers(0, 2)), "smoothed": True,
+                "matrix": scenarios._m(20 * k * c * flip, 20 * k * c, int(rng.integers(-200, W * 12)), int(rng.integers(-200, H * 12)), 20 * k * sn * flip, -20 * k * sn)}
+        kind = int(rng.integers(0, 3))
+        if kind == 0:
+            pts = rng.uniform(-0.2, 1.2, (int(rng.integers(3, 7)), 2)) * [W, H]
+        elif kind == 1:
+            x0, y0 = rng.uniform(0, W / 2), rng.uniform(0, H / 2)
+            x1, y1 = x0 + rng.uniform(3, W), y0 + rng.uniform(3, H)
+            pts = np.array([(x0, y0), (x1, y0), (x1, y1), (x0, y1)])
+        else:
+            x0, y0 = int(rng.integers(0, W // 2)), int(rng.integers(0, H // 2))
+            x1, y1 = x0 + int(rng.integers(1, W)), y0 + int(rng.integers(1, H))
+            pts = np.array([(x0, y0), (x1, y0), (x1, y1), (x0, y1)], float)
+        mat = scenarios._m(float(rng.choice([1, 1, 0.7, 1.6])), float(rng.choice([1, 1, 1.3])), int(rng.integers(-200, 300)), int(rng.integers(-200, 300)))
+        kids.append({"type": "shape", "definition": scenarios._poly_shape(np.rint(pts * 20), fill), "matrix": mat})
+    return dict(width=W, height=H, bitmaps=[bmp], stage={"children": kids})

@@ -177,14 +177,26 @@ def scenarios():
     sc = 5.0
     bmp = load_fixture("homestuck-beta-3.bitmap")
     out["bitmap_magnified"] = dict(width=math.ceil((b["x_max"] - b["x_min"]) / 20 * sc), height=math.ceil((b["y_max"] - b["y_min"]) / 20 * sc),
-                                   exact=False, bitmaps=[bmp], tolerance=4, stage={"children": [
+                                   exact=True, bitmaps=[bmp], stage={"children": [
         {"type": "shape", "definition": tag4, "matrix": _m(sc, sc, -b["x_min"] * sc, -b["y_min"] * sc)}]})
     # --- the reference's textured fixture at its own size: the bitmap is minified 2.58x, i.e. CAIRO_FILTER_GOOD's separable
     #     convolution (pixman) rather than bilinear; and a rotated, strongly minified repeat fill
     out["fixture_homestuck-beta-4"] = dict(width=math.ceil((b["x_max"] - b["x_min"]) / 20), height=math.ceil((b["y_max"] - b["y_min"]) / 20),
-                                           exact=False, bitmaps=[bmp], tolerance=2, stage={"children": [
+                                           exact=True, bitmaps=[bmp], stage={"children": [
         {"type": "shape", "definition": tag4, "matrix": _m(tx=-b["x_min"], ty=-b["y_min"])}]})
-    out["bitmap_minified_rotated"] = dict(width=120, height=90, exact=False, bitmaps=[bmp], tolerance=2, stage={"children": [
+    out["bitmap_minified_rotated"] = dict(width=120, height=90, exact=True, bitmaps=[bmp], stage={"children": [
         {"type": "shape", "definition": tag4, "matrix": _m(0.55, 0.4, 500 - (0.55 * b["x_min"] - 0.15 * b["y_min"]),
                                                                  150 - (0.2 * b["x_min"] + 0.4 * b["y_min"]), 0.2, -0.15)}]})
+    # --- non-repeating bitmaps smaller than the polygon they fill: the operation is bounded by the source's own extents, which also
+    #     become the polygon limits (magnified: half a source pixel of filter blur, rounded; minified: rounded out); on top of a
+    #     translucent solid so that both blend paths (clear surface / OVER) are hit
+    big = [(100, 160), (2900, 60), (2940, 2100), (1500, 2160), (60, 2040)]
+    under = {"type": "shape", "definition": _poly_shape([(40, 900), (2960, 700), (2960, 1500), (40, 1300)], {"type": "solid", "color": _rgba(40, 200, 90, 120)})}
+    for name, k, rot, tx, ty, rep, first in (("bitmap_no_repeat_magnified", 1.45, 0.35, 700, 300, False, True),
+                                             ("bitmap_no_repeat_minified", 0.31, -0.5, 600, 500, False, False),
+                                             ("bitmap_repeat_over_solid", 0.9, 2.2, 300, 200, True, False)):
+        c, sn = math.cos(rot), math.sin(rot)
+        fill = {"type": "bitmap", "bitmap_id": 3, "repeating": rep, "smoothed": True, "matrix": _m(20 * k * c, 20 * k * c, tx, ty, 20 * k * sn, -20 * k * sn)}
+        shape = {"type": "shape", "definition": _poly_shape(big, fill)}
+        out[name] = dict(width=150, height=110, exact=True, bitmaps=[bmp], stage={"children": [shape, under] if first else [under, shape]})
     return out

@@ -190,6 +190,21 @@ def test_fuzz_stroked_shapes_vs_oracle():
         assert diff_stats(product_render(sc), oracle_render(sc)) == (0, 0), it
 
 
+def test_fuzz_bitmap_fills_vs_oracle():
+    """Random bitmap-filled shapes (repeat / no-repeat, 20x minified to 30x magnified, rotated, reflected, partly off-frame, on a
+    clear frame and over translucent solids): the shader uses pixman's integer sample positions, weights and sums, so the frame
+    is bit-identical to the oracle's."""
+    from helpers import rand_bitmap_scene
+    rng = np.random.default_rng(4242)
+    painted = 0
+    for it in range(60):
+        sc = rand_bitmap_scene(rng)
+        ref = oracle_render(sc)
+        assert diff_stats(product_render(sc), ref) == (0, 0), it
+        painted += int((ref[..., 3] > 0).sum())
+    assert painted > 50000
+
+
 # ---- every internal route of the row/tile kernels gives the same pixels
 @pytest.mark.parametrize("env", [{"SWFR_FAST_LIMIT": "0"}, {"SWFR_FAST_LIMIT": "3"}, {"SWFR_CELL_MODE": "0"}, {"SWFR_CHUNK_ROWS": "64"},
                                  {"SWFR_CHUNK_ROWS": "8"}, {"SWFR_CHUNK_ROWS": "8", "SWFR_FAST_LIMIT": "3"}, {"SWFR_CHUNK_ROWS": "16", "SWFR_CELL_MODE": "0"},

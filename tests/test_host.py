@@ -121,6 +121,33 @@ def test_frame_edges_equal_oracle_polygons(name):
     tap.close()
 
 
+def test_fuzz_bitmap_scenes_edges_equal_oracle():
+    """Bitmap fills: a non-repeating bitmap bounds its fill by its own device-space extents, which become the polygon limits --
+    the frame builder must clip exactly as the oracle (and Cairo) does."""
+    from helpers import rand_bitmap_scene
+    rng = np.random.default_rng(99)
+    for it in range(150):
+        sc = rand_bitmap_scene(rng)
+        r = S.Renderer(sc["width"], sc["height"], device=api.DEVICE_HOST_ONLY)
+        for b in sc["bitmaps"]:
+            r.add_bitmap(b)
+        edges, paths, styles = r.build_frame(sc["stage"])
+        tap = _Tap(sc["width"], sc["height"])
+        rp = cr.CanvasReplay(tap, linear_extension=True)
+        for b in sc["bitmaps"]:
+            rp.add_bitmap(b)
+        rp.render(sc["stage"])
+        tor = [(pe, rect) for pe, rect in tap.polys if not rect]
+        got = [p for p in paths if p["kind"] == api.PATH_TOR]
+        # the oracle also records polygons whose pixel rectangle is empty; the frame builder drops those
+        tor = [(pe, rect) for pe, rect in tor if len(pe)]
+        for pth in got:
+            e = edges[pth["first_edge"]: pth["first_edge"] + pth["n_edges"]]
+            g = np.stack([e[k] for k in ("x1", "y1", "x2", "y2", "top", "bottom", "dir")], 1)
+            assert any(g.shape == pe.shape and (g == pe).all() for pe, _ in tor), it
+        tap.close(); r.close()
+
+
 def test_synthetic_scene_builder_equals_host_api():
     pts, cols = synth.scene(seed=synth.S1["seed"], n_shapes=300, width=3840, height=2160)
     e1, p1, s1 = api.polygons_to_scene(synth.twips_to_fixed(pts), cols, 3840, 2160)

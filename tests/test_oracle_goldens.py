@@ -50,15 +50,14 @@ def test_render_morph_golden_png(ratio, fname, allowed):
 
 
 def test_render_textured_golden_png():
-    """homestuck-beta-4 is minified 2.58x: Cairo's FILTER_GOOD = pixman's separable convolution (restated in the oracle;
-    the sample position comes from the double-precision matrix, so a few pixels sit one LSB off the reference's PNG)."""
+    """homestuck-beta-4 is minified 2.58x: Cairo's FILTER_GOOD = pixman's separable convolution at pixman's own 16.16 sample
+    positions, bounded by the non-repeating bitmap's extents -- identical to the reference's PNG."""
     sc = dict(width=54, height=81, bitmaps=[fixture("homestuck-beta-3.bitmap")],
               stage=cr.stage_for_shape(fixture("homestuck-beta-4"))[2])
     out = cr.unpremultiply(oracle_render(sc))
     ref = golden("ref_homestuck-beta-4", "rgba_straight")
     assert out.shape == ref.shape
-    n, mx = diff_stats(out, ref)
-    assert mx <= 1 and n <= 0.005 * out.shape[0] * out.shape[1], (n, mx)
+    assert diff_stats(out, ref) == (0, 0)
 
 
 def test_reference_spec_metric_on_all_seven_goldens():

@@ -186,12 +186,13 @@ def test_stroker_styles(kind):
 # ---- bitmap fills: CAIRO_FILTER_GOOD = bilinear above scale 0.75, pixman's separable convolution below.  Tables and accumulation
 #      are pixman's integers; the sample position comes from the double matrix (pixman rounds its matrix to 16.16 first), so a small
 #      share of the pixels may sit an LSB or two off.  EXTEND_REPEAT keeps the bitmap's own border out of the picture.
+@pytest.mark.parametrize("repeat", [True, False])
 @pytest.mark.parametrize("kind", ["minify_rotated", "minify_axis", "mixed", "magnify"])
-def test_bitmap_fill_filters(kind):
+def test_bitmap_fill_filters(kind, repeat):
+    """Surface patterns under CAIRO_FILTER_GOOD, both extend modes: bilinear / separable convolution at pixman's 16.16 sample
+    positions (matrix rounded and re-centred on the operation's rectangle), EXTEND_NONE bounded by the source extents: bit-exact."""
     rng = np.random.default_rng(zlib.crc32(kind.encode()) % 991)
     W, H = 64, 48
-    total = differing = 0
-    worst = 0
     for _ in range(40):
         tw, th = int(rng.integers(8, 40)), int(rng.integers(8, 40))
         bmp = rng.integers(0, 256, (th, tw, 4)).astype(np.uint8)
@@ -208,9 +209,87 @@ def test_bitmap_fill_filters(kind):
             b = be.create_bitmap(tw, th, bmp.tobytes())
             be.begin_path(); be.move_to(2, 2); be.line_to(W - 3, 3); be.line_to(W - 2, H - 2); be.line_to(3, H - 4); be.line_to(2, 2)
             be.save(); be.transform(*m)
-            be.set_fill_pattern(b, True); be.fill(); be.restore()
+            be.set_fill_pattern(b, repeat); be.fill(); be.restore()
             imgs.append(be.premultiplied_rgba().astype(int)); be.close()
-        d = np.abs(imgs[0] - imgs[1]).max(-1)
-        total += d.size; differing += int((d > 0).sum()); worst = max(worst, int(d.max()))
-    # bilinear weights are 7-bit functions of the position, so the position rounding shows a little more there
-    assert worst <= (3 if kind in ("magnify", "mixed") else 2) and differing <= 0.02 * total, (kind, worst, differing, total)
+        assert np.array_equal(imgs[0], imgs[1]), (kind, repeat, m, tw, th)
+
+
+@pytest.mark.parametrize("seed", list(range(1, 11)))
+def test_bitmap_fill_scenes(seed):
+    """Whole drawing sequences as the renderer issues them (scale(1/20); optional object matrix; per fill save / transform(fill
+    matrix) / fill / restore): one to three overlapping bitmap fills per frame -- polygons, curves, unaligned and pixel-aligned
+    rectangles, off-frame geometry, reflections, 1x1 to 40x40 bitmaps from 20x minified to 40x magnified, repeat and no-repeat,
+    on a clear surface and on top of each other.  Bit-exact."""
+    rng = np.random.default_rng(seed)
+    painted = 0
+    for it in range(50):
+        W, H = int(rng.integers(20, 90)), int(rng.integers(20, 70))
+        tw, th = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+        bmp = rng.integers(0, 256, (th, tw, 4)).astype(np.uint8)
+        if rng.integers(0, 2):
+            bmp[..., 3] = 255
+        ops = []
+        for k in range(int(rng.integers(1, 4))):
+            lo, hi = [(0.05, 0.74), (0.3, 3.0), (0.76, 8.0), (15, 40)][int(rng.integers(0, 4))]
+            sx, sy = rng.uniform(lo, hi), rng.uniform(lo, hi)
+            t = rng.uniform(-3.2, 3.2) if rng.integers(0, 3) else 0.0
+            c, s_ = np.cos(t), np.sin(t)
+            if rng.integers(0, 5) == 0:
+                sx = -sx
+            fm = (sx * c * 20, sx * s_ * 20, -sy * s_ * 20, sy * c * 20, float(rng.integers(-200, 1500)), float(rng.integers(-200, 1200)))
+            kind = int(rng.integers(0, 4))
+            if kind == 0:     # polygon in twips, partly off-frame
+                pts = [(int(rng.integers(-300, W * 20 + 300)), int(rng.integers(-300, H * 20 + 300))) for _ in range(int(rng.integers(3, 7)))]
+            elif kind == 1:   # rectangle, not pixel aligned
+                x0, y0 = int(rng.integers(-100, W * 10)), int(rng.integers(-100, H * 10))
+                x1, y1 = x0 + int(rng.integers(50, W * 15)), y0 + int(rng.integers(50, H * 15))
+                pts = [(x0, y0), (x1, y0), (x1, y1), (x0, y1)]
+            elif kind == 2:   # rectangle, pixel aligned
+                x0, y0 = 20 * int(rng.integers(0, W // 2)), 20 * int(rng.integers(0, H // 2))
+                x1, y1 = x0 + 20 * int(rng.integers(1, W)), y0 + 20 * int(rng.integers(1, H))
+                pts = [(x0, y0), (x1, y0), (x1, y1), (x0, y1)]
+            else:             # one curved side
+                pts = [(int(rng.integers(0, W * 20)), int(rng.integers(0, H * 20))) for _ in range(4)]
+            ops.append((fm, pts, bool(rng.integers(0, 2)), kind == 3))
+        om = (float(rng.uniform(0.5, 2.0)), 0.0, 0.0, float(rng.uniform(0.5, 2.0)), float(rng.integers(-100, 100)), float(rng.integers(-100, 100))) if rng.integers(0, 2) else None
+        imgs = []
+        for be in (cb.CairoBackend(W, H), ob.OracleBackend(W, H)):
+            be.set_transform_identity(); be.clear_all(); be.scale(1 / 20, 1 / 20)
+            b = be.create_bitmap(tw, th, bmp.tobytes())
+            be.save()
+            if om:
+                be.transform(*om)
+            for fm, pts, rep, curved in ops:
+                be.begin_path(); be.move_to(*pts[0])
+                if curved:
+                    be.quadratic_curve_to(pts[1][0], pts[1][1], pts[2][0], pts[2][1]); be.line_to(*pts[3])
+                else:
+                    for q in pts[1:]:
+                        be.line_to(*q)
+                be.line_to(*pts[0])
+                be.save(); be.transform(*fm)
+                be.set_fill_pattern(b, rep); be.fill(); be.restore()
+            be.restore()
+            imgs.append(be.premultiplied_rgba().astype(int)); be.close()
+        assert np.array_equal(imgs[0], imgs[1]), (seed, it)
+        painted += int((imgs[0][..., 3] > 0).sum())
+    assert painted > 8000
+
+
+@pytest.mark.parametrize("seed", [7, 8, 9, 10])
+def test_bitmap_scenes_through_the_canvas_replay(seed):
+    """The scenes of the GPU bitmap fuzz (tests/helpers.py rand_bitmap_scene: swf-tree shapes with bitmap fills, drawn by the
+    restated CanvasRenderer) rendered by libcairo and by the oracle: identical frames."""
+    from helpers import rand_bitmap_scene
+    from oracle import canvas_replay as cr
+    rng = np.random.default_rng(seed)
+    for it in range(40):
+        sc = rand_bitmap_scene(rng)
+        imgs = []
+        for be in (cb.CairoBackend(sc["width"], sc["height"]), ob.OracleBackend(sc["width"], sc["height"])):
+            rp = cr.CanvasReplay(be, linear_extension=True)
+            for b in sc["bitmaps"]:
+                rp.add_bitmap(b)
+            rp.render(sc["stage"])
+            imgs.append(be.premultiplied_rgba().astype(int)); be.close()
+        assert np.array_equal(imgs[0], imgs[1]), (seed, it)
