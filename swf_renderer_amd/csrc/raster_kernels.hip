@@ -230,6 +230,12 @@ __global__ __launch_bounds__(256) void k_front(const swfr_edge* __restrict__ in,
 #define ROWS_BIG_MAXA 64         // capacity of the generic (LDS list) routine in k_rows_big
 #define ROWS_STAGE 64            // paths with at most this many edges are staged into LDS
 
+#ifdef SWFR_PHASES                 // -DSWFR_PHASES: clocks per phase of a k_rows wavefront, summed into counters[8..15] (diagnostic builds only)
+#define RPHASE(i) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); rph[i] += (uint32_t)(now_ - rph_t); rph_t = now_; } while (0)
+#else
+#define RPHASE(i) do { } while (0)
+#endif
+
 struct FastLds {
     uint16_t eid[ROWS_FAST_N][64];      // per row (lane): local indices of its active edges
     int32_t roles[ROWS_FAST_N][64];     // SUB rows: role bits, OR-ed in by the 15 sub-row lanes
@@ -245,7 +251,9 @@ template <class EPTR>
 __device__ __forceinline__ void fast_rows(EPTR E, uint32_t n_list, const DevPath& P, int r, bool live, int fast_limit, FastLds& F, int lane,
                                           uint32_t& mode_out, int& n_out_edges, bool& overflow_out,
                                           int32_t (&roles)[ROWS_FAST_N], int32_t (&cols)[ROWS_FAST_N], int (&el)[ROWS_FAST_N],
-                                          int32_t (&Q1)[ROWS_FAST_N], int64_t (&R1)[ROWS_FAST_N], int32_t (&Q2)[ROWS_FAST_N], int64_t (&R2)[ROWS_FAST_N]) {
+                                          int32_t (&Q1)[ROWS_FAST_N], int64_t (&R1)[ROWS_FAST_N], int32_t (&Q2)[ROWS_FAST_N], int64_t (&R2)[ROWS_FAST_N],
+                                          uint32_t* rph, unsigned long long& rph_t) {
+    (void)rph; (void)rph_t;
     const int s0 = r * 15;
     const unsigned mask = P.fill_rule ? 1u : ~0u;
     int n = 0;
@@ -266,6 +274,7 @@ __device__ __forceinline__ void fast_rows(EPTR E, uint32_t n_list, const DevPath
         }
     }
     if (overflow) n = 0;
+    RPHASE(2);
     // wave-uniform bound on the active edges of any row of this wave: the unrolled slot loops stop there
     const int nmax = __ballot(n > 6) ? 8 : __ballot(n > 4) ? 6 : __ballot(n > 2) ? 4 : 2;
     // ---- rows that can still be FULL: x of every active edge at the first sample row of this pixel row and of the next
@@ -297,6 +306,7 @@ __device__ __forceinline__ void fast_rows(EPTR E, uint32_t n_list, const DevPath
         }
     }
     if (overflow) n = 0;
+    RPHASE(3);
     uint32_t mode = ROW_EMPTY;
     bool is_sub = false;
     if (n > 0) {
@@ -350,6 +360,7 @@ __device__ __forceinline__ void fast_rows(EPTR E, uint32_t n_list, const DevPath
         }
     }
     __syncthreads();                                          // F.* written by the row owners, read by the sample lanes
+    RPHASE(4);
     // ---- phase B: the wave's SUB rows, 4 rows x 15 sub-rows per pass
     unsigned long long pending = __ballot(is_sub);
     const int g = lane / 15, sub = lane - g * 15;
@@ -411,6 +422,7 @@ __device__ __forceinline__ void fast_rows(EPTR E, uint32_t n_list, const DevPath
 #pragma unroll
         for (int s = 0; s < ROWS_FAST_N; ++s) { roles[s] = F.roles[s][lane]; cols[s] = (int32_t)((uint32_t)F.clo[s][lane] | ((uint32_t)F.chi[s][lane] << 16)); }
     }
+    RPHASE(5);
     mode_out = mode; n_out_edges = n; overflow_out = overflow;
 }
 
@@ -421,7 +433,13 @@ __device__ __forceinline__ void rows_chunk_body(uint32_t block, const DevEdge* _
                                                 const BandSlot* __restrict__ band_slots, const uint32_t* __restrict__ band_off,
                                                 uint8_t* __restrict__ cls_t, int width, int height, int fused,
                                                 const swfr_edge* __restrict__ raw, const swfr_style* __restrict__ styles,
-                                                BandEntry* __restrict__ band_list) {
+                                                BandEntry* __restrict__ band_list, uint32_t* __restrict__ counters) {
+    (void)counters;
+    uint32_t rph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long rph_t = 0;
+#ifdef SWFR_PHASES
+    rph_t = __builtin_amdgcn_s_memtime();
+#endif
     __shared__ FastLds F;
     __shared__ DevEdge staged[ROWS_STAGE];
     __shared__ uint16_t staged_id[ROWS_STAGE], staged_hi[ROWS_STAGE];   // path-relative index of a staged edge (diagnostic eid)
@@ -433,10 +451,21 @@ __device__ __forceinline__ void rows_chunk_body(uint32_t block, const DevEdge* _
     const DevPath P = paths[lo];
     const int r = (int)ck.first_row + lane;
     const int chunk_rows = (int)ck.rows;                                // 64, or fewer for scenes of a few tall paths
+    // the classification at the end needs where this chunk's tile-rows keep their class bytes: asked for now, so that the answer
+    // is not queued behind the record stores (loads and stores return in order on this part)
+    BandSlot cls_bs = {0u, 0u, 0u, 0u};
+    uint32_t cls_b0 = 0, cls_b1 = 0;
+    if ((fused & 1) && ck.slot0 != ~0u && (lane >> 4) < chunk_rows / TILE_H && ((int)ck.first_row / TILE_H + (lane >> 4)) * TILE_H < height) {
+        const int band = (int)ck.first_row / TILE_H + (lane >> 4);
+        cls_bs = band_slots[ck.slot0 + (uint32_t)(lane >> 4)];
+        cls_b0 = band_off[band];
+        cls_b1 = band_off[band + 1];
+    }
     const bool in_path = P.kind == SWFR_PATH_TOR && lane < chunk_rows && r >= P.y_min && r < P.y_max;   // chunks start on tile-row boundaries
     bool live = in_path;
     if (live && band_count > 1 && (uint32_t)((r / TILE_H) % band_count) != band_index) live = false;
     const uint32_t t = row_base[lo] + (uint32_t)(r - P.y_min);          // row task index (valid when in_path)
+    RPHASE(0);
     if (P.n_edges > 65535u) fast_limit = 0;                             // 16-bit local edge indices in the fast path
     // ---- stage the edges that can be active in this chunk's 64 rows (path order kept): the row loops then run over that
     //      short list in LDS instead of over every edge of the path; only if more than ROWS_STAGE overlap do they read L2
@@ -459,11 +488,12 @@ __device__ __forceinline__ void rows_chunk_body(uint32_t block, const DevEdge* _
         if (n_list > ROWS_STAGE) { use_lds = false; break; }
     }
     __syncthreads();
+    RPHASE(1);
     uint32_t mode; int n; bool overflow;
     int32_t roles[ROWS_FAST_N], cols[ROWS_FAST_N]; int el[ROWS_FAST_N];
     int32_t Q1[ROWS_FAST_N], Q2[ROWS_FAST_N]; int64_t R1[ROWS_FAST_N], R2[ROWS_FAST_N];
-    if (use_lds) fast_rows((const DevEdge*)staged, n_list, P, r, live, fast_limit, F, lane, mode, n, overflow, roles, cols, el, Q1, R1, Q2, R2);
-    else fast_rows(edges + P.first_edge, P.n_edges, P, r, live, fast_limit, F, lane, mode, n, overflow, roles, cols, el, Q1, R1, Q2, R2);
+    if (use_lds) fast_rows((const DevEdge*)staged, n_list, P, r, live, fast_limit, F, lane, mode, n, overflow, roles, cols, el, Q1, R1, Q2, R2, rph, rph_t);
+    else fast_rows(edges + P.first_edge, P.n_edges, P, r, live, fast_limit, F, lane, mode, n, overflow, roles, cols, el, Q1, R1, Q2, R2, rph, rph_t);
     uint32_t n_out = 0;
 #pragma unroll
     for (int s = 0; s < ROWS_FAST_N; ++s) n_out += (s < n && roles[s] != 0) ? 1u : 0u;
@@ -495,6 +525,7 @@ __device__ __forceinline__ void rows_chunk_body(uint32_t block, const DevEdge* _
             }
         }
     }
+    RPHASE(6);
     // ---- classification of this chunk's (tile, path) pairs (what k_class does, from the record headers still in registers):
     //      a chunk holds whole tile-rows of its path, lanes 16g..16g+15 are the pixel rows of tile-row g
     if ((fused & 2) && ck.slot0 != ~0u && lane < chunk_rows / TILE_H) {
@@ -514,10 +545,8 @@ __device__ __forceinline__ void rows_chunk_body(uint32_t block, const DevEdge* _
         uint8_t* out = cls_t;                                 // + tile column * n_b
         uint32_t n_b = 0;
         if (band_ok) {
-            const BandSlot bs = band_slots[ck.slot0 + (uint32_t)(band - (int)ck.first_row / TILE_H)];
-            const uint32_t b0 = band_off[band];
-            n_b = band_off[band + 1] - b0;
-            out = cls_t + (size_t)tiles_x * b0 + (bs.slot - b0);
+            n_b = cls_b1 - cls_b0;
+            out = cls_t + (size_t)tiles_x * cls_b0 + (cls_bs.slot - cls_b0);
         }
         const int tc0 = P.x_min / TILE_W, tc1 = (P.x_max - 1) / TILE_W;
         // columns the path's rectangle does not reach: empty (sixteen lanes share a tile-row and stride over the columns)
@@ -550,13 +579,21 @@ __device__ __forceinline__ void rows_chunk_body(uint32_t block, const DevEdge* _
                     else f = CLS_PARTIAL | CLS_NOTFULL | CLS_NONEMPTY;
                 }
             }
-            f |= (uint32_t)__shfl_xor((int)f, 8);             // OR over the tile-row's sixteen lanes; every lane active
-            f |= (uint32_t)__shfl_xor((int)f, 4);
-            f |= (uint32_t)__shfl_xor((int)f, 2);
-            f |= (uint32_t)__shfl_xor((int)f, 1);
+            // OR over the tile-row's sixteen lanes (one DPP row): four rotations, no LDS round trips; every lane is active here
+            f |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f, 0x128, 0xf, 0xf, false);   // row_ror:8
+            f |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f, 0x124, 0xf, 0xf, false);   // row_ror:4
+            f |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f, 0x122, 0xf, 0xf, false);   // row_ror:2
+            f |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f, 0x121, 0xf, 0xf, false);   // row_ror:1
             if ((lane & 15) == 0 && band_ok) out[(size_t)tc * n_b] = (uint8_t)f;
         }
     }
+    RPHASE(7);
+#ifdef SWFR_PHASES
+    if (lane == 0 && (block & 63u) == 0u) {                                      // a sample of the wavefronts: contended atomics are slow
+        for (int i = 0; i < 8; ++i) atomicAdd(&counters[8 + i], rph[i] >> 4);   // units of 16 clocks
+        atomicAdd(&counters[16], 1u);
+    }
+#endif
 }
 
 // k_rows for scenes made of a few tall paths (the host then cuts the paths into 8-row chunks): lane = (row of the chunk, slot
@@ -1025,7 +1062,7 @@ __global__ __launch_bounds__(64) void k_rows(const DevEdge* __restrict__ edges, 
                                              BandEntry* __restrict__ band_list) {
     if (blockIdx.x < n_big) big_row_body(blockIdx.x, edges, paths, row_base, big_rows, n_big, rows, records, counters, cell_mode);
     else rows_chunk_body(blockIdx.x - n_big, edges, paths, row_base, chunks, n_paths, rows, records, band_index, band_count, fast_limit, cell_mode,
-                         band_slots, band_off, cls_t, width, height, fused, raw, styles, band_list);
+                         band_slots, band_off, cls_t, width, height, fused, raw, styles, band_list, counters);
 }
 __global__ __launch_bounds__(64) void k_rows_rs(const DevEdge* __restrict__ edges, const DevPath* __restrict__ paths,
                                                 const uint32_t* __restrict__ row_base, const ChunkInfo* __restrict__ chunks,
@@ -1337,6 +1374,7 @@ __global__ __launch_bounds__(64) void k_class(const BandEntry* __restrict__ band
 #define TLIST 32                       // tile list entries per round
 #define REC_STAGE 32                   // records staged in LDS per round
 #define P2B 8                          // rows scanned + blended per straight-line step
+#define BLEND_QUEUE 256                // edge pixels of one (path, strip) blended in compacted form; the accumulator holds 264 pairs
 #define PBATCH (64 / STRIP_H)           // partial paths whose row headers and records are fetched in one round trip each
 
 template <bool SHADERS>
@@ -1420,7 +1458,7 @@ __device__ __forceinline__ void tiles_body(const swfr_edge* __restrict__ raw_edg
                                               int width, int height, int tiles_x, uint32_t band_index, uint32_t band_count, int dbg,
                                               uint32_t* __restrict__ counters, uint32_t n_rows_total, uint32_t n_rec_cap,
                                               const uint32_t* __restrict__ order) {
-    __shared__ int acc[STRIP_H][ACC_STRIDE];
+    __shared__ __attribute__((aligned(16))) int acc[STRIP_H][ACC_STRIDE];   // also the queue of the compacted blend (8-byte pairs)
     __shared__ int plist[PBATCH];
     __shared__ __attribute__((aligned(16))) uint32_t ent[TLIST][12];   // BandEntry as 9 dwords in a 48-byte slot (16-byte LDS writes)
     __shared__ uint32_t cls[TLIST];
@@ -1704,11 +1742,50 @@ __device__ __forceinline__ void tiles_body(const swfr_edge* __restrict__ raw_edg
                         al[u] = (uint32_t)((((area << 4) + area) + 256) >> 9) & 255u;   // area * 17 without a 64-bit multiply-add
                         if (cx < e_xmin || cx >= e_xmax) al[u] = 0;
                     }
+                    bool blended = false;
+                    if (!SHADERS && P2B == STRIP_H && (eflags & BE_LERP) && dbg != 14) {
+                        // Solid colour, SOURCE-lerp: a pixel with coverage 255 takes the colour, one with 0 keeps its own, and only
+                        // the few edge pixels need the two rounded products.  Those are queued -- {coverage, pixel} through the
+                        // (now empty) accumulator -- and blended with lanes = queued pixels: one pass for the strip's eight rows
+                        // instead of one masked pass per row.
+                        unsigned long long pmask[P2B];
+                        int qbase[P2B], nq = 0;
+#pragma unroll
+                        for (int u = 0; u < P2B; ++u) {
+                            pmask[u] = __ballot(al[u] - 1u < 254u);
+                            qbase[u] = nq;
+                            nq += (int)__popcll(pmask[u]);
+                            px[u] = al[u] == 255u ? solid : px[u];
+                        }
+                        if (nq <= (dbg == 15 ? 12 : BLEND_QUEUE)) {            // wave-uniform; more edge pixels: the per-row path below
+                            uint2* q = reinterpret_cast<uint2*>(&A[0][0]);
+                            int qi[P2B];
+#pragma unroll
+                            for (int u = 0; u < P2B; ++u) {
+                                qi[u] = qbase[u] + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(pmask[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pmask[u], 0u));
+                                if ((pmask[u] >> lane) & 1ull) q[qi[u]] = make_uint2(al[u], px[u]);
+                            }
+                            __syncthreads();
+                            for (int b = lane; b < nq; b += 64) {
+                                const uint2 e = q[b];
+                                q[b].x = lerp_pixel(solid, e.x, e.y);
+                            }
+                            __syncthreads();
+#pragma unroll
+                            for (int u = 0; u < P2B; ++u)
+                                if ((pmask[u] >> lane) & 1ull) px[u] = q[qi[u]].x;
+                            __syncthreads();
+                            for (int b = lane; b < nq; b += 64) q[b] = make_uint2(0u, 0u);   // the accumulator is handed back empty
+                            blended = true;
+                        }
+                    }
+                    if (!blended) {
 #pragma unroll
                     for (int u = 0; u < P2B; ++u) {
                         const int rr = r4 + u;
                         if (SHADERS) { if (al[u]) px[rr] = blend_pixel(px[rr], al[u], eflags, solid, styles, style, bitmaps, cx, ty0 + rr); }
                         else { const uint32_t b = blend_pixel(px[rr], al[u], eflags, solid, styles, style, bitmaps, cx, ty0 + rr); px[rr] = al[u] ? b : px[rr]; }
+                    }
                     }
                 }
                 __syncthreads();                                   // acc cleared before the next path accumulates

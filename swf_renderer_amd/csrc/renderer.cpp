@@ -681,6 +681,14 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
     if (r->tiles_dbg == 9)
         std::fprintf(stderr, "[swfr] tile/path pairs %u, partial %u, full %u, culled entries %u\n", counters[CNT_PAIRS],
                      counters[CNT_PARTIAL], counters[CNT_FULL], counters[CNT_CULLED]);
+#ifdef SWFR_PHASES
+    if (std::getenv("SWFR_PRINT_PHASES") && counters[16]) {
+        static const char* names[8] = {"descriptors", "stage edges", "gather", "evaluate", "full test", "sample rows", "records", "bands+class"};
+        std::fprintf(stderr, "[swfr] k_rows phases, clocks per wavefront (%u wavefronts):", counters[16]);
+        for (int i = 0; i < 8; ++i) std::fprintf(stderr, " %s %.0f", names[i], 16.0 * counters[8 + i] / counters[16]);
+        std::fprintf(stderr, "\n");
+    }
+#endif
     r->fb_valid = true;
     return check_counters(r, counters);
 }
