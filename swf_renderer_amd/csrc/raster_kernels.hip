@@ -900,16 +900,40 @@ __device__ __forceinline__ void big_row_body(uint32_t block, const DevEdge* __re
     if (lane == 0) { ri.n_rec = (uint16_t)__popcll(hm); ri.mode = (uint16_t)mode; rows[t] = ri; }
 }
 
-// Rows with more than ROWS_BIG_MAXA (64) and up to ROWS_HUGE_MAXA (256) active edges of one path: one 256-thread workgroup per
-// row, thread = active edge, sort keys in LDS.  Same decisions as big_row_body; launched only when the host listed such rows.
-#define ROWS_HUGE_MAXA 256
+// Rows with more than ROWS_BIG_MAXA (64) and up to ROWS_HUGE_MAXA (2048) active edges of one path (a line of text outlines
+// filled with one style, hatching): one 256-thread workgroup per row; thread t owns the active edges t, t + 256, ... (path
+// order), the sort keys of all of them sit in LDS and every owned edge is ranked against them.  Same decisions as big_row_body;
+// launched only when the host listed such rows.
+#define ROWS_HUGE_MAXA 2048
+#define ROWS_HUGE_EPT (ROWS_HUGE_MAXA / 256)
+// x of edge e at the top and bottom of pixel row s0/15 (exact end points of a FULL record) and the sort keys of the row
+__device__ __forceinline__ void huge_full_keys(const DevEdge& e, int s0, int& c0, int& c1, int& cpv, int32_t& q1, int64_t& r1, int32_t& q2, int64_t& r2) {
+    c0 = c1 = cpv = e.x1; q1 = q2 = e.x1; r1 = r2 = 0;
+    if (!e.dy) return;
+    int32_t qa, qb; int64_t ra, rb;
+    edge_x_at(e, s0, qa, ra);
+    edge_x_at(e, s0 + 15, qb, rb);
+    c0 = cell_of(qa, ra, e.dy);
+    c1 = cell_of(qb, rb, e.dy);
+    cpv = c0;
+    if (e.ytop < s0) {
+        int32_t q = qa - (int32_t)e.dq; int64_t rm = ra - e.dr;
+        if (rm < 0) { --q; rm += e.dy; } else if (rm >= e.dy) { ++q; rm -= e.dy; }
+        cpv = cell_of(q, rm, e.dy);
+    }
+    const int32_t hq = (int32_t)(e.dq / 2); const int64_t hr = e.dr / 2;
+    qa -= hq; ra -= hr; if (ra < 0) { --qa; ra += e.dy; } else if (ra >= e.dy) { ++qa; ra -= e.dy; }
+    qb -= hq; rb -= hr; if (rb < 0) { --qb; rb += e.dy; } else if (rb >= e.dy) { ++qb; rb -= e.dy; }
+    q1 = qa; r1 = ra; q2 = qb; r2 = rb;
+}
 __global__ __launch_bounds__(256) void k_rows_huge(const DevEdge* __restrict__ edges, const DevPath* __restrict__ paths,
                                                    const uint32_t* __restrict__ row_base, const BigRow* __restrict__ huge_rows, uint32_t n_huge,
                                                    RowInfo* __restrict__ rows, Rec* __restrict__ records, uint32_t* __restrict__ counters,
                                                    int cell_mode) {
     __shared__ uint32_t active[ROWS_HUGE_MAXA];
-    __shared__ int k_c0[ROWS_HUGE_MAXA], k_c1[ROWS_HUGE_MAXA], k_cp[ROWS_HUGE_MAXA], k_nw[ROWS_HUGE_MAXA], k_dr[ROWS_HUGE_MAXA];
-    __shared__ int k_cc[ROWS_HUGE_MAXA], k_dd[ROWS_HUGE_MAXA];       // per sample row: cell and direction (0 = inactive there)
+    // FULL test: cell at the row top / bottom / one sample row earlier and (new-in-this-row | direction);
+    // sample rows: k_a = cell, k_d = direction (0 = inactive there)
+    __shared__ int k_a[ROWS_HUGE_MAXA], k_b[ROWS_HUGE_MAXA], k_c[ROWS_HUGE_MAXA], k_d[ROWS_HUGE_MAXA];
     __shared__ uint32_t wave_cnt[4];
     __shared__ int flags;                                            // bit 0: some edge starts / ends inside the row, bit 1: FULL test failed
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -942,111 +966,124 @@ __global__ __launch_bounds__(256) void k_rows_huge(const DevEdge* __restrict__ e
         if (tid == 0) { atomicOr(&counters[CNT_ERROR], 1u); rows[t] = ri; }
         return;
     }
-    const bool mine = tid < n;
-    const uint32_t k_mine = active[mine ? tid : 0];
-    const DevEdge e = E[k_mine];
-    const bool slanted = e.dy != 0;
-    if (mine && ((e.ytop > s0) | (e.ybot < s0 + 15))) atomicOr(&flags, 1);
+    const int nb = (n + 255) >> 8;                                   // owned edges per thread (workgroup-uniform)
+    uint32_t role[ROWS_HUGE_EPT], cols[ROWS_HUGE_EPT];
+#pragma unroll
+    for (int m = 0; m < ROWS_HUGE_EPT; ++m) { role[m] = 0; cols[m] = 0; }
+    for (int j = tid; j < n; j += 256) {
+        const DevEdge e = E[active[j]];
+        if ((e.ytop > s0) | (e.ybot < s0 + 15)) atomicOr(&flags, 1);
+    }
     __syncthreads();
-    uint32_t role = 0, cols = 0;
-    int32_t q1 = e.x1, q2 = e.x1; int64_t r1 = 0, r2 = 0;
     bool full = (flags & 1) == 0;
     if (full) {
-        int c0 = e.x1, c1 = e.x1, cpv = e.x1;
-        if (slanted) {
-            int32_t qa, qb; int64_t ra, rb;
-            edge_x_at(e, s0, qa, ra);
-            edge_x_at(e, s0 + 15, qb, rb);
-            c0 = cell_of(qa, ra, e.dy);
-            c1 = cell_of(qb, rb, e.dy);
-            cpv = c0;
-            if (e.ytop < s0) {
-                int32_t q = qa - (int32_t)e.dq; int64_t rm = ra - e.dr;
-                if (rm < 0) { --q; rm += e.dy; } else if (rm >= e.dy) { ++q; rm -= e.dy; }
-                cpv = cell_of(q, rm, e.dy);
-            }
-            const int32_t hq = (int32_t)(e.dq / 2); const int64_t hr = e.dr / 2;
-            qa -= hq; ra -= hr; if (ra < 0) { --qa; ra += e.dy; } else if (ra >= e.dy) { ++qa; ra -= e.dy; }
-            qb -= hq; rb -= hr; if (rb < 0) { --qb; rb += e.dy; } else if (rb >= e.dy) { ++qb; rb -= e.dy; }
-            q1 = qa; r1 = ra; q2 = qb; r2 = rb;
+        for (int j = tid; j < n; j += 256) {
+            const DevEdge e = E[active[j]];
+            int c0, c1, cpv; int32_t q1, q2; int64_t r1, r2;
+            huge_full_keys(e, s0, c0, c1, cpv, q1, r1, q2, r2);
+            k_a[j] = c0; k_b[j] = c1; k_c[j] = cpv; k_d[j] = ((e.ytop == s0) ? 4 : 0) | (e.dir + 1);
         }
-        const int nw = (e.ytop == s0) ? 1 : 0, dr = e.dir;
-        if (mine) { k_c0[tid] = c0; k_c1[tid] = c1; k_cp[tid] = cpv; k_nw[tid] = nw; k_dr[tid] = dr; }
         __syncthreads();
-        int w = 0; bool fg = true, lg = true, ok = true;
-        if (mine)
+#pragma unroll
+        for (int m = 0; m < ROWS_HUGE_EPT; ++m) {
+            const int j = m * 256 + tid;
+            if (m >= nb || j >= n) continue;
+            const int c0 = k_a[j], c1 = k_b[j], cpv = k_c[j], nw = k_d[j] >> 2, dr = (k_d[j] & 3) - 1;
+            int w = 0; bool fg = true, lg = true, ok = true;
             for (int i = 0; i < n; ++i) {                            // LDS broadcast reads
-                if (i == tid) continue;
-                const int ci = k_c0[i], ei = k_c1[i], pi = k_cp[i], ni = k_nw[i], di = k_dr[i];
+                if (i == j) continue;
+                const int ci = k_a[i], ei = k_b[i], pi = k_c[i], ni = k_d[i] >> 2, di = (k_d[i] & 3) - 1;
                 const bool tie = ci == c0, tie2 = ni == nw;
-                const bool t3 = ni == 0 ? (pi < cpv || (pi == cpv && i < tid)) : (i < tid);
+                const bool t3 = ni == 0 ? (pi < cpv || (pi == cpv && i < j)) : (i < j);
                 const bool before = ci < c0 || (tie && (ni < nw || (tie2 && t3)));
                 if (before) { w += di; if (ei > c1) ok = false; if (tie) fg = false; }
                 else if (tie) lg = false;
             }
-        if (mine && !ok) atomicOr(&flags, 2);
+            if (!ok) atomicOr(&flags, 2);
+            const bool in_b = ((unsigned)w & mask) != 0, in_a = ((unsigned)(w + dr) & mask) != 0;
+            if (!in_b && fg) role[m] = REC_FULL | 1u;
+            else if (!in_a && lg) role[m] = REC_FULL | 2u;
+        }
         __syncthreads();
         full = (flags & 2) == 0;
-        if (full && mine) {
-            const bool in_b = ((unsigned)w & mask) != 0, in_a = ((unsigned)(w + dr) & mask) != 0;
-            if (!in_b && fg) role = REC_FULL | 1u;
-            else if (!in_a && lg) role = REC_FULL | 2u;
-            if (role) { const int a = q1 >> 8, b = q2 >> 8; cols = clamp_col(min(a, b)) | (clamp_col(max(a, b)) << 16); }
-        }
     }
     const uint32_t mode = full ? ROW_FULL : ROW_SUB;
     if (!full) {
-        int clo = 65535, chi = 0;
+        int clo[ROWS_HUGE_EPT], chi[ROWS_HUGE_EPT];
+#pragma unroll
+        for (int m = 0; m < ROWS_HUGE_EPT; ++m) { role[m] = 0; clo[m] = 65535; chi[m] = 0; }
         for (int sub = 0; sub < 15; ++sub) {
             const int ss = s0 + sub;
-            const bool act = mine && e.ytop <= ss && ss < e.ybot;
-            int cc = e.x1;
-            if (act && slanted) { int32_t q; int64_t rm; edge_x_at(e, ss, q, rm); cc = cell_of(q, rm, e.dy); }
-            const int dd = act ? e.dir : 0;
-            if (mine) { k_cc[tid] = cc; k_dd[tid] = dd; }
+            for (int j = tid; j < n; j += 256) {
+                const DevEdge e = E[active[j]];
+                const bool act = e.ytop <= ss && ss < e.ybot;
+                int cc = e.x1;
+                if (act && e.dy) { int32_t q; int64_t rm; edge_x_at(e, ss, q, rm); cc = cell_of(q, rm, e.dy); }
+                k_a[j] = cc; k_d[j] = act ? e.dir : 0;
+            }
             __syncthreads();
-            if (act) {
+#pragma unroll
+            for (int m = 0; m < ROWS_HUGE_EPT; ++m) {
+                const int j = m * 256 + tid;
+                if (m >= nb || j >= n) continue;
+                const int dd = k_d[j], cc = k_a[j];
+                if (dd == 0) continue;
                 int wb = 0, gsum = dd; bool rep = true;
                 for (int i = 0; i < n; ++i) {
-                    const int di = k_dd[i];
-                    if (i == tid || di == 0) continue;           // dir is +-1 for an active edge
-                    const int ci = k_cc[i];
+                    const int di = k_d[i];
+                    if (i == j || di == 0) continue;             // dir is +-1 for an active edge
+                    const int ci = k_a[i];
                     if (ci < cc) wb += di;
-                    else if (ci == cc) { gsum += di; if (i < tid) rep = false; }
+                    else if (ci == cc) { gsum += di; if (i < j) rep = false; }
                 }
                 if (rep) {
                     const bool in_b = ((unsigned)wb & mask) != 0, in_a = ((unsigned)(wb + gsum) & mask) != 0;
                     if (in_a != in_b) {
-                        role |= (uint32_t)(in_a ? 1 : 2) << (2 * sub);
+                        role[m] |= (uint32_t)(in_a ? 1 : 2) << (2 * sub);
                         const int col = (int)clamp_col(cc >> 8);
-                        clo = min(clo, col); chi = max(chi, col);
+                        clo[m] = min(clo[m], col); chi[m] = max(chi[m], col);
                     }
                 }
             }
-            __syncthreads();                                         // k_cc / k_dd are rewritten for the next sample row
+            __syncthreads();                                         // k_a / k_d are rewritten for the next sample row
         }
-        cols = (uint32_t)clo | ((uint32_t)chi << 16);
+#pragma unroll
+        for (int m = 0; m < ROWS_HUGE_EPT; ++m) cols[m] = (uint32_t)clo[m] | ((uint32_t)chi[m] << 16);
     }
-    // ---- records in path order: rank among the edges that carry a role
-    const bool has = mine && role != 0;
-    const unsigned long long hm = __ballot(has);
-    if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(hm);
-    __syncthreads();
-    if (has) {
-        uint32_t off = br.rec_base + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
-        for (int w = 0; w < wave; ++w) off += wave_cnt[w];
-        Rec rc;
-        if (role & REC_FULL) {
-            bool as_cells = false;
-            if (cell_mode & 1) as_cells = full_cells_ends(q1, r1, q2, r2, e.dy, (role & 1u) ? +1 : -1, rc);
-            if (!as_cells) {
-                rc.roles = role; rc.cols = cols; rc.eid = P.first_edge + k_mine; rc.dy = e.dy; rc.span = 0;
-                rc.q1 = q1; rc.r1 = r1; rc.q2 = q2; rc.r2 = r2;
-            }
-        } else rc = make_record(e, P.first_edge + k_mine, s0, role, cols);
-        records[off] = rc;
+    // ---- records in path order: rank among the edges that carry a role (blocks of 256 owned edges in turn)
+    uint32_t emitted = 0;
+#pragma unroll
+    for (int m = 0; m < ROWS_HUGE_EPT; ++m) {
+        if (m >= nb) continue;                                       // workgroup-uniform
+        const int j = m * 256 + tid;
+        const bool has = j < n && role[m] != 0;
+        const unsigned long long hm = __ballot(has);
+        if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(hm);
+        __syncthreads();
+        if (has) {
+            uint32_t off = br.rec_base + emitted + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
+            for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+            const uint32_t k_mine = active[j];
+            const DevEdge e = E[k_mine];
+            Rec rc;
+            if (role[m] & REC_FULL) {
+                int c0, c1, cpv; int32_t q1, q2; int64_t r1, r2;
+                huge_full_keys(e, s0, c0, c1, cpv, q1, r1, q2, r2);
+                const int a = q1 >> 8, b = q2 >> 8;
+                const uint32_t fcols = clamp_col(min(a, b)) | (clamp_col(max(a, b)) << 16);
+                bool as_cells = false;
+                if (cell_mode & 1) as_cells = full_cells_ends(q1, r1, q2, r2, e.dy, (role[m] & 1u) ? +1 : -1, rc);
+                if (!as_cells) {
+                    rc.roles = role[m]; rc.cols = fcols; rc.eid = P.first_edge + k_mine; rc.dy = e.dy; rc.span = 0;
+                    rc.q1 = q1; rc.r1 = r1; rc.q2 = q2; rc.r2 = r2;
+                }
+            } else rc = make_record(e, P.first_edge + k_mine, s0, role[m], cols[m]);
+            records[off] = rc;
+        }
+        emitted += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        __syncthreads();                                             // wave_cnt is rewritten by the next block
     }
-    if (tid == 0) { ri.n_rec = (uint16_t)(wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3]); ri.mode = (uint16_t)mode; rows[t] = ri; }
+    if (tid == 0) { ri.n_rec = (uint16_t)emitted; ri.mode = (uint16_t)mode; rows[t] = ri; }
 }
 
 // The row pass is one launch: the first n_big workgroups take the crowded rows (the longest wavefronts start first), the rest

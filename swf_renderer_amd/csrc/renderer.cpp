@@ -380,7 +380,7 @@ int upload(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, size
     std::vector<ChunkInfo> chunks;                    // one k_rows workgroup each
     std::vector<uint32_t> chunk_cap;
     std::vector<BandSlot> band_slots;
-    std::vector<BigRow> huge_rows;                    // rows with more than 64 active edges: one 256-thread workgroup each
+    std::vector<BigRow> huge_rows;                    // rows with more than 64 active edges: one 256-thread workgroup each (k_rows_huge, up to 2048)
     std::vector<BigRow> big_rows;                     // rec_base holds the row's slot count until the prefix pass below
     std::vector<int32_t> active;
     const uint32_t bc = r->cfg.band_count > 1 ? r->cfg.band_count : 1, bi = r->cfg.band_count > 1 ? r->cfg.band_index : 0;
@@ -443,7 +443,7 @@ int upload(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, size
                 run += active[y];
                 const uint32_t band = (uint32_t(p.y_min) + y) / TILE_H;
                 if (bc > 1 && band % bc != bi) continue;          // another rank's tile-row: k_rows leaves it empty
-                if (run > 64) huge_rows.push_back(BigRow{uint32_t(i), int32_t(p.y_min) + int32_t(y), uint32_t(run), 0});   // k_rows_huge (<= 256)
+                if (run > 64) huge_rows.push_back(BigRow{uint32_t(i), int32_t(p.y_min) + int32_t(y), uint32_t(run), 0});   // k_rows_huge (<= 2048)
                 else if (run > limit) big_rows.push_back(BigRow{uint32_t(i), int32_t(p.y_min) + int32_t(y), uint32_t(run), 0});
                 else chunk_cap[c0 + (uint32_t(p.y_min) + y - chunk_a0) / chunk_rows] += uint32_t(run);
             }
@@ -617,7 +617,7 @@ int check_counters(swfr_renderer* r, const uint32_t* counters) {
     }
     if (counters[CNT_ERROR]) {
         r->fb_valid = false;
-        return fail(r, SWFR_ERR_CAPACITY, "a pixel row has more than 256 active edges of one path (scan converter capacity)");
+        return fail(r, SWFR_ERR_CAPACITY, "a pixel row has more than 2048 active edges of one path (scan converter capacity)");
     }
     return SWFR_OK;
 }

@@ -333,22 +333,23 @@ def _comb(teeth, width_twips):
     return scenarios._poly_shape(pts, {"type": "solid", "color": scenarios._rgba(1, 2, 3)})
 
 
-@pytest.mark.parametrize("teeth", [12, 40, 100])
+@pytest.mark.parametrize("teeth", [12, 40, 100, 140, 500, 1000])
 def test_crowded_rows_vs_oracle(teeth):
-    """Rows with 24, 80 and 200 active edges of one path: the crowded-row wavefronts (9..64 edges) and the 256-thread
-    workgroups of k_rows_huge (65..256) against the oracle, both fill rules."""
-    tag = _comb(teeth, 2000)
+    """Rows with 24 ... 2000 active edges of one path (a line of text outlines in one fill style looks like this): the crowded-row
+    wavefronts (9..64 edges) and the workgroups of k_rows_huge (65..2048, every thread ranks up to eight edges) against the
+    oracle, both fill rules; the teeth get narrower than a pixel."""
+    tag = _comb(teeth, 2000 if teeth <= 140 else 6000)
     for eo in (False, True):
-        sc = dict(width=120, height=100, even_odd=eo, stage={"children": [{"type": "shape", "definition": tag}]})
+        sc = dict(width=120 if teeth <= 140 else 320, height=100, even_odd=eo, stage={"children": [{"type": "shape", "definition": tag}]})
         assert diff_stats(product_render(sc), oracle_render(sc)) == (0, 0), (teeth, eo)
 
 
 def test_many_active_edges_fails_loudly_not_silently():
     import swf_renderer_amd as S
     from swf_renderer_amd import api
-    # a comb with 140 teeth: 280 edges are active in every row, beyond the per-row capacity of 256
-    tag = _comb(140, 2200)
-    r = S.Renderer(120, 100)
+    # a comb with 1100 teeth: 2200 edges are active in every row, beyond the per-row capacity of 2048
+    tag = _comb(1100, 6000)
+    r = S.Renderer(320, 100)
     with pytest.raises(S.SwfrError) as e:
         r.render({"children": [{"type": "shape", "definition": tag}]})
     assert e.value.code == api.ERR_CAPACITY
