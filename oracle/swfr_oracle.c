@@ -1008,6 +1008,13 @@ typedef struct {
     int32_t *xpar, *ypar;                    /* (1 << bits) phases x width taps, 16.16 */
     /* SURFACE: what pixman is given for one drawing operation (source_prepare_pixman): 16.16 transform + integer offset */
     int64_t pm[2][3]; int pox, poy;
+    /* RADIAL as pixman holds it (source_prepare_radial): circles in 16.16 after cairo's fit-to-range scaling, the quadratic's
+       constant terms, and one colour ramp per interval between consecutive stops (sentinels at both ends: PAD) */
+    int64_t g_c1x, g_c1y, g_c1r, g_dx, g_dy, g_dr;
+    double g_a, g_inva, g_mindr;
+    int g_n;                                 /* intervals = stops + 1 */
+    int64_t *g_x;                            /* g_n + 1 boundaries: INT32_MIN, stop offsets (16.16), INT32_MAX */
+    float *g_ramp;                           /* per interval: a_s, a_b, r_s, r_b, g_s, g_b, b_s, b_b */
 } source_t;
 
 /* ---- the pattern matrix as pixman gets it (cairo-matrix.c _cairo_matrix_to_pixman_matrix_offset, cairo-image-source.c
@@ -1015,9 +1022,8 @@ typedef struct {
         to 16.16 (ties to even) and its translation is then corrected so that the centre of the operation's rectangle maps where
         the double matrix would put it.  x0..y1 is that rectangle (bounded extents of the fill / stroke, in pixels). */
 static int32_t f16_from_double(double d) { return (int32_t)(int64_t)nearbyint(d * 65536.0); }
-static void source_prepare_pixman(source_t *s, int x0, int y0, int x1, int y1)
+static void source_prepare_pixman_m(source_t *s, mat_t m, int x0, int y0, int x1, int y1)
 {
-    mat_t m = s->inv;
     const double xc = x0 + (x1 - x0) / 2., yc = y0 + (y1 - y0) / 2.;
     s->pox = s->poy = 0;
     if (m.x0 != 0.0 || m.y0 != 0.0) {
@@ -1054,6 +1060,101 @@ static void source_prepare_pixman(source_t *s, int x0, int y0, int x1, int y1)
         if (dx == 0 && dy == 0) break;
     }
 }
+static void source_prepare_pixman(source_t *s, int x0, int y0, int x1, int y1) { source_prepare_pixman_m(s, s->inv, x0, y0, x1, y1); }
+
+/* ---- radial gradients exactly as cairo 1.16 + pixman 0.40 compute them (cairo-image-source.c _pixman_image_for_gradient,
+        cairo-pattern.c _cairo_gradient_pattern_fit_to_range, pixman-radial-gradient.c, pixman-gradient-walker.c): the circles are
+        scaled into +-16383 (the matrix takes the inverse factor) and rounded to 16.16; B and C of the quadratic are exact 64-bit
+        integers of the pixel's 16.16 sample position; the root is taken in doubles; the colour ramp between two stops is evaluated
+        in single precision and premultiplied there.  Extend is PAD (cairo's default for gradients). */
+static void source_prepare_radial(source_t *s, int x0, int y0, int x1, int y1)
+{
+    double c0x = s->cx0, c0y = s->cy0, c0r = s->r0, c1x = s->cx1, c1y = s->cy1, c1r = s->r1;
+    double dim = fabs(c0x);
+    dim = fmax(dim, fabs(c0y)); dim = fmax(dim, fabs(c0r)); dim = fmax(dim, fabs(c1x)); dim = fmax(dim, fabs(c1y)); dim = fmax(dim, fabs(c1r));
+    dim = fmax(dim, fabs(c0x - c1x)); dim = fmax(dim, fabs(c0y - c1y)); dim = fmax(dim, fabs(c0r - c1r));
+    mat_t m = s->inv;
+    if (dim > 16383.0) {                                             /* PIXMAN_MAX_INT >> 1 */
+        dim = 16383.0 / dim;
+        c0x *= dim; c0y *= dim; c0r *= dim; c1x *= dim; c1y *= dim; c1r *= dim;
+        mat_t sc = { dim, 0, 0, dim, 0, 0 };
+        mat_multiply(&m, &s->inv, &sc);
+    }
+    source_prepare_pixman_m(s, m, x0, y0, x1, y1);
+    s->g_c1x = f16_from_double(c0x); s->g_c1y = f16_from_double(c0y); s->g_c1r = f16_from_double(c0r);
+    s->g_dx = f16_from_double(c1x) - s->g_c1x; s->g_dy = f16_from_double(c1y) - s->g_c1y; s->g_dr = f16_from_double(c1r) - s->g_c1r;
+    s->g_a = (double)(s->g_dx * s->g_dx + s->g_dy * s->g_dy - s->g_dr * s->g_dr);
+    s->g_inva = s->g_a != 0 ? 1. * 65536 / s->g_a : 0;
+    s->g_mindr = -1. * 65536 * (double)s->g_c1r;
+    /* stops with the two PAD sentinels; one ramp per interval (gradient_walker_reset) */
+    const int n = s->nstops;
+    free(s->g_x); free(s->g_ramp);
+    s->g_n = n + 1;
+    s->g_x = malloc(sizeof(int64_t) * (size_t)(n + 2));
+    s->g_ramp = malloc(sizeof(float) * 8 * (size_t)(n + 1));
+    uint16_t (*col)[4] = malloc(sizeof(uint16_t[4]) * (size_t)(n + 2));
+    for (int i = 0; i < n; i++) {
+        s->g_x[i + 1] = f16_from_double(s->stops[i].t);
+        col[i + 1][0] = (uint16_t)(s->stops[i].a * 65535.0 + 0.5); col[i + 1][1] = (uint16_t)(s->stops[i].r * 65535.0 + 0.5);
+        col[i + 1][2] = (uint16_t)(s->stops[i].g * 65535.0 + 0.5); col[i + 1][3] = (uint16_t)(s->stops[i].b * 65535.0 + 0.5);
+    }
+    s->g_x[0] = INT32_MIN; s->g_x[n + 1] = INT32_MAX;
+    if (n) { memcpy(col[0], col[1], sizeof col[0]); memcpy(col[n + 1], col[n], sizeof col[0]); }
+    for (int k = 0; k <= n && n; k++) {
+        const int64_t left_x = s->g_x[k], right_x = s->g_x[k + 1];
+        const uint16_t *lc = col[k], *rc = col[k + 1];
+        float *w = s->g_ramp + 8 * k;
+        const float lx = left_x * (1.0f / 65536.0f), rx = right_x * (1.0f / 65536.0f);
+        for (int ch = 0; ch < 4; ch++) {
+            const float l = lc[ch] * (1.0f / 257.0f), r = rc[ch] * (1.0f / 257.0f);
+            if ((-FLT_MIN < (rx - lx) && (rx - lx) < FLT_MIN) || left_x == INT32_MIN || right_x == INT32_MAX) {
+                w[2 * ch] = 0.0f; w[2 * ch + 1] = (l + r) / 510.0f;
+            } else {
+                const float w_rec = 1.0f / (rx - lx);
+                w[2 * ch + 1] = (l * rx - r * lx) * w_rec * (1.0f / 255.0f);
+                w[2 * ch] = (r - l) * w_rec * (1.0f / 255.0f);
+            }
+        }
+    }
+    free(col);
+}
+static uint32_t radial_walker_pixel(const source_t *s, int64_t x)
+{
+    /* the interval: first stop with x < stop.x ends it (a position equal to a stop belongs to the interval on its right) */
+    int k = 0;
+    while (k < s->g_n - 1 && !(x < s->g_x[k + 1])) k++;
+    const float *w = s->g_ramp + 8 * k;
+    const float y = x * (1.0f / 65536.0f);
+    const float fa = 255.f * (w[0] * y + w[1]);
+    const float fr = fa * (w[2] * y + w[3]), fg = fa * (w[4] * y + w[5]), fb = fa * (w[6] * y + w[7]);
+    return (((uint32_t)(fa + .5f) << 24) & 0xff000000u) | (((uint32_t)(fr + .5f) << 16) & 0x00ff0000u) |
+           (((uint32_t)(fg + .5f) << 8) & 0x0000ff00u) | ((uint32_t)(fb + .5f) & 0x000000ffu);
+}
+static void source_pixman_position(const source_t *s, int px, int py, int64_t *vx, int64_t *vy);
+static uint32_t sample_radial_pixman(const source_t *s, int px, int py)
+{
+    if (!s->nstops) return 0;
+    int64_t vx, vy;
+    source_pixman_position(s, px, py, &vx, &vy);
+    vx -= s->g_c1x; vy -= s->g_c1y;
+    const int64_t bi = vx * s->g_dx + vy * s->g_dy + s->g_c1r * s->g_dr;
+    const int64_t ci = vx * vx + vy * vy - s->g_c1r * s->g_c1r;
+    const double a = s->g_a, b = (double)bi, c = (double)ci, dr = (double)s->g_dr;
+    if (a == 0) {
+        if (b == 0) return 0;
+        const double t = 65536 / 2 * c / b;
+        if (t * dr >= s->g_mindr) return radial_walker_pixel(s, (int64_t)t);
+        return 0;
+    }
+    const double discr = b * b + a * -c;
+    if (discr >= 0) {
+        const double sq = sqrt(discr), t0 = (b + sq) * s->g_inva, t1 = (b - sq) * s->g_inva;
+        if (t0 * dr >= s->g_mindr) return radial_walker_pixel(s, (int64_t)t0);
+        else if (t1 * dr >= s->g_mindr) return radial_walker_pixel(s, (int64_t)t1);
+    }
+    return 0;
+}
+
 /* pixman's sample position of destination pixel (px, py), 16.16 (pixman_transform_point_3d of the pixel centre; stepping along
    the scanline by the matrix column is exact, so every pixel can be evaluated by itself) */
 static void source_pixman_position(const source_t *s, int px, int py, int64_t *vx, int64_t *vy)
@@ -1232,8 +1333,9 @@ static uint32_t gradient_color(const source_t *s, double t)
 static uint32_t sample_source(const source_t *s, int px, int py)
 {
     double x = px + 0.5, y = py + 0.5;
-    if (s->kind != SRC_SURFACE) mat_point(&s->inv, &x, &y);
-    if (s->kind == SRC_RADIAL) {
+    if (s->kind == SRC_LINEAR) mat_point(&s->inv, &x, &y);
+    if (s->kind == SRC_RADIAL) return sample_radial_pixman(s, px, py);
+    if (s->kind == SRC_RADIAL) {                           /* (float64 model, kept for reference: within +-1 of the above) */
         /* |p - c(t)| = r(t), larger root, PAD extend */
         double cdx = s->cx1 - s->cx0, cdy = s->cy1 - s->cy0, dr = s->r1 - s->r0;
         double pdx = x - s->cx0, pdy = y - s->cy0;
@@ -1612,6 +1714,7 @@ static void boxes_render(swfo_ctx *c, const polygon_t *g, int even_odd, int lerp
     int bw = px1 - px0, bh = py1 - py0;
     if (bw <= 0 || bh <= 0) { free(ve); free(ys); return; }
     if (c->src.kind == SRC_SURFACE) source_prepare_pixman(&c->src, px0, py0, px1, py1);
+    if (c->src.kind == SRC_RADIAL) source_prepare_radial(&c->src, px0, py0, px1, py1);
     uint32_t *acc = calloc((size_t)bw * bh, sizeof(uint32_t));
     unsigned mask = even_odd ? 1u : ~0u;
     for (int s = 0; s + 1 < 2 * n; s++) {
@@ -1726,6 +1829,7 @@ static void render_polygon(swfo_ctx *c, polygon_t *g, int even_odd)
     if (xmin < c->bx0) xmin = c->bx0; if (ymin < c->by0) ymin = c->by0; if (xmax > c->bx1) xmax = c->bx1; if (ymax > c->by1) ymax = c->by1;
     if (xmin >= xmax || ymin >= ymax) return;
     if (c->src.kind == SRC_SURFACE) source_prepare_pixman(&c->src, xmin, ymin, xmax, ymax);
+    if (c->src.kind == SRC_RADIAL) source_prepare_radial(&c->src, xmin, ymin, xmax, ymax);
     tor_render(c, g, even_odd, lerp_mode, xmin, ymin, xmax, ymax);
 }
 
@@ -1829,7 +1933,7 @@ EXPORT swfo_ctx *swfo_create(int w, int h)
 EXPORT void swfo_destroy(swfo_ctx *c)
 {
     if (!c) return;
-    free(c->px); free(c->path.ops); free(c->path.pts); free(c->src.stops); free(c->src.xpar); free(c->src.ypar);
+    free(c->px); free(c->path.ops); free(c->path.pts); free(c->src.stops); free(c->src.xpar); free(c->src.ypar); free(c->src.g_x); free(c->src.g_ramp);
     free(c->ch); free(c->ua); free(c->touched); free(c->tmark); free(c->last_poly);
     free(c);
 }

@@ -116,11 +116,26 @@ struct DevFilter {
 };
 static_assert(sizeof(DevFilter) == 64, "DevFilter layout");
 
+// A radial gradient as pixman holds it for one drawing operation (host: radial_of; cairo-image-source.c _pixman_image_for_gradient,
+// pixman-radial-gradient.c, pixman-gradient-walker.c): the 16.16 sample position as for bitmaps, the circles after Cairo's
+// fit-to-range scaling, the constant terms of the quadratic, and one single-precision colour ramp per interval between stops
+// (PAD sentinels at both ends).  DevFilter::pad of the style holds its index + 1 into the handle's gradient table.
+struct DevGradient {
+    int64_t base_x, base_y;
+    int32_t m00, m01, m10, m11;
+    int32_t c1x, c1y, c1r, dx, dy, dr;       // 16.16
+    int32_t n_intervals, pad;
+    double a, inva, mindr;
+    int32_t x[SWFR_MAX_STOPS + 2];           // interval boundaries: INT32_MIN, stop offsets, INT32_MAX
+    float ramp[SWFR_MAX_STOPS + 1][8];       // a_s, a_b, r_s, r_b, g_s, g_b, b_s, b_b
+};
+
 // what the shader needs besides the style itself
 struct Sources {
     const DevBitmap* bitmaps;
     const DevFilter* filters;    // per style index
     const int32_t* fparams;
+    const DevGradient* gradients;
 };
 
 }  // namespace swfr

@@ -148,7 +148,7 @@ struct swfr_renderer {
         swfr_edge* raw = nullptr; DevPath* paths = nullptr; swfr_style* styles = nullptr;
         uint32_t *row_base = nullptr, *band_off = nullptr, *order = nullptr;
         BigRow *big_rows = nullptr, *huge_rows = nullptr; BandSlot* band_slots = nullptr; ChunkInfo* chunk_base = nullptr;
-        DevFilter* filters = nullptr; int32_t* filter_params = nullptr;
+        DevFilter* filters = nullptr; int32_t* filter_params = nullptr; DevGradient* gradients = nullptr;
         size_t n_edges = 0, n_paths = 0, n_styles = 0, n_tasks = 0, n_chunks = 0, n_bands = 0, rec_cap = 0, rec_main = 0, n_big = 0, n_huge = 0,
                chunk_rows = 64, n_band_entries = 0;
         bool any_shader = false, fused_class = false, fused_front = false, has_order = false;
@@ -291,9 +291,9 @@ int64_t fixed_16_16(double d) { return int64_t(std::nearbyint(d * 65536.0)); }  
 // The pattern matrix as pixman gets it (cairo-matrix.c _cairo_matrix_to_pixman_matrix_offset, cairo-image-source.c
 // _pixman_image_set_properties): an integer translation is split off so that what remains is small, the matrix is rounded to
 // 16.16 and its translation is corrected until the centre of the operation's rectangle maps where the double matrix puts it.
-void pixman_transform_of(const swfr_style& st, const int rect[4], DevFilter& f) {
-    Affine m;
-    m.xx = st.inv[0]; m.yx = st.inv[1]; m.xy = st.inv[2]; m.yy = st.inv[3]; m.x0 = st.inv[4]; m.y0 = st.inv[5];
+struct PixmanPosition { int64_t base_x, base_y; int32_t m00, m01, m10, m11; };
+PixmanPosition pixman_transform_of(Affine m, const int rect[4]) {
+    PixmanPosition f;
     const double xc = rect[0] + (rect[2] - rect[0]) / 2., yc = rect[1] + (rect[3] - rect[1]) / 2.;
     int64_t ox = 0, oy = 0;
     if (m.x0 != 0.0 || m.y0 != 0.0) {
@@ -343,12 +343,73 @@ void pixman_transform_of(const swfr_style& st, const int rect[4], DevFilter& f) 
     f.base_x = (p[0][0] * X0 + p[0][1] * Y0 + p[0][2] * 65536 + 0x8000) >> 16;
     f.base_y = (p[1][0] * X0 + p[1][1] * Y0 + p[1][2] * 65536 + 0x8000) >> 16;
     f.m00 = int32_t(p[0][0]); f.m01 = int32_t(p[0][1]); f.m10 = int32_t(p[1][0]); f.m11 = int32_t(p[1][1]);
+    return f;
+}
+Affine pattern_matrix(const swfr_style& st) {
+    Affine m;
+    m.xx = st.inv[0]; m.yx = st.inv[1]; m.xy = st.inv[2]; m.yy = st.inv[3]; m.x0 = st.inv[4]; m.y0 = st.inv[5];
+    return m;
+}
+
+// A radial gradient as cairo 1.16 hands it to pixman 0.40 and as pixman evaluates it: circles scaled into +-16383 (the matrix
+// takes the inverse factor), 16.16 circles and stops, 16-bit colours, single-precision ramps per interval (gradient_walker_reset),
+// PAD sentinels.  The device evaluates B and C of the quadratic as exact 64-bit integers, the root in doubles, the ramp in floats.
+DevGradient radial_of(const swfr_style& st, const int rect[4]) {
+    DevGradient g;
+    std::memset(&g, 0, sizeof g);
+    double c0x = st.c0x, c0y = st.c0y, c0r = st.r0, c1x = st.c1x, c1y = st.c1y, c1r = st.r1;
+    double dim = std::fabs(c0x);
+    for (double v : {c0y, c0r, c1x, c1y, c1r, c0x - c1x, c0y - c1y, c0r - c1r}) dim = std::max(dim, std::fabs(v));
+    Affine m = pattern_matrix(st);
+    if (dim > 16383.0) {                                            // PIXMAN_MAX_INT >> 1
+        dim = 16383.0 / dim;
+        c0x *= dim; c0y *= dim; c0r *= dim; c1x *= dim; c1y *= dim; c1r *= dim;
+        m = m.then(Affine::scale(dim, dim));
+    }
+    const PixmanPosition pos = pixman_transform_of(m, rect);
+    g.base_x = pos.base_x; g.base_y = pos.base_y; g.m00 = pos.m00; g.m01 = pos.m01; g.m10 = pos.m10; g.m11 = pos.m11;
+    const int64_t f1x = fixed_16_16(c0x), f1y = fixed_16_16(c0y), f1r = fixed_16_16(c0r);
+    const int64_t dx = fixed_16_16(c1x) - f1x, dy = fixed_16_16(c1y) - f1y, dr = fixed_16_16(c1r) - f1r;
+    g.c1x = int32_t(f1x); g.c1y = int32_t(f1y); g.c1r = int32_t(f1r); g.dx = int32_t(dx); g.dy = int32_t(dy); g.dr = int32_t(dr);
+    g.a = double(dx * dx + dy * dy - dr * dr);
+    g.inva = g.a != 0 ? 1. * 65536 / g.a : 0;
+    g.mindr = -1. * 65536 * double(f1r);
+    const int n = int(st.n_stops);
+    g.n_intervals = n ? n + 1 : 0;
+    uint16_t col[SWFR_MAX_STOPS + 2][4] = {};
+    for (int i = 0; i < n; ++i) {
+        g.x[i + 1] = int32_t(fixed_16_16(double(st.stop_offset[i])));
+        // cairo_pattern_add_color_stop_rgba keeps doubles; _cairo_color_double_to_short = (uint16)(v * 65535 + 0.5)
+        col[i + 1][0] = uint16_t(double(st.stop_rgba[i][3]) * 65535.0 + 0.5);
+        col[i + 1][1] = uint16_t(double(st.stop_rgba[i][0]) * 65535.0 + 0.5);
+        col[i + 1][2] = uint16_t(double(st.stop_rgba[i][1]) * 65535.0 + 0.5);
+        col[i + 1][3] = uint16_t(double(st.stop_rgba[i][2]) * 65535.0 + 0.5);
+    }
+    g.x[0] = INT32_MIN; g.x[n + 1] = INT32_MAX;
+    if (n) { std::memcpy(col[0], col[1], sizeof col[0]); std::memcpy(col[n + 1], col[n], sizeof col[0]); }
+    for (int k = 0; k <= n && n; ++k) {
+        const int64_t left_x = g.x[k], right_x = g.x[k + 1];
+        const float lx = left_x * (1.0f / 65536.0f), rx = right_x * (1.0f / 65536.0f);
+        for (int ch = 0; ch < 4; ++ch) {
+            const float l = col[k][ch] * (1.0f / 257.0f), rr = col[k + 1][ch] * (1.0f / 257.0f);
+            if ((-FLT_MIN < (rx - lx) && (rx - lx) < FLT_MIN) || left_x == INT32_MIN || right_x == INT32_MAX) {
+                g.ramp[k][2 * ch] = 0.0f;
+                g.ramp[k][2 * ch + 1] = (l + rr) / 510.0f;
+            } else {
+                const float w_rec = 1.0f / (rx - lx);
+                g.ramp[k][2 * ch + 1] = (l * rx - rr * lx) * w_rec * (1.0f / 255.0f);
+                g.ramp[k][2 * ch] = (rr - l) * w_rec * (1.0f / 255.0f);
+            }
+        }
+    }
+    return g;
 }
 
 DevFilter good_filter(const swfr_style& st, const int rect[4], std::vector<int32_t>& params) {
     DevFilter f{};
     if (st.kind != SWFR_STYLE_BITMAP) return f;
-    pixman_transform_of(st, rect, f);
+    const PixmanPosition pos = pixman_transform_of(pattern_matrix(st), rect);
+    f.base_x = pos.base_x; f.base_y = pos.base_y; f.m00 = pos.m00; f.m01 = pos.m01; f.m10 = pos.m10; f.m11 = pos.m11;
     const double xx = st.inv[0], yx = st.inv[1], xy = st.inv[2], yy = st.inv[3], x0 = st.inv[4], y0 = st.inv[5];
     if (good_use_bilinear(xx, xy, x0) && good_use_bilinear(yx, yy, y0)) return f;
     double dx = std::hypot(xx, xy), dy = std::hypot(yx, yy);
@@ -534,6 +595,7 @@ int upload(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, size
     }
     // the scene's read-only arrays: one pinned staging buffer, one H2D copy, views into one device arena
     std::vector<DevFilter> filters(n_styles);
+    std::vector<DevGradient> gradients;
     std::vector<int32_t> fparams;
     {
         // a bitmap style belongs to one drawing operation: pixman's transform is anchored at the centre of that operation's rectangle
@@ -541,14 +603,20 @@ int upload(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, size
         std::vector<uint8_t> seen(n_styles, 0);
         for (size_t i = 0; i < n_paths; ++i) {
             const swfr_path& p = paths[i];
-            if (styles[p.style].kind != SWFR_STYLE_BITMAP) continue;
+            if (styles[p.style].kind != SWFR_STYLE_BITMAP && styles[p.style].kind != SWFR_STYLE_RADIAL) continue;
             int* q = &rect[4 * size_t(p.style)];
             if (seen[p.style] && (q[0] != p.x_min || q[1] != p.y_min || q[2] != p.x_max || q[3] != p.y_max))
-                throw StatusError{SWFR_ERR_INVALID, "paths that share a bitmap style must share the pixel rectangle (one drawing operation)"};
+                throw StatusError{SWFR_ERR_INVALID, "paths that share a bitmap or radial-gradient style must share the pixel rectangle (one drawing operation)"};
             seen[p.style] = 1;
             q[0] = p.x_min; q[1] = p.y_min; q[2] = p.x_max; q[3] = p.y_max;
         }
-        for (size_t i = 0; i < n_styles; ++i) filters[i] = good_filter(styles[i], &rect[4 * i], fparams);
+        for (size_t i = 0; i < n_styles; ++i) {
+            filters[i] = good_filter(styles[i], &rect[4 * i], fparams);
+            if (styles[i].kind == SWFR_STYLE_RADIAL) {
+                gradients.push_back(radial_of(styles[i], &rect[4 * i]));
+                filters[i].pad = int32_t(gradients.size());            // index + 1 into the gradient table
+            }
+        }
     }
     sc.has_order = !order.empty();
     {
@@ -557,7 +625,7 @@ int upload(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, size
         A.begin(P(n_edges * sizeof(swfr_edge)) + P(n_paths * sizeof(swfr_path)) + P(n_styles * sizeof(swfr_style)) +
                 P((n_paths + 1) * sizeof(uint32_t)) + P(band_slots.size() * sizeof(BandSlot)) + P(order.size() * sizeof(uint32_t)) +
                 P(big_rows.size() * sizeof(BigRow)) + P(huge_rows.size() * sizeof(BigRow)) + P(chunks.size() * sizeof(ChunkInfo)) + P((n_bands + 1) * sizeof(uint32_t)) +
-                P(n_styles * sizeof(DevFilter)) + P(fparams.size() * sizeof(int32_t)) + 4096);
+                P(n_styles * sizeof(DevFilter)) + P(fparams.size() * sizeof(int32_t)) + P(gradients.size() * sizeof(DevGradient)) + 4096);
         sc.raw = static_cast<swfr_edge*>(A.push(staged.data(), n_edges * sizeof(swfr_edge)));
         sc.paths = static_cast<DevPath*>(A.push(paths, n_paths * sizeof(swfr_path)));
         sc.styles = static_cast<swfr_style*>(A.push(styles, n_styles * sizeof(swfr_style)));
@@ -570,6 +638,7 @@ int upload(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, size
         sc.band_off = static_cast<uint32_t*>(A.push(band_off.data(), (n_bands + 1) * sizeof(uint32_t)));
         sc.filters = static_cast<DevFilter*>(A.push(filters.data(), n_styles * sizeof(DevFilter)));
         sc.filter_params = static_cast<int32_t*>(A.push(fparams.data(), fparams.size() * sizeof(int32_t)));
+        sc.gradients = static_cast<DevGradient*>(A.push(gradients.data(), gradients.size() * sizeof(DevGradient)));
         A.flush(up_stream);
     }
     if (r->bitmap_table_dirty) {
@@ -605,7 +674,7 @@ void launch_frame(swfr_renderer* r, const swfr_renderer::Scene& sc, swfr_rendere
     }
     if (e) HIP_CHECK(hipEventRecord(e[2], st));
     launch_tiles(st, sc.raw, sc.band_off, F.d_band_list.ptr, F.d_cls.ptr, F.d_rows.ptr, F.d_records.ptr, sc.styles,
-                 Sources{r->d_bitmap_table.ptr, sc.filters, sc.filter_params}, fb, int(r->width), int(r->height), bi, bc, r->tiles_dbg,
+                 Sources{r->d_bitmap_table.ptr, sc.filters, sc.filter_params, sc.gradients}, fb, int(r->width), int(r->height), bi, bc, r->tiles_dbg,
                  F.d_counters.ptr, uint32_t(sc.n_tasks), uint32_t(sc.rec_cap), sc.any_shader, sc.has_order ? sc.order : nullptr);
     if (e) HIP_CHECK(hipEventRecord(e[3], st));
 }

@@ -222,3 +222,29 @@ def rand_bitmap_scene(rng):
         mat = scenarios._m(float(rng.choice([1, 1, 0.7, 1.6])), float(rng.choice([1, 1, 1.3])), int(rng.integers(-200, 300)), int(rng.integers(-200, 300)))
         kids.append({"type": "shape", "definition": scenarios._poly_shape(np.rint(pts * 20), fill), "matrix": mat})
     return dict(width=W, height=H, bitmaps=[bmp], stage={"children": kids})
+
+
+def rand_radial_scene(rng):
+    """One random frame of shapes with radial / focal gradient fills as the reference draws them (fill matrix maps the +-16384
+    gradient box onto the shape), 1-8 stops with translucent colours and duplicate ratios, on a clear frame and over each other.
+    The gradient circle is at least 0.6 frame diagonals wide and centred in the frame: samples stay inside pixman's 16.16 range."""
+    import scenarios
+    W, H = int(rng.integers(40, 200)), int(rng.integers(40, 140))
+    kids = []
+    for _ in range(int(rng.integers(1, 4))):
+        n = int(rng.integers(1, 9))
+        ratios = sorted(int(v) for v in rng.integers(0, 256, n))
+        if n > 2 and rng.integers(0, 3) == 0:
+            ratios[1] = ratios[0]
+        colors = [(ratios[i], (int(rng.integers(0, 256)), int(rng.integers(0, 256)), int(rng.integers(0, 256)), int(rng.choice([255, 255, 128, 0, 37])))) for i in range(n)]
+        ky = float(rng.uniform(0.5, 1.0))
+        sc = float(rng.uniform(0.6, 3.0)) * 20 / 16384 * float(np.hypot(W, H)) / ky
+        t = float(rng.uniform(-3.2, 3.2))
+        c, sn = np.cos(t), np.sin(t)
+        fill = {"type": "focal-gradient" if rng.integers(0, 2) else "radial-gradient", "gradient": scenarios._grad(colors),
+                "matrix": scenarios._m(sc * c, sc * ky * c, int(rng.integers(0, W * 20)), int(rng.integers(0, H * 20)), sc * sn, -sc * ky * sn)}
+        if fill["type"] == "focal-gradient":
+            fill["focal_point"] = {"epsilons": int(rng.integers(-240, 241))}   # Sfixed8P8: -0.94 .. 0.94
+        pts = rng.uniform(-0.1, 1.1, (int(rng.integers(3, 7)), 2)) * [W, H]
+        kids.append({"type": "shape", "definition": scenarios._poly_shape(np.rint(pts * 20), fill)})
+    return dict(width=W, height=H, stage={"children": kids})

@@ -89,14 +89,14 @@ def scenarios():
     circ = _circleish(1300, 1100, 1000)
     gm = _m(1000 / 16384, 1000 / 16384, 1300, 1100)
     rad = {"type": "radial-gradient", "matrix": gm, "gradient": _grad([(0, (255, 0, 0)), (128, (0, 255, 0)), (255, (0, 0, 255))])}
-    out["gradient_radial"] = dict(width=130, height=115, exact=False, stage={"children": [{"type": "shape", "definition": _poly_shape(circ, rad)}]})
+    out["gradient_radial"] = dict(width=130, height=115, exact=True, stage={"children": [{"type": "shape", "definition": _poly_shape(circ, rad)}]})
     foc = {"type": "focal-gradient", "matrix": gm, "focal_point": {"epsilons": 128},
            "gradient": _grad([(0, (255, 255, 255)), (255, (10, 20, 200))])}
-    out["gradient_focal"] = dict(width=130, height=115, exact=False, stage={"children": [{"type": "shape", "definition": _poly_shape(circ, foc)}]})
+    out["gradient_focal"] = dict(width=130, height=115, exact=True, stage={"children": [{"type": "shape", "definition": _poly_shape(circ, foc)}]})
     alp = {"type": "radial-gradient", "matrix": _m(1200 / 16384, 700 / 16384, 1300, 1100, 0.01, -0.02),
            "gradient": _grad([(0, (255, 200, 0, 255)), (100, (0, 100, 255, 60)), (255, (255, 0, 255, 200))])}
     back = _poly_shape([(100, 100), (2500, 300), (2300, 2200), (200, 1900)], {"type": "solid", "color": _rgba(40, 90, 20)})
-    out["gradient_alpha_over"] = dict(width=130, height=115, exact=False, stage={"children": [
+    out["gradient_alpha_over"] = dict(width=130, height=115, exact=True, stage={"children": [
         {"type": "shape", "definition": back}, {"type": "shape", "definition": _poly_shape(circ, alp)}]})
     lin = {"type": "linear-gradient", "matrix": _m(1000 / 16384, 1000 / 16384, 1300, 1100, 0.02, 0.0),
            "gradient": _grad([(0, (0, 0, 0)), (80, (255, 128, 0)), (255, (255, 255, 255))])}

@@ -293,3 +293,69 @@ def test_bitmap_scenes_through_the_canvas_replay(seed):
             rp.render(sc["stage"])
             imgs.append(be.premultiplied_rgba().astype(int)); be.close()
         assert np.array_equal(imgs[0], imgs[1]), (seed, it)
+
+
+@pytest.mark.parametrize("seed", [21, 22, 23, 24])
+def test_radial_gradient_fills(seed):
+    """Radial / focal gradients the way the renderer issues them (createRadialGradient(f * 16384, 0, 0, 0, 0, 16384) under the fill
+    matrix, 1-8 stops, translucent stops, duplicate offsets, shapes partly off the frame, on a clear frame and over other fills),
+    plus general two-circle gradients: cairo's fit-to-range scaling, pixman's 16.16 circles, exact integer B and C, the double root
+    and the single-precision colour ramp are all restated -- identical frames."""
+    rng = np.random.default_rng(seed)
+    painted = 0
+    for it in range(60):
+        W, H = int(rng.integers(30, 120)), int(rng.integers(30, 100))
+        ops = []
+        for k in range(int(rng.integers(1, 4))):
+            n = int(rng.integers(1, 9))
+            offs = np.sort(rng.integers(0, 256, n)) / 255.0
+            if n > 2 and rng.integers(0, 3) == 0:
+                offs[1] = offs[0]
+            stops = [(float(offs[i]), int(rng.integers(0, 256)), int(rng.integers(0, 256)), int(rng.integers(0, 256)),
+                      int(rng.choice([255, 255, 128, 0, 37]))) for i in range(n)]
+            # the gradient circle (radius 16384 units) is at least 0.6 frame diagonals wide along its short axis and centred
+            # inside the frame: every sample then stays within twice the radius, i.e. inside pixman's 16.16 range after cairo's
+            # range fitting (beyond that pixman_transform_point_3d fails and the reference stack leaves stale scanline bytes)
+            ky = rng.uniform(0.5, 1.0)
+            sc = rng.uniform(0.6, 3.0) * 20 / 16384 * float(np.hypot(W, H)) / ky
+            t = rng.uniform(-3.2, 3.2)
+            c, s_ = np.cos(t), np.sin(t)
+            fm = (sc * c * 16384 / 16384, sc * s_, -sc * ky * s_, sc * ky * c, float(rng.integers(0, W * 20)), float(rng.integers(0, H * 20)))
+            if rng.integers(0, 4) == 0:   # a general pair of circles in a small pattern space
+                circles = (float(rng.uniform(-40, 40)), float(rng.uniform(-40, 40)), float(rng.uniform(0, 20)),
+                           float(rng.uniform(-40, 40)), float(rng.uniform(-40, 40)), float(rng.uniform(20, 90)))
+                fm = (20.0 * c, 20.0 * s_, -20.0 * s_, 20.0 * c, fm[4], fm[5])
+            else:
+                focal = float(rng.choice([0.0, 0.0, rng.uniform(-0.95, 0.95)]))
+                circles = (focal * 16384, 0.0, 0.0, 0.0, 0.0, 16384.0)
+            pts = [(int(rng.integers(-300, W * 20 + 300)), int(rng.integers(-300, H * 20 + 300))) for _ in range(int(rng.integers(3, 7)))]
+            ops.append((fm, circles, stops, pts))
+        imgs = []
+        for be in (cb.CairoBackend(W, H), ob.OracleBackend(W, H)):
+            be.set_transform_identity(); be.clear_all(); be.scale(1 / 20, 1 / 20)
+            for fm, circles, stops, pts in ops:
+                be.begin_path(); be.move_to(*pts[0])
+                for q in pts[1:]:
+                    be.line_to(*q)
+                be.line_to(*pts[0])
+                be.save(); be.transform(*fm)
+                be.set_fill_radial(*circles, stops); be.fill(); be.restore()
+            imgs.append(be.premultiplied_rgba().astype(int)); be.close()
+        assert np.array_equal(imgs[0], imgs[1]), (seed, it, int(np.abs(imgs[0] - imgs[1]).max()), int((np.abs(imgs[0] - imgs[1]).max(-1) > 0).sum()))
+        painted += int((imgs[0][..., 3] > 0).sum())
+    assert painted > 20000
+
+
+@pytest.mark.parametrize("seed", [31, 32])
+def test_radial_scenes_through_the_canvas_replay(seed):
+    """The scenes of the GPU gradient fuzz (tests/helpers.py rand_radial_scene) rendered by libcairo and by the oracle: identical."""
+    from helpers import rand_radial_scene
+    from oracle import canvas_replay as cr
+    rng = np.random.default_rng(seed)
+    for it in range(40):
+        sc = rand_radial_scene(rng)
+        imgs = []
+        for be in (cb.CairoBackend(sc["width"], sc["height"]), ob.OracleBackend(sc["width"], sc["height"])):
+            cr.CanvasReplay(be, linear_extension=True).render(sc["stage"])
+            imgs.append(be.premultiplied_rgba().astype(int)); be.close()
+        assert np.array_equal(imgs[0], imgs[1]), (seed, it)
