@@ -98,37 +98,50 @@ __device__ __forceinline__ uint32_t pack_cell(int col_rel, int ch, int ua) {
     return (uint32_t)(col_rel & 255) | ((uint32_t)(ch & 255) << 8) | ((uint32_t)(ua & 0xffff) << 16);
 }
 // Cells of a FULL-row edge (A.5 render_edge) as a cell record, from the edge's exact x at the row top (q1 + r1/dy) and
-// bottom (q2 + r2/dy); false when the edge spans more than REC_MAX_CELLS columns
-__device__ __forceinline__ bool full_cells_ends(int32_t q1, int64_t r1, int32_t q2, int64_t r2, int64_t edy, int sign, Rec& rc) {
+// bottom (q2 + r2/dy), written straight into the record's slot in global memory (the cell index is a run-time value: a record
+// built in a local struct first would live in scratch memory); false -- nothing written -- when the edge spans more than
+// REC_MAX_CELLS columns
+__device__ __forceinline__ bool full_cells_ends(int32_t q1, int64_t r1, int32_t q2, int64_t r2, int64_t edy, int sign, Rec* __restrict__ dst) {
     int ix1 = q1 >> 8, f1 = q1 & 255, ix2 = q2 >> 8, f2 = q2 & 255;
-    uint32_t* cells = reinterpret_cast<uint32_t*>(&rc.q1);
     if (ix2 < ix1) { int t = ix1; ix1 = ix2; ix2 = t; t = f1; f1 = f2; f2 = t; int32_t tq = q1; q1 = q2; q2 = tq; int64_t tr = r1; r1 = r2; r2 = tr; }
     const int n = ix2 - ix1 + 1;
     if (n > REC_MAX_CELLS || ix1 < 0 || ix2 > 65534) return false;
-    rc.cols = clamp_col(ix1) | (clamp_col(ix2) << 16);
-    rc.roles = REC_CELLS | (uint32_t)n | ((uint32_t)((sign * 15) & 255) << 8);
-    if (n == 1) { cells[0] = pack_cell(0, sign * 15, sign * (f1 + f2) * 15); return true; }
+    const uint32_t cols = clamp_col(ix1) | (clamp_col(ix2) << 16);
+    const uint32_t roles = REC_CELLS | (uint32_t)n | ((uint32_t)((sign * 15) & 255) << 8);
+    uint32_t* cells = reinterpret_cast<uint32_t*>(&dst->q1);
+    if (n == 1) {                                           // header and the only cell in one 16-byte store
+        *reinterpret_cast<uint4*>(dst) = make_uint4(roles, cols, pack_cell(0, sign * 15, sign * (f1 + f2) * 15), 0u);
+        return true;
+    }
     const int64_t dx = (int64_t)(q2 - q1) * edy + (r2 - r1);
     const int64_t t0 = ((int64_t)((ix1 + 1) * 256 - q1) * edy - r1) * 15;
     const int64_t F = 15ll * 256 * edy;
     int64_t yq, yr, fq = 0, fr = 0;
     floor_div(t0, dx, yq, yr);
     if (n > 2) floor_div(F, dx, fq, fr);
-    int y_prev = 0;
-#pragma unroll 1
-    for (int k = 0; k < n - 1; ++k) {
-        if (k > 0) { yq += fq; yr += fr; if (yr >= dx) { ++yq; yr -= dx; } }
+    // first two cells with the header (every record has at least two here), the others one by one
+    const int h0 = (int)yq;
+    uint32_t c1;
+    int y_prev = h0;
+    if (n == 2) c1 = pack_cell(1, sign * (15 - y_prev), sign * (15 - y_prev) * f2);
+    else {
+        yq += fq; yr += fr; if (yr >= dx) { ++yq; yr -= dx; }
         const int h = (int)yq - y_prev;
-        cells[k] = pack_cell(k, sign * h, sign * h * (k == 0 ? 256 + f1 : 256));
+        c1 = pack_cell(1, sign * h, sign * h * 256);
         y_prev = (int)yq;
     }
-    cells[n - 1] = pack_cell(n - 1, sign * (15 - y_prev), sign * (15 - y_prev) * f2);
+    *reinterpret_cast<uint4*>(dst) = make_uint4(roles, cols, pack_cell(0, sign * h0, sign * h0 * (256 + f1)), c1);
+    if (n > 2) {
+#pragma unroll 1
+        for (int k = 2; k < n - 1; ++k) {
+            yq += fq; yr += fr; if (yr >= dx) { ++yq; yr -= dx; }
+            const int h = (int)yq - y_prev;
+            cells[k] = pack_cell(k, sign * h, sign * h * 256);
+            y_prev = (int)yq;
+        }
+        cells[n - 1] = pack_cell(n - 1, sign * (15 - y_prev), sign * (15 - y_prev) * f2);
+    }
     return true;
-}
-__device__ __forceinline__ bool full_cells(const DevEdge& e, int s0, int sign, Rec& rc) {
-    int32_t q1, q2; int64_t r1, r2;
-    full_row_ends(e, s0, q1, r1, q2, r2);
-    return full_cells_ends(q1, r1, q2, r2, e.dy, sign, rc);
 }
 
 // wave64 inclusive prefix sum with DPP row shifts + row broadcasts (no LDS traffic)
@@ -507,21 +520,22 @@ __device__ __forceinline__ void rows_chunk_body(uint32_t block, const DevEdge* _
 #pragma unroll
         for (int s = 0; s < ROWS_FAST_N; ++s) {
             if (s < n && roles[s] != 0) {
-                Rec rc;
                 const uint32_t eidx = use_lds ? ((uint32_t)staged_id[el[s]] | ((uint32_t)staged_hi[el[s]] << 16)) : (uint32_t)el[s];
                 if ((uint32_t)roles[s] & REC_FULL) {     // end points are already known: cells, or the generic FULL record
                     const int64_t edy = use_lds ? staged[el[s]].dy : edges[P.first_edge + el[s]].dy;
                     bool as_cells = false;
-                    if (cell_mode & 1) as_cells = full_cells_ends(Q1[s], R1[s], Q2[s], R2[s], edy, ((uint32_t)roles[s] & 1u) ? +1 : -1, rc);
+                    if (cell_mode & 1) as_cells = full_cells_ends(Q1[s], R1[s], Q2[s], R2[s], edy, ((uint32_t)roles[s] & 1u) ? +1 : -1, &records[off]);
                     if (!as_cells) {
+                        Rec rc;
                         rc.roles = (uint32_t)roles[s]; rc.cols = (uint32_t)cols[s]; rc.eid = P.first_edge + eidx; rc.dy = edy; rc.span = 0;
                         rc.q1 = Q1[s]; rc.r1 = R1[s]; rc.q2 = Q2[s]; rc.r2 = R2[s];
+                        records[off] = rc;
                     }
                 } else {
                     const DevEdge e = use_lds ? staged[el[s]] : edges[P.first_edge + el[s]];
-                    rc = make_record(e, P.first_edge + eidx, r * 15, (uint32_t)roles[s], (uint32_t)cols[s]);
+                    records[off] = make_record(e, P.first_edge + eidx, r * 15, (uint32_t)roles[s], (uint32_t)cols[s]);
                 }
-                records[off++] = rc;
+                ++off;
             }
         }
     }
@@ -707,16 +721,16 @@ __device__ __forceinline__ void rows_by_slot(EPTR E, uint32_t n_list, const uint
     if (has) {
         const uint32_t off = ck.rec_base + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
         const uint32_t eidx = staged_k ? staged_k[my_k] : (uint32_t)my_k;
-        Rec rc;
         if (role & REC_FULL) {
             bool as_cells = false;
-            if (cell_mode & 1) as_cells = full_cells_ends(q1, r1, q2, r2, e.dy, (role & 1u) ? +1 : -1, rc);
+            if (cell_mode & 1) as_cells = full_cells_ends(q1, r1, q2, r2, e.dy, (role & 1u) ? +1 : -1, &records[off]);
             if (!as_cells) {
+                Rec rc;
                 rc.roles = role; rc.cols = cols; rc.eid = P.first_edge + eidx; rc.dy = e.dy; rc.span = 0;
                 rc.q1 = q1; rc.r1 = r1; rc.q2 = q2; rc.r2 = r2;
+                records[off] = rc;
             }
-        } else rc = make_record(e, P.first_edge + eidx, s0, role, cols);
-        records[off] = rc;
+        } else records[off] = make_record(e, P.first_edge + eidx, s0, role, cols);
     }
     if (slot == 0 && in_path && !overflow) {
         RowInfo ri;
@@ -742,9 +756,9 @@ __device__ __forceinline__ void rows_rs_body(uint32_t block, const DevEdge* __re
     bool use_lds = true;
     for (uint32_t eb = 0; eb < P.n_edges; eb += 64) {
         const uint32_t k = eb + (uint32_t)lane;
-        DevEdge ek;
-        bool hit = false;
-        if (k < P.n_edges) { ek = edges[P.first_edge + k]; hit = ek.ytop < hi_s && ek.ybot > lo_s; }
+        // (read unconditionally from a clamped index: a struct assigned under a branch ends up in scratch memory)
+        const DevEdge ek = edges[P.first_edge + min(k, P.n_edges - 1u)];
+        const bool hit = k < P.n_edges && ek.ytop < hi_s && ek.ybot > lo_s;
         const unsigned long long hb = __ballot(hit);
         const uint32_t at = n_list + (uint32_t)__popcll(hb & ((1ull << lane) - 1ull));
         if (hit && at < ROWS_STAGE) { staged[at] = ek; staged_k[at] = k; }
@@ -886,16 +900,16 @@ __device__ __forceinline__ void big_row_body(uint32_t block, const DevEdge* __re
     const unsigned long long hm = __ballot(has);
     if (has) {
         const uint32_t off = br.rec_base + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
-        Rec rc;
         if (role & REC_FULL) {
             bool as_cells = false;
-            if (cell_mode & 1) as_cells = full_cells_ends(q1, r1, q2, r2, e.dy, (role & 1u) ? +1 : -1, rc);
+            if (cell_mode & 1) as_cells = full_cells_ends(q1, r1, q2, r2, e.dy, (role & 1u) ? +1 : -1, &records[off]);
             if (!as_cells) {
+                Rec rc;
                 rc.roles = role; rc.cols = cols; rc.eid = P.first_edge + k_mine; rc.dy = e.dy; rc.span = 0;
                 rc.q1 = q1; rc.r1 = r1; rc.q2 = q2; rc.r2 = r2;
+                records[off] = rc;
             }
-        } else rc = make_record(e, P.first_edge + k_mine, s0, role, cols);
-        records[off] = rc;
+        } else records[off] = make_record(e, P.first_edge + k_mine, s0, role, cols);
     }
     if (lane == 0) { ri.n_rec = (uint16_t)__popcll(hm); ri.mode = (uint16_t)mode; rows[t] = ri; }
 }
@@ -1065,20 +1079,20 @@ __global__ __launch_bounds__(256) void k_rows_huge(const DevEdge* __restrict__ e
             for (int w = 0; w < wave; ++w) off += wave_cnt[w];
             const uint32_t k_mine = active[j];
             const DevEdge e = E[k_mine];
-            Rec rc;
             if (role[m] & REC_FULL) {
                 int c0, c1, cpv; int32_t q1, q2; int64_t r1, r2;
                 huge_full_keys(e, s0, c0, c1, cpv, q1, r1, q2, r2);
                 const int a = q1 >> 8, b = q2 >> 8;
                 const uint32_t fcols = clamp_col(min(a, b)) | (clamp_col(max(a, b)) << 16);
                 bool as_cells = false;
-                if (cell_mode & 1) as_cells = full_cells_ends(q1, r1, q2, r2, e.dy, (role[m] & 1u) ? +1 : -1, rc);
+                if (cell_mode & 1) as_cells = full_cells_ends(q1, r1, q2, r2, e.dy, (role[m] & 1u) ? +1 : -1, &records[off]);
                 if (!as_cells) {
+                    Rec rc;
                     rc.roles = role[m]; rc.cols = fcols; rc.eid = P.first_edge + k_mine; rc.dy = e.dy; rc.span = 0;
                     rc.q1 = q1; rc.r1 = r1; rc.q2 = q2; rc.r2 = r2;
+                    records[off] = rc;
                 }
-            } else rc = make_record(e, P.first_edge + k_mine, s0, role[m], cols[m]);
-            records[off] = rc;
+            } else records[off] = make_record(e, P.first_edge + k_mine, s0, role[m], cols[m]);
         }
         emitted += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
         __syncthreads();                                             // wave_cnt is rewritten by the next block
@@ -1684,7 +1698,9 @@ __device__ __forceinline__ void tiles_body(const swfr_edge* __restrict__ raw_edg
                     // row headers: lane = (path of the batch, row of the strip)
                     uint32_t my_cnt = 0, off = 0;
                     {
-                        const int bp = lane / STRIP_H, row = lane % STRIP_H;
+                        int lv = lane;
+                        asm volatile("" : "+v"(lv));                       // as below: keep this address arithmetic out of the prologue
+                        const int bp = lv / STRIP_H, row = lv % STRIP_H;
                         if (bp < batch_n) {
                             const int mine = plist[bp];
                             const uint32_t myw = ent[mine][2];
@@ -1737,7 +1753,11 @@ __device__ __forceinline__ void tiles_body(const swfr_edge* __restrict__ raw_edg
                         for (int d0 = 0; d0 < wn * 12; d0 += 64 * 6) {
                             uint32_t tmp[6];
                             // dword d = d0 + 64 u + lane is word w of staged record t: (t, w) advance by (5, 4) per u, no divisions
-                            int t = d0 / 12 + lane_t, w = lane_w;          // d0 is a multiple of 384 = 32 records
+                            // (the lane's position is made opaque here: otherwise the compiler hoists the twelve per-lane addresses of
+                            //  this loop to the kernel's prologue and spills them -- scratch stores in every wavefront, used by few)
+                            int lt = lane_t, lw = lane_w;
+                            asm volatile("" : "+v"(lt), "+v"(lw));
+                            int t = d0 / 12 + lt, w = lw;                  // d0 is a multiple of 384 = 32 records
 #pragma unroll
                             for (int u = 0; u < 6; ++u) {
                                 const int d = d0 + u * 64 + lane;
@@ -1836,11 +1856,11 @@ __device__ __forceinline__ void tiles_body(const swfr_edge* __restrict__ raw_edg
                         }
                         if (nq <= (dbg == 15 ? 12 : BLEND_QUEUE)) {            // wave-uniform; more edge pixels: the per-row path below
                             uint2* q = reinterpret_cast<uint2*>(&A[0][0]);
-                            int qi[P2B];
+                            // (the slot of a queued pixel is recomputed when its result is read back: eight live registers less)
 #pragma unroll
                             for (int u = 0; u < P2B; ++u) {
-                                qi[u] = qbase[u] + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(pmask[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pmask[u], 0u));
-                                if ((pmask[u] >> lane) & 1ull) q[qi[u]] = make_uint2(al[u], px[u]);
+                                const int qi = qbase[u] + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(pmask[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pmask[u], 0u));
+                                if ((pmask[u] >> lane) & 1ull) q[qi] = make_uint2(al[u], px[u]);
                             }
                             __syncthreads();
                             for (int b = lane; b < nq; b += 64) {
@@ -1849,8 +1869,10 @@ __device__ __forceinline__ void tiles_body(const swfr_edge* __restrict__ raw_edg
                             }
                             __syncthreads();
 #pragma unroll
-                            for (int u = 0; u < P2B; ++u)
-                                if ((pmask[u] >> lane) & 1ull) px[u] = q[qi[u]].x;
+                            for (int u = 0; u < P2B; ++u) {
+                                const int qi = qbase[u] + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(pmask[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pmask[u], 0u));
+                                if ((pmask[u] >> lane) & 1ull) px[u] = q[qi].x;
+                            }
                             __syncthreads();
                             for (int b = lane; b < nq; b += 64) q[b] = make_uint2(0u, 0u);   // the accumulator is handed back empty
                             blended = true;
