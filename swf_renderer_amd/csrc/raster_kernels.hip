@@ -265,7 +265,7 @@ __device__ __forceinline__ void fast_rows(EPTR E, uint32_t n_list, const DevPath
                                           uint32_t& mode_out, int& n_out_edges, bool& overflow_out,
                                           int32_t (&roles)[ROWS_FAST_N], int32_t (&cols)[ROWS_FAST_N], int (&el)[ROWS_FAST_N],
                                           int32_t (&Q1)[ROWS_FAST_N], int64_t (&R1)[ROWS_FAST_N], int32_t (&Q2)[ROWS_FAST_N], int64_t (&R2)[ROWS_FAST_N],
-                                          uint32_t* rph, unsigned long long& rph_t) {
+                                          uint32_t* rph, unsigned long long& rph_t, int& nmax_out) {
     (void)rph; (void)rph_t;
     const int s0 = r * 15;
     const unsigned mask = P.fill_rule ? 1u : ~0u;
@@ -290,11 +290,13 @@ __device__ __forceinline__ void fast_rows(EPTR E, uint32_t n_list, const DevPath
     RPHASE(2);
     // wave-uniform bound on the active edges of any row of this wave: the unrolled slot loops stop there
     const int nmax = __ballot(n > 6) ? 8 : __ballot(n > 4) ? 6 : __ballot(n > 2) ? 4 : 2;
+    nmax_out = nmax;
     // ---- rows that can still be FULL: x of every active edge at the first sample row of this pixel row and of the next
     //      (one reciprocal multiply + integer fix-up each); kept as the exact row-top / row-bottom end points for the records
     if (n > 0 && !mid_row) {
 #pragma unroll
         for (int s = 0; s < ROWS_FAST_N; ++s) {
+            if (s >= nmax) continue;                          // wave-uniform
             if (s >= n) continue;
             const DevEdge e = E[el[s]];
             int32_t qa = e.x1, qb = e.x1; int64_t ra = 0, rb = 0;
@@ -369,7 +371,10 @@ __device__ __forceinline__ void fast_rows(EPTR E, uint32_t n_list, const DevPath
             mode = ROW_SUB;
             is_sub = true;
 #pragma unroll
-            for (int s = 0; s < ROWS_FAST_N; ++s) { F.eid[s][lane] = (uint16_t)el[s]; F.roles[s][lane] = 0; F.clo[s][lane] = 65535; F.chi[s][lane] = 0; }
+            for (int s = 0; s < ROWS_FAST_N; ++s) {
+                if (s >= nmax) continue;                      // wave-uniform: the sample lanes stop at nmax as well
+                F.eid[s][lane] = (uint16_t)el[s]; F.roles[s][lane] = 0; F.clo[s][lane] = 65535; F.chi[s][lane] = 0;
+            }
         }
     }
     __syncthreads();                                          // F.* written by the row owners, read by the sample lanes
@@ -433,7 +438,10 @@ __device__ __forceinline__ void fast_rows(EPTR E, uint32_t n_list, const DevPath
     __syncthreads();                                          // role bits OR-ed in by the sample lanes
     if (is_sub) {
 #pragma unroll
-        for (int s = 0; s < ROWS_FAST_N; ++s) { roles[s] = F.roles[s][lane]; cols[s] = (int32_t)((uint32_t)F.clo[s][lane] | ((uint32_t)F.chi[s][lane] << 16)); }
+        for (int s = 0; s < ROWS_FAST_N; ++s) {
+            if (s >= nmax) continue;                          // (roles of the slots beyond stay 0)
+            roles[s] = F.roles[s][lane]; cols[s] = (int32_t)((uint32_t)F.clo[s][lane] | ((uint32_t)F.chi[s][lane] << 16));
+        }
     }
     RPHASE(5);
     mode_out = mode; n_out_edges = n; overflow_out = overflow;
@@ -502,14 +510,14 @@ __device__ __forceinline__ void rows_chunk_body(uint32_t block, const DevEdge* _
     }
     __syncthreads();
     RPHASE(1);
-    uint32_t mode; int n; bool overflow;
+    uint32_t mode; int n, nmax = ROWS_FAST_N; bool overflow;
     int32_t roles[ROWS_FAST_N], cols[ROWS_FAST_N]; int el[ROWS_FAST_N];
     int32_t Q1[ROWS_FAST_N], Q2[ROWS_FAST_N]; int64_t R1[ROWS_FAST_N], R2[ROWS_FAST_N];
-    if (use_lds) fast_rows((const DevEdge*)staged, n_list, P, r, live, fast_limit, F, lane, mode, n, overflow, roles, cols, el, Q1, R1, Q2, R2, rph, rph_t);
-    else fast_rows(edges + P.first_edge, P.n_edges, P, r, live, fast_limit, F, lane, mode, n, overflow, roles, cols, el, Q1, R1, Q2, R2, rph, rph_t);
+    if (use_lds) fast_rows((const DevEdge*)staged, n_list, P, r, live, fast_limit, F, lane, mode, n, overflow, roles, cols, el, Q1, R1, Q2, R2, rph, rph_t, nmax);
+    else fast_rows(edges + P.first_edge, P.n_edges, P, r, live, fast_limit, F, lane, mode, n, overflow, roles, cols, el, Q1, R1, Q2, R2, rph, rph_t, nmax);
     uint32_t n_out = 0;
 #pragma unroll
-    for (int s = 0; s < ROWS_FAST_N; ++s) n_out += (s < n && roles[s] != 0) ? 1u : 0u;
+    for (int s = 0; s < ROWS_FAST_N; ++s) n_out += (s < nmax && s < n && roles[s] != 0) ? 1u : 0u;
     // ---- record slots: the chunk owns [rec_base, rec_base + bound); lanes take consecutive pieces (no atomics)
     const uint32_t incl = (uint32_t)wave_scan_incl((int)n_out);
     const uint32_t base = ck.rec_base;
@@ -519,6 +527,7 @@ __device__ __forceinline__ void rows_chunk_body(uint32_t block, const DevEdge* _
         rows[t] = ri;
 #pragma unroll
         for (int s = 0; s < ROWS_FAST_N; ++s) {
+            if (s >= nmax) continue;                                     // wave-uniform: no row of this wave has that many edges
             if (s < n && roles[s] != 0) {
                 const uint32_t eidx = use_lds ? ((uint32_t)staged_id[el[s]] | ((uint32_t)staged_hi[el[s]] << 16)) : (uint32_t)el[s];
                 if ((uint32_t)roles[s] & REC_FULL) {     // end points are already known: cells, or the generic FULL record
@@ -579,6 +588,7 @@ __device__ __forceinline__ void rows_chunk_body(uint32_t block, const DevEdge* _
                     bool inter = false;
 #pragma unroll
                     for (int s2 = 0; s2 < ROWS_FAST_N; ++s2) {
+                        if (s2 >= nmax) continue;                        // wave-uniform
                         if (s2 >= n || roles[s2] == 0) continue;
                         const int clo = (int)((uint32_t)cols[s2] & 0xffffu), chi = (int)((uint32_t)cols[s2] >> 16);
                         if (chi < tx0 && chi < 65535) carry += record_height((uint32_t)roles[s2]);
