@@ -304,6 +304,23 @@ def image_to_pam(width: int, height: int, rgba: bytes) -> bytes:
     return header.encode("ascii") + rgba
 
 
+def image_to_png(width: int, height: int, rgba: bytes) -> bytes:
+    """Straight RGBA8 -> PNG (8-bit RGBA, filter 0 on every row): what the reference's test harness keeps next to its goldens
+    (`canvas.toBuffer("image/png")`, ts/src/test/node-canvas-renderer.spec.ts:67-84); the pixels round-trip exactly."""
+    import struct
+    import zlib
+    rgba = bytes(rgba)
+    if len(rgba) != width * height * 4:
+        raise ValueError("image_to_png: data length does not match the dimensions")
+
+    def chunk(tag, body):
+        return struct.pack(">I", len(body)) + tag + body + struct.pack(">I", zlib.crc32(tag + body) & 0xffffffff)
+
+    rows = b"".join(b"\x00" + rgba[y * width * 4:(y + 1) * width * 4] for y in range(height))
+    return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", width, height, 8, 6, 0, 0, 0)) +
+            chunk(b"IDAT", zlib.compress(rows, 6)) + chunk(b"IEND", b""))
+
+
 def decode_x_swf_bmp(data: bytes):
     """`image/x-swf-bmp` format 3 (zlib colour-mapped) -> (width, height, straight RGBA bytes).
 
@@ -481,6 +498,12 @@ class Renderer:
         img = self.read_image(premultiplied=False)
         with open(path, "wb") as f:
             f.write(image_to_pam(self.width, self.height, np.ascontiguousarray(img).tobytes()))
+
+    def write_png(self, path: str) -> None:
+        """Dumps the last frame (straight RGBA) as PNG -- the format of the reference's golden images."""
+        img = self.read_image(premultiplied=False)
+        with open(path, "wb") as f:
+            f.write(image_to_png(self.width, self.height, np.ascontiguousarray(img).tobytes()))
 
     def read_image(self, premultiplied=False) -> np.ndarray:
         """HxWx4 uint8 RGBA; straight (as the reference's PNG/getImageData) unless premultiplied=True."""

@@ -121,6 +121,19 @@ def test_frame_edges_equal_oracle_polygons(name):
     tap.close()
 
 
+def test_png_writer_round_trips_through_a_png_decoder():
+    """image_to_png: the reference's golden images are PNGs; ours decode to the same straight RGBA bytes."""
+    import io
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    for w, h in ((1, 1), (7, 3), (54, 81)):
+        px = rng.integers(0, 256, (h, w, 4)).astype(np.uint8)
+        back = np.asarray(Image.open(io.BytesIO(api.image_to_png(w, h, px.tobytes()))).convert("RGBA"))
+        assert np.array_equal(back, px)
+    with pytest.raises(ValueError):
+        api.image_to_png(2, 2, b"\x00" * 15)
+
+
 def test_fuzz_bitmap_scenes_edges_equal_oracle():
     """Bitmap fills: a non-repeating bitmap bounds its fill by its own device-space extents, which become the polygon limits --
     the frame builder must clip exactly as the oracle (and Cairo) does."""
