@@ -230,6 +230,11 @@ int  swfr_last_timing(swfr_renderer *r, swfr_timing *out);
    DEVICE buffer (e.g. a torch tensor's data_ptr) so that the caller can gather it with RCCL. */
 size_t swfr_band_slab_bytes(const swfr_renderer *r);
 int  swfr_copy_band_slab(swfr_renderer *r, void *device_dst);
+
+/* Diagnostics (tools/soak_case.py): copies an intermediate buffer of the last rendered frame to the host.
+   what = 0: row headers (8 bytes per (path, pixel row): record offset u32, count u16, mode u16); 1: records (48 bytes each).
+   Returns the number of bytes copied (at most `bytes`), or a negative SWFR_ERR_*. */
+long swfr_debug_copy(swfr_renderer *r, int what, void *dst, size_t bytes);
 /* Device pointer of the premultiplied RGBA8 framebuffer (width*height*4 bytes, tight rows). */
 void *swfr_device_framebuffer(swfr_renderer *r);
 

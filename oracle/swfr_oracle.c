@@ -1696,11 +1696,15 @@ typedef struct { fx_t x; fx_t top, bottom; int dir; } vedge_t;
 static int cmp_fx(const void *a, const void *b) { fx_t x = *(const fx_t *)a, y = *(const fx_t *)b; return (x > y) - (x < y); }
 static int cmp_vedge(const void *a, const void *b) { const vedge_t *x = a, *y = b; return (x->x > y->x) - (x->x < y->x); }
 
-static void boxes_render(swfo_ctx *c, const polygon_t *g, int even_odd, int lerp_mode)
+/* both painters return 1 when the operation counts as drawn (the surface is no longer clear afterwards) and 0 for
+   CAIRO_INT_STATUS_NOTHING_TO_DO: the geometry's extents miss the operation's bounded rectangle (trim_extents_to_polygon /
+   trim_extents_to_boxes), e.g. a stroke whose approximate extents touch the frame while its outline lies outside.  No boxes at
+   all is "success" in clip_and_composite_boxes (probe: the next translucent fill then takes the OVER path). */
+static int boxes_render(swfo_ctx *c, const polygon_t *g, int even_odd, int lerp_mode)
 {
     /* exact area of the fill region per pixel: c = sum wx*wy over disjoint boxes, alpha = (c>>8)-(c>>16) */
     int n = g->n;
-    if (!n) return;
+    if (!n) return 1;
     vedge_t *ve = malloc(sizeof(vedge_t) * n);
     fx_t *ys = malloc(sizeof(fx_t) * 2 * n);
     for (int i = 0; i < n; i++) {
@@ -1712,7 +1716,7 @@ static void boxes_render(swfo_ctx *c, const polygon_t *g, int even_odd, int lerp
     int px0 = fx_floor_i(g->x1.x), px1 = fx_ceil_i(g->x2.x), py0 = fx_floor_i(g->x1.y), py1 = fx_ceil_i(g->x2.y);
     if (px0 < c->bx0) px0 = c->bx0; if (py0 < c->by0) py0 = c->by0; if (px1 > c->bx1) px1 = c->bx1; if (py1 > c->by1) py1 = c->by1;
     int bw = px1 - px0, bh = py1 - py0;
-    if (bw <= 0 || bh <= 0) { free(ve); free(ys); return; }
+    if (bw <= 0 || bh <= 0) { free(ve); free(ys); return 0; }
     if (c->src.kind == SRC_SURFACE) source_prepare_pixman(&c->src, px0, py0, px1, py1);
     if (c->src.kind == SRC_RADIAL) source_prepare_radial(&c->src, px0, py0, px1, py1);
     uint32_t *acc = calloc((size_t)bw * bh, sizeof(uint32_t));
@@ -1756,6 +1760,7 @@ static void boxes_render(swfo_ctx *c, const polygon_t *g, int even_odd, int lerp
         }
     }
     free(acc); free(ve); free(ys);
+    return 1;
 }
 
 /* ------------------------------------------------------------------ draw ops */
@@ -1820,17 +1825,18 @@ static void remember_polygon(swfo_ctx *c, const polygon_t *g, int rectilinear)
         o[0] = e->p1.x; o[1] = e->p1.y; o[2] = e->p2.x; o[3] = e->p2.y; o[4] = e->top; o[5] = e->bottom; o[6] = e->dir;
     }
 }
-static void render_polygon(swfo_ctx *c, polygon_t *g, int even_odd)
+static int render_polygon(swfo_ctx *c, polygon_t *g, int even_odd)
 {
     ensure_scratch(c);
-    if (!g->n) return;
+    if (!g->n) return 0;
     int lerp_mode = source_is_opaque_solid(&c->src) || c->is_clear;
     int xmin = fx_floor_i(g->x1.x), xmax = fx_ceil_i(g->x2.x), ymin = fx_floor_i(g->x1.y), ymax = fx_ceil_i(g->x2.y);
     if (xmin < c->bx0) xmin = c->bx0; if (ymin < c->by0) ymin = c->by0; if (xmax > c->bx1) xmax = c->bx1; if (ymax > c->by1) ymax = c->by1;
-    if (xmin >= xmax || ymin >= ymax) return;
+    if (xmin >= xmax || ymin >= ymax) return 0;
     if (c->src.kind == SRC_SURFACE) source_prepare_pixman(&c->src, xmin, ymin, xmax, ymax);
     if (c->src.kind == SRC_RADIAL) source_prepare_radial(&c->src, xmin, ymin, xmax, ymax);
     tor_render(c, g, even_odd, lerp_mode, xmin, ymin, xmax, ymax);
+    return 1;
 }
 
 EXPORT int swfo_fill_preserve(swfo_ctx *c)
@@ -1846,13 +1852,14 @@ EXPORT int swfo_fill_preserve(swfo_ctx *c)
     polygon_init(&g, needs_limits, l1, l2);
     path_fill_to_polygon(p, 0.1, &g);
     remember_polygon(c, &g, path_fill_is_rectilinear(p));
+    int drawn;
     if (path_fill_is_rectilinear(p)) {
         int lerp_mode = source_is_opaque_solid(&c->src) || c->is_clear;
-        boxes_render(c, &g, gs->fill_rule, lerp_mode);
+        drawn = boxes_render(c, &g, gs->fill_rule, lerp_mode);
     } else
-        render_polygon(c, &g, gs->fill_rule);
+        drawn = render_polygon(c, &g, gs->fill_rule);
     free(g.e);
-    c->is_clear = 0;
+    if (drawn) c->is_clear = 0;
     return 0;
 }
 
@@ -1890,9 +1897,8 @@ EXPORT int swfo_stroke_preserve(swfo_ctx *c)
         if (path_stroke_rectilinear(p, &gs->ctm, gs->line_width, gs->join, gs->cap, gs->miter_limit, &g)) {
             remember_polygon(c, &g, 1);
             int lerp_mode = source_is_opaque_solid(&c->src) || c->is_clear;
-            boxes_render(c, &g, 0, lerp_mode);
+            if (boxes_render(c, &g, 0, lerp_mode)) c->is_clear = 0;
             free(g.e);
-            c->is_clear = 0;
             return 0;
         }
         g.n = 0;
@@ -1913,9 +1919,8 @@ EXPORT int swfo_stroke_preserve(swfo_ctx *c)
     }
     c->last_unsupported = path_stroke_to_polygon(p, &s);
     remember_polygon(c, &g, 0);
-    render_polygon(c, &g, 0);
+    if (render_polygon(c, &g, 0)) c->is_clear = 0;
     free(g.e); free(s.cw.p); free(s.ccw.p);
-    c->is_clear = 0;
     return c->last_unsupported;
 }
 

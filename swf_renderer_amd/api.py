@@ -26,7 +26,7 @@ EXPORTS = [
     "swfr_abi_version", "swfr_create", "swfr_destroy", "swfr_last_error", "swfr_register_shape",
     "swfr_register_morph_shape", "swfr_register_bitmap", "swfr_render", "swfr_render_batch", "swfr_read_image", "swfr_upload_edges",
     "swfr_render_resident", "swfr_render_edges", "swfr_build_frame", "swfr_shape_json", "swfr_last_timing",
-    "swfr_band_slab_bytes", "swfr_copy_band_slab", "swfr_device_framebuffer",
+    "swfr_band_slab_bytes", "swfr_copy_band_slab", "swfr_device_framebuffer", "swfr_debug_copy",
 ]
 
 
@@ -181,6 +181,8 @@ def load_library():
     L.swfr_band_slab_bytes.argtypes = [P]
     L.swfr_copy_band_slab.restype = I
     L.swfr_copy_band_slab.argtypes = [P, P]
+    L.swfr_debug_copy.restype = C.c_long
+    L.swfr_debug_copy.argtypes = [P, I, P, C.c_size_t]
     L.swfr_device_framebuffer.restype = P
     L.swfr_device_framebuffer.argtypes = [P]
     if L.swfr_abi_version() != 1:

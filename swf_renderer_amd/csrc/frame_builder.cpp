@@ -175,8 +175,13 @@ uint32_t FrameBuilder::push_solid(uint32_t pixel) {
 
 void FrameBuilder::emit_polygon(Polygon& poly, bool rectilinear, uint32_t style, bool opaque_solid, int bx0, int by0, int bx1, int by1) {
     const bool lerp_blend = opaque_solid || surface_clear_;
-    surface_clear_ = false;  // any drawing op that was not "nothing to do" dirties the surface
-    if (poly.empty()) return;
+    // Cairo: geometry whose extents miss the operation's rectangle is NOTHING_TO_DO and leaves the surface's "clear" state alone
+    // (trim_extents_to_polygon / _to_boxes) -- e.g. a stroke whose approximate extents touch the frame while its outline does
+    // not; a rectilinear path that yields no boxes at all counts as drawn (clip_and_composite_boxes)
+    if (poly.empty()) {
+        if (rectilinear) surface_clear_ = false;
+        return;
+    }
     swfr_path p;
     std::memset(&p, 0, sizeof p);
     p.first_edge = uint32_t(edges_.size());
@@ -189,6 +194,7 @@ void FrameBuilder::emit_polygon(Polygon& poly, bool rectilinear, uint32_t style,
     p.x_max = std::min(ceil_px(poly.ext_max().x), std::min(bx1, int(w_)));
     p.y_max = std::min(ceil_px(poly.ext_max().y), std::min(by1, int(h_)));
     if (p.x_min >= p.x_max || p.y_min >= p.y_max) return;
+    surface_clear_ = false;
     if (rectilinear) {
         p.kind = SWFR_PATH_BOXES;
         rectilinear_to_boxes(poly, even_odd_, edges_);

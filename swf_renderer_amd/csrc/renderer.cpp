@@ -1012,6 +1012,18 @@ int swfr_copy_band_slab(swfr_renderer* r, void* device_dst) {
     });
 }
 
+long swfr_debug_copy(swfr_renderer* r, int what, void* dst, size_t bytes) {
+    if (!r || !dst) return -long(SWFR_ERR_INVALID);
+    if (!r->has_device) return -long(SWFR_ERR_NO_DEVICE);
+    const swfr_renderer::FrameSet& F = r->fs[0];
+    const void* src = what == 0 ? static_cast<const void*>(F.d_rows.ptr) : static_cast<const void*>(F.d_records.ptr);
+    const size_t have = what == 0 ? F.d_rows.cap * sizeof(RowInfo) : F.d_records.cap * sizeof(Rec);
+    const size_t n = std::min(bytes, have);
+    if (!src || !n) return 0;
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(dst, src, n, hipMemcpyDeviceToHost) != hipSuccess) return -long(SWFR_ERR_DEVICE);
+    return long(n);
+}
+
 void* swfr_device_framebuffer(swfr_renderer* r) { return (r && r->has_device) ? (r->fb_cur ? r->fb_cur : r->fs[0].d_fb.ptr) : nullptr; }
 
 #pragma GCC visibility pop

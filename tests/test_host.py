@@ -20,7 +20,7 @@ SC = scenarios.scenarios()
 
 def test_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "swfr.h")).read()
-    declared = set(re.findall(r"^(?:int|void|const char \*|uint32_t|size_t|void \*)\s*\*?(swfr_[a-z_]+)\s*\(", header, re.M))
+    declared = set(re.findall(r"^(?:int|long|void|const char \*|uint32_t|size_t|void \*)\s*\*?(swfr_[a-z_]+)\s*\(", header, re.M))
     assert declared == set(api.EXPORTS), declared ^ set(api.EXPORTS)
     L = S.load_library()
     for name in declared:
