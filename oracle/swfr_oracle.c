@@ -19,6 +19,7 @@
  * Sections:  [A.1] fixed point  [A.2] path  [A.3] spline  [A.5b] polygon + limits
  *            [A.8] stroker      [A.5] tor scan converter  [A.6] boxes  [A.7] compositing
  */
+#include <stdio.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -1257,7 +1258,7 @@ typedef struct swfo_ctx {
     gstate_t gs[64]; int ngs;
     path_t path;
     source_t src;
-    int last_unsupported;
+    int last_unsupported, trace_rows;
     /* scratch */
     int32_t *ch, *ua; int *touched; int ntouched; uint8_t *tmark;
     uint8_t *rowcov;
@@ -1674,6 +1675,11 @@ static void tor_render(swfo_ctx *c, const polygon_t *g, int even_odd, int lerp_m
             if (a.head.next == &a.tail) continue;
             do_full = can_do_full_row(&a);
         }
+        if (c->trace_rows) {                                /* SWFO_TRACE_ROWS: row modes and the active list, for tools/soak_case.py */
+            fprintf(stderr, "row %d full %d :", ymin + i, do_full);
+            for (tedge_t *e = a.head.next; e != &a.tail; e = e->next) fprintf(stderr, " [cell %d dir %d left %d]", e->cell, e->dir, e->height_left);
+            fprintf(stderr, "\n");
+        }
         if (do_full) full_row(&a, mask);
         else {
             for (int sub = 0; sub < GRID_Y; sub++) {
@@ -1933,6 +1939,7 @@ EXPORT swfo_ctx *swfo_create(int w, int h)
     c->gs[0].line_width = 2.0; c->gs[0].miter_limit = 10.0; c->gs[0].cap = 0; c->gs[0].join = 0; c->gs[0].fill_rule = 0;
     path_reset(&c->path);
     c->src.kind = SRC_SOLID; c->src.pixel = 0xff000000u;
+    c->trace_rows = getenv("SWFO_TRACE_ROWS") != NULL;
     return c;
 }
 EXPORT void swfo_destroy(swfo_ctx *c)

@@ -243,6 +243,21 @@ __global__ __launch_bounds__(256) void k_front(const swfr_edge* __restrict__ in,
 #define ROWS_BIG_MAXA 64         // capacity of the generic (LDS list) routine in k_rows_big
 #define ROWS_STAGE 64            // paths with at most this many edges are staged into LDS
 
+// Order of two active edges a, b whose cells coincide at sample row s0 and at s0 - 1: a sorts first iff it had the smaller cell at
+// the last earlier sample row where the two differed (Cairo's list is re-sorted whenever a cell order is violated and left alone
+// on ties); if they never differed since the later one became active, the one that became active earlier, else path order.
+__device__ __forceinline__ bool tied_order(const DevEdge& a, const DevEdge& b, int s0, bool path_order) {
+    const int lo = max(a.ytop, b.ytop);
+    for (int s = s0 - 2; s >= lo; --s) {
+        int ca = a.x1, cb = b.x1;
+        if (a.dy) { int32_t q; int64_t r; edge_x_at(a, s, q, r); ca = cell_of(q, r, a.dy); }
+        if (b.dy) { int32_t q; int64_t r; edge_x_at(b, s, q, r); cb = cell_of(q, r, b.dy); }
+        if (ca != cb) return ca < cb;
+    }
+    if (a.ytop != b.ytop) return a.ytop < b.ytop;
+    return path_order;
+}
+
 #ifdef SWFR_PHASES                 // -DSWFR_PHASES: clocks per phase of a k_rows wavefront, summed into counters[8..15] (diagnostic builds only)
 #define RPHASE(i) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); rph[i] += (uint32_t)(now_ - rph_t); rph_t = now_; } while (0)
 #else
@@ -253,7 +268,34 @@ struct FastLds {
     uint16_t eid[ROWS_FAST_N][64];      // per row (lane): local indices of its active edges
     int32_t roles[ROWS_FAST_N][64];     // SUB rows: role bits, OR-ed in by the 15 sub-row lanes
     int32_t clo[ROWS_FAST_N][64], chi[ROWS_FAST_N][64];
+    uint16_t flag[ROWS_FAST_N][64];     // slow_full_row: in = new-in-row | (dir + 1) << 1, out |= first << 3 | last << 4 | (winding before + 32) << 5
 };
+
+// The FULL test of one row (lane) in loop form, for rows with coincident active edges (see tied_order): keys are read from the
+// lane's own column of F, the per-edge results go back into F.flag.  Same decisions as the unrolled test in fast_rows otherwise.
+__device__ __forceinline__ bool slow_full_row(FastLds& F, const DevEdge* E, int lane, int n, int s0) {
+    bool full = true;
+    for (int j = 0; j < n; ++j) {
+        const int cj = F.roles[j][lane], ej = F.clo[j][lane], pj = F.chi[j][lane], fj = (int)F.flag[j][lane], nwj = fj & 1;
+        int w = 0; bool fg = true, lg = true;
+        for (int i = 0; i < n; ++i) {
+            if (i == j) continue;
+            const int ci = F.roles[i][lane], ei = F.clo[i][lane], pi = F.chi[i][lane], fi = (int)F.flag[i][lane], nwi = fi & 1, di = ((fi >> 1) & 3) - 1;
+            const bool tie = ci == cj, tie2 = nwi == nwj;
+            bool first = i < j;
+            if (tie && nwi == 0 && nwj == 0 && pi == pj) {
+                const DevEdge ea = E[F.eid[i][lane]], eb = E[F.eid[j][lane]];
+                first = tied_order(ea, eb, s0, i < j);
+            }
+            const bool t3 = nwi == 0 ? (pi < pj || (pi == pj && first)) : (i < j);
+            const bool before = ci < cj || (tie && (nwi < nwj || (tie2 && t3)));
+            if (before) { w += di; if (ei > ej) full = false; if (tie) fg = false; }
+            else if (tie) lg = false;
+        }
+        F.flag[j][lane] = (uint16_t)((fj & 7) | (fg ? 8 : 0) | (lg ? 16 : 0) | ((w + 32) << 5));
+    }
+    return full;
+}
 
 // Register-resident row routine for rows with at most ROWS_FAST_N active edges.
 //   phase A (lane = row): gather the active edges, FULL/SUB decision by pairwise order tests, FULL roles from
@@ -326,6 +368,7 @@ __device__ __forceinline__ void fast_rows(EPTR E, uint32_t n_list, const DevPath
     bool is_sub = false;
     if (n > 0) {
         bool full = !mid_row;
+        bool deep = false;
         int wb[ROWS_FAST_N];
         unsigned firstg = 0, lastg = 0;
 #pragma unroll
@@ -342,14 +385,37 @@ __device__ __forceinline__ void fast_rows(EPTR E, uint32_t n_list, const DevPath
                     // does edge i sort before edge j?  (cell, active-before-new, previous cell, path order)
                     const bool tie = cs[i] == cs[j];
                     const bool tie2 = nw[i] == nw[j];
-                    const bool t3 = nw[i] == 0 ? (cp[i] < cp[j] || (cp[i] == cp[j] && i < j)) : (i < j);
+                    const bool cpeq = cp[i] == cp[j];
+                    const bool t3 = nw[i] == 0 ? (cp[i] < cp[j] || (cpeq && i < j)) : (i < j);
                     const bool before = cs[i] < cs[j] || (tie && (nw[i] < nw[j] || (tie2 && t3)));
+                    deep |= valid && tie && tie2 && cpeq && nw[i] == 0;   // coincident for two sample rows: settled below (rare)
                     if (valid && before) { w += dr[i]; if (ce[i] > ce[j]) full = false; if (tie) fg = false; }
                     if (valid && !before && tie) lg = false;
                 }
                 wb[j] = w;
                 if (fg) firstg |= 1u << j;
                 if (lg) lastg |= 1u << j;
+            }
+        }
+        // rows in which two active edges coincide at this sample row and the one before: the whole test again, in loop form,
+        // with the order of such pairs taken from where they last differed (tied_order); the keys travel through the lane's own
+        // LDS column.  Wave-uniform and rare: near-parallel edges leaving a common vertex (round joins and caps produce them).
+        if (__ballot(deep && !mid_row) != 0ull) {
+#pragma unroll
+            for (int s = 0; s < ROWS_FAST_N; ++s) {
+                F.roles[s][lane] = cs[s]; F.clo[s][lane] = ce[s]; F.chi[s][lane] = cp[s]; F.eid[s][lane] = (uint16_t)el[s];
+                F.flag[s][lane] = (uint16_t)(nw[s] | ((dr[s] + 1) << 1));
+            }
+            if (deep && !mid_row) {
+                full = slow_full_row(F, (const DevEdge*)E, lane, n, s0);
+                firstg = lastg = 0;
+#pragma unroll
+                for (int j = 0; j < ROWS_FAST_N; ++j) {
+                    const int f = (int)F.flag[j][lane];
+                    wb[j] = ((f >> 5) & 63) - 32;
+                    if (f & 8) firstg |= 1u << j;
+                    if (f & 16) lastg |= 1u << j;
+                }
             }
         }
         if (full) {
@@ -678,9 +744,17 @@ __device__ __forceinline__ void rows_by_slot(EPTR E, uint32_t n_list, const uint
     for (int i = 0; i < 8; ++i) {
         const int src = gbase | i;
         const int ci = __shfl(c0, src), ei = __shfl(c1, src), pi = __shfl(cpv, src), ni = __shfl(nw, src), di = __shfl(dr, src);
+        // two edges already active whose cells coincide here and one sample row earlier (near-parallel edges leaving a common
+        // vertex): their list order is the cell order of the last sample row where they differed, else the order of insertion
+        const bool deep = mine && cand && i < n && i != slot && ci == c0 && ni == 0 && nw == 0 && pi == cpv;
+        bool deep_first = i < slot;
+        if (__ballot(deep) != 0ull) {                             // wave-uniform, rare
+            const int ki = __shfl(my_k, src);
+            if (deep) { const DevEdge eo = E[ki]; deep_first = tied_order(eo, e, s0, i < slot); }
+        }
         if (!(mine && cand) || i >= n || i == slot) continue;
         const bool tie = ci == c0, tie2 = ni == nw;
-        const bool t3 = ni == 0 ? (pi < cpv || (pi == cpv && i < slot)) : (i < slot);
+        const bool t3 = ni == 0 ? (pi < cpv || (pi == cpv && deep_first)) : (i < slot);
         const bool before = ci < c0 || (tie && (ni < nw || (tie2 && t3)));
         if (before) { w += di; if (ei > c1) ok = false; if (tie) fg = false; }
         else if (tie) lg = false;
@@ -851,7 +925,12 @@ __device__ __forceinline__ void big_row_body(uint32_t block, const DevEdge* __re
             if (i == lane) continue;
             // does edge i sort before this lane's edge?  (cell, active-before-new, previous cell, path order)
             const bool tie = ci == c0, tie2 = ni == nw;
-            const bool t3 = ni == 0 ? (pi < cpv || (pi == cpv && i < lane)) : (i < lane);
+            bool deep_first = i < lane;
+            if (mine && tie && ni == 0 && nw == 0 && pi == cpv) {   // coincident for two sample rows: see tied_order (rare)
+                const DevEdge eo = E[active[i]];
+                deep_first = tied_order(eo, e, s0, i < lane);
+            }
+            const bool t3 = ni == 0 ? (pi < cpv || (pi == cpv && deep_first)) : (i < lane);
             const bool before = ci < c0 || (tie && (ni < nw || (tie2 && t3)));
             if (before) { w += di; if (ei > c1) ok = false; if (tie) fg = false; }
             else if (tie) lg = false;
@@ -1018,7 +1097,12 @@ __global__ __launch_bounds__(256) void k_rows_huge(const DevEdge* __restrict__ e
                 if (i == j) continue;
                 const int ci = k_a[i], ei = k_b[i], pi = k_c[i], ni = k_d[i] >> 2, di = (k_d[i] & 3) - 1;
                 const bool tie = ci == c0, tie2 = ni == nw;
-                const bool t3 = ni == 0 ? (pi < cpv || (pi == cpv && i < j)) : (i < j);
+                bool deep_first = i < j;
+                if (tie && ni == 0 && nw == 0 && pi == cpv) {        // coincident for two sample rows: see tied_order (rare)
+                    const DevEdge ea = E[active[i]], eb = E[active[j]];
+                    deep_first = tied_order(ea, eb, s0, i < j);
+                }
+                const bool t3 = ni == 0 ? (pi < cpv || (pi == cpv && deep_first)) : (i < j);
                 const bool before = ci < c0 || (tie && (ni < nw || (tie2 && t3)));
                 if (before) { w += di; if (ei > c1) ok = false; if (tie) fg = false; }
                 else if (tie) lg = false;

@@ -248,3 +248,42 @@ def rand_radial_scene(rng):
         pts = rng.uniform(-0.1, 1.1, (int(rng.integers(3, 7)), 2)) * [W, H]
         kids.append({"type": "shape", "definition": scenarios._poly_shape(np.rint(pts * 20), fill)})
     return dict(width=W, height=H, stage={"children": kids})
+
+
+def rand_mixed_scene(rng):
+    """solid polygons (both fill rules, translucent), strokes of every style, morph shapes"""
+    import scenarios
+    from test_host import _rand_path_shape
+    W, H = int(rng.integers(40, 260)), int(rng.integers(40, 180))
+    kids = []
+    for _ in range(int(rng.integers(1, 6))):
+        k = int(rng.integers(0, 3))
+        if k == 0:
+            n = int(rng.integers(3, 10))
+            mode = int(rng.integers(0, 4))
+            if mode == 0: pts = rng.uniform(0, 1, (n, 2)) * [W, H]
+            elif mode == 1: pts = rng.integers(0, 4 * min(W, H), (n, 2)) / 4.0
+            elif mode == 2: pts = rng.integers(0, min(W, H), (n, 2)).astype(float)
+            else: pts = rng.uniform(-40, 40 + max(W, H), (n, 2))
+            col = scenarios._rgba(*[int(v) for v in rng.integers(0, 256, 3)], int(rng.choice([255, 255, 200, 128, 31, 1])))
+            kids.append({"type": "shape", "definition": scenarios._poly_shape(np.rint(pts * 20), {"type": "solid", "color": col})})
+        else:
+            morph = k == 2
+            tag = _rand_path_shape(rng, int(rng.choice([1, 2, 5, 20, 45, 90, 200])), morph)
+            sx, sy = float(rng.choice([1, 1, 0.6, 1.7, -1])), float(rng.choice([1, 1, 0.8, 1.3]))
+            mat = scenarios._m(sx, sy, int(rng.integers(-300, 900)) + (2000 if sx < 0 else 0), int(rng.integers(-300, 500)),
+                               float(rng.choice([0, 0, 0.2])), float(rng.choice([0, 0, -0.15])))
+            kids.append({"type": "morph-shape", "definition": tag, "ratio": float(rng.uniform(0, 1)), "matrix": mat} if morph else
+                        {"type": "shape", "definition": tag, "matrix": mat})
+    return dict(width=W, height=H, even_odd=bool(rng.integers(0, 2)), stage={"children": kids})
+
+
+
+
+def soak_scene(name, seed, index):
+    """Scene `index` of generator `name` in tools/soak.py's numbering (the generators are seeded per name)."""
+    gens = {"mixed": rand_mixed_scene, "bitmap": rand_bitmap_scene, "radial": rand_radial_scene}
+    rng = np.random.default_rng(seed + sum(map(ord, name)))
+    for _ in range(index + 1):
+        sc = gens[name](rng)
+    return sc

@@ -220,6 +220,17 @@ def test_fuzz_radial_gradients_vs_oracle():
     assert painted > 50000
 
 
+@pytest.mark.parametrize("case", [("radial", 1000, 940), ("mixed", 1000, 445), ("mixed", 1000, 688), ("bitmap", 1000, 820),
+                                  ("mixed", 2000, 755), ("mixed", 2000, 1130), ("mixed", 2000, 1265)])
+def test_soak_regressions_tied_edges(case):
+    """Scenes a soak run (tools/soak.py gpu) found: two active edges whose cells coincide over several sample rows (near-parallel
+    edges leaving a common vertex) -- their order in Cairo's list, which decides whether a pixel row is converted analytically,
+    comes from the last sample row where they differed, not from the one before the row."""
+    from helpers import soak_scene
+    sc = soak_scene(*case)
+    assert diff_stats(product_render(sc), oracle_render(sc)) == (0, 0), case
+
+
 # ---- every internal route of the row/tile kernels gives the same pixels
 @pytest.mark.parametrize("env", [{"SWFR_FAST_LIMIT": "0"}, {"SWFR_FAST_LIMIT": "3"}, {"SWFR_CELL_MODE": "0"}, {"SWFR_CHUNK_ROWS": "64"},
                                  {"SWFR_CHUNK_ROWS": "8"}, {"SWFR_CHUNK_ROWS": "8", "SWFR_FAST_LIMIT": "3"}, {"SWFR_CHUNK_ROWS": "16", "SWFR_CELL_MODE": "0"},

@@ -359,3 +359,23 @@ def test_radial_scenes_through_the_canvas_replay(seed):
             cr.CanvasReplay(be, linear_extension=True).render(sc["stage"])
             imgs.append(be.premultiplied_rgba().astype(int)); be.close()
         assert np.array_equal(imgs[0], imgs[1]), (seed, it)
+
+
+def test_operation_that_paints_nothing_keeps_the_surface_clear():
+    """Soak finding: a stroke whose approximate extents touch the frame while its outline lies outside is NOTHING_TO_DO for Cairo --
+    the surface stays "clear", so the next translucent fill is composited with the SOURCE rule (0x7f rounding), not OVER (0x80):
+    alpha 128 under coverage 1 gives 0, not 1."""
+    from helpers import soak_scene
+    from oracle import canvas_replay as cr
+    for case in (("mixed", 1000, 382), ("mixed", 1000, 545), ("mixed", 1000, 714), ("bitmap", 1000, 332)):
+        sc = soak_scene(*case)
+        imgs = []
+        for be in (cb.CairoBackend(sc["width"], sc["height"]), ob.OracleBackend(sc["width"], sc["height"])):
+            if sc.get("even_odd"):
+                be.set_fill_rule(True)
+            rp = cr.CanvasReplay(be, linear_extension=True)
+            for b in sc.get("bitmaps", []):
+                rp.add_bitmap(b)
+            rp.render(sc["stage"])
+            imgs.append(be.premultiplied_rgba().astype(int)); be.close()
+        assert np.array_equal(imgs[0], imgs[1]), case

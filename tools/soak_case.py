@@ -10,10 +10,8 @@ from helpers import oracle_render
 
 
 def scene(name, seed, idx):
-    rng = np.random.default_rng(seed + sum(map(ord, name)))
-    for _ in range(idx + 1):
-        sc = soak.GENS[name](rng)
-    return sc
+    from helpers import soak_scene
+    return soak_scene(name, seed, idx)
 
 
 def host_vs_oracle(sc):
