@@ -243,16 +243,61 @@ __global__ __launch_bounds__(256) void k_front(const swfr_edge* __restrict__ in,
 #define ROWS_BIG_MAXA 64         // capacity of the generic (LDS list) routine in k_rows_big
 #define ROWS_STAGE 64            // paths with at most this many edges are staged into LDS
 
-// Order of two active edges a, b whose cells coincide at sample row s0 and at s0 - 1: a sorts first iff it had the smaller cell at
-// the last earlier sample row where the two differed (Cairo's list is re-sorted whenever a cell order is violated and left alone
-// on ties); if they never differed since the later one became active, the one that became active earlier, else path order.
-__device__ __forceinline__ bool tied_order(const DevEdge& a, const DevEdge& b, int s0, bool path_order) {
+// All edges of one path, whichever form the kernel has them in (k_front's DevEdge array, or the raw edges when the row pass
+// computes the constants itself).
+struct PathEdges {
+    const DevEdge* dev; const swfr_edge* raw; const DevPath* P; bool from_raw;
+    __device__ __forceinline__ DevEdge operator()(uint32_t k) const { return from_raw ? make_dev_edge(raw[P->first_edge + k], *P) : dev[P->first_edge + k]; }
+    __device__ __forceinline__ uint32_t size() const { return P->n_edges; }
+};
+// Was pixel row rho of the path converted sample row by sample row (Cairo then re-sorts its edge list at every sample row), or
+// analytically (the list is looked at only at the row's first sample row)?  Sampled iff an edge becomes active after the first
+// sample row, an active edge ends before the last, or two edges swap places over the row (edges that tie at the row's first
+// sample row are taken as not swapping; paths with more than 128 edges skip this quadratic test).
+__device__ __forceinline__ bool row_was_sampled(const PathEdges& PE, int rho) {
+    const int s = rho * 15;
+    const uint32_t ne = PE.size();
+    for (uint32_t k = 0; k < ne; ++k) {
+        const DevEdge e = PE(k);
+        if (e.ybot <= s || e.ytop >= s + 15) continue;
+        if (e.ytop > s || e.ybot < s + 15) return true;
+    }
+    if (ne > 128u) return false;
+    for (uint32_t u = 0; u < ne; ++u) {
+        const DevEdge eu = PE(u);
+        if (eu.ybot <= s || eu.ytop >= s + 15) continue;
+        int u0 = eu.x1, u1 = eu.x1;
+        if (eu.dy) { int32_t q; int64_t r; edge_x_at(eu, s, q, r); u0 = cell_of(q, r, eu.dy); edge_x_at(eu, s + 15, q, r); u1 = cell_of(q, r, eu.dy); }
+        for (uint32_t v = u + 1; v < ne; ++v) {
+            const DevEdge ev = PE(v);
+            if (ev.ybot <= s || ev.ytop >= s + 15) continue;
+            int v0 = ev.x1, v1 = ev.x1;
+            if (ev.dy) { int32_t q; int64_t r; edge_x_at(ev, s, q, r); v0 = cell_of(q, r, ev.dy); edge_x_at(ev, s + 15, q, r); v1 = cell_of(q, r, ev.dy); }
+            if ((u0 < v0 && u1 > v1) || (u0 > v0 && u1 < v1)) return true;
+        }
+    }
+    return false;
+}
+// Order of two active edges a, b whose cells coincide at the first sample row s0 of a pixel row (near-parallel edges leaving a
+// common vertex: round joins and caps produce them).  Cairo's list is re-sorted whenever it is looked at and a cell order is
+// violated, and left alone on ties: a sorts first iff it had the smaller cell the last time the list was looked at while the two
+// differed -- every sample row of a sampled pixel row, the first sample row only of an analytically converted one -- and if they
+// never differed since the later one became active, the one that became active earlier, else path order.
+__device__ __forceinline__ bool tied_order(const PathEdges& PE, const DevEdge& a, const DevEdge& b, int s0, bool path_order) {
     const int lo = max(a.ytop, b.ytop);
-    for (int s = s0 - 2; s >= lo; --s) {
+    auto differ = [&](int s, bool& a_first) {
         int ca = a.x1, cb = b.x1;
         if (a.dy) { int32_t q; int64_t r; edge_x_at(a, s, q, r); ca = cell_of(q, r, a.dy); }
         if (b.dy) { int32_t q; int64_t r; edge_x_at(b, s, q, r); cb = cell_of(q, r, b.dy); }
-        if (ca != cb) return ca < cb;
+        a_first = ca < cb;
+        return ca != cb;
+    };
+    bool af = path_order;
+    for (int rho = s0 / 15 - 1; rho * 15 + 14 >= lo; --rho) {
+        const int rs = rho * 15;
+        if (row_was_sampled(PE, rho)) {
+            for (int s = rs + 14; s >= max(rs, lo); --s) if (differ(s, af)) return af;
+        } else if (rs >= lo && differ(rs, af)) return af;
     }
     if (a.ytop != b.ytop) return a.ytop < b.ytop;
     return path_order;
@@ -273,8 +318,28 @@ struct FastLds {
 
 // The FULL test of one row (lane) in loop form, for rows with coincident active edges (see tied_order): keys are read from the
 // lane's own column of F, the per-edge results go back into F.flag.  Same decisions as the unrolled test in fast_rows otherwise.
-__device__ __forceinline__ bool slow_full_row(FastLds& F, const DevEdge* E, int lane, int n, int s0) {
+__device__ __forceinline__ bool slow_full_row(FastLds& F, const PathEdges& PE, const DevEdge* E, int lane, int n, int s0) {
     bool full = true;
+    // a new edge that ties with an active one goes first when another new edge sorts between the active edge's predecessor and the
+    // tie (Cairo merges the sorted new edges into the active list in alternating runs): bit k of nfmask says so for active edge k
+    unsigned nfmask = 0;
+    for (int k = 0; k < n; ++k) {
+        const int ck = F.roles[k][lane], pk = F.chi[k][lane];
+        if ((int)F.flag[k][lane] & 1) continue;
+        int L = INT_MIN; bool tied_before = false, any_new = false;
+        for (int a = 0; a < n; ++a) {
+            if (a == k || ((int)F.flag[a][lane] & 1)) continue;
+            const int ca = F.roles[a][lane], pa = F.chi[a][lane];
+            if (ca < ck) L = max(L, ca);
+            else if (ca == ck && (pa < pk || (pa == pk && a < k))) tied_before = true;
+        }
+        for (int b = 0; b < n; ++b) {
+            if (!((int)F.flag[b][lane] & 1)) continue;
+            const int cb = F.roles[b][lane];
+            any_new |= cb >= L && cb < ck;
+        }
+        if (!tied_before && any_new) nfmask |= 1u << k;
+    }
     for (int j = 0; j < n; ++j) {
         const int cj = F.roles[j][lane], ej = F.clo[j][lane], pj = F.chi[j][lane], fj = (int)F.flag[j][lane], nwj = fj & 1;
         int w = 0; bool fg = true, lg = true;
@@ -283,12 +348,13 @@ __device__ __forceinline__ bool slow_full_row(FastLds& F, const DevEdge* E, int 
             const int ci = F.roles[i][lane], ei = F.clo[i][lane], pi = F.chi[i][lane], fi = (int)F.flag[i][lane], nwi = fi & 1, di = ((fi >> 1) & 3) - 1;
             const bool tie = ci == cj, tie2 = nwi == nwj;
             bool first = i < j;
-            if (tie && nwi == 0 && nwj == 0 && pi == pj) {
+            if (tie && nwi == 0 && nwj == 0) {
                 const DevEdge ea = E[F.eid[i][lane]], eb = E[F.eid[j][lane]];
-                first = tied_order(ea, eb, s0, i < j);
+                first = tied_order(PE, ea, eb, s0, i < j);
             }
-            const bool t3 = nwi == 0 ? (pi < pj || (pi == pj && first)) : (i < j);
-            const bool before = ci < cj || (tie && (nwi < nwj || (tie2 && t3)));
+            const bool t3 = nwi == 0 ? first : (i < j);
+            const bool t_mixed = nwi == 0 ? !((nfmask >> i) & 1u) : ((nfmask >> j) & 1u) != 0;
+            const bool before = ci < cj || (tie && (tie2 ? t3 : t_mixed));
             if (before) { w += di; if (ei > ej) full = false; if (tie) fg = false; }
             else if (tie) lg = false;
         }
@@ -307,7 +373,7 @@ __device__ __forceinline__ void fast_rows(EPTR E, uint32_t n_list, const DevPath
                                           uint32_t& mode_out, int& n_out_edges, bool& overflow_out,
                                           int32_t (&roles)[ROWS_FAST_N], int32_t (&cols)[ROWS_FAST_N], int (&el)[ROWS_FAST_N],
                                           int32_t (&Q1)[ROWS_FAST_N], int64_t (&R1)[ROWS_FAST_N], int32_t (&Q2)[ROWS_FAST_N], int64_t (&R2)[ROWS_FAST_N],
-                                          uint32_t* rph, unsigned long long& rph_t, int& nmax_out) {
+                                          uint32_t* rph, unsigned long long& rph_t, int& nmax_out, const PathEdges& PE) {
     (void)rph; (void)rph_t;
     const int s0 = r * 15;
     const unsigned mask = P.fill_rule ? 1u : ~0u;
@@ -388,7 +454,7 @@ __device__ __forceinline__ void fast_rows(EPTR E, uint32_t n_list, const DevPath
                     const bool cpeq = cp[i] == cp[j];
                     const bool t3 = nw[i] == 0 ? (cp[i] < cp[j] || (cpeq && i < j)) : (i < j);
                     const bool before = cs[i] < cs[j] || (tie && (nw[i] < nw[j] || (tie2 && t3)));
-                    deep |= valid && tie && tie2 && cpeq && nw[i] == 0;   // coincident for two sample rows: settled below (rare)
+                    deep |= valid && tie && ((tie2 && nw[i] == 0) || !tie2);   // coincident active edges, or a new edge tying with an active one: settled below (rare)
                     if (valid && before) { w += dr[i]; if (ce[i] > ce[j]) full = false; if (tie) fg = false; }
                     if (valid && !before && tie) lg = false;
                 }
@@ -407,7 +473,7 @@ __device__ __forceinline__ void fast_rows(EPTR E, uint32_t n_list, const DevPath
                 F.flag[s][lane] = (uint16_t)(nw[s] | ((dr[s] + 1) << 1));
             }
             if (deep && !mid_row) {
-                full = slow_full_row(F, (const DevEdge*)E, lane, n, s0);
+                full = slow_full_row(F, PE, (const DevEdge*)E, lane, n, s0);
                 firstg = lastg = 0;
 #pragma unroll
                 for (int j = 0; j < ROWS_FAST_N; ++j) {
@@ -576,11 +642,12 @@ __device__ __forceinline__ void rows_chunk_body(uint32_t block, const DevEdge* _
     }
     __syncthreads();
     RPHASE(1);
+    const PathEdges PE = {edges, raw, &P, (fused & 2) != 0};
     uint32_t mode; int n, nmax = ROWS_FAST_N; bool overflow;
     int32_t roles[ROWS_FAST_N], cols[ROWS_FAST_N]; int el[ROWS_FAST_N];
     int32_t Q1[ROWS_FAST_N], Q2[ROWS_FAST_N]; int64_t R1[ROWS_FAST_N], R2[ROWS_FAST_N];
-    if (use_lds) fast_rows((const DevEdge*)staged, n_list, P, r, live, fast_limit, F, lane, mode, n, overflow, roles, cols, el, Q1, R1, Q2, R2, rph, rph_t, nmax);
-    else fast_rows(edges + P.first_edge, P.n_edges, P, r, live, fast_limit, F, lane, mode, n, overflow, roles, cols, el, Q1, R1, Q2, R2, rph, rph_t, nmax);
+    if (use_lds) fast_rows((const DevEdge*)staged, n_list, P, r, live, fast_limit, F, lane, mode, n, overflow, roles, cols, el, Q1, R1, Q2, R2, rph, rph_t, nmax, PE);
+    else fast_rows(edges + P.first_edge, P.n_edges, P, r, live, fast_limit, F, lane, mode, n, overflow, roles, cols, el, Q1, R1, Q2, R2, rph, rph_t, nmax, PE);
     uint32_t n_out = 0;
 #pragma unroll
     for (int s = 0; s < ROWS_FAST_N; ++s) n_out += (s < nmax && s < n && roles[s] != 0) ? 1u : 0u;
@@ -692,7 +759,7 @@ __device__ __forceinline__ void rows_chunk_body(uint32_t block, const DevEdge* _
 template <class EPTR>
 __device__ __forceinline__ void rows_by_slot(EPTR E, uint32_t n_list, const uint32_t* staged_k, const DevPath& P, const ChunkInfo& ck,
                                              const uint32_t* __restrict__ row_base, RowInfo* __restrict__ rows, Rec* __restrict__ records,
-                                             uint32_t band_index, uint32_t band_count, int fast_limit, int cell_mode, int lane) {
+                                             uint32_t band_index, uint32_t band_count, int fast_limit, int cell_mode, int lane, const PathEdges& PE) {
     const int g = lane >> 3, slot = lane & 7, gbase = lane & ~7;
     const int r = (int)ck.first_row + g, s0 = r * 15;
     const bool in_path = P.kind == SWFR_PATH_TOR && g < (int)ck.rows && r < P.y_max;
@@ -739,25 +806,55 @@ __device__ __forceinline__ void rows_by_slot(EPTR E, uint32_t n_list, const uint
     }
     const int nw = (e.ytop == s0) ? 1 : 0, dr = e.dir;
     // ---- FULL test: keys of the other slots of this row by shuffles (every lane takes part: bpermute reads 0 from idle lanes)
-    int w = 0; bool fg = true, lg = true, ok = true;
+    // (a new edge that ties with an active one: Cairo merges the sorted new edges into the active list in alternating runs, and
+    //  the new edge goes first when another new edge sorts between the active edge's predecessor and the tie -- `nf` below is that
+    //  predicate of an active edge; it stays false, "active first", unless such a tie exists in the wave)
+    int w = 0; bool fg = true, lg = true, ok = true, mixed = false;
+    bool nf = false;
+    for (int pass = 0; pass < 2; ++pass) {                      // second pass only when a new edge ties with an active one (rare)
+        w = 0; fg = lg = ok = true;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int src = gbase | i;
-        const int ci = __shfl(c0, src), ei = __shfl(c1, src), pi = __shfl(cpv, src), ni = __shfl(nw, src), di = __shfl(dr, src);
-        // two edges already active whose cells coincide here and one sample row earlier (near-parallel edges leaving a common
-        // vertex): their list order is the cell order of the last sample row where they differed, else the order of insertion
-        const bool deep = mine && cand && i < n && i != slot && ci == c0 && ni == 0 && nw == 0 && pi == cpv;
-        bool deep_first = i < slot;
-        if (__ballot(deep) != 0ull) {                             // wave-uniform, rare
-            const int ki = __shfl(my_k, src);
-            if (deep) { const DevEdge eo = E[ki]; deep_first = tied_order(eo, e, s0, i < slot); }
+        for (int i = 0; i < 8; ++i) {
+            const int src = gbase | i;
+            const int ci = __shfl(c0, src), ei = __shfl(c1, src), pi = __shfl(cpv, src), ni = __shfl(nw, src), di = __shfl(dr, src);
+            const int nfi = __shfl((int)nf, src);
+            // two edges already active whose cells coincide here and one sample row earlier (near-parallel edges leaving a common
+            // vertex): their list order is the cell order of the last sample row where they differed, else the order of insertion
+            const bool deep = mine && cand && i < n && i != slot && ci == c0 && ni == 0 && nw == 0;
+            bool deep_first = i < slot;
+            if (__ballot(deep) != 0ull) {                       // wave-uniform, rare
+                const int ki = __shfl(my_k, src);
+                if (deep) { const DevEdge eo = E[ki]; deep_first = tied_order(PE, eo, e, s0, i < slot); }
+            }
+            if (!(mine && cand) || i >= n || i == slot) continue;
+            const bool tie = ci == c0, tie2 = ni == nw;
+            const bool t3 = ni == 0 ? deep_first : (i < slot);
+            const bool t_mixed = ni == 0 ? !nfi : nf;           // active / new tie: the active one first unless its `nf` holds
+            const bool before = ci < c0 || (tie && (tie2 ? t3 : t_mixed));
+            mixed |= tie && !tie2;
+            if (before) { w += di; if (ei > c1) ok = false; if (tie) fg = false; }
+            else if (tie) lg = false;
         }
-        if (!(mine && cand) || i >= n || i == slot) continue;
-        const bool tie = ci == c0, tie2 = ni == nw;
-        const bool t3 = ni == 0 ? (pi < cpv || (pi == cpv && deep_first)) : (i < slot);
-        const bool before = ci < c0 || (tie && (ni < nw || (tie2 && t3)));
-        if (before) { w += di; if (ei > c1) ok = false; if (tie) fg = false; }
-        else if (tie) lg = false;
+        if (pass == 1 || __ballot(mixed) == 0ull) break;
+        // nf of this lane's edge, if it is active: no active edge ties with it and sorts before it, and some new edge has its
+        // cell in [L, c0) where L is the largest cell of the active edges left of it
+        int L = INT_MIN; bool tied_before = false, any_new = false;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int src = gbase | i;
+            const int ci = __shfl(c0, src), pi = __shfl(cpv, src), ni = __shfl(nw, src);
+            if (i >= n || i == slot || ni != 0) continue;
+            if (ci < c0) L = max(L, ci);
+            else if (ci == c0 && (pi < cpv || (pi == cpv && i < slot))) tied_before = true;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int src = gbase | i;
+            const int ci = __shfl(c0, src), ni = __shfl(nw, src);
+            if (i >= n || i == slot || ni != 1) continue;
+            any_new |= ci >= L && ci < c0;
+        }
+        nf = mine && cand && nw == 0 && !tied_before && any_new;
     }
     const unsigned long long bad = __ballot(mine && cand && !ok);
     const bool full = cand && ((bad >> gbase) & 0xffull) == 0ull;
@@ -850,8 +947,9 @@ __device__ __forceinline__ void rows_rs_body(uint32_t block, const DevEdge* __re
         if (n_list > ROWS_STAGE) { use_lds = false; break; }
     }
     __syncthreads();
-    if (use_lds) rows_by_slot((const DevEdge*)staged, n_list, (const uint32_t*)staged_k, P, ck, row_base, rows, records, band_index, band_count, fast_limit, cell_mode, lane);
-    else rows_by_slot(edges + P.first_edge, P.n_edges, (const uint32_t*)nullptr, P, ck, row_base, rows, records, band_index, band_count, fast_limit, cell_mode, lane);
+    const PathEdges PE = {edges, nullptr, &P, false};
+    if (use_lds) rows_by_slot((const DevEdge*)staged, n_list, (const uint32_t*)staged_k, P, ck, row_base, rows, records, band_index, band_count, fast_limit, cell_mode, lane, PE);
+    else rows_by_slot(edges + P.first_edge, P.n_edges, (const uint32_t*)nullptr, P, ck, row_base, rows, records, band_index, band_count, fast_limit, cell_mode, lane, PE);
 }
 
 // Rows with more than ROWS_FAST_N active edges of one path (the host lists them at upload, with their record slots):
@@ -870,6 +968,7 @@ __device__ __forceinline__ void big_row_body(uint32_t block, const DevEdge* __re
     const uint32_t t = row_base[br.path] + (uint32_t)(r - P.y_min);
     const unsigned mask = P.fill_rule ? 1u : ~0u;
     const DevEdge* E = edges + P.first_edge;
+    const PathEdges PE = {edges, nullptr, &P, false};
     // ---- gather: compact the indices of the active edges, 64 candidates per pass (path order is kept)
     int n = 0;
     bool too_many = false;
@@ -918,22 +1017,42 @@ __device__ __forceinline__ void big_row_body(uint32_t block, const DevEdge* __re
             q1 = qa; r1 = ra; q2 = qb; r2 = rb;
         }
         const int nw = (e.ytop == s0) ? 1 : 0, dr = e.dir;
-        int w = 0; bool fg = true, lg = true, ok = true;
-        for (int i = 0; i < n; ++i) {                         // wave-uniform loop: lane i's keys broadcast to every lane
-            const int ci = __builtin_amdgcn_readlane(c0, i), ei = __builtin_amdgcn_readlane(c1, i), pi = __builtin_amdgcn_readlane(cpv, i);
-            const int ni = __builtin_amdgcn_readlane(nw, i), di = __builtin_amdgcn_readlane(dr, i);
-            if (i == lane) continue;
-            // does edge i sort before this lane's edge?  (cell, active-before-new, previous cell, path order)
-            const bool tie = ci == c0, tie2 = ni == nw;
-            bool deep_first = i < lane;
-            if (mine && tie && ni == 0 && nw == 0 && pi == cpv) {   // coincident for two sample rows: see tied_order (rare)
-                const DevEdge eo = E[active[i]];
-                deep_first = tied_order(eo, e, s0, i < lane);
+        int w = 0; bool fg = true, lg = true, ok = true, mixed = false;
+        unsigned long long nfb = 0ull;                       // bit k: active edge k lets a tying new edge go first (see rows_by_slot)
+        for (int pass = 0; pass < 2; ++pass) {
+            w = 0; fg = lg = ok = true;
+            for (int i = 0; i < n; ++i) {                     // wave-uniform loop: lane i's keys broadcast to every lane
+                const int ci = __builtin_amdgcn_readlane(c0, i), ei = __builtin_amdgcn_readlane(c1, i), pi = __builtin_amdgcn_readlane(cpv, i);
+                const int ni = __builtin_amdgcn_readlane(nw, i), di = __builtin_amdgcn_readlane(dr, i);
+                if (i == lane) continue;
+                // does edge i sort before this lane's edge?  (cell, active / new, previous cell, path order)
+                const bool tie = ci == c0, tie2 = ni == nw;
+                bool deep_first = i < lane;
+                if (mine && tie && ni == 0 && nw == 0) {   // coincident active edges: see tied_order (rare)
+                    const DevEdge eo = E[active[i]];
+                    deep_first = tied_order(PE, eo, e, s0, i < lane);
+                }
+                const bool t3 = ni == 0 ? deep_first : (i < lane);
+                const bool t_mixed = ni == 0 ? !((nfb >> i) & 1ull) : ((nfb >> lane) & 1ull) != 0ull;
+                const bool before = ci < c0 || (tie && (tie2 ? t3 : t_mixed));
+                mixed |= mine && tie && !tie2;
+                if (before) { w += di; if (ei > c1) ok = false; if (tie) fg = false; }
+                else if (tie) lg = false;
             }
-            const bool t3 = ni == 0 ? (pi < cpv || (pi == cpv && deep_first)) : (i < lane);
-            const bool before = ci < c0 || (tie && (ni < nw || (tie2 && t3)));
-            if (before) { w += di; if (ei > c1) ok = false; if (tie) fg = false; }
-            else if (tie) lg = false;
+            if (pass == 1 || __ballot(mixed) == 0ull) break;
+            int L = INT_MIN; bool tied_before = false, any_new = false;
+            for (int i = 0; i < n; ++i) {
+                const int ci = __builtin_amdgcn_readlane(c0, i), pi = __builtin_amdgcn_readlane(cpv, i), ni = __builtin_amdgcn_readlane(nw, i);
+                if (i == lane || ni != 0) continue;
+                if (ci < c0) L = max(L, ci);
+                else if (ci == c0 && (pi < cpv || (pi == cpv && i < lane))) tied_before = true;
+            }
+            for (int i = 0; i < n; ++i) {
+                const int ci = __builtin_amdgcn_readlane(c0, i), ni = __builtin_amdgcn_readlane(nw, i);
+                if (i == lane || ni != 1) continue;
+                any_new |= ci >= L && ci < c0;
+            }
+            nfb = __ballot(mine && nw == 0 && !tied_before && any_new);
         }
         full = __ballot(mine && !ok) == 0ull;
         if (full && mine) {
@@ -1047,6 +1166,7 @@ __global__ __launch_bounds__(256) void k_rows_huge(const DevEdge* __restrict__ e
     const uint32_t t = row_base[br.path] + (uint32_t)(r - P.y_min);
     const unsigned mask = P.fill_rule ? 1u : ~0u;
     const DevEdge* E = edges + P.first_edge;
+    const PathEdges PE = {edges, nullptr, &P, false};
     if (tid == 0) flags = 0;
     // ---- gather the active edges in path order: ballot per wavefront, wavefront totals through LDS
     int n = 0;
@@ -1087,30 +1207,69 @@ __global__ __launch_bounds__(256) void k_rows_huge(const DevEdge* __restrict__ e
             k_a[j] = c0; k_b[j] = c1; k_c[j] = cpv; k_d[j] = ((e.ytop == s0) ? 4 : 0) | (e.dir + 1);
         }
         __syncthreads();
+        // (k_d bit 3, set between the two passes: this active edge lets a tying new edge go first -- see rows_by_slot; the second
+        //  pass runs only when a new edge ties with an active one, flags bit 2)
+        for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
-        for (int m = 0; m < ROWS_HUGE_EPT; ++m) {
-            const int j = m * 256 + tid;
-            if (m >= nb || j >= n) continue;
-            const int c0 = k_a[j], c1 = k_b[j], cpv = k_c[j], nw = k_d[j] >> 2, dr = (k_d[j] & 3) - 1;
-            int w = 0; bool fg = true, lg = true, ok = true;
-            for (int i = 0; i < n; ++i) {                            // LDS broadcast reads
-                if (i == j) continue;
-                const int ci = k_a[i], ei = k_b[i], pi = k_c[i], ni = k_d[i] >> 2, di = (k_d[i] & 3) - 1;
-                const bool tie = ci == c0, tie2 = ni == nw;
-                bool deep_first = i < j;
-                if (tie && ni == 0 && nw == 0 && pi == cpv) {        // coincident for two sample rows: see tied_order (rare)
-                    const DevEdge ea = E[active[i]], eb = E[active[j]];
-                    deep_first = tied_order(ea, eb, s0, i < j);
+            for (int m = 0; m < ROWS_HUGE_EPT; ++m) {
+                const int j = m * 256 + tid;
+                role[m] = 0;
+                if (m >= nb || j >= n) continue;
+                const int c0 = k_a[j], c1 = k_b[j], cpv = k_c[j], nw = (k_d[j] >> 2) & 1, dr = (k_d[j] & 3) - 1, nfj = (k_d[j] >> 3) & 1;
+                int w = 0; bool fg = true, lg = true, ok = true, mixed = false;
+                for (int i = 0; i < n; ++i) {                        // LDS broadcast reads
+                    if (i == j) continue;
+                    const int ci = k_a[i], ei = k_b[i], pi = k_c[i], ni = (k_d[i] >> 2) & 1, di = (k_d[i] & 3) - 1, nfi = (k_d[i] >> 3) & 1;
+                    const bool tie = ci == c0, tie2 = ni == nw;
+                    bool deep_first = i < j;
+                    if (tie && ni == 0 && nw == 0) {    // coincident active edges: see tied_order (rare)
+                        const DevEdge ea = E[active[i]], eb = E[active[j]];
+                        deep_first = tied_order(PE, ea, eb, s0, i < j);
+                    }
+                    const bool t3 = ni == 0 ? deep_first : (i < j);
+                    const bool t_mixed = ni == 0 ? !nfi : nfj != 0;
+                    const bool before = ci < c0 || (tie && (tie2 ? t3 : t_mixed));
+                    mixed |= tie && !tie2;
+                    if (before) { w += di; if (ei > c1) ok = false; if (tie) fg = false; }
+                    else if (tie) lg = false;
                 }
-                const bool t3 = ni == 0 ? (pi < cpv || (pi == cpv && deep_first)) : (i < j);
-                const bool before = ci < c0 || (tie && (ni < nw || (tie2 && t3)));
-                if (before) { w += di; if (ei > c1) ok = false; if (tie) fg = false; }
-                else if (tie) lg = false;
+                if (!ok) atomicOr(&flags, 2);
+                if (mixed) atomicOr(&flags, 4);
+                const bool in_b = ((unsigned)w & mask) != 0, in_a = ((unsigned)(w + dr) & mask) != 0;
+                if (!in_b && fg) role[m] = REC_FULL | 1u;
+                else if (!in_a && lg) role[m] = REC_FULL | 2u;
             }
-            if (!ok) atomicOr(&flags, 2);
-            const bool in_b = ((unsigned)w & mask) != 0, in_a = ((unsigned)(w + dr) & mask) != 0;
-            if (!in_b && fg) role[m] = REC_FULL | 1u;
-            else if (!in_a && lg) role[m] = REC_FULL | 2u;
+            __syncthreads();
+            if (pass == 1 || !(flags & 4)) break;                   // workgroup-uniform
+            __syncthreads();
+            if (tid == 0) flags &= ~2;                               // the order test is repeated with the final order
+            unsigned nfbits = 0;
+#pragma unroll
+            for (int m = 0; m < ROWS_HUGE_EPT; ++m) {
+                const int j = m * 256 + tid;
+                if (m >= nb || j >= n || ((k_d[j] >> 2) & 1)) continue;
+                const int c0 = k_a[j], cpv = k_c[j];
+                int L = INT_MIN; bool tied_before = false, any_new = false;
+                for (int i = 0; i < n; ++i) {
+                    if (i == j || ((k_d[i] >> 2) & 1)) continue;
+                    const int ci = k_a[i], pi = k_c[i];
+                    if (ci < c0) L = max(L, ci);
+                    else if (ci == c0 && (pi < cpv || (pi == cpv && i < j))) tied_before = true;
+                }
+                for (int i = 0; i < n; ++i) {
+                    if (!((k_d[i] >> 2) & 1)) continue;
+                    const int ci = k_a[i];
+                    any_new |= ci >= L && ci < c0;
+                }
+                if (!tied_before && any_new) nfbits |= 1u << m;
+            }
+            __syncthreads();                                         // every thread has read the keys it needs
+#pragma unroll
+            for (int m = 0; m < ROWS_HUGE_EPT; ++m) {
+                const int j = m * 256 + tid;
+                if (m < nb && j < n && ((nfbits >> m) & 1u)) k_d[j] |= 8;
+            }
+            __syncthreads();
         }
         __syncthreads();
         full = (flags & 2) == 0;

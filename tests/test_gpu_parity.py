@@ -220,12 +220,15 @@ def test_fuzz_radial_gradients_vs_oracle():
     assert painted > 50000
 
 
-@pytest.mark.parametrize("case", [("radial", 1000, 940), ("mixed", 1000, 445), ("mixed", 1000, 688), ("bitmap", 1000, 820),
-                                  ("mixed", 2000, 755), ("mixed", 2000, 1130), ("mixed", 2000, 1265)])
+@pytest.mark.parametrize("case", [("radial", 1000, 940), ("mixed", 1000, 445), ("mixed", 1000, 607), ("mixed", 1000, 688), ("bitmap", 1000, 820),
+                                  ("mixed", 2000, 755), ("mixed", 2000, 1130), ("mixed", 2000, 1265), ("mixed", 4000, 241), ("mixed", 4000, 1424),
+                                  ("mixed", 5000, 507), ("radial", 7000, 670), ("bitmap", 7000, 816), ("mixed", 8000, 995)])
 def test_soak_regressions_tied_edges(case):
-    """Scenes a soak run (tools/soak.py gpu) found: two active edges whose cells coincide over several sample rows (near-parallel
-    edges leaving a common vertex) -- their order in Cairo's list, which decides whether a pixel row is converted analytically,
-    comes from the last sample row where they differed, not from the one before the row."""
+    """Scenes soak runs (tools/soak.py gpu) found: edges whose cells coincide at a pixel row's first sample row.  Their order in
+    Cairo's list decides whether the row is converted analytically: two active edges keep the order of the last time the list was
+    looked at while they differed (every sample row of a sampled pixel row, the first one of an analytic row -- reconstructed per
+    row from the path's edges); a new edge goes before a tying active one when another new edge sorts between that edge's
+    predecessor and the tie (Cairo's merge consumes its two lists in alternating runs)."""
     from helpers import soak_scene
     sc = soak_scene(*case)
     assert diff_stats(product_render(sc), oracle_render(sc)) == (0, 0), case
