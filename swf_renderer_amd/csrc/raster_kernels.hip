@@ -278,12 +278,80 @@ __device__ __forceinline__ bool row_was_sampled(const PathEdges& PE, int rho) {
     }
     return false;
 }
+// ---- the order Cairo gives edges that become active at the same sample row m: the row's bucket holds them in path order, and
+//      sort_edges -- pairs, then merges of runs of 2, 4, ... with merge_sorted_edges, whose two loops consume the lists in
+//      alternating runs ("<=" on both sides: on a tie the list being consumed keeps going) -- sorts them by cell.  Restated for up
+//      to eight such edges in registers (lists are packed 4-bit slot numbers, cells are looked up by select chains); more than
+//      eight: path order.
+__device__ __forceinline__ int sel8(const int (&v)[8], int i) {
+    int r = v[0];
+#pragma unroll
+    for (int t = 1; t < 8; ++t) r = (i == t) ? v[t] : r;
+    return r;
+}
+__device__ __forceinline__ uint32_t merge_runs(uint32_t A, int na, uint32_t B, int nb, const int (&cell)[8]) {
+    if (nb == 0) return A;
+    if (na == 0) return B;
+    uint32_t out = 0; int no = 0, ia = 0, ib = 0;
+    auto a_slot = [&](int i) { return (int)((A >> (4 * i)) & 15u); };
+    auto b_slot = [&](int i) { return (int)((B >> (4 * i)) & 15u); };
+    bool phase_a = sel8(cell, a_slot(0)) <= sel8(cell, b_slot(0));
+    for (int guard = 0; guard < 32; ++guard) {
+        if (phase_a) {
+            const int x = sel8(cell, b_slot(ib));
+            while (ia < na && sel8(cell, a_slot(ia)) <= x) { out |= (uint32_t)a_slot(ia) << (4 * no); ++no; ++ia; }
+            if (ia == na) { while (ib < nb) { out |= (uint32_t)b_slot(ib) << (4 * no); ++no; ++ib; } break; }
+        }
+        {
+            const int x = sel8(cell, a_slot(ia));
+            while (ib < nb && sel8(cell, b_slot(ib)) <= x) { out |= (uint32_t)b_slot(ib) << (4 * no); ++no; ++ib; }
+            if (ib == nb) { while (ia < na) { out |= (uint32_t)a_slot(ia) << (4 * no); ++no; ++ia; } break; }
+        }
+        phase_a = true;
+    }
+    return out;
+}
+// does path edge ka come before kb in that order?  (both become active at sample row m)
+__device__ __forceinline__ bool new_order_before(const PathEdges& PE, uint32_t ka, uint32_t kb, int m, bool path_order) {
+    int cell[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int cnt = 0, sa = -1, sb = -1;
+    const uint32_t ne = PE.size();
+    for (uint32_t k = 0; k < ne; ++k) {
+        const DevEdge e = PE(k);
+        if (e.ytop != m || e.ybot <= m) continue;
+        if (cnt >= 8) return path_order;
+        int c = e.x1;
+        if (e.dy) { int32_t q; int64_t r; edge_x_at(e, m, q, r); c = cell_of(q, r, e.dy); }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) if (t == cnt) cell[t] = c;
+        if (k == ka) sa = cnt;
+        if (k == kb) sb = cnt;
+        ++cnt;
+    }
+    if (sa < 0 || sb < 0) return path_order;
+    // sort_edges on slots 0..cnt-1: pairs, then 2+2, 2+2, then 4+4
+    uint32_t run[4]; int rn[4];
+#pragma unroll
+    for (int p2 = 0; p2 < 4; ++p2) {
+        const int x = 2 * p2, y = 2 * p2 + 1;
+        if (y < cnt) { const bool keep = sel8(cell, x) <= sel8(cell, y); run[p2] = keep ? (uint32_t)(x | (y << 4)) : (uint32_t)(y | (x << 4)); rn[p2] = 2; }
+        else if (x < cnt) { run[p2] = (uint32_t)x; rn[p2] = 1; }
+        else { run[p2] = 0; rn[p2] = 0; }
+    }
+    const uint32_t L = merge_runs(run[0], rn[0], run[1], rn[1], cell);
+    const uint32_t R = merge_runs(run[2], rn[2], run[3], rn[3], cell);
+    const uint32_t all = merge_runs(L, rn[0] + rn[1], R, rn[2] + rn[3], cell);
+    int pa = 0, pb = 0;
+    for (int i = 0; i < cnt; ++i) { const int slot = (int)((all >> (4 * i)) & 15u); if (slot == sa) pa = i; if (slot == sb) pb = i; }
+    return pa < pb;
+}
+
 // Order of two active edges a, b whose cells coincide at the first sample row s0 of a pixel row (near-parallel edges leaving a
 // common vertex: round joins and caps produce them).  Cairo's list is re-sorted whenever it is looked at and a cell order is
 // violated, and left alone on ties: a sorts first iff it had the smaller cell the last time the list was looked at while the two
 // differed -- every sample row of a sampled pixel row, the first sample row only of an analytically converted one -- and if they
 // never differed since the later one became active, the one that became active earlier, else path order.
-__device__ __forceinline__ bool tied_order(const PathEdges& PE, const DevEdge& a, const DevEdge& b, int s0, bool path_order) {
+__device__ __forceinline__ bool tied_order(const PathEdges& PE, const DevEdge& a, const DevEdge& b, uint32_t ka, uint32_t kb, int s0, bool path_order) {
     const int lo = max(a.ytop, b.ytop);
     auto differ = [&](int s, bool& a_first) {
         int ca = a.x1, cb = b.x1;
@@ -299,8 +367,38 @@ __device__ __forceinline__ bool tied_order(const PathEdges& PE, const DevEdge& a
             for (int s = rs + 14; s >= max(rs, lo); --s) if (differ(s, af)) return af;
         } else if (rs >= lo && differ(rs, af)) return af;
     }
-    if (a.ytop != b.ytop) return a.ytop < b.ytop;
-    return path_order;
+    if (a.ytop != b.ytop) {
+        // one was active when the other arrived at sample row m, tying with it: the active one stays in front unless another edge
+        // arriving at m sorts between the active edge's predecessor and the tie (merge_sorted_edges consumes its lists in
+        // alternating runs; active edges that tie with it are left out of the predecessor search)
+        const bool a_active = a.ytop < b.ytop;
+        const DevEdge& act = a_active ? a : b;
+        const uint32_t k_act = a_active ? ka : kb, k_new = a_active ? kb : ka;
+        const int m = max(a.ytop, b.ytop);
+        int c = act.x1;
+        if (act.dy) { int32_t q; int64_t r; edge_x_at(act, m, q, r); c = cell_of(q, r, act.dy); }
+        const uint32_t ne = PE.size();
+        int L = INT_MIN;
+        for (uint32_t k = 0; k < ne; ++k) {
+            if (k == k_act) continue;
+            const DevEdge e = PE(k);
+            if (!(e.ytop < m && e.ybot > m)) continue;
+            int ce = e.x1;
+            if (e.dy) { int32_t q; int64_t r; edge_x_at(e, m, q, r); ce = cell_of(q, r, e.dy); }
+            if (ce < c) L = max(L, ce);
+        }
+        bool new_first = false;
+        for (uint32_t k = 0; k < ne && !new_first; ++k) {
+            if (k == k_new) continue;
+            const DevEdge e = PE(k);
+            if (!(e.ytop == m && e.ybot > m)) continue;
+            int ce = e.x1;
+            if (e.dy) { int32_t q; int64_t r; edge_x_at(e, m, q, r); ce = cell_of(q, r, e.dy); }
+            new_first = ce >= L && ce < c;
+        }
+        return a_active ? !new_first : new_first;
+    }
+    return new_order_before(PE, ka, kb, a.ytop, path_order);
 }
 
 #ifdef SWFR_PHASES                 // -DSWFR_PHASES: clocks per phase of a k_rows wavefront, summed into counters[8..15] (diagnostic builds only)
@@ -318,7 +416,8 @@ struct FastLds {
 
 // The FULL test of one row (lane) in loop form, for rows with coincident active edges (see tied_order): keys are read from the
 // lane's own column of F, the per-edge results go back into F.flag.  Same decisions as the unrolled test in fast_rows otherwise.
-__device__ __forceinline__ bool slow_full_row(FastLds& F, const PathEdges& PE, const DevEdge* E, int lane, int n, int s0) {
+__device__ __forceinline__ bool slow_full_row(FastLds& F, const PathEdges& PE, const DevEdge* E, const uint16_t* sid, const uint16_t* shi, int lane, int n, int s0) {
+    auto path_index = [&](int local) { return sid ? ((uint32_t)sid[local] | ((uint32_t)shi[local] << 16)) : (uint32_t)local; };
     bool full = true;
     // a new edge that ties with an active one goes first when another new edge sorts between the active edge's predecessor and the
     // tie (Cairo merges the sorted new edges into the active list in alternating runs): bit k of nfmask says so for active edge k
@@ -350,9 +449,10 @@ __device__ __forceinline__ bool slow_full_row(FastLds& F, const PathEdges& PE, c
             bool first = i < j;
             if (tie && nwi == 0 && nwj == 0) {
                 const DevEdge ea = E[F.eid[i][lane]], eb = E[F.eid[j][lane]];
-                first = tied_order(PE, ea, eb, s0, i < j);
+                first = tied_order(PE, ea, eb, path_index(F.eid[i][lane]), path_index(F.eid[j][lane]), s0, i < j);
             }
-            const bool t3 = nwi == 0 ? first : (i < j);
+            else if (tie && nwi == 1 && nwj == 1) first = new_order_before(PE, path_index(F.eid[i][lane]), path_index(F.eid[j][lane]), s0, i < j);
+            const bool t3 = first;
             const bool t_mixed = nwi == 0 ? !((nfmask >> i) & 1u) : ((nfmask >> j) & 1u) != 0;
             const bool before = ci < cj || (tie && (tie2 ? t3 : t_mixed));
             if (before) { w += di; if (ei > ej) full = false; if (tie) fg = false; }
@@ -373,7 +473,8 @@ __device__ __forceinline__ void fast_rows(EPTR E, uint32_t n_list, const DevPath
                                           uint32_t& mode_out, int& n_out_edges, bool& overflow_out,
                                           int32_t (&roles)[ROWS_FAST_N], int32_t (&cols)[ROWS_FAST_N], int (&el)[ROWS_FAST_N],
                                           int32_t (&Q1)[ROWS_FAST_N], int64_t (&R1)[ROWS_FAST_N], int32_t (&Q2)[ROWS_FAST_N], int64_t (&R2)[ROWS_FAST_N],
-                                          uint32_t* rph, unsigned long long& rph_t, int& nmax_out, const PathEdges& PE) {
+                                          uint32_t* rph, unsigned long long& rph_t, int& nmax_out, const PathEdges& PE,
+                                          const uint16_t* sid, const uint16_t* shi) {
     (void)rph; (void)rph_t;
     const int s0 = r * 15;
     const unsigned mask = P.fill_rule ? 1u : ~0u;
@@ -454,7 +555,7 @@ __device__ __forceinline__ void fast_rows(EPTR E, uint32_t n_list, const DevPath
                     const bool cpeq = cp[i] == cp[j];
                     const bool t3 = nw[i] == 0 ? (cp[i] < cp[j] || (cpeq && i < j)) : (i < j);
                     const bool before = cs[i] < cs[j] || (tie && (nw[i] < nw[j] || (tie2 && t3)));
-                    deep |= valid && tie && ((tie2 && nw[i] == 0) || !tie2);   // coincident active edges, or a new edge tying with an active one: settled below (rare)
+                    deep |= valid && tie;                         // coincident edges: their order is settled below (rare)
                     if (valid && before) { w += dr[i]; if (ce[i] > ce[j]) full = false; if (tie) fg = false; }
                     if (valid && !before && tie) lg = false;
                 }
@@ -473,7 +574,7 @@ __device__ __forceinline__ void fast_rows(EPTR E, uint32_t n_list, const DevPath
                 F.flag[s][lane] = (uint16_t)(nw[s] | ((dr[s] + 1) << 1));
             }
             if (deep && !mid_row) {
-                full = slow_full_row(F, PE, (const DevEdge*)E, lane, n, s0);
+                full = slow_full_row(F, PE, (const DevEdge*)E, sid, shi, lane, n, s0);
                 firstg = lastg = 0;
 #pragma unroll
                 for (int j = 0; j < ROWS_FAST_N; ++j) {
@@ -646,8 +747,8 @@ __device__ __forceinline__ void rows_chunk_body(uint32_t block, const DevEdge* _
     uint32_t mode; int n, nmax = ROWS_FAST_N; bool overflow;
     int32_t roles[ROWS_FAST_N], cols[ROWS_FAST_N]; int el[ROWS_FAST_N];
     int32_t Q1[ROWS_FAST_N], Q2[ROWS_FAST_N]; int64_t R1[ROWS_FAST_N], R2[ROWS_FAST_N];
-    if (use_lds) fast_rows((const DevEdge*)staged, n_list, P, r, live, fast_limit, F, lane, mode, n, overflow, roles, cols, el, Q1, R1, Q2, R2, rph, rph_t, nmax, PE);
-    else fast_rows(edges + P.first_edge, P.n_edges, P, r, live, fast_limit, F, lane, mode, n, overflow, roles, cols, el, Q1, R1, Q2, R2, rph, rph_t, nmax, PE);
+    if (use_lds) fast_rows((const DevEdge*)staged, n_list, P, r, live, fast_limit, F, lane, mode, n, overflow, roles, cols, el, Q1, R1, Q2, R2, rph, rph_t, nmax, PE, (const uint16_t*)staged_id, (const uint16_t*)staged_hi);
+    else fast_rows(edges + P.first_edge, P.n_edges, P, r, live, fast_limit, F, lane, mode, n, overflow, roles, cols, el, Q1, R1, Q2, R2, rph, rph_t, nmax, PE, (const uint16_t*)nullptr, (const uint16_t*)nullptr);
     uint32_t n_out = 0;
 #pragma unroll
     for (int s = 0; s < ROWS_FAST_N; ++s) n_out += (s < nmax && s < n && roles[s] != 0) ? 1u : 0u;
@@ -820,15 +921,19 @@ __device__ __forceinline__ void rows_by_slot(EPTR E, uint32_t n_list, const uint
             const int nfi = __shfl((int)nf, src);
             // two edges already active whose cells coincide here and one sample row earlier (near-parallel edges leaving a common
             // vertex): their list order is the cell order of the last sample row where they differed, else the order of insertion
-            const bool deep = mine && cand && i < n && i != slot && ci == c0 && ni == 0 && nw == 0;
+            const bool deep = mine && cand && i < n && i != slot && ci == c0 && ni == nw;
             bool deep_first = i < slot;
             if (__ballot(deep) != 0ull) {                       // wave-uniform, rare
                 const int ki = __shfl(my_k, src);
-                if (deep) { const DevEdge eo = E[ki]; deep_first = tied_order(PE, eo, e, s0, i < slot); }
+                if (deep) {
+                    const uint32_t pk_i = staged_k ? staged_k[ki] : (uint32_t)ki, pk_me = staged_k ? staged_k[my_k] : (uint32_t)my_k;
+                    if (nw == 0) { const DevEdge eo = E[ki]; deep_first = tied_order(PE, eo, e, pk_i, pk_me, s0, i < slot); }
+                    else deep_first = new_order_before(PE, pk_i, pk_me, s0, i < slot);
+                }
             }
             if (!(mine && cand) || i >= n || i == slot) continue;
             const bool tie = ci == c0, tie2 = ni == nw;
-            const bool t3 = ni == 0 ? deep_first : (i < slot);
+            const bool t3 = deep_first;
             const bool t_mixed = ni == 0 ? !nfi : nf;           // active / new tie: the active one first unless its `nf` holds
             const bool before = ci < c0 || (tie && (tie2 ? t3 : t_mixed));
             mixed |= tie && !tie2;
@@ -1030,9 +1135,10 @@ __device__ __forceinline__ void big_row_body(uint32_t block, const DevEdge* __re
                 bool deep_first = i < lane;
                 if (mine && tie && ni == 0 && nw == 0) {   // coincident active edges: see tied_order (rare)
                     const DevEdge eo = E[active[i]];
-                    deep_first = tied_order(PE, eo, e, s0, i < lane);
+                    deep_first = tied_order(PE, eo, e, active[i], k_mine, s0, i < lane);
                 }
-                const bool t3 = ni == 0 ? deep_first : (i < lane);
+                else if (mine && tie && ni == 1 && nw == 1) deep_first = new_order_before(PE, active[i], k_mine, s0, i < lane);
+                const bool t3 = deep_first;
                 const bool t_mixed = ni == 0 ? !((nfb >> i) & 1ull) : ((nfb >> lane) & 1ull) != 0ull;
                 const bool before = ci < c0 || (tie && (tie2 ? t3 : t_mixed));
                 mixed |= mine && tie && !tie2;
@@ -1224,9 +1330,10 @@ __global__ __launch_bounds__(256) void k_rows_huge(const DevEdge* __restrict__ e
                     bool deep_first = i < j;
                     if (tie && ni == 0 && nw == 0) {    // coincident active edges: see tied_order (rare)
                         const DevEdge ea = E[active[i]], eb = E[active[j]];
-                        deep_first = tied_order(PE, ea, eb, s0, i < j);
+                        deep_first = tied_order(PE, ea, eb, active[i], active[j], s0, i < j);
                     }
-                    const bool t3 = ni == 0 ? deep_first : (i < j);
+                    else if (tie && ni == 1 && nw == 1) deep_first = new_order_before(PE, active[i], active[j], s0, i < j);
+                    const bool t3 = deep_first;
                     const bool t_mixed = ni == 0 ? !nfi : nfj != 0;
                     const bool before = ci < c0 || (tie && (tie2 ? t3 : t_mixed));
                     mixed |= tie && !tie2;
