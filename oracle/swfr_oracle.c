@@ -2049,6 +2049,19 @@ EXPORT int swfo_last_polygon(swfo_ctx *c, const int32_t **edges, int *rectilinea
     return c->last_poly_n;
 }
 EXPORT int swfo_is_clear(swfo_ctx *c) { return c->is_clear; }
+EXPORT uint32_t swfo_debug_sample(swfo_ctx *c, int px, int py) { return sample_source(&c->src, px, py); }   /* diagnostics */
+/* diagnostics: the pixman parameters of the current radial source as last prepared (tools/pixman_probe.py) */
+EXPORT int swfo_debug_radial(swfo_ctx *c, int64_t *out /* 16: pm[6], pox, poy, c1x, c1y, c1r, dx, dy, dr, n_intervals, - */, int64_t *stops_x, float *ramp)
+{
+    const source_t *s = &c->src;
+    if (s->kind != SRC_RADIAL || !s->g_x) return 0;
+    for (int i = 0; i < 6; i++) out[i] = s->pm[i / 3][i % 3];
+    out[6] = s->pox; out[7] = s->poy; out[8] = s->g_c1x; out[9] = s->g_c1y; out[10] = s->g_c1r; out[11] = s->g_dx; out[12] = s->g_dy; out[13] = s->g_dr;
+    out[14] = s->g_n; out[15] = 0;
+    for (int i = 0; i <= s->g_n; i++) stops_x[i] = s->g_x[i];
+    for (int i = 0; i < 8 * s->g_n; i++) ramp[i] = s->g_ramp[i];
+    return 1;
+}
 
 /* Direct entry for timing/large scenes: fill closed polygons given in 24.8 device coordinates.
    counts[i] vertices each, colours premultiplied ARGB.  Same code path as swfo_fill_preserve. */

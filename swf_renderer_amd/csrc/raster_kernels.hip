@@ -237,6 +237,9 @@ __global__ __launch_bounds__(256) void k_front(const swfr_edge* __restrict__ in,
 #define CLS_PARTIAL 1u                // some row needs the general accumulate + scan path
 #define CLS_NOTFULL 2u                // some in-frame row of the tile is not uniformly alpha 255
 #define CLS_NONEMPTY 4u               // some row has coverage
+#define CLS_HOLE 16u                  // (inside the classifiers only) a row of the path has no coverage in this tile: with CLS_NONEMPTY
+                                      // from another row the tile is partial even if no single pixel is -- e.g. the last row of a path
+                                      // whose bottom lies less than a sample row below a pixel boundary
 #define CLS_BOX 8u                    // rectilinear path evaluated per pixel from its boxes
 
 #define ROWS_FAST_N 8            // active edges per row handled in registers by k_rows
@@ -832,7 +835,7 @@ __device__ __forceinline__ void rows_chunk_body(uint32_t block, const DevEdge* _
                     const bool inside_x = P.x_min <= tx0 && P.x_max >= tile_x1;
                     const uint32_t a = (uint32_t)((carry * 512 * 17 + 256) >> 9) & 255u;
                     if (inter) f = CLS_PARTIAL | CLS_NOTFULL | CLS_NONEMPTY;
-                    else if (a == 0) f = CLS_NOTFULL;
+                    else if (a == 0) f = CLS_NOTFULL | CLS_HOLE;
                     else if (a == 255 && inside_x) f = CLS_NONEMPTY;
                     else f = CLS_PARTIAL | CLS_NOTFULL | CLS_NONEMPTY;
                 }
@@ -842,6 +845,8 @@ __device__ __forceinline__ void rows_chunk_body(uint32_t block, const DevEdge* _
             f |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f, 0x124, 0xf, 0xf, false);   // row_ror:4
             f |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f, 0x122, 0xf, 0xf, false);   // row_ror:2
             f |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f, 0x121, 0xf, 0xf, false);   // row_ror:1
+            if ((f & (CLS_HOLE | CLS_NONEMPTY)) == (CLS_HOLE | CLS_NONEMPTY)) f |= CLS_PARTIAL;
+            f &= ~CLS_HOLE;
             if ((lane & 15) == 0 && band_ok) out[(size_t)tc * n_b] = (uint8_t)f;
         }
     }
@@ -1808,7 +1813,7 @@ __global__ __launch_bounds__(64) void k_class(const BandEntry* __restrict__ band
                 const bool inside_x = e.x_min <= tx0 && e.x_max >= tile_x1;
                 const uint32_t a = (uint32_t)((carry * 512 * 17 + 256) >> 9) & 255u;
                 if (inter) f = CLS_PARTIAL | CLS_NOTFULL | CLS_NONEMPTY;
-                else if (a == 0) f = CLS_NOTFULL;
+                else if (a == 0) f = CLS_NOTFULL | CLS_HOLE;
                 else if (a == 255 && inside_x) f = CLS_NONEMPTY;
                 else f = CLS_PARTIAL | CLS_NOTFULL | CLS_NONEMPTY;       // uniform partial alpha or column masking
             }
@@ -1818,6 +1823,8 @@ __global__ __launch_bounds__(64) void k_class(const BandEntry* __restrict__ band
         f |= (uint32_t)__shfl_xor((int)f, 4);
         f |= (uint32_t)__shfl_xor((int)f, 2);
         f |= (uint32_t)__shfl_xor((int)f, 1);
+        if ((f & (CLS_HOLE | CLS_NONEMPTY)) == (CLS_HOLE | CLS_NONEMPTY)) f |= CLS_PARTIAL;
+        f &= ~CLS_HOLE;
         if (row == 0 && tc <= tc1) out[(size_t)tc * n_b] = (uint8_t)f;
     }
 }

@@ -280,9 +280,36 @@ def rand_mixed_scene(rng):
 
 
 
+def rand_big_scene(rng):
+    """A large frame (several hundred tiles) with dozens of overlapping shapes of every kind: the 64-row chunks of the fused row
+    kernel, long band lists, occlusion culling and the shaded tile kernel all at once."""
+    import scenarios
+    W, H = int(rng.integers(500, 1300)), int(rng.integers(400, 900))
+    bmp = make_bitmap_tag(3, int(rng.integers(8, 64)), int(rng.integers(8, 64)), rng)
+    kids = []
+    for _ in range(int(rng.integers(15, 50))):
+        kind = int(rng.integers(0, 10))
+        if kind < 5:
+            sub = rand_mixed_scene(rng)
+        elif kind < 8:
+            sub = rand_bitmap_scene(rng)
+        else:
+            sub = rand_radial_scene(rng)
+        k = sub["stage"]["children"][int(rng.integers(0, len(sub["stage"]["children"])))]
+        k = dict(k)
+        sc = float(rng.choice([1.0, 2.5, 4.0, 7.0]))
+        m0 = k.get("matrix") or scenarios._m()
+        tx, ty = int(rng.integers(-200, W * 20 - 200)), int(rng.integers(-200, H * 20 - 200))
+        # outer placement: scale the child's own matrix and move it somewhere in the big frame
+        k["matrix"] = {"scale_x": int(m0["scale_x"] * sc), "scale_y": int(m0["scale_y"] * sc), "rotate_skew0": int(m0["rotate_skew0"] * sc),
+                       "rotate_skew1": int(m0["rotate_skew1"] * sc), "translate_x": int(m0["translate_x"] * sc) + tx, "translate_y": int(m0["translate_y"] * sc) + ty}
+        kids.append(k)
+    return dict(width=W, height=H, bitmaps=[bmp], stage={"children": kids})
+
+
 def soak_scene(name, seed, index):
     """Scene `index` of generator `name` in tools/soak.py's numbering (the generators are seeded per name)."""
-    gens = {"mixed": rand_mixed_scene, "bitmap": rand_bitmap_scene, "radial": rand_radial_scene}
+    gens = {"mixed": rand_mixed_scene, "bitmap": rand_bitmap_scene, "radial": rand_radial_scene, "big": rand_big_scene}
     rng = np.random.default_rng(seed + sum(map(ord, name)))
     for _ in range(index + 1):
         sc = gens[name](rng)

@@ -236,6 +236,22 @@ def test_soak_regressions_tied_edges(case):
     assert diff_stats(product_render(sc), oracle_render(sc)) == (0, 0), case
 
 
+def test_tile_with_an_uncovered_path_row_is_not_a_full_cover():
+    """Soak finding (large frames): a path whose bottom lies less than a sample row below a pixel boundary has a last pixel row with
+    no active sample row at all.  A tile that the path covers completely in its other rows is then neither empty nor full although
+    no single pixel of it is partial: it must take the accumulate-and-scan route, not the full-cover shortcut."""
+    for sy in (1.0001, 1.0, 1.002):                                  # bottom at y = 242.026 (the case), 242.0, 242.48
+        pts = np.array([(9.75, 213.40), (350.65, 242.0), (155.5, 242.0)])
+        for col in (scenarios._rgba(200, 80, 40, 255), scenarios._rgba(200, 80, 40, 140)):
+            tag = scenarios._poly_shape(np.rint(pts * 20), {"type": "solid", "color": col})
+            sc = dict(width=512, height=300, stage={"children": [{"type": "shape", "definition": tag, "matrix": scenarios._m(1.0, sy)}]})
+            assert diff_stats(product_render(sc), oracle_render(sc)) == (0, 0), (sy, col)
+    for case in (("big", 200, 551), ("big", 200, 572)):
+        from helpers import soak_scene
+        sc = soak_scene(*case)
+        assert diff_stats(product_render(sc), oracle_render(sc)) == (0, 0), case
+
+
 # ---- every internal route of the row/tile kernels gives the same pixels
 @pytest.mark.parametrize("env", [{"SWFR_FAST_LIMIT": "0"}, {"SWFR_FAST_LIMIT": "3"}, {"SWFR_CELL_MODE": "0"}, {"SWFR_CHUNK_ROWS": "64"},
                                  {"SWFR_CHUNK_ROWS": "8"}, {"SWFR_CHUNK_ROWS": "8", "SWFR_FAST_LIMIT": "3"}, {"SWFR_CHUNK_ROWS": "16", "SWFR_CELL_MODE": "0"},
