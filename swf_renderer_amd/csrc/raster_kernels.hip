@@ -252,63 +252,44 @@ struct PathEdges {
     const DevEdge* dev; const swfr_edge* raw; const DevPath* P; bool from_raw;
     __device__ __forceinline__ DevEdge operator()(uint32_t k) const { return from_raw ? make_dev_edge(raw[P->first_edge + k], *P) : dev[P->first_edge + k]; }
     __device__ __forceinline__ uint32_t size() const { return P->n_edges; }
+    // the sample-row span alone (the part of make_dev_edge that needs no division)
+    __device__ __forceinline__ void span(uint32_t k, int& ytop, int& ybot) const {
+        if (!from_raw) { ytop = dev[P->first_edge + k].ytop; ybot = dev[P->first_edge + k].ybot; return; }
+        const swfr_edge& e = raw[P->first_edge + k];
+        ytop = max((int)((15ll * e.top + 128) >> 8), P->y_min * 15);
+        ybot = min((int)((15ll * e.bottom + 128) >> 8), P->y_max * 15);
+        if (ybot <= ytop) ytop = ybot = 0;
+    }
 };
-// Was pixel row rho of the path converted sample row by sample row (Cairo then re-sorts its edge list at every sample row), or
-// analytically (the list is looked at only at the row's first sample row)?  Sampled iff an edge becomes active after the first
-// sample row, an active edge ends before the last, or two edges swap places over the row (edges that tie at the row's first
-// sample row are taken as not swapping; paths with more than 128 edges skip this quadratic test).
-__device__ __forceinline__ bool row_was_sampled(const PathEdges& PE, int rho) {
-    const int s = rho * 15;
-    const uint32_t ne = PE.size();
-    for (uint32_t k = 0; k < ne; ++k) {
-        const DevEdge e = PE(k);
-        if (e.ybot <= s || e.ytop >= s + 15) continue;
-        if (e.ytop > s || e.ybot < s + 15) return true;
-    }
-    if (ne > 128u) return false;
-    for (uint32_t u = 0; u < ne; ++u) {
-        const DevEdge eu = PE(u);
-        if (eu.ybot <= s || eu.ytop >= s + 15) continue;
-        int u0 = eu.x1, u1 = eu.x1;
-        if (eu.dy) { int32_t q; int64_t r; edge_x_at(eu, s, q, r); u0 = cell_of(q, r, eu.dy); edge_x_at(eu, s + 15, q, r); u1 = cell_of(q, r, eu.dy); }
-        for (uint32_t v = u + 1; v < ne; ++v) {
-            const DevEdge ev = PE(v);
-            if (ev.ybot <= s || ev.ytop >= s + 15) continue;
-            int v0 = ev.x1, v1 = ev.x1;
-            if (ev.dy) { int32_t q; int64_t r; edge_x_at(ev, s, q, r); v0 = cell_of(q, r, ev.dy); edge_x_at(ev, s + 15, q, r); v1 = cell_of(q, r, ev.dy); }
-            if ((u0 < v0 && u1 > v1) || (u0 > v0 && u1 < v1)) return true;
-        }
-    }
-    return false;
-}
 // ---- the order Cairo gives edges that become active at the same sample row m: the row's bucket holds them in path order, and
 //      sort_edges -- pairs, then merges of runs of 2, 4, ... with merge_sorted_edges, whose two loops consume the lists in
 //      alternating runs ("<=" on both sides: on a tie the list being consumed keeps going) -- sorts them by cell.  Restated for up
-//      to eight such edges in registers (lists are packed 4-bit slot numbers, cells are looked up by select chains); more than
-//      eight: path order.
-__device__ __forceinline__ int sel8(const int (&v)[8], int i) {
+//      to sixteen such edges in registers (lists are packed 4-bit slot numbers, cells are looked up by select chains); more than
+//      sixteen: path order.
+#define NEW_SORT_MAX 8
+__device__ __forceinline__ int sel_cell(const int (&v)[NEW_SORT_MAX], int i) {
     int r = v[0];
 #pragma unroll
-    for (int t = 1; t < 8; ++t) r = (i == t) ? v[t] : r;
+    for (int t = 1; t < NEW_SORT_MAX; ++t) r = (i == t) ? v[t] : r;
     return r;
 }
-__device__ __forceinline__ uint32_t merge_runs(uint32_t A, int na, uint32_t B, int nb, const int (&cell)[8]) {
+__device__ __forceinline__ uint64_t merge_runs(uint64_t A, int na, uint64_t B, int nb, const int (&cell)[NEW_SORT_MAX]) {
     if (nb == 0) return A;
     if (na == 0) return B;
-    uint32_t out = 0; int no = 0, ia = 0, ib = 0;
-    auto a_slot = [&](int i) { return (int)((A >> (4 * i)) & 15u); };
-    auto b_slot = [&](int i) { return (int)((B >> (4 * i)) & 15u); };
-    bool phase_a = sel8(cell, a_slot(0)) <= sel8(cell, b_slot(0));
-    for (int guard = 0; guard < 32; ++guard) {
+    uint64_t out = 0; int no = 0, ia = 0, ib = 0;
+    auto a_slot = [&](int i) { return (int)((A >> (4 * i)) & 15ull); };
+    auto b_slot = [&](int i) { return (int)((B >> (4 * i)) & 15ull); };
+    bool phase_a = sel_cell(cell, a_slot(0)) <= sel_cell(cell, b_slot(0));
+    for (int guard = 0; guard < 2 * NEW_SORT_MAX + 2; ++guard) {
         if (phase_a) {
-            const int x = sel8(cell, b_slot(ib));
-            while (ia < na && sel8(cell, a_slot(ia)) <= x) { out |= (uint32_t)a_slot(ia) << (4 * no); ++no; ++ia; }
-            if (ia == na) { while (ib < nb) { out |= (uint32_t)b_slot(ib) << (4 * no); ++no; ++ib; } break; }
+            const int x = sel_cell(cell, b_slot(ib));
+            while (ia < na && sel_cell(cell, a_slot(ia)) <= x) { out |= (uint64_t)a_slot(ia) << (4 * no); ++no; ++ia; }
+            if (ia == na) { while (ib < nb) { out |= (uint64_t)b_slot(ib) << (4 * no); ++no; ++ib; } break; }
         }
         {
-            const int x = sel8(cell, a_slot(ia));
-            while (ib < nb && sel8(cell, b_slot(ib)) <= x) { out |= (uint32_t)b_slot(ib) << (4 * no); ++no; ++ib; }
-            if (ib == nb) { while (ia < na) { out |= (uint32_t)a_slot(ia) << (4 * no); ++no; ++ia; } break; }
+            const int x = sel_cell(cell, a_slot(ia));
+            while (ib < nb && sel_cell(cell, b_slot(ib)) <= x) { out |= (uint64_t)b_slot(ib) << (4 * no); ++no; ++ib; }
+            if (ib == nb) { while (ia < na) { out |= (uint64_t)a_slot(ia) << (4 * no); ++no; ++ia; } break; }
         }
         phase_a = true;
     }
@@ -316,39 +297,118 @@ __device__ __forceinline__ uint32_t merge_runs(uint32_t A, int na, uint32_t B, i
 }
 // does path edge ka come before kb in that order?  (both become active at sample row m)
 __device__ __forceinline__ bool new_order_before(const PathEdges& PE, uint32_t ka, uint32_t kb, int m, bool path_order) {
-    int cell[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int cell[NEW_SORT_MAX];
+#pragma unroll
+    for (int t = 0; t < NEW_SORT_MAX; ++t) cell[t] = 0;
     int cnt = 0, sa = -1, sb = -1;
     const uint32_t ne = PE.size();
     for (uint32_t k = 0; k < ne; ++k) {
+        int yt, yb;
+        PE.span(k, yt, yb);
+        if (yt != m || yb <= m) continue;
+        if (cnt >= NEW_SORT_MAX) return path_order;
         const DevEdge e = PE(k);
-        if (e.ytop != m || e.ybot <= m) continue;
-        if (cnt >= 8) return path_order;
         int c = e.x1;
         if (e.dy) { int32_t q; int64_t r; edge_x_at(e, m, q, r); c = cell_of(q, r, e.dy); }
 #pragma unroll
-        for (int t = 0; t < 8; ++t) if (t == cnt) cell[t] = c;
+        for (int t = 0; t < NEW_SORT_MAX; ++t) if (t == cnt) cell[t] = c;
         if (k == ka) sa = cnt;
         if (k == kb) sb = cnt;
         ++cnt;
     }
     if (sa < 0 || sb < 0) return path_order;
-    // sort_edges on slots 0..cnt-1: pairs, then 2+2, 2+2, then 4+4
-    uint32_t run[4]; int rn[4];
+    // sort_edges on slots 0..cnt-1: pairs, then runs of 2 + 2, 4 + 4, 8 + 8
+    uint64_t run[NEW_SORT_MAX / 2]; int rn[NEW_SORT_MAX / 2];
 #pragma unroll
-    for (int p2 = 0; p2 < 4; ++p2) {
+    for (int p2 = 0; p2 < NEW_SORT_MAX / 2; ++p2) {
         const int x = 2 * p2, y = 2 * p2 + 1;
-        if (y < cnt) { const bool keep = sel8(cell, x) <= sel8(cell, y); run[p2] = keep ? (uint32_t)(x | (y << 4)) : (uint32_t)(y | (x << 4)); rn[p2] = 2; }
-        else if (x < cnt) { run[p2] = (uint32_t)x; rn[p2] = 1; }
+        if (y < cnt) { const bool keep = sel_cell(cell, x) <= sel_cell(cell, y); run[p2] = keep ? (uint64_t)(x | (y << 4)) : (uint64_t)(y | (x << 4)); rn[p2] = 2; }
+        else if (x < cnt) { run[p2] = (uint64_t)x; rn[p2] = 1; }
         else { run[p2] = 0; rn[p2] = 0; }
     }
-    const uint32_t L = merge_runs(run[0], rn[0], run[1], rn[1], cell);
-    const uint32_t R = merge_runs(run[2], rn[2], run[3], rn[3], cell);
-    const uint32_t all = merge_runs(L, rn[0] + rn[1], R, rn[2] + rn[3], cell);
+#pragma unroll
+    for (int width = 1; width < NEW_SORT_MAX / 2; width *= 2) {
+#pragma unroll
+        for (int p2 = 0; p2 < NEW_SORT_MAX / 2; p2 += 2 * width) {
+            run[p2] = merge_runs(run[p2], rn[p2], run[p2 + width], rn[p2 + width], cell);
+            rn[p2] += rn[p2 + width];
+        }
+    }
+    const uint64_t all = run[0];
     int pa = 0, pb = 0;
-    for (int i = 0; i < cnt; ++i) { const int slot = (int)((all >> (4 * i)) & 15u); if (slot == sa) pa = i; if (slot == sb) pb = i; }
+    for (int i = 0; i < cnt; ++i) { const int slot = (int)((all >> (4 * i)) & 15ull); if (slot == sa) pa = i; if (slot == sb) pb = i; }
     return pa < pb;
 }
 
+// Two edges that tie at sample row m, where one of them arrives while the other is already active: the active one stays in front
+// unless another edge arriving at m sorts between the active edge's predecessor and the tie (merge_sorted_edges consumes its lists
+// in alternating runs; active edges that tie with it are left out of the predecessor search).  True when a goes first.
+__device__ __forceinline__ bool arrival_order(const PathEdges& PE, const DevEdge& a, const DevEdge& b, uint32_t ka, uint32_t kb) {
+    const bool a_active = a.ytop < b.ytop;
+    const DevEdge& act = a_active ? a : b;
+    const uint32_t k_act = a_active ? ka : kb, k_new = a_active ? kb : ka;
+    const int m = max(a.ytop, b.ytop);
+    int c = act.x1;
+    if (act.dy) { int32_t q; int64_t r; edge_x_at(act, m, q, r); c = cell_of(q, r, act.dy); }
+    const uint32_t ne = PE.size();
+    int L = INT_MIN;
+    for (uint32_t k = 0; k < ne; ++k) {
+        if (k == k_act) continue;
+        const DevEdge e = PE(k);
+        if (!(e.ytop < m && e.ybot > m)) continue;
+        int ce = e.x1;
+        if (e.dy) { int32_t q; int64_t r; edge_x_at(e, m, q, r); ce = cell_of(q, r, e.dy); }
+        if (ce < c) L = max(L, ce);
+    }
+    bool new_first = false;
+    for (uint32_t k = 0; k < ne && !new_first; ++k) {
+        if (k == k_new) continue;
+        const DevEdge e = PE(k);
+        if (!(e.ytop == m && e.ybot > m)) continue;
+        int ce = e.x1;
+        if (e.dy) { int32_t q; int64_t r; edge_x_at(e, m, q, r); ce = cell_of(q, r, e.dy); }
+        new_first = ce >= L && ce < c;
+    }
+    return a_active ? !new_first : new_first;
+}
+// Was pixel row rho of the path converted sample row by sample row (Cairo then re-sorts its edge list at every sample row), or
+// analytically (the list is looked at only at the row's first sample row)?  Sampled iff an edge becomes active after the first
+// sample row, an active edge ends before the last, or two edges swap places over the row.  Edges that tie at the row's first
+// sample row swap when the one in front ends up behind: their order is known when at least one of them became active at that
+// sample row (the sort / merge rules above); two older edges are taken as not swapping.  Paths with more than 512 edges skip
+// this quadratic test.
+__device__ __forceinline__ bool row_was_sampled(const PathEdges& PE, int rho) {
+    const int s = rho * 15;
+    const uint32_t ne = PE.size();
+    for (uint32_t k = 0; k < ne; ++k) {
+        int yt, yb;
+        PE.span(k, yt, yb);
+        if (yb <= s || yt >= s + 15) continue;
+        if (yt > s || yb < s + 15) return true;
+    }
+    if (ne > 512u) return false;
+    for (uint32_t u = 0; u < ne; ++u) {
+        int yt, yb;
+        PE.span(u, yt, yb);
+        if (yb <= s || yt >= s + 15) continue;
+        const DevEdge eu = PE(u);
+        int u0 = eu.x1, u1 = eu.x1;
+        if (eu.dy) { int32_t q; int64_t r; edge_x_at(eu, s, q, r); u0 = cell_of(q, r, eu.dy); edge_x_at(eu, s + 15, q, r); u1 = cell_of(q, r, eu.dy); }
+        for (uint32_t v = u + 1; v < ne; ++v) {
+            PE.span(v, yt, yb);
+            if (yb <= s || yt >= s + 15) continue;
+            const DevEdge ev = PE(v);
+            int v0 = ev.x1, v1 = ev.x1;
+            if (ev.dy) { int32_t q; int64_t r; edge_x_at(ev, s, q, r); v0 = cell_of(q, r, ev.dy); edge_x_at(ev, s + 15, q, r); v1 = cell_of(q, r, ev.dy); }
+            if ((u0 < v0 && u1 > v1) || (u0 > v0 && u1 < v1)) return true;
+            if (u0 == v0 && u1 != v1 && (eu.ytop == s || ev.ytop == s)) {
+                const bool u_first = eu.ytop == ev.ytop ? new_order_before(PE, u, v, s, true) : arrival_order(PE, eu, ev, u, v);
+                if (u_first ? u1 > v1 : v1 > u1) return true;
+            }
+        }
+    }
+    return false;
+}
 // Order of two active edges a, b whose cells coincide at the first sample row s0 of a pixel row (near-parallel edges leaving a
 // common vertex: round joins and caps produce them).  Cairo's list is re-sorted whenever it is looked at and a cell order is
 // violated, and left alone on ties: a sorts first iff it had the smaller cell the last time the list was looked at while the two
@@ -370,37 +430,7 @@ __device__ __forceinline__ bool tied_order(const PathEdges& PE, const DevEdge& a
             for (int s = rs + 14; s >= max(rs, lo); --s) if (differ(s, af)) return af;
         } else if (rs >= lo && differ(rs, af)) return af;
     }
-    if (a.ytop != b.ytop) {
-        // one was active when the other arrived at sample row m, tying with it: the active one stays in front unless another edge
-        // arriving at m sorts between the active edge's predecessor and the tie (merge_sorted_edges consumes its lists in
-        // alternating runs; active edges that tie with it are left out of the predecessor search)
-        const bool a_active = a.ytop < b.ytop;
-        const DevEdge& act = a_active ? a : b;
-        const uint32_t k_act = a_active ? ka : kb, k_new = a_active ? kb : ka;
-        const int m = max(a.ytop, b.ytop);
-        int c = act.x1;
-        if (act.dy) { int32_t q; int64_t r; edge_x_at(act, m, q, r); c = cell_of(q, r, act.dy); }
-        const uint32_t ne = PE.size();
-        int L = INT_MIN;
-        for (uint32_t k = 0; k < ne; ++k) {
-            if (k == k_act) continue;
-            const DevEdge e = PE(k);
-            if (!(e.ytop < m && e.ybot > m)) continue;
-            int ce = e.x1;
-            if (e.dy) { int32_t q; int64_t r; edge_x_at(e, m, q, r); ce = cell_of(q, r, e.dy); }
-            if (ce < c) L = max(L, ce);
-        }
-        bool new_first = false;
-        for (uint32_t k = 0; k < ne && !new_first; ++k) {
-            if (k == k_new) continue;
-            const DevEdge e = PE(k);
-            if (!(e.ytop == m && e.ybot > m)) continue;
-            int ce = e.x1;
-            if (e.dy) { int32_t q; int64_t r; edge_x_at(e, m, q, r); ce = cell_of(q, r, e.dy); }
-            new_first = ce >= L && ce < c;
-        }
-        return a_active ? !new_first : new_first;
-    }
+    if (a.ytop != b.ytop) return arrival_order(PE, a, b, ka, kb);
     return new_order_before(PE, ka, kb, a.ytop, path_order);
 }
 
@@ -1467,7 +1497,7 @@ __global__ __launch_bounds__(256) void k_rows_huge(const DevEdge* __restrict__ e
 
 // The row pass is one launch: the first n_big workgroups take the crowded rows (the longest wavefronts start first), the rest
 // take the chunks -- lane = row for crowded scenes (k_rows), lane = (row, slot) for scenes of a few tall paths (k_rows_rs).
-__global__ __launch_bounds__(64) void k_rows(const DevEdge* __restrict__ edges, const DevPath* __restrict__ paths,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void k_rows(const DevEdge* __restrict__ edges, const DevPath* __restrict__ paths,
                                              const uint32_t* __restrict__ row_base, const ChunkInfo* __restrict__ chunks,
                                              uint32_t n_paths, RowInfo* __restrict__ rows, Rec* __restrict__ records,
                                              uint32_t band_index, uint32_t band_count, int fast_limit, int cell_mode,
