@@ -1051,8 +1051,13 @@ static void source_prepare_pixman_m(source_t *s, mat_t m, int x0, int y0, int x1
     if (!mat_invert_cairo(&inv)) return;
     for (int it = 0; it < 5; it++) {
         const int64_t vx = f16_from_double(xc), vy = f16_from_double(yc);
-        double x = (double)((s->pm[0][0] * vx + s->pm[0][1] * vy + s->pm[0][2] * 65536 + 0x8000) >> 16) / 65536.0;
-        double y = (double)((s->pm[1][0] * vx + s->pm[1][1] * vy + s->pm[1][2] * 65536 + 0x8000) >> 16) / 65536.0;
+        const int64_t tx = (s->pm[0][0] * vx + s->pm[0][1] * vy + s->pm[0][2] * 65536 + 0x8000) >> 16;
+        const int64_t ty = (s->pm[1][0] * vx + s->pm[1][1] * vy + s->pm[1][2] * 65536 + 0x8000) >> 16;
+        /* cairo-matrix.c "If we can't transform the reference point, skip the adjustment": pixman_transform_point_3d (pixman-matrix.c)
+           reports failure when a coordinate of the result does not fit 16.16 -- gradients scaled to +-16383 whose centre of
+           operation maps beyond +-32768 */
+        if (tx != (int32_t)tx || ty != (int32_t)ty) return;
+        double x = (double)tx / 65536.0, y = (double)ty / 65536.0;
         mat_point(&inv, &x, &y);
         x -= xc; y -= yc;
         mat_distance(&m, &x, &y);
@@ -1061,7 +1066,13 @@ static void source_prepare_pixman_m(source_t *s, mat_t m, int x0, int y0, int x1
         if (dx == 0 && dy == 0) break;
     }
 }
-static void source_prepare_pixman(source_t *s, int x0, int y0, int x1, int y1) { source_prepare_pixman_m(s, s->inv, x0, y0, x1, y1); }
+static void source_prepare_pixman(source_t *s, int x0, int y0, int x1, int y1)
+{
+    source_prepare_pixman_m(s, s->inv, x0, y0, x1, y1);
+    if (getenv("SWFO_TRACE_SOURCE"))
+        fprintf(stderr, "surface transform %d %d %d | %d %d %d offset %d %d rect %d %d %d %d\n", (int)s->pm[0][0], (int)s->pm[0][1], (int)s->pm[0][2],
+                (int)s->pm[1][0], (int)s->pm[1][1], (int)s->pm[1][2], s->pox, s->poy, x0, y0, x1, y1);
+}
 
 /* ---- radial gradients exactly as cairo 1.16 + pixman 0.40 compute them (cairo-image-source.c _pixman_image_for_gradient,
         cairo-pattern.c _cairo_gradient_pattern_fit_to_range, pixman-radial-gradient.c, pixman-gradient-walker.c): the circles are
@@ -1082,6 +1093,9 @@ static void source_prepare_radial(source_t *s, int x0, int y0, int x1, int y1)
         mat_multiply(&m, &s->inv, &sc);
     }
     source_prepare_pixman_m(s, m, x0, y0, x1, y1);
+    if (getenv("SWFO_TRACE_SOURCE"))                                 /* diagnostic: compare with what libcairo hands pixman */
+        fprintf(stderr, "radial transform %d %d %d | %d %d %d offset %d %d rect %d %d %d %d\n", (int)s->pm[0][0], (int)s->pm[0][1], (int)s->pm[0][2],
+                (int)s->pm[1][0], (int)s->pm[1][1], (int)s->pm[1][2], s->pox, s->poy, x0, y0, x1, y1);
     s->g_c1x = f16_from_double(c0x); s->g_c1y = f16_from_double(c0y); s->g_c1r = f16_from_double(c0r);
     s->g_dx = f16_from_double(c1x) - s->g_c1x; s->g_dy = f16_from_double(c1y) - s->g_c1y; s->g_dr = f16_from_double(c1r) - s->g_c1r;
     s->g_a = (double)(s->g_dx * s->g_dx + s->g_dy * s->g_dy - s->g_dr * s->g_dr);
@@ -1812,7 +1826,17 @@ static int op_bounds(swfo_ctx *c, pt_t e1, pt_t e2, int *needs_limits)
     c->bx0 = x0; c->by0 = y0; c->bx1 = x1; c->by1 = y1;
     return x0 < x1 && y0 < y1;
 }
-static int source_is_clear(const source_t *s) { return s->kind == SRC_SOLID && (s->pixel >> 24) == 0; }
+/* cairo-pattern.c _cairo_pattern_is_clear: a transparent solid, or a gradient without a stop that is not transparent
+   (_gradient_is_clear; CAIRO_COLOR_IS_CLEAR is alpha_short <= 0x00ff).  cairo-surface.c nothing_to_do then skips the OVER. */
+static int source_is_clear(const source_t *s)
+{
+    if (s->kind == SRC_SOLID) return (s->pixel >> 24) == 0;
+    if (s->kind == SRC_RADIAL || s->kind == SRC_LINEAR) {
+        for (int i = 0; i < s->nstops; i++) if (s->stops[i].a * 65535.0 + 0.5 >= 256.0) return 0;
+        return 1;
+    }
+    return 0;
+}
 static int source_is_opaque_solid(const source_t *s) { return s->kind == SRC_SOLID && (s->pixel >> 24) == 0xff; }
 
 static void ensure_scratch(swfo_ctx *c)

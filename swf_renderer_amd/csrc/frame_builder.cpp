@@ -267,6 +267,9 @@ void FrameBuilder::emit_fill(const OwnedFill& f, bool morph, double ratio) {
             st.stop_rgba[i][2] = float(c.b / 255.0);
             st.stop_rgba[i][3] = float(c.a / 255.0);
         }
+        // a gradient whose stops are all transparent is a clear source (_cairo_pattern_is_clear -> _gradient_is_clear): OVER with
+        // it is a no-op that leaves the surface's "clear" state alone, like the transparent solid above
+        if (std::all_of(stops.begin(), stops.end(), [](const swfr_color_stop& c) { return c.color.a == 0; })) return;
         styles_.push_back(st);
         style_index = uint32_t(styles_.size() - 1);
     }

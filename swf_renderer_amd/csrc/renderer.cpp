@@ -325,8 +325,12 @@ PixmanPosition pixman_transform_of(Affine m, const int rect[4]) {
     if (!unity && inv.invert_cairo()) {
         for (int it = 0; it < 5; ++it) {
             const int64_t vx = fixed_16_16(xc), vy = fixed_16_16(yc);
-            double x = double((p[0][0] * vx + p[0][1] * vy + p[0][2] * 65536 + 0x8000) >> 16) / 65536.0;
-            double y = double((p[1][0] * vx + p[1][1] * vy + p[1][2] * 65536 + 0x8000) >> 16) / 65536.0;
+            const int64_t tx = (p[0][0] * vx + p[0][1] * vy + p[0][2] * 65536 + 0x8000) >> 16;
+            const int64_t ty = (p[1][0] * vx + p[1][1] * vy + p[1][2] * 65536 + 0x8000) >> 16;
+            // pixman_transform_point_3d fails when the centre does not map into 16.16 (|coordinate| >= 32768): Cairo then leaves
+            // the translation as rounded ("If we can't transform the reference point, skip the adjustment")
+            if (tx != (int32_t)tx || ty != (int32_t)ty) break;
+            double x = double(tx) / 65536.0, y = double(ty) / 65536.0;
             inv.apply(x, y);
             x -= xc;
             y -= yc;
