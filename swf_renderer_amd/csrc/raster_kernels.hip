@@ -375,18 +375,24 @@ __device__ __forceinline__ bool arrival_order(const PathEdges& PE, const DevEdge
 // analytically (the list is looked at only at the row's first sample row)?  Sampled iff an edge becomes active after the first
 // sample row, an active edge ends before the last, or two edges swap places over the row.  Edges that tie at the row's first
 // sample row swap when the one in front ends up behind: their order is known when at least one of them became active at that
-// sample row (the sort / merge rules above); two older edges are taken as not swapping.  Paths with more than 512 edges skip
-// this quadratic test.
+// sample row (the sort / merge rules above); two older edges are ordered by their own history, one level deep (DEPTH), and
+// taken as not swapping beyond that.  The pair test is skipped
+// when (active edges of the row) x (edges of the path) exceeds 2^21 -- thousands of edges in one row.
+template <int DEPTH>
+__device__ __forceinline__ bool tied_order_at(const PathEdges& PE, const DevEdge& a, const DevEdge& b, uint32_t ka, uint32_t kb, int s0, bool path_order);
+template <int DEPTH>
 __device__ __forceinline__ bool row_was_sampled(const PathEdges& PE, int rho) {
     const int s = rho * 15;
     const uint32_t ne = PE.size();
+    uint32_t n_active = 0;
     for (uint32_t k = 0; k < ne; ++k) {
         int yt, yb;
         PE.span(k, yt, yb);
         if (yb <= s || yt >= s + 15) continue;
         if (yt > s || yb < s + 15) return true;
+        ++n_active;
     }
-    if (ne > 512u) return false;
+    if ((uint64_t)n_active * ne > (1u << 21)) return false;      // the pair test below reads n_active * ne spans
     for (uint32_t u = 0; u < ne; ++u) {
         int yt, yb;
         PE.span(u, yt, yb);
@@ -401,8 +407,11 @@ __device__ __forceinline__ bool row_was_sampled(const PathEdges& PE, int rho) {
             int v0 = ev.x1, v1 = ev.x1;
             if (ev.dy) { int32_t q; int64_t r; edge_x_at(ev, s, q, r); v0 = cell_of(q, r, ev.dy); edge_x_at(ev, s + 15, q, r); v1 = cell_of(q, r, ev.dy); }
             if ((u0 < v0 && u1 > v1) || (u0 > v0 && u1 < v1)) return true;
-            if (u0 == v0 && u1 != v1 && (eu.ytop == s || ev.ytop == s)) {
-                const bool u_first = eu.ytop == ev.ytop ? new_order_before(PE, u, v, s, true) : arrival_order(PE, eu, ev, u, v);
+            if (u0 == v0 && u1 != v1) {
+                bool u_first;
+                if (eu.ytop == s || ev.ytop == s) u_first = eu.ytop == ev.ytop ? new_order_before(PE, u, v, s, true) : arrival_order(PE, eu, ev, u, v);
+                else if constexpr (DEPTH > 0) u_first = tied_order_at<DEPTH - 1>(PE, eu, ev, u, v, s, true);   // two older edges: their history
+                else continue;
                 if (u_first ? u1 > v1 : v1 > u1) return true;
             }
         }
@@ -414,7 +423,8 @@ __device__ __forceinline__ bool row_was_sampled(const PathEdges& PE, int rho) {
 // violated, and left alone on ties: a sorts first iff it had the smaller cell the last time the list was looked at while the two
 // differed -- every sample row of a sampled pixel row, the first sample row only of an analytically converted one -- and if they
 // never differed since the later one became active, the one that became active earlier, else path order.
-__device__ __forceinline__ bool tied_order(const PathEdges& PE, const DevEdge& a, const DevEdge& b, uint32_t ka, uint32_t kb, int s0, bool path_order) {
+template <int DEPTH>
+__device__ __forceinline__ bool tied_order_at(const PathEdges& PE, const DevEdge& a, const DevEdge& b, uint32_t ka, uint32_t kb, int s0, bool path_order) {
     const int lo = max(a.ytop, b.ytop);
     auto differ = [&](int s, bool& a_first) {
         int ca = a.x1, cb = b.x1;
@@ -426,12 +436,16 @@ __device__ __forceinline__ bool tied_order(const PathEdges& PE, const DevEdge& a
     bool af = path_order;
     for (int rho = s0 / 15 - 1; rho * 15 + 14 >= lo; --rho) {
         const int rs = rho * 15;
-        if (row_was_sampled(PE, rho)) {
+        if (row_was_sampled<DEPTH>(PE, rho)) {
             for (int s = rs + 14; s >= max(rs, lo); --s) if (differ(s, af)) return af;
         } else if (rs >= lo && differ(rs, af)) return af;
     }
     if (a.ytop != b.ytop) return arrival_order(PE, a, b, ka, kb);
     return new_order_before(PE, ka, kb, a.ytop, path_order);
+}
+// one level of history behind the history: whether an earlier row was sampled may itself hinge on a tie of two older edges
+__device__ __forceinline__ bool tied_order(const PathEdges& PE, const DevEdge& a, const DevEdge& b, uint32_t ka, uint32_t kb, int s0, bool path_order) {
+    return tied_order_at<1>(PE, a, b, ka, kb, s0, path_order);
 }
 
 #ifdef SWFR_PHASES                 // -DSWFR_PHASES: clocks per phase of a k_rows wavefront, summed into counters[8..15] (diagnostic builds only)

@@ -307,9 +307,27 @@ def rand_big_scene(rng):
     return dict(width=W, height=H, bitmaps=[bmp], stage={"children": kids})
 
 
+def rand_long_scene(rng):
+    """Strokes of 40 to 150 segments (round joins and caps when the shape is a morph shape): outlines of many hundred to a few
+    thousand edges in ONE path -- the row kernels' larger routines, and the tie-order reconstruction over long edge lists."""
+    import scenarios
+    from test_host import _rand_path_shape
+    W, H = int(rng.integers(250, 700)), int(rng.integers(200, 500))
+    kids = []
+    for _ in range(int(rng.integers(1, 4))):
+        morph = bool(rng.integers(0, 3))
+        tag = _rand_path_shape(rng, int(rng.choice([20, 45, 90, 200])), morph, segments=(40, 150))
+        sx = float(rng.choice([1, 1.7, 2.5]))
+        mat = scenarios._m(sx, sx * float(rng.choice([1, 0.8, 1.3])), int(rng.integers(-300, W * 10)), int(rng.integers(-300, H * 10)),
+                           float(rng.choice([0, 0, 0.2])), float(rng.choice([0, 0, -0.15])))
+        kids.append({"type": "morph-shape", "definition": tag, "ratio": float(rng.uniform(0, 1)), "matrix": mat} if morph else
+                    {"type": "shape", "definition": tag, "matrix": mat})
+    return dict(width=W, height=H, even_odd=bool(rng.integers(0, 2)), stage={"children": kids})
+
+
 def soak_scene(name, seed, index):
     """Scene `index` of generator `name` in tools/soak.py's numbering (the generators are seeded per name)."""
-    gens = {"mixed": rand_mixed_scene, "bitmap": rand_bitmap_scene, "radial": rand_radial_scene, "big": rand_big_scene}
+    gens = {"mixed": rand_mixed_scene, "bitmap": rand_bitmap_scene, "radial": rand_radial_scene, "big": rand_big_scene, "long": rand_long_scene}
     rng = np.random.default_rng(seed + sum(map(ord, name)))
     for _ in range(index + 1):
         sc = gens[name](rng)

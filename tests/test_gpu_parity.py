@@ -240,6 +240,17 @@ def test_soak_regressions_tied_edges(case):
     assert diff_stats(product_render(sc), oracle_render(sc)) == (0, 0), case
 
 
+def test_tie_of_two_older_edges_decides_whether_the_row_before_was_sampled():
+    """Soak finding (big 7000/2285, child 3; fixture written by tools/make_soak_fixture.py): three edges of a round join tie at the
+    first sample row of a pixel row and leave it in another order, so Cairo samples that row -- and none of them is new there, so
+    their order comes from the row before that (one level of history behind the history, tied_order_at<1>)."""
+    import json
+    sc = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "soak_big_7000_2285_child3.json")))
+    ref = oracle_render(sc)
+    assert (np.asarray(ref)[..., 3] > 0).sum() > 5000
+    assert diff_stats(product_render(sc), ref) == (0, 0)
+
+
 def test_tile_with_an_uncovered_path_row_is_not_a_full_cover():
     """Soak finding (large frames): a path whose bottom lies less than a sample row below a pixel boundary has a last pixel row with
     no active sample row at all.  A tile that the path covers completely in its other rows is then neither empty nor full although

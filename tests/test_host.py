@@ -205,7 +205,7 @@ def test_empty_and_degenerate_inputs():
     assert len(p) == 0
 
 
-def _rand_path_shape(rng, line_width, morph=False):
+def _rand_path_shape(rng, line_width, morph=False, segments=(1, 8)):
     """A random open path of straight / quadratic / axis-aligned segments with a solid line style (and sometimes a fill)."""
     kind = rng.choice(["straight", "curved", "rectilinear", "mixed"])
     x, y = int(rng.integers(200, 1500)), int(rng.integers(200, 1200))
@@ -220,7 +220,7 @@ def _rand_path_shape(rng, line_width, morph=False):
         sc["left_fill"] = 1
     recs = [sc]
     xs, ys = [x], [y]
-    for k in range(int(rng.integers(1, 8))):
+    for k in range(int(rng.integers(*segments))):
         if kind == "rectilinear":
             d = (int(rng.integers(-600, 600)), 0) if k % 2 == 0 else (0, int(rng.integers(-600, 600)))
         else:

@@ -7,12 +7,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import scenarios
-from helpers import oracle_render, rand_bitmap_scene, rand_radial_scene, rand_mixed_scene, rand_big_scene, soak_scene
+from helpers import oracle_render, rand_bitmap_scene, rand_radial_scene, rand_mixed_scene, rand_big_scene, rand_long_scene, soak_scene
 
 
 GENS = {"mixed": rand_mixed_scene, "bitmap": rand_bitmap_scene, "radial": rand_radial_scene}   # same numbering as tests/helpers.py soak_scene
 if os.environ.get("SOAK_BIG"):
     GENS = {"big": rand_big_scene}                          # SOAK_BIG=1: large frames with dozens of shapes instead
+if os.environ.get("SOAK_LONG"):
+    GENS = {"long": rand_long_scene}                        # SOAK_LONG=1: strokes of 40-150 segments, hundreds to thousands of edges per path
 
 
 def cairo_render(sc):
