@@ -177,7 +177,7 @@ def main():
         tiles_ms = tm["tiles_ms"] / max(tm["timed_frames"], 1)
         achieved = algo_bytes / (tiles_ms * 1e-3) / 1e9 if tiles_ms > 0 else 0.0
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01l_pmc_k_tiles.json")
+        pmc = os.path.join(ROOT, "profiles", "r01m_pmc_k_tiles.json")
         if os.path.exists(pmc) and not bands and args.workload == "s1":
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
         line = {

@@ -266,7 +266,7 @@ struct PathEdges {
 //      alternating runs ("<=" on both sides: on a tie the list being consumed keeps going) -- sorts them by cell.  Restated for up
 //      to sixteen such edges in registers (lists are packed 4-bit slot numbers, cells are looked up by select chains); more than
 //      sixteen: path order.
-#define NEW_SORT_MAX 8
+#define NEW_SORT_MAX 16
 __device__ __forceinline__ int sel_cell(const int (&v)[NEW_SORT_MAX], int i) {
     int r = v[0];
 #pragma unroll

@@ -223,14 +223,15 @@ def test_fuzz_radial_gradients_vs_oracle():
 @pytest.mark.parametrize("case", [("radial", 1000, 940), ("mixed", 1000, 445), ("mixed", 1000, 607), ("mixed", 1000, 688), ("bitmap", 1000, 820),
                                   ("mixed", 2000, 755), ("mixed", 2000, 1130), ("mixed", 2000, 1265), ("mixed", 4000, 241), ("mixed", 4000, 1424),
                                   ("mixed", 5000, 507), ("radial", 7000, 670), ("bitmap", 7000, 816), ("mixed", 7000, 101), ("mixed", 7000, 388),
-                                  ("mixed", 8000, 995), ("mixed", 8000, 1018), ("mixed", 23000, 196), ("big", 300, 146), ("big", 300, 9), ("big", 5000, 854)])
+                                  ("mixed", 8000, 995), ("mixed", 8000, 1018), ("mixed", 23000, 196), ("big", 300, 146), ("big", 300, 9), ("big", 5000, 854), ("long", 300, 171)])
 def test_soak_regressions_tied_edges(case):
     """Scenes soak runs (tools/soak.py gpu) found: edges whose cells coincide at a pixel row's first sample row.  Their order in
     Cairo's list decides whether the row is converted analytically: two active edges keep the order of the last time the list was
     looked at while they differed (every sample row of a sampled pixel row, the first one of an analytic row -- reconstructed per
     row from the path's edges); a new edge goes before a tying active one when another new edge sorts between that edge's
     predecessor and the tie (Cairo's merge consumes its two lists in alternating runs); edges that arrive at the same sample row
-    come out of Cairo's merge sort of the bucket, replayed for up to eight of them.  Whether an earlier row was sampled is itself
+    come out of Cairo's merge sort of the bucket, replayed for up to sixteen of them (long 300/171: a stroke cut by the frame's
+    top edge starts twelve edges at sample row 0).  Whether an earlier row was sampled is itself
     decided with these rules when edges tie at its first sample row and at least one of them is new there (big 300/146: three
     edges of a round join start in one cell and leave it in the opposite order).  The last two are host-side findings of the
     oracle-vs-libcairo soak (tests/test_oracle_vs_cairo.py): the gradient translation fix that is skipped when the centre of the
