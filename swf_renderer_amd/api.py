@@ -519,6 +519,16 @@ class Renderer:
     def copy_band_slab(self, device_ptr: int):
         self._check(self.L.swfr_copy_band_slab(self.h, device_ptr))
 
+    def band_slab(self) -> np.ndarray:
+        """This handle's packed tile-rows ([rows, width, 4] uint8, premultiplied) through swfr_copy_band_slab and a device
+        buffer -- what a rank hands to the gather."""
+        import torch
+        rows = self.band_slab_bytes() // (self.width * 4)
+        t = torch.zeros((rows, self.width, 4), dtype=torch.uint8, device="cuda")
+        self.copy_band_slab(t.data_ptr())
+        torch.cuda.synchronize()
+        return t.cpu().numpy()
+
 
 def solid_style(pixel_argb_premultiplied: int) -> Style:
     s = Style()

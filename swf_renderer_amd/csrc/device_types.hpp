@@ -130,6 +130,52 @@ struct DevGradient {
     float ramp[SWFR_MAX_STOPS + 1][8];       // a_s, a_b, r_s, r_b, g_s, g_b, b_s, b_b
 };
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Pipeline 2 (raster2.hip): the row pass hands the tile pass CELLS, not edges.  A cell is one entry of Cairo's per-row cell list
+// (covered_height / uncovered_area of one pixel column), already clipped to the converter's column range; the cells
+// of one (path, pixel row) are contiguous, RowInfo2 says where.  The tile pass does no edge arithmetic at all.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct Cell {
+    int16_t col;             // pixel column (frames are at most 32768 wide)
+    int16_t ch;              // covered height, in sample rows (-15 .. 15 per edge)
+    int32_t ua;              // uncovered area
+};
+static_assert(sizeof(Cell) == 8, "Cell layout");
+constexpr int MAX_CELLS_PER_EDGE_ROW = 17;   // a FULL-row edge has at most 15 + 2 cells with a non-zero height, a sampled one 15
+
+// per (band entry, pixel row of its tile-row): indexed entry * TILE_H + (y % TILE_H), so a tile finds it from the band list position
+struct RowInfo2 {
+    uint32_t off;            // first cell
+    uint16_t n;              // cells
+    uint16_t mode;           // ROW_* (diagnostics)
+};
+enum : uint32_t { ROW_DEFER = 3 };   // left to the slow-row kernel (coincident edges, or more active edges than the fast kernel keeps)
+
+struct BandEntry2 {
+    int16_t x_min, x_max, y_min, y_max;   // the converter's pixel rectangle
+    uint32_t flags;                       // BE_* | tile-row << 8
+    uint32_t solid;                       // premultiplied pixel of a solid style
+    uint32_t style;
+    uint32_t first_edge, n_edges;         // boxes paths
+    uint32_t path;
+};
+static_assert(sizeof(BandEntry2) == 32, "BandEntry2 layout");
+
+// a pixel row the fast row kernel leaves to the slow one
+struct SlowRow {
+    uint32_t path;
+    int32_t row;             // absolute pixel row
+    uint32_t ri;             // index of its RowInfo2
+    uint32_t pad;
+};
+
+// counters of pipeline 2 (per frame in flight)
+enum : uint32_t { C2_ERROR = 0, C2_SLOW = 1, C2_HUGE = 2, C2_TIE_ROWS = 3, C2_TIE_PAIRTEST_SKIPPED = 4, C2_TIE_SORT_OVERFLOW = 5, C2_TIE_DEPTH = 6,
+                  C2_CELLS = 7, C2_HEAD = 8 /* .. 15: cell allocation heads */, C2_WORDS = 32 };
+constexpr uint32_t C2_HEADS = 8;
+// error bits
+enum : uint32_t { E2_ACTIVE_EDGES = 1u, E2_ROW_TABLE = 2u, E2_CELL_RANGE = 4u, E2_CELL_ARENA = 8u, E2_SLOW_QUEUE = 16u };
+
 // what the shader needs besides the style itself
 struct Sources {
     const DevBitmap* bitmaps;

@@ -24,6 +24,14 @@
 
 #include "device_types.hpp"
 
+// SWFR_OPAQUE(x): hides a per-lane value from the optimiser (keeps address arithmetic out of a kernel's prologue).
+// (SWFR_EMU: tools/emu compiles this file as plain C++ for the lock-step emulator, a development aid.)
+#ifdef SWFR_EMU
+#define SWFR_OPAQUE(x) asm volatile("" : "+r"(x))
+#else
+#define SWFR_OPAQUE(x) asm volatile("" : "+v"(x))
+#endif
+
 namespace swfr {
 
 // ---------------------------------------------------------------------------------------------
@@ -418,6 +426,12 @@ __device__ __forceinline__ bool row_was_sampled(const PathEdges& PE, int rho) {
     }
     return false;
 }
+// Two edges on one and the same line (a shape edge with fill0 == fill1 is decoded twice, once per direction: decode-swf-shape.ts:364-369):
+// their x agrees at every sample row, so they add and remove the same cells whichever comes first in Cairo's list -- their mutual
+// order needs no history.  (Only their order against a third edge that ties with them does.)
+__device__ __forceinline__ bool same_line(const DevEdge& a, const DevEdge& b) {
+    return a.x1 == b.x1 && a.y1 == b.y1 && a.ex == b.ex && a.dy == b.dy;
+}
 // Order of two active edges a, b whose cells coincide at the first sample row s0 of a pixel row (near-parallel edges leaving a
 // common vertex: round joins and caps produce them).  Cairo's list is re-sorted whenever it is looked at and a cell order is
 // violated, and left alone on ties: a sorts first iff it had the smaller cell the last time the list was looked at while the two
@@ -494,11 +508,12 @@ __device__ __forceinline__ bool slow_full_row(FastLds& F, const PathEdges& PE, c
             const int ci = F.roles[i][lane], ei = F.clo[i][lane], pi = F.chi[i][lane], fi = (int)F.flag[i][lane], nwi = fi & 1, di = ((fi >> 1) & 3) - 1;
             const bool tie = ci == cj, tie2 = nwi == nwj;
             bool first = i < j;
-            if (tie && nwi == 0 && nwj == 0) {
+            if (tie && nwi == nwj) {
                 const DevEdge ea = E[F.eid[i][lane]], eb = E[F.eid[j][lane]];
-                first = tied_order(PE, ea, eb, path_index(F.eid[i][lane]), path_index(F.eid[j][lane]), s0, i < j);
+                if (same_line(ea, eb)) first = i < j;
+                else if (nwi == 0) first = tied_order(PE, ea, eb, path_index(F.eid[i][lane]), path_index(F.eid[j][lane]), s0, i < j);
+                else first = new_order_before(PE, path_index(F.eid[i][lane]), path_index(F.eid[j][lane]), s0, i < j);
             }
-            else if (tie && nwi == 1 && nwj == 1) first = new_order_before(PE, path_index(F.eid[i][lane]), path_index(F.eid[j][lane]), s0, i < j);
             const bool t3 = first;
             const bool t_mixed = nwi == 0 ? !((nfmask >> i) & 1u) : ((nfmask >> j) & 1u) != 0;
             const bool before = ci < cj || (tie && (tie2 ? t3 : t_mixed));
@@ -619,6 +634,15 @@ __device__ __forceinline__ void fast_rows(EPTR E, uint32_t n_list, const DevPath
             for (int s = 0; s < ROWS_FAST_N; ++s) {
                 F.roles[s][lane] = cs[s]; F.clo[s][lane] = ce[s]; F.chi[s][lane] = cp[s]; F.eid[s][lane] = (uint16_t)el[s];
                 F.flag[s][lane] = (uint16_t)(nw[s] | ((dr[s] + 1) << 1));
+            }
+            if (deep && !mid_row) {
+                // ties between two edges on one and the same line need no history (see same_line): when every tie of the row is
+                // of that kind the unrolled test above already has the answer
+                bool real = false;
+                for (int i = 0; i < n && !real; ++i)
+                    for (int j = i + 1; j < n && !real; ++j)
+                        if (F.roles[i][lane] == F.roles[j][lane]) { const DevEdge ea = E[F.eid[i][lane]], eb = E[F.eid[j][lane]]; real = !same_line(ea, eb); }
+                deep = real;
             }
             if (deep && !mid_row) {
                 full = slow_full_row(F, PE, (const DevEdge*)E, sid, shi, lane, n, s0);
@@ -976,7 +1000,9 @@ __device__ __forceinline__ void rows_by_slot(EPTR E, uint32_t n_list, const uint
                 const int ki = __shfl(my_k, src);
                 if (deep) {
                     const uint32_t pk_i = staged_k ? staged_k[ki] : (uint32_t)ki, pk_me = staged_k ? staged_k[my_k] : (uint32_t)my_k;
-                    if (nw == 0) { const DevEdge eo = E[ki]; deep_first = tied_order(PE, eo, e, pk_i, pk_me, s0, i < slot); }
+                    const DevEdge eo = E[ki];
+                    if (same_line(eo, e)) deep_first = i < slot;
+                    else if (nw == 0) deep_first = tied_order(PE, eo, e, pk_i, pk_me, s0, i < slot);
                     else deep_first = new_order_before(PE, pk_i, pk_me, s0, i < slot);
                 }
             }
@@ -1182,11 +1208,12 @@ __device__ __forceinline__ void big_row_body(uint32_t block, const DevEdge* __re
                 // does edge i sort before this lane's edge?  (cell, active / new, previous cell, path order)
                 const bool tie = ci == c0, tie2 = ni == nw;
                 bool deep_first = i < lane;
-                if (mine && tie && ni == 0 && nw == 0) {   // coincident active edges: see tied_order (rare)
+                if (mine && tie && ni == nw) {             // coincident edges: see tied_order (rare)
                     const DevEdge eo = E[active[i]];
-                    deep_first = tied_order(PE, eo, e, active[i], k_mine, s0, i < lane);
+                    if (same_line(eo, e)) deep_first = i < lane;
+                    else if (nw == 0) deep_first = tied_order(PE, eo, e, active[i], k_mine, s0, i < lane);
+                    else deep_first = new_order_before(PE, active[i], k_mine, s0, i < lane);
                 }
-                else if (mine && tie && ni == 1 && nw == 1) deep_first = new_order_before(PE, active[i], k_mine, s0, i < lane);
                 const bool t3 = deep_first;
                 const bool t_mixed = ni == 0 ? !((nfb >> i) & 1ull) : ((nfb >> lane) & 1ull) != 0ull;
                 const bool before = ci < c0 || (tie && (tie2 ? t3 : t_mixed));
@@ -1377,11 +1404,12 @@ __global__ __launch_bounds__(256) void k_rows_huge(const DevEdge* __restrict__ e
                     const int ci = k_a[i], ei = k_b[i], pi = k_c[i], ni = (k_d[i] >> 2) & 1, di = (k_d[i] & 3) - 1, nfi = (k_d[i] >> 3) & 1;
                     const bool tie = ci == c0, tie2 = ni == nw;
                     bool deep_first = i < j;
-                    if (tie && ni == 0 && nw == 0) {    // coincident active edges: see tied_order (rare)
+                    if (tie && ni == nw) {              // coincident edges: see tied_order (rare)
                         const DevEdge ea = E[active[i]], eb = E[active[j]];
-                        deep_first = tied_order(PE, ea, eb, active[i], active[j], s0, i < j);
+                        if (same_line(ea, eb)) deep_first = i < j;
+                        else if (nw == 0) deep_first = tied_order(PE, ea, eb, active[i], active[j], s0, i < j);
+                        else deep_first = new_order_before(PE, active[i], active[j], s0, i < j);
                     }
-                    else if (tie && ni == 1 && nw == 1) deep_first = new_order_before(PE, active[i], active[j], s0, i < j);
                     const bool t3 = deep_first;
                     const bool t_mixed = ni == 0 ? !nfi : nfj != 0;
                     const bool before = ci < c0 || (tie && (tie2 ? t3 : t_mixed));
@@ -2023,7 +2051,7 @@ __device__ __forceinline__ void tiles_body(const swfr_edge* __restrict__ raw_edg
                 const int at = ln + __popcll(b & ((1ull << lane) - 1ull));
                 const uint32_t* src = reinterpret_cast<const uint32_t*>(&band_list[band_begin + bi]);
                 // 36-byte entry: two 16-byte global loads + one dword (the entries are only 4-byte aligned: dword-aligned vector type)
-                typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+                struct __attribute__((aligned(4))) u32x4_a4 { uint32_t x, y, z, w; };
                 const u32x4_a4 q0 = *reinterpret_cast<const u32x4_a4*>(src), q1 = *reinterpret_cast<const u32x4_a4*>(src + 4);
                 const uint32_t q2 = src[8];
                 *reinterpret_cast<uint4*>(&ent[at][0]) = make_uint4(q0.x, q0.y, q0.z, q0.w);
@@ -2110,7 +2138,7 @@ __device__ __forceinline__ void tiles_body(const swfr_edge* __restrict__ raw_edg
                     uint32_t my_cnt = 0, off = 0;
                     {
                         int lv = lane;
-                        asm volatile("" : "+v"(lv));                       // as below: keep this address arithmetic out of the prologue
+                        SWFR_OPAQUE(lv);                       // as below: keep this address arithmetic out of the prologue
                         const int bp = lv / STRIP_H, row = lv % STRIP_H;
                         if (bp < batch_n) {
                             const int mine = plist[bp];
@@ -2167,7 +2195,7 @@ __device__ __forceinline__ void tiles_body(const swfr_edge* __restrict__ raw_edg
                             // (the lane's position is made opaque here: otherwise the compiler hoists the twelve per-lane addresses of
                             //  this loop to the kernel's prologue and spills them -- scratch stores in every wavefront, used by few)
                             int lt = lane_t, lw = lane_w;
-                            asm volatile("" : "+v"(lt), "+v"(lw));
+                            SWFR_OPAQUE(lt); SWFR_OPAQUE(lw);
                             int t = d0 / 12 + lt, w = lw;                  // d0 is a multiple of 384 = 32 records
 #pragma unroll
                             for (int u = 0; u < 6; ++u) {
