@@ -16,7 +16,9 @@ constexpr int STRIPS_PER_TILE = TILE_H / STRIP_H;
 struct DevEdge {
     int32_t ytop, ybot;      // active sub-rows [ytop, ybot), 15 per pixel row, clamped to the path's rows
     int32_t x1, y1;          // upper end point of the line (24.8)
-    int32_t dir, pad;
+    int32_t dir;
+    int32_t pad;             // pipeline 2, paths with queued rows: position among the edges that start at the same sample row, in the order
+                             // Cairo's sort of that bucket gives them (k2_start_ranks)
     int64_t ex;              // (x2 - x1) * 256
     int64_t dy;              // (y2 - y1) * 15 * 512, 0 for vertical edges
     int64_t dq, dr;          // per-sub-row slope: truncated quotient / remainder of ex*512 / dy
@@ -171,10 +173,12 @@ struct SlowRow {
 
 // counters of pipeline 2 (per frame in flight)
 enum : uint32_t { C2_ERROR = 0, C2_SLOW = 1, C2_HUGE = 2, C2_TIE_ROWS = 3, C2_TIE_PAIRTEST_SKIPPED = 4, C2_TIE_SORT_OVERFLOW = 5, C2_TIE_DEPTH = 6,
-                  C2_CELLS = 7, C2_HEAD = 8 /* .. 15: cell allocation heads */, C2_WORDS = 32 };
+                  C2_CELLS = 7, C2_HEAD = 8 /* .. 15: cell allocation heads */, C2_PATHQ = 16,
+                  C2_SLOWQ = 16 /* + pass (1..3): rows queued again for a later pass */, C2_HUGEQ = 20 /* + pass (1..3) */, C2_WORDS = 32 };
+constexpr uint32_t SLOW_PASSES = 4;      // a queued row whose history runs through another queued row waits for the next pass
 constexpr uint32_t C2_HEADS = 8;
 // error bits
-enum : uint32_t { E2_ACTIVE_EDGES = 1u, E2_ROW_TABLE = 2u, E2_CELL_RANGE = 4u, E2_CELL_ARENA = 8u, E2_SLOW_QUEUE = 16u };
+enum : uint32_t { E2_ACTIVE_EDGES = 1u, E2_ROW_TABLE = 2u, E2_CELL_RANGE = 4u, E2_CELL_ARENA = 8u, E2_SLOW_QUEUE = 16u, E2_START_GROUP = 32u };
 
 // what the shader needs besides the style itself
 struct Sources {
@@ -182,6 +186,31 @@ struct Sources {
     const DevFilter* filters;    // per style index
     const int32_t* fparams;
     const DevGradient* gradients;
+};
+
+// one k2_tiles wavefront of the launch list: which strip, and its tile-row's slice of the band list
+struct StripDesc {
+    uint32_t wg;             // tile * STRIPS_PER_TILE + strip, tiles counted over the handle's own tile-rows
+    uint32_t band_begin, n_b;
+    uint32_t pad;
+};
+
+// Everything the kernels need to know about one frame (device memory; blockIdx.y indexes an array of these).
+struct Frame2 {
+    // the scene (read-only)
+    const swfr_edge* raw; const DevPath* paths; const swfr_style* styles;
+    const ChunkInfo* chunks; const BandSlot* band_slots; const uint32_t* band_off; const StripDesc* strips;
+    Sources src;
+    // per frame in flight (kernel-written)
+    DevEdge* edges; BandEntry2* band_list; uint8_t* cls; RowInfo2* rows; Cell* cells; SlowRow* slow; SlowRow* huge; uint32_t* counters;
+    uint32_t* path_flag; uint32_t* path_queue;     // paths with queued rows: their edges get start ranks (k2_start_ranks)
+    uint32_t* fb;
+    uint32_t n_edges, n_paths, n_chunks, n_slots, n_bands, n_strips, cell_slice, slow_cap;
+    int32_t width, height, tiles_x;
+    uint32_t band_index, band_count, fast_limit, any_shader, dbg;
+    uint32_t cell_heads;     // (unused)
+    uint32_t cell_main;      // cells [0, cell_main) belong to the chunk wavefronts of k2_rows, the rest to the slow rows' bump allocator
+    uint32_t pad[1];
 };
 
 }  // namespace swfr

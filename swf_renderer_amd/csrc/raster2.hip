@@ -20,20 +20,17 @@
 
 namespace swfr {
 
-// Everything the kernels need to know about one frame (device memory; blockIdx.y indexes an array of these).
-struct Frame2 {
-    // the scene (read-only)
-    const swfr_edge* raw; const DevPath* paths; const swfr_style* styles;
-    const ChunkInfo* chunks; const BandSlot* band_slots; const uint32_t* band_off; const uint32_t* order;
-    Sources src;
-    // per frame in flight (kernel-written)
-    DevEdge* edges; BandEntry2* band_list; uint8_t* cls; RowInfo2* rows; Cell* cells; SlowRow* slow; SlowRow* huge; uint32_t* counters;
-    uint32_t* fb;
-    uint32_t n_edges, n_paths, n_chunks, n_slots, n_bands, n_strips, cell_slice, slow_cap;
-    int32_t width, height, tiles_x;
-    uint32_t band_index, band_count, fast_limit, any_shader, dbg;
-    uint32_t pad[3];
-};
+// Barrier for hand-offs through LDS only.  __syncthreads() also waits for every outstanding global store (s_waitcnt vmcnt(0)), which
+// costs a full memory round trip wherever a wavefront has just written cells or pixels; this one orders LDS traffic alone.
+__device__ __forceinline__ void lds_barrier() {
+#ifdef SWFR_EMU
+    __syncthreads();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+#endif
+}
 
 #define CLS_OPAQUE 32u                // the path is an opaque solid blended with the lerp rule: a full cover of it hides what lies below
 
@@ -96,15 +93,14 @@ __device__ __forceinline__ void full_cells(int32_t q1, int64_t r1, int32_t q2, i
 __device__ __forceinline__ void sub_cell(Cell* __restrict__ dst, int x, int sgn, int xminp, int xmaxp) {
     put_cell(dst, x >> 8, sgn, sgn * 2 * (x & 255), xminp, xmaxp);
 }
-// `n` cells for the calling wavefront (one lane allocates; every lane gets the base): eight bump allocators, each with its own
-// slice of the frame's arena, picked by workgroup number.  ~0u when the slice is full (the frame then fails loudly).
-__device__ __forceinline__ uint32_t alloc_cells(uint32_t* __restrict__ counters, uint32_t n, uint32_t slice, int lane) {
+// `n` cells for the calling wavefront of a slow-row kernel (one lane allocates; every lane gets the base): a bump allocator over the
+// part of the frame's arena behind the chunk wavefronts' region.  ~0u when it is full (the frame then fails loudly).
+__device__ __forceinline__ uint32_t alloc_cells(const Frame2& FR, uint32_t n, int lane) {
     uint32_t base = 0;
     if (lane == 0 && n) {
-        const uint32_t head = blockIdx.x % C2_HEADS;
-        const uint32_t old = atomicAdd(&counters[C2_HEAD + head], n);
-        base = head * slice + old;
-        if ((uint64_t)old + n > slice) { atomicOr(&counters[C2_ERROR], E2_CELL_ARENA); base = ~0u; }
+        const uint32_t old = atomicAdd(&FR.counters[C2_HEAD], n);
+        base = FR.cell_main + old;
+        if ((uint64_t)base + n > FR.cell_slice) { atomicOr(&FR.counters[C2_ERROR], E2_CELL_ARENA); base = ~0u; }
     }
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
 }
@@ -127,11 +123,11 @@ __device__ __forceinline__ BandEntry2 make_band_entry2(const DevPath& P, uint32_
 }
 // blocks [0, n_setup): one thread per edge; the rest: one thread per (path, tile-row) pair -- its band entry and, for a boxes
 // path (which has no rows for k2_rows to classify), the class bytes of its tiles
-__global__ __launch_bounds__(256) void k2_front(const Frame2* __restrict__ frames, uint32_t n_setup_max) {
-    const Frame2& F = frames[blockIdx.y];
+__device__ __forceinline__ void front2_body(const Frame2& F, uint32_t n_setup_max) {
     if (blockIdx.x == 0 && threadIdx.x < C2_WORDS) F.counters[threadIdx.x] = 0;
     if (blockIdx.x < n_setup_max) {
         const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+        if (i < F.n_paths) F.path_flag[i] = 0;
         if (i >= F.n_edges) return;
         const swfr_edge e = F.raw[i];
         F.edges[i] = make_dev_edge(e, F.paths[e.reserved]);
@@ -159,25 +155,54 @@ __global__ __launch_bounds__(256) void k2_front(const Frame2* __restrict__ frame
         }
     }
 }
+__global__ __launch_bounds__(256) void k2_front(const Frame2 FR, uint32_t n_setup_max) { front2_body(FR, n_setup_max); }
+__global__ __launch_bounds__(256) void k2_front_b(const Frame2* __restrict__ frames, uint32_t n_setup_max) { front2_body(frames[blockIdx.y], n_setup_max); }
 
 // ---------------------------------------------------------------------------------------------
 // k2_rows
 // ---------------------------------------------------------------------------------------------
+#ifdef SWFR_PHASES                 // -DSWFR_PHASES: clocks per phase of a k2_rows wavefront, summed into counters[24..31] (diagnostic builds only)
+#define R2PHASE(i) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); r2ph[i] += (uint32_t)(now_ - r2ph_t); r2ph_t = now_; } while (0)
+#else
+#define R2PHASE(i) do { } while (0)
+#endif
 struct SubStage {
-    Cell cells[4][ROWS_FAST_N * 15];   // the cells of the (up to four) SUB rows of one pass
+    uint32_t cells[4][ROWS_FAST_N * 15];   // the cells of the (up to four) SUB rows of one pass, packed: column << 16 | fraction << 1 | closes
     uint32_t cnt[4];
 };
+// (FastLds of raster_kernels.hip without the scratch of its loop-form FULL test: 7 KB instead of 8, and with the packed staging and
+//  the staged edges a k2_rows wavefront needs 12.9 KB of LDS -- twelve of them fit a CU, as many as its registers allow)
+struct FastLds2 {
+    uint16_t eid[ROWS_FAST_N][64];
+    int32_t roles[ROWS_FAST_N][64];
+    int32_t clo[ROWS_FAST_N][64], chi[ROWS_FAST_N][64];
+};
+// a staged SUB cell: the span end at cell position x (24.8) opens (sgn > 0) or closes a span
+__device__ __forceinline__ uint32_t pack_sub_cell(int x, int sgn, int xminp, int xmaxp) {
+    int col = x >> 8, f = x & 255, live = 1;
+    if (col >= xmaxp) { col = xmaxp - 1; f = 0; live = 0; }
+    else if (col < xminp) { col = xminp; f = 0; }
+    return ((uint32_t)col << 16) | ((uint32_t)live << 15) | ((uint32_t)f << 1) | (sgn < 0 ? 1u : 0u);
+}
+__device__ __forceinline__ Cell unpack_sub_cell(uint32_t w) {
+    Cell c;
+    const int sgn = (w & 1u) ? -1 : 1, live = (int)((w >> 15) & 1u);
+    c.col = (int16_t)(w >> 16); c.ch = (int16_t)(sgn * live); c.ua = sgn * 2 * (int)((w >> 1) & 255u);
+    return c;
+}
 
 // fast_rows of raster_kernels.hip with two changes.  (1) A row in which two edges on different lines coincide at the first sample
 // row (their order is a matter of Cairo's list history) is not decided here: `defer_out`.  (2) The sample lanes of a SUB row do
 // not only set role bits, they produce the row's cells: staged in LDS per pass of four rows, then allocated and copied out by the
 // whole wavefront, and the rows' RowInfo2 written (index `ri` per row lane; ~0u: the path has no band entry, nothing is kept).
 template <class EPTR>
-__device__ __forceinline__ void rows2_fast(EPTR E, uint32_t n_list, const DevPath& P, int r, bool live, int fast_limit, FastLds& F, SubStage& S, int lane,
+__device__ __forceinline__ void rows2_fast(EPTR E, uint32_t n_list, const DevPath& P, int r, bool live, int fast_limit, FastLds2& F, SubStage& S, int lane,
                                            uint32_t& mode_out, int& n_out_edges, bool& overflow_out, bool& defer_out,
                                            int32_t (&roles)[ROWS_FAST_N], int32_t (&cols)[ROWS_FAST_N], int (&el)[ROWS_FAST_N],
                                            int32_t (&Q1)[ROWS_FAST_N], int64_t (&R1)[ROWS_FAST_N], int32_t (&Q2)[ROWS_FAST_N], int64_t (&R2)[ROWS_FAST_N],
-                                           int& nmax_out, uint32_t ri, const Frame2& FR) {
+                                           int& nmax_out, uint32_t ri, const Frame2& FR, int& n_cells_out, uint32_t& incl_out, uint32_t& base_out,
+                                           uint32_t* r2ph, unsigned long long& r2ph_t, uint32_t chunk_cell_base) {
+    (void)r2ph; (void)r2ph_t;
     const int s0 = r * 15;
     const unsigned mask = P.fill_rule ? 1u : ~0u;
     int n = 0;
@@ -198,6 +223,7 @@ __device__ __forceinline__ void rows2_fast(EPTR E, uint32_t n_list, const DevPat
         }
     }
     if (overflow) n = 0;
+    R2PHASE(2);
     // wave-uniform bound on the active edges of any row of this wave: the unrolled slot loops stop there
     const int nmax = __ballot(n > 6) ? 8 : __ballot(n > 4) ? 6 : __ballot(n > 2) ? 4 : 2;
     nmax_out = nmax;
@@ -229,6 +255,7 @@ __device__ __forceinline__ void rows2_fast(EPTR E, uint32_t n_list, const DevPat
             Q1[s] = qa; R1[s] = ra; Q2[s] = qb; R2[s] = rb;
         }
     }
+    R2PHASE(3);
     uint32_t mode = ROW_EMPTY;
     bool is_sub = false, defer = false;
     if (n > 0) {
@@ -268,7 +295,10 @@ __device__ __forceinline__ void rows2_fast(EPTR E, uint32_t n_list, const DevPat
                 bool real = false;
                 for (int i = 0; i < n && !real; ++i)
                     for (int j = i + 1; j < n && !real; ++j)
-                        if (F.roles[i][lane] == F.roles[j][lane]) { const DevEdge ea = E[F.eid[i][lane]], eb = E[F.eid[j][lane]]; real = !same_line(ea, eb); }
+                        if (F.roles[i][lane] == F.roles[j][lane]) {
+                            const int a = F.eid[i][lane], b = F.eid[j][lane];
+                            real = !(E[a].x1 == E[b].x1 && E[a].y1 == E[b].y1 && E[a].ex == E[b].ex && E[a].dy == E[b].dy);       // same_line
+                        }
                 defer = real;
             }
         }
@@ -298,8 +328,25 @@ __device__ __forceinline__ void rows2_fast(EPTR E, uint32_t n_list, const DevPat
             }
         }
     }
+    // ---- room for the rows' cells inside the wavefront's region: a FULL row takes the exact number of its cells, a SUB row room for
+    //      one cell per (active edge, sample row) -- its cells are counted while they are made, so the row uses a prefix of its room
+    int n_cells = 0;
+    if (mode == ROW_FULL && ri != ~0u) {
+#pragma unroll
+        for (int s = 0; s < ROWS_FAST_N; ++s) {
+            if (s >= nmax) continue;                          // wave-uniform
+            if (s < n && roles[s] != 0) n_cells += full_span(Q1[s], Q2[s]);
+        }
+    }
+    const int room = is_sub && ri != ~0u ? n * 15 : n_cells;
+    const uint32_t incl_cells = (uint32_t)wave_scan_incl(room);
+    const uint32_t total_cells = (uint32_t)__builtin_amdgcn_readlane((int)incl_cells, 63);
+    // the wavefront's cells start at its chunk's slot: (edge, row) pairs before it x MAX_CELLS_PER_EDGE_ROW -- no allocator in this kernel
+    const uint32_t wave_base = ((uint64_t)chunk_cell_base + total_cells <= (uint64_t)FR.cell_slice) ? chunk_cell_base : ~0u;
+    if (wave_base == ~0u && lane == 0) atomicOr(&FR.counters[C2_ERROR], E2_CELL_ARENA);
+    R2PHASE(4);
     if (lane < 4) S.cnt[lane] = 0;
-    __syncthreads();                                          // F.* written by the row owners, read by the sample lanes
+    lds_barrier();                                          // F.* written by the row owners, read by the sample lanes
     // ---- the wave's SUB rows, 4 rows x 15 sample rows per pass: roles for the classification, cells for the tile pass
     unsigned long long pending = __ballot(is_sub);
     const int g = lane / 15, sub = lane - g * 15;
@@ -309,8 +356,8 @@ __device__ __forceinline__ void rows2_fast(EPTR E, uint32_t n_list, const DevPat
         int R = -1;
         for (int t = 0; t <= g && t < 4; ++t) { if (!m) { R = -1; break; } R = __ffsll((long long)m) - 1; m &= m - 1; }
         if (g >= 4) R = -1;
-        int rows_in_pass = 0;
-        for (int t = 0; t < 4 && pending; ++t) { pending &= pending - 1; ++rows_in_pass; }
+        const unsigned long long pass_rows = pending;           // its four lowest bits set are this pass's rows
+        for (int t = 0; t < 4 && pending; ++t) pending &= pending - 1;
         // cross-lane reads must run with every lane active: ds_bpermute returns 0 for a disabled source lane
         const int Rsrc = R >= 0 ? R : 0;
         const int nR = __shfl(n_all, Rsrc);
@@ -354,36 +401,46 @@ __device__ __forceinline__ void rows2_fast(EPTR E, uint32_t n_list, const DevPat
                     atomicMax(&F.chi[j][R], col);
                     if (riR != ~0u) {
                         const uint32_t at = atomicAdd(&S.cnt[g], 1u);
-                        sub_cell(&S.cells[g][at], cc[j], in_a ? 1 : -1, P.x_min, P.x_max);
+                        S.cells[g][at] = pack_sub_cell(cc[j], in_a ? 1 : -1, P.x_min, P.x_max);
                     }
                 }
             }
         }
-        __syncthreads();                                      // the pass's cells are staged
-        // ---- allocate, copy out (coalesced), row headers
+        lds_barrier();                                      // the pass's cells are staged
+        // ---- copy out (coalesced) into the rows' room, row headers
         {
             const uint32_t c0 = S.cnt[0], c1 = S.cnt[1], c2 = S.cnt[2], c3 = S.cnt[3];
             const uint32_t total = c0 + c1 + c2 + c3;
-            const uint32_t base = alloc_cells(FR.counters, total, FR.cell_slice, lane);
-            if (base != ~0u) {
+            // where the rooms of the pass's rows start: the row lanes know (exclusive prefix of the rooms), every lane asks
+            const uint32_t my_room = wave_base + incl_cells - (uint32_t)room;
+            uint32_t pm2 = 0; int Rg[4];
+            {
+                unsigned long long m2 = pass_rows;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { Rg[t] = m2 ? __ffsll((long long)m2) - 1 : 0; m2 &= m2 - 1; }
+                (void)pm2;
+            }
+            const uint32_t b0 = (uint32_t)__shfl((int)my_room, Rg[0]), b1 = (uint32_t)__shfl((int)my_room, Rg[1]);
+            const uint32_t b2 = (uint32_t)__shfl((int)my_room, Rg[2]), b3 = (uint32_t)__shfl((int)my_room, Rg[3]);
+            if (wave_base != ~0u) {
                 for (uint32_t t = (uint32_t)lane; t < total; t += 64) {
                     const int gg = t < c0 ? 0 : (t < c0 + c1 ? 1 : (t < c0 + c1 + c2 ? 2 : 3));
                     const uint32_t pre = gg == 0 ? 0u : (gg == 1 ? c0 : (gg == 2 ? c0 + c1 : c0 + c1 + c2));
-                    FR.cells[base + t] = S.cells[gg][t - pre];
+                    const uint32_t bb = gg == 0 ? b0 : (gg == 1 ? b1 : (gg == 2 ? b2 : b3));
+                    FR.cells[bb + (t - pre)] = unpack_sub_cell(S.cells[gg][t - pre]);
                 }
             }
             if (sub == 0 && R >= 0 && riR != ~0u) {          // the first sample lane of each of the pass's rows writes its header
-                const uint32_t pre = g == 0 ? 0u : (g == 1 ? c0 : (g == 2 ? c0 + c1 : c0 + c1 + c2));
-                RowInfo2 h; h.off = base == ~0u ? 0u : base + pre; h.n = base == ~0u ? (uint16_t)0 : (uint16_t)S.cnt[g]; h.mode = (uint16_t)ROW_SUB;
+                const uint32_t bb = g == 0 ? b0 : (g == 1 ? b1 : (g == 2 ? b2 : b3));
+                RowInfo2 h; h.off = wave_base == ~0u ? 0u : bb; h.n = wave_base == ~0u ? (uint16_t)0 : (uint16_t)S.cnt[g]; h.mode = (uint16_t)ROW_SUB;
                 FR.rows[riR] = h;
             }
         }
-        __syncthreads();                                      // staging read: reset the counters for the next pass
+        lds_barrier();                                      // staging read: reset the counters for the next pass
         if (lane < 4) S.cnt[lane] = 0;
-        __syncthreads();
-        (void)rows_in_pass;
+        lds_barrier();
     }
-    __syncthreads();                                          // role bits OR-ed in by the sample lanes
+    lds_barrier();                                          // role bits OR-ed in by the sample lanes
     if (is_sub) {
 #pragma unroll
         for (int s = 0; s < ROWS_FAST_N; ++s) {
@@ -391,12 +448,19 @@ __device__ __forceinline__ void rows2_fast(EPTR E, uint32_t n_list, const DevPat
             roles[s] = F.roles[s][lane]; cols[s] = (int32_t)((uint32_t)F.clo[s][lane] | ((uint32_t)F.chi[s][lane] << 16));
         }
     }
+    R2PHASE(5);
     mode_out = mode; n_out_edges = n; overflow_out = overflow; defer_out = defer;
+    n_cells_out = n_cells; incl_out = incl_cells - (uint32_t)room + (uint32_t)n_cells; base_out = wave_base;     // (the caller's offset is base + incl - n_cells)
 }
 
 
 __device__ __forceinline__ void rows2_chunk_body(const Frame2& FR, uint32_t block) {
-    __shared__ FastLds F;
+    uint32_t r2ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long r2ph_t = 0;
+#ifdef SWFR_PHASES
+    r2ph_t = __builtin_amdgcn_s_memtime();
+#endif
+    __shared__ FastLds2 F;
     __shared__ SubStage S;
     __shared__ DevEdge staged[ROWS_STAGE];
     const int lane = threadIdx.x;
@@ -424,6 +488,7 @@ __device__ __forceinline__ void rows2_chunk_body(const Frame2& FR, uint32_t bloc
     if (live && band_count > 1 && (uint32_t)((r / TILE_H) % band_count) != band_index) live = false;
     int fast_limit = (int)FR.fast_limit;
     if (P.n_edges > 65535u) fast_limit = 0;                             // 16-bit local edge indices in the fast path
+    R2PHASE(0);
     // ---- stage the edges that can be active in this chunk's rows (path order kept)
     const int lo_s = (int)ck.first_row * 15, hi_s = lo_s + chunk_rows * 15;
     uint32_t n_list = 0;
@@ -438,28 +503,19 @@ __device__ __forceinline__ void rows2_chunk_body(const Frame2& FR, uint32_t bloc
         n_list += (uint32_t)__popcll(hb);
         if (n_list > ROWS_STAGE) { use_lds = false; break; }
     }
-    __syncthreads();
+    lds_barrier();
+    R2PHASE(1);
     uint32_t mode; int n, nmax = ROWS_FAST_N; bool overflow, defer;
     int32_t roles[ROWS_FAST_N], cols[ROWS_FAST_N]; int el[ROWS_FAST_N];
     int32_t Q1[ROWS_FAST_N], Q2[ROWS_FAST_N]; int64_t R1[ROWS_FAST_N], R2[ROWS_FAST_N];
-    if (use_lds) rows2_fast((const DevEdge*)staged, n_list, P, r, live, fast_limit, F, S, lane, mode, n, overflow, defer, roles, cols, el, Q1, R1, Q2, R2, nmax, ri, FR);
-    else rows2_fast(FR.edges + P.first_edge, P.n_edges, P, r, live, fast_limit, F, S, lane, mode, n, overflow, defer, roles, cols, el, Q1, R1, Q2, R2, nmax, ri, FR);
+    int n_cells; uint32_t incl, base;
+    if (use_lds) rows2_fast((const DevEdge*)staged, n_list, P, r, live, fast_limit, F, S, lane, mode, n, overflow, defer, roles, cols, el, Q1, R1, Q2, R2, nmax, ri, FR, n_cells, incl, base, r2ph, r2ph_t, ck.rec_base * (uint32_t)MAX_CELLS_PER_EDGE_ROW);
+    else rows2_fast(FR.edges + P.first_edge, P.n_edges, P, r, live, fast_limit, F, S, lane, mode, n, overflow, defer, roles, cols, el, Q1, R1, Q2, R2, nmax, ri, FR, n_cells, incl, base, r2ph, r2ph_t, ck.rec_base * (uint32_t)MAX_CELLS_PER_EDGE_ROW);
     const bool slow = live && (overflow || defer);
-    // ---- FULL rows: cells of every boundary edge, densely packed behind one allocation of the wavefront
-    int n_cells = 0;
+    // ---- FULL rows: cells of every boundary edge, densely packed behind the wavefront's allocation
     const bool emit = mode == ROW_FULL && ri != ~0u && !slow;
-    if (emit) {
-#pragma unroll
-        for (int s = 0; s < ROWS_FAST_N; ++s) {
-            if (s >= nmax) continue;                                     // wave-uniform
-            if (s < n && roles[s] != 0) n_cells += full_span(Q1[s], Q2[s]);
-        }
-    }
-    const uint32_t incl = (uint32_t)wave_scan_incl(n_cells);
-    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-    const uint32_t base = alloc_cells(FR.counters, total, FR.cell_slice, lane);
     if (ri != ~0u && lane < chunk_rows && mode != ROW_SUB) {            // (the SUB rows' headers were written with their cells)
-        RowInfo2 h; h.off = 0; h.n = 0; h.mode = (uint16_t)(slow ? ROW_DEFER : mode);
+        RowInfo2 h; h.off = 0; h.n = 0; h.mode = (uint16_t)((slow || (in_path && !live)) ? ROW_DEFER : mode);   // (another rank's row: not known here)
         if (emit && base != ~0u) {
             uint32_t off = base + incl - (uint32_t)n_cells;
             h.off = off; h.n = (uint16_t)n_cells;
@@ -475,17 +531,26 @@ __device__ __forceinline__ void rows2_chunk_body(const Frame2& FR, uint32_t bloc
         }
         FR.rows[ri] = h;
     }
+    R2PHASE(6);
     // ---- rows left to the slow-row kernel
     {
         const bool q = slow && ri != ~0u;
         const unsigned long long qm = __ballot(q);
         if (qm) {
             uint32_t qb = 0;
-            if (lane == 0) qb = atomicAdd(&FR.counters[C2_SLOW], (uint32_t)__popcll(qm));
+            if (lane == 0) {
+                qb = atomicAdd(&FR.counters[C2_SLOW], (uint32_t)__popcll(qm));
+                if (atomicOr(&FR.path_flag[lo], 1u) == 0u) FR.path_queue[atomicAdd(&FR.counters[C2_PATHQ], 1u)] = lo;   // once per path
+            }
             qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)qb);
             if (q) {
                 const uint32_t at = qb + (uint32_t)__popcll(qm & ((1ull << lane) - 1ull));
-                if (at < FR.slow_cap) { SlowRow sr; sr.path = lo; sr.row = r; sr.ri = ri; sr.pad = defer ? 1u : 0u; FR.slow[at] = sr; }
+                if (at < FR.slow_cap) {
+                    SlowRow sr; sr.path = lo; sr.row = r; sr.ri = ri;
+                    // where the path's (path, tile-row) pairs start in band_slots (the slow kernel looks up earlier rows' headers) | tie flag
+                    sr.pad = (ck.slot0 - (uint32_t)((int)ck.first_row / TILE_H - band_lo)) | (defer ? 0x80000000u : 0u);
+                    FR.slow[at] = sr;
+                }
                 else atomicOr(&FR.counters[C2_ERROR], E2_SLOW_QUEUE);
             }
         }
@@ -543,9 +608,20 @@ __device__ __forceinline__ void rows2_chunk_body(const Frame2& FR, uint32_t bloc
             if ((lane & 15) == 0 && band_ok) out[(size_t)tc * n_b] = (uint8_t)f;
         }
     }
+    R2PHASE(7);
+#ifdef SWFR_PHASES
+    if (lane == 0 && (block & 63u) == 0u) {                                      // a sample of the wavefronts: contended atomics are slow
+        for (int i = 0; i < 8; ++i) atomicAdd(&FR.counters[24 + i], r2ph[i] >> 4);   // units of 16 clocks
+        atomicAdd(&FR.counters[C2_CELLS], 1u);
+    }
+#endif
 }
 
-__global__ __launch_bounds__(64) void k2_rows(const Frame2* __restrict__ frames) {
+__global__ __launch_bounds__(64) void k2_rows(const Frame2 FR) {
+    if (blockIdx.x >= FR.n_chunks) return;
+    rows2_chunk_body(FR, blockIdx.x);
+}
+__global__ __launch_bounds__(64) void k2_rows_b(const Frame2* __restrict__ frames) {
     const Frame2& FR = frames[blockIdx.y];
     if (blockIdx.x >= FR.n_chunks) return;
     rows2_chunk_body(FR, blockIdx.x);
@@ -553,17 +629,561 @@ __global__ __launch_bounds__(64) void k2_rows(const Frame2* __restrict__ frames)
 
 
 // ---------------------------------------------------------------------------------------------
+// The order Cairo gives the edges that become active at one sample row (oracle: sort_edges / merge_sorted_edges -- pairs, then
+// merges of runs of 2, 4, ... where a merge keeps consuming the list it is on through ties), for any number of them: slot
+// numbers 0 .. cnt-1 (path order) in `a` / `b` (ping-pong), keys in `cell`.  merge_step merges the runs [s, s + width) and
+// [s + width, s + 2 width) of `src` into `dst`; the caller loops over widths (one lane for a wavefront's row, one thread per
+// merge for a workgroup's).  new_order_before of raster_kernels.hip is the same replay for up to sixteen edges in registers.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void sort_pairs(uint16_t* __restrict__ dst, const int* __restrict__ cell, int p, int cnt) {
+    const int x = 2 * p, y = 2 * p + 1;
+    if (y < cnt) { const bool keep = cell[x] <= cell[y]; dst[x] = (uint16_t)(keep ? x : y); dst[y] = (uint16_t)(keep ? y : x); }
+    else if (x < cnt) dst[x] = (uint16_t)x;
+}
+__device__ __forceinline__ void merge_step(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, const int* __restrict__ cell, int s, int width, int cnt) {
+    const int a1 = min(s + width, cnt), b1 = min(s + 2 * width, cnt);
+    int ia = s, ib = a1, o = s;
+    if (ib >= b1) { while (ia < a1) dst[o++] = src[ia++]; return; }
+    bool phase_a = cell[src[ia]] <= cell[src[ib]];
+    for (;;) {
+        if (phase_a) {
+            const int x = cell[src[ib]];
+            while (ia < a1 && cell[src[ia]] <= x) dst[o++] = src[ia++];
+            if (ia == a1) { while (ib < b1) dst[o++] = src[ib++]; return; }
+        }
+        const int x = cell[src[ia]];
+        while (ib < b1 && cell[src[ib]] <= x) dst[o++] = src[ib++];
+        if (ib == b1) { while (ia < a1) dst[o++] = src[ia++]; return; }
+        phase_a = true;
+    }
+}
+
+// k2_start_ranks: for every path with queued rows, the position of each edge among the edges that start at the same sample row in
+// the order Cairo's sort of that bucket gives them (DevEdge::pad): what new_order_before needs, for any number of edges.  One
+// 256-thread workgroup per path; an edge alone at its sample row keeps 0, a pair is ordered directly, larger groups are replayed
+// one after the other with the merge sort above.
+#define START_MAX 2048                 // edges of one path that may start at one sample row (more: the frame fails loudly)
+__device__ __forceinline__ void rank_tmp(DevEdge* E, int i, int rank) { E[i].pad = rank; }
+__device__ __forceinline__ void start_ranks_body(const Frame2& FR, uint32_t p) {
+    __shared__ int sort_cell[START_MAX];
+    __shared__ uint16_t sort_a[START_MAX], sort_b[START_MAX];
+    __shared__ uint32_t member[START_MAX];
+    __shared__ uint32_t wave_cnt[4];
+    __shared__ int next_y, grp_n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const DevPath P = FR.paths[p];
+    if (P.kind != SWFR_PATH_TOR) return;
+    DevEdge* E = FR.edges + P.first_edge;
+    const int ne = (int)P.n_edges;
+    // edges alone at their sample row keep rank 0, pairs are ordered directly; members of larger groups are marked (-1)
+    for (int i = tid; i < ne; i += 256) {
+        const int yt = E[i].ytop;
+        int cnt = 0, partner = -1;
+        if (E[i].ybot > yt)
+            for (int j = 0; j < ne; ++j)
+                if (j != i && E[j].ytop == yt && E[j].ybot > yt) { ++cnt; partner = j; }
+        int rank = 0;
+        if (cnt == 1) {
+            const DevEdge a = E[i], b = E[partner];
+            int ca = a.x1, cb = b.x1;
+            if (a.dy) { int32_t q; int64_t rm; edge_x_at(a, yt, q, rm); ca = cell_of(q, rm, a.dy); }
+            if (b.dy) { int32_t q; int64_t rm; edge_x_at(b, yt, q, rm); cb = cell_of(q, rm, b.dy); }
+            rank = i < partner ? (ca <= cb ? 0 : 1) : (cb <= ca ? 1 : 0);      // sort_edges on a pair: the first stays first unless its cell is larger
+        } else if (cnt > 1) rank = -1;
+        rank_tmp(E, i, rank);
+    }
+    __syncthreads();
+    // the larger groups, in ascending order of their sample row; `done_y`: everything up to it has been handled
+    int done_y = INT_MIN;
+    for (;;) {
+        if (tid == 0) next_y = INT_MAX;
+        __syncthreads();
+        for (int i = tid; i < ne; i += 256) {
+            const int yt = E[i].ytop;
+            if (E[i].pad == -1 && yt > done_y) atomicMin(&next_y, yt);
+        }
+        __syncthreads();
+        const int y = next_y;
+        __syncthreads();
+        if (y == INT_MAX) break;                             // workgroup-uniform
+        // its members in path order
+        int n = 0;
+        for (int base = 0; base < ne; base += 256) {
+            const int i = base + tid;
+            const bool is = i < ne && E[i].ytop == y && E[i].pad == -1;
+            const unsigned long long b = __ballot(is);
+            if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(b);
+            __syncthreads();
+            int at = n;
+            for (int w = 0; w < wave; ++w) at += (int)wave_cnt[w];
+            at += __popcll(b & ((1ull << lane) - 1ull));
+            if (is && at < START_MAX) {
+                member[at] = (uint32_t)i;
+                const DevEdge e = E[i];
+                int c = e.x1;
+                if (e.dy) { int32_t q; int64_t rm; edge_x_at(e, y, q, rm); c = cell_of(q, rm, e.dy); }
+                sort_cell[at] = c;
+            }
+            n += (int)(wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3]);
+            __syncthreads();
+        }
+        if (tid == 0) grp_n = n;
+        __syncthreads();
+        if (n > START_MAX) { if (tid == 0) atomicOr(&FR.counters[C2_ERROR], E2_START_GROUP); return; }     // workgroup-uniform
+        for (int q = tid; q < (n + 1) / 2; q += 256) sort_pairs(sort_a, sort_cell, q, n);
+        __syncthreads();
+        uint16_t *src = sort_a, *dst = sort_b;
+        for (int width = 2; width < n; width *= 2) {
+            for (int s2 = tid * 2 * width; s2 < n; s2 += 256 * 2 * width) merge_step(src, dst, sort_cell, s2, width, n);
+            __syncthreads();
+            uint16_t* t = src; src = dst; dst = t;
+        }
+        for (int q = tid; q < n; q += 256) E[member[src[q]]].pad = q;
+        __syncthreads();
+        done_y = y;
+    }
+}
+__device__ __forceinline__ void start_ranks_loop(const Frame2& FR) {
+    const uint32_t nq = min(FR.counters[C2_PATHQ], FR.n_paths);
+    for (uint32_t i = blockIdx.x; i < nq; i += gridDim.x) {
+        start_ranks_body(FR, FR.path_queue[i]);
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void k2_start_ranks(const Frame2 FR) { start_ranks_loop(FR); }
+__global__ __launch_bounds__(256) void k2_start_ranks_b(const Frame2* __restrict__ frames) { start_ranks_loop(frames[blockIdx.y]); }
+
+// ---------------------------------------------------------------------------------------------
+// k2_rows_slow: the queued rows, one wavefront each, lane = active edge (up to 64; more: the huge queue).  big_row_body of
+// raster_kernels.hip -- including the replay of Cairo's list order for coincident edges (tied_order) -- with cells as output.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t slow_count_index(uint32_t pass) { return pass == 0 ? (uint32_t)C2_SLOW : C2_SLOWQ + pass; }
+__device__ __forceinline__ uint32_t huge_count_index(uint32_t pass) { return pass == 0 ? (uint32_t)C2_HUGE : C2_HUGEQ + pass; }
+__device__ __forceinline__ void slow_row_body(const Frame2& FR, const SlowRow sr, uint32_t pass) {
+    __shared__ uint32_t active[ROWS_BIG_MAXA];
+    __shared__ uint32_t retry;
+    const int lane = threadIdx.x;
+    const DevPath P = FR.paths[sr.path];
+    const int r = sr.row, s0 = r * 15;
+    const unsigned mask = P.fill_rule ? 1u : ~0u;
+    const DevEdge* E = FR.edges + P.first_edge;
+    const PathEdges PE = {FR.edges, nullptr, &P, false, FR.counters, FR.rows, FR.band_slots, sr.pad & 0x7fffffffu, pass + 1 < SLOW_PASSES ? &retry : nullptr};
+    if (threadIdx.x == 0) retry = 0;
+    // ---- gather: compact the indices of the active edges, 64 candidates per pass (path order is kept)
+    int n = 0;
+    bool too_many = false;
+    for (uint32_t base = 0; base < P.n_edges; base += 64) {
+        const uint32_t k = base + (uint32_t)lane;
+        bool act = false;
+        if (k < P.n_edges) { const int ytop = E[k].ytop, ybot = E[k].ybot; act = !(ybot <= s0 || ytop >= s0 + 15); }
+        const unsigned long long b = __ballot(act);
+        const int at = n + __popcll(b & ((1ull << lane) - 1ull));
+        if (act && at < ROWS_BIG_MAXA) active[at] = k;
+        n += __popcll(b);
+        if (n > ROWS_BIG_MAXA) { too_many = true; break; }
+    }
+    lds_barrier();
+    if (too_many) {                                            // a workgroup of k2_rows_huge takes it
+        if (lane == 0) {
+            const uint32_t at = atomicAdd(&FR.counters[huge_count_index(pass)], 1u);
+            if (at < FR.slow_cap) FR.huge[(pass & 1u) * FR.slow_cap + at] = sr; else atomicOr(&FR.counters[C2_ERROR], E2_SLOW_QUEUE);
+        }
+        return;
+    }
+    const bool mine = lane < n;
+    const uint32_t k_mine = mine ? active[lane] : active[0];
+    const DevEdge e = E[n ? k_mine : 0];                      // lanes past the list compute on a valid edge and are ignored
+    const bool slanted = e.dy != 0;
+    const bool mid_row = __ballot(mine && ((e.ytop > s0) | (e.ybot < s0 + 15))) != 0ull;
+    uint32_t role = 0;
+    int32_t q1 = e.x1, q2 = e.x1; int64_t r1 = 0, r2 = 0;
+    bool full = !mid_row && n > 0;
+    if (full) {
+        int c0 = e.x1, c1 = e.x1, cpv = e.x1;
+        if (slanted) {
+            int32_t qa, qb; int64_t ra, rb;
+            edge_x_at(e, s0, qa, ra);
+            edge_x_at(e, s0 + 15, qb, rb);
+            c0 = cell_of(qa, ra, e.dy);
+            c1 = cell_of(qb, rb, e.dy);
+            cpv = c0;
+            if (e.ytop < s0) {
+                int32_t q = qa - (int32_t)e.dq; int64_t rm = ra - e.dr;
+                if (rm < 0) { --q; rm += e.dy; } else if (rm >= e.dy) { ++q; rm -= e.dy; }
+                cpv = cell_of(q, rm, e.dy);
+            }
+            const int32_t hq = (int32_t)(e.dq / 2); const int64_t hr = e.dr / 2;
+            qa -= hq; ra -= hr; if (ra < 0) { --qa; ra += e.dy; } else if (ra >= e.dy) { ++qa; ra -= e.dy; }
+            qb -= hq; rb -= hr; if (rb < 0) { --qb; rb += e.dy; } else if (rb >= e.dy) { ++qb; rb -= e.dy; }
+            q1 = qa; r1 = ra; q2 = qb; r2 = rb;
+        }
+        const int nw = (e.ytop == s0) ? 1 : 0, dr = e.dir;
+        const int new_rank = e.pad;                          // among the edges that start at the same sample row (k2_start_ranks)
+        int w = 0; bool fg = true, lg = true, ok = true, mixed = false;
+        unsigned long long nfb = 0ull;                       // bit k: active edge k lets a tying new edge go first (see rows_by_slot)
+        for (int pass = 0; pass < 2; ++pass) {
+            w = 0; fg = lg = ok = true;
+            for (int i = 0; i < n; ++i) {                     // wave-uniform loop: lane i's keys broadcast to every lane
+                const int ci = __builtin_amdgcn_readlane(c0, i), ei = __builtin_amdgcn_readlane(c1, i), pi = __builtin_amdgcn_readlane(cpv, i);
+                const int ni = __builtin_amdgcn_readlane(nw, i), di = __builtin_amdgcn_readlane(dr, i), ri_new = __builtin_amdgcn_readlane(new_rank, i);
+                (void)pi;
+                if (i == lane) continue;
+                const bool tie = ci == c0, tie2 = ni == nw;
+                bool deep_first = i < lane;
+                if (mine && tie && ni == nw) {             // coincident edges: see tied_order
+                    const DevEdge eo = E[active[i]];
+                    if (same_line(eo, e)) deep_first = i < lane;
+                    else if (nw == 0) deep_first = tied_order(PE, eo, e, active[i], k_mine, s0, i < lane);
+                    else deep_first = ri_new < new_rank;
+                }
+                const bool t3 = deep_first;
+                const bool t_mixed = ni == 0 ? !((nfb >> i) & 1ull) : ((nfb >> lane) & 1ull) != 0ull;
+                const bool before = ci < c0 || (tie && (tie2 ? t3 : t_mixed));
+                mixed |= mine && tie && !tie2;
+                if (before) { w += di; if (ei > c1) ok = false; if (tie) fg = false; }
+                else if (tie) lg = false;
+            }
+            if (pass == 1 || __ballot(mixed) == 0ull) break;
+            int L = INT_MIN; bool tied_before = false, any_new = false;
+            for (int i = 0; i < n; ++i) {
+                const int ci = __builtin_amdgcn_readlane(c0, i), pi = __builtin_amdgcn_readlane(cpv, i), ni = __builtin_amdgcn_readlane(nw, i);
+                if (i == lane || ni != 0) continue;
+                if (ci < c0) L = max(L, ci);
+                else if (ci == c0 && (pi < cpv || (pi == cpv && i < lane))) tied_before = true;
+            }
+            for (int i = 0; i < n; ++i) {
+                const int ci = __builtin_amdgcn_readlane(c0, i), ni = __builtin_amdgcn_readlane(nw, i);
+                if (i == lane || ni != 1) continue;
+                any_new |= ci >= L && ci < c0;
+            }
+            nfb = __ballot(mine && nw == 0 && !tied_before && any_new);
+        }
+        full = __ballot(mine && !ok) == 0ull;
+        if (full && mine) {
+            const bool in_b = ((unsigned)w & mask) != 0, in_a = ((unsigned)(w + dr) & mask) != 0;
+            if (!in_b && fg) role = REC_FULL | 1u;            // left edge of a span
+            else if (!in_a && lg) role = REC_FULL | 2u;       // right edge
+        }
+    }
+    const uint32_t mode = n == 0 ? ROW_EMPTY : (full ? ROW_FULL : ROW_SUB);
+    if (n > 0 && !full) {
+        // ---- SUB row: fifteen sample rows; lane = (sample row group g, edge je), cells ranked inside the group by shuffles
+        role = 0;
+        const int W = n <= 16 ? 16 : (n <= 32 ? 32 : 64), G = 64 / W;      // wave-uniform
+        const int g = lane / W, je = lane - g * W;
+        const bool mine_s = je < n;
+        const DevEdge es = E[active[mine_s ? je : 0]];
+        const bool slanted_s = es.dy != 0;
+        for (int p = 0; p * G < 15; ++p) {
+            const int sub = p * G + g, ss = s0 + sub;
+            const bool act = mine_s && sub < 15 && es.ytop <= ss && ss < es.ybot;
+            int cc = es.x1;
+            if (act && slanted_s) { int32_t q; int64_t rm; edge_x_at(es, ss, q, rm); cc = cell_of(q, rm, es.dy); }
+            const int dd = act ? es.dir : 0;
+            int wb = 0, gsum = dd; bool rep = true;
+            for (int i = 0; i < n; ++i) {                               // wave-uniform; every lane takes part in the shuffles
+                const int src = g * W + i;
+                const int ci = __shfl(cc, src), di = __shfl(dd, src);
+                if (!act || i == je || di == 0) continue;
+                if (ci < cc) wb += di;
+                else if (ci == cc) { gsum += di; if (i < je) rep = false; }
+            }
+            if (act && rep) {
+                const bool in_b = ((unsigned)wb & mask) != 0, in_a = ((unsigned)(wb + gsum) & mask) != 0;
+                if (in_a != in_b) role |= (uint32_t)(in_a ? 1 : 2) << (2 * sub);
+            }
+        }
+        for (int off = W; off < 64; off <<= 1) role |= (uint32_t)__shfl_xor((int)role, off);
+    }
+    lds_barrier();
+    if (retry) {                                               // (wave-uniform) an earlier row it depends on is still queued: next pass
+        if (lane == 0) {
+            const uint32_t at = atomicAdd(&FR.counters[slow_count_index(pass + 1)], 1u);
+            FR.slow[((pass + 1) & 1u) * FR.slow_cap + at] = sr;       // (never more rows than this pass had)
+        }
+        return;
+    }
+    // ---- cells: one allocation for the row
+    const bool has = mine && role != 0;
+    int n_cells = 0;
+    if (has) n_cells = (role & REC_FULL) ? full_span(q1, q2) : __popc((role | (role >> 1)) & 0x15555555u);
+    const uint32_t incl = (uint32_t)wave_scan_incl(n_cells);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    const uint32_t base = alloc_cells(FR, total, lane);
+    if (has && base != ~0u) {
+        Cell* dst = &FR.cells[base + incl - (uint32_t)n_cells];
+        if (role & REC_FULL) full_cells(q1, r1, q2, r2, e.dy, (role & 1u) ? +1 : -1, P.x_min, P.x_max, dst);
+        else {
+            for (int sub = 0; sub < 15; ++sub) {
+                const uint32_t f = (role >> (2 * sub)) & 3u;
+                if (!f) continue;
+                int cc = e.x1;
+                if (slanted) { int32_t q; int64_t rm; edge_x_at(e, s0 + sub, q, rm); cc = cell_of(q, rm, e.dy); }
+                sub_cell(dst++, cc, f == 1u ? 1 : -1, P.x_min, P.x_max);
+            }
+        }
+    }
+    if (lane == 0) {
+        RowInfo2 h; h.off = base == ~0u ? 0u : base; h.n = base == ~0u ? (uint16_t)0 : (uint16_t)total; h.mode = (uint16_t)mode;
+        if (total > 65535u) { atomicOr(&FR.counters[C2_ERROR], E2_CELL_RANGE); h.n = 0; }
+        FR.rows[sr.ri] = h;
+        if (sr.pad >> 31) atomicAdd(&FR.counters[C2_TIE_ROWS], 1u);
+    }
+}
+__device__ __forceinline__ void slow_rows_loop(const Frame2& FR, uint32_t pass) {
+    const uint32_t n_slow = min(FR.counters[slow_count_index(pass)], FR.slow_cap);
+    for (uint32_t i = blockIdx.x; i < n_slow; i += gridDim.x) {
+        slow_row_body(FR, FR.slow[(pass & 1u) * FR.slow_cap + i], pass);
+        __syncthreads();                                       // `active` is rewritten by the next row
+    }
+}
+__global__ __launch_bounds__(64) void k2_rows_slow(const Frame2 FR, uint32_t pass) { slow_rows_loop(FR, pass); }
+__global__ __launch_bounds__(64) void k2_rows_slow_b(const Frame2* __restrict__ frames, uint32_t pass) { slow_rows_loop(frames[blockIdx.y], pass); }
+
+// k2_rows_huge: rows with 65 .. 2048 active edges of one path, one 256-thread workgroup each (k_rows_huge of raster_kernels.hip
+// with cells as output): thread t owns the active edges t, t + 256, ... and ranks each against the row's sort keys in LDS.
+__device__ __forceinline__ void huge_row_body(const Frame2& FR, const SlowRow sr, uint32_t pass) {
+    __shared__ uint32_t retry;
+    __shared__ uint32_t active[ROWS_HUGE_MAXA];
+    __shared__ int k_a[ROWS_HUGE_MAXA], k_b[ROWS_HUGE_MAXA], k_c[ROWS_HUGE_MAXA], k_d[ROWS_HUGE_MAXA];
+    __shared__ uint32_t wave_cnt[4];
+    __shared__ int flags;                                            // bit 0: some edge starts / ends inside the row, bit 1: FULL test failed
+    __shared__ uint32_t cell_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const DevPath P = FR.paths[sr.path];
+    const int r = sr.row, s0 = r * 15;
+    const unsigned mask = P.fill_rule ? 1u : ~0u;
+    const DevEdge* E = FR.edges + P.first_edge;
+    const PathEdges PE = {FR.edges, nullptr, &P, false, FR.counters, FR.rows, FR.band_slots, sr.pad & 0x7fffffffu, pass + 1 < SLOW_PASSES ? &retry : nullptr};
+    if (tid == 0) { flags = 0; retry = 0; }
+    int n = 0;
+    for (uint32_t base = 0; base < P.n_edges; base += 256) {
+        const uint32_t k = base + (uint32_t)tid;
+        bool act = false;
+        if (k < P.n_edges) { const int ytop = E[k].ytop, ybot = E[k].ybot; act = !(ybot <= s0 || ytop >= s0 + 15); }
+        const unsigned long long b = __ballot(act);
+        if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(b);
+        __syncthreads();
+        int at = n;
+        for (int w = 0; w < wave; ++w) at += (int)wave_cnt[w];
+        at += __popcll(b & ((1ull << lane) - 1ull));
+        if (act && at < ROWS_HUGE_MAXA) active[at] = k;
+        n += (int)(wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3]);
+        __syncthreads();
+    }
+    RowInfo2 ri; ri.off = 0; ri.n = 0; ri.mode = ROW_EMPTY;
+    if (n > ROWS_HUGE_MAXA) {                                        // workgroup-uniform
+        if (tid == 0) { atomicOr(&FR.counters[C2_ERROR], E2_ACTIVE_EDGES); FR.rows[sr.ri] = ri; }
+        return;
+    }
+    const int nb = (n + 255) >> 8;                                   // owned edges per thread (workgroup-uniform)
+    uint32_t role[ROWS_HUGE_EPT];
+#pragma unroll
+    for (int m = 0; m < ROWS_HUGE_EPT; ++m) role[m] = 0;
+    for (int j = tid; j < n; j += 256) {
+        const DevEdge e = E[active[j]];
+        if ((e.ytop > s0) | (e.ybot < s0 + 15)) atomicOr(&flags, 1);
+    }
+    __syncthreads();
+    bool full = (flags & 1) == 0;
+    if (full) {
+        for (int j = tid; j < n; j += 256) {
+            const DevEdge e = E[active[j]];
+            int c0, c1, cpv; int32_t q1, q2; int64_t r1, r2;
+            huge_full_keys(e, s0, c0, c1, cpv, q1, r1, q2, r2);
+            k_a[j] = c0; k_b[j] = c1; k_c[j] = cpv; k_d[j] = ((e.ytop == s0) ? 4 : 0) | (e.dir + 1);
+        }
+        __syncthreads();
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int m = 0; m < ROWS_HUGE_EPT; ++m) {
+                const int j = m * 256 + tid;
+                role[m] = 0;
+                if (m >= nb || j >= n) continue;
+                const int c0 = k_a[j], c1 = k_b[j], nw = (k_d[j] >> 2) & 1, dr = (k_d[j] & 3) - 1, nfj = (k_d[j] >> 3) & 1;
+                int w = 0; bool fg = true, lg = true, ok = true, mixed = false;
+                for (int i = 0; i < n; ++i) {                        // LDS broadcast reads
+                    if (i == j) continue;
+                    const int ci = k_a[i], ei = k_b[i], ni = (k_d[i] >> 2) & 1, di = (k_d[i] & 3) - 1, nfi = (k_d[i] >> 3) & 1;
+                    const bool tie = ci == c0, tie2 = ni == nw;
+                    bool deep_first = i < j;
+                    if (tie && ni == nw) {              // coincident edges: see tied_order (rare)
+                        const DevEdge ea = E[active[i]], eb = E[active[j]];
+                        if (same_line(ea, eb)) deep_first = i < j;
+                        else if (nw == 0) deep_first = tied_order(PE, ea, eb, active[i], active[j], s0, i < j);
+                        else deep_first = ea.pad < eb.pad;              // start ranks (k2_start_ranks)
+                    }
+                    const bool t3 = deep_first;
+                    const bool t_mixed = ni == 0 ? !nfi : nfj != 0;
+                    const bool before = ci < c0 || (tie && (tie2 ? t3 : t_mixed));
+                    mixed |= tie && !tie2;
+                    if (before) { w += di; if (ei > c1) ok = false; if (tie) fg = false; }
+                    else if (tie) lg = false;
+                }
+                if (!ok) atomicOr(&flags, 2);
+                if (mixed) atomicOr(&flags, 4);
+                const bool in_b = ((unsigned)w & mask) != 0, in_a = ((unsigned)(w + dr) & mask) != 0;
+                if (!in_b && fg) role[m] = REC_FULL | 1u;
+                else if (!in_a && lg) role[m] = REC_FULL | 2u;
+            }
+            __syncthreads();
+            if (pass == 1 || !(flags & 4)) break;                   // workgroup-uniform
+            __syncthreads();
+            if (tid == 0) flags &= ~2;                               // the order test is repeated with the final order
+            unsigned nfbits = 0;
+#pragma unroll
+            for (int m = 0; m < ROWS_HUGE_EPT; ++m) {
+                const int j = m * 256 + tid;
+                if (m >= nb || j >= n || ((k_d[j] >> 2) & 1)) continue;
+                const int c0 = k_a[j], cpv = k_c[j];
+                int L = INT_MIN; bool tied_before = false, any_new = false;
+                for (int i = 0; i < n; ++i) {
+                    if (i == j || ((k_d[i] >> 2) & 1)) continue;
+                    const int ci = k_a[i], pi = k_c[i];
+                    if (ci < c0) L = max(L, ci);
+                    else if (ci == c0 && (pi < cpv || (pi == cpv && i < j))) tied_before = true;
+                }
+                for (int i = 0; i < n; ++i) {
+                    if (!((k_d[i] >> 2) & 1)) continue;
+                    const int ci = k_a[i];
+                    any_new |= ci >= L && ci < c0;
+                }
+                if (!tied_before && any_new) nfbits |= 1u << m;
+            }
+            __syncthreads();                                         // every thread has read the keys it needs
+#pragma unroll
+            for (int m = 0; m < ROWS_HUGE_EPT; ++m) {
+                const int j = m * 256 + tid;
+                if (m < nb && j < n && ((nfbits >> m) & 1u)) k_d[j] |= 8;
+            }
+            __syncthreads();
+        }
+        __syncthreads();
+        full = (flags & 2) == 0;
+    }
+    const uint32_t mode = full ? ROW_FULL : ROW_SUB;
+    if (!full) {
+#pragma unroll
+        for (int m = 0; m < ROWS_HUGE_EPT; ++m) role[m] = 0;
+        for (int sub = 0; sub < 15; ++sub) {
+            const int ss = s0 + sub;
+            for (int j = tid; j < n; j += 256) {
+                const DevEdge e = E[active[j]];
+                const bool act = e.ytop <= ss && ss < e.ybot;
+                int cc = e.x1;
+                if (act && e.dy) { int32_t q; int64_t rm; edge_x_at(e, ss, q, rm); cc = cell_of(q, rm, e.dy); }
+                k_a[j] = cc; k_d[j] = act ? e.dir : 0;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < ROWS_HUGE_EPT; ++m) {
+                const int j = m * 256 + tid;
+                if (m >= nb || j >= n) continue;
+                const int dd = k_d[j], cc = k_a[j];
+                if (dd == 0) continue;
+                int wb = 0, gsum = dd; bool rep = true;
+                for (int i = 0; i < n; ++i) {
+                    const int di = k_d[i];
+                    if (i == j || di == 0) continue;             // dir is +-1 for an active edge
+                    const int ci = k_a[i];
+                    if (ci < cc) wb += di;
+                    else if (ci == cc) { gsum += di; if (i < j) rep = false; }
+                }
+                if (rep) {
+                    const bool in_b = ((unsigned)wb & mask) != 0, in_a = ((unsigned)(wb + gsum) & mask) != 0;
+                    if (in_a != in_b) role[m] |= (uint32_t)(in_a ? 1 : 2) << (2 * sub);
+                }
+            }
+            __syncthreads();                                         // k_a / k_d are rewritten for the next sample row
+        }
+    }
+    __syncthreads();
+    if (retry) {                                                     // (workgroup-uniform) depends on a row that is still queued: next pass
+        if (tid == 0) {
+            const uint32_t at = atomicAdd(&FR.counters[huge_count_index(pass + 1)], 1u);
+            if (at < FR.slow_cap) FR.huge[((pass + 1) & 1u) * FR.slow_cap + at] = sr; else atomicOr(&FR.counters[C2_ERROR], E2_SLOW_QUEUE);
+        }
+        return;
+    }
+    // ---- cells: count per thread, one allocation for the row, every thread writes its edges' cells behind its prefix
+    uint32_t mine_cells = 0;
+#pragma unroll
+    for (int m = 0; m < ROWS_HUGE_EPT; ++m) {
+        const int j = m * 256 + tid;
+        if (m >= nb || j >= n || role[m] == 0) continue;
+        if (role[m] & REC_FULL) {
+            const DevEdge e = E[active[j]];
+            int c0, c1, cpv; int32_t q1, q2; int64_t r1, r2;
+            huge_full_keys(e, s0, c0, c1, cpv, q1, r1, q2, r2);
+            mine_cells += (uint32_t)full_span(q1, q2);
+        } else mine_cells += (uint32_t)__popc((role[m] | (role[m] >> 1)) & 0x15555555u);
+    }
+    const uint32_t incl = (uint32_t)wave_scan_incl((int)mine_cells);
+    if (lane == 63) wave_cnt[wave] = incl;
+    __syncthreads();
+    uint32_t before = incl - mine_cells;
+    for (int w = 0; w < wave; ++w) before += wave_cnt[w];
+    const uint32_t total = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    if (tid == 0) {
+        uint32_t base = 0;
+        if (total) {
+            const uint32_t old = atomicAdd(&FR.counters[C2_HEAD], total);
+            base = FR.cell_main + old;
+            if ((uint64_t)base + total > FR.cell_slice || total > 65535u) { atomicOr(&FR.counters[C2_ERROR], total > 65535u ? E2_CELL_RANGE : E2_CELL_ARENA); base = ~0u; }
+        }
+        cell_base = base;
+    }
+    __syncthreads();
+    const uint32_t base = cell_base;
+    if (base != ~0u) {
+        Cell* dst = &FR.cells[base + before];
+#pragma unroll
+        for (int m = 0; m < ROWS_HUGE_EPT; ++m) {
+            const int j = m * 256 + tid;
+            if (m >= nb || j >= n || role[m] == 0) continue;
+            const DevEdge e = E[active[j]];
+            if (role[m] & REC_FULL) {
+                int c0, c1, cpv; int32_t q1, q2; int64_t r1, r2;
+                huge_full_keys(e, s0, c0, c1, cpv, q1, r1, q2, r2);
+                full_cells(q1, r1, q2, r2, e.dy, (role[m] & 1u) ? +1 : -1, P.x_min, P.x_max, dst);
+                dst += full_span(q1, q2);
+            } else {
+                for (int sub = 0; sub < 15; ++sub) {
+                    const uint32_t f = (role[m] >> (2 * sub)) & 3u;
+                    if (!f) continue;
+                    int cc = e.x1;
+                    if (e.dy) { int32_t q; int64_t rm; edge_x_at(e, s0 + sub, q, rm); cc = cell_of(q, rm, e.dy); }
+                    sub_cell(dst++, cc, f == 1u ? 1 : -1, P.x_min, P.x_max);
+                }
+            }
+        }
+    }
+    if (tid == 0) { ri.off = base == ~0u ? 0u : base; ri.n = base == ~0u ? (uint16_t)0 : (uint16_t)total; ri.mode = (uint16_t)mode; FR.rows[sr.ri] = ri; }
+}
+__device__ __forceinline__ void huge_rows_loop(const Frame2& FR, uint32_t pass) {
+    const uint32_t n_huge = min(FR.counters[huge_count_index(pass)], FR.slow_cap);
+    for (uint32_t i = blockIdx.x; i < n_huge; i += gridDim.x) {
+        huge_row_body(FR, FR.huge[(pass & 1u) * FR.slow_cap + i], pass);
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void k2_rows_huge(const Frame2 FR, uint32_t pass) { huge_rows_loop(FR, pass); }
+__global__ __launch_bounds__(256) void k2_rows_huge_b(const Frame2* __restrict__ frames, uint32_t pass) { huge_rows_loop(frames[blockIdx.y], pass); }
+
+// ---------------------------------------------------------------------------------------------
 // k2_tiles
 // ---------------------------------------------------------------------------------------------
-#define T2_LIST 64                     // band entries of a tile kept per round (lane = list position)
-#define T2_PRE 2                       // rounds of 64 cells of a batch fetched ahead into registers
+#define T2_LIST 32                     // band entries of a tile kept per round (lane = list position; lanes 32.. fetch the row headers)
+#define T2_PRE 1                       // rounds of 64 cells of a batch fetched ahead into registers
 
-// Persistent wavefronts: each walks strips w = blockIdx.x, blockIdx.x + gridDim.x, ... of the launch order (heaviest first when
-// the scene has one).  lane = pixel column; the strip's eight rows of pixels live in registers until the single store.
+// One wavefront per strip of the launch list (heaviest first when the scene has an order); lane = pixel column; the strip's eight
+// rows of pixels live in registers until the single store.  Dependent memory round trips per strip: strip descriptor -> class
+// bytes -> {band entries, row headers} -> cells.
 template <bool SHADERS>
 __device__ __forceinline__ void tiles2_body(const Frame2& FR) {
     __shared__ __attribute__((aligned(16))) int acc[STRIP_H][ACC_STRIDE];   // also the queue of the compacted blend (8-byte pairs)
     __shared__ __attribute__((aligned(16))) uint32_t ent[T2_LIST][8];       // BandEntry2 as dwords
+    __shared__ __attribute__((aligned(16))) uint32_t rinfo[T2_LIST][2 * STRIP_H];   // the strip's eight RowInfo2 of a tor entry
     __shared__ uint32_t sel[T2_LIST];                                       // list position -> band list index | class << 24
     __shared__ uint32_t seg_off[64], seg_start[64 + 1];                     // per (batch path, strip row): first cell, exclusive prefix of counts
     __shared__ int plist[PBATCH];
@@ -573,10 +1193,11 @@ __device__ __forceinline__ void tiles2_body(const Frame2& FR) {
     const swfr_style* __restrict__ styles = FR.styles;
     const Sources bitmaps = FR.src;
     for (int i = lane; i < STRIP_H * ACC_STRIDE; i += 64) (&acc[0][0])[i] = 0;
-    __syncthreads();
+    lds_barrier();
 
     for (uint32_t w = blockIdx.x; w < FR.n_strips; w += gridDim.x) {
-        const uint32_t wg = FR.order ? FR.order[w] : w;
+        const StripDesc sd = FR.strips[w];
+        const uint32_t wg = sd.wg;
         const int tile = (int)(wg / STRIPS_PER_TILE), strip = (int)(wg % STRIPS_PER_TILE);
         const int tcol = tile % tiles_x;
         int trow = tile / tiles_x;
@@ -588,8 +1209,7 @@ __device__ __forceinline__ void tiles2_body(const Frame2& FR) {
 #pragma unroll
         for (int rr = 0; rr < STRIP_H; ++rr) px[rr] = 0u;
 
-        const uint32_t band_begin = FR.band_off[trow], band_end = FR.band_off[trow + 1];
-        const uint32_t n_b = band_end - band_begin;
+        const uint32_t band_begin = sd.band_begin, n_b = sd.n_b;
         const uint8_t* mycls = FR.cls + (size_t)tiles_x * band_begin + (size_t)tcol * n_b;   // this tile's class byte per band entry
         uint32_t next = 0;
         while (next < n_b) {
@@ -611,7 +1231,7 @@ __device__ __forceinline__ void tiles2_body(const Frame2& FR) {
                 if (hit) sel[ln + __popcll(b & ((1ull << lane) - 1ull))] = bi | (f << 24);
                 ln += cnt;
             }
-            __syncthreads();                                      // sel written by other lanes
+            lds_barrier();                                      // sel written by other lanes
             // ---- occlusion, from the class bytes alone: everything below the last opaque full cover is invisible in this tile
             int start = 0;
             {
@@ -619,14 +1239,27 @@ __device__ __forceinline__ void tiles2_body(const Frame2& FR) {
                 const unsigned long long b = __ballot((f & (CLS_PARTIAL | CLS_NOTFULL | CLS_BOX | CLS_OPAQUE)) == CLS_OPAQUE);
                 if (b) start = 63 - __clzll((long long)b);
             }
-            // ---- the surviving entries, one per lane: 32 bytes as two 16-byte loads
-            if (lane >= start && lane < ln) {
-                const uint4* src = reinterpret_cast<const uint4*>(&FR.band_list[band_begin + (sel[lane] & 0xffffffu)]);
-                const uint4 q0 = src[0], q1 = src[1];
-                *reinterpret_cast<uint4*>(&ent[lane][0]) = q0;
-                *reinterpret_cast<uint4*>(&ent[lane][4]) = q1;
+            // ---- the surviving entries (lanes 0..31: 32 bytes as two 16-byte loads) and, for the partial tor paths among them, the
+            //      headers of this strip's eight rows (lanes 32..63: 64 bytes) -- both addressed by the band list position alone
+            {
+                const int li = lane & (T2_LIST - 1);
+                if (li >= start && li < ln) {
+                    const uint32_t sv = sel[li];
+                    const uint32_t bidx = band_begin + (sv & 0xffffffu);
+                    if (lane < T2_LIST) {
+                        const uint4* src = reinterpret_cast<const uint4*>(&FR.band_list[bidx]);
+                        const uint4 q0 = src[0], q1 = src[1];
+                        *reinterpret_cast<uint4*>(&ent[li][0]) = q0;
+                        *reinterpret_cast<uint4*>(&ent[li][4]) = q1;
+                    } else if (((sv >> 24) & (CLS_PARTIAL | CLS_BOX)) == CLS_PARTIAL) {
+                        const uint4* src = reinterpret_cast<const uint4*>(&FR.rows[(size_t)bidx * TILE_H + (uint32_t)(strip * STRIP_H)]);
+                        const uint4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
+                        uint4* dst = reinterpret_cast<uint4*>(&rinfo[li][0]);
+                        dst[0] = q0; dst[1] = q1; dst[2] = q2; dst[3] = q3;
+                    }
+                }
             }
-            __syncthreads();
+            lds_barrier();
 
             // ---- painter's order walk
             int batch_n = 0, batch_i = 0;
@@ -663,9 +1296,9 @@ __device__ __forceinline__ void tiles2_body(const Frame2& FR) {
                 } else if (f & CLS_PARTIAL) {
                     // ---- tor (A.5): the path's cells of this strip's rows
                     if (batch_i == batch_n) {
-                        // the next PBATCH partial tor paths of the list, this one first (lane = list position): their row headers in
-                        // one round trip, lane = (path of the batch, row of the strip), and the first cells of the flat sequence
-                        bool isp = lane >= li && lane < ln && ((sel[lane] >> 24) & (CLS_PARTIAL | CLS_BOX)) == CLS_PARTIAL;
+                        // the next PBATCH partial tor paths of the list, this one first (lane = list position); their row headers are
+                        // in LDS: lane = (path of the batch, row of the strip) forms the flat cell sequence and fetches its first cells
+                        bool isp = lane >= li && lane < ln && ((sel[lane & (T2_LIST - 1)] >> 24) & (CLS_PARTIAL | CLS_BOX)) == CLS_PARTIAL;
                         if (isp) {
                             const uint32_t lyw = ent[lane][1];
                             const int l_ymin = (int)(int16_t)(lyw & 0xffffu), l_ymax = (int)(int16_t)(lyw >> 16);
@@ -675,15 +1308,14 @@ __device__ __forceinline__ void tiles2_body(const Frame2& FR) {
                         const int rank = __popcll(pm & ((1ull << lane) - 1ull));
                         if (isp && rank < PBATCH) plist[rank] = lane;
                         batch_n = min((int)__popcll(pm), PBATCH); batch_i = 0;
-                        __syncthreads();                                   // plist visible
+                        lds_barrier();                                   // plist visible
                         uint32_t my_cnt = 0, off = 0;
                         {
                             const int bp = lane / STRIP_H, row = lane % STRIP_H;
                             if (bp < batch_n && ty0 + row < height) {
-                                const uint32_t bidx = band_begin + (sel[plist[bp]] & 0xffffffu);
-                                const RowInfo2 ri = FR.rows[(size_t)bidx * TILE_H + (uint32_t)(strip * STRIP_H + row)];
-                                off = ri.off; my_cnt = ri.n;
-                                if ((uint64_t)off + my_cnt > (uint64_t)FR.cell_slice * C2_HEADS) { atomicOr(&FR.counters[C2_ERROR], E2_CELL_RANGE); my_cnt = 0; }
+                                const int pl = plist[bp];
+                                off = rinfo[pl][2 * row]; my_cnt = rinfo[pl][2 * row + 1] & 0xffffu;
+                                if ((uint64_t)off + my_cnt > (uint64_t)FR.cell_slice) { atomicOr(&FR.counters[C2_ERROR], E2_CELL_RANGE); my_cnt = 0; }
                             }
                         }
                         const int incl = wave_scan_incl((int)my_cnt);       // every lane active
@@ -691,7 +1323,7 @@ __device__ __forceinline__ void tiles2_body(const Frame2& FR) {
                         seg_off[lane] = off;
                         seg_start[lane] = (uint32_t)(incl - (int)my_cnt);
                         seg_start[64] = (uint32_t)total;
-                        __syncthreads();                                   // seg_off / seg_start visible to every lane
+                        lds_barrier();                                   // seg_off / seg_start visible to every lane
 #pragma unroll
                         for (int u = 0; u < T2_PRE; ++u) {
                             const uint32_t g = (uint32_t)(u * 64 + lane);
@@ -730,22 +1362,25 @@ __device__ __forceinline__ void tiles2_body(const Frame2& FR) {
                             else if (i < TILE_W) atomicAdd(&arow[i], (int)c.ch * (1 << 20) + c.ua);
                         }
                     }
-                    __syncthreads();                                       // acc complete
+                    lds_barrier();                                       // acc complete
                     int (*A)[ACC_STRIDE] = acc;
                     // ---- prefix sum, alpha, blend; clears as it reads.  All eight rows in one straight-line block so that their LDS
                     //      round trips and DPP scan chains interleave; a row nothing was accumulated into scans zeros
                     {
-                        int v[STRIP_H], carry[STRIP_H];
+                        int v[STRIP_H];
 #pragma unroll
-                        for (int u = 0; u < STRIP_H; ++u) { v[u] = A[u][lane]; carry[u] = A[u][ACC_CARRY]; }
+                        for (int u = 0; u < STRIP_H; ++u) v[u] = A[u][lane];
+                        const int carries = A[lane & (STRIP_H - 1)][ACC_CARRY];   // lane u holds row u's carry: one register for the eight
 #pragma unroll
-                        for (int u = 0; u < STRIP_H; ++u) { A[u][lane] = 0; if (lane == 0) A[u][ACC_CARRY] = 0; }
+                        for (int u = 0; u < STRIP_H; ++u) A[u][lane] = 0;
+                        if (lane < STRIP_H) A[lane][ACC_CARRY] = 0;
                         uint32_t al[STRIP_H];
 #pragma unroll
                         for (int u = 0; u < STRIP_H; ++u) {
                             const int ua = (v[u] << 12) >> 12;             // low 20 bits, sign-extended
                             int ch = (v[u] - ua) >> 20;
-                            if (lane == 0) ch += carry[u];
+                            const int carry_u = __builtin_amdgcn_readlane(carries, u);
+                            if (lane == 0) ch += carry_u;
                             const int scan = wave_scan_incl(ch);
                             const int area = scan * 512 - ua;
                             al[u] = (uint32_t)((((area << 4) + area) + 256) >> 9) & 255u;   // area * 17
@@ -772,18 +1407,18 @@ __device__ __forceinline__ void tiles2_body(const Frame2& FR) {
                                     const int qi = qbase[u] + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(pmask[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pmask[u], 0u));
                                     if ((pmask[u] >> lane) & 1ull) q[qi] = make_uint2(al[u], px[u]);
                                 }
-                                __syncthreads();
+                                lds_barrier();
                                 for (int b = lane; b < nq; b += 64) {
                                     const uint2 e = q[b];
                                     q[b].x = lerp_pixel(solid, e.x, e.y);
                                 }
-                                __syncthreads();
+                                lds_barrier();
 #pragma unroll
                                 for (int u = 0; u < STRIP_H; ++u) {
                                     const int qi = qbase[u] + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(pmask[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pmask[u], 0u));
                                     if ((pmask[u] >> lane) & 1ull) px[u] = q[qi].x;
                                 }
-                                __syncthreads();
+                                lds_barrier();
                                 for (int b = lane; b < nq; b += 64) q[b] = make_uint2(0u, 0u);   // the accumulator is handed back empty
                                 blended = true;
                             }
@@ -796,7 +1431,7 @@ __device__ __forceinline__ void tiles2_body(const Frame2& FR) {
                             }
                         }
                     }
-                    __syncthreads();                                       // acc cleared before the next path accumulates
+                    lds_barrier();                                       // acc cleared before the next path accumulates
                 } else {
                     // full cover: every in-frame pixel of the path's rows in this tile has coverage 255
 #pragma unroll
@@ -804,7 +1439,7 @@ __device__ __forceinline__ void tiles2_body(const Frame2& FR) {
                         if (rr >= row_lo && rr < row_hi) px[rr] = blend_pixel_t<SHADERS>(px[rr], 255u, eflags, solid, styles, style, bitmaps, cx, ty0 + rr);
                 }
             }
-            __syncthreads();                                               // ent / sel are rewritten by the next round
+            lds_barrier();                                               // ent / sel are rewritten by the next round
         }
         // ---- one store per pixel: premultiplied R,G,B,A bytes; the wave writes 256 contiguous bytes per row
         if (cx < width) {
@@ -821,27 +1456,50 @@ __device__ __forceinline__ void tiles2_body(const Frame2& FR) {
     }
 }
 
-__global__ __launch_bounds__(64) void k2_tiles_solid(const Frame2* __restrict__ frames) { tiles2_body<false>(frames[blockIdx.y]); }
-__global__ __launch_bounds__(64) void k2_tiles_shaded(const Frame2* __restrict__ frames) { tiles2_body<true>(frames[blockIdx.y]); }
+#ifndef T2_WAVES
+#define T2_WAVES 6
+#endif
+// (two entry points per kernel: one frame, its descriptor passed by value -- the fields arrive with the kernel arguments, no memory
+//  round trip -- and a batch of frames, blockIdx.y indexing an array of descriptors in device memory)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(T2_WAVES))) void k2_tiles_solid(const Frame2 FR) { tiles2_body<false>(FR); }
+__global__ __launch_bounds__(64) void k2_tiles_shaded(const Frame2 FR) { tiles2_body<true>(FR); }
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(T2_WAVES))) void k2_tiles_solid_b(const Frame2* __restrict__ frames) { tiles2_body<false>(frames[blockIdx.y]); }
+__global__ __launch_bounds__(64) void k2_tiles_shaded_b(const Frame2* __restrict__ frames) { tiles2_body<true>(frames[blockIdx.y]); }
 
 // ---------------------------------------------------------------------------------------------
-// launchers
+// launchers: `host` != nullptr: one frame, descriptor by value; else `frames` is a device array of n_frames descriptors
 // ---------------------------------------------------------------------------------------------
-void launch2_front(hipStream_t st, const Frame2* frames, uint32_t n_frames, uint32_t max_edges, uint32_t max_slots) {
-    uint32_t n_setup = (max_edges + 255) / 256;
+void launch2_front(hipStream_t st, const Frame2* host, const Frame2* frames, uint32_t n_frames, uint32_t max_edges, uint32_t max_slots) {
+    uint32_t n_setup = (max_edges + 255) / 256;            // (max_edges: the larger of the edge and path counts, the setup threads also clear the path flags)
     const uint32_t n_b = (max_slots + 255) / 256;
     if (n_setup + n_b == 0) n_setup = 1;          // counters are still cleared
-    hipLaunchKernelGGL(k2_front, dim3(n_setup + n_b, n_frames), dim3(256), 0, st, frames, n_setup);
+    if (host) hipLaunchKernelGGL(k2_front, dim3(n_setup + n_b), dim3(256), 0, st, *host, n_setup);
+    else hipLaunchKernelGGL(k2_front_b, dim3(n_setup + n_b, n_frames), dim3(256), 0, st, frames, n_setup);
 }
-void launch2_rows(hipStream_t st, const Frame2* frames, uint32_t n_frames, uint32_t max_chunks) {
+void launch2_rows(hipStream_t st, const Frame2* host, const Frame2* frames, uint32_t n_frames, uint32_t max_chunks) {
     if (!max_chunks) return;
-    hipLaunchKernelGGL(k2_rows, dim3(max_chunks, n_frames), dim3(64), 0, st, frames);
+    if (host) hipLaunchKernelGGL(k2_rows, dim3(max_chunks), dim3(64), 0, st, *host);
+    else hipLaunchKernelGGL(k2_rows_b, dim3(max_chunks, n_frames), dim3(64), 0, st, frames);
 }
-void launch2_tiles(hipStream_t st, const Frame2* frames, uint32_t n_frames, uint32_t max_strips, uint32_t grid_cap, bool any_shader) {
+void launch2_rows_slow(hipStream_t st, const Frame2* host, const Frame2* frames, uint32_t n_frames, uint32_t grid_slow, uint32_t grid_huge, uint32_t max_passes) {
+    if (grid_slow) { if (host) hipLaunchKernelGGL(k2_start_ranks, dim3(grid_slow / 4 + 1), dim3(256), 0, st, *host); else hipLaunchKernelGGL(k2_start_ranks_b, dim3(grid_slow / 4 + 1, n_frames), dim3(256), 0, st, frames); }
+    // a queued row whose edge-order history runs through another queued row is queued again for the next pass
+    for (uint32_t pass = 0; pass < SLOW_PASSES; ++pass) {
+        if (grid_slow) { if (host) hipLaunchKernelGGL(k2_rows_slow, dim3(grid_slow), dim3(64), 0, st, *host, pass); else hipLaunchKernelGGL(k2_rows_slow_b, dim3(grid_slow, n_frames), dim3(64), 0, st, frames, pass); }
+        if (grid_huge) { if (host) hipLaunchKernelGGL(k2_rows_huge, dim3(grid_huge), dim3(256), 0, st, *host, pass); else hipLaunchKernelGGL(k2_rows_huge_b, dim3(grid_huge, n_frames), dim3(256), 0, st, frames, pass); }
+        if (pass + 1 >= max_passes) break;
+    }
+}
+void launch2_tiles(hipStream_t st, const Frame2* host, const Frame2* frames, uint32_t n_frames, uint32_t max_strips, uint32_t grid_cap, bool any_shader) {
     if (!max_strips) return;
     const uint32_t g = max_strips < grid_cap ? max_strips : grid_cap;
-    if (any_shader) hipLaunchKernelGGL(k2_tiles_shaded, dim3(g, n_frames), dim3(64), 0, st, frames);
-    else hipLaunchKernelGGL(k2_tiles_solid, dim3(g, n_frames), dim3(64), 0, st, frames);
+    if (host) {
+        if (any_shader) hipLaunchKernelGGL(k2_tiles_shaded, dim3(g), dim3(64), 0, st, *host);
+        else hipLaunchKernelGGL(k2_tiles_solid, dim3(g), dim3(64), 0, st, *host);
+    } else {
+        if (any_shader) hipLaunchKernelGGL(k2_tiles_shaded_b, dim3(g, n_frames), dim3(64), 0, st, frames);
+        else hipLaunchKernelGGL(k2_tiles_solid_b, dim3(g, n_frames), dim3(64), 0, st, frames);
+    }
 }
 
 }  // namespace swfr

@@ -258,6 +258,16 @@ __global__ __launch_bounds__(256) void k_front(const swfr_edge* __restrict__ in,
 // computes the constants itself).
 struct PathEdges {
     const DevEdge* dev; const swfr_edge* raw; const DevPath* P; bool from_raw;
+    uint32_t* diag;          // pipeline 2: counters; the replay's capacity limits are counted there (the frame then fails loudly)
+    __device__ __forceinline__ void limit_hit(uint32_t which) const { if (diag) atomicOr(&diag[which], 1u); }
+    // pipeline 2: the row headers the row kernel has already written say how an earlier row of this path was converted
+    const RowInfo2* rows2; const BandSlot* band_slots; uint32_t bs0;      // bs0: band_slots index of the path's first tile-row
+    uint32_t* retry;         // set (and a placeholder returned) when an earlier row's header is not there yet: the row is queued again
+    __device__ __forceinline__ uint32_t known_mode(int rho) const {
+        if (!rows2 || rho < P->y_min || rho >= P->y_max) return ROW_DEFER;
+        const BandSlot bs = band_slots[bs0 + (uint32_t)(rho / TILE_H - P->y_min / TILE_H)];
+        return rows2[(size_t)bs.slot * TILE_H + (uint32_t)(rho & (TILE_H - 1))].mode;
+    }
     __device__ __forceinline__ DevEdge operator()(uint32_t k) const { return from_raw ? make_dev_edge(raw[P->first_edge + k], *P) : dev[P->first_edge + k]; }
     __device__ __forceinline__ uint32_t size() const { return P->n_edges; }
     // the sample-row span alone (the part of make_dev_edge that needs no division)
@@ -269,6 +279,12 @@ struct PathEdges {
         if (ybot <= ytop) ytop = ybot = 0;
     }
 };
+// Two edges on one and the same line (a shape edge with fill0 == fill1 is decoded twice, once per direction: decode-swf-shape.ts:364-369):
+// their x agrees at every sample row, so they add and remove the same cells whichever comes first in Cairo's list -- their mutual
+// order needs no history.  (Only their order against a third edge that ties with them does.)
+__device__ __forceinline__ bool same_line(const DevEdge& a, const DevEdge& b) {
+    return a.x1 == b.x1 && a.y1 == b.y1 && a.ex == b.ex && a.dy == b.dy;
+}
 // ---- the order Cairo gives edges that become active at the same sample row m: the row's bucket holds them in path order, and
 //      sort_edges -- pairs, then merges of runs of 2, 4, ... with merge_sorted_edges, whose two loops consume the lists in
 //      alternating runs ("<=" on both sides: on a tie the list being consumed keeps going) -- sorts them by cell.  Restated for up
@@ -305,6 +321,7 @@ __device__ __forceinline__ uint64_t merge_runs(uint64_t A, int na, uint64_t B, i
 }
 // does path edge ka come before kb in that order?  (both become active at sample row m)
 __device__ __forceinline__ bool new_order_before(const PathEdges& PE, uint32_t ka, uint32_t kb, int m, bool path_order) {
+    if (PE.rows2) return PE.dev[PE.P->first_edge + ka].pad < PE.dev[PE.P->first_edge + kb].pad;   // pipeline 2: k2_start_ranks has replayed the sort
     int cell[NEW_SORT_MAX];
 #pragma unroll
     for (int t = 0; t < NEW_SORT_MAX; ++t) cell[t] = 0;
@@ -314,7 +331,7 @@ __device__ __forceinline__ bool new_order_before(const PathEdges& PE, uint32_t k
         int yt, yb;
         PE.span(k, yt, yb);
         if (yt != m || yb <= m) continue;
-        if (cnt >= NEW_SORT_MAX) return path_order;
+        if (cnt >= NEW_SORT_MAX) { PE.limit_hit(C2_TIE_SORT_OVERFLOW); return path_order; }
         const DevEdge e = PE(k);
         int c = e.x1;
         if (e.dy) { int32_t q; int64_t r; edge_x_at(e, m, q, r); c = cell_of(q, r, e.dy); }
@@ -390,6 +407,12 @@ template <int DEPTH>
 __device__ __forceinline__ bool tied_order_at(const PathEdges& PE, const DevEdge& a, const DevEdge& b, uint32_t ka, uint32_t kb, int s0, bool path_order);
 template <int DEPTH>
 __device__ __forceinline__ bool row_was_sampled(const PathEdges& PE, int rho) {
+    {   // the row kernel has decided that row already unless it, too, was left to the slow kernel
+        const uint32_t m = PE.known_mode(rho);
+        if (m == ROW_SUB) return true;
+        if (m == ROW_FULL || m == ROW_EMPTY) return false;
+        if (PE.retry && rho >= PE.P->y_min && rho < PE.P->y_max) { *PE.retry = 1u; return false; }   // that row is queued, too: next pass
+    }
     const int s = rho * 15;
     const uint32_t ne = PE.size();
     uint32_t n_active = 0;
@@ -400,7 +423,7 @@ __device__ __forceinline__ bool row_was_sampled(const PathEdges& PE, int rho) {
         if (yt > s || yb < s + 15) return true;
         ++n_active;
     }
-    if ((uint64_t)n_active * ne > (1u << 21)) return false;      // the pair test below reads n_active * ne spans
+    if ((uint64_t)n_active * ne > (1u << 21)) { PE.limit_hit(C2_TIE_PAIRTEST_SKIPPED); return false; }      // the pair test below reads n_active * ne spans
     for (uint32_t u = 0; u < ne; ++u) {
         int yt, yb;
         PE.span(u, yt, yb);
@@ -419,18 +442,12 @@ __device__ __forceinline__ bool row_was_sampled(const PathEdges& PE, int rho) {
                 bool u_first;
                 if (eu.ytop == s || ev.ytop == s) u_first = eu.ytop == ev.ytop ? new_order_before(PE, u, v, s, true) : arrival_order(PE, eu, ev, u, v);
                 else if constexpr (DEPTH > 0) u_first = tied_order_at<DEPTH - 1>(PE, eu, ev, u, v, s, true);   // two older edges: their history
-                else continue;
+                else { if (!same_line(eu, ev)) PE.limit_hit(C2_TIE_DEPTH); continue; }
                 if (u_first ? u1 > v1 : v1 > u1) return true;
             }
         }
     }
     return false;
-}
-// Two edges on one and the same line (a shape edge with fill0 == fill1 is decoded twice, once per direction: decode-swf-shape.ts:364-369):
-// their x agrees at every sample row, so they add and remove the same cells whichever comes first in Cairo's list -- their mutual
-// order needs no history.  (Only their order against a third edge that ties with them does.)
-__device__ __forceinline__ bool same_line(const DevEdge& a, const DevEdge& b) {
-    return a.x1 == b.x1 && a.y1 == b.y1 && a.ex == b.ex && a.dy == b.dy;
 }
 // Order of two active edges a, b whose cells coincide at the first sample row s0 of a pixel row (near-parallel edges leaving a
 // common vertex: round joins and caps produce them).  Cairo's list is re-sorted whenever it is looked at and a cell order is
@@ -814,7 +831,7 @@ __device__ __forceinline__ void rows_chunk_body(uint32_t block, const DevEdge* _
     }
     __syncthreads();
     RPHASE(1);
-    const PathEdges PE = {edges, raw, &P, (fused & 2) != 0};
+    const PathEdges PE = {edges, raw, &P, (fused & 2) != 0, nullptr, nullptr, nullptr, 0u, nullptr};
     uint32_t mode; int n, nmax = ROWS_FAST_N; bool overflow;
     int32_t roles[ROWS_FAST_N], cols[ROWS_FAST_N]; int el[ROWS_FAST_N];
     int32_t Q1[ROWS_FAST_N], Q2[ROWS_FAST_N]; int64_t R1[ROWS_FAST_N], R2[ROWS_FAST_N];
@@ -1127,7 +1144,7 @@ __device__ __forceinline__ void rows_rs_body(uint32_t block, const DevEdge* __re
         if (n_list > ROWS_STAGE) { use_lds = false; break; }
     }
     __syncthreads();
-    const PathEdges PE = {edges, nullptr, &P, false};
+    const PathEdges PE = {edges, nullptr, &P, false, nullptr, nullptr, nullptr, 0u, nullptr};
     if (use_lds) rows_by_slot((const DevEdge*)staged, n_list, (const uint32_t*)staged_k, P, ck, row_base, rows, records, band_index, band_count, fast_limit, cell_mode, lane, PE);
     else rows_by_slot(edges + P.first_edge, P.n_edges, (const uint32_t*)nullptr, P, ck, row_base, rows, records, band_index, band_count, fast_limit, cell_mode, lane, PE);
 }
@@ -1148,7 +1165,7 @@ __device__ __forceinline__ void big_row_body(uint32_t block, const DevEdge* __re
     const uint32_t t = row_base[br.path] + (uint32_t)(r - P.y_min);
     const unsigned mask = P.fill_rule ? 1u : ~0u;
     const DevEdge* E = edges + P.first_edge;
-    const PathEdges PE = {edges, nullptr, &P, false};
+    const PathEdges PE = {edges, nullptr, &P, false, nullptr, nullptr, nullptr, 0u, nullptr};
     // ---- gather: compact the indices of the active edges, 64 candidates per pass (path order is kept)
     int n = 0;
     bool too_many = false;
@@ -1348,7 +1365,7 @@ __global__ __launch_bounds__(256) void k_rows_huge(const DevEdge* __restrict__ e
     const uint32_t t = row_base[br.path] + (uint32_t)(r - P.y_min);
     const unsigned mask = P.fill_rule ? 1u : ~0u;
     const DevEdge* E = edges + P.first_edge;
-    const PathEdges PE = {edges, nullptr, &P, false};
+    const PathEdges PE = {edges, nullptr, &P, false, nullptr, nullptr, nullptr, 0u, nullptr};
     if (tid == 0) flags = 0;
     // ---- gather the active edges in path order: ballot per wavefront, wavefront totals through LDS
     int n = 0;

@@ -32,6 +32,10 @@ void launch_rows(hipStream_t, const DevEdge*, const DevPath*, const uint32_t*, c
                  const swfr_edge*, const swfr_style*, BandEntry*, const BigRow*, uint32_t);
 void launch_tiles(hipStream_t, const swfr_edge*, const uint32_t*, const BandEntry*, const uint8_t*, const RowInfo*, const Rec*, const swfr_style*,
                   Sources, uint32_t*, int, int, uint32_t, uint32_t, int, uint32_t*, uint32_t, uint32_t, bool, const uint32_t*);
+void launch2_front(hipStream_t, const Frame2*, const Frame2*, uint32_t, uint32_t, uint32_t);
+void launch2_rows(hipStream_t, const Frame2*, const Frame2*, uint32_t, uint32_t);
+void launch2_rows_slow(hipStream_t, const Frame2*, const Frame2*, uint32_t, uint32_t, uint32_t, uint32_t);
+void launch2_tiles(hipStream_t, const Frame2*, const Frame2*, uint32_t, uint32_t, uint32_t, bool);
 void launch_unpremultiply(hipStream_t, const uint32_t*, uint32_t*, size_t);
 void launch_pack_band(hipStream_t, const uint32_t*, uint32_t*, int, int, uint32_t, uint32_t, uint32_t);
 }  // namespace swfr
@@ -39,6 +43,8 @@ void launch_pack_band(hipStream_t, const uint32_t*, uint32_t*, int, int, uint32_
 using namespace swfr;
 
 namespace {
+
+constexpr size_t COUNTER_WORDS = C2_WORDS > CNT_WORDS ? C2_WORDS : CNT_WORDS;   // per frame set, whichever pipeline runs
 
 struct HipError {
     hipError_t code;
@@ -152,6 +158,12 @@ struct swfr_renderer {
         size_t n_edges = 0, n_paths = 0, n_styles = 0, n_tasks = 0, n_chunks = 0, n_bands = 0, rec_cap = 0, rec_main = 0, n_big = 0, n_huge = 0,
                chunk_rows = 64, n_band_entries = 0;
         bool any_shader = false, fused_class = false, fused_front = false, has_order = false;
+        size_t n_incidences = 0, n_strips = 0;   // (edge, pixel row) pairs: bounds the cells of a frame; k_tiles wavefronts
+        Frame2* frames_dev = nullptr;            // pipeline 2: one descriptor per frame set (contiguous, in the arena)
+        Frame2 frames_host[4];                   // ... and on the host: a single frame's launches pass theirs by value
+        StripDesc* strips = nullptr;
+        uint32_t slow_passes = SLOW_PASSES;      // passes of the slow-row kernels the scene needs (known after a frame of a resident scene)
+        int slow_state = 0;                      // 0: unknown (both slow-row kernels are launched), 1: the scene has no queued rows, 2: none with > 64 edges
     };
     Scene scn[4];
     // One set of kernel-written per-frame buffers and the stream they are used on.  With SWFR_FRAMES_IN_FLIGHT = n consecutive
@@ -164,6 +176,13 @@ struct swfr_renderer {
         DevBuf<RowInfo> d_rows;
         DevBuf<Rec> d_records;
         DevBuf<uint32_t> d_counters, d_fb;
+        // pipeline 2
+        DevBuf<BandEntry2> d_band2;
+        DevBuf<RowInfo2> d_rows2;
+        DevBuf<Cell> d_cells;
+        DevBuf<SlowRow> d_slow, d_huge;
+        DevBuf<uint32_t> d_path_flag, d_path_queue;
+        size_t cell_slice = 0, slow_cap = 0, cell_heads = 1;
     };
     FrameSet fs[4];
     DevBuf<DevBitmap> d_bitmap_table;
@@ -182,6 +201,10 @@ struct swfr_renderer {
     int tiles_dbg = 0;                      // SWFR_TILES_DEBUG: timing-only ablations of k_tiles (wrong pixels)
     int cell_mode = 3;                      // SWFR_CELL_MODE: 1 = FULL rows as precomputed cells, 2 = SUB rows (test knob)
     int fast_limit = 8;                     // rows with more active edges go through k_rows_big (SWFR_FAST_LIMIT: test knob)
+    int pipeline = 2;                       // SWFR_PIPELINE=1: the round-1 kernels (edge records); 2: cells (raster2.hip)
+    int tiles_grid = 0;                     // SWFR_TILES_GRID: persistent k2_tiles wavefronts per frame (0 = default)
+    Frame2* d_frames = nullptr;             // one descriptor per frame set, contiguous: a batch of frames is one launch
+    Frame2* h_frames = nullptr;             // pinned staging of the same
 
     ~swfr_renderer() {
         if (has_device) {
@@ -190,10 +213,13 @@ struct swfr_renderer {
             for (int k = 0; k < 4; ++k) {
                 FrameSet& x = fs[k];
                 x.d_edges.release(); x.d_band_list.release(); x.d_cls.release(); x.d_rows.release(); x.d_records.release(); x.d_counters.release(); x.d_fb.release();
+                x.d_band2.release(); x.d_rows2.release(); x.d_cells.release(); x.d_slow.release(); x.d_huge.release(); x.d_path_flag.release(); x.d_path_queue.release();
                 if (k > 0 && x.stream) (void)hipStreamDestroy(x.stream);
                 scn[k].arena.release();
             }
             if (h_counters) (void)hipHostFree(h_counters);
+            if (d_frames) (void)hipFree(d_frames);
+            if (h_frames) (void)hipHostFree(h_frames);
             for (auto& kv : bitmaps) if (kv.second.pixels) (void)hipFree(kv.second.pixels);
             for (auto& e : ev) if (e) (void)hipEventDestroy(e);
             if (stream) (void)hipStreamDestroy(stream);
@@ -431,11 +457,12 @@ DevFilter good_filter(const swfr_style& st, const int rect[4], std::vector<int32
 // Uploads a scene into scene slot `si` (H2D on frame set `si`'s stream) and sizes the kernel-written buffers: of every frame
 // set in flight (`all_sets`, resident rendering: the sets share scene 0) or of set `si` only (batch rendering: one scene per set).
 int upload(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, size_t n_edges, const swfr_path* paths, size_t n_paths,
-           const swfr_style* styles, size_t n_styles) {
+           const swfr_style* styles, size_t n_styles, uint32_t* fb_override = nullptr) {
     if (!r->has_device) return fail(r, SWFR_ERR_NO_DEVICE, "host-only handle cannot rasterize");
     validate_scene(r, edges, n_edges, paths, n_paths, styles, n_styles);
     swfr_renderer::Scene& sc = r->scn[si];
     if (si == 0) r->scene_ready = false;
+    sc.slow_state = 0; sc.slow_passes = SLOW_PASSES;
     if (si > 0 && !r->fs[si].stream) HIP_CHECK(hipStreamCreateWithFlags(&r->fs[si].stream, hipStreamNonBlocking));
     const hipStream_t up_stream = r->fs[si].stream;
     // stage: edges tagged with their path index; row prefix over tor paths; record capacity bound
@@ -455,14 +482,14 @@ int upload(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, size
     // rows per k_rows workgroup: 64 when that already gives the GPU a thousand wavefronts, fewer for scenes made of a few tall
     // paths (a wavefront's run time is set by its longest row loop, so those scenes want more, shorter wavefronts)
     uint32_t chunk_rows = ROWS_CHUNK;
-    if (r->force_chunk_rows == 8 || r->force_chunk_rows == 16 || r->force_chunk_rows == 32 || r->force_chunk_rows == 64) {
+    if ((r->force_chunk_rows == 8 && r->pipeline != 2) || r->force_chunk_rows == 16 || r->force_chunk_rows == 32 || r->force_chunk_rows == 64) {
         chunk_rows = uint32_t(r->force_chunk_rows);           // SWFR_CHUNK_ROWS: test knob (8 selects the row x slot kernel)
     } else {
         for (;;) {
             size_t n = 0;
             for (size_t i = 0; i < n_paths; ++i)
                 if (paths[i].kind == SWFR_PATH_TOR) n += size_t(paths[i].y_max - paths[i].y_min + int(chunk_rows) - 1) / chunk_rows;
-            if (n >= 1024 || chunk_rows <= 8) break;
+            if (n >= 1024 || chunk_rows <= (r->pipeline == 2 ? uint32_t(TILE_H) : 8u)) break;   // (pipeline 2: chunks are whole tile-rows)
             chunk_rows >>= 1;
         }
     }
@@ -582,6 +609,8 @@ int upload(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, size
     // belongs to a chunk), the chunks also compute their edges' constants and write their band entries: k_front is not launched
     sc.fused_front = sc.fused_class && r->allow_fused > 1 && max_path_edges <= 64 && !any_flat;
     sc.n_band_entries = band_off[n_bands];
+    sc.n_incidences = rec_cap;
+    sc.n_strips = size_t(local_tile_rows(r)) * ((r->width + TILE_W - 1) / TILE_W) * STRIPS_PER_TILE;
     (void)pair_cap;
     // per-frame (kernel-written) buffers: grow-only allocations
     const int n_sets = std::max(1, std::min(r->in_flight, 4));
@@ -590,7 +619,23 @@ int upload(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, size
         auto& x = r->fs[k];
         x.d_edges.reserve(n_edges); x.d_rows.reserve(sc.n_tasks); x.d_records.reserve(sc.rec_cap); x.d_band_list.reserve(sc.n_band_entries);
         x.d_cls.reserve(sc.n_band_entries * ((r->width + TILE_W - 1) / TILE_W) + 64);   // class byte per (band entry, tile column)
-        x.d_counters.reserve(CNT_WORDS);
+        x.d_counters.reserve(COUNTER_WORDS);
+        if (r->pipeline == 2) {
+            // every (edge, pixel row) pair yields at most MAX_CELLS_PER_EDGE_ROW cells; the arena is cut into C2_HEADS slices, one per
+            // bump allocator (wavefronts pick theirs by workgroup number), with a factor two for uneven shares
+            // (a scene of a few wavefronts uses one allocator: shares of a handful of wavefronts are not even)
+            // the chunk wavefronts of k2_rows write at fixed places (their share of that bound, from the chunk table); the rows of the
+            // slow-row kernels take theirs from one bump allocator behind that region
+            const size_t heads = 1;
+            const size_t slice = sc.n_incidences * MAX_CELLS_PER_EDGE_ROW * 2 + 2048;
+            x.d_band2.reserve(sc.n_band_entries); x.d_rows2.reserve(sc.n_band_entries * TILE_H + 64); x.d_cells.reserve(slice * heads);
+            x.cell_heads = heads;
+            x.d_slow.reserve(2 * (sc.n_tasks + 64)); x.d_huge.reserve(2 * (sc.n_tasks + 64));     // (two queues each: a pass reads one and refills the other)
+            x.d_path_flag.reserve(n_paths + 64); x.d_path_queue.reserve(n_paths + 64);
+            x.cell_slice = slice; x.slow_cap = sc.n_tasks + 64;
+            // class bytes outside the paths' rectangles are never written by a kernel: cleared once per uploaded scene
+            HIP_CHECK(hipMemsetAsync(x.d_cls.ptr, 0, sc.n_band_entries * ((r->width + TILE_W - 1) / TILE_W) + 64, up_stream));
+        }
         if (!x.d_fb.ptr) {
             x.d_fb.reserve(size_t(r->width) * r->height);
             HIP_CHECK(hipMemsetAsync(x.d_fb.ptr, 0, size_t(r->width) * r->height * 4, up_stream));
@@ -623,13 +668,24 @@ int upload(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, size
         }
     }
     sc.has_order = !order.empty();
+    // the launch list of the tile pass: every strip of this handle's tile-rows with its tile-row's slice of the band list
+    std::vector<StripDesc> strips;
+    if (r->pipeline == 2) {
+        const uint32_t tiles_x = (r->width + TILE_W - 1) / TILE_W;
+        strips.resize(sc.n_strips);
+        for (uint32_t w = 0; w < strips.size(); ++w) {
+            const uint32_t wg = order.empty() ? w : order[w];
+            const uint32_t trow = (wg / STRIPS_PER_TILE / tiles_x) * bc + bi;
+            strips[w] = StripDesc{wg, band_off[trow], band_off[trow + 1] - band_off[trow], 0};
+        }
+    }
     {
         SceneArena& A = sc.arena;
         auto P = SceneArena::padded;
         A.begin(P(n_edges * sizeof(swfr_edge)) + P(n_paths * sizeof(swfr_path)) + P(n_styles * sizeof(swfr_style)) +
                 P((n_paths + 1) * sizeof(uint32_t)) + P(band_slots.size() * sizeof(BandSlot)) + P(order.size() * sizeof(uint32_t)) +
                 P(big_rows.size() * sizeof(BigRow)) + P(huge_rows.size() * sizeof(BigRow)) + P(chunks.size() * sizeof(ChunkInfo)) + P((n_bands + 1) * sizeof(uint32_t)) +
-                P(n_styles * sizeof(DevFilter)) + P(fparams.size() * sizeof(int32_t)) + P(gradients.size() * sizeof(DevGradient)) + 4096);
+                P(n_styles * sizeof(DevFilter)) + P(fparams.size() * sizeof(int32_t)) + P(gradients.size() * sizeof(DevGradient)) + P(4 * sizeof(Frame2)) + P(strips.size() * sizeof(StripDesc)) + 4096);
         sc.raw = static_cast<swfr_edge*>(A.push(staged.data(), n_edges * sizeof(swfr_edge)));
         sc.paths = static_cast<DevPath*>(A.push(paths, n_paths * sizeof(swfr_path)));
         sc.styles = static_cast<swfr_style*>(A.push(styles, n_styles * sizeof(swfr_style)));
@@ -643,6 +699,31 @@ int upload(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, size
         sc.filters = static_cast<DevFilter*>(A.push(filters.data(), n_styles * sizeof(DevFilter)));
         sc.filter_params = static_cast<int32_t*>(A.push(fparams.data(), fparams.size() * sizeof(int32_t)));
         sc.gradients = static_cast<DevGradient*>(A.push(gradients.data(), gradients.size() * sizeof(DevGradient)));
+        if (r->pipeline == 2) {
+            sc.strips = static_cast<StripDesc*>(A.push(strips.data(), strips.size() * sizeof(StripDesc)));
+            if (r->bitmap_table_dirty) r->d_bitmap_table.reserve(r->bitmap_table.size());     // (filled below; the address is what the descriptor needs)
+            Frame2 fr[4];
+            std::memset(fr, 0, sizeof fr);
+            for (int k = 0; k < 4; ++k) {
+                if (all_sets ? k >= n_sets : k != si) continue;
+                auto& x = r->fs[k];
+                Frame2& f = fr[k];
+                f.raw = sc.raw; f.paths = sc.paths; f.styles = sc.styles; f.chunks = sc.chunk_base; f.band_slots = sc.band_slots; f.band_off = sc.band_off;
+                f.strips = sc.strips;
+                f.src = Sources{r->d_bitmap_table.ptr, sc.filters, sc.filter_params, sc.gradients};
+                f.edges = x.d_edges.ptr; f.band_list = x.d_band2.ptr; f.cls = x.d_cls.ptr; f.rows = x.d_rows2.ptr; f.cells = x.d_cells.ptr;
+                f.slow = x.d_slow.ptr; f.huge = x.d_huge.ptr; f.counters = x.d_counters.ptr;
+                f.path_flag = x.d_path_flag.ptr; f.path_queue = x.d_path_queue.ptr;
+                f.fb = (fb_override && k == si) ? fb_override : x.d_fb.ptr;
+                f.n_edges = uint32_t(n_edges); f.n_paths = uint32_t(n_paths); f.n_chunks = uint32_t(sc.n_chunks); f.n_slots = uint32_t(sc.n_band_entries);
+                f.n_bands = uint32_t(n_bands); f.n_strips = uint32_t(sc.n_strips); f.cell_slice = uint32_t(x.cell_slice); f.slow_cap = uint32_t(x.slow_cap);
+                f.width = int32_t(r->width); f.height = int32_t(r->height); f.tiles_x = int32_t((r->width + TILE_W - 1) / TILE_W);
+                f.band_index = bi; f.band_count = bc; f.fast_limit = uint32_t(std::min(std::max(r->fast_limit, 0), 8)); f.any_shader = sc.any_shader ? 1u : 0u;
+                f.dbg = uint32_t(r->tiles_dbg); f.cell_heads = 1; f.cell_main = uint32_t(sc.n_incidences * MAX_CELLS_PER_EDGE_ROW);
+            }
+            sc.frames_dev = static_cast<Frame2*>(A.push(fr, sizeof fr));
+            std::memcpy(sc.frames_host, fr, sizeof fr);
+        }
         A.flush(up_stream);
     }
     if (r->bitmap_table_dirty) {
@@ -662,6 +743,22 @@ int upload(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, size
 void launch_frame(swfr_renderer* r, const swfr_renderer::Scene& sc, swfr_renderer::FrameSet& F, uint32_t* fb, hipEvent_t* e) {
     const uint32_t bc = r->cfg.band_count > 1 ? r->cfg.band_count : 1, bi = r->cfg.band_count > 1 ? r->cfg.band_index : 0;
     const hipStream_t st = F.stream;
+    if (r->pipeline == 2) {
+        // the frame's descriptor (scene arrays, this set's buffers, the framebuffer) was written with the scene
+        const Frame2* fh = &sc.frames_host[&F - r->fs];
+        if (e) HIP_CHECK(hipEventRecord(e[0], st));
+        launch2_front(st, fh, nullptr, 1, uint32_t(std::max(sc.n_edges, sc.n_paths)), uint32_t(sc.n_band_entries));
+        if (e) HIP_CHECK(hipEventRecord(e[1], st));
+        launch2_rows(st, fh, nullptr, 1, uint32_t(sc.n_chunks));
+        // the queued rows (coincident edges, crowded rows): skipped once a frame of this resident scene has shown there are none
+        if (sc.n_chunks && sc.slow_state != 1) launch2_rows_slow(st, fh, nullptr, 1, 1024u, sc.slow_state == 2 ? 0u : 256u, sc.slow_passes);
+        if (e) HIP_CHECK(hipEventRecord(e[2], st));
+        const uint32_t grid = r->tiles_grid > 0 ? uint32_t(r->tiles_grid) : ~0u;
+        launch2_tiles(st, fh, nullptr, 1, uint32_t(sc.n_strips), grid, sc.any_shader);
+        if (e) HIP_CHECK(hipEventRecord(e[3], st));
+        (void)fb;
+        return;
+    }
     if (e) HIP_CHECK(hipEventRecord(e[0], st));
     if (sc.n_paths && !sc.fused_front)   // edge constants + band lists (the row kernel does both itself when fused_front)
         launch_front(st, sc.raw, sc.paths, F.d_edges.ptr, uint32_t(sc.n_edges), sc.band_slots, uint32_t(sc.n_band_entries),
@@ -684,6 +781,28 @@ void launch_frame(swfr_renderer* r, const swfr_renderer::Scene& sc, swfr_rendere
 }
 
 int check_counters(swfr_renderer* r, const uint32_t* counters) {
+    if (r->pipeline == 2) {
+        const uint32_t err = counters[C2_ERROR];
+        if (err & ~(E2_ACTIVE_EDGES | E2_START_GROUP | E2_CELL_ARENA)) {
+            r->fb_valid = false;
+            return fail(r, SWFR_ERR_DEVICE, "internal consistency check failed in the raster kernels (code " + std::to_string(err) + ")");
+        }
+        if (err) {
+            r->fb_valid = false;
+            return fail(r, SWFR_ERR_CAPACITY, err & E2_CELL_ARENA ? "cell arena exhausted (uneven allocator shares)" :
+                        "a pixel row has more than 2048 active edges of one path, or more than 2048 of its edges start at one sample row (scan converter capacity)");
+        }
+        // the replay of Cairo's edge-list order for coincident edges has capacity limits; a scene that reaches one is refused,
+        // never rendered approximately
+        if (counters[C2_TIE_PAIRTEST_SKIPPED] | counters[C2_TIE_SORT_OVERFLOW] | counters[C2_TIE_DEPTH]) {
+            r->fb_valid = false;
+            return fail(r, SWFR_ERR_CAPACITY, std::string("coincident edges beyond the capacity of the list-order replay (") +
+                        (counters[C2_TIE_PAIRTEST_SKIPPED] ? "crossing test over more than 2^21 edge pairs; " : "") +
+                        (counters[C2_TIE_SORT_OVERFLOW] ? "more than 16 edges starting at one sample row; " : "") +
+                        (counters[C2_TIE_DEPTH] ? "tie history deeper than one level; " : "") + ")");
+        }
+        return SWFR_OK;
+    }
     if (counters[CNT_ERROR] & ~1u) {
         r->fb_valid = false;
         return fail(r, SWFR_ERR_DEVICE, "internal consistency check failed in k_tiles (code " + std::to_string(counters[CNT_ERROR]) + ")");
@@ -701,7 +820,7 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
     if (frames == 0) frames = 1;
     const swfr_renderer::Scene& sc = r->scn[0];
     float setup_ms = 0, rows_ms = 0, tiles_ms = 0, total_ms = 0;
-    uint32_t counters[CNT_WORDS] = {};
+    uint32_t counters[COUNTER_WORDS] = {};
     if (frames > 4096) frames = 4096;
     // all frames are queued back to back, rotating over the frame sets; events bracket every kernel on the stream the frame runs on
     uint32_t n_sets = 1;
@@ -715,11 +834,11 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
     const uint32_t stride = r->event_stride < 1 ? 1u : uint32_t(r->event_stride);
     hipEvent_t ev_begin = r->ev[size_t(frames) * 4], ev_end = r->ev[size_t(frames) * 4 + 1];
     hipEvent_t* ev_join = &r->ev[size_t(frames) * 4 + 2];
-    HIP_CHECK(hipMemsetAsync(r->fs[0].d_counters.ptr, 0, CNT_WORDS * sizeof(uint32_t), r->stream));
+    HIP_CHECK(hipMemsetAsync(r->fs[0].d_counters.ptr, 0, COUNTER_WORDS * sizeof(uint32_t), r->stream));
     HIP_CHECK(hipEventRecord(ev_begin, r->stream));
     for (uint32_t k = 1; k < n_sets; ++k) {
         HIP_CHECK(hipStreamWaitEvent(r->fs[k].stream, ev_begin, 0));
-        HIP_CHECK(hipMemsetAsync(r->fs[k].d_counters.ptr, 0, CNT_WORDS * sizeof(uint32_t), r->fs[k].stream));
+        HIP_CHECK(hipMemsetAsync(r->fs[k].d_counters.ptr, 0, COUNTER_WORDS * sizeof(uint32_t), r->fs[k].stream));
     }
     for (uint32_t f = 0; f < frames; ++f) {
         swfr_renderer::FrameSet& F = r->fs[f % n_sets];
@@ -733,9 +852,9 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
     HIP_CHECK(hipEventRecord(ev_end, r->stream));
     HIP_CHECK(hipGetLastError());
     // the counters of every set come back through pinned memory behind the last kernel: one synchronisation for everything
-    if (!r->h_counters) HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&r->h_counters), 4 * CNT_WORDS * sizeof(uint32_t), hipHostMallocDefault));
+    if (!r->h_counters) HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&r->h_counters), 4 * COUNTER_WORDS * sizeof(uint32_t), hipHostMallocDefault));
     for (uint32_t k = 0; k < n_sets; ++k)
-        HIP_CHECK(hipMemcpyAsync(r->h_counters + k * CNT_WORDS, r->fs[k].d_counters.ptr, CNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
+        HIP_CHECK(hipMemcpyAsync(r->h_counters + k * COUNTER_WORDS, r->fs[k].d_counters.ptr, COUNTER_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
     HIP_CHECK(hipStreamSynchronize(r->stream));
     r->fb_cur = r->fs[(frames - 1) % n_sets].d_fb.ptr;
     uint32_t timed_frames = 0;
@@ -749,13 +868,22 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
     }
     HIP_CHECK(hipEventElapsedTime(&total_ms, ev_begin, ev_end));
     std::memcpy(counters, r->h_counters, sizeof counters);
-    for (uint32_t k = 1; k < n_sets; ++k) counters[CNT_ERROR] |= r->h_counters[k * CNT_WORDS + CNT_ERROR];
+    for (uint32_t k = 1; k < n_sets; ++k) {
+        counters[CNT_ERROR] |= r->h_counters[k * COUNTER_WORDS + CNT_ERROR];
+        counters[C2_ERROR] |= r->h_counters[k * COUNTER_WORDS + C2_ERROR];
+    }
     r->timing = swfr_timing{total_ms, setup_ms, rows_ms, tiles_ms, frames, sc.n_edges, sc.n_paths, sc.n_tasks, sc.rec_main, timed_frames};
     if (r->tiles_dbg == 9)
         std::fprintf(stderr, "[swfr] tile/path pairs %u, partial %u, full %u, culled entries %u\n", counters[CNT_PAIRS],
                      counters[CNT_PARTIAL], counters[CNT_FULL], counters[CNT_CULLED]);
 #ifdef SWFR_PHASES
-    if (std::getenv("SWFR_PRINT_PHASES") && counters[16]) {
+    if (std::getenv("SWFR_PRINT_PHASES") && r->pipeline == 2 && counters[C2_CELLS]) {
+        static const char* names[8] = {"descriptors", "stage edges", "gather", "evaluate", "full test + alloc", "sample rows", "full cells", "queue + class"};
+        std::fprintf(stderr, "[swfr] k2_rows phases, clocks per wavefront (%u wavefronts):", counters[C2_CELLS]);
+        for (int i = 0; i < 8; ++i) std::fprintf(stderr, " %s %.0f", names[i], 16.0 * counters[24 + i] / counters[C2_CELLS]);
+        std::fprintf(stderr, "\n");
+    }
+    if (std::getenv("SWFR_PRINT_PHASES") && r->pipeline != 2 && counters[16]) {
         static const char* names[8] = {"descriptors", "stage edges", "gather", "evaluate", "full test", "sample rows", "records", "bands+class"};
         std::fprintf(stderr, "[swfr] k_rows phases, clocks per wavefront (%u wavefronts):", counters[16]);
         for (int i = 0; i < 8; ++i) std::fprintf(stderr, " %s %.0f", names[i], 16.0 * counters[8 + i] / counters[16]);
@@ -763,6 +891,20 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
     }
 #endif
     r->fb_valid = true;
+    if (r->pipeline == 2) {
+        uint32_t slow = 0, huge = 0;
+        for (uint32_t k = 0; k < n_sets; ++k) { slow |= r->h_counters[k * COUNTER_WORDS + C2_SLOW]; huge |= r->h_counters[k * COUNTER_WORDS + C2_HUGE]; }
+        uint32_t passes = 1;
+        for (uint32_t k = 0; k < n_sets; ++k)
+            for (uint32_t q = 1; q < SLOW_PASSES; ++q) {
+                const uint32_t* c = r->h_counters + k * COUNTER_WORDS;
+                if (c[C2_SLOWQ + q] | c[C2_HUGEQ + q]) { passes = std::max(passes, q + 1); huge |= c[C2_HUGEQ + q]; }
+            }
+        r->scn[0].slow_state = slow == 0 ? 1 : (huge == 0 ? 2 : 0);     // what the next frames of this resident scene can skip
+        r->scn[0].slow_passes = passes;
+        r->timing.n_records = 0;
+        for (uint32_t h = 0; h < C2_HEADS; ++h) r->timing.n_records += counters[C2_HEAD + h];     // cells of the last frame of set 0
+    }
     return check_counters(r, counters);
 }
 
@@ -777,7 +919,7 @@ int render_batch(swfr_renderer* r, const swfr_stage* stages, uint32_t n, void* d
     const uint32_t n_sets = uint32_t(std::max(1, std::min(r->in_flight, 4)));
     std::vector<uint32_t*> pinned_counters;
     uint32_t* hc = nullptr;
-    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&hc), size_t(n) * CNT_WORDS * sizeof(uint32_t), hipHostMallocDefault));
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&hc), size_t(n) * COUNTER_WORDS * sizeof(uint32_t), hipHostMallocDefault));
     int rc = SWFR_OK;
     try {
         for (uint32_t i = 0; i < n; ++i) {
@@ -786,14 +928,15 @@ int render_batch(swfr_renderer* r, const swfr_stage* stages, uint32_t n, void* d
             const auto& e = r->builder->edges();
             const auto& p = r->builder->paths();
             const auto& s = r->builder->styles();
-            rc = upload(r, k, false, e.data(), e.size(), p.data(), p.size(), s.data(), s.size());
+            uint32_t* fb_dst = device_dst ? reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(device_dst) + size_t(i) * frame_stride) : nullptr;
+            rc = upload(r, k, false, e.data(), e.size(), p.data(), p.size(), s.data(), s.size(), fb_dst);
             if (rc != SWFR_OK) break;
             swfr_renderer::FrameSet& F = r->fs[k];
             if (k > 0 && i < n_sets) HIP_CHECK(hipStreamSynchronize(r->stream));   // first use of the set: bitmap table etc. are in place
-            HIP_CHECK(hipMemsetAsync(F.d_counters.ptr, 0, CNT_WORDS * sizeof(uint32_t), F.stream));
+            HIP_CHECK(hipMemsetAsync(F.d_counters.ptr, 0, COUNTER_WORDS * sizeof(uint32_t), F.stream));
             uint32_t* fb = device_dst ? reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(device_dst) + size_t(i) * frame_stride) : F.d_fb.ptr;
             launch_frame(r, r->scn[k], F, fb, nullptr);
-            HIP_CHECK(hipMemcpyAsync(hc + size_t(i) * CNT_WORDS, F.d_counters.ptr, CNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, F.stream));
+            HIP_CHECK(hipMemcpyAsync(hc + size_t(i) * COUNTER_WORDS, F.d_counters.ptr, COUNTER_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, F.stream));
             r->fb_cur = fb;
         }
         HIP_CHECK(hipGetLastError());
@@ -806,7 +949,7 @@ int render_batch(swfr_renderer* r, const swfr_stage* stages, uint32_t n, void* d
     r->scene_ready = false;                 // scene 0 now holds some frame of the batch, not a scene the caller uploaded
     r->fb_valid = true;
     if (rc == SWFR_OK)
-        for (uint32_t i = 0; i < n && rc == SWFR_OK; ++i) rc = check_counters(r, hc + size_t(i) * CNT_WORDS);
+        for (uint32_t i = 0; i < n && rc == SWFR_OK; ++i) rc = check_counters(r, hc + size_t(i) * COUNTER_WORDS);
     (void)hipHostFree(hc);
     return rc;
 }
@@ -832,6 +975,8 @@ int swfr_create(uint32_t width, uint32_t height, const swfr_config* cfg, swfr_re
     if (r->cfg.band_count > 1 && r->cfg.band_index >= r->cfg.band_count) return SWFR_ERR_INVALID;
     r->builder.reset(new FrameBuilder(width, height, (r->cfg.flags & SWFR_FLAG_EVEN_ODD) != 0));
     if (const char* fl = std::getenv("SWFR_FAST_LIMIT")) r->fast_limit = std::atoi(fl);
+    if (const char* pl = std::getenv("SWFR_PIPELINE")) r->pipeline = std::atoi(pl) == 1 ? 1 : 2;
+    if (const char* tg = std::getenv("SWFR_TILES_GRID")) r->tiles_grid = std::atoi(tg);
     if (const char* td = std::getenv("SWFR_TILES_DEBUG")) r->tiles_dbg = std::atoi(td);
     if (const char* fc = std::getenv("SWFR_FUSED_CLASS")) r->allow_fused = std::atoi(fc);
     if (const char* cr = std::getenv("SWFR_CHUNK_ROWS")) r->force_chunk_rows = std::atoi(cr);
@@ -853,7 +998,7 @@ int swfr_create(uint32_t width, uint32_t height, const swfr_config* cfg, swfr_re
         raw->fs[0].stream = raw->stream;
         raw->fs[0].d_fb.reserve(size_t(width) * height);
         HIP_CHECK(hipMemsetAsync(raw->fs[0].d_fb.ptr, 0, size_t(width) * height * 4, raw->stream));
-        raw->fs[0].d_counters.reserve(CNT_WORDS);
+        raw->fs[0].d_counters.reserve(COUNTER_WORDS);
         HIP_CHECK(hipStreamSynchronize(raw->stream));
         return int(SWFR_OK);
     });
