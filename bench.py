@@ -5,16 +5,23 @@ synthetic shape set (scene S1).
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A step is one pass of the hot path over one frame: edge setup -> per-row winding -> tile raster/shade/blend
--> RGBA8 framebuffer in HBM, with the edge list already resident in HBM; consecutive frames alternate between two
-sets of per-frame buffers on two HIP streams (SWFR_FRAMES_IN_FLIGHT).  With N > 1 every rank rasterizes whole frames
-of the batch (a step is one frame per rank, weak scaling, no data-path collective); `--sharding bands` instead
-shards one frame's tile-rows over the ranks and ends every step with one RCCL gather to rank 0 (strong scaling).
-Rank 0 prints ONE JSON line: the BASELINE metric, the HBM roofline of k_tiles from HIP events in the timed region
-(and the same kernel with one frame in flight beside it), and the CPU oracle timed on this box.
+A step is one pass of the hot path over one frame, starting from the raw edge list resident in HBM: binning on the device
+(band lists in painter's order, row chunks, scan-converter constants) -> per-row winding / cells -> launch order of the
+strips -> tile raster/shade/blend -> RGBA8 framebuffer in HBM.  Consecutive frames rotate over SWFR_FRAMES_IN_FLIGHT
+(default 3) sets of per-frame buffers, each on its own HIP stream.
+
+N > 1 (one process per GPU): the frame's tile-rows are sharded over the ranks (north star: "frame tiles shard naturally
+across the 8 GPUs ... with an RCCL gather") -- `--sharding bands`, the default, strong scaling: every step is one frame,
+rank k rasterizes its tile-rows and one gather per frame assembles the image on rank 0.  The same run also measures
+BASELINE.json's config 5 (S2: 8K, 100k edges, same split) and reports it as `config5_s2_bands`.  `--sharding frames`
+(whole frames per rank, no data-path collective, weak scaling) is kept as an explicitly named alternative.
+
+Rank 0 prints ONE JSON line: the BASELINE metric, the HBM roofline of the tile kernel from HIP events in the timed region
+(and the same kernel with one frame in flight), the full reference-style path (a new Stage every frame through
+swfr_render, timed below the C-ABI), the frame checked against the libcairo known answer, and the CPU oracle timed on
+this box (all cores and one).
 """
 import argparse
-import ctypes
 import json
 import os
 import sys
@@ -24,58 +31,97 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured ceiling
+DEFAULT_IN_FLIGHT = 3
 
 
-def cpu_baseline(fx, cols, W, H, budget_s=12.0, name="S1"):
-    """The oracle (single-thread C restatement) timed on this box's host cores on a bounded sample."""
+def _oracle_args(fx, cols):
     import numpy as np
-    from oracle import oracle_backend as ob
-    L = ob.lib()
     argb = ((cols[:, 3].astype(np.uint32) << 24) | (cols[:, 0].astype(np.uint32) << 16) |
             (cols[:, 1].astype(np.uint32) << 8) | cols[:, 2]).astype(np.uint32)
     counts = np.full(len(fx), fx.shape[1], dtype=np.int32)
     xy = np.ascontiguousarray(fx.reshape(-1))
-    frames, t0 = 0, time.perf_counter()
-    while True:
-        ctx = L.swfo_create(W, H)
-        L.swfo_fill_polygons_fixed(ctx, xy.ctypes.data, counts.ctypes.data, argb.ctypes.data, len(fx), 0)
-        L.swfo_destroy(ctx)
-        frames += 1
-        dt = time.perf_counter() - t0
-        if dt > budget_s or frames >= 200:
-            break
-    return {"value": round(W * H * frames / dt / 1e6, 2), "unit": "Mpixels/s", "cores": 1, "kind": "port",
-            "sample": "%d full %s frames (%dx%d, %d stars) in %.1f s, single thread, oracle/swfr_oracle.c" % (frames, name, W, H, len(fx), dt)}
+    return xy, counts, argb
+
+
+def cpu_baseline(fx, cols, W, H, budget_s=8.0, name="S1"):
+    """The oracle (C restatement of the reference's Cairo arithmetic) timed on this box's host cores on a bounded sample:
+    whole frames of the workload, first on one thread, then one frame stream per core (ctypes releases the GIL)."""
+    import threading
+    from oracle import oracle_backend as ob
+    L = ob.lib()
+    xy, counts, argb = _oracle_args(fx, cols)
+
+    def frames_for(seconds, out, k):
+        n, t0 = 0, time.perf_counter()
+        while True:
+            ctx = L.swfo_create(W, H)
+            L.swfo_fill_polygons_fixed(ctx, xy.ctypes.data, counts.ctypes.data, argb.ctypes.data, len(fx), 0)
+            L.swfo_destroy(ctx)
+            n += 1
+            if time.perf_counter() - t0 > seconds or n >= 200:
+                break
+        out[k] = (n, time.perf_counter() - t0)
+
+    one = [None]
+    frames_for(budget_s / 2, one, 0)
+    cores = max(1, min(len(os.sched_getaffinity(0)), 16))     # (a GPU box's CPU share per GPU is 16 cores)
+    res = [None] * cores
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=frames_for, args=(budget_s / 2, res, k)) for k in range(cores)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    wall = time.perf_counter() - t0
+    total = sum(r[0] for r in res)
+    return {"value": round(W * H * total / wall / 1e6, 2), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+            "sample": "%d full %s frames (%dx%d, %d stars) in %.1f s on %d threads, one frame stream per thread, oracle/swfr_oracle.c" % (total, name, W, H, len(fx), wall, cores),
+            "single_thread": {"value": round(W * H * one[0][0] / one[0][1] / 1e6, 2), "cores": 1,
+                              "sample": "%d frames in %.1f s" % one[0]}}
 
 
 def oracle_frame(fx, cols, W, H):
-    """One frame of the scene by the CPU oracle as premultiplied RGBA8 (checker for --verify on S2)."""
+    """One frame of the scene by the CPU oracle as premultiplied RGBA8 (the checker of S2)."""
     import numpy as np
     from oracle import oracle_backend as ob
     L = ob.lib()
     ctx = L.swfo_create(W, H)
-    argb = ((cols[:, 3].astype(np.uint32) << 24) | (cols[:, 0].astype(np.uint32) << 16) |
-            (cols[:, 1].astype(np.uint32) << 8) | cols[:, 2]).astype(np.uint32)
-    counts = np.full(len(fx), fx.shape[1], dtype=np.int32)
-    xy = np.ascontiguousarray(fx.reshape(-1))
+    xy, counts, argb = _oracle_args(fx, cols)
     L.swfo_fill_polygons_fixed(ctx, xy.ctypes.data, counts.ctypes.data, argb.ctypes.data, len(fx), 0)
     px = np.ctypeslib.as_array(L.swfo_pixels(ctx), shape=(H, W)).copy()
     L.swfo_destroy(ctx)
     return np.stack([(px >> 16) & 255, (px >> 8) & 255, px & 255, px >> 24], -1).astype(np.uint8)
 
 
+def latest_traffic():
+    """HBM bytes per launch of the tile kernel from the newest committed PMC profile (FETCH_SIZE / WRITE_SIZE passes,
+    gfx950 corrections: tools/profile_r02.py), with its source; (None, None) when there is none."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_k_tiles.json"))):
+        best = f
+    if not best:
+        return None, None
+    try:
+        return json.load(open(best)).get("hbm_bytes_per_launch"), os.path.relpath(best, ROOT)
+    except Exception:
+        return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-full-path", action="store_true", help="skip the reference-style full path (new Stage per frame) measurement")
+    ap.add_argument("--no-verify", action="store_true", help="skip the check of the frame against the known answer after the timed region")
+    ap.add_argument("--verify", action="store_true", help="(default) kept for compatibility")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 path on one GPU: every rank renders on cuda:0, slabs are gathered as CPU tensors")
-    ap.add_argument("--verify", action="store_true", help="rank 0 checks the assembled frame against the S1 known answer (S2: against the oracle)")
-    ap.add_argument("--sharding", default="frames", choices=["frames", "bands"],
-                    help="N>1: frames = every rank rasterizes whole frames of the batch, no data-path collective (weak scaling, default); "
-                         "bands = one frame's tile-rows interleaved over the ranks + one RCCL gather per frame to rank 0 (strong scaling)")
+    ap.add_argument("--sharding", default="bands", choices=["frames", "bands"],
+                    help="N>1: bands (default) = one frame's tile-rows sharded over the ranks + one RCCL gather per frame to rank 0 (strong scaling, "
+                         "the north star's split); frames = every rank rasterizes whole frames, no data-path collective (weak scaling)")
     ap.add_argument("--workload", default="s1", choices=["s1", "s2"],
                     help="s1 = BASELINE.json's metric configuration (4K, 10k edges; the default and the judged line); s2 = 8K, 100k edges")
     args = ap.parse_args()
@@ -103,111 +149,136 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-
-    cfg = synth.S1 if args.workload == "s1" else synth.S2
-    W, H = cfg["width"], cfg["height"]
-    pts, cols = synth.scene(**cfg)
-    fx = synth.twips_to_fixed(pts)
-    # host half through the product's own C++ frame builder (register_shape + scene walk), as swfr_render does
-    host = S.Renderer(W, H, device=api.DEVICE_HOST_ONLY)
-    t0 = time.perf_counter()
-    stage = api.stars_to_stage(pts, cols)
-    edges, paths, styles = host.build_frame(stage)
-    t_host = time.perf_counter() - t0
-    host.close()
-
-    bands = world > 1 and args.sharding == "bands"
-    r = S.Renderer(W, H, device=local_rank, band_index=rank if bands else 0, band_count=world if bands else 0)
-    r.upload_edges(edges, paths, styles)                      # inputs resident in HBM before the timed region
-    pipe = None
-    if bands:
-        pipe = D.FramePipeline(r, W, H, rank, world, device="cpu" if rehearsal else "cuda")
+    in_flight = int(os.environ.get("SWFR_FRAMES_IN_FLIGHT", str(DEFAULT_IN_FLIGHT)))
 
     def sync_all():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def step_multi():
-        return pipe.step()
+    def scene_of(cfg):
+        W, H = cfg["width"], cfg["height"]
+        pts, cols = synth.scene(**cfg)
+        fx = synth.twips_to_fixed(pts)
+        # host half through the product's own C++ frame builder (register_shape + scene walk), as swfr_render does
+        host = S.Renderer(W, H, device=api.DEVICE_HOST_ONLY)
+        t0 = time.perf_counter()
+        stage = api.stars_to_stage(pts, cols)
+        edges, paths, styles = host.build_frame(stage)
+        t_host = time.perf_counter() - t0
+        host.close()
+        return W, H, pts, cols, fx, stage, (edges, paths, styles), t_host
 
-    # ---- warmup
-    if not bands:
-        r.render_resident(min(max(args.warmup, 1), 2048))
+    def run_bands(cfg_name, cfg, steps, warmup):
+        """One frame per step, tile-rows sharded over the ranks, one gather per frame; returns (seconds, image on rank 0, scene)."""
+        W, H, pts, cols, fx, stage, scene, _ = scene_of(cfg)
+        rb = S.Renderer(W, H, device=local_rank, band_index=rank, band_count=world)
+        rb.upload_edges(*scene)
+        pipe = D.FramePipeline(rb, W, H, rank, world, device="cpu" if rehearsal else "cuda")
+        for _ in range(max(warmup, 1)):
+            pipe.step()
+        pipe.finish()
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            pipe.step()
+        out = pipe.finish()
+        sync_all()
+        dt = time.perf_counter() - t0
+        tm = rb.timing()
+        rb.close()
+        return dt, out, (W, H, fx, cols, scene), tm
+
+    bands = world > 1 and args.sharding == "bands"
+    cfg = synth.S1 if args.workload == "s1" else synth.S2
+    extra = {}
+    if bands:
+        dt, out, (W, H, fx, cols, scene), tm = run_bands(args.workload, cfg, args.steps, args.warmup)
+        edges, paths, styles = scene
+        t_host = 0.0
+        r = None
     else:
-        for _ in range(max(args.warmup, 1)):
-            step_multi()
-    sync_all()
-    # ---- timed region: exactly K steps
-    t0 = time.perf_counter()
-    if not bands:
-        left = args.steps                                     # K frames queued back to back on the handle's streams
-        while left > 0:                                       # (the library takes at most 4096 frames per call)
+        W, H, pts, cols, fx, stage, (edges, paths, styles), t_host = scene_of(cfg)
+        r = S.Renderer(W, H, device=local_rank)
+        r.upload_edges(edges, paths, styles)                      # inputs resident in HBM before the timed region
+        r.render_resident(min(max(args.warmup, 1), 2048))
+        sync_all()
+        t0 = time.perf_counter()
+        left = args.steps                                         # K frames queued back to back on the handle's streams
+        while left > 0:                                           # (the library takes at most 4096 frames per call)
             n = min(left, 2048)
             r.render_resident(n)
             left -= n
-    else:
+        sync_all()
+        dt = time.perf_counter() - t0
+        tm = r.timing()
         out = None
-        for _ in range(args.steps):
-            out = step_multi()
-        out = pipe.finish()
-    sync_all()
-    dt = time.perf_counter() - t0
-    tm = r.timing()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    if args.verify and rank == 0:
+    verified = None
+    if not args.no_verify and rank == 0:
         import hashlib
         img = out.cpu().numpy() if bands else r.read_image(premultiplied=True)
         if args.workload == "s1":
-            ok = hashlib.sha256(np.ascontiguousarray(img).tobytes()).hexdigest() == synth.S1_SHA256_PREMUL
+            verified = hashlib.sha256(np.ascontiguousarray(img).tobytes()).hexdigest() == synth.S1_SHA256_PREMUL
         else:
-            ok = np.array_equal(np.asarray(img), oracle_frame(fx, cols, W, H))
-        print("verify: assembled frame %s the %s" % ("matches" if ok else "DOES NOT match", "libcairo known answer" if args.workload == "s1" else "CPU oracle"), file=sys.stderr, flush=True)
-        if not ok:
+            verified = bool(np.array_equal(np.asarray(img), oracle_frame(fx, cols, W, H)))
+        if not verified:
+            print("verify: the frame of the timed region DOES NOT match the %s" % ("libcairo known answer" if args.workload == "s1" else "CPU oracle"), file=sys.stderr, flush=True)
             raise SystemExit(3)
+
+    # ---- secondary measurements of the same run (outside the timed region)
+    if bands and args.workload == "s1":
+        # BASELINE.json config 5: the 100k-edge 8K scene over the same ranks
+        dt5, out5, (W5, H5, fx5, cols5, scene5), _ = run_bands("s2", synth.S2, max(5, min(args.steps, 40)), 3)
+        t5 = torch.tensor([dt5], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t5, op=dist.ReduceOp.MAX)
+        k5 = max(5, min(args.steps, 40))
+        extra["config5_s2_bands"] = {"workload": "S2: 7680x4320, 10000 stars (99909 edges), tile-rows sharded over %d ranks, one gather per frame" % world,
+                                     "value": round(W5 * H5 * k5 / float(t5.item()) / 1e6, 2), "unit": "Mpixels/s",
+                                     "frames_per_sec": round(k5 / float(t5.item()), 1), "steps": k5}
     if rank == 0:
         n_edges, n_paths = len(edges), len(paths)
-        algo_bytes = 4 * W * H + 16 * n_edges + 16 * n_paths           # SURVEY.md 8(d), per frame = per k_tiles launch
+        algo_bytes = 4 * W * H + 16 * n_edges + 16 * n_paths           # SURVEY.md 8(d), per frame = per tile-kernel launch
         if bands:
             algo_bytes = 4 * W * D.local_tile_rows(H, 0, world) * D.TILE_H + 16 * n_edges + 16 * n_paths
-        tiles_ms = tm["tiles_ms"] / max(tm["timed_frames"], 1)
+        nt = max(tm["timed_frames"], 1)
+        tiles_ms = tm["tiles_ms"] / nt
         achieved = algo_bytes / (tiles_ms * 1e-3) / 1e9 if tiles_ms > 0 else 0.0
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01m_pmc_k_tiles.json")
-        if os.path.exists(pmc) and not bands and args.workload == "s1":
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        traffic, traffic_src = latest_traffic() if (not bands and args.workload == "s1") else (None, None)
+        frames_total = args.steps * (1 if bands or world == 1 else world)
         line = {
             "metric": "Mpixels/sec rasterized @ 4K, 10k-edge synthetic shape set" if args.workload == "s1" else "Mpixels/sec rasterized @ 8K, 100k-edge synthetic shape set",
-            # frames sharding: a step is one frame on every rank (N frames); bands sharding: one frame over all ranks
-            "value": round(W * H * args.steps * (1 if bands or world == 1 else world) / dt / 1e6, 2),
+            # bands sharding: one frame over all ranks per step; frames sharding: a step is one frame on every rank (N frames)
+            "value": round(W * H * frames_total / dt / 1e6, 2),
             "unit": "Mpixels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "frames_per_sec": round(args.steps * (1 if bands or world == 1 else world) / dt, 1),
+            "frames_per_sec": round(frames_total / dt, 1),
             "higher_is_better": True,
             "scaling": "strong" if bands else "weak",
             "vs_baseline": None,
             "dtype": "int64/u8",
             "data": "synthetic",
+            "verified": verified,
             "config": {"workload": "%s: %dx%d, %d ten-vertex stars, opaque solid, nonzero, seed 0xC0FFEE" % (args.workload.upper(), W, H, len(fx)),
                        "n_edges": n_edges, "n_paths": n_paths,
-                       "sharding": ("tile-row bands interleaved over %d ranks, one RCCL gather per frame" % world) if bands else
+                       "sharding": ("tile-row bands over %d ranks, one RCCL gather per frame" % world) if bands else
                                    ("whole frames, one per rank and step, no data-path collective" if world > 1 else "single GPU"),
-                       "host_edge_list_build_ms": round(t_host * 1e3, 2)},
-            "kernel_ms_per_frame": {"k_setup": round(tm["setup_ms"] / max(tm["timed_frames"], 1), 4), "k_rows": round(tm["rows_ms"] / max(tm["timed_frames"], 1), 4),
-                                    "k_tiles": round(tiles_ms, 4)},
-            "roofline": {"bound": "hbm", "kernel": "k_tiles", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                       "frames_in_flight": 1 if bands else in_flight,
+                       "device_path": "raw edge list -> k2_bin -> k2_rows -> k2_tiles, every frame"},
+            "kernel_ms_per_frame": {"k2_bin": round(tm["setup_ms"] / nt, 4), "k2_rows": round(tm["rows_ms"] / nt, 4), "k2_tiles": round(tiles_ms, 4)},
+            "roofline": {"bound": "hbm", "kernel": "k2_tiles", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": algo_bytes},
         }
-        line["config"]["frames_in_flight"] = int(os.environ.get("SWFR_FRAMES_IN_FLIGHT", "2")) if not bands else 1
-        if world == 1 and line["config"]["frames_in_flight"] > 1:
-            # the timed region overlaps consecutive frames on two streams, which stretches every kernel's own duration;
-            # the same kernel timed with one frame in flight (a second handle, outside the timed region) is reported beside it
+        line.update(extra)
+        if world == 1 and in_flight > 1:
+            # the timed region overlaps consecutive frames on several streams, which stretches every kernel's own duration;
+            # the same kernels timed with one frame in flight (a second handle, outside the timed region) are reported beside it
             os.environ["SWFR_FRAMES_IN_FLIGHT"] = "1"
             r1 = S.Renderer(W, H, device=local_rank)
             r1.upload_edges(edges, paths, styles)
@@ -215,14 +286,48 @@ def main():
             r1.render_resident(64)
             t1 = r1.timing()
             r1.close()
-            iso_ms = t1["tiles_ms"] / max(t1["timed_frames"], 1)
+            os.environ["SWFR_FRAMES_IN_FLIGHT"] = str(in_flight)
+            n1 = max(t1["timed_frames"], 1)
+            iso_ms = t1["tiles_ms"] / n1
             iso = algo_bytes / (iso_ms * 1e-3) / 1e9 if iso_ms > 0 else 0.0
-            line["roofline"]["one_frame_in_flight"] = {"k_tiles_ms": round(iso_ms, 4), "achieved": round(iso, 2), "frac": round(iso / HBM_PEAK_GBS, 5),
-                                                       "value": round(W * H * 64 / (t1["total_ms"] * 1e-3) / 1e6, 2)}
+            line["roofline"]["one_frame_in_flight"] = {"k2_tiles_ms": round(iso_ms, 4), "k2_rows_ms": round(t1["rows_ms"] / n1, 4),
+                                                       "k2_bin_ms": round(t1["setup_ms"] / n1, 4), "achieved": round(iso, 2),
+                                                       "frac": round(iso / HBM_PEAK_GBS, 5), "value": round(W * H * 64 / (t1["total_ms"] * 1e-3) / 1e6, 2)}
+        if world == 1 and not args.no_full_path and args.workload == "s1":
+            # ---- the reference's calling pattern: a different Stage every frame through swfr_render (blocking), timed below the
+            #      C-ABI (swfr_render_sequence); four variants of S1 (the stars shifted by 0..3 px) so that no frame repeats the last
+            variants = []
+            for k in range(4):
+                p2 = pts.copy()
+                p2[..., 0] += 20 * k
+                variants.append(api.stars_to_stage(p2, cols))
+            r.render_sequence(variants, 1)                        # registers the definitions, warms the buffers
+            secs, acc = r.render_sequence(variants, 8)
+            nfr = 4 * 8
+            t0 = time.perf_counter()
+            r.read_image(premultiplied=True)
+            d2h = time.perf_counter() - t0
+            full = {"frames_per_sec": round(nfr / secs, 1), "Mpixels_per_sec": round(W * H * nfr / secs / 1e6, 1),
+                    "what": "swfr_render of a new Stage per frame (blocking), %d frames, timed in C" % nfr,
+                    "build_host_ms": round(acc["build_ms"] / nfr, 4), "upload_host_ms": round(acc["upload_host_ms"] / nfr, 4),
+                    "h2d_ms": round(acc["h2d_ms"] / nfr, 4), "h2d_bytes": int(acc["h2d_bytes"] / nfr), "device_ms": round(acc["device_ms"] / nfr, 4),
+                    "d2h_ms": round(d2h * 1e3, 3), "d2h_what": "swfr_read_image of the 33 MB frame into pageable host memory"}
+            # the same frames as one pipelined batch (swfr_render_batch: the host builds frame i+1 while frame i is rasterized)
+            frames_t = torch.empty((4, H, W, 4), dtype=torch.uint8, device="cuda")
+            r.render_batch(variants, frames_t.data_ptr(), H * W * 4)
+            t0 = time.perf_counter()
+            for _ in range(4):
+                r.render_batch(variants, frames_t.data_ptr(), H * W * 4)
+            tb = time.perf_counter() - t0
+            full["batch_frames_per_sec"] = round(16 / tb, 1)
+            del frames_t
+            line["full_path"] = full
+        line["config"]["host_edge_list_build_ms_python"] = round(t_host * 1e3, 2)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(fx, cols, W, H, name=args.workload.upper())
         print(json.dumps(line), flush=True)
-    r.close()
+    if r is not None:
+        r.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

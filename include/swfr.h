@@ -157,7 +157,9 @@ int  swfr_read_image(swfr_renderer *r, uint8_t *dst, size_t dst_stride, int prem
 
 /* ---- low-level entry: the hot path proper (edge list -> RGBA8 in HBM) ---------------------- */
 /* One edge of a flattened, limit-clipped polygon in 24.8 device coordinates: the line
-   (x1,y1)-(x2,y2) with y1 < y2 is active for y in [top,bottom); dir is the winding direction. */
+   (x1,y1)-(x2,y2) with y1 < y2 is active for y in [top,bottom); dir is the winding direction.
+   `reserved` is the index of the owning path (the device bins edges by it): swfr_build_frame fills
+   it in, swfr_upload_edges / swfr_render_edges overwrite it from the paths' edge ranges. */
 typedef struct { int32_t x1, y1, x2, y2, top, bottom, dir, reserved; } swfr_edge;
 
 enum { SWFR_PATH_TOR = 0,   /* general polygon: Cairo "tor" 15x256 scan conversion */
@@ -225,6 +227,23 @@ typedef struct {
     uint32_t timed_frames;               /* frames / SWFR_EVENT_STRIDE (default 16) */
 } swfr_timing;
 int  swfr_last_timing(swfr_renderer *r, swfr_timing *out);
+
+/* Where the time of the last swfr_render went (the reference's calling pattern: one blocking call per frame). */
+typedef struct {
+    double build_ms;                     /* host: Stage -> edge list (scene walk, flattening, stroking, clipping) */
+    double upload_host_ms;               /* host: staging copy + table layout (prefix sums over the paths) */
+    double h2d_ms;                       /* the scene's one host-to-device copy (HIP events) */
+    double device_ms;                    /* first kernel start -> last kernel end (HIP events) */
+    double total_ms;                     /* wall clock of the whole call, synchronisation included */
+    uint64_t h2d_bytes;
+} swfr_path_timing;
+int  swfr_last_path_timing(swfr_renderer *r, swfr_path_timing *out);
+
+/* The reference's animation loop in one call: for (rep < repeat) for (i < n_stages) swfr_render(stages[i]) -- every frame built,
+   uploaded, binned, rasterized and waited for exactly as by swfr_render -- timed on the host side of the C-ABI.  `seconds`
+   receives the wall clock of the loop; `sum` (optional) the per-stage times added up. */
+int  swfr_render_sequence(swfr_renderer *r, const swfr_stage *stages, uint32_t n_stages, uint32_t repeat, double *seconds,
+                          swfr_path_timing *sum);
 
 /* Multi-GPU: copy this handle's band slab (its tile-rows, packed in order) into a caller-owned
    DEVICE buffer (e.g. a torch tensor's data_ptr) so that the caller can gather it with RCCL. */

@@ -26,7 +26,8 @@ EXPORTS = [
     "swfr_abi_version", "swfr_create", "swfr_destroy", "swfr_last_error", "swfr_register_shape",
     "swfr_register_morph_shape", "swfr_register_bitmap", "swfr_render", "swfr_render_batch", "swfr_read_image", "swfr_upload_edges",
     "swfr_render_resident", "swfr_render_edges", "swfr_build_frame", "swfr_shape_json", "swfr_last_timing",
-    "swfr_band_slab_bytes", "swfr_copy_band_slab", "swfr_device_framebuffer", "swfr_debug_copy",
+    "swfr_band_slab_bytes", "swfr_copy_band_slab", "swfr_device_framebuffer", "swfr_debug_copy", "swfr_last_path_timing",
+    "swfr_render_sequence",
 ]
 
 
@@ -126,6 +127,11 @@ class Timing(C.Structure):
                 ("n_records", C.c_uint64), ("timed_frames", C.c_uint32)]
 
 
+class PathTiming(C.Structure):
+    _fields_ = [("build_ms", C.c_double), ("upload_host_ms", C.c_double), ("h2d_ms", C.c_double), ("device_ms", C.c_double),
+                ("total_ms", C.c_double), ("h2d_bytes", C.c_uint64)]
+
+
 EDGE_DTYPE = np.dtype([(n, "<i4") for n in ("x1", "y1", "x2", "y2", "top", "bottom", "dir", "reserved")])
 PATH_DTYPE = np.dtype([("first_edge", "<u4"), ("n_edges", "<u4"), ("kind", "<u4"), ("fill_rule", "<u4"), ("style", "<u4"),
                        ("lerp", "<u4"), ("x_min", "<i4"), ("y_min", "<i4"), ("x_max", "<i4"), ("y_max", "<i4")])
@@ -185,6 +191,10 @@ def load_library():
     L.swfr_debug_copy.argtypes = [P, I, P, C.c_size_t]
     L.swfr_device_framebuffer.restype = P
     L.swfr_device_framebuffer.argtypes = [P]
+    L.swfr_last_path_timing.restype = I
+    L.swfr_last_path_timing.argtypes = [P, C.POINTER(PathTiming)]
+    L.swfr_render_sequence.restype = I
+    L.swfr_render_sequence.argtypes = [P, C.POINTER(Stage), U, U, C.POINTER(C.c_double), C.POINTER(PathTiming)]
     if L.swfr_abi_version() != 1:
         raise ImportError("libswfr.so ABI mismatch")
     _LIB = L
@@ -445,6 +455,20 @@ class Renderer:
         s = self._stage(arena, stage)
         self._check(self.L.swfr_render(self.h, C.byref(s)))
 
+    def render_sequence(self, stages, repeat=1):
+        """The reference's animation loop, timed below the C-ABI: `repeat` x (swfr_render of every stage in turn, each blocking).
+        Returns (seconds, dict of the per-frame times added up)."""
+        arena = _Arena()
+        arr = (Stage * max(len(stages), 1))(*[self._stage(arena, st) for st in stages])
+        secs, acc = C.c_double(), PathTiming()
+        self._check(self.L.swfr_render_sequence(self.h, arr, len(stages), int(repeat), C.byref(secs), C.byref(acc)))
+        return secs.value, {n: getattr(acc, n) for n, _ in PathTiming._fields_}
+
+    def path_timing(self) -> dict:
+        t = PathTiming()
+        self.L.swfr_last_path_timing(self.h, C.byref(t))
+        return {n: getattr(t, n) for n, _ in PathTiming._fields_}
+
     def render_batch(self, stages, device_ptr=None, frame_stride=0):
         """A batch of different frames in one call (e.g. the 256 ratios of a morph shape), pipelined over the handle's streams.
         Frame i lands at device_ptr + i * frame_stride (device memory: pass tensor.data_ptr()); without a destination only the
@@ -578,6 +602,7 @@ def polygons_to_scene(fixed_xy: np.ndarray, colors_rgba8: np.ndarray, width: int
         counts.append(c)
     edges = np.array(edge_rows, dtype=np.int32).view(EDGE_DTYPE).reshape(-1) if edge_rows else np.zeros(0, EDGE_DTYPE)
     counts = np.array(counts, dtype=np.uint32)
+    edges["reserved"] = np.repeat(np.arange(int((counts > 0).sum()), dtype=np.int32), counts[counts > 0])   # owning path (paths without edges are dropped below)
     paths = np.zeros(n, dtype=PATH_DTYPE)
     paths["first_edge"] = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.uint32)
     paths["n_edges"] = counts

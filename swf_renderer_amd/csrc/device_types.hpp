@@ -199,8 +199,13 @@ struct StripDesc {
 struct Frame2 {
     // the scene (read-only)
     const swfr_edge* raw; const DevPath* paths; const swfr_style* styles;
-    const ChunkInfo* chunks; const BandSlot* band_slots; const uint32_t* band_off; const StripDesc* strips;
     Sources src;
+    // layout of the tables below, from the paths' rectangles alone (host: prefix sums over the paths / the tile-rows)
+    const uint32_t* path_chunks; const uint32_t* path_slots; const uint32_t* path_inc;   // per path: first chunk, first band slot, first (edge, row) pair
+    const uint32_t* band_off;                                          // per tile-row: first entry of its band list
+    // binning, per frame in flight (kernel-written: k2_bin, k2_rows, k2_order)
+    ChunkInfo* chunks; BandSlot* band_slots; StripDesc* strips;
+    uint32_t* band_cnt; uint32_t* strip_cost;                          // strip_cost: zero between frames (k2_order clears what it has read)
     // per frame in flight (kernel-written)
     DevEdge* edges; BandEntry2* band_list; uint8_t* cls; RowInfo2* rows; Cell* cells; SlowRow* slow; SlowRow* huge; uint32_t* counters;
     uint32_t* path_flag; uint32_t* path_queue;     // paths with queued rows: their edges get start ranks (k2_start_ranks)
@@ -210,7 +215,10 @@ struct Frame2 {
     uint32_t band_index, band_count, fast_limit, any_shader, dbg;
     uint32_t cell_heads;     // (unused)
     uint32_t cell_main;      // cells [0, cell_main) belong to the chunk wavefronts of k2_rows, the rest to the slow rows' bump allocator
-    uint32_t pad[1];
+    uint32_t chunk_rows;     // pixel rows per k2_rows wavefront (16, 32 or 64)
+    uint32_t chunk_cap, slot_cap;   // capacities of chunks[] / band_slots[] and band_list[] (the host sizes them from the paths' rectangles)
+    uint32_t strip_order;    // 0: strips in row-major order, 1: heaviest first
+    uint32_t pad[2];
 };
 
 }  // namespace swfr

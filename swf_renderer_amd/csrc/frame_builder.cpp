@@ -203,7 +203,10 @@ void FrameBuilder::emit_polygon(Polygon& poly, bool rectilinear, uint32_t style,
         edges_.insert(edges_.end(), poly.edges().begin(), poly.edges().end());
     }
     p.n_edges = uint32_t(edges_.size()) - p.first_edge;
-    if (p.n_edges) paths_.push_back(p);
+    if (p.n_edges) {
+        for (uint32_t k = p.first_edge; k < p.first_edge + p.n_edges; ++k) edges_[k].reserved = int32_t(paths_.size());   // owning path: the device bins by it
+        paths_.push_back(p);
+    } else edges_.resize(p.first_edge);
 }
 
 void FrameBuilder::emit_fill(const OwnedFill& f, bool morph, double ratio) {
@@ -317,7 +320,7 @@ void FrameBuilder::emit_fill(const OwnedFill& f, bool morph, double ratio) {
     }
     if (x0 >= x1 || y0 >= y1) return;                   // nothing to do: surface stays clear
     const bool needs_clip = mask_w > x1 - x0 || mask_h > y1 - y0;
-    Polygon poly;
+    Polygon& poly = poly_;                            // (reused: its edge vector keeps its capacity from shape to shape)
     const Pt lo{fixed_t(x0) * 256, fixed_t(y0) * 256}, hi{fixed_t(x1) * 256, fixed_t(y1) * 256};  // the limits are the bounded rectangle
     poly.reset(needs_clip, lo, hi);
     if (needs_clip) fill_to_polygon_clipped(path_, poly, lo, hi); else fill_to_polygon(path_, poly);
@@ -364,7 +367,7 @@ void FrameBuilder::emit_stroke(const StyledPath& p, bool morph, double ratio) {
     // strokes are filled non-zero regardless of the configured fill rule
     const bool saved = even_odd_;
     even_odd_ = false;
-    Polygon poly;
+    Polygon& poly = poly_;
     bool done = false;
     if (path_.stroke_is_rectilinear()) {
         // Cairo's box stroker when it accepts the style: the union of one box per segment, painted like a rectilinear fill

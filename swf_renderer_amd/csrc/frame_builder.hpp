@@ -63,6 +63,7 @@ private:
     std::map<uint32_t, BitmapInfo> bitmaps_;
     std::vector<State> stack_;
     DevicePath path_;
+    Polygon poly_;
     bool surface_clear_ = true;
     std::vector<swfr_edge> edges_;
     std::vector<swfr_path> paths_;

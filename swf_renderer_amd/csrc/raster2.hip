@@ -3,7 +3,8 @@
 // Same arithmetic as raster_kernels.hip (Cairo's "tor" scan conversion; the row routines below are
 // the ones of that file with another output format), different data flow:
 //
-//   k2_front   per edge: scan-converter constants (A.5 make_edge); per (path, tile-row): the band entry; counters cleared
+//   k2_bin_a / _scan / _fill   binning on the device from the raw edge list: scan-converter constants per edge (A.5 make_edge),
+//              row chunks, band lists in painter's order, cell bases, the tile pass's launch list (heaviest strips first)
 //   k2_rows    one wavefront per (path, <= 64 pixel rows), lane = row: active edges, FULL / SUB decision, roles -- and then the
 //              row's CELLS {column, covered height, uncovered area}, i.e. Cairo's cell list itself (A.5 render_edge /
 //              add_subspan), densely packed per wavefront (one allocation per wavefront from eight bump allocators), plus the
@@ -106,7 +107,15 @@ __device__ __forceinline__ uint32_t alloc_cells(const Frame2& FR, uint32_t n, in
 }
 
 // ---------------------------------------------------------------------------------------------
-// k2_front
+// binning (per frame, on the device, from the raw edge list)
+//   k2_bin    one workgroup per tile-row: the paths that touch it, in painter's order (ordered compaction over the path list) ->
+//             band entries, (path, tile-row) -> entry table, class bytes of boxes paths; one thread per edge: the scan converter's
+//             constants (A.5 make_edge); one thread per path: its row chunks; counters cleared
+//   k2_rows   (below) also adds, per (tile, path) pair with a boundary in it, the boundary rows to the cost of the tile's strips
+//             ... and the last workgroup of k2_bin sorts the strips by the costs of the previous frame rendered with the same buffers
+//             (counting sort): the launch list of the tile pass, heaviest strips first
+// The host contributes the LAYOUT of the tables only -- prefix sums over the paths' rectangles (chunks, band slots) and row spans
+// (cells), and over the tile-rows (band list offsets): O(paths) additions, no per-row, per-edge-row or per-tile work.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ BandEntry2 make_band_entry2(const DevPath& P, uint32_t p, uint32_t band, const swfr_style* __restrict__ styles) {
     BandEntry2 e;
@@ -121,42 +130,152 @@ __device__ __forceinline__ BandEntry2 make_band_entry2(const DevPath& P, uint32_
     e.flags = fl | (band << 8); e.solid = pixel;
     return e;
 }
-// blocks [0, n_setup): one thread per edge; the rest: one thread per (path, tile-row) pair -- its band entry and, for a boxes
-// path (which has no rows for k2_rows to classify), the class bytes of its tiles
-__device__ __forceinline__ void front2_body(const Frame2& F, uint32_t n_setup_max) {
-    if (blockIdx.x == 0 && threadIdx.x < C2_WORDS) F.counters[threadIdx.x] = 0;
-    if (blockIdx.x < n_setup_max) {
-        const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-        if (i < F.n_paths) F.path_flag[i] = 0;
-        if (i >= F.n_edges) return;
-        const swfr_edge e = F.raw[i];
-        F.edges[i] = make_dev_edge(e, F.paths[e.reserved]);
+__device__ __forceinline__ bool path_has_area(const DevPath& P) { return P.y_max > P.y_min && P.x_max > P.x_min; }
+// first pixel row of a tor path's first chunk (chunks are whole tile-rows) and how many chunks it has
+__device__ __forceinline__ uint32_t path_chunk_count(const DevPath& P, uint32_t chunk_rows, uint32_t& a0) {
+    a0 = (uint32_t)P.y_min / TILE_H * TILE_H;
+    if (P.kind != SWFR_PATH_TOR || P.y_max <= P.y_min) return 0u;
+    return ((uint32_t)P.y_max - a0 + chunk_rows - 1) / chunk_rows;
+}
+constexpr uint32_t ORDER_BUCKETS = 128;
+__device__ __forceinline__ uint32_t order_bucket(uint32_t cost) { return ORDER_BUCKETS - 1 - min(cost / 2, ORDER_BUCKETS - 1); }   // bucket 0 = heaviest
+
+__device__ __forceinline__ void order_body(const Frame2& F);
+constexpr uint32_t BIN_THREADS = 1024;
+__device__ __forceinline__ void bin_body(const Frame2& F) {
+    __shared__ uint32_t wave_cnt[BIN_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (blockIdx.x == 0 && tid < C2_WORDS) F.counters[tid] = 0;
+    if (blockIdx.x == gridDim.x - 1) { order_body(F); return; }          // the last workgroup: the tile pass's launch list
+    if (blockIdx.x < F.n_bands) {
+        // ---- the paths that touch tile-row `band`, in painter's order
+        const int band = (int)blockIdx.x;
+        const uint32_t b0 = F.band_off[band], n_b = F.band_off[band + 1] - b0;
+        uint32_t n = 0;
+        for (uint32_t base = 0; base < F.n_paths && n < n_b; base += BIN_THREADS) {    // (workgroup-uniform: stops when the list is complete)
+            const uint32_t p = base + (uint32_t)tid;
+            bool hit = false;
+            DevPath P;
+            if (p < F.n_paths) { P = F.paths[p]; hit = path_has_area(P) && P.y_min / TILE_H <= band && band <= (P.y_max - 1) / TILE_H; }
+            const unsigned long long bal = __ballot(hit);
+            if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(bal);
+            __syncthreads();
+            uint32_t at = n;
+            for (int w = 0; w < wave; ++w) at += wave_cnt[w];
+            at += (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            if (hit && at < n_b) {
+                const uint32_t slot = b0 + at;
+                const BandEntry2 e = make_band_entry2(P, p, (uint32_t)band, F.styles);
+                F.band_list[slot] = e;
+                BandSlot bs; bs.path = p; bs.slot = slot; bs.band = (uint32_t)band; bs.pad = 0;
+                F.band_slots[F.path_slots[p] + (uint32_t)(band - P.y_min / TILE_H)] = bs;
+                if (P.kind == SWFR_PATH_BOXES) {
+                    uint8_t* out = F.cls + (size_t)F.tiles_x * b0 + at;
+                    const int ty0 = band * TILE_H, tile_y1 = min(ty0 + TILE_H, F.height);
+                    const uint32_t opq = (e.flags & BE_OPAQUE_COVER) ? CLS_OPAQUE : 0u;
+                    for (int tc = P.x_min / TILE_W; tc <= (P.x_max - 1) / TILE_W; ++tc) {
+                        const int tx0 = tc * TILE_W, tile_x1 = min(tx0 + TILE_W, F.width);
+                        uint32_t f = CLS_BOX | CLS_NONEMPTY | CLS_NOTFULL;
+                        if (P.n_edges == 1) {                     // one box that contains the whole tile: full cover
+                            const swfr_edge bx = F.raw[P.first_edge];
+                            if (bx.x1 <= tx0 * 256 && bx.x2 >= tile_x1 * 256 && bx.y1 <= ty0 * 256 && bx.y2 >= tile_y1 * 256) f = CLS_NONEMPTY | opq;
+                        }
+                        out[(size_t)tc * n_b] = (uint8_t)f;
+                    }
+                }
+            }
+            for (uint32_t w = 0; w < BIN_THREADS / 64; ++w) n += wave_cnt[w];
+            __syncthreads();
+        }
+        if (n != n_b && tid == 0) atomicOr(&F.counters[C2_ERROR], E2_ROW_TABLE);      // the host counted the same rectangles: cannot happen
         return;
     }
-    const uint32_t g = (blockIdx.x - n_setup_max) * 256 + threadIdx.x;
-    if (g >= F.n_slots) return;
-    const BandSlot bs = F.band_slots[g];
-    const DevPath P = F.paths[bs.path];
-    const BandEntry2 e = make_band_entry2(P, bs.path, bs.band, F.styles);
-    F.band_list[bs.slot] = e;
-    if (P.kind == SWFR_PATH_BOXES) {
-        const uint32_t b0 = F.band_off[bs.band], n_b = F.band_off[bs.band + 1] - b0;
-        uint8_t* out = F.cls + (size_t)F.tiles_x * b0 + (bs.slot - b0);
-        const int ty0 = (int)bs.band * TILE_H, tile_y1 = min(ty0 + TILE_H, F.height);
-        const uint32_t opq = (e.flags & BE_OPAQUE_COVER) ? CLS_OPAQUE : 0u;
-        for (int tc = P.x_min / TILE_W; tc <= (P.x_max - 1) / TILE_W; ++tc) {
-            const int tx0 = tc * TILE_W, tile_x1 = min(tx0 + TILE_W, F.width);
-            uint32_t f = CLS_BOX | CLS_NONEMPTY | CLS_NOTFULL;
-            if (P.n_edges == 1) {                     // one box that contains the whole tile: full cover
-                const swfr_edge bx = F.raw[P.first_edge];
-                if (bx.x1 <= tx0 * 256 && bx.x2 >= tile_x1 * 256 && bx.y1 <= ty0 * 256 && bx.y2 >= tile_y1 * 256) f = CLS_NONEMPTY | opq;
-            }
-            out[(size_t)tc * n_b] = (uint8_t)f;
+    const uint32_t i = (blockIdx.x - F.n_bands) * BIN_THREADS + (uint32_t)tid;       // (batched launches: a frame with fewer tile-rows leaves blocks idle)
+    // ---- one thread per edge: scan converter constants
+    if (i < F.n_edges) {
+        const swfr_edge e = F.raw[i];
+        F.edges[i] = make_dev_edge(e, F.paths[e.reserved]);
+    }
+    // ---- one thread per path: its chunk descriptors
+    if (i < F.n_paths) {
+        const DevPath P = F.paths[i];
+        F.path_flag[i] = 0;
+        uint32_t a0;
+        const uint32_t nc = path_chunk_count(P, F.chunk_rows, a0);
+        const uint32_t c0 = F.path_chunks[i], inc0 = F.path_inc[i];
+        const bool area = path_has_area(P);
+        for (uint32_t c = 0; c < nc; ++c) {
+            ChunkInfo ck;
+            ck.path = i; ck.first_row = a0 + c * F.chunk_rows; ck.rec_base = inc0; ck.rows = F.chunk_rows;
+            ck.slot0 = area ? F.path_slots[i] + (ck.first_row / TILE_H - (uint32_t)P.y_min / TILE_H) : ~0u;
+            ck.pad[0] = ck.pad[1] = ck.pad[2] = 0;
+            if (c0 + c < F.chunk_cap) F.chunks[c0 + c] = ck;
         }
     }
 }
-__global__ __launch_bounds__(256) void k2_front(const Frame2 FR, uint32_t n_setup_max) { front2_body(FR, n_setup_max); }
-__global__ __launch_bounds__(256) void k2_front_b(const Frame2* __restrict__ frames, uint32_t n_setup_max) { front2_body(frames[blockIdx.y], n_setup_max); }
+// the launch list of the tile pass: counting sort of the strips by the cost k2_rows added up during the PREVIOUS frame rendered with
+// these buffers (heaviest first; any order inside a bucket; a scheduling hint only -- a scene's first frame runs in row-major
+// order); the costs are cleared for this frame's k2_rows.  One 1024-thread workgroup, the last one of the k2_bin launch.
+#define ORDER_LDS_STRIPS 98304         // strips whose bucket numbers fit the workgroup's LDS (a 12288 x 8192 frame); larger frames re-read the costs
+__device__ __forceinline__ void order_body(const Frame2& F) {
+    __shared__ uint32_t bucket[ORDER_BUCKETS + 1];
+    __shared__ uint2 rowinfo[2048];                        // per tile-row of the handle: {first band list entry, entries}
+    __shared__ uint8_t bkt[ORDER_LDS_STRIPS];
+    const int tid = threadIdx.x;
+    const uint32_t n_strips = F.n_strips, bc = F.band_count > 1 ? F.band_count : 1, bi = F.band_count > 1 ? F.band_index : 0;
+    const uint32_t per_row = STRIPS_PER_TILE * (uint32_t)F.tiles_x;
+    const uint32_t n_local = n_strips / per_row;
+    const bool cached = n_strips <= ORDER_LDS_STRIPS;
+    for (uint32_t l = (uint32_t)tid; l < n_local && l < 2048u; l += 1024) {
+        const uint32_t trow = l * bc + bi, b0 = F.band_off[trow];
+        rowinfo[l] = make_uint2(b0, F.band_off[trow + 1] - b0);
+    }
+    if (F.strip_order) {
+        for (uint32_t b = (uint32_t)tid; b <= ORDER_BUCKETS; b += 1024) bucket[b] = 0;
+        lds_barrier();
+        // every cost is read once (four independent loads in flight per thread), its bucket number kept in LDS, the costs cleared
+        for (uint32_t w0 = (uint32_t)tid; w0 < n_strips; w0 += 4096) {
+            uint32_t c[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const uint32_t w = w0 + (uint32_t)u * 1024; c[u] = w < n_strips ? F.strip_cost[w] : 0u; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t w = w0 + (uint32_t)u * 1024;
+                if (w >= n_strips) continue;
+                const uint32_t k = order_bucket(c[u]);
+                atomicAdd(&bucket[k + 1], 1u);
+                if (cached) { bkt[w] = (uint8_t)k; F.strip_cost[w] = 0; }
+            }
+        }
+        lds_barrier();
+        if (tid < 64) {                                   // prefix of the 128 bucket sizes by one wavefront
+            uint32_t carry = 0;
+            for (uint32_t base = 0; base <= ORDER_BUCKETS; base += 64) {
+                const uint32_t b = base + (uint32_t)tid;
+                const uint32_t x = b <= ORDER_BUCKETS ? bucket[b] : 0u;
+                const uint32_t incl = (uint32_t)wave_scan_incl((int)x);
+                if (b <= ORDER_BUCKETS) bucket[b] = carry + incl;          // bucket[b] = first slot of bucket b (its size was stored at b + 1)
+                carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            }
+        }
+    }
+    lds_barrier();
+    for (uint32_t w = (uint32_t)tid; w < n_strips; w += 1024) {
+        uint32_t at = w;
+        if (F.strip_order) {
+            uint32_t k;
+            if (cached) k = bkt[w]; else { k = order_bucket(F.strip_cost[w]); F.strip_cost[w] = 0; }
+            at = atomicAdd(&bucket[k], 1u);
+        }
+        const uint32_t l = w / per_row;
+        uint2 ri;
+        if (l < 2048u) ri = rowinfo[l]; else { const uint32_t trow = l * bc + bi, b0 = F.band_off[trow]; ri = make_uint2(b0, F.band_off[trow + 1] - b0); }
+        StripDesc sd; sd.wg = w; sd.band_begin = ri.x; sd.n_b = ri.y; sd.pad = 0;
+        F.strips[at] = sd;
+    }
+}
+__global__ __launch_bounds__(1024) void k2_bin(const Frame2 FR) { bin_body(FR); }
+__global__ __launch_bounds__(1024) void k2_bin_b(const Frame2* __restrict__ frames) { bin_body(frames[blockIdx.y]); }
 
 // ---------------------------------------------------------------------------------------------
 // k2_rows
@@ -493,24 +612,28 @@ __device__ __forceinline__ void rows2_chunk_body(const Frame2& FR, uint32_t bloc
     const int lo_s = (int)ck.first_row * 15, hi_s = lo_s + chunk_rows * 15;
     uint32_t n_list = 0;
     bool use_lds = true;
+    int inc_before = 0;                                                  // (edge, pixel row) pairs of this path above the chunk: where its cells start
     for (uint32_t eb = 0; eb < P.n_edges; eb += 64) {
         const uint32_t k = eb + (uint32_t)lane;
         const DevEdge ek = FR.edges[P.first_edge + min(k, P.n_edges - 1u)];
-        const bool hit = k < P.n_edges && ek.ytop < hi_s && ek.ybot > lo_s;
+        const bool valid = k < P.n_edges && ek.ybot > ek.ytop;
+        if (valid) inc_before += max(0, min((ek.ybot - 1) / 15 + 1, (int)ck.first_row) - ek.ytop / 15);
+        const bool hit = use_lds && valid && ek.ytop < hi_s && ek.ybot > lo_s;
         const unsigned long long hb = __ballot(hit);
         const uint32_t at = n_list + (uint32_t)__popcll(hb & ((1ull << lane) - 1ull));
         if (hit && at < ROWS_STAGE) staged[at] = ek;
         n_list += (uint32_t)__popcll(hb);
-        if (n_list > ROWS_STAGE) { use_lds = false; break; }
+        if (n_list > ROWS_STAGE) use_lds = false;                        // (the loop goes on: every edge of the path counts for inc_before)
     }
+    const uint32_t chunk_cell_base = (ck.rec_base + (uint32_t)__builtin_amdgcn_readlane(wave_scan_incl(inc_before), 63)) * (uint32_t)MAX_CELLS_PER_EDGE_ROW;
     lds_barrier();
     R2PHASE(1);
     uint32_t mode; int n, nmax = ROWS_FAST_N; bool overflow, defer;
     int32_t roles[ROWS_FAST_N], cols[ROWS_FAST_N]; int el[ROWS_FAST_N];
     int32_t Q1[ROWS_FAST_N], Q2[ROWS_FAST_N]; int64_t R1[ROWS_FAST_N], R2[ROWS_FAST_N];
     int n_cells; uint32_t incl, base;
-    if (use_lds) rows2_fast((const DevEdge*)staged, n_list, P, r, live, fast_limit, F, S, lane, mode, n, overflow, defer, roles, cols, el, Q1, R1, Q2, R2, nmax, ri, FR, n_cells, incl, base, r2ph, r2ph_t, ck.rec_base * (uint32_t)MAX_CELLS_PER_EDGE_ROW);
-    else rows2_fast(FR.edges + P.first_edge, P.n_edges, P, r, live, fast_limit, F, S, lane, mode, n, overflow, defer, roles, cols, el, Q1, R1, Q2, R2, nmax, ri, FR, n_cells, incl, base, r2ph, r2ph_t, ck.rec_base * (uint32_t)MAX_CELLS_PER_EDGE_ROW);
+    if (use_lds) rows2_fast((const DevEdge*)staged, n_list, P, r, live, fast_limit, F, S, lane, mode, n, overflow, defer, roles, cols, el, Q1, R1, Q2, R2, nmax, ri, FR, n_cells, incl, base, r2ph, r2ph_t, chunk_cell_base);
+    else rows2_fast(FR.edges + P.first_edge, P.n_edges, P, r, live, fast_limit, F, S, lane, mode, n, overflow, defer, roles, cols, el, Q1, R1, Q2, R2, nmax, ri, FR, n_cells, incl, base, r2ph, r2ph_t, chunk_cell_base);
     const bool slow = live && (overflow || defer);
     // ---- FULL rows: cells of every boundary edge, densely packed behind the wavefront's allocation
     const bool emit = mode == ROW_FULL && ri != ~0u && !slow;
@@ -574,9 +697,10 @@ __device__ __forceinline__ void rows2_chunk_body(const Frame2& FR, uint32_t bloc
         for (int tc = tc0; tc <= tc1; ++tc) {                 // wave-uniform
             const int tx0 = tc * TILE_W, tile_x1 = min(tx0 + TILE_W, width);
             uint32_t f = 0;
+            bool row_partial = false;                                    // this lane's row has a boundary of the path in this tile
             if (in_frame) {
                 if (!in_rows) f = CLS_NOTFULL;
-                else if (slow) f = CLS_PARTIAL | CLS_NOTFULL | CLS_NONEMPTY;      // not known yet: the general route is always right
+                else if (slow) { f = CLS_PARTIAL | CLS_NOTFULL | CLS_NONEMPTY; row_partial = true; }      // not known yet: the general route is always right
                 else {
                     int carry = 0;
                     bool inter = false;
@@ -595,6 +719,7 @@ __device__ __forceinline__ void rows2_chunk_body(const Frame2& FR, uint32_t bloc
                     else if (a == 0) f = CLS_NOTFULL | CLS_HOLE;
                     else if (a == 255 && inside_x) f = CLS_NONEMPTY;
                     else f = CLS_PARTIAL | CLS_NOTFULL | CLS_NONEMPTY;
+                    row_partial = inter;
                 }
             }
             // OR over the tile-row's sixteen lanes (one DPP row): four rotations; every lane is active here
@@ -606,6 +731,16 @@ __device__ __forceinline__ void rows2_chunk_body(const Frame2& FR, uint32_t bloc
             f &= ~CLS_HOLE;
             if ((f & (CLS_PARTIAL | CLS_NOTFULL | CLS_NONEMPTY)) == CLS_NONEMPTY) f |= opq;        // a full cover that hides what lies below
             if ((lane & 15) == 0 && band_ok) out[(size_t)tc * n_b] = (uint8_t)f;
+            // the tile's strips get heavier by the rows of this path with a boundary in the tile (the tile pass starts its heaviest
+            // strips first): lanes 0 and 8 of the tile-row's sixteen add their half's rows
+            if (FR.strip_order) {
+                const unsigned long long pb = __ballot(row_partial);
+                if ((lane & 7) == 0 && band_ok && (f & CLS_PARTIAL) && (band_count <= 1 || (uint32_t)band % band_count == band_index)) {
+                    const uint32_t wgt = (uint32_t)__popcll((pb >> lane) & 0xffull);
+                    const uint32_t local_trow = band_count > 1 ? (uint32_t)band / band_count : (uint32_t)band;
+                    if (wgt) atomicAdd(&FR.strip_cost[((size_t)local_trow * FR.tiles_x + tc) * STRIPS_PER_TILE + ((lane >> 3) & 1)], wgt);
+                }
+            }
         }
     }
     R2PHASE(7);
@@ -1469,12 +1604,10 @@ __global__ __launch_bounds__(64) void k2_tiles_shaded_b(const Frame2* __restrict
 // ---------------------------------------------------------------------------------------------
 // launchers: `host` != nullptr: one frame, descriptor by value; else `frames` is a device array of n_frames descriptors
 // ---------------------------------------------------------------------------------------------
-void launch2_front(hipStream_t st, const Frame2* host, const Frame2* frames, uint32_t n_frames, uint32_t max_edges, uint32_t max_slots) {
-    uint32_t n_setup = (max_edges + 255) / 256;            // (max_edges: the larger of the edge and path counts, the setup threads also clear the path flags)
-    const uint32_t n_b = (max_slots + 255) / 256;
-    if (n_setup + n_b == 0) n_setup = 1;          // counters are still cleared
-    if (host) hipLaunchKernelGGL(k2_front, dim3(n_setup + n_b), dim3(256), 0, st, *host, n_setup);
-    else hipLaunchKernelGGL(k2_front_b, dim3(n_setup + n_b, n_frames), dim3(256), 0, st, frames, n_setup);
+void launch2_bin(hipStream_t st, const Frame2* host, const Frame2* frames, uint32_t n_frames, uint32_t max_edges_or_paths, uint32_t max_bands) {
+    const uint32_t g = max_bands + (max_edges_or_paths + BIN_THREADS - 1) / BIN_THREADS + 1;      // + the workgroup that orders the strips
+    if (host) hipLaunchKernelGGL(k2_bin, dim3(g), dim3(BIN_THREADS), 0, st, *host);
+    else hipLaunchKernelGGL(k2_bin_b, dim3(g, n_frames), dim3(BIN_THREADS), 0, st, frames);
 }
 void launch2_rows(hipStream_t st, const Frame2* host, const Frame2* frames, uint32_t n_frames, uint32_t max_chunks) {
     if (!max_chunks) return;

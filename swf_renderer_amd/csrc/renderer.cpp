@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
@@ -32,7 +33,7 @@ void launch_rows(hipStream_t, const DevEdge*, const DevPath*, const uint32_t*, c
                  const swfr_edge*, const swfr_style*, BandEntry*, const BigRow*, uint32_t);
 void launch_tiles(hipStream_t, const swfr_edge*, const uint32_t*, const BandEntry*, const uint8_t*, const RowInfo*, const Rec*, const swfr_style*,
                   Sources, uint32_t*, int, int, uint32_t, uint32_t, int, uint32_t*, uint32_t, uint32_t, bool, const uint32_t*);
-void launch2_front(hipStream_t, const Frame2*, const Frame2*, uint32_t, uint32_t, uint32_t);
+void launch2_bin(hipStream_t, const Frame2*, const Frame2*, uint32_t, uint32_t, uint32_t);
 void launch2_rows(hipStream_t, const Frame2*, const Frame2*, uint32_t, uint32_t);
 void launch2_rows_slow(hipStream_t, const Frame2*, const Frame2*, uint32_t, uint32_t, uint32_t, uint32_t);
 void launch2_tiles(hipStream_t, const Frame2*, const Frame2*, uint32_t, uint32_t, uint32_t, bool);
@@ -94,6 +95,7 @@ struct SceneArena {
     uint8_t* host = nullptr;
     size_t cap = 0, used = 0;
     hipEvent_t copied = nullptr;             // recorded behind the H2D: the staging buffer may be rewritten after it
+    hipEvent_t copy_begin = nullptr, copy_end = nullptr;   // timing of the copy (swfr_last_path_timing)
     void begin(size_t bytes) {
         if (copied) HIP_CHECK(hipEventSynchronize(copied));
         if (bytes > cap) {
@@ -115,16 +117,22 @@ struct SceneArena {
         used += padded(bytes);
         return d;
     }
-    void flush(hipStream_t st) {
+    void flush(hipStream_t st, bool timed = false) {
+        if (timed) {
+            if (!copy_begin) { HIP_CHECK(hipEventCreate(&copy_begin)); HIP_CHECK(hipEventCreate(&copy_end)); }
+            HIP_CHECK(hipEventRecord(copy_begin, st));
+        }
         if (used) HIP_CHECK(hipMemcpyAsync(dev, host, used, hipMemcpyHostToDevice, st));
+        if (timed) HIP_CHECK(hipEventRecord(copy_end, st));
         if (!copied) HIP_CHECK(hipEventCreateWithFlags(&copied, hipEventDisableTiming));
         HIP_CHECK(hipEventRecord(copied, st));
     }
     void release() {
         if (copied) (void)hipEventDestroy(copied);
+        if (copy_begin) { (void)hipEventDestroy(copy_begin); (void)hipEventDestroy(copy_end); }
         if (dev) (void)hipFree(dev);
         if (host) (void)hipHostFree(host);
-        dev = host = nullptr; copied = nullptr; cap = used = 0;
+        dev = host = nullptr; copied = nullptr; copy_begin = copy_end = nullptr; cap = used = 0;
     }
 };
 
@@ -182,18 +190,23 @@ struct swfr_renderer {
         DevBuf<Cell> d_cells;
         DevBuf<SlowRow> d_slow, d_huge;
         DevBuf<uint32_t> d_path_flag, d_path_queue;
+        DevBuf<ChunkInfo> d_chunks;
+        DevBuf<BandSlot> d_band_slots;
+        DevBuf<StripDesc> d_strips;
+        DevBuf<uint32_t> d_band_off, d_path_chunks, d_path_slots, d_path_inc, d_band_cnt, d_strip_cost;
         size_t cell_slice = 0, slow_cap = 0, cell_heads = 1;
     };
     FrameSet fs[4];
     DevBuf<DevBitmap> d_bitmap_table;
     DevBuf<uint32_t> d_tmp;
-    int in_flight = 2;
+    int in_flight = 3;
     uint32_t* fb_cur = nullptr;             // framebuffer of the last completed frame
     std::map<uint32_t, DeviceBitmap> bitmaps;
     std::vector<DevBitmap> bitmap_table;   // indexed by bitmap id
     bool bitmap_table_dirty = false, bitmap_table_dirty_copied = false;
     bool scene_ready = false, fb_valid = false;
     swfr_timing timing{};
+    swfr_path_timing path_timing{};
     int allow_fused = 2;                    // SWFR_FUSED_CLASS=0: always launch k_class (test knob)
     int force_chunk_rows = 0;               // SWFR_CHUNK_ROWS: test knob
     int strip_order = 1;                    // SWFR_STRIP_ORDER=0: launch the k_tiles wavefronts in row-major order
@@ -213,7 +226,8 @@ struct swfr_renderer {
             for (int k = 0; k < 4; ++k) {
                 FrameSet& x = fs[k];
                 x.d_edges.release(); x.d_band_list.release(); x.d_cls.release(); x.d_rows.release(); x.d_records.release(); x.d_counters.release(); x.d_fb.release();
-                x.d_band2.release(); x.d_rows2.release(); x.d_cells.release(); x.d_slow.release(); x.d_huge.release(); x.d_path_flag.release(); x.d_path_queue.release();
+                x.d_band2.release(); x.d_rows2.release(); x.d_cells.release(); x.d_slow.release(); x.d_huge.release(); x.d_path_flag.release(); x.d_path_queue.release(); x.d_chunks.release(); x.d_band_slots.release(); x.d_strips.release();
+                x.d_band_off.release(); x.d_path_chunks.release(); x.d_path_slots.release(); x.d_path_inc.release(); x.d_band_cnt.release(); x.d_strip_cost.release();
                 if (k > 0 && x.stream) (void)hipStreamDestroy(x.stream);
                 scn[k].arena.release();
             }
@@ -454,12 +468,190 @@ DevFilter good_filter(const swfr_style& st, const int rect[4], std::vector<int32
     return f;
 }
 
+// pixman's view of every bitmap / radial-gradient style of a scene (sample positions, filter tables, colour ramps)
+void prepare_sources(const swfr_path* paths, size_t n_paths, const swfr_style* styles, size_t n_styles, std::vector<DevFilter>& filters,
+                     std::vector<DevGradient>& gradients, std::vector<int32_t>& fparams) {
+    filters.assign(n_styles, DevFilter{});
+    // a bitmap style belongs to one drawing operation: pixman's transform is anchored at the centre of that operation's rectangle
+    std::vector<int> rect(4 * n_styles, 0);
+    std::vector<uint8_t> seen(n_styles, 0);
+    for (size_t i = 0; i < n_paths; ++i) {
+        const swfr_path& p = paths[i];
+        if (styles[p.style].kind != SWFR_STYLE_BITMAP && styles[p.style].kind != SWFR_STYLE_RADIAL) continue;
+        int* q = &rect[4 * size_t(p.style)];
+        if (seen[p.style] && (q[0] != p.x_min || q[1] != p.y_min || q[2] != p.x_max || q[3] != p.y_max))
+            throw StatusError{SWFR_ERR_INVALID, "paths that share a bitmap or radial-gradient style must share the pixel rectangle (one drawing operation)"};
+        seen[p.style] = 1;
+        q[0] = p.x_min; q[1] = p.y_min; q[2] = p.x_max; q[3] = p.y_max;
+    }
+    for (size_t i = 0; i < n_styles; ++i) {
+        filters[i] = good_filter(styles[i], &rect[4 * i], fparams);
+        if (styles[i].kind == SWFR_STYLE_RADIAL) {
+            gradients.push_back(radial_of(styles[i], &rect[4 * i]));
+            filters[i].pad = int32_t(gradients.size());            // index + 1 into the gradient table
+        }
+    }
+}
+
+// Pipeline 2: uploads a scene -- the raw edge list, the paths and the styles, nothing derived from them -- and sizes the buffers
+// the kernels write.  All binning (row chunks, band lists, cell bases, the tile pass's launch list) happens on the device, per
+// frame (k2_bin_a / _scan / _fill); the host only adds up, over the PATHS' rectangles, how large those tables get.
+int upload2(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, size_t n_edges, const swfr_path* paths, size_t n_paths,
+            const swfr_style* styles, size_t n_styles, uint32_t* fb_override, bool edges_tagged) {
+    swfr_renderer::Scene& sc = r->scn[si];
+    if (si == 0) r->scene_ready = false;
+    sc.slow_state = 0; sc.slow_passes = SLOW_PASSES;
+    if (si > 0 && !r->fs[si].stream) HIP_CHECK(hipStreamCreateWithFlags(&r->fs[si].stream, hipStreamNonBlocking));
+    const hipStream_t up_stream = r->fs[si].stream;
+    const uint32_t bc = r->cfg.band_count > 1 ? r->cfg.band_count : 1, bi = r->cfg.band_count > 1 ? r->cfg.band_index : 0;
+    const size_t n_bands = (r->height + TILE_H - 1) / TILE_H;
+    const uint32_t tiles_x = (r->width + TILE_W - 1) / TILE_W;
+    // ---- table sizes from the paths' rectangles (O(paths)); rows per k2_rows wavefront: 64 when that already gives the GPU a
+    //      thousand wavefronts, fewer (whole tile-rows) for scenes made of a few tall paths
+    uint32_t chunk_rows = ROWS_CHUNK;
+    size_t incidences = 0;
+    auto count_chunks = [&](uint32_t cr) {
+        size_t n = 0;
+        for (size_t i = 0; i < n_paths; ++i)
+            if (paths[i].kind == SWFR_PATH_TOR && paths[i].y_max > paths[i].y_min)
+                n += (size_t(paths[i].y_max) - size_t(paths[i].y_min) / TILE_H * TILE_H + cr - 1) / cr;
+        return n;
+    };
+    if (r->force_chunk_rows == 16 || r->force_chunk_rows == 32 || r->force_chunk_rows == 64) chunk_rows = uint32_t(r->force_chunk_rows);
+    else while (chunk_rows > uint32_t(TILE_H) && count_chunks(chunk_rows) < 1024) chunk_rows >>= 1;
+    size_t n_chunks = 0, n_slots = 0, n_rows = 0;
+    sc.any_shader = false;
+    for (size_t i = 0; i < n_styles; ++i) sc.any_shader = sc.any_shader || styles[i].kind != SWFR_STYLE_SOLID;
+    // layout of the device's tables: exclusive prefixes over the paths (first chunk, first band slot) and over the tile-rows (band
+    // list offsets, by a difference array over the paths' tile-row ranges)
+    std::vector<uint32_t> chunk_base(n_paths + 1), slot_base(n_paths + 1), inc_base(n_paths + 1, 0), band_off(n_bands + 2, 0);
+    for (size_t i = 0; i < n_paths; ++i) {
+        const swfr_path& p = paths[i];
+        chunk_base[i] = uint32_t(n_chunks); slot_base[i] = uint32_t(n_slots);
+        if (p.kind == SWFR_PATH_TOR && p.y_max > p.y_min) n_chunks += (size_t(p.y_max) - size_t(p.y_min) / TILE_H * TILE_H + chunk_rows - 1) / chunk_rows;
+        if (p.y_max > p.y_min && p.x_max > p.x_min) {
+            const size_t b0 = size_t(p.y_min / TILE_H), b1 = size_t((p.y_max - 1) / TILE_H);
+            n_slots += b1 - b0 + 1;
+            ++band_off[b0 + 1]; --band_off[b1 + 2];
+        }
+        if (p.kind == SWFR_PATH_TOR) n_rows += size_t(p.y_max - p.y_min);
+    }
+    chunk_base[n_paths] = uint32_t(n_chunks); slot_base[n_paths] = uint32_t(n_slots);
+    for (size_t b = 1; b <= n_bands + 1; ++b) band_off[b] += band_off[b - 1];       // difference array -> counts, shifted by one
+    for (size_t b = 1; b <= n_bands + 1; ++b) band_off[b] += band_off[b - 1];       // counts -> exclusive prefix: band_off[b] = entries of tile-rows < b
+    // ---- the edges, tagged with their path, and a bound on the (edge, pixel row) pairs (every pair yields at most
+    //      MAX_CELLS_PER_EDGE_ROW cells): one pass over the edge list, the same pass that copies it into the staging buffer
+    sc.n_edges = n_edges; sc.n_paths = n_paths; sc.n_styles = n_styles;
+    sc.n_chunks = n_chunks; sc.chunk_rows = chunk_rows; sc.n_bands = n_bands; sc.n_band_entries = n_slots; sc.n_tasks = n_rows;
+    sc.n_strips = size_t(local_tile_rows(r)) * tiles_x * STRIPS_PER_TILE;
+    sc.has_order = r->strip_order != 0;
+    std::vector<DevFilter> filters;
+    std::vector<DevGradient> gradients;
+    std::vector<int32_t> fparams;
+    prepare_sources(paths, n_paths, styles, n_styles, filters, gradients, fparams);
+    SceneArena& A = sc.arena;
+    auto P = SceneArena::padded;
+    A.begin(P(n_edges * sizeof(swfr_edge)) + P(n_paths * sizeof(swfr_path)) + P(n_styles * sizeof(swfr_style)) + P(n_styles * sizeof(DevFilter)) +
+            P(fparams.size() * sizeof(int32_t)) + P(gradients.size() * sizeof(DevGradient)) + P(4 * sizeof(Frame2)) + 3 * P((n_paths + 1) * sizeof(uint32_t)) +
+            P((n_bands + 2) * sizeof(uint32_t)) + 4096);
+    swfr_edge* staged = reinterpret_cast<swfr_edge*>(A.host + A.used);
+    sc.raw = static_cast<swfr_edge*>(A.push(edges, n_edges * sizeof(swfr_edge)));
+    if (!edges_tagged)
+        for (size_t i = 0; i < n_paths; ++i)
+            for (uint32_t k = 0; k < paths[i].n_edges; ++k) staged[paths[i].first_edge + k].reserved = int32_t(i);
+    for (size_t i = 0; i < n_edges; ++i) {              // pixel rows an edge can have a sample row in (a bound: +1 for the rounding of the sample grid)
+        const swfr_edge& e = staged[i];
+        const swfr_path& p = paths[e.reserved];
+        if (p.kind != SWFR_PATH_TOR) continue;
+        const int64_t top = std::max<int64_t>(e.top, int64_t(p.y_min) * 256), bot = std::min<int64_t>(e.bottom, int64_t(p.y_max) * 256);
+        if (bot > top) inc_base[size_t(e.reserved) + 1] += uint32_t(((bot + 255) >> 8) - (top >> 8)) + 1;
+    }
+    for (size_t i = 0; i < n_paths; ++i) inc_base[i + 1] += inc_base[i];
+    incidences = inc_base[n_paths];
+    sc.n_incidences = incidences;
+    sc.paths = static_cast<DevPath*>(A.push(paths, n_paths * sizeof(swfr_path)));
+    sc.styles = static_cast<swfr_style*>(A.push(styles, n_styles * sizeof(swfr_style)));
+    sc.filters = static_cast<DevFilter*>(A.push(filters.data(), n_styles * sizeof(DevFilter)));
+    sc.filter_params = static_cast<int32_t*>(A.push(fparams.data(), fparams.size() * sizeof(int32_t)));
+    sc.gradients = static_cast<DevGradient*>(A.push(gradients.data(), gradients.size() * sizeof(DevGradient)));
+    const uint32_t* d_chunk_base = static_cast<uint32_t*>(A.push(chunk_base.data(), (n_paths + 1) * sizeof(uint32_t)));
+    const uint32_t* d_slot_base = static_cast<uint32_t*>(A.push(slot_base.data(), (n_paths + 1) * sizeof(uint32_t)));
+    const uint32_t* d_inc_base = static_cast<uint32_t*>(A.push(inc_base.data(), (n_paths + 1) * sizeof(uint32_t)));
+    const uint32_t* d_band_off = static_cast<uint32_t*>(A.push(band_off.data(), (n_bands + 2) * sizeof(uint32_t)));
+    // ---- per-frame (kernel-written) buffers: grow-only allocations; the tables the binning kernels accumulate into are zero
+    //      between frames (the kernels clear what they have read), so a fresh allocation is cleared once
+    const int n_sets = std::max(1, std::min(r->in_flight, 4));
+    auto reserve_zeroed = [&](DevBuf<uint32_t>& b, size_t n) {
+        const uint32_t* before = b.ptr;
+        b.reserve(n);
+        if (b.ptr != before) HIP_CHECK(hipMemsetAsync(b.ptr, 0, b.cap * sizeof(uint32_t), up_stream));
+    };
+    const size_t cell_main = incidences * MAX_CELLS_PER_EDGE_ROW, cell_total = cell_main * 2 + 4096;
+    if (cell_total > 0xfffffff0ull) throw StatusError{SWFR_ERR_CAPACITY, "scene too large for 32-bit cell offsets"};
+    for (int k = 0; k < 4; ++k) {
+        if (all_sets ? k >= n_sets : k != si) continue;
+        auto& x = r->fs[k];
+        if (!x.stream) HIP_CHECK(hipStreamCreateWithFlags(&x.stream, hipStreamNonBlocking));
+        x.d_edges.reserve(n_edges); x.d_band2.reserve(n_slots); x.d_rows2.reserve(n_slots * TILE_H + 64); x.d_cells.reserve(cell_total);
+        x.d_slow.reserve(2 * (n_rows + 64)); x.d_huge.reserve(2 * (n_rows + 64));
+        x.d_path_flag.reserve(n_paths + 64); x.d_path_queue.reserve(n_paths + 64);
+        x.d_chunks.reserve(n_chunks + 1); x.d_band_slots.reserve(n_slots + 1); x.d_strips.reserve(sc.n_strips + 1);
+        reserve_zeroed(x.d_strip_cost, sc.n_strips + 1);
+        x.cell_slice = cell_total; x.slow_cap = n_rows + 64;
+        x.d_counters.reserve(COUNTER_WORDS);
+        x.d_cls.reserve(n_slots * tiles_x + 64);
+        // class bytes outside the paths' rectangles are never written by a kernel: cleared once per uploaded scene
+        HIP_CHECK(hipMemsetAsync(x.d_cls.ptr, 0, n_slots * tiles_x + 64, up_stream));
+        if (!x.d_fb.ptr) {
+            x.d_fb.reserve(size_t(r->width) * r->height);
+            HIP_CHECK(hipMemsetAsync(x.d_fb.ptr, 0, size_t(r->width) * r->height * 4, up_stream));
+        }
+    }
+    if (r->bitmap_table_dirty) r->d_bitmap_table.reserve(r->bitmap_table.size());     // (filled below; the address is what the descriptor needs)
+    Frame2 fr[4];
+    std::memset(fr, 0, sizeof fr);
+    for (int k = 0; k < 4; ++k) {
+        if (all_sets ? k >= n_sets : k != si) continue;
+        auto& x = r->fs[k];
+        Frame2& f = fr[k];
+        f.raw = sc.raw; f.paths = sc.paths; f.styles = sc.styles;
+        f.src = Sources{r->d_bitmap_table.ptr, sc.filters, sc.filter_params, sc.gradients};
+        f.chunks = x.d_chunks.ptr; f.band_slots = x.d_band_slots.ptr; f.band_off = d_band_off; f.strips = x.d_strips.ptr;
+        f.path_chunks = d_chunk_base; f.path_slots = d_slot_base; f.path_inc = d_inc_base;
+        f.band_cnt = nullptr; f.strip_cost = x.d_strip_cost.ptr;
+        f.edges = x.d_edges.ptr; f.band_list = x.d_band2.ptr; f.cls = x.d_cls.ptr; f.rows = x.d_rows2.ptr; f.cells = x.d_cells.ptr;
+        f.slow = x.d_slow.ptr; f.huge = x.d_huge.ptr; f.counters = x.d_counters.ptr;
+        f.path_flag = x.d_path_flag.ptr; f.path_queue = x.d_path_queue.ptr;
+        f.fb = (fb_override && k == si) ? fb_override : x.d_fb.ptr;
+        f.n_edges = uint32_t(n_edges); f.n_paths = uint32_t(n_paths); f.n_chunks = uint32_t(n_chunks); f.n_slots = uint32_t(n_slots);
+        f.n_bands = uint32_t(n_bands); f.n_strips = uint32_t(sc.n_strips); f.cell_slice = uint32_t(cell_total); f.slow_cap = uint32_t(x.slow_cap);
+        f.width = int32_t(r->width); f.height = int32_t(r->height); f.tiles_x = int32_t(tiles_x);
+        f.band_index = bi; f.band_count = bc; f.fast_limit = uint32_t(std::min(std::max(r->fast_limit, 0), 8)); f.any_shader = sc.any_shader ? 1u : 0u;
+        f.dbg = uint32_t(r->tiles_dbg); f.cell_heads = 1; f.cell_main = uint32_t(cell_main);
+        f.chunk_rows = chunk_rows; f.chunk_cap = uint32_t(n_chunks + 1); f.slot_cap = uint32_t(n_slots + 1); f.strip_order = r->strip_order ? 1u : 0u;
+    }
+    sc.frames_dev = static_cast<Frame2*>(A.push(fr, sizeof fr));
+    std::memcpy(sc.frames_host, fr, sizeof fr);
+    A.flush(up_stream, si == 0 && all_sets);
+    if (r->bitmap_table_dirty) {
+        if (!r->bitmap_table.empty())
+            HIP_CHECK(hipMemcpyAsync(r->d_bitmap_table.ptr, r->bitmap_table.data(), r->bitmap_table.size() * sizeof(DevBitmap),
+                                     hipMemcpyHostToDevice, r->stream));
+        r->bitmap_table_dirty = false;
+        r->bitmap_table_dirty_copied = true;
+    }
+    if (r->bitmap_table_dirty_copied) { HIP_CHECK(hipStreamSynchronize(r->stream)); r->bitmap_table_dirty_copied = false; }   // bitmap_table may be edited next
+    if (si == 0) r->scene_ready = true;
+    return SWFR_OK;
+}
+
 // Uploads a scene into scene slot `si` (H2D on frame set `si`'s stream) and sizes the kernel-written buffers: of every frame
 // set in flight (`all_sets`, resident rendering: the sets share scene 0) or of set `si` only (batch rendering: one scene per set).
 int upload(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, size_t n_edges, const swfr_path* paths, size_t n_paths,
            const swfr_style* styles, size_t n_styles, uint32_t* fb_override = nullptr) {
     if (!r->has_device) return fail(r, SWFR_ERR_NO_DEVICE, "host-only handle cannot rasterize");
     validate_scene(r, edges, n_edges, paths, n_paths, styles, n_styles);
+    if (r->pipeline == 2) return upload2(r, si, all_sets, edges, n_edges, paths, n_paths, styles, n_styles, fb_override, false);
     swfr_renderer::Scene& sc = r->scn[si];
     if (si == 0) r->scene_ready = false;
     sc.slow_state = 0; sc.slow_passes = SLOW_PASSES;
@@ -643,30 +835,10 @@ int upload(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, size
         if (!x.stream) HIP_CHECK(hipStreamCreateWithFlags(&x.stream, hipStreamNonBlocking));
     }
     // the scene's read-only arrays: one pinned staging buffer, one H2D copy, views into one device arena
-    std::vector<DevFilter> filters(n_styles);
+    std::vector<DevFilter> filters;
     std::vector<DevGradient> gradients;
     std::vector<int32_t> fparams;
-    {
-        // a bitmap style belongs to one drawing operation: pixman's transform is anchored at the centre of that operation's rectangle
-        std::vector<int> rect(4 * n_styles, 0);
-        std::vector<uint8_t> seen(n_styles, 0);
-        for (size_t i = 0; i < n_paths; ++i) {
-            const swfr_path& p = paths[i];
-            if (styles[p.style].kind != SWFR_STYLE_BITMAP && styles[p.style].kind != SWFR_STYLE_RADIAL) continue;
-            int* q = &rect[4 * size_t(p.style)];
-            if (seen[p.style] && (q[0] != p.x_min || q[1] != p.y_min || q[2] != p.x_max || q[3] != p.y_max))
-                throw StatusError{SWFR_ERR_INVALID, "paths that share a bitmap or radial-gradient style must share the pixel rectangle (one drawing operation)"};
-            seen[p.style] = 1;
-            q[0] = p.x_min; q[1] = p.y_min; q[2] = p.x_max; q[3] = p.y_max;
-        }
-        for (size_t i = 0; i < n_styles; ++i) {
-            filters[i] = good_filter(styles[i], &rect[4 * i], fparams);
-            if (styles[i].kind == SWFR_STYLE_RADIAL) {
-                gradients.push_back(radial_of(styles[i], &rect[4 * i]));
-                filters[i].pad = int32_t(gradients.size());            // index + 1 into the gradient table
-            }
-        }
-    }
+    prepare_sources(paths, n_paths, styles, n_styles, filters, gradients, fparams);
     sc.has_order = !order.empty();
     // the launch list of the tile pass: every strip of this handle's tile-rows with its tile-row's slice of the band list
     std::vector<StripDesc> strips;
@@ -747,7 +919,7 @@ void launch_frame(swfr_renderer* r, const swfr_renderer::Scene& sc, swfr_rendere
         // the frame's descriptor (scene arrays, this set's buffers, the framebuffer) was written with the scene
         const Frame2* fh = &sc.frames_host[&F - r->fs];
         if (e) HIP_CHECK(hipEventRecord(e[0], st));
-        launch2_front(st, fh, nullptr, 1, uint32_t(std::max(sc.n_edges, sc.n_paths)), uint32_t(sc.n_band_entries));
+        launch2_bin(st, fh, nullptr, 1, uint32_t(std::max(sc.n_edges, sc.n_paths)), uint32_t(sc.n_bands));
         if (e) HIP_CHECK(hipEventRecord(e[1], st));
         launch2_rows(st, fh, nullptr, 1, uint32_t(sc.n_chunks));
         // the queued rows (coincident edges, crowded rows): skipped once a frame of this resident scene has shown there are none
@@ -929,7 +1101,10 @@ int render_batch(swfr_renderer* r, const swfr_stage* stages, uint32_t n, void* d
             const auto& p = r->builder->paths();
             const auto& s = r->builder->styles();
             uint32_t* fb_dst = device_dst ? reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(device_dst) + size_t(i) * frame_stride) : nullptr;
-            rc = upload(r, k, false, e.data(), e.size(), p.data(), p.size(), s.data(), s.size(), fb_dst);
+            if (r->pipeline == 2) {
+                validate_scene(r, e.data(), e.size(), p.data(), p.size(), s.data(), s.size());
+                rc = upload2(r, k, false, e.data(), e.size(), p.data(), p.size(), s.data(), s.size(), fb_dst, true);
+            } else rc = upload(r, k, false, e.data(), e.size(), p.data(), p.size(), s.data(), s.size(), fb_dst);
             if (rc != SWFR_OK) break;
             swfr_renderer::FrameSet& F = r->fs[k];
             if (k > 0 && i < n_sets) HIP_CHECK(hipStreamSynchronize(r->stream));   // first use of the set: bitmap table etc. are in place
@@ -1092,14 +1267,55 @@ int swfr_render(swfr_renderer* r, const swfr_stage* stage) {
     if (!r || !stage) return fail(r, SWFR_ERR_INVALID, "null argument");
     if (!r->has_device) return fail(r, SWFR_ERR_NO_DEVICE, "host-only handle cannot rasterize");
     return guarded(r, [&]() {
+        using clk = std::chrono::steady_clock;
+        auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        const auto t0 = clk::now();
         r->builder->build(*stage);
+        const auto t1 = clk::now();
         const auto& e = r->builder->edges();
         const auto& p = r->builder->paths();
         const auto& s = r->builder->styles();
-        const int rc = upload(r, 0, true, e.data(), e.size(), p.data(), p.size(), s.data(), s.size());
+        int rc;
+        if (r->pipeline == 2) {                             // (the builder's edges carry their path index already)
+            validate_scene(r, e.data(), e.size(), p.data(), p.size(), s.data(), s.size());
+            rc = upload2(r, 0, true, e.data(), e.size(), p.data(), p.size(), s.data(), s.size(), nullptr, true);
+        } else rc = upload(r, 0, true, e.data(), e.size(), p.data(), p.size(), s.data(), s.size());
+        const auto t2 = clk::now();
         if (rc != SWFR_OK) return rc;
-        return render_resident(r, 1);
+        rc = render_resident(r, 1);
+        const auto t3 = clk::now();
+        swfr_path_timing& pt = r->path_timing;
+        pt.build_ms = ms(t0, t1); pt.upload_host_ms = ms(t1, t2); pt.device_ms = r->timing.total_ms; pt.total_ms = ms(t0, t3);
+        pt.h2d_bytes = r->scn[0].arena.used; pt.h2d_ms = 0;
+        if (r->pipeline == 2 && r->scn[0].arena.copy_begin) {
+            float h = 0;
+            if (hipEventElapsedTime(&h, r->scn[0].arena.copy_begin, r->scn[0].arena.copy_end) == hipSuccess) pt.h2d_ms = h;
+        }
+        return rc;
     });
+}
+
+int swfr_last_path_timing(swfr_renderer* r, swfr_path_timing* out) {
+    if (!r || !out) return SWFR_ERR_INVALID;
+    *out = r->path_timing;
+    return SWFR_OK;
+}
+
+int swfr_render_sequence(swfr_renderer* r, const swfr_stage* stages, uint32_t n_stages, uint32_t repeat, double* seconds, swfr_path_timing* sum) {
+    if (!r || (!stages && n_stages) || !seconds) return fail(r, SWFR_ERR_INVALID, "null argument");
+    swfr_path_timing acc{};
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t rep = 0; rep < repeat; ++rep)
+        for (uint32_t i = 0; i < n_stages; ++i) {
+            const int rc = swfr_render(r, &stages[i]);
+            if (rc != SWFR_OK) return rc;
+            const swfr_path_timing& pt = r->path_timing;
+            acc.build_ms += pt.build_ms; acc.upload_host_ms += pt.upload_host_ms; acc.h2d_ms += pt.h2d_ms; acc.device_ms += pt.device_ms;
+            acc.total_ms += pt.total_ms; acc.h2d_bytes += pt.h2d_bytes;
+        }
+    *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (sum) *sum = acc;
+    return SWFR_OK;
 }
 
 int swfr_render_batch(swfr_renderer* r, const swfr_stage* stages, uint32_t n_stages, void* device_dst, size_t frame_stride) {
