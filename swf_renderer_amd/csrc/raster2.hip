@@ -16,7 +16,8 @@
 //              stream -> LDS accumulators -> wave64 prefix sum -> alpha -> shade -> blend in registers -> one store per pixel.
 //              No edge arithmetic, no 64-bit or floating-point instruction on the solid-colour path.
 //
-// Every kernel takes an array of frame descriptors and blockIdx.y picks the frame: a batch of frames is one launch per kernel.
+// Every kernel takes an array of frame descriptors (device memory) and blockIdx.y picks the frame: a batch of frames is one launch
+// per kernel.
 #include "raster_kernels.hip"
 
 namespace swfr {
@@ -32,6 +33,17 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 #endif
 }
+
+// Kernels get their frame's descriptor as the blockIdx.y-th element of an array in device memory and read its fields through the
+// constant address space: wave-uniform scalar loads, issued where a field is first needed, like those of kernel arguments (through
+// a plain pointer the compiler uses vector loads and every field costs a vector register).
+#ifdef SWFR_EMU
+typedef const Frame2* FramePtr;
+#define FRAME_PTR(frames, i) ((frames) + (i))
+#else
+typedef const Frame2 __attribute__((address_space(4)))* FramePtr;
+#define FRAME_PTR(frames, i) ((FramePtr)((frames) + (i)))
+#endif
 
 #define CLS_OPAQUE 32u                // the path is an opaque solid blended with the lerp rule: a full cover of it hides what lies below
 
@@ -96,12 +108,12 @@ __device__ __forceinline__ void sub_cell(Cell* __restrict__ dst, int x, int sgn,
 }
 // `n` cells for the calling wavefront of a slow-row kernel (one lane allocates; every lane gets the base): a bump allocator over the
 // part of the frame's arena behind the chunk wavefronts' region.  ~0u when it is full (the frame then fails loudly).
-__device__ __forceinline__ uint32_t alloc_cells(const Frame2& FR, uint32_t n, int lane) {
+__device__ __forceinline__ uint32_t alloc_cells(FramePtr FR, uint32_t n, int lane) {
     uint32_t base = 0;
     if (lane == 0 && n) {
-        const uint32_t old = atomicAdd(&FR.counters[C2_HEAD], n);
-        base = FR.cell_main + old;
-        if ((uint64_t)base + n > FR.cell_slice) { atomicOr(&FR.counters[C2_ERROR], E2_CELL_ARENA); base = ~0u; }
+        const uint32_t old = atomicAdd(&FR->counters[C2_HEAD], n);
+        base = FR->cell_main + old;
+        if ((uint64_t)base + n > FR->cell_slice) { atomicOr(&FR->counters[C2_ERROR], E2_CELL_ARENA); base = ~0u; }
     }
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
 }
@@ -140,23 +152,23 @@ __device__ __forceinline__ uint32_t path_chunk_count(const DevPath& P, uint32_t 
 constexpr uint32_t ORDER_BUCKETS = 128;
 __device__ __forceinline__ uint32_t order_bucket(uint32_t cost) { return ORDER_BUCKETS - 1 - min(cost / 2, ORDER_BUCKETS - 1); }   // bucket 0 = heaviest
 
-__device__ __forceinline__ void order_body(const Frame2& F);
+__device__ __forceinline__ void order_body(FramePtr F);
 constexpr uint32_t BIN_THREADS = 1024;
-__device__ __forceinline__ void bin_body(const Frame2& F) {
+__device__ __forceinline__ void bin_body(FramePtr F) {
     __shared__ uint32_t wave_cnt[BIN_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (blockIdx.x == 0 && tid < C2_WORDS) F.counters[tid] = 0;
+    if (blockIdx.x == 0 && tid < C2_WORDS) F->counters[tid] = 0;
     if (blockIdx.x == gridDim.x - 1) { order_body(F); return; }          // the last workgroup: the tile pass's launch list
-    if (blockIdx.x < F.n_bands) {
+    if (blockIdx.x < F->n_bands) {
         // ---- the paths that touch tile-row `band`, in painter's order
         const int band = (int)blockIdx.x;
-        const uint32_t b0 = F.band_off[band], n_b = F.band_off[band + 1] - b0;
+        const uint32_t b0 = F->band_off[band], n_b = F->band_off[band + 1] - b0;
         uint32_t n = 0;
-        for (uint32_t base = 0; base < F.n_paths && n < n_b; base += BIN_THREADS) {    // (workgroup-uniform: stops when the list is complete)
+        for (uint32_t base = 0; base < F->n_paths && n < n_b; base += BIN_THREADS) {    // (workgroup-uniform: stops when the list is complete)
             const uint32_t p = base + (uint32_t)tid;
             bool hit = false;
             DevPath P;
-            if (p < F.n_paths) { P = F.paths[p]; hit = path_has_area(P) && P.y_min / TILE_H <= band && band <= (P.y_max - 1) / TILE_H; }
+            if (p < F->n_paths) { P = F->paths[p]; hit = path_has_area(P) && P.y_min / TILE_H <= band && band <= (P.y_max - 1) / TILE_H; }
             const unsigned long long bal = __ballot(hit);
             if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(bal);
             __syncthreads();
@@ -165,19 +177,19 @@ __device__ __forceinline__ void bin_body(const Frame2& F) {
             at += (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
             if (hit && at < n_b) {
                 const uint32_t slot = b0 + at;
-                const BandEntry2 e = make_band_entry2(P, p, (uint32_t)band, F.styles);
-                F.band_list[slot] = e;
+                const BandEntry2 e = make_band_entry2(P, p, (uint32_t)band, F->styles);
+                F->band_list[slot] = e;
                 BandSlot bs; bs.path = p; bs.slot = slot; bs.band = (uint32_t)band; bs.pad = 0;
-                F.band_slots[F.path_slots[p] + (uint32_t)(band - P.y_min / TILE_H)] = bs;
+                F->band_slots[F->path_slots[p] + (uint32_t)(band - P.y_min / TILE_H)] = bs;
                 if (P.kind == SWFR_PATH_BOXES) {
-                    uint8_t* out = F.cls + (size_t)F.tiles_x * b0 + at;
-                    const int ty0 = band * TILE_H, tile_y1 = min(ty0 + TILE_H, F.height);
+                    uint8_t* out = F->cls + (size_t)F->tiles_x * b0 + at;
+                    const int ty0 = band * TILE_H, tile_y1 = min(ty0 + TILE_H, F->height);
                     const uint32_t opq = (e.flags & BE_OPAQUE_COVER) ? CLS_OPAQUE : 0u;
                     for (int tc = P.x_min / TILE_W; tc <= (P.x_max - 1) / TILE_W; ++tc) {
-                        const int tx0 = tc * TILE_W, tile_x1 = min(tx0 + TILE_W, F.width);
+                        const int tx0 = tc * TILE_W, tile_x1 = min(tx0 + TILE_W, F->width);
                         uint32_t f = CLS_BOX | CLS_NONEMPTY | CLS_NOTFULL;
                         if (P.n_edges == 1) {                     // one box that contains the whole tile: full cover
-                            const swfr_edge bx = F.raw[P.first_edge];
+                            const swfr_edge bx = F->raw[P.first_edge];
                             if (bx.x1 <= tx0 * 256 && bx.x2 >= tile_x1 * 256 && bx.y1 <= ty0 * 256 && bx.y2 >= tile_y1 * 256) f = CLS_NONEMPTY | opq;
                         }
                         out[(size_t)tc * n_b] = (uint8_t)f;
@@ -187,29 +199,29 @@ __device__ __forceinline__ void bin_body(const Frame2& F) {
             for (uint32_t w = 0; w < BIN_THREADS / 64; ++w) n += wave_cnt[w];
             __syncthreads();
         }
-        if (n != n_b && tid == 0) atomicOr(&F.counters[C2_ERROR], E2_ROW_TABLE);      // the host counted the same rectangles: cannot happen
+        if (n != n_b && tid == 0) atomicOr(&F->counters[C2_ERROR], E2_ROW_TABLE);      // the host counted the same rectangles: cannot happen
         return;
     }
-    const uint32_t i = (blockIdx.x - F.n_bands) * BIN_THREADS + (uint32_t)tid;       // (batched launches: a frame with fewer tile-rows leaves blocks idle)
+    const uint32_t i = (blockIdx.x - F->n_bands) * BIN_THREADS + (uint32_t)tid;       // (batched launches: a frame with fewer tile-rows leaves blocks idle)
     // ---- one thread per edge: scan converter constants
-    if (i < F.n_edges) {
-        const swfr_edge e = F.raw[i];
-        F.edges[i] = make_dev_edge(e, F.paths[e.reserved]);
+    if (i < F->n_edges) {
+        const swfr_edge e = F->raw[i];
+        F->edges[i] = make_dev_edge(e, F->paths[e.reserved]);
     }
     // ---- one thread per path: its chunk descriptors
-    if (i < F.n_paths) {
-        const DevPath P = F.paths[i];
-        F.path_flag[i] = 0;
+    if (i < F->n_paths) {
+        const DevPath P = F->paths[i];
+        F->path_flag[i] = 0;
         uint32_t a0;
-        const uint32_t nc = path_chunk_count(P, F.chunk_rows, a0);
-        const uint32_t c0 = F.path_chunks[i], inc0 = F.path_inc[i];
+        const uint32_t nc = path_chunk_count(P, F->chunk_rows, a0);
+        const uint32_t c0 = F->path_chunks[i], inc0 = F->path_inc[i];
         const bool area = path_has_area(P);
         for (uint32_t c = 0; c < nc; ++c) {
             ChunkInfo ck;
-            ck.path = i; ck.first_row = a0 + c * F.chunk_rows; ck.rec_base = inc0; ck.rows = F.chunk_rows;
-            ck.slot0 = area ? F.path_slots[i] + (ck.first_row / TILE_H - (uint32_t)P.y_min / TILE_H) : ~0u;
+            ck.path = i; ck.first_row = a0 + c * F->chunk_rows; ck.rec_base = inc0; ck.rows = F->chunk_rows;
+            ck.slot0 = area ? F->path_slots[i] + (ck.first_row / TILE_H - (uint32_t)P.y_min / TILE_H) : ~0u;
             ck.pad[0] = ck.pad[1] = ck.pad[2] = 0;
-            if (c0 + c < F.chunk_cap) F.chunks[c0 + c] = ck;
+            if (c0 + c < F->chunk_cap) F->chunks[c0 + c] = ck;
         }
     }
 }
@@ -217,34 +229,34 @@ __device__ __forceinline__ void bin_body(const Frame2& F) {
 // these buffers (heaviest first; any order inside a bucket; a scheduling hint only -- a scene's first frame runs in row-major
 // order); the costs are cleared for this frame's k2_rows.  One 1024-thread workgroup, the last one of the k2_bin launch.
 #define ORDER_LDS_STRIPS 98304         // strips whose bucket numbers fit the workgroup's LDS (a 12288 x 8192 frame); larger frames re-read the costs
-__device__ __forceinline__ void order_body(const Frame2& F) {
+__device__ __forceinline__ void order_body(FramePtr F) {
     __shared__ uint32_t bucket[ORDER_BUCKETS + 1];
     __shared__ uint2 rowinfo[2048];                        // per tile-row of the handle: {first band list entry, entries}
     __shared__ uint8_t bkt[ORDER_LDS_STRIPS];
     const int tid = threadIdx.x;
-    const uint32_t n_strips = F.n_strips, bc = F.band_count > 1 ? F.band_count : 1, bi = F.band_count > 1 ? F.band_index : 0;
-    const uint32_t per_row = STRIPS_PER_TILE * (uint32_t)F.tiles_x;
+    const uint32_t n_strips = F->n_strips, bc = F->band_count > 1 ? F->band_count : 1, bi = F->band_count > 1 ? F->band_index : 0;
+    const uint32_t per_row = STRIPS_PER_TILE * (uint32_t)F->tiles_x;
     const uint32_t n_local = n_strips / per_row;
     const bool cached = n_strips <= ORDER_LDS_STRIPS;
     for (uint32_t l = (uint32_t)tid; l < n_local && l < 2048u; l += 1024) {
-        const uint32_t trow = l * bc + bi, b0 = F.band_off[trow];
-        rowinfo[l] = make_uint2(b0, F.band_off[trow + 1] - b0);
+        const uint32_t trow = l * bc + bi, b0 = F->band_off[trow];
+        rowinfo[l] = make_uint2(b0, F->band_off[trow + 1] - b0);
     }
-    if (F.strip_order) {
+    if (F->strip_order) {
         for (uint32_t b = (uint32_t)tid; b <= ORDER_BUCKETS; b += 1024) bucket[b] = 0;
         lds_barrier();
         // every cost is read once (four independent loads in flight per thread), its bucket number kept in LDS, the costs cleared
         for (uint32_t w0 = (uint32_t)tid; w0 < n_strips; w0 += 4096) {
             uint32_t c[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const uint32_t w = w0 + (uint32_t)u * 1024; c[u] = w < n_strips ? F.strip_cost[w] : 0u; }
+            for (int u = 0; u < 4; ++u) { const uint32_t w = w0 + (uint32_t)u * 1024; c[u] = w < n_strips ? F->strip_cost[w] : 0u; }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const uint32_t w = w0 + (uint32_t)u * 1024;
                 if (w >= n_strips) continue;
                 const uint32_t k = order_bucket(c[u]);
                 atomicAdd(&bucket[k + 1], 1u);
-                if (cached) { bkt[w] = (uint8_t)k; F.strip_cost[w] = 0; }
+                if (cached) { bkt[w] = (uint8_t)k; F->strip_cost[w] = 0; }
             }
         }
         lds_barrier();
@@ -262,20 +274,19 @@ __device__ __forceinline__ void order_body(const Frame2& F) {
     lds_barrier();
     for (uint32_t w = (uint32_t)tid; w < n_strips; w += 1024) {
         uint32_t at = w;
-        if (F.strip_order) {
+        if (F->strip_order) {
             uint32_t k;
-            if (cached) k = bkt[w]; else { k = order_bucket(F.strip_cost[w]); F.strip_cost[w] = 0; }
+            if (cached) k = bkt[w]; else { k = order_bucket(F->strip_cost[w]); F->strip_cost[w] = 0; }
             at = atomicAdd(&bucket[k], 1u);
         }
         const uint32_t l = w / per_row;
         uint2 ri;
-        if (l < 2048u) ri = rowinfo[l]; else { const uint32_t trow = l * bc + bi, b0 = F.band_off[trow]; ri = make_uint2(b0, F.band_off[trow + 1] - b0); }
+        if (l < 2048u) ri = rowinfo[l]; else { const uint32_t trow = l * bc + bi, b0 = F->band_off[trow]; ri = make_uint2(b0, F->band_off[trow + 1] - b0); }
         StripDesc sd; sd.wg = w; sd.band_begin = ri.x; sd.n_b = ri.y; sd.pad = 0;
-        F.strips[at] = sd;
+        F->strips[at] = sd;
     }
 }
-__global__ __launch_bounds__(1024) void k2_bin(const Frame2 FR) { bin_body(FR); }
-__global__ __launch_bounds__(1024) void k2_bin_b(const Frame2* __restrict__ frames) { bin_body(frames[blockIdx.y]); }
+__global__ __launch_bounds__(1024) void k2_bin_b(const Frame2* __restrict__ frames) { bin_body(FRAME_PTR(frames, blockIdx.y)); }
 
 // ---------------------------------------------------------------------------------------------
 // k2_rows
@@ -319,7 +330,7 @@ __device__ __forceinline__ void rows2_fast(EPTR E, uint32_t n_list, const DevPat
                                            uint32_t& mode_out, int& n_out_edges, bool& overflow_out, bool& defer_out,
                                            int32_t (&roles)[ROWS_FAST_N], int32_t (&cols)[ROWS_FAST_N], int (&el)[ROWS_FAST_N],
                                            int32_t (&Q1)[ROWS_FAST_N], int64_t (&R1)[ROWS_FAST_N], int32_t (&Q2)[ROWS_FAST_N], int64_t (&R2)[ROWS_FAST_N],
-                                           int& nmax_out, uint32_t ri, const Frame2& FR, int& n_cells_out, uint32_t& incl_out, uint32_t& base_out,
+                                           int& nmax_out, uint32_t ri, FramePtr FR, int& n_cells_out, uint32_t& incl_out, uint32_t& base_out,
                                            uint32_t* r2ph, unsigned long long& r2ph_t, uint32_t chunk_cell_base) {
     (void)r2ph; (void)r2ph_t;
     const int s0 = r * 15;
@@ -461,8 +472,8 @@ __device__ __forceinline__ void rows2_fast(EPTR E, uint32_t n_list, const DevPat
     const uint32_t incl_cells = (uint32_t)wave_scan_incl(room);
     const uint32_t total_cells = (uint32_t)__builtin_amdgcn_readlane((int)incl_cells, 63);
     // the wavefront's cells start at its chunk's slot: (edge, row) pairs before it x MAX_CELLS_PER_EDGE_ROW -- no allocator in this kernel
-    const uint32_t wave_base = ((uint64_t)chunk_cell_base + total_cells <= (uint64_t)FR.cell_slice) ? chunk_cell_base : ~0u;
-    if (wave_base == ~0u && lane == 0) atomicOr(&FR.counters[C2_ERROR], E2_CELL_ARENA);
+    const uint32_t wave_base = ((uint64_t)chunk_cell_base + total_cells <= (uint64_t)FR->cell_slice) ? chunk_cell_base : ~0u;
+    if (wave_base == ~0u && lane == 0) atomicOr(&FR->counters[C2_ERROR], E2_CELL_ARENA);
     R2PHASE(4);
     if (lane < 4) S.cnt[lane] = 0;
     lds_barrier();                                          // F.* written by the row owners, read by the sample lanes
@@ -546,13 +557,13 @@ __device__ __forceinline__ void rows2_fast(EPTR E, uint32_t n_list, const DevPat
                     const int gg = t < c0 ? 0 : (t < c0 + c1 ? 1 : (t < c0 + c1 + c2 ? 2 : 3));
                     const uint32_t pre = gg == 0 ? 0u : (gg == 1 ? c0 : (gg == 2 ? c0 + c1 : c0 + c1 + c2));
                     const uint32_t bb = gg == 0 ? b0 : (gg == 1 ? b1 : (gg == 2 ? b2 : b3));
-                    FR.cells[bb + (t - pre)] = unpack_sub_cell(S.cells[gg][t - pre]);
+                    FR->cells[bb + (t - pre)] = unpack_sub_cell(S.cells[gg][t - pre]);
                 }
             }
             if (sub == 0 && R >= 0 && riR != ~0u) {          // the first sample lane of each of the pass's rows writes its header
                 const uint32_t bb = g == 0 ? b0 : (g == 1 ? b1 : (g == 2 ? b2 : b3));
                 RowInfo2 h; h.off = wave_base == ~0u ? 0u : bb; h.n = wave_base == ~0u ? (uint16_t)0 : (uint16_t)S.cnt[g]; h.mode = (uint16_t)ROW_SUB;
-                FR.rows[riR] = h;
+                FR->rows[riR] = h;
             }
         }
         lds_barrier();                                      // staging read: reset the counters for the next pass
@@ -573,7 +584,7 @@ __device__ __forceinline__ void rows2_fast(EPTR E, uint32_t n_list, const DevPat
 }
 
 
-__device__ __forceinline__ void rows2_chunk_body(const Frame2& FR, uint32_t block) {
+__device__ __forceinline__ void rows2_chunk_body(FramePtr FR, uint32_t block) {
     uint32_t r2ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long r2ph_t = 0;
 #ifdef SWFR_PHASES
@@ -583,12 +594,12 @@ __device__ __forceinline__ void rows2_chunk_body(const Frame2& FR, uint32_t bloc
     __shared__ SubStage S;
     __shared__ DevEdge staged[ROWS_STAGE];
     const int lane = threadIdx.x;
-    const ChunkInfo ck = FR.chunks[block];                               // wave-uniform: path and edge reads are scalar
+    const ChunkInfo ck = FR->chunks[block];                               // wave-uniform: path and edge reads are scalar
     const uint32_t lo = ck.path;
-    const DevPath P = FR.paths[lo];
+    const DevPath P = FR->paths[lo];
     const int r = (int)ck.first_row + lane;
     const int chunk_rows = (int)ck.rows;                                 // 16, 32 or 64: whole tile-rows, starting on a tile-row boundary
-    const uint32_t band_index = FR.band_index, band_count = FR.band_count;
+    const uint32_t band_index = FR->band_index, band_count = FR->band_count;
     // the band entry of this lane's tile-row: where its row headers and class bytes go
     const int g16 = lane >> 4;
     const int band = (int)ck.first_row / TILE_H + g16;
@@ -597,15 +608,15 @@ __device__ __forceinline__ void rows2_chunk_body(const Frame2& FR, uint32_t bloc
     BandSlot cls_bs = {0u, 0u, 0u, 0u};
     uint32_t cls_b0 = 0, cls_b1 = 0;
     if (band_ok) {
-        cls_bs = FR.band_slots[ck.slot0 + (uint32_t)g16];
-        cls_b0 = FR.band_off[band];
-        cls_b1 = FR.band_off[band + 1];
+        cls_bs = FR->band_slots[ck.slot0 + (uint32_t)g16];
+        cls_b0 = FR->band_off[band];
+        cls_b1 = FR->band_off[band + 1];
     }
     const uint32_t ri = band_ok ? cls_bs.slot * TILE_H + (uint32_t)(lane & (TILE_H - 1)) : ~0u;
     const bool in_path = P.kind == SWFR_PATH_TOR && lane < chunk_rows && r >= P.y_min && r < P.y_max;
     bool live = in_path;
     if (live && band_count > 1 && (uint32_t)((r / TILE_H) % band_count) != band_index) live = false;
-    int fast_limit = (int)FR.fast_limit;
+    int fast_limit = (int)FR->fast_limit;
     if (P.n_edges > 65535u) fast_limit = 0;                             // 16-bit local edge indices in the fast path
     R2PHASE(0);
     // ---- stage the edges that can be active in this chunk's rows (path order kept)
@@ -615,7 +626,7 @@ __device__ __forceinline__ void rows2_chunk_body(const Frame2& FR, uint32_t bloc
     int inc_before = 0;                                                  // (edge, pixel row) pairs of this path above the chunk: where its cells start
     for (uint32_t eb = 0; eb < P.n_edges; eb += 64) {
         const uint32_t k = eb + (uint32_t)lane;
-        const DevEdge ek = FR.edges[P.first_edge + min(k, P.n_edges - 1u)];
+        const DevEdge ek = FR->edges[P.first_edge + min(k, P.n_edges - 1u)];
         const bool valid = k < P.n_edges && ek.ybot > ek.ytop;
         if (valid) inc_before += max(0, min((ek.ybot - 1) / 15 + 1, (int)ck.first_row) - ek.ytop / 15);
         const bool hit = use_lds && valid && ek.ytop < hi_s && ek.ybot > lo_s;
@@ -633,7 +644,7 @@ __device__ __forceinline__ void rows2_chunk_body(const Frame2& FR, uint32_t bloc
     int32_t Q1[ROWS_FAST_N], Q2[ROWS_FAST_N]; int64_t R1[ROWS_FAST_N], R2[ROWS_FAST_N];
     int n_cells; uint32_t incl, base;
     if (use_lds) rows2_fast((const DevEdge*)staged, n_list, P, r, live, fast_limit, F, S, lane, mode, n, overflow, defer, roles, cols, el, Q1, R1, Q2, R2, nmax, ri, FR, n_cells, incl, base, r2ph, r2ph_t, chunk_cell_base);
-    else rows2_fast(FR.edges + P.first_edge, P.n_edges, P, r, live, fast_limit, F, S, lane, mode, n, overflow, defer, roles, cols, el, Q1, R1, Q2, R2, nmax, ri, FR, n_cells, incl, base, r2ph, r2ph_t, chunk_cell_base);
+    else rows2_fast(FR->edges + P.first_edge, P.n_edges, P, r, live, fast_limit, F, S, lane, mode, n, overflow, defer, roles, cols, el, Q1, R1, Q2, R2, nmax, ri, FR, n_cells, incl, base, r2ph, r2ph_t, chunk_cell_base);
     const bool slow = live && (overflow || defer);
     // ---- FULL rows: cells of every boundary edge, densely packed behind the wavefront's allocation
     const bool emit = mode == ROW_FULL && ri != ~0u && !slow;
@@ -646,13 +657,13 @@ __device__ __forceinline__ void rows2_chunk_body(const Frame2& FR, uint32_t bloc
             for (int s = 0; s < ROWS_FAST_N; ++s) {
                 if (s >= nmax) continue;
                 if (s < n && roles[s] != 0) {
-                    const int64_t edy = use_lds ? staged[el[s]].dy : FR.edges[P.first_edge + el[s]].dy;
-                    full_cells(Q1[s], R1[s], Q2[s], R2[s], edy, ((uint32_t)roles[s] & 1u) ? +1 : -1, P.x_min, P.x_max, &FR.cells[off]);
+                    const int64_t edy = use_lds ? staged[el[s]].dy : FR->edges[P.first_edge + el[s]].dy;
+                    full_cells(Q1[s], R1[s], Q2[s], R2[s], edy, ((uint32_t)roles[s] & 1u) ? +1 : -1, P.x_min, P.x_max, &FR->cells[off]);
                     off += (uint32_t)full_span(Q1[s], Q2[s]);
                 }
             }
         }
-        FR.rows[ri] = h;
+        FR->rows[ri] = h;
     }
     R2PHASE(6);
     // ---- rows left to the slow-row kernel
@@ -662,19 +673,19 @@ __device__ __forceinline__ void rows2_chunk_body(const Frame2& FR, uint32_t bloc
         if (qm) {
             uint32_t qb = 0;
             if (lane == 0) {
-                qb = atomicAdd(&FR.counters[C2_SLOW], (uint32_t)__popcll(qm));
-                if (atomicOr(&FR.path_flag[lo], 1u) == 0u) FR.path_queue[atomicAdd(&FR.counters[C2_PATHQ], 1u)] = lo;   // once per path
+                qb = atomicAdd(&FR->counters[C2_SLOW], (uint32_t)__popcll(qm));
+                if (atomicOr(&FR->path_flag[lo], 1u) == 0u) FR->path_queue[atomicAdd(&FR->counters[C2_PATHQ], 1u)] = lo;   // once per path
             }
             qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)qb);
             if (q) {
                 const uint32_t at = qb + (uint32_t)__popcll(qm & ((1ull << lane) - 1ull));
-                if (at < FR.slow_cap) {
+                if (at < FR->slow_cap) {
                     SlowRow sr; sr.path = lo; sr.row = r; sr.ri = ri;
                     // where the path's (path, tile-row) pairs start in band_slots (the slow kernel looks up earlier rows' headers) | tie flag
                     sr.pad = (ck.slot0 - (uint32_t)((int)ck.first_row / TILE_H - band_lo)) | (defer ? 0x80000000u : 0u);
-                    FR.slow[at] = sr;
+                    FR->slow[at] = sr;
                 }
-                else atomicOr(&FR.counters[C2_ERROR], E2_SLOW_QUEUE);
+                else atomicOr(&FR->counters[C2_ERROR], E2_SLOW_QUEUE);
             }
         }
     }
@@ -682,14 +693,14 @@ __device__ __forceinline__ void rows2_chunk_body(const Frame2& FR, uint32_t bloc
     //      pixel rows of tile-row g.  Only the columns of the path's rectangle are written (the rest of the class matrix was
     //      cleared when the scene was uploaded and nothing ever writes there).
     if (ck.slot0 != ~0u && P.kind == SWFR_PATH_TOR) {
-        const int width = FR.width, height = FR.height;
-        uint8_t* out = FR.cls;
+        const int width = FR->width, height = FR->height;
+        uint8_t* out = FR->cls;
         uint32_t n_b = 0;
         if (band_ok) {
             n_b = cls_b1 - cls_b0;
-            out = FR.cls + (size_t)FR.tiles_x * cls_b0 + (cls_bs.slot - cls_b0);
+            out = FR->cls + (size_t)FR->tiles_x * cls_b0 + (cls_bs.slot - cls_b0);
         }
-        const swfr_style& st = FR.styles[P.style];
+        const swfr_style& st = FR->styles[P.style];
         const uint32_t opq = (st.kind == SWFR_STYLE_SOLID && P.lerp && (st.pixel >> 24) == 0xffu) ? CLS_OPAQUE : 0u;
         const int tc0 = P.x_min / TILE_W, tc1 = (P.x_max - 1) / TILE_W;
         const int y = r;
@@ -733,12 +744,12 @@ __device__ __forceinline__ void rows2_chunk_body(const Frame2& FR, uint32_t bloc
             if ((lane & 15) == 0 && band_ok) out[(size_t)tc * n_b] = (uint8_t)f;
             // the tile's strips get heavier by the rows of this path with a boundary in the tile (the tile pass starts its heaviest
             // strips first): lanes 0 and 8 of the tile-row's sixteen add their half's rows
-            if (FR.strip_order) {
+            if (FR->strip_order) {
                 const unsigned long long pb = __ballot(row_partial);
                 if ((lane & 7) == 0 && band_ok && (f & CLS_PARTIAL) && (band_count <= 1 || (uint32_t)band % band_count == band_index)) {
                     const uint32_t wgt = (uint32_t)__popcll((pb >> lane) & 0xffull);
                     const uint32_t local_trow = band_count > 1 ? (uint32_t)band / band_count : (uint32_t)band;
-                    if (wgt) atomicAdd(&FR.strip_cost[((size_t)local_trow * FR.tiles_x + tc) * STRIPS_PER_TILE + ((lane >> 3) & 1)], wgt);
+                    if (wgt) atomicAdd(&FR->strip_cost[((size_t)local_trow * FR->tiles_x + tc) * STRIPS_PER_TILE + ((lane >> 3) & 1)], wgt);
                 }
             }
         }
@@ -746,19 +757,15 @@ __device__ __forceinline__ void rows2_chunk_body(const Frame2& FR, uint32_t bloc
     R2PHASE(7);
 #ifdef SWFR_PHASES
     if (lane == 0 && (block & 63u) == 0u) {                                      // a sample of the wavefronts: contended atomics are slow
-        for (int i = 0; i < 8; ++i) atomicAdd(&FR.counters[24 + i], r2ph[i] >> 4);   // units of 16 clocks
-        atomicAdd(&FR.counters[C2_CELLS], 1u);
+        for (int i = 0; i < 8; ++i) atomicAdd(&FR->counters[24 + i], r2ph[i] >> 4);   // units of 16 clocks
+        atomicAdd(&FR->counters[C2_CELLS], 1u);
     }
 #endif
 }
 
-__global__ __launch_bounds__(64) void k2_rows(const Frame2 FR) {
-    if (blockIdx.x >= FR.n_chunks) return;
-    rows2_chunk_body(FR, blockIdx.x);
-}
 __global__ __launch_bounds__(64) void k2_rows_b(const Frame2* __restrict__ frames) {
-    const Frame2& FR = frames[blockIdx.y];
-    if (blockIdx.x >= FR.n_chunks) return;
+    FramePtr FR = FRAME_PTR(frames, blockIdx.y);
+    if (blockIdx.x >= FR->n_chunks) return;
     rows2_chunk_body(FR, blockIdx.x);
 }
 
@@ -799,16 +806,16 @@ __device__ __forceinline__ void merge_step(const uint16_t* __restrict__ src, uin
 // one after the other with the merge sort above.
 #define START_MAX 2048                 // edges of one path that may start at one sample row (more: the frame fails loudly)
 __device__ __forceinline__ void rank_tmp(DevEdge* E, int i, int rank) { E[i].pad = rank; }
-__device__ __forceinline__ void start_ranks_body(const Frame2& FR, uint32_t p) {
+__device__ __forceinline__ void start_ranks_body(FramePtr FR, uint32_t p) {
     __shared__ int sort_cell[START_MAX];
     __shared__ uint16_t sort_a[START_MAX], sort_b[START_MAX];
     __shared__ uint32_t member[START_MAX];
     __shared__ uint32_t wave_cnt[4];
     __shared__ int next_y, grp_n;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const DevPath P = FR.paths[p];
+    const DevPath P = FR->paths[p];
     if (P.kind != SWFR_PATH_TOR) return;
-    DevEdge* E = FR.edges + P.first_edge;
+    DevEdge* E = FR->edges + P.first_edge;
     const int ne = (int)P.n_edges;
     // edges alone at their sample row keep rank 0, pairs are ordered directly; members of larger groups are marked (-1)
     for (int i = tid; i < ne; i += 256) {
@@ -864,7 +871,7 @@ __device__ __forceinline__ void start_ranks_body(const Frame2& FR, uint32_t p) {
         }
         if (tid == 0) grp_n = n;
         __syncthreads();
-        if (n > START_MAX) { if (tid == 0) atomicOr(&FR.counters[C2_ERROR], E2_START_GROUP); return; }     // workgroup-uniform
+        if (n > START_MAX) { if (tid == 0) atomicOr(&FR->counters[C2_ERROR], E2_START_GROUP); return; }     // workgroup-uniform
         for (int q = tid; q < (n + 1) / 2; q += 256) sort_pairs(sort_a, sort_cell, q, n);
         __syncthreads();
         uint16_t *src = sort_a, *dst = sort_b;
@@ -878,15 +885,14 @@ __device__ __forceinline__ void start_ranks_body(const Frame2& FR, uint32_t p) {
         done_y = y;
     }
 }
-__device__ __forceinline__ void start_ranks_loop(const Frame2& FR) {
-    const uint32_t nq = min(FR.counters[C2_PATHQ], FR.n_paths);
+__device__ __forceinline__ void start_ranks_loop(FramePtr FR) {
+    const uint32_t nq = min(FR->counters[C2_PATHQ], FR->n_paths);
     for (uint32_t i = blockIdx.x; i < nq; i += gridDim.x) {
-        start_ranks_body(FR, FR.path_queue[i]);
+        start_ranks_body(FR, FR->path_queue[i]);
         __syncthreads();
     }
 }
-__global__ __launch_bounds__(256) void k2_start_ranks(const Frame2 FR) { start_ranks_loop(FR); }
-__global__ __launch_bounds__(256) void k2_start_ranks_b(const Frame2* __restrict__ frames) { start_ranks_loop(frames[blockIdx.y]); }
+__global__ __launch_bounds__(256) void k2_start_ranks_b(const Frame2* __restrict__ frames) { start_ranks_loop(FRAME_PTR(frames, blockIdx.y)); }
 
 // ---------------------------------------------------------------------------------------------
 // k2_rows_slow: the queued rows, one wavefront each, lane = active edge (up to 64; more: the huge queue).  big_row_body of
@@ -894,15 +900,15 @@ __global__ __launch_bounds__(256) void k2_start_ranks_b(const Frame2* __restrict
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t slow_count_index(uint32_t pass) { return pass == 0 ? (uint32_t)C2_SLOW : C2_SLOWQ + pass; }
 __device__ __forceinline__ uint32_t huge_count_index(uint32_t pass) { return pass == 0 ? (uint32_t)C2_HUGE : C2_HUGEQ + pass; }
-__device__ __forceinline__ void slow_row_body(const Frame2& FR, const SlowRow sr, uint32_t pass) {
+__device__ __forceinline__ void slow_row_body(FramePtr FR, const SlowRow sr, uint32_t pass) {
     __shared__ uint32_t active[ROWS_BIG_MAXA];
     __shared__ uint32_t retry;
     const int lane = threadIdx.x;
-    const DevPath P = FR.paths[sr.path];
+    const DevPath P = FR->paths[sr.path];
     const int r = sr.row, s0 = r * 15;
     const unsigned mask = P.fill_rule ? 1u : ~0u;
-    const DevEdge* E = FR.edges + P.first_edge;
-    const PathEdges PE = {FR.edges, nullptr, &P, false, FR.counters, FR.rows, FR.band_slots, sr.pad & 0x7fffffffu, pass + 1 < SLOW_PASSES ? &retry : nullptr};
+    const DevEdge* E = FR->edges + P.first_edge;
+    const PathEdges PE = {FR->edges, nullptr, &P, false, FR->counters, FR->rows, FR->band_slots, sr.pad & 0x7fffffffu, pass + 1 < SLOW_PASSES ? &retry : nullptr};
     if (threadIdx.x == 0) retry = 0;
     // ---- gather: compact the indices of the active edges, 64 candidates per pass (path order is kept)
     int n = 0;
@@ -920,8 +926,8 @@ __device__ __forceinline__ void slow_row_body(const Frame2& FR, const SlowRow sr
     lds_barrier();
     if (too_many) {                                            // a workgroup of k2_rows_huge takes it
         if (lane == 0) {
-            const uint32_t at = atomicAdd(&FR.counters[huge_count_index(pass)], 1u);
-            if (at < FR.slow_cap) FR.huge[(pass & 1u) * FR.slow_cap + at] = sr; else atomicOr(&FR.counters[C2_ERROR], E2_SLOW_QUEUE);
+            const uint32_t at = atomicAdd(&FR->counters[huge_count_index(pass)], 1u);
+            if (at < FR->slow_cap) FR->huge[(pass & 1u) * FR->slow_cap + at] = sr; else atomicOr(&FR->counters[C2_ERROR], E2_SLOW_QUEUE);
         }
         return;
     }
@@ -1033,8 +1039,8 @@ __device__ __forceinline__ void slow_row_body(const Frame2& FR, const SlowRow sr
     lds_barrier();
     if (retry) {                                               // (wave-uniform) an earlier row it depends on is still queued: next pass
         if (lane == 0) {
-            const uint32_t at = atomicAdd(&FR.counters[slow_count_index(pass + 1)], 1u);
-            FR.slow[((pass + 1) & 1u) * FR.slow_cap + at] = sr;       // (never more rows than this pass had)
+            const uint32_t at = atomicAdd(&FR->counters[slow_count_index(pass + 1)], 1u);
+            FR->slow[((pass + 1) & 1u) * FR->slow_cap + at] = sr;       // (never more rows than this pass had)
         }
         return;
     }
@@ -1046,7 +1052,7 @@ __device__ __forceinline__ void slow_row_body(const Frame2& FR, const SlowRow sr
     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     const uint32_t base = alloc_cells(FR, total, lane);
     if (has && base != ~0u) {
-        Cell* dst = &FR.cells[base + incl - (uint32_t)n_cells];
+        Cell* dst = &FR->cells[base + incl - (uint32_t)n_cells];
         if (role & REC_FULL) full_cells(q1, r1, q2, r2, e.dy, (role & 1u) ? +1 : -1, P.x_min, P.x_max, dst);
         else {
             for (int sub = 0; sub < 15; ++sub) {
@@ -1060,24 +1066,23 @@ __device__ __forceinline__ void slow_row_body(const Frame2& FR, const SlowRow sr
     }
     if (lane == 0) {
         RowInfo2 h; h.off = base == ~0u ? 0u : base; h.n = base == ~0u ? (uint16_t)0 : (uint16_t)total; h.mode = (uint16_t)mode;
-        if (total > 65535u) { atomicOr(&FR.counters[C2_ERROR], E2_CELL_RANGE); h.n = 0; }
-        FR.rows[sr.ri] = h;
-        if (sr.pad >> 31) atomicAdd(&FR.counters[C2_TIE_ROWS], 1u);
+        if (total > 65535u) { atomicOr(&FR->counters[C2_ERROR], E2_CELL_RANGE); h.n = 0; }
+        FR->rows[sr.ri] = h;
+        if (sr.pad >> 31) atomicAdd(&FR->counters[C2_TIE_ROWS], 1u);
     }
 }
-__device__ __forceinline__ void slow_rows_loop(const Frame2& FR, uint32_t pass) {
-    const uint32_t n_slow = min(FR.counters[slow_count_index(pass)], FR.slow_cap);
+__device__ __forceinline__ void slow_rows_loop(FramePtr FR, uint32_t pass) {
+    const uint32_t n_slow = min(FR->counters[slow_count_index(pass)], FR->slow_cap);
     for (uint32_t i = blockIdx.x; i < n_slow; i += gridDim.x) {
-        slow_row_body(FR, FR.slow[(pass & 1u) * FR.slow_cap + i], pass);
+        slow_row_body(FR, FR->slow[(pass & 1u) * FR->slow_cap + i], pass);
         __syncthreads();                                       // `active` is rewritten by the next row
     }
 }
-__global__ __launch_bounds__(64) void k2_rows_slow(const Frame2 FR, uint32_t pass) { slow_rows_loop(FR, pass); }
-__global__ __launch_bounds__(64) void k2_rows_slow_b(const Frame2* __restrict__ frames, uint32_t pass) { slow_rows_loop(frames[blockIdx.y], pass); }
+__global__ __launch_bounds__(64) void k2_rows_slow_b(const Frame2* __restrict__ frames, uint32_t pass) { slow_rows_loop(FRAME_PTR(frames, blockIdx.y), pass); }
 
 // k2_rows_huge: rows with 65 .. 2048 active edges of one path, one 256-thread workgroup each (k_rows_huge of raster_kernels.hip
 // with cells as output): thread t owns the active edges t, t + 256, ... and ranks each against the row's sort keys in LDS.
-__device__ __forceinline__ void huge_row_body(const Frame2& FR, const SlowRow sr, uint32_t pass) {
+__device__ __forceinline__ void huge_row_body(FramePtr FR, const SlowRow sr, uint32_t pass) {
     __shared__ uint32_t retry;
     __shared__ uint32_t active[ROWS_HUGE_MAXA];
     __shared__ int k_a[ROWS_HUGE_MAXA], k_b[ROWS_HUGE_MAXA], k_c[ROWS_HUGE_MAXA], k_d[ROWS_HUGE_MAXA];
@@ -1085,11 +1090,11 @@ __device__ __forceinline__ void huge_row_body(const Frame2& FR, const SlowRow sr
     __shared__ int flags;                                            // bit 0: some edge starts / ends inside the row, bit 1: FULL test failed
     __shared__ uint32_t cell_base;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const DevPath P = FR.paths[sr.path];
+    const DevPath P = FR->paths[sr.path];
     const int r = sr.row, s0 = r * 15;
     const unsigned mask = P.fill_rule ? 1u : ~0u;
-    const DevEdge* E = FR.edges + P.first_edge;
-    const PathEdges PE = {FR.edges, nullptr, &P, false, FR.counters, FR.rows, FR.band_slots, sr.pad & 0x7fffffffu, pass + 1 < SLOW_PASSES ? &retry : nullptr};
+    const DevEdge* E = FR->edges + P.first_edge;
+    const PathEdges PE = {FR->edges, nullptr, &P, false, FR->counters, FR->rows, FR->band_slots, sr.pad & 0x7fffffffu, pass + 1 < SLOW_PASSES ? &retry : nullptr};
     if (tid == 0) { flags = 0; retry = 0; }
     int n = 0;
     for (uint32_t base = 0; base < P.n_edges; base += 256) {
@@ -1108,7 +1113,7 @@ __device__ __forceinline__ void huge_row_body(const Frame2& FR, const SlowRow sr
     }
     RowInfo2 ri; ri.off = 0; ri.n = 0; ri.mode = ROW_EMPTY;
     if (n > ROWS_HUGE_MAXA) {                                        // workgroup-uniform
-        if (tid == 0) { atomicOr(&FR.counters[C2_ERROR], E2_ACTIVE_EDGES); FR.rows[sr.ri] = ri; }
+        if (tid == 0) { atomicOr(&FR->counters[C2_ERROR], E2_ACTIVE_EDGES); FR->rows[sr.ri] = ri; }
         return;
     }
     const int nb = (n + 255) >> 8;                                   // owned edges per thread (workgroup-uniform)
@@ -1235,8 +1240,8 @@ __device__ __forceinline__ void huge_row_body(const Frame2& FR, const SlowRow sr
     __syncthreads();
     if (retry) {                                                     // (workgroup-uniform) depends on a row that is still queued: next pass
         if (tid == 0) {
-            const uint32_t at = atomicAdd(&FR.counters[huge_count_index(pass + 1)], 1u);
-            if (at < FR.slow_cap) FR.huge[((pass + 1) & 1u) * FR.slow_cap + at] = sr; else atomicOr(&FR.counters[C2_ERROR], E2_SLOW_QUEUE);
+            const uint32_t at = atomicAdd(&FR->counters[huge_count_index(pass + 1)], 1u);
+            if (at < FR->slow_cap) FR->huge[((pass + 1) & 1u) * FR->slow_cap + at] = sr; else atomicOr(&FR->counters[C2_ERROR], E2_SLOW_QUEUE);
         }
         return;
     }
@@ -1262,16 +1267,16 @@ __device__ __forceinline__ void huge_row_body(const Frame2& FR, const SlowRow sr
     if (tid == 0) {
         uint32_t base = 0;
         if (total) {
-            const uint32_t old = atomicAdd(&FR.counters[C2_HEAD], total);
-            base = FR.cell_main + old;
-            if ((uint64_t)base + total > FR.cell_slice || total > 65535u) { atomicOr(&FR.counters[C2_ERROR], total > 65535u ? E2_CELL_RANGE : E2_CELL_ARENA); base = ~0u; }
+            const uint32_t old = atomicAdd(&FR->counters[C2_HEAD], total);
+            base = FR->cell_main + old;
+            if ((uint64_t)base + total > FR->cell_slice || total > 65535u) { atomicOr(&FR->counters[C2_ERROR], total > 65535u ? E2_CELL_RANGE : E2_CELL_ARENA); base = ~0u; }
         }
         cell_base = base;
     }
     __syncthreads();
     const uint32_t base = cell_base;
     if (base != ~0u) {
-        Cell* dst = &FR.cells[base + before];
+        Cell* dst = &FR->cells[base + before];
 #pragma unroll
         for (int m = 0; m < ROWS_HUGE_EPT; ++m) {
             const int j = m * 256 + tid;
@@ -1293,17 +1298,102 @@ __device__ __forceinline__ void huge_row_body(const Frame2& FR, const SlowRow sr
             }
         }
     }
-    if (tid == 0) { ri.off = base == ~0u ? 0u : base; ri.n = base == ~0u ? (uint16_t)0 : (uint16_t)total; ri.mode = (uint16_t)mode; FR.rows[sr.ri] = ri; }
+    if (tid == 0) { ri.off = base == ~0u ? 0u : base; ri.n = base == ~0u ? (uint16_t)0 : (uint16_t)total; ri.mode = (uint16_t)mode; FR->rows[sr.ri] = ri; }
 }
-__device__ __forceinline__ void huge_rows_loop(const Frame2& FR, uint32_t pass) {
-    const uint32_t n_huge = min(FR.counters[huge_count_index(pass)], FR.slow_cap);
+__device__ __forceinline__ void huge_rows_loop(FramePtr FR, uint32_t pass) {
+    const uint32_t n_huge = min(FR->counters[huge_count_index(pass)], FR->slow_cap);
     for (uint32_t i = blockIdx.x; i < n_huge; i += gridDim.x) {
-        huge_row_body(FR, FR.huge[(pass & 1u) * FR.slow_cap + i], pass);
+        huge_row_body(FR, FR->huge[(pass & 1u) * FR->slow_cap + i], pass);
         __syncthreads();
     }
 }
-__global__ __launch_bounds__(256) void k2_rows_huge(const Frame2 FR, uint32_t pass) { huge_rows_loop(FR, pass); }
-__global__ __launch_bounds__(256) void k2_rows_huge_b(const Frame2* __restrict__ frames, uint32_t pass) { huge_rows_loop(frames[blockIdx.y], pass); }
+__global__ __launch_bounds__(256) void k2_rows_huge_b(const Frame2* __restrict__ frames, uint32_t pass) { huge_rows_loop(FRAME_PTR(frames, blockIdx.y), pass); }
+
+// ---------------------------------------------------------------------------------------------
+// shading in pipeline 2: three instances of the tile kernel -- solid colours only; + bitmap fills (integer arithmetic only: pixman's
+// 16.16 sample positions, bilinear or separable convolution -- the branch of raster_kernels.hip's shade() for bitmaps, inlined);
+// + gradients (that file's shade(): double precision, a call).  A scene gets the lightest instance that covers its styles.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t shade_bitmap(const swfr_style& s, uint32_t style_index, const Sources& src, int px, int py) {
+    const DevBitmap bm = src.bitmaps[s.bitmap];
+    const DevFilter& flt = src.filters[style_index];
+    // pixman's own 16.16 sample position of this pixel's centre
+    const long long fxp = flt.base_x + (long long)px * flt.m00 + (long long)py * flt.m01;
+    const long long fyp = flt.base_y + (long long)px * flt.m10 + (long long)py * flt.m11;
+    const bool repeat = s.extend == 1;
+    const int bw = (int)bm.width, bh = (int)bm.height;
+    if (flt.on) {
+        // CAIRO_FILTER_GOOD below scale 0.75: pixman's separable convolution (integer tables and accumulation)
+        long long x = fxp, y = fyp;
+        const int xsh = 16 - flt.xbits, ysh = 16 - flt.ybits;
+        const long long x_off = (((long long)flt.cw << 16) - 65536) >> 1, y_off = (((long long)flt.ch << 16) - 65536) >> 1;
+        x = ((x >> xsh) << xsh) + ((1 << xsh) >> 1);          // the middle of the closest phase
+        y = ((y >> ysh) << ysh) + ((1 << ysh) >> 1);
+        const int phx = (int)((x & 0xffff) >> xsh), phy = (int)((y & 0xffff) >> ysh);
+        const int32_t* yp = src.fparams + flt.y_off + phy * flt.ch;
+        const int32_t* xp0 = src.fparams + flt.x_off + phx * flt.cw;
+        const int x1 = (int)((x - 1 - x_off) >> 16), y1 = (int)((y - 1 - y_off) >> 16);
+        long long sr = 0, sg = 0, sb = 0, sa = 0;
+        for (int i = 0; i < flt.ch; ++i) {
+            const long long fy = yp[i];
+            if (!fy) continue;
+            int ry = y1 + i;
+            if (repeat) ry = ((ry % bh) + bh) % bh;
+            for (int j = 0; j < flt.cw; ++j) {
+                const int32_t fx = xp0[j];
+                if (!fx) continue;
+                int rx = x1 + j;
+                uint32_t pixel;
+                if (repeat) { rx = ((rx % bw) + bw) % bw; pixel = bm.pixels[(size_t)ry * bm.width + rx]; }
+                else pixel = (rx < 0 || ry < 0 || rx >= bw || ry >= bh) ? 0u : bm.pixels[(size_t)ry * bm.width + rx];
+                const int f = (int)((fy * fx + 0x8000) >> 16);
+                sr += (int)((pixel >> 16) & 255u) * f; sg += (int)((pixel >> 8) & 255u) * f; sb += (int)(pixel & 255u) * f; sa += (int)(pixel >> 24) * f;
+            }
+        }
+        sa = (sa + 0x8000) >> 16; sr = (sr + 0x8000) >> 16; sg = (sg + 0x8000) >> 16; sb = (sb + 0x8000) >> 16;
+        sa = min(max(sa, 0ll), 255ll); sr = min(max(sr, 0ll), 255ll); sg = min(max(sg, 0ll), 255ll); sb = min(max(sb, 0ll), 255ll);
+        return ((uint32_t)sa << 24) | ((uint32_t)sr << 16) | ((uint32_t)sg << 8) | (uint32_t)sb;
+    }
+    // bilinear with 7-bit weights (what CAIRO_FILTER_GOOD becomes for scales > .75): the four texel loads are issued together
+    const long long bxp = fxp - 0x8000, byp = fyp - 0x8000;
+    const int x0 = (int)(bxp >> 16), y0 = (int)(byp >> 16);
+    const uint32_t wx = (uint32_t)((bxp >> 9) & 0x7f), wy = (uint32_t)((byp >> 9) & 0x7f);
+    int xa = x0, xb = x0 + 1, ya = y0, yb = y0 + 1;
+    bool oxa = false, oxb = false, oya = false, oyb = false;
+    if (repeat) {
+        xa = ((xa % bw) + bw) % bw; xb = xa + 1 == bw ? 0 : xa + 1;
+        ya = ((ya % bh) + bh) % bh; yb = ya + 1 == bh ? 0 : ya + 1;
+    } else {
+        oxa = xa < 0 || xa >= bw; oxb = xb < 0 || xb >= bw; oya = ya < 0 || ya >= bh; oyb = yb < 0 || yb >= bh;
+        xa = min(max(xa, 0), bw - 1); xb = min(max(xb, 0), bw - 1); ya = min(max(ya, 0), bh - 1); yb = min(max(yb, 0), bh - 1);
+    }
+    const uint32_t* rowa = bm.pixels + (size_t)ya * bm.width;
+    const uint32_t* rowb = bm.pixels + (size_t)yb * bm.width;
+    uint32_t c00 = rowa[xa], c10 = rowa[xb], c01 = rowb[xa], c11 = rowb[xb];
+    if (oxa || oya) c00 = 0; if (oxb || oya) c10 = 0; if (oxa || oyb) c01 = 0; if (oxb || oyb) c11 = 0;
+    const uint32_t w00 = (128 - wx) * (128 - wy), w10 = wx * (128 - wy), w01 = (128 - wx) * wy, w11 = wx * wy;
+    uint32_t out = 0;
+#pragma unroll
+    for (int sh = 0; sh < 32; sh += 8) {
+        const uint32_t acc = ((c00 >> sh) & 255u) * w00 + ((c10 >> sh) & 255u) * w10 + ((c01 >> sh) & 255u) * w01 + ((c11 >> sh) & 255u) * w11;
+        out |= ((acc >> 14) & 255u) << sh;
+    }
+    return out;
+}
+// SHADERS: 0 solid colours only, 1 + bitmaps, 2 + gradients
+template <int SHADERS>
+__device__ __forceinline__ uint32_t blend2(uint32_t dst, uint32_t a, uint32_t eflags, uint32_t solid, const swfr_style* __restrict__ styles,
+                                           uint32_t style, const Sources& src, int cx, int cy) {
+    if (SHADERS == 0 || (eflags & BE_SOLID)) {
+        if (eflags & BE_LERP) return a == 255u ? solid : lerp_pixel(solid, a, dst);
+        return over_pixel(a == 255u ? solid : mul_un8(solid, a), dst);
+    }
+    uint32_t c;
+    if (SHADERS == 1) c = shade_bitmap(styles[style], style, src, cx, cy);
+    else c = styles[style].kind == SWFR_STYLE_BITMAP ? shade_bitmap(styles[style], style, src, cx, cy) : shade(styles[style], style, src, cx, cy);
+    const uint32_t s = mul_un8(c, a);
+    return (eflags & BE_LERP) ? s : over_pixel(s, dst);
+}
 
 // ---------------------------------------------------------------------------------------------
 // k2_tiles
@@ -1314,8 +1404,8 @@ __global__ __launch_bounds__(256) void k2_rows_huge_b(const Frame2* __restrict__
 // One wavefront per strip of the launch list (heaviest first when the scene has an order); lane = pixel column; the strip's eight
 // rows of pixels live in registers until the single store.  Dependent memory round trips per strip: strip descriptor -> class
 // bytes -> {band entries, row headers} -> cells.
-template <bool SHADERS>
-__device__ __forceinline__ void tiles2_body(const Frame2& FR) {
+template <int SHADERS>
+__device__ __forceinline__ void tiles2_body(FramePtr FR) {
     __shared__ __attribute__((aligned(16))) int acc[STRIP_H][ACC_STRIDE];   // also the queue of the compacted blend (8-byte pairs)
     __shared__ __attribute__((aligned(16))) uint32_t ent[T2_LIST][8];       // BandEntry2 as dwords
     __shared__ __attribute__((aligned(16))) uint32_t rinfo[T2_LIST][2 * STRIP_H];   // the strip's eight RowInfo2 of a tor entry
@@ -1324,19 +1414,19 @@ __device__ __forceinline__ void tiles2_body(const Frame2& FR) {
     __shared__ int plist[PBATCH];
 
     const int lane = threadIdx.x;
-    const int width = FR.width, height = FR.height, tiles_x = FR.tiles_x;
-    const swfr_style* __restrict__ styles = FR.styles;
-    const Sources bitmaps = FR.src;
+    const int width = FR->width, height = FR->height, tiles_x = FR->tiles_x;
+    const swfr_style* __restrict__ styles = FR->styles;
+    const Sources bitmaps = {FR->src.bitmaps, FR->src.filters, FR->src.fparams, FR->src.gradients};
     for (int i = lane; i < STRIP_H * ACC_STRIDE; i += 64) (&acc[0][0])[i] = 0;
     lds_barrier();
 
-    for (uint32_t w = blockIdx.x; w < FR.n_strips; w += gridDim.x) {
-        const StripDesc sd = FR.strips[w];
+    for (uint32_t w = blockIdx.x; w < FR->n_strips; w += gridDim.x) {
+        const StripDesc sd = FR->strips[w];
         const uint32_t wg = sd.wg;
         const int tile = (int)(wg / STRIPS_PER_TILE), strip = (int)(wg % STRIPS_PER_TILE);
         const int tcol = tile % tiles_x;
         int trow = tile / tiles_x;
-        if (FR.band_count > 1) trow = trow * (int)FR.band_count + (int)FR.band_index;
+        if (FR->band_count > 1) trow = trow * (int)FR->band_count + (int)FR->band_index;
         const int tx0 = tcol * TILE_W, ty0 = trow * TILE_H + strip * STRIP_H;
         if (ty0 >= height) continue;
         const int cx = tx0 + lane;
@@ -1345,7 +1435,7 @@ __device__ __forceinline__ void tiles2_body(const Frame2& FR) {
         for (int rr = 0; rr < STRIP_H; ++rr) px[rr] = 0u;
 
         const uint32_t band_begin = sd.band_begin, n_b = sd.n_b;
-        const uint8_t* mycls = FR.cls + (size_t)tiles_x * band_begin + (size_t)tcol * n_b;   // this tile's class byte per band entry
+        const uint8_t* mycls = FR->cls + (size_t)tiles_x * band_begin + (size_t)tcol * n_b;   // this tile's class byte per band entry
         uint32_t next = 0;
         while (next < n_b) {
             // ---- bin: band entries with a non-empty class for this tile, painter's order kept (wave-local compaction)
@@ -1382,12 +1472,12 @@ __device__ __forceinline__ void tiles2_body(const Frame2& FR) {
                     const uint32_t sv = sel[li];
                     const uint32_t bidx = band_begin + (sv & 0xffffffu);
                     if (lane < T2_LIST) {
-                        const uint4* src = reinterpret_cast<const uint4*>(&FR.band_list[bidx]);
+                        const uint4* src = reinterpret_cast<const uint4*>(&FR->band_list[bidx]);
                         const uint4 q0 = src[0], q1 = src[1];
                         *reinterpret_cast<uint4*>(&ent[li][0]) = q0;
                         *reinterpret_cast<uint4*>(&ent[li][4]) = q1;
                     } else if (((sv >> 24) & (CLS_PARTIAL | CLS_BOX)) == CLS_PARTIAL) {
-                        const uint4* src = reinterpret_cast<const uint4*>(&FR.rows[(size_t)bidx * TILE_H + (uint32_t)(strip * STRIP_H)]);
+                        const uint4* src = reinterpret_cast<const uint4*>(&FR->rows[(size_t)bidx * TILE_H + (uint32_t)(strip * STRIP_H)]);
                         const uint4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
                         uint4* dst = reinterpret_cast<uint4*>(&rinfo[li][0]);
                         dst[0] = q0; dst[1] = q1; dst[2] = q2; dst[3] = q3;
@@ -1420,13 +1510,13 @@ __device__ __forceinline__ void tiles2_body(const Frame2& FR) {
                         const int cy = ty0 + rr;
                         uint32_t cov = 0u;
                         for (uint32_t k = 0; k < e_nedges; ++k) {
-                            const swfr_edge bx = FR.raw[e_first + k];
+                            const swfr_edge bx = FR->raw[e_first + k];
                             const int wx = min(bx.x2, (cx + 1) * 256) - max(bx.x1, cx * 256);
                             const int wy = min(bx.y2, (cy + 1) * 256) - max(bx.y1, cy * 256);
                             if (wx > 0 && wy > 0) cov += (uint32_t)(wx * wy);
                         }
                         const uint32_t a = ((cov >> 8) - (cov >> 16)) & 255u;
-                        if (a) px[rr] = blend_pixel_t<SHADERS>(px[rr], a, eflags, solid, styles, style, bitmaps, cx, cy);
+                        if (a) px[rr] = blend2<SHADERS>(px[rr], a, eflags, solid, styles, style, bitmaps, cx, cy);
                     }
                 } else if (f & CLS_PARTIAL) {
                     // ---- tor (A.5): the path's cells of this strip's rows
@@ -1450,7 +1540,7 @@ __device__ __forceinline__ void tiles2_body(const Frame2& FR) {
                             if (bp < batch_n && ty0 + row < height) {
                                 const int pl = plist[bp];
                                 off = rinfo[pl][2 * row]; my_cnt = rinfo[pl][2 * row + 1] & 0xffffu;
-                                if ((uint64_t)off + my_cnt > (uint64_t)FR.cell_slice) { atomicOr(&FR.counters[C2_ERROR], E2_CELL_RANGE); my_cnt = 0; }
+                                if ((uint64_t)off + my_cnt > (uint64_t)FR->cell_slice) { atomicOr(&FR->counters[C2_ERROR], E2_CELL_RANGE); my_cnt = 0; }
                             }
                         }
                         const int incl = wave_scan_incl((int)my_cnt);       // every lane active
@@ -1467,7 +1557,7 @@ __device__ __forceinline__ void tiles2_body(const Frame2& FR) {
                                 int lo = 0, hi = 64;                        // last segment with seg_start <= g
                                 while (lo + 1 < hi) { const int mid = (lo + hi) >> 1; if (seg_start[mid] <= g) lo = mid; else hi = mid; }
                                 pre_seg[u] = (uint32_t)lo;
-                                if (g < (uint32_t)total) pre[u] = FR.cells[seg_off[lo] + (g - seg_start[lo])];
+                                if (g < (uint32_t)total) pre[u] = FR->cells[seg_off[lo] + (g - seg_start[lo])];
                             }
                         }
                     }
@@ -1487,7 +1577,7 @@ __device__ __forceinline__ void tiles2_body(const Frame2& FR) {
                                 int lo = bp * STRIP_H, hi = (bp + 1) * STRIP_H;
                                 while (lo + 1 < hi) { const int mid = (lo + hi) >> 1; if (seg_start[mid] <= (uint32_t)g) lo = mid; else hi = mid; }
                                 sg = (uint32_t)lo;
-                                c = FR.cells[seg_off[lo] + ((uint32_t)g - seg_start[lo])];
+                                c = FR->cells[seg_off[lo] + ((uint32_t)g - seg_start[lo])];
                             }
                         }
                         if (g >= g0 && g < g1) {
@@ -1522,7 +1612,7 @@ __device__ __forceinline__ void tiles2_body(const Frame2& FR) {
                             if (cx < e_xmin || cx >= e_xmax || u < row_lo || u >= row_hi) al[u] = 0;
                         }
                         bool blended = false;
-                        if (!SHADERS && (eflags & BE_LERP)) {
+                        if (SHADERS == 0 && (eflags & BE_LERP)) {
                             // Solid colour, SOURCE-lerp: coverage 255 takes the colour, 0 keeps the pixel, and only the few edge pixels
                             // need the two rounded products: queued -- {coverage, pixel} through the (now empty) accumulator -- and
                             // blended with lanes = queued pixels, one pass for the strip's eight rows
@@ -1561,8 +1651,8 @@ __device__ __forceinline__ void tiles2_body(const Frame2& FR) {
                         if (!blended) {
 #pragma unroll
                             for (int u = 0; u < STRIP_H; ++u) {
-                                if (SHADERS) { if (al[u]) px[u] = blend_pixel_t<SHADERS>(px[u], al[u], eflags, solid, styles, style, bitmaps, cx, ty0 + u); }
-                                else { const uint32_t b = blend_pixel_t<SHADERS>(px[u], al[u], eflags, solid, styles, style, bitmaps, cx, ty0 + u); px[u] = al[u] ? b : px[u]; }
+                                if (SHADERS != 0) { if (al[u]) px[u] = blend2<SHADERS>(px[u], al[u], eflags, solid, styles, style, bitmaps, cx, ty0 + u); }
+                                else { const uint32_t b = blend2<SHADERS>(px[u], al[u], eflags, solid, styles, style, bitmaps, cx, ty0 + u); px[u] = al[u] ? b : px[u]; }
                             }
                         }
                     }
@@ -1571,14 +1661,14 @@ __device__ __forceinline__ void tiles2_body(const Frame2& FR) {
                     // full cover: every in-frame pixel of the path's rows in this tile has coverage 255
 #pragma unroll
                     for (int rr = 0; rr < STRIP_H; ++rr)
-                        if (rr >= row_lo && rr < row_hi) px[rr] = blend_pixel_t<SHADERS>(px[rr], 255u, eflags, solid, styles, style, bitmaps, cx, ty0 + rr);
+                        if (rr >= row_lo && rr < row_hi) px[rr] = blend2<SHADERS>(px[rr], 255u, eflags, solid, styles, style, bitmaps, cx, ty0 + rr);
                 }
             }
             lds_barrier();                                               // ent / sel are rewritten by the next round
         }
         // ---- one store per pixel: premultiplied R,G,B,A bytes; the wave writes 256 contiguous bytes per row
         if (cx < width) {
-            uint32_t* rowp = FR.fb + (size_t)ty0 * (size_t)width + cx;
+            uint32_t* rowp = FR->fb + (size_t)ty0 * (size_t)width + cx;
 #pragma unroll
             for (int rr = 0; rr < STRIP_H; ++rr) {
                 if (ty0 + rr < height) {
@@ -1596,43 +1686,36 @@ __device__ __forceinline__ void tiles2_body(const Frame2& FR) {
 #endif
 // (two entry points per kernel: one frame, its descriptor passed by value -- the fields arrive with the kernel arguments, no memory
 //  round trip -- and a batch of frames, blockIdx.y indexing an array of descriptors in device memory)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(T2_WAVES))) void k2_tiles_solid(const Frame2 FR) { tiles2_body<false>(FR); }
-__global__ __launch_bounds__(64) void k2_tiles_shaded(const Frame2 FR) { tiles2_body<true>(FR); }
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(T2_WAVES))) void k2_tiles_solid_b(const Frame2* __restrict__ frames) { tiles2_body<false>(frames[blockIdx.y]); }
-__global__ __launch_bounds__(64) void k2_tiles_shaded_b(const Frame2* __restrict__ frames) { tiles2_body<true>(frames[blockIdx.y]); }
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(T2_WAVES))) void k2_tiles_solid_b(const Frame2* __restrict__ frames) { tiles2_body<0>(FRAME_PTR(frames, blockIdx.y)); }
+__global__ __launch_bounds__(64) void k2_tiles_bitmap_b(const Frame2* __restrict__ frames) { tiles2_body<1>(FRAME_PTR(frames, blockIdx.y)); }
+__global__ __launch_bounds__(64) void k2_tiles_shaded_b(const Frame2* __restrict__ frames) { tiles2_body<2>(FRAME_PTR(frames, blockIdx.y)); }
 
 // ---------------------------------------------------------------------------------------------
-// launchers: `host` != nullptr: one frame, descriptor by value; else `frames` is a device array of n_frames descriptors
+// launchers: `frames` is a device array of n_frames descriptors, blockIdx.y picks one
 // ---------------------------------------------------------------------------------------------
-void launch2_bin(hipStream_t st, const Frame2* host, const Frame2* frames, uint32_t n_frames, uint32_t max_edges_or_paths, uint32_t max_bands) {
+void launch2_bin(hipStream_t st, const Frame2* frames, uint32_t n_frames, uint32_t max_edges_or_paths, uint32_t max_bands) {
     const uint32_t g = max_bands + (max_edges_or_paths + BIN_THREADS - 1) / BIN_THREADS + 1;      // + the workgroup that orders the strips
-    if (host) hipLaunchKernelGGL(k2_bin, dim3(g), dim3(BIN_THREADS), 0, st, *host);
-    else hipLaunchKernelGGL(k2_bin_b, dim3(g, n_frames), dim3(BIN_THREADS), 0, st, frames);
+    hipLaunchKernelGGL(k2_bin_b, dim3(g, n_frames), dim3(BIN_THREADS), 0, st, frames);
 }
-void launch2_rows(hipStream_t st, const Frame2* host, const Frame2* frames, uint32_t n_frames, uint32_t max_chunks) {
+void launch2_rows(hipStream_t st, const Frame2* frames, uint32_t n_frames, uint32_t max_chunks) {
     if (!max_chunks) return;
-    if (host) hipLaunchKernelGGL(k2_rows, dim3(max_chunks), dim3(64), 0, st, *host);
-    else hipLaunchKernelGGL(k2_rows_b, dim3(max_chunks, n_frames), dim3(64), 0, st, frames);
+    hipLaunchKernelGGL(k2_rows_b, dim3(max_chunks, n_frames), dim3(64), 0, st, frames);
 }
-void launch2_rows_slow(hipStream_t st, const Frame2* host, const Frame2* frames, uint32_t n_frames, uint32_t grid_slow, uint32_t grid_huge, uint32_t max_passes) {
-    if (grid_slow) { if (host) hipLaunchKernelGGL(k2_start_ranks, dim3(grid_slow / 4 + 1), dim3(256), 0, st, *host); else hipLaunchKernelGGL(k2_start_ranks_b, dim3(grid_slow / 4 + 1, n_frames), dim3(256), 0, st, frames); }
+void launch2_rows_slow(hipStream_t st, const Frame2* frames, uint32_t n_frames, uint32_t grid_slow, uint32_t grid_huge, uint32_t max_passes) {
+    if (grid_slow) hipLaunchKernelGGL(k2_start_ranks_b, dim3(grid_slow / 4 + 1, n_frames), dim3(256), 0, st, frames);
     // a queued row whose edge-order history runs through another queued row is queued again for the next pass
     for (uint32_t pass = 0; pass < SLOW_PASSES; ++pass) {
-        if (grid_slow) { if (host) hipLaunchKernelGGL(k2_rows_slow, dim3(grid_slow), dim3(64), 0, st, *host, pass); else hipLaunchKernelGGL(k2_rows_slow_b, dim3(grid_slow, n_frames), dim3(64), 0, st, frames, pass); }
-        if (grid_huge) { if (host) hipLaunchKernelGGL(k2_rows_huge, dim3(grid_huge), dim3(256), 0, st, *host, pass); else hipLaunchKernelGGL(k2_rows_huge_b, dim3(grid_huge, n_frames), dim3(256), 0, st, frames, pass); }
+        if (grid_slow) hipLaunchKernelGGL(k2_rows_slow_b, dim3(grid_slow, n_frames), dim3(64), 0, st, frames, pass);
+        if (grid_huge) hipLaunchKernelGGL(k2_rows_huge_b, dim3(grid_huge, n_frames), dim3(256), 0, st, frames, pass);
         if (pass + 1 >= max_passes) break;
     }
 }
-void launch2_tiles(hipStream_t st, const Frame2* host, const Frame2* frames, uint32_t n_frames, uint32_t max_strips, uint32_t grid_cap, bool any_shader) {
+void launch2_tiles(hipStream_t st, const Frame2* frames, uint32_t n_frames, uint32_t max_strips, uint32_t grid_cap, int shader_level) {
     if (!max_strips) return;
     const uint32_t g = max_strips < grid_cap ? max_strips : grid_cap;
-    if (host) {
-        if (any_shader) hipLaunchKernelGGL(k2_tiles_shaded, dim3(g), dim3(64), 0, st, *host);
-        else hipLaunchKernelGGL(k2_tiles_solid, dim3(g), dim3(64), 0, st, *host);
-    } else {
-        if (any_shader) hipLaunchKernelGGL(k2_tiles_shaded_b, dim3(g, n_frames), dim3(64), 0, st, frames);
-        else hipLaunchKernelGGL(k2_tiles_solid_b, dim3(g, n_frames), dim3(64), 0, st, frames);
-    }
+    if (shader_level >= 2) hipLaunchKernelGGL(k2_tiles_shaded_b, dim3(g, n_frames), dim3(64), 0, st, frames);
+    else if (shader_level == 1) hipLaunchKernelGGL(k2_tiles_bitmap_b, dim3(g, n_frames), dim3(64), 0, st, frames);
+    else hipLaunchKernelGGL(k2_tiles_solid_b, dim3(g, n_frames), dim3(64), 0, st, frames);
 }
 
 }  // namespace swfr

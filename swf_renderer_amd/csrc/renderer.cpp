@@ -33,10 +33,10 @@ void launch_rows(hipStream_t, const DevEdge*, const DevPath*, const uint32_t*, c
                  const swfr_edge*, const swfr_style*, BandEntry*, const BigRow*, uint32_t);
 void launch_tiles(hipStream_t, const swfr_edge*, const uint32_t*, const BandEntry*, const uint8_t*, const RowInfo*, const Rec*, const swfr_style*,
                   Sources, uint32_t*, int, int, uint32_t, uint32_t, int, uint32_t*, uint32_t, uint32_t, bool, const uint32_t*);
-void launch2_bin(hipStream_t, const Frame2*, const Frame2*, uint32_t, uint32_t, uint32_t);
-void launch2_rows(hipStream_t, const Frame2*, const Frame2*, uint32_t, uint32_t);
-void launch2_rows_slow(hipStream_t, const Frame2*, const Frame2*, uint32_t, uint32_t, uint32_t, uint32_t);
-void launch2_tiles(hipStream_t, const Frame2*, const Frame2*, uint32_t, uint32_t, uint32_t, bool);
+void launch2_bin(hipStream_t, const Frame2*, uint32_t, uint32_t, uint32_t);
+void launch2_rows(hipStream_t, const Frame2*, uint32_t, uint32_t);
+void launch2_rows_slow(hipStream_t, const Frame2*, uint32_t, uint32_t, uint32_t, uint32_t);
+void launch2_tiles(hipStream_t, const Frame2*, uint32_t, uint32_t, uint32_t, int);
 void launch_unpremultiply(hipStream_t, const uint32_t*, uint32_t*, size_t);
 void launch_pack_band(hipStream_t, const uint32_t*, uint32_t*, int, int, uint32_t, uint32_t, uint32_t);
 }  // namespace swfr
@@ -166,6 +166,7 @@ struct swfr_renderer {
         size_t n_edges = 0, n_paths = 0, n_styles = 0, n_tasks = 0, n_chunks = 0, n_bands = 0, rec_cap = 0, rec_main = 0, n_big = 0, n_huge = 0,
                chunk_rows = 64, n_band_entries = 0;
         bool any_shader = false, fused_class = false, fused_front = false, has_order = false;
+        int shader_level = 0;
         size_t n_incidences = 0, n_strips = 0;   // (edge, pixel row) pairs: bounds the cells of a frame; k_tiles wavefronts
         Frame2* frames_dev = nullptr;            // pipeline 2: one descriptor per frame set (contiguous, in the arena)
         Frame2 frames_host[4];                   // ... and on the host: a single frame's launches pass theirs by value
@@ -216,6 +217,18 @@ struct swfr_renderer {
     int fast_limit = 8;                     // rows with more active edges go through k_rows_big (SWFR_FAST_LIMIT: test knob)
     int pipeline = 2;                       // SWFR_PIPELINE=1: the round-1 kernels (edge records); 2: cells (raster2.hip)
     int tiles_grid = 0;                     // SWFR_TILES_GRID: persistent k2_tiles wavefronts per frame (0 = default)
+    // swfr_render_batch, pipeline 2: groups of frames rendered by ONE launch per kernel (blockIdx.y = frame); two groups alternate,
+    // the host builds one while the GPU works on the other
+    struct BatchGroup {
+        SceneArena arena;                   // the frames' edge lists, tables and descriptors: one H2D copy per group
+        DevBuf<uint8_t> work, cls;          // the kernel-written buffers of every frame of the group, carved from two allocations
+        hipStream_t stream = nullptr;
+        uint32_t* h_counters = nullptr;     // pinned
+        size_t h_counters_cap = 0;
+        hipEvent_t ev_begin = nullptr, ev_end = nullptr;   // around the group's kernels
+    };
+    BatchGroup groups[2];
+    int batch_frames = 64;                  // SWFR_BATCH_FRAMES: frames per launch in swfr_render_batch
     Frame2* d_frames = nullptr;             // one descriptor per frame set, contiguous: a batch of frames is one launch
     Frame2* h_frames = nullptr;             // pinned staging of the same
 
@@ -232,6 +245,12 @@ struct swfr_renderer {
                 scn[k].arena.release();
             }
             if (h_counters) (void)hipHostFree(h_counters);
+            for (auto& g : groups) {
+                g.arena.release(); g.work.release(); g.cls.release();
+                if (g.stream) (void)hipStreamDestroy(g.stream);
+                if (g.h_counters) (void)hipHostFree(g.h_counters);
+                if (g.ev_begin) { (void)hipEventDestroy(g.ev_begin); (void)hipEventDestroy(g.ev_end); }
+            }
             if (d_frames) (void)hipFree(d_frames);
             if (h_frames) (void)hipHostFree(h_frames);
             for (auto& kv : bitmaps) if (kv.second.pixels) (void)hipFree(kv.second.pixels);
@@ -493,23 +512,26 @@ void prepare_sources(const swfr_path* paths, size_t n_paths, const swfr_style* s
     }
 }
 
-// Pipeline 2: uploads a scene -- the raw edge list, the paths and the styles, nothing derived from them -- and sizes the buffers
-// the kernels write.  All binning (row chunks, band lists, cell bases, the tile pass's launch list) happens on the device, per
-// frame (k2_bin_a / _scan / _fill); the host only adds up, over the PATHS' rectangles, how large those tables get.
-int upload2(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, size_t n_edges, const swfr_path* paths, size_t n_paths,
-            const swfr_style* styles, size_t n_styles, uint32_t* fb_override, bool edges_tagged) {
-    swfr_renderer::Scene& sc = r->scn[si];
-    if (si == 0) r->scene_ready = false;
-    sc.slow_state = 0; sc.slow_passes = SLOW_PASSES;
-    if (si > 0 && !r->fs[si].stream) HIP_CHECK(hipStreamCreateWithFlags(&r->fs[si].stream, hipStreamNonBlocking));
-    const hipStream_t up_stream = r->fs[si].stream;
-    const uint32_t bc = r->cfg.band_count > 1 ? r->cfg.band_count : 1, bi = r->cfg.band_count > 1 ? r->cfg.band_index : 0;
-    const size_t n_bands = (r->height + TILE_H - 1) / TILE_H;
-    const uint32_t tiles_x = (r->width + TILE_W - 1) / TILE_W;
-    // ---- table sizes from the paths' rectangles (O(paths)); rows per k2_rows wavefront: 64 when that already gives the GPU a
-    //      thousand wavefronts, fewer (whole tile-rows) for scenes made of a few tall paths
+// What the host works out about a scene for pipeline 2: the LAYOUT of the tables the device fills -- how many row chunks, band
+// entries and cells there can be and where each path's share starts (prefix sums over the paths' rectangles and edge row spans,
+// and over the tile-rows) -- plus pixman's view of the bitmap / gradient styles.  No binning: that is the device's work, per frame.
+struct SceneLayout {
     uint32_t chunk_rows = ROWS_CHUNK;
-    size_t incidences = 0;
+    size_t n_chunks = 0, n_slots = 0, n_rows = 0, n_bands = 0, n_strips = 0, incidences = 0, cell_main = 0, cell_total = 0;
+    bool any_shader = false;
+    int shader_level = 0;       // 0 solid colours only, 1 + bitmap fills, 2 + gradients: picks the tile kernel's instance
+    std::vector<uint32_t> chunk_base, slot_base, inc_base, band_off;
+    std::vector<DevFilter> filters;
+    std::vector<DevGradient> gradients;
+    std::vector<int32_t> fparams;
+};
+// `edges` carry their path index in `reserved`
+void layout_scene(const swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_path* paths, size_t n_paths,
+                  const swfr_style* styles, size_t n_styles, SceneLayout& L) {
+    L.n_bands = (r->height + TILE_H - 1) / TILE_H;
+    const uint32_t tiles_x = (r->width + TILE_W - 1) / TILE_W;
+    // rows per k2_rows wavefront: 64 when that already gives the GPU a thousand wavefronts, fewer (whole tile-rows) for scenes made
+    // of a few tall paths
     auto count_chunks = [&](uint32_t cr) {
         size_t n = 0;
         for (size_t i = 0; i < n_paths; ++i)
@@ -517,87 +539,132 @@ int upload2(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, siz
                 n += (size_t(paths[i].y_max) - size_t(paths[i].y_min) / TILE_H * TILE_H + cr - 1) / cr;
         return n;
     };
-    if (r->force_chunk_rows == 16 || r->force_chunk_rows == 32 || r->force_chunk_rows == 64) chunk_rows = uint32_t(r->force_chunk_rows);
-    else while (chunk_rows > uint32_t(TILE_H) && count_chunks(chunk_rows) < 1024) chunk_rows >>= 1;
-    size_t n_chunks = 0, n_slots = 0, n_rows = 0;
-    sc.any_shader = false;
-    for (size_t i = 0; i < n_styles; ++i) sc.any_shader = sc.any_shader || styles[i].kind != SWFR_STYLE_SOLID;
-    // layout of the device's tables: exclusive prefixes over the paths (first chunk, first band slot) and over the tile-rows (band
-    // list offsets, by a difference array over the paths' tile-row ranges)
-    std::vector<uint32_t> chunk_base(n_paths + 1), slot_base(n_paths + 1), inc_base(n_paths + 1, 0), band_off(n_bands + 2, 0);
+    L.chunk_rows = ROWS_CHUNK;
+    if (r->force_chunk_rows == 16 || r->force_chunk_rows == 32 || r->force_chunk_rows == 64) L.chunk_rows = uint32_t(r->force_chunk_rows);
+    else while (L.chunk_rows > uint32_t(TILE_H) && count_chunks(L.chunk_rows) < 1024) L.chunk_rows >>= 1;
+    L.any_shader = false; L.shader_level = 0;
+    for (size_t i = 0; i < n_styles; ++i) {
+        L.any_shader = L.any_shader || styles[i].kind != SWFR_STYLE_SOLID;
+        L.shader_level = std::max(L.shader_level, styles[i].kind == SWFR_STYLE_SOLID ? 0 : (styles[i].kind == SWFR_STYLE_BITMAP ? 1 : 2));
+    }
+    // exclusive prefixes over the paths (first chunk, first band slot) and over the tile-rows (band list offsets, by a difference
+    // array over the paths' tile-row ranges)
+    L.n_chunks = L.n_slots = L.n_rows = 0;
+    L.chunk_base.assign(n_paths + 1, 0); L.slot_base.assign(n_paths + 1, 0); L.inc_base.assign(n_paths + 1, 0); L.band_off.assign(L.n_bands + 2, 0);
     for (size_t i = 0; i < n_paths; ++i) {
         const swfr_path& p = paths[i];
-        chunk_base[i] = uint32_t(n_chunks); slot_base[i] = uint32_t(n_slots);
-        if (p.kind == SWFR_PATH_TOR && p.y_max > p.y_min) n_chunks += (size_t(p.y_max) - size_t(p.y_min) / TILE_H * TILE_H + chunk_rows - 1) / chunk_rows;
+        L.chunk_base[i] = uint32_t(L.n_chunks); L.slot_base[i] = uint32_t(L.n_slots);
+        if (p.kind == SWFR_PATH_TOR && p.y_max > p.y_min) L.n_chunks += (size_t(p.y_max) - size_t(p.y_min) / TILE_H * TILE_H + L.chunk_rows - 1) / L.chunk_rows;
         if (p.y_max > p.y_min && p.x_max > p.x_min) {
             const size_t b0 = size_t(p.y_min / TILE_H), b1 = size_t((p.y_max - 1) / TILE_H);
-            n_slots += b1 - b0 + 1;
-            ++band_off[b0 + 1]; --band_off[b1 + 2];
+            L.n_slots += b1 - b0 + 1;
+            ++L.band_off[b0 + 1]; --L.band_off[b1 + 2];
         }
-        if (p.kind == SWFR_PATH_TOR) n_rows += size_t(p.y_max - p.y_min);
+        if (p.kind == SWFR_PATH_TOR) L.n_rows += size_t(p.y_max - p.y_min);
     }
-    chunk_base[n_paths] = uint32_t(n_chunks); slot_base[n_paths] = uint32_t(n_slots);
-    for (size_t b = 1; b <= n_bands + 1; ++b) band_off[b] += band_off[b - 1];       // difference array -> counts, shifted by one
-    for (size_t b = 1; b <= n_bands + 1; ++b) band_off[b] += band_off[b - 1];       // counts -> exclusive prefix: band_off[b] = entries of tile-rows < b
-    // ---- the edges, tagged with their path, and a bound on the (edge, pixel row) pairs (every pair yields at most
-    //      MAX_CELLS_PER_EDGE_ROW cells): one pass over the edge list, the same pass that copies it into the staging buffer
-    sc.n_edges = n_edges; sc.n_paths = n_paths; sc.n_styles = n_styles;
-    sc.n_chunks = n_chunks; sc.chunk_rows = chunk_rows; sc.n_bands = n_bands; sc.n_band_entries = n_slots; sc.n_tasks = n_rows;
-    sc.n_strips = size_t(local_tile_rows(r)) * tiles_x * STRIPS_PER_TILE;
-    sc.has_order = r->strip_order != 0;
-    std::vector<DevFilter> filters;
-    std::vector<DevGradient> gradients;
-    std::vector<int32_t> fparams;
-    prepare_sources(paths, n_paths, styles, n_styles, filters, gradients, fparams);
-    SceneArena& A = sc.arena;
-    auto P = SceneArena::padded;
-    A.begin(P(n_edges * sizeof(swfr_edge)) + P(n_paths * sizeof(swfr_path)) + P(n_styles * sizeof(swfr_style)) + P(n_styles * sizeof(DevFilter)) +
-            P(fparams.size() * sizeof(int32_t)) + P(gradients.size() * sizeof(DevGradient)) + P(4 * sizeof(Frame2)) + 3 * P((n_paths + 1) * sizeof(uint32_t)) +
-            P((n_bands + 2) * sizeof(uint32_t)) + 4096);
-    swfr_edge* staged = reinterpret_cast<swfr_edge*>(A.host + A.used);
-    sc.raw = static_cast<swfr_edge*>(A.push(edges, n_edges * sizeof(swfr_edge)));
-    if (!edges_tagged)
-        for (size_t i = 0; i < n_paths; ++i)
-            for (uint32_t k = 0; k < paths[i].n_edges; ++k) staged[paths[i].first_edge + k].reserved = int32_t(i);
-    for (size_t i = 0; i < n_edges; ++i) {              // pixel rows an edge can have a sample row in (a bound: +1 for the rounding of the sample grid)
-        const swfr_edge& e = staged[i];
+    L.chunk_base[n_paths] = uint32_t(L.n_chunks); L.slot_base[n_paths] = uint32_t(L.n_slots);
+    for (size_t b = 1; b <= L.n_bands + 1; ++b) L.band_off[b] += L.band_off[b - 1];       // difference array -> counts, shifted by one
+    for (size_t b = 1; b <= L.n_bands + 1; ++b) L.band_off[b] += L.band_off[b - 1];       // counts -> exclusive prefix: entries of tile-rows < b
+    // pixel rows an edge can have a sample row in (a bound: +1 for the rounding of the sample grid): every (edge, row) pair yields
+    // at most MAX_CELLS_PER_EDGE_ROW cells
+    for (size_t i = 0; i < n_edges; ++i) {
+        const swfr_edge& e = edges[i];
         const swfr_path& p = paths[e.reserved];
         if (p.kind != SWFR_PATH_TOR) continue;
         const int64_t top = std::max<int64_t>(e.top, int64_t(p.y_min) * 256), bot = std::min<int64_t>(e.bottom, int64_t(p.y_max) * 256);
-        if (bot > top) inc_base[size_t(e.reserved) + 1] += uint32_t(((bot + 255) >> 8) - (top >> 8)) + 1;
+        if (bot > top) L.inc_base[size_t(e.reserved) + 1] += uint32_t(((bot + 255) >> 8) - (top >> 8)) + 1;
     }
-    for (size_t i = 0; i < n_paths; ++i) inc_base[i + 1] += inc_base[i];
-    incidences = inc_base[n_paths];
-    sc.n_incidences = incidences;
-    sc.paths = static_cast<DevPath*>(A.push(paths, n_paths * sizeof(swfr_path)));
-    sc.styles = static_cast<swfr_style*>(A.push(styles, n_styles * sizeof(swfr_style)));
-    sc.filters = static_cast<DevFilter*>(A.push(filters.data(), n_styles * sizeof(DevFilter)));
-    sc.filter_params = static_cast<int32_t*>(A.push(fparams.data(), fparams.size() * sizeof(int32_t)));
-    sc.gradients = static_cast<DevGradient*>(A.push(gradients.data(), gradients.size() * sizeof(DevGradient)));
-    const uint32_t* d_chunk_base = static_cast<uint32_t*>(A.push(chunk_base.data(), (n_paths + 1) * sizeof(uint32_t)));
-    const uint32_t* d_slot_base = static_cast<uint32_t*>(A.push(slot_base.data(), (n_paths + 1) * sizeof(uint32_t)));
-    const uint32_t* d_inc_base = static_cast<uint32_t*>(A.push(inc_base.data(), (n_paths + 1) * sizeof(uint32_t)));
-    const uint32_t* d_band_off = static_cast<uint32_t*>(A.push(band_off.data(), (n_bands + 2) * sizeof(uint32_t)));
-    // ---- per-frame (kernel-written) buffers: grow-only allocations; the tables the binning kernels accumulate into are zero
-    //      between frames (the kernels clear what they have read), so a fresh allocation is cleared once
+    for (size_t i = 0; i < n_paths; ++i) L.inc_base[i + 1] += L.inc_base[i];
+    L.incidences = L.inc_base[n_paths];
+    L.cell_main = L.incidences * MAX_CELLS_PER_EDGE_ROW;
+    L.cell_total = L.cell_main * 2 + 4096;
+    if (L.cell_total > 0xfffffff0ull) throw StatusError{SWFR_ERR_CAPACITY, "scene too large for 32-bit cell offsets"};
+    L.n_strips = size_t(local_tile_rows(r)) * tiles_x * STRIPS_PER_TILE;
+    L.filters.clear(); L.gradients.clear(); L.fparams.clear();
+    prepare_sources(paths, n_paths, styles, n_styles, L.filters, L.gradients, L.fparams);
+}
+// bytes of the scene's read-only part in an arena (raw arrays + layout prefixes + sources), each piece padded
+size_t scene_arena_bytes(const SceneLayout& L, size_t n_edges, size_t n_paths, size_t n_styles) {
+    auto P = SceneArena::padded;
+    return P(n_edges * sizeof(swfr_edge)) + P(n_paths * sizeof(swfr_path)) + P(n_styles * sizeof(swfr_style)) + P(n_styles * sizeof(DevFilter)) +
+           P(L.fparams.size() * sizeof(int32_t)) + P(L.gradients.size() * sizeof(DevGradient)) + 3 * P((n_paths + 1) * sizeof(uint32_t)) +
+           P((L.n_bands + 2) * sizeof(uint32_t));
+}
+// pushes that part and fills the descriptor's scene fields; the edge array's host staging copy is returned (for tagging)
+swfr_edge* push_scene(SceneArena& A, const SceneLayout& L, const swfr_edge* edges, size_t n_edges, const swfr_path* paths, size_t n_paths,
+                      const swfr_style* styles, size_t n_styles, Frame2& f) {
+    swfr_edge* staged = reinterpret_cast<swfr_edge*>(A.host + A.used);
+    f.raw = static_cast<swfr_edge*>(A.push(edges, n_edges * sizeof(swfr_edge)));
+    f.paths = static_cast<DevPath*>(A.push(paths, n_paths * sizeof(swfr_path)));
+    f.styles = static_cast<swfr_style*>(A.push(styles, n_styles * sizeof(swfr_style)));
+    f.src.filters = static_cast<DevFilter*>(A.push(L.filters.data(), n_styles * sizeof(DevFilter)));
+    f.src.fparams = static_cast<int32_t*>(A.push(L.fparams.data(), L.fparams.size() * sizeof(int32_t)));
+    f.src.gradients = static_cast<DevGradient*>(A.push(L.gradients.data(), L.gradients.size() * sizeof(DevGradient)));
+    f.path_chunks = static_cast<uint32_t*>(A.push(L.chunk_base.data(), (n_paths + 1) * sizeof(uint32_t)));
+    f.path_slots = static_cast<uint32_t*>(A.push(L.slot_base.data(), (n_paths + 1) * sizeof(uint32_t)));
+    f.path_inc = static_cast<uint32_t*>(A.push(L.inc_base.data(), (n_paths + 1) * sizeof(uint32_t)));
+    f.band_off = static_cast<uint32_t*>(A.push(L.band_off.data(), (L.n_bands + 2) * sizeof(uint32_t)));
+    return staged;
+}
+void fill_frame_sizes(const swfr_renderer* r, const SceneLayout& L, size_t n_edges, size_t n_paths, Frame2& f) {
+    const uint32_t bc = r->cfg.band_count > 1 ? r->cfg.band_count : 1, bi = r->cfg.band_count > 1 ? r->cfg.band_index : 0;
+    f.n_edges = uint32_t(n_edges); f.n_paths = uint32_t(n_paths); f.n_chunks = uint32_t(L.n_chunks); f.n_slots = uint32_t(L.n_slots);
+    f.n_bands = uint32_t(L.n_bands); f.n_strips = uint32_t(L.n_strips); f.cell_slice = uint32_t(L.cell_total); f.slow_cap = uint32_t(L.n_rows + 64);
+    f.width = int32_t(r->width); f.height = int32_t(r->height); f.tiles_x = int32_t((r->width + TILE_W - 1) / TILE_W);
+    f.band_index = bi; f.band_count = bc; f.fast_limit = uint32_t(std::min(std::max(r->fast_limit, 0), 8)); f.any_shader = L.any_shader ? 1u : 0u;
+    f.dbg = uint32_t(r->tiles_dbg); f.cell_heads = 1; f.cell_main = uint32_t(L.cell_main);
+    f.chunk_rows = L.chunk_rows; f.chunk_cap = uint32_t(L.n_chunks + 1); f.slot_cap = uint32_t(L.n_slots + 1); f.strip_order = r->strip_order ? 1u : 0u;
+}
+
+// Pipeline 2: uploads a scene -- the raw edge list, the paths and the styles, plus the layout above -- and sizes the buffers the
+// kernels write.
+int upload2(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, size_t n_edges, const swfr_path* paths, size_t n_paths,
+            const swfr_style* styles, size_t n_styles, uint32_t* fb_override, bool edges_tagged) {
+    swfr_renderer::Scene& sc = r->scn[si];
+    if (si == 0) r->scene_ready = false;
+    sc.slow_state = 0; sc.slow_passes = SLOW_PASSES;
+    if (si > 0 && !r->fs[si].stream) HIP_CHECK(hipStreamCreateWithFlags(&r->fs[si].stream, hipStreamNonBlocking));
+    const hipStream_t up_stream = r->fs[si].stream;
+    const uint32_t tiles_x = (r->width + TILE_W - 1) / TILE_W;
+    std::vector<swfr_edge> tagged;
+    if (!edges_tagged) {
+        tagged.assign(edges, edges + n_edges);
+        for (size_t i = 0; i < n_paths; ++i)
+            for (uint32_t k = 0; k < paths[i].n_edges; ++k) tagged[paths[i].first_edge + k].reserved = int32_t(i);
+        edges = tagged.data();
+    }
+    static thread_local SceneLayout layout_scratch;        // (vectors keep their capacity from frame to frame)
+    SceneLayout& L = layout_scratch;
+    layout_scene(r, edges, n_edges, paths, n_paths, styles, n_styles, L);
+    sc.n_edges = n_edges; sc.n_paths = n_paths; sc.n_styles = n_styles; sc.any_shader = L.any_shader; sc.shader_level = L.shader_level;
+    sc.n_chunks = L.n_chunks; sc.chunk_rows = L.chunk_rows; sc.n_bands = L.n_bands; sc.n_band_entries = L.n_slots; sc.n_tasks = L.n_rows;
+    sc.n_strips = L.n_strips; sc.n_incidences = L.incidences;
+    sc.has_order = r->strip_order != 0;
+    SceneArena& A = sc.arena;
+    A.begin(scene_arena_bytes(L, n_edges, n_paths, n_styles) + SceneArena::padded(4 * sizeof(Frame2)) + 4096);
+    Frame2 proto;
+    std::memset(&proto, 0, sizeof proto);
+    push_scene(A, L, edges, n_edges, paths, n_paths, styles, n_styles, proto);
+    sc.raw = const_cast<swfr_edge*>(proto.raw); sc.paths = const_cast<DevPath*>(proto.paths); sc.styles = const_cast<swfr_style*>(proto.styles);
+    fill_frame_sizes(r, L, n_edges, n_paths, proto);
+    const size_t n_slots = L.n_slots, n_rows = L.n_rows, n_chunks = L.n_chunks;
+    // ---- per-frame (kernel-written) buffers: grow-only allocations
     const int n_sets = std::max(1, std::min(r->in_flight, 4));
     auto reserve_zeroed = [&](DevBuf<uint32_t>& b, size_t n) {
         const uint32_t* before = b.ptr;
         b.reserve(n);
         if (b.ptr != before) HIP_CHECK(hipMemsetAsync(b.ptr, 0, b.cap * sizeof(uint32_t), up_stream));
     };
-    const size_t cell_main = incidences * MAX_CELLS_PER_EDGE_ROW, cell_total = cell_main * 2 + 4096;
-    if (cell_total > 0xfffffff0ull) throw StatusError{SWFR_ERR_CAPACITY, "scene too large for 32-bit cell offsets"};
     for (int k = 0; k < 4; ++k) {
         if (all_sets ? k >= n_sets : k != si) continue;
         auto& x = r->fs[k];
         if (!x.stream) HIP_CHECK(hipStreamCreateWithFlags(&x.stream, hipStreamNonBlocking));
-        x.d_edges.reserve(n_edges); x.d_band2.reserve(n_slots); x.d_rows2.reserve(n_slots * TILE_H + 64); x.d_cells.reserve(cell_total);
-        x.d_slow.reserve(2 * (n_rows + 64)); x.d_huge.reserve(2 * (n_rows + 64));
+        x.d_edges.reserve(n_edges); x.d_band2.reserve(n_slots); x.d_rows2.reserve(n_slots * TILE_H + 64); x.d_cells.reserve(L.cell_total);
+        x.d_slow.reserve(2 * (n_rows + 64)); x.d_huge.reserve(2 * (n_rows + 64));     // (two queues each: a pass reads one and refills the other)
         x.d_path_flag.reserve(n_paths + 64); x.d_path_queue.reserve(n_paths + 64);
-        x.d_chunks.reserve(n_chunks + 1); x.d_band_slots.reserve(n_slots + 1); x.d_strips.reserve(sc.n_strips + 1);
-        reserve_zeroed(x.d_strip_cost, sc.n_strips + 1);
-        x.cell_slice = cell_total; x.slow_cap = n_rows + 64;
+        x.d_chunks.reserve(n_chunks + 1); x.d_band_slots.reserve(n_slots + 1); x.d_strips.reserve(L.n_strips + 1);
+        reserve_zeroed(x.d_strip_cost, L.n_strips + 1);                                 // (zero between frames: the ordering workgroup clears what it has read)
+        x.cell_slice = L.cell_total; x.slow_cap = n_rows + 64;
         x.d_counters.reserve(COUNTER_WORDS);
         x.d_cls.reserve(n_slots * tiles_x + 64);
         // class bytes outside the paths' rectangles are never written by a kernel: cleared once per uploaded scene
@@ -608,27 +675,20 @@ int upload2(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, siz
         }
     }
     if (r->bitmap_table_dirty) r->d_bitmap_table.reserve(r->bitmap_table.size());     // (filled below; the address is what the descriptor needs)
+    proto.src.bitmaps = r->d_bitmap_table.ptr;
     Frame2 fr[4];
     std::memset(fr, 0, sizeof fr);
     for (int k = 0; k < 4; ++k) {
         if (all_sets ? k >= n_sets : k != si) continue;
         auto& x = r->fs[k];
         Frame2& f = fr[k];
-        f.raw = sc.raw; f.paths = sc.paths; f.styles = sc.styles;
-        f.src = Sources{r->d_bitmap_table.ptr, sc.filters, sc.filter_params, sc.gradients};
-        f.chunks = x.d_chunks.ptr; f.band_slots = x.d_band_slots.ptr; f.band_off = d_band_off; f.strips = x.d_strips.ptr;
-        f.path_chunks = d_chunk_base; f.path_slots = d_slot_base; f.path_inc = d_inc_base;
+        f = proto;
+        f.chunks = x.d_chunks.ptr; f.band_slots = x.d_band_slots.ptr; f.strips = x.d_strips.ptr;
         f.band_cnt = nullptr; f.strip_cost = x.d_strip_cost.ptr;
         f.edges = x.d_edges.ptr; f.band_list = x.d_band2.ptr; f.cls = x.d_cls.ptr; f.rows = x.d_rows2.ptr; f.cells = x.d_cells.ptr;
         f.slow = x.d_slow.ptr; f.huge = x.d_huge.ptr; f.counters = x.d_counters.ptr;
         f.path_flag = x.d_path_flag.ptr; f.path_queue = x.d_path_queue.ptr;
         f.fb = (fb_override && k == si) ? fb_override : x.d_fb.ptr;
-        f.n_edges = uint32_t(n_edges); f.n_paths = uint32_t(n_paths); f.n_chunks = uint32_t(n_chunks); f.n_slots = uint32_t(n_slots);
-        f.n_bands = uint32_t(n_bands); f.n_strips = uint32_t(sc.n_strips); f.cell_slice = uint32_t(cell_total); f.slow_cap = uint32_t(x.slow_cap);
-        f.width = int32_t(r->width); f.height = int32_t(r->height); f.tiles_x = int32_t(tiles_x);
-        f.band_index = bi; f.band_count = bc; f.fast_limit = uint32_t(std::min(std::max(r->fast_limit, 0), 8)); f.any_shader = sc.any_shader ? 1u : 0u;
-        f.dbg = uint32_t(r->tiles_dbg); f.cell_heads = 1; f.cell_main = uint32_t(cell_main);
-        f.chunk_rows = chunk_rows; f.chunk_cap = uint32_t(n_chunks + 1); f.slot_cap = uint32_t(n_slots + 1); f.strip_order = r->strip_order ? 1u : 0u;
     }
     sc.frames_dev = static_cast<Frame2*>(A.push(fr, sizeof fr));
     std::memcpy(sc.frames_host, fr, sizeof fr);
@@ -917,16 +977,16 @@ void launch_frame(swfr_renderer* r, const swfr_renderer::Scene& sc, swfr_rendere
     const hipStream_t st = F.stream;
     if (r->pipeline == 2) {
         // the frame's descriptor (scene arrays, this set's buffers, the framebuffer) was written with the scene
-        const Frame2* fh = &sc.frames_host[&F - r->fs];
+        const Frame2* fh = sc.frames_dev + (&F - r->fs);        // the set's descriptor, uploaded with the scene
         if (e) HIP_CHECK(hipEventRecord(e[0], st));
-        launch2_bin(st, fh, nullptr, 1, uint32_t(std::max(sc.n_edges, sc.n_paths)), uint32_t(sc.n_bands));
+        launch2_bin(st, fh, 1, uint32_t(std::max(sc.n_edges, sc.n_paths)), uint32_t(sc.n_bands));
         if (e) HIP_CHECK(hipEventRecord(e[1], st));
-        launch2_rows(st, fh, nullptr, 1, uint32_t(sc.n_chunks));
+        launch2_rows(st, fh, 1, uint32_t(sc.n_chunks));
         // the queued rows (coincident edges, crowded rows): skipped once a frame of this resident scene has shown there are none
-        if (sc.n_chunks && sc.slow_state != 1) launch2_rows_slow(st, fh, nullptr, 1, 1024u, sc.slow_state == 2 ? 0u : 256u, sc.slow_passes);
+        if (sc.n_chunks && sc.slow_state != 1) launch2_rows_slow(st, fh, 1, 1024u, sc.slow_state == 2 ? 0u : 256u, sc.slow_passes);
         if (e) HIP_CHECK(hipEventRecord(e[2], st));
         const uint32_t grid = r->tiles_grid > 0 ? uint32_t(r->tiles_grid) : ~0u;
-        launch2_tiles(st, fh, nullptr, 1, uint32_t(sc.n_strips), grid, sc.any_shader);
+        launch2_tiles(st, fh, 1, uint32_t(sc.n_strips), grid, sc.shader_level);
         if (e) HIP_CHECK(hipEventRecord(e[3], st));
         (void)fb;
         return;
@@ -1084,10 +1144,132 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
 // of frame set i mod n and rasterized on that set's stream straight into device_dst + i * frame_stride, while the host already
 // builds frame i+1.  Nothing waits for the GPU until the end (a scene slot's pinned staging buffer is reused only after its
 // previous H2D copy has completed).
+// swfr_render_batch for pipeline 2 with a device destination: the frames are rendered in groups of SWFR_BATCH_FRAMES (default 64) by
+// one launch per kernel and group (blockIdx.y = frame of the group, every frame with its own descriptor, tables and buffers), so a
+// batch of small frames -- the 256 ratios of a morph shape -- fills the GPU instead of paying a launch chain per frame.  Two groups
+// alternate: the host builds group g + 1 (scene walk, flattening, layout) while the GPU rasterizes group g.
+int render_batch2(swfr_renderer* r, const swfr_stage* stages, uint32_t n, void* device_dst, size_t frame_stride) {
+    struct FrameData { std::vector<swfr_edge> e; std::vector<swfr_path> p; std::vector<swfr_style> s; SceneLayout L; };
+    static thread_local std::vector<FrameData> fd;
+    const uint32_t B = uint32_t(std::max(1, r->batch_frames));
+    const uint32_t tiles_x = (r->width + TILE_W - 1) / TILE_W;
+    auto pad = [](size_t b) { return (b + 255) & ~size_t(255); };
+    if (r->bitmap_table_dirty) {
+        r->d_bitmap_table.reserve(r->bitmap_table.size());
+        if (!r->bitmap_table.empty()) HIP_CHECK(hipMemcpy(r->d_bitmap_table.ptr, r->bitmap_table.data(), r->bitmap_table.size() * sizeof(DevBitmap), hipMemcpyHostToDevice));
+        r->bitmap_table_dirty = false;
+    }
+    int rc = SWFR_OK;
+    double device_ms = 0;                                   // kernels only, summed over the groups (they do not overlap each other much)
+    uint32_t gi = 0;
+    struct Pending { uint32_t first, count; };
+    Pending pend[2] = {{0, 0}, {0, 0}};
+    auto finish_group = [&](int g) {                        // waits for a group's launches and checks its frames' counters
+        auto& G = r->groups[g];
+        if (!pend[g].count) return;
+        HIP_CHECK(hipStreamSynchronize(G.stream));
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, G.ev_begin, G.ev_end) == hipSuccess) device_ms += ms;
+        for (uint32_t k = 0; k < pend[g].count && rc == SWFR_OK; ++k) rc = check_counters(r, G.h_counters + size_t(k) * COUNTER_WORDS);
+        pend[g].count = 0;
+    };
+    for (uint32_t first = 0; first < n && rc == SWFR_OK; first += B, ++gi) {
+        const uint32_t cnt = std::min(B, n - first);
+        const int g = int(gi & 1);
+        auto& G = r->groups[g];
+        if (!G.stream) HIP_CHECK(hipStreamCreateWithFlags(&G.stream, hipStreamNonBlocking));
+        // ---- host: build the group's frames (the other group is being rasterized meanwhile)
+        if (fd.size() < cnt) fd.resize(cnt);
+        size_t arena_bytes = pad(cnt * sizeof(Frame2)) + 4096, work_bytes = 0, cls_bytes = 0;
+        size_t max_ep = 0, max_bands = 0, max_chunks = 0, max_strips = 0;
+        int shader_level = 0;
+        for (uint32_t k = 0; k < cnt; ++k) {
+            FrameData& F = fd[k];
+            r->builder->build(stages[first + k]);
+            F.e = r->builder->edges(); F.p = r->builder->paths(); F.s = r->builder->styles();
+            validate_scene(r, F.e.data(), F.e.size(), F.p.data(), F.p.size(), F.s.data(), F.s.size());
+            layout_scene(r, F.e.data(), F.e.size(), F.p.data(), F.p.size(), F.s.data(), F.s.size(), F.L);
+            arena_bytes += scene_arena_bytes(F.L, F.e.size(), F.p.size(), F.s.size());
+            const SceneLayout& L = F.L;
+            work_bytes += pad(F.e.size() * sizeof(DevEdge)) + pad(L.n_slots * sizeof(BandEntry2)) + pad((L.n_slots * TILE_H + 64) * sizeof(RowInfo2)) +
+                          pad(L.cell_total * sizeof(Cell)) + 2 * pad(2 * (L.n_rows + 64) * sizeof(SlowRow)) + 2 * pad((F.p.size() + 64) * sizeof(uint32_t)) +
+                          pad((L.n_chunks + 1) * sizeof(ChunkInfo)) + pad((L.n_slots + 1) * sizeof(BandSlot)) + pad((L.n_strips + 1) * sizeof(StripDesc)) +
+                          pad((L.n_strips + 1) * sizeof(uint32_t)) + pad(COUNTER_WORDS * sizeof(uint32_t));
+            cls_bytes += pad(L.n_slots * tiles_x + 64);
+            max_ep = std::max(max_ep, std::max(F.e.size(), F.p.size())); max_bands = std::max(max_bands, L.n_bands);
+            max_chunks = std::max(max_chunks, L.n_chunks); max_strips = std::max(max_strips, L.n_strips);
+            shader_level = std::max(shader_level, L.shader_level);
+        }
+        // ---- this group's previous use must be over before its staging and device buffers are rewritten
+        finish_group(g);
+        if (rc != SWFR_OK) break;
+        G.arena.begin(arena_bytes);
+        const uint8_t* work_before = G.work.ptr;
+        G.work.reserve(work_bytes + 4096); G.cls.reserve(cls_bytes + 4096);
+        if (G.work.ptr != work_before) HIP_CHECK(hipMemsetAsync(G.work.ptr, 0, G.work.cap, G.stream));      // (fresh memory: the strip costs start at zero)
+        HIP_CHECK(hipMemsetAsync(G.cls.ptr, 0, cls_bytes, G.stream));                                        // class bytes outside the paths' rectangles
+        if (G.h_counters_cap < cnt) {
+            if (G.h_counters) (void)hipHostFree(G.h_counters);
+            HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&G.h_counters), size_t(B) * COUNTER_WORDS * sizeof(uint32_t), hipHostMallocDefault));
+            G.h_counters_cap = B;
+        }
+        std::vector<Frame2> fr(cnt);
+        uint8_t* w = G.work.ptr;
+        uint8_t* c = G.cls.ptr;
+        auto carve = [&](size_t bytes) { uint8_t* q = w; w += pad(bytes); return q; };
+        for (uint32_t k = 0; k < cnt; ++k) {
+            FrameData& F = fd[k];
+            const SceneLayout& L = F.L;
+            Frame2& f = fr[k];
+            std::memset(&f, 0, sizeof f);
+            push_scene(G.arena, L, F.e.data(), F.e.size(), F.p.data(), F.p.size(), F.s.data(), F.s.size(), f);
+            fill_frame_sizes(r, L, F.e.size(), F.p.size(), f);
+            f.src.bitmaps = r->d_bitmap_table.ptr;
+            f.edges = reinterpret_cast<DevEdge*>(carve(F.e.size() * sizeof(DevEdge)));
+            f.band_list = reinterpret_cast<BandEntry2*>(carve(L.n_slots * sizeof(BandEntry2)));
+            f.rows = reinterpret_cast<RowInfo2*>(carve((L.n_slots * TILE_H + 64) * sizeof(RowInfo2)));
+            f.cells = reinterpret_cast<Cell*>(carve(L.cell_total * sizeof(Cell)));
+            f.slow = reinterpret_cast<SlowRow*>(carve(2 * (L.n_rows + 64) * sizeof(SlowRow)));
+            f.huge = reinterpret_cast<SlowRow*>(carve(2 * (L.n_rows + 64) * sizeof(SlowRow)));
+            f.path_flag = reinterpret_cast<uint32_t*>(carve((F.p.size() + 64) * sizeof(uint32_t)));
+            f.path_queue = reinterpret_cast<uint32_t*>(carve((F.p.size() + 64) * sizeof(uint32_t)));
+            f.chunks = reinterpret_cast<ChunkInfo*>(carve((L.n_chunks + 1) * sizeof(ChunkInfo)));
+            f.band_slots = reinterpret_cast<BandSlot*>(carve((L.n_slots + 1) * sizeof(BandSlot)));
+            f.strips = reinterpret_cast<StripDesc*>(carve((L.n_strips + 1) * sizeof(StripDesc)));
+            f.strip_cost = reinterpret_cast<uint32_t*>(carve((L.n_strips + 1) * sizeof(uint32_t)));
+            f.counters = reinterpret_cast<uint32_t*>(carve(COUNTER_WORDS * sizeof(uint32_t)));
+            f.cls = c; c += pad(L.n_slots * tiles_x + 64);
+            f.strip_order = 0;                              // (a frame's buffers held another frame before: no cost history to order by)
+            f.fb = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(device_dst) + size_t(first + k) * frame_stride);
+        }
+        const Frame2* frames_dev = static_cast<Frame2*>(G.arena.push(fr.data(), cnt * sizeof(Frame2)));
+        G.arena.flush(G.stream);
+        if (!G.ev_begin) { HIP_CHECK(hipEventCreate(&G.ev_begin)); HIP_CHECK(hipEventCreate(&G.ev_end)); }
+        HIP_CHECK(hipEventRecord(G.ev_begin, G.stream));
+        launch2_bin(G.stream, frames_dev, cnt, uint32_t(max_ep), uint32_t(max_bands));
+        launch2_rows(G.stream, frames_dev, cnt, uint32_t(max_chunks));
+        if (max_chunks) launch2_rows_slow(G.stream, frames_dev, cnt, 256u, 64u, SLOW_PASSES);
+        launch2_tiles(G.stream, frames_dev, cnt, uint32_t(max_strips), ~0u, shader_level);
+        HIP_CHECK(hipEventRecord(G.ev_end, G.stream));
+        for (uint32_t k = 0; k < cnt; ++k)
+            HIP_CHECK(hipMemcpyAsync(G.h_counters + size_t(k) * COUNTER_WORDS, fr[k].counters, COUNTER_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, G.stream));
+        HIP_CHECK(hipGetLastError());
+        pend[g] = Pending{first, cnt};
+        r->fb_cur = fr[cnt - 1].fb;
+    }
+    finish_group(0);
+    finish_group(1);
+    r->scene_ready = false;
+    r->fb_valid = rc == SWFR_OK;
+    r->timing = swfr_timing{float(device_ms), 0, 0, 0, n, 0, 0, 0, 0, 0};     // (swfr_last_timing: total_ms = the groups' kernel time)
+    return rc;
+}
+
 int render_batch(swfr_renderer* r, const swfr_stage* stages, uint32_t n, void* device_dst, size_t frame_stride) {
     if (!r->has_device) return fail(r, SWFR_ERR_NO_DEVICE, "host-only handle cannot rasterize");
     if (n == 0) return SWFR_OK;
     if (device_dst && frame_stride < size_t(r->width) * r->height * 4) return fail(r, SWFR_ERR_INVALID, "frame stride smaller than a frame");
+    if (r->pipeline == 2 && device_dst && r->batch_frames > 1) return render_batch2(r, stages, n, device_dst, frame_stride);
     const uint32_t n_sets = uint32_t(std::max(1, std::min(r->in_flight, 4)));
     std::vector<uint32_t*> pinned_counters;
     uint32_t* hc = nullptr;
@@ -1152,6 +1334,7 @@ int swfr_create(uint32_t width, uint32_t height, const swfr_config* cfg, swfr_re
     if (const char* fl = std::getenv("SWFR_FAST_LIMIT")) r->fast_limit = std::atoi(fl);
     if (const char* pl = std::getenv("SWFR_PIPELINE")) r->pipeline = std::atoi(pl) == 1 ? 1 : 2;
     if (const char* tg = std::getenv("SWFR_TILES_GRID")) r->tiles_grid = std::atoi(tg);
+    if (const char* bf = std::getenv("SWFR_BATCH_FRAMES")) r->batch_frames = std::max(1, std::atoi(bf));
     if (const char* td = std::getenv("SWFR_TILES_DEBUG")) r->tiles_dbg = std::atoi(td);
     if (const char* fc = std::getenv("SWFR_FUSED_CLASS")) r->allow_fused = std::atoi(fc);
     if (const char* cr = std::getenv("SWFR_CHUNK_ROWS")) r->force_chunk_rows = std::atoi(cr);

@@ -300,6 +300,30 @@ def test_config3_morph_1080p_vs_oracle():
         assert diff_stats(product_render(sc), oracle_render(sc)) == (0, 0), k
 
 
+def test_config3_morph_256_ratios_1080p_as_one_batch():
+    """BASELINE.json config 3 as the reference runs it (node-canvas-renderer.spec.ts:84-116: one render per ratio) but through
+    swfr_render_batch: 256 ratios at 1920x1080 into one device tensor, groups of frames per kernel launch; a sample of the
+    ratios against the oracle, and every frame against the per-frame path for one more."""
+    import torch
+    import swf_renderer_amd as S
+    tag = fixture("homestuck-beta-29")
+    b, mb = tag["bounds"], tag["morph_bounds"]
+    x0, x1 = min(b["x_min"], mb["x_min"]), max(b["x_max"], mb["x_max"])
+    y0, y1 = min(b["y_min"], mb["y_min"]), max(b["y_max"], mb["y_max"])
+    sx, sy = 1920 * 20 / (x1 - x0), 1080 * 20 / (y1 - y0)
+    stages = [{"children": [{"type": "morph-shape", "definition": tag, "ratio": k / 255, "matrix": scenarios._m(sx, sy, -x0 * sx, -y0 * sy)}]}
+              for k in range(256)]
+    r = S.Renderer(1920, 1080)
+    out = torch.zeros((256, 1080, 1920, 4), dtype=torch.uint8, device="cuda")
+    r.render_batch(stages, out.data_ptr(), 1080 * 1920 * 4)
+    for k in (0, 63, 64, 77, 128, 255):                     # (63 / 64: the last frame of one launch group and the first of the next)
+        got = out[k].cpu().numpy()
+        assert diff_stats(got, oracle_render(dict(width=1920, height=1080, stage=stages[k]))) == (0, 0), k
+    r.render(stages[200])
+    assert (r.read_image(premultiplied=True) == out[200].cpu().numpy()).all()
+    r.close()
+
+
 def test_config4_textured_4k_vs_oracle():
     """Bitmap fill magnified to 3840x2160 (bilinear region of FILTER_GOOD): the HIP shader and the oracle both sample at
     pixman's integer 16.16 positions with its 7-bit weights, so the frames are identical; against libcairo that arithmetic is

@@ -35,6 +35,8 @@ def run(name, W, H, stages, bitmaps=(), resident_frames=200):
     t0 = time.perf_counter()
     r.render_batch(stages, out_t.data_ptr(), H * W * 4)
     dt_batch = (time.perf_counter() - t0) / len(stages)
+    tb = r.timing()
+    dt_batch_dev = tb["total_ms"] * 1e-3 / max(tb["frames"], 1)     # the groups' kernels only (HIP events)
     del out_t
     # device path alone: the last stage's edge list, resident
     edges, paths, styles = r.build_frame(stages[-1])
@@ -47,6 +49,7 @@ def run(name, W, H, stages, bitmaps=(), resident_frames=200):
     out = {"config": name, "frame": "%dx%d" % (W, H), "frames": len(stages), "edges": int(len(edges)), "paths": int(len(paths)),
            "full_path_frames_per_s": round(1 / dt_full, 1), "full_path_Mpx_per_s": round(W * H / dt_full / 1e6, 1),
            "batch_frames_per_s": round(1 / dt_batch, 1), "batch_Mpx_per_s": round(W * H / dt_batch / 1e6, 1),
+           "batch_device_frames_per_s": round(1 / dt_batch_dev, 1) if dt_batch_dev > 0 else None,
            "device_frames_per_s": round(1 / dt_dev, 1), "device_Mpx_per_s": round(W * H / dt_dev / 1e6, 1),
            "kernel_us": {k: round(tm[k + "_ms"] * 1e3 / max(tm["timed_frames"], 1), 1) for k in ("setup", "rows", "tiles")}}
     print(json.dumps(out), flush=True)
