@@ -115,8 +115,14 @@ struct DevFilter {
     int32_t m00, m01, m10, m11;
     int32_t pad;
     int64_t base_x, base_y;
+    // pipeline 2: what the bitmap shader needs of the style and of the bitmap table, so that one load of this record is all it waits for
+    const uint32_t* pixels;  // premultiplied ARGB, tight rows (bitmap styles)
+    uint32_t width, height;
+    uint32_t extend;         // 0 none, 1 repeat
+    uint32_t kind;           // SWFR_STYLE_*
+    uint32_t pad2[2];
 };
-static_assert(sizeof(DevFilter) == 64, "DevFilter layout");
+static_assert(sizeof(DevFilter) == 96, "DevFilter layout");
 
 // A radial gradient as pixman holds it for one drawing operation (host: radial_of; cairo-image-source.c _pixman_image_for_gradient,
 // pixman-radial-gradient.c, pixman-gradient-walker.c): the 16.16 sample position as for bitmaps, the circles after Cairo's

@@ -185,13 +185,12 @@ __device__ __forceinline__ void bin_body(FramePtr F) {
                     uint8_t* out = F->cls + (size_t)F->tiles_x * b0 + at;
                     const int ty0 = band * TILE_H, tile_y1 = min(ty0 + TILE_H, F->height);
                     const uint32_t opq = (e.flags & BE_OPAQUE_COVER) ? CLS_OPAQUE : 0u;
+                    const swfr_edge bx = F->raw[P.first_edge];             // (only looked at when the path is a single box)
+                    const bool one_box = P.n_edges == 1 && bx.y1 <= ty0 * 256 && bx.y2 >= tile_y1 * 256;
                     for (int tc = P.x_min / TILE_W; tc <= (P.x_max - 1) / TILE_W; ++tc) {
                         const int tx0 = tc * TILE_W, tile_x1 = min(tx0 + TILE_W, F->width);
                         uint32_t f = CLS_BOX | CLS_NONEMPTY | CLS_NOTFULL;
-                        if (P.n_edges == 1) {                     // one box that contains the whole tile: full cover
-                            const swfr_edge bx = F->raw[P.first_edge];
-                            if (bx.x1 <= tx0 * 256 && bx.x2 >= tile_x1 * 256 && bx.y1 <= ty0 * 256 && bx.y2 >= tile_y1 * 256) f = CLS_NONEMPTY | opq;
-                        }
+                        if (one_box && bx.x1 <= tx0 * 256 && bx.x2 >= tile_x1 * 256) f = CLS_NONEMPTY | opq;     // the box contains the whole tile: full cover
                         out[(size_t)tc * n_b] = (uint8_t)f;
                     }
                 }
@@ -228,6 +227,26 @@ __device__ __forceinline__ void bin_body(FramePtr F) {
 // the launch list of the tile pass: counting sort of the strips by the cost k2_rows added up during the PREVIOUS frame rendered with
 // these buffers (heaviest first; any order inside a bucket; a scheduling hint only -- a scene's first frame runs in row-major
 // order); the costs are cleared for this frame's k2_rows.  One 1024-thread workgroup, the last one of the k2_bin launch.
+// bucket[k] += 1 for every lane with `valid`; `slot`, when given, receives the lane's old value.  When the wavefront's lanes all
+// name the same bucket (a frame whose strips all cost the same: sixty-four atomics on one LDS word would serialise, every time) one
+// lane adds for all of them; otherwise every lane adds for itself.
+__device__ __forceinline__ void wave_bucket_add(uint32_t* bucket, uint32_t k, bool valid, uint32_t* slot) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long todo = __ballot(valid);
+    if (!todo) return;                                                    // wave-uniform
+    const int leader = __ffsll((long long)todo) - 1;
+    const uint32_t kk = (uint32_t)__builtin_amdgcn_readlane((int)k, leader);
+    const unsigned long long m = __ballot(valid && k == kk);
+    if (m == todo) {                                                      // wave-uniform
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&bucket[kk], (uint32_t)__popcll(m));
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+        if (slot && valid) *slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    } else if (valid) {
+        const uint32_t old = atomicAdd(&bucket[k], 1u);
+        if (slot) *slot = old;
+    }
+}
 #define ORDER_LDS_STRIPS 98304         // strips whose bucket numbers fit the workgroup's LDS (a 12288 x 8192 frame); larger frames re-read the costs
 __device__ __forceinline__ void order_body(FramePtr F) {
     __shared__ uint32_t bucket[ORDER_BUCKETS + 1];
@@ -253,10 +272,10 @@ __device__ __forceinline__ void order_body(FramePtr F) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const uint32_t w = w0 + (uint32_t)u * 1024;
-                if (w >= n_strips) continue;
+                const bool valid = w < n_strips;
                 const uint32_t k = order_bucket(c[u]);
-                atomicAdd(&bucket[k + 1], 1u);
-                if (cached) { bkt[w] = (uint8_t)k; F->strip_cost[w] = 0; }
+                wave_bucket_add(bucket, k + 1, valid, nullptr);          // (one LDS atomic per distinct bucket of the wavefront)
+                if (valid && cached) { bkt[w] = (uint8_t)k; F->strip_cost[w] = 0; }
             }
         }
         lds_barrier();
@@ -272,13 +291,16 @@ __device__ __forceinline__ void order_body(FramePtr F) {
         }
     }
     lds_barrier();
-    for (uint32_t w = (uint32_t)tid; w < n_strips; w += 1024) {
+    for (uint32_t w0 = 0; w0 < n_strips; w0 += 1024) {                 // (workgroup-uniform trip count: the wavefronts vote inside)
+        const uint32_t w = w0 + (uint32_t)tid;
+        const bool valid = w < n_strips;
         uint32_t at = w;
         if (F->strip_order) {
-            uint32_t k;
-            if (cached) k = bkt[w]; else { k = order_bucket(F->strip_cost[w]); F->strip_cost[w] = 0; }
-            at = atomicAdd(&bucket[k], 1u);
+            uint32_t k = 0;
+            if (valid) { if (cached) k = bkt[w]; else { k = order_bucket(F->strip_cost[w]); F->strip_cost[w] = 0; } }
+            wave_bucket_add(bucket, k, valid, &at);
         }
+        if (!valid) continue;
         const uint32_t l = w / per_row;
         uint2 ri;
         if (l < 2048u) ri = rowinfo[l]; else { const uint32_t trow = l * bc + bi, b0 = F->band_off[trow]; ri = make_uint2(b0, F->band_off[trow + 1] - b0); }
@@ -1314,13 +1336,57 @@ __global__ __launch_bounds__(256) void k2_rows_huge_b(const Frame2* __restrict__
 // 16.16 sample positions, bilinear or separable convolution -- the branch of raster_kernels.hip's shade() for bitmaps, inlined);
 // + gradients (that file's shade(): double precision, a call).  A scene gets the lightest instance that covers its styles.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t shade_bitmap(const swfr_style& s, uint32_t style_index, const Sources& src, int px, int py) {
-    const DevBitmap bm = src.bitmaps[s.bitmap];
+// the four texels of a bilinear sample (7-bit weights: what CAIRO_FILTER_GOOD becomes for scales > .75): where they are -- `p`, already
+// clamped / wrapped into the bitmap, so the loads can be issued unconditionally and several pixels' loads together -- which of them lie
+// outside a non-repeating bitmap, and the weights
+struct BilinearTap {
+    const uint32_t* p[2][2];             // [x][y]
+    uint32_t wx, wy;
+    bool oxa, oxb, oya, oyb;
+};
+__device__ __forceinline__ void bilinear_taps(const DevFilter& flt, int px, int py, BilinearTap& t) {
+    const bool repeat = flt.extend == 1;
+    const struct { const uint32_t* pixels; uint32_t width, height; } bm = {flt.pixels, flt.width, flt.height};
+    const long long bxp = flt.base_x + (long long)px * flt.m00 + (long long)py * flt.m01 - 0x8000;     // pixman's 16.16 sample position, half a texel back
+    const long long byp = flt.base_y + (long long)px * flt.m10 + (long long)py * flt.m11 - 0x8000;
+    const int bw = (int)bm.width, bh = (int)bm.height;
+    const int x0 = (int)(bxp >> 16), y0 = (int)(byp >> 16);
+    t.wx = (uint32_t)((bxp >> 9) & 0x7f); t.wy = (uint32_t)((byp >> 9) & 0x7f);
+    int xa = x0, xb = x0 + 1, ya = y0, yb = y0 + 1;
+    t.oxa = t.oxb = t.oya = t.oyb = false;
+    if (repeat) {
+        xa = ((xa % bw) + bw) % bw; xb = xa + 1 == bw ? 0 : xa + 1;
+        ya = ((ya % bh) + bh) % bh; yb = ya + 1 == bh ? 0 : ya + 1;
+    } else {
+        t.oxa = xa < 0 || xa >= bw; t.oxb = xb < 0 || xb >= bw; t.oya = ya < 0 || ya >= bh; t.oyb = yb < 0 || yb >= bh;
+        xa = min(max(xa, 0), bw - 1); xb = min(max(xb, 0), bw - 1); ya = min(max(ya, 0), bh - 1); yb = min(max(yb, 0), bh - 1);
+    }
+    const uint32_t* rowa = bm.pixels + (size_t)ya * bm.width;
+    const uint32_t* rowb = bm.pixels + (size_t)yb * bm.width;
+    t.p[0][0] = rowa + xa; t.p[1][0] = rowa + xb; t.p[0][1] = rowb + xa; t.p[1][1] = rowb + xb;
+}
+__device__ __forceinline__ uint32_t bilinear_mix(const BilinearTap& t, const uint32_t* q00, const uint32_t* q10, const uint32_t* q01, const uint32_t* q11) {
+    uint32_t c00 = *q00, c10 = *q10, c01 = *q01, c11 = *q11;
+    if (t.oxa || t.oya) c00 = 0;
+    if (t.oxb || t.oya) c10 = 0;
+    if (t.oxa || t.oyb) c01 = 0;
+    if (t.oxb || t.oyb) c11 = 0;
+    const uint32_t w00 = (128 - t.wx) * (128 - t.wy), w10 = t.wx * (128 - t.wy), w01 = (128 - t.wx) * t.wy, w11 = t.wx * t.wy;
+    uint32_t out = 0;
+#pragma unroll
+    for (int sh = 0; sh < 32; sh += 8) {
+        const uint32_t acc = ((c00 >> sh) & 255u) * w00 + ((c10 >> sh) & 255u) * w10 + ((c01 >> sh) & 255u) * w01 + ((c11 >> sh) & 255u) * w11;
+        out |= ((acc >> 14) & 255u) << sh;
+    }
+    return out;
+}
+__device__ __forceinline__ uint32_t shade_bitmap(uint32_t style_index, const Sources& src, int px, int py) {
     const DevFilter& flt = src.filters[style_index];
+    const struct { const uint32_t* pixels; uint32_t width, height; } bm = {flt.pixels, flt.width, flt.height};
     // pixman's own 16.16 sample position of this pixel's centre
     const long long fxp = flt.base_x + (long long)px * flt.m00 + (long long)py * flt.m01;
     const long long fyp = flt.base_y + (long long)px * flt.m10 + (long long)py * flt.m11;
-    const bool repeat = s.extend == 1;
+    const bool repeat = flt.extend == 1;
     const int bw = (int)bm.width, bh = (int)bm.height;
     if (flt.on) {
         // CAIRO_FILTER_GOOD below scale 0.75: pixman's separable convolution (integer tables and accumulation)
@@ -1354,31 +1420,9 @@ __device__ __forceinline__ uint32_t shade_bitmap(const swfr_style& s, uint32_t s
         sa = min(max(sa, 0ll), 255ll); sr = min(max(sr, 0ll), 255ll); sg = min(max(sg, 0ll), 255ll); sb = min(max(sb, 0ll), 255ll);
         return ((uint32_t)sa << 24) | ((uint32_t)sr << 16) | ((uint32_t)sg << 8) | (uint32_t)sb;
     }
-    // bilinear with 7-bit weights (what CAIRO_FILTER_GOOD becomes for scales > .75): the four texel loads are issued together
-    const long long bxp = fxp - 0x8000, byp = fyp - 0x8000;
-    const int x0 = (int)(bxp >> 16), y0 = (int)(byp >> 16);
-    const uint32_t wx = (uint32_t)((bxp >> 9) & 0x7f), wy = (uint32_t)((byp >> 9) & 0x7f);
-    int xa = x0, xb = x0 + 1, ya = y0, yb = y0 + 1;
-    bool oxa = false, oxb = false, oya = false, oyb = false;
-    if (repeat) {
-        xa = ((xa % bw) + bw) % bw; xb = xa + 1 == bw ? 0 : xa + 1;
-        ya = ((ya % bh) + bh) % bh; yb = ya + 1 == bh ? 0 : ya + 1;
-    } else {
-        oxa = xa < 0 || xa >= bw; oxb = xb < 0 || xb >= bw; oya = ya < 0 || ya >= bh; oyb = yb < 0 || yb >= bh;
-        xa = min(max(xa, 0), bw - 1); xb = min(max(xb, 0), bw - 1); ya = min(max(ya, 0), bh - 1); yb = min(max(yb, 0), bh - 1);
-    }
-    const uint32_t* rowa = bm.pixels + (size_t)ya * bm.width;
-    const uint32_t* rowb = bm.pixels + (size_t)yb * bm.width;
-    uint32_t c00 = rowa[xa], c10 = rowa[xb], c01 = rowb[xa], c11 = rowb[xb];
-    if (oxa || oya) c00 = 0; if (oxb || oya) c10 = 0; if (oxa || oyb) c01 = 0; if (oxb || oyb) c11 = 0;
-    const uint32_t w00 = (128 - wx) * (128 - wy), w10 = wx * (128 - wy), w01 = (128 - wx) * wy, w11 = wx * wy;
-    uint32_t out = 0;
-#pragma unroll
-    for (int sh = 0; sh < 32; sh += 8) {
-        const uint32_t acc = ((c00 >> sh) & 255u) * w00 + ((c10 >> sh) & 255u) * w10 + ((c01 >> sh) & 255u) * w01 + ((c11 >> sh) & 255u) * w11;
-        out |= ((acc >> 14) & 255u) << sh;
-    }
-    return out;
+    BilinearTap t;
+    bilinear_taps(flt, px, py, t);
+    return bilinear_mix(t, t.p[0][0], t.p[1][0], t.p[0][1], t.p[1][1]);
 }
 // SHADERS: 0 solid colours only, 1 + bitmaps, 2 + gradients
 template <int SHADERS>
@@ -1389,10 +1433,45 @@ __device__ __forceinline__ uint32_t blend2(uint32_t dst, uint32_t a, uint32_t ef
         return over_pixel(a == 255u ? solid : mul_un8(solid, a), dst);
     }
     uint32_t c;
-    if (SHADERS == 1) c = shade_bitmap(styles[style], style, src, cx, cy);
-    else c = styles[style].kind == SWFR_STYLE_BITMAP ? shade_bitmap(styles[style], style, src, cx, cy) : shade(styles[style], style, src, cx, cy);
+    if (SHADERS == 1) c = shade_bitmap(style, src, cx, cy);
+    else c = src.filters[style].kind == SWFR_STYLE_BITMAP ? shade_bitmap(style, src, cx, cy) : shade(styles[style], style, src, cx, cy);
     const uint32_t s = mul_un8(c, a);
     return (eflags & BE_LERP) ? s : over_pixel(s, dst);
+}
+
+// the strip's eight rows of one lane blended with coverages al[]: a bilinear bitmap's texel loads are issued for four rows at a time
+// (thirty-two independent loads in flight per wavefront instead of four), everything else row by row
+template <int SHADERS>
+__device__ __forceinline__ void blend_rows(uint32_t (&px)[STRIP_H], const uint32_t (&al)[STRIP_H], uint32_t eflags, uint32_t solid,
+                                           const swfr_style* __restrict__ styles, uint32_t style, const Sources& src, int cx, int ty0) {
+    if (SHADERS == 0 || (eflags & BE_SOLID)) {
+#pragma unroll
+        for (int u = 0; u < STRIP_H; ++u) { const uint32_t b = blend2<0>(px[u], al[u], eflags, solid, styles, style, src, cx, ty0 + u); px[u] = al[u] ? b : px[u]; }
+        return;
+    }
+    const DevFilter& flt = src.filters[style];
+    if (flt.kind == SWFR_STYLE_BITMAP && !flt.on) {
+#pragma unroll
+        for (int r4 = 0; r4 < STRIP_H; r4 += 4) {
+            if (!(__ballot((al[r4] | al[r4 + 1] | al[r4 + 2] | al[r4 + 3]) != 0u))) continue;       // wave-uniform: nothing to paint in these rows
+            BilinearTap t[4];
+            uint32_t c[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) bilinear_taps(flt, cx, ty0 + r4 + u, t[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { c[u][0] = *t[u].p[0][0]; c[u][1] = *t[u].p[1][0]; c[u][2] = *t[u].p[0][1]; c[u][3] = *t[u].p[1][1]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t col = bilinear_mix(t[u], &c[u][0], &c[u][1], &c[u][2], &c[u][3]);
+                const uint32_t sc = mul_un8(col, al[r4 + u]);
+                const uint32_t b = (eflags & BE_LERP) ? sc : over_pixel(sc, px[r4 + u]);
+                px[r4 + u] = al[r4 + u] ? b : px[r4 + u];
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int u = 0; u < STRIP_H; ++u) if (al[u]) px[u] = blend2<SHADERS>(px[u], al[u], eflags, solid, styles, style, src, cx, ty0 + u);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1504,8 +1583,10 @@ __device__ __forceinline__ void tiles2_body(FramePtr FR) {
                 if (f & CLS_BOX) {
                     // ---- rectilinear (A.6): exact area of disjoint boxes, alpha = (c>>8) - (c>>16)
                     const uint32_t e_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)ent[li][5]), e_nedges = (uint32_t)__builtin_amdgcn_readfirstlane((int)ent[li][6]);
+                    uint32_t al[STRIP_H];
 #pragma unroll
                     for (int rr = 0; rr < STRIP_H; ++rr) {
+                        al[rr] = 0;
                         if (rr < row_lo || rr >= row_hi) continue;         // wave-uniform
                         const int cy = ty0 + rr;
                         uint32_t cov = 0u;
@@ -1515,9 +1596,9 @@ __device__ __forceinline__ void tiles2_body(FramePtr FR) {
                             const int wy = min(bx.y2, (cy + 1) * 256) - max(bx.y1, cy * 256);
                             if (wx > 0 && wy > 0) cov += (uint32_t)(wx * wy);
                         }
-                        const uint32_t a = ((cov >> 8) - (cov >> 16)) & 255u;
-                        if (a) px[rr] = blend2<SHADERS>(px[rr], a, eflags, solid, styles, style, bitmaps, cx, cy);
+                        al[rr] = ((cov >> 8) - (cov >> 16)) & 255u;
                     }
+                    blend_rows<SHADERS>(px, al, eflags, solid, styles, style, bitmaps, cx, ty0);
                 } else if (f & CLS_PARTIAL) {
                     // ---- tor (A.5): the path's cells of this strip's rows
                     if (batch_i == batch_n) {
@@ -1648,20 +1729,15 @@ __device__ __forceinline__ void tiles2_body(FramePtr FR) {
                                 blended = true;
                             }
                         }
-                        if (!blended) {
-#pragma unroll
-                            for (int u = 0; u < STRIP_H; ++u) {
-                                if (SHADERS != 0) { if (al[u]) px[u] = blend2<SHADERS>(px[u], al[u], eflags, solid, styles, style, bitmaps, cx, ty0 + u); }
-                                else { const uint32_t b = blend2<SHADERS>(px[u], al[u], eflags, solid, styles, style, bitmaps, cx, ty0 + u); px[u] = al[u] ? b : px[u]; }
-                            }
-                        }
+                        if (!blended) blend_rows<SHADERS>(px, al, eflags, solid, styles, style, bitmaps, cx, ty0);
                     }
                     lds_barrier();                                       // acc cleared before the next path accumulates
                 } else {
                     // full cover: every in-frame pixel of the path's rows in this tile has coverage 255
+                    uint32_t al[STRIP_H];
 #pragma unroll
-                    for (int rr = 0; rr < STRIP_H; ++rr)
-                        if (rr >= row_lo && rr < row_hi) px[rr] = blend2<SHADERS>(px[rr], 255u, eflags, solid, styles, style, bitmaps, cx, ty0 + rr);
+                    for (int rr = 0; rr < STRIP_H; ++rr) al[rr] = (rr >= row_lo && rr < row_hi) ? 255u : 0u;
+                    blend_rows<SHADERS>(px, al, eflags, solid, styles, style, bitmaps, cx, ty0);
                 }
             }
             lds_barrier();                                               // ent / sel are rewritten by the next round

@@ -489,7 +489,7 @@ DevFilter good_filter(const swfr_style& st, const int rect[4], std::vector<int32
 
 // pixman's view of every bitmap / radial-gradient style of a scene (sample positions, filter tables, colour ramps)
 void prepare_sources(const swfr_path* paths, size_t n_paths, const swfr_style* styles, size_t n_styles, std::vector<DevFilter>& filters,
-                     std::vector<DevGradient>& gradients, std::vector<int32_t>& fparams) {
+                     std::vector<DevGradient>& gradients, std::vector<int32_t>& fparams, const std::vector<DevBitmap>& bitmap_table) {
     filters.assign(n_styles, DevFilter{});
     // a bitmap style belongs to one drawing operation: pixman's transform is anchored at the centre of that operation's rectangle
     std::vector<int> rect(4 * n_styles, 0);
@@ -505,6 +505,11 @@ void prepare_sources(const swfr_path* paths, size_t n_paths, const swfr_style* s
     }
     for (size_t i = 0; i < n_styles; ++i) {
         filters[i] = good_filter(styles[i], &rect[4 * i], fparams);
+        filters[i].kind = styles[i].kind; filters[i].extend = styles[i].extend;
+        if (styles[i].kind == SWFR_STYLE_BITMAP && styles[i].bitmap < bitmap_table.size()) {
+            const DevBitmap& bm = bitmap_table[styles[i].bitmap];
+            filters[i].pixels = bm.pixels; filters[i].width = bm.width; filters[i].height = bm.height;
+        }
         if (styles[i].kind == SWFR_STYLE_RADIAL) {
             gradients.push_back(radial_of(styles[i], &rect[4 * i]));
             filters[i].pad = int32_t(gradients.size());            // index + 1 into the gradient table
@@ -581,7 +586,7 @@ void layout_scene(const swfr_renderer* r, const swfr_edge* edges, size_t n_edges
     if (L.cell_total > 0xfffffff0ull) throw StatusError{SWFR_ERR_CAPACITY, "scene too large for 32-bit cell offsets"};
     L.n_strips = size_t(local_tile_rows(r)) * tiles_x * STRIPS_PER_TILE;
     L.filters.clear(); L.gradients.clear(); L.fparams.clear();
-    prepare_sources(paths, n_paths, styles, n_styles, L.filters, L.gradients, L.fparams);
+    prepare_sources(paths, n_paths, styles, n_styles, L.filters, L.gradients, L.fparams, r->bitmap_table);
 }
 // bytes of the scene's read-only part in an arena (raw arrays + layout prefixes + sources), each piece padded
 size_t scene_arena_bytes(const SceneLayout& L, size_t n_edges, size_t n_paths, size_t n_styles) {
@@ -898,7 +903,7 @@ int upload(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, size
     std::vector<DevFilter> filters;
     std::vector<DevGradient> gradients;
     std::vector<int32_t> fparams;
-    prepare_sources(paths, n_paths, styles, n_styles, filters, gradients, fparams);
+    prepare_sources(paths, n_paths, styles, n_styles, filters, gradients, fparams, r->bitmap_table);
     sc.has_order = !order.empty();
     // the launch list of the tile pass: every strip of this handle's tile-rows with its tile-row's slice of the band list
     std::vector<StripDesc> strips;

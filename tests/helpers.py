@@ -189,6 +189,18 @@ def make_bitmap_tag(bitmap_id, width, height, rng, colors=64):
     return {"type": "define-bitmap", "id": bitmap_id, "width": width, "height": height, "media_type": "image/x-swf-bmp", "data": data.hex()}
 
 
+def large_texture_scene(width=3840, height=2160, tex=4096, seed=99):
+    """BASELINE.json config 4's HBM-bound variant: a frame-filling rectangle with a tex x tex bitmap fill sampled
+    at width / tex pixels per texel (bilinear: every texel of the visible part is fetched about once, nothing stays in a cache)."""
+    import scenarios
+    rng = np.random.default_rng(seed)
+    bmp = make_bitmap_tag(9, tex, tex, rng, colors=256)
+    k = width / tex
+    fill = {"type": "bitmap", "bitmap_id": 9, "repeating": False, "smoothed": True, "matrix": scenarios._m(20 * k, 20 * k, 0, 0)}
+    pts = np.array([(0, 0), (width, 0), (width, height), (0, height)], float)
+    return dict(width=width, height=height, bitmaps=[bmp], stage={"children": [{"type": "shape", "definition": scenarios._poly_shape(np.rint(pts * 20), fill)}]})
+
+
 def rand_bitmap_scene(rng):
     """One random frame of bitmap-filled shapes as the renderer draws them: repeat / no-repeat fills from 20x minified to 30x
     magnified, rotated, reflected, partly off-frame, polygons and (un)aligned rectangles, with translucent solids in between."""

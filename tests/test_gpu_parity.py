@@ -336,6 +336,13 @@ def test_config4_textured_4k_vs_oracle():
     assert diff_stats(product_render(sc), oracle_render(sc)) == (0, 0)
 
 
+def test_config4_large_texture_4k_vs_oracle():
+    """Config 4 with a texture that does not fit a cache (4096 x 4096, 64 MB, sampled about 1:1 over the 4K frame)."""
+    from helpers import large_texture_scene
+    sc = large_texture_scene()
+    assert diff_stats(product_render(sc), oracle_render(sc)) == (0, 0)
+
+
 # ---- full BASELINE sizes
 def _s_scene(cfg):
     from swf_renderer_amd import api, synth

@@ -82,6 +82,15 @@ def main():
     sx, sy = 3840 * 20 / (b["x_max"] - b["x_min"]), 2160 * 20 / (b["y_max"] - b["y_min"])
     st4 = {"children": [{"type": "shape", "definition": tag4, "matrix": m(sx, sy, -b["x_min"] * sx, -b["y_min"] * sy)}]}
     run("config4_textured_4k_magnified", 3840, 2160, [st4] * 20, bitmaps=[fixture("homestuck-beta-3.bitmap")])
+    # ... and the HBM-bound variant: a 4096 x 4096 texture (64 MB) sampled about 1:1
+    from helpers import large_texture_scene
+    big = large_texture_scene()
+    out = run("config4_textured_4k_large_texture", 3840, 2160, [big["stage"]] * 10, bitmaps=big["bitmaps"])
+    if out:
+        texels = 4096 * int(2160 * 4096 / 3840) * 4                       # bytes of the visible part of the texture
+        us = out["kernel_us"]["tiles"]
+        print(json.dumps({"config": "config4_textured_4k_large_texture", "k2_tiles_us": us, "algorithmic_bytes": 4 * 3840 * 2160 + texels,
+                          "achieved_GBps": round((4 * 3840 * 2160 + texels) / us / 1e3, 1), "frac_of_8TBps": round((4 * 3840 * 2160 + texels) / us / 1e3 / 8000, 4)}), flush=True)
 
 
 if __name__ == "__main__":

@@ -10,8 +10,8 @@ OUT = os.path.join(ROOT, "profiles")
 
 
 def one(pattern):
-    f = glob.glob(os.path.join(G, pattern))
-    return f[0] if f else None
+    f = sorted(glob.glob(os.path.join(G, pattern)), key=os.path.getmtime)      # (gpurun_out keeps earlier runs of a tag: the newest)
+    return f[-1] if f else None
 
 
 def kname(n):
