@@ -12,7 +12,8 @@ strips -> tile raster/shade/blend -> RGBA8 framebuffer in HBM.  Consecutive fram
 
 N > 1 (one process per GPU): the frame's tile-rows are sharded over the ranks (north star: "frame tiles shard naturally
 across the 8 GPUs ... with an RCCL gather") -- `--sharding bands`, the default, strong scaling: every step is one frame,
-rank k rasterizes its tile-rows and one gather per frame assembles the image on rank 0.  The same run also measures
+rank k rasterizes its contiguous block of tile-rows straight into a tensor, and one gather per frame deposits the blocks
+in rank 0's image in place, overlapped with the next frame's kernels (swf_renderer_amd/distributed.py).  The same run also measures
 BASELINE.json's config 5 (S2: 8K, 100k edges, same split) and reports it as `config5_s2_bands`.  `--sharding frames`
 (whole frames per rank, no data-path collective, weak scaling) is kept as an explicitly named alternative.
 
@@ -172,19 +173,22 @@ def main():
     def run_bands(cfg_name, cfg, steps, warmup):
         """One frame per step, tile-rows sharded over the ranks, one gather per frame; returns (seconds, image on rank 0, scene)."""
         W, H, pts, cols, fx, stage, scene, _ = scene_of(cfg)
-        rb = S.Renderer(W, H, device=local_rank, band_index=rank, band_count=world)
-        rb.upload_edges(*scene)
-        pipe = D.FramePipeline(rb, W, H, rank, world, device="cpu" if rehearsal else "cuda")
+        rb = S.Renderer(W, H, device=local_rank, band_index=rank, band_count=world, contiguous_bands=True)
+        pipe = D.FramePipeline(rb, W, H, rank, world, device="cpu" if rehearsal else "cuda")   # (targets first: the upload bakes their addresses in)
+        pipe.upload(*scene)
         for _ in range(max(warmup, 1)):
             pipe.step()
         pipe.finish()
         sync_all()
         t0 = time.perf_counter()
         for _ in range(steps):
-            pipe.step()
+            pipe.step()                                           # queue a frame + its gather; no host wait inside the loop
         out = pipe.finish()
         sync_all()
         dt = time.perf_counter() - t0
+        if out is not None:
+            out = out.clone()
+        rb.render_resident(8)                                     # per-kernel HIP-event times of this rank's share (outside the timed region)
         tm = rb.timing()
         rb.close()
         return dt, out, (W, H, fx, cols, scene), tm
@@ -244,7 +248,7 @@ def main():
         n_edges, n_paths = len(edges), len(paths)
         algo_bytes = 4 * W * H + 16 * n_edges + 16 * n_paths           # SURVEY.md 8(d), per frame = per tile-kernel launch
         if bands:
-            algo_bytes = 4 * W * D.local_tile_rows(H, 0, world) * D.TILE_H + 16 * n_edges + 16 * n_paths
+            algo_bytes = 4 * W * min(D.block_rows(H, world) * D.TILE_H, H) + 16 * n_edges + 16 * n_paths
         nt = max(tm["timed_frames"], 1)
         tiles_ms = tm["tiles_ms"] / nt
         achieved = algo_bytes / (tiles_ms * 1e-3) / 1e9 if tiles_ms > 0 else 0.0
@@ -266,9 +270,9 @@ def main():
             "verified": verified,
             "config": {"workload": "%s: %dx%d, %d ten-vertex stars, opaque solid, nonzero, seed 0xC0FFEE" % (args.workload.upper(), W, H, len(fx)),
                        "n_edges": n_edges, "n_paths": n_paths,
-                       "sharding": ("tile-row bands over %d ranks, one RCCL gather per frame" % world) if bands else
+                       "sharding": ("contiguous blocks of tile-rows over %d ranks, rendered in place, one RCCL gather per frame overlapped with the next frame" % world) if bands else
                                    ("whole frames, one per rank and step, no data-path collective" if world > 1 else "single GPU"),
-                       "frames_in_flight": 1 if bands else in_flight,
+                       "frames_in_flight": in_flight,
                        "device_path": "raw edge list -> k2_bin -> k2_rows -> k2_tiles, every frame"},
             "kernel_ms_per_frame": {"k2_bin": round(tm["setup_ms"] / nt, 4), "k2_rows": round(tm["rows_ms"] / nt, 4), "k2_tiles": round(tiles_ms, 4)},
             "roofline": {"bound": "hbm", "kernel": "k2_tiles", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -134,12 +134,16 @@ typedef struct {
 /* ---- configuration ------------------------------------------------------------------------ */
 #define SWFR_DEVICE_HOST_ONLY (-1)       /* decode + geometry only; swfr_render fails with NO_DEVICE */
 #define SWFR_FLAG_EVEN_ODD 1u            /* fill rule override (the reference always uses nonzero) */
+#define SWFR_FLAG_BANDS_CONTIGUOUS 2u    /* multi-GPU: this handle's tile-rows are one contiguous block, see band_index below */
 
 typedef struct {
     int32_t device;                      /* HIP device ordinal, or SWFR_DEVICE_HOST_ONLY */
     uint32_t flags;
-    uint32_t band_index, band_count;     /* multi-GPU: this handle rasterizes tile-rows
-                                            t with t % band_count == band_index (0,0|1 = all) */
+    uint32_t band_index, band_count;     /* multi-GPU: this handle rasterizes the tile-rows (16 pixel rows each) t with
+                                            t % band_count == band_index (0,0|1 = all), or, with SWFR_FLAG_BANDS_CONTIGUOUS,
+                                            the block [band_index * n, (band_index + 1) * n), n = ceil(tile-rows / band_count):
+                                            a rank's part of the frame is then one contiguous range of rows, which a gather can
+                                            deposit in the assembled image without a copy */
 } swfr_config;
 
 /* ---- lifecycle / assets / render ----------------------------------------------------------- */
@@ -249,6 +253,18 @@ int  swfr_render_sequence(swfr_renderer *r, const swfr_stage *stages, uint32_t n
    DEVICE buffer (e.g. a torch tensor's data_ptr) so that the caller can gather it with RCCL. */
 size_t swfr_band_slab_bytes(const swfr_renderer *r);
 int  swfr_copy_band_slab(swfr_renderer *r, void *device_dst);
+
+/* Multi-GPU / pipelined use.  swfr_set_targets: the frames of the resident scene are rendered straight into caller-owned DEVICE
+   buffers (width*height*4 bytes each, premultiplied RGBA8, tight rows; e.g. torch tensors) -- frame set k of the handle (there are
+   SWFR_FRAMES_IN_FLIGHT of them, rotating) writes targets[k]; takes effect with the next swfr_upload_edges.  A handle that owns only
+   some tile-rows writes only those rows.  swfr_render_resident_async queues one frame on the next frame set without waiting and
+   reports which set (and so which target and which stream) it used; swfr_stream_handle gives that set's hipStream_t so that the
+   caller's own streams can be ordered behind / before it with events; swfr_wait blocks until everything queued has finished and
+   reports the kernels' error state like swfr_render_resident does. */
+int  swfr_set_targets(swfr_renderer *r, void *const *device_targets, uint32_t n_targets);
+int  swfr_render_resident_async(swfr_renderer *r, uint32_t *out_set);
+void *swfr_stream_handle(swfr_renderer *r, uint32_t set);
+int  swfr_wait(swfr_renderer *r);
 
 /* Diagnostics (tools/soak_case.py): copies an intermediate buffer of the last rendered frame to the host.
    what = 0: row headers (8 bytes per (path, pixel row): record offset u32, count u16, mode u16); 1: records (48 bytes each).

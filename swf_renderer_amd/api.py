@@ -18,6 +18,7 @@ _LIB = None
 OK, ERR_INVALID, ERR_NOT_IMPLEMENTED, ERR_NOT_FOUND, ERR_NO_DEVICE, ERR_DEVICE, ERR_CAPACITY = range(7)
 DEVICE_HOST_ONLY = -1
 FLAG_EVEN_ODD = 1
+FLAG_BANDS_CONTIGUOUS = 2
 PATH_TOR, PATH_BOXES = 0, 1
 STYLE_SOLID, STYLE_RADIAL, STYLE_LINEAR, STYLE_BITMAP = 0, 1, 2, 3
 MAX_STOPS = 16
@@ -27,7 +28,7 @@ EXPORTS = [
     "swfr_register_morph_shape", "swfr_register_bitmap", "swfr_render", "swfr_render_batch", "swfr_read_image", "swfr_upload_edges",
     "swfr_render_resident", "swfr_render_edges", "swfr_build_frame", "swfr_shape_json", "swfr_last_timing",
     "swfr_band_slab_bytes", "swfr_copy_band_slab", "swfr_device_framebuffer", "swfr_debug_copy", "swfr_last_path_timing",
-    "swfr_render_sequence",
+    "swfr_render_sequence", "swfr_set_targets", "swfr_render_resident_async", "swfr_stream_handle", "swfr_wait",
 ]
 
 
@@ -191,6 +192,14 @@ def load_library():
     L.swfr_debug_copy.argtypes = [P, I, P, C.c_size_t]
     L.swfr_device_framebuffer.restype = P
     L.swfr_device_framebuffer.argtypes = [P]
+    L.swfr_set_targets.restype = I
+    L.swfr_set_targets.argtypes = [P, C.POINTER(C.c_void_p), U]
+    L.swfr_render_resident_async.restype = I
+    L.swfr_render_resident_async.argtypes = [P, C.POINTER(U)]
+    L.swfr_stream_handle.restype = P
+    L.swfr_stream_handle.argtypes = [P, U]
+    L.swfr_wait.restype = I
+    L.swfr_wait.argtypes = [P]
     L.swfr_last_path_timing.restype = I
     L.swfr_last_path_timing.argtypes = [P, C.POINTER(PathTiming)]
     L.swfr_render_sequence.restype = I
@@ -356,10 +365,10 @@ def decode_x_swf_bmp(data: bytes):
 class Renderer:
     """`new NodeCanvasRenderer(width, height)` + `Renderer{render, addBitmap}` over libswfr.so."""
 
-    def __init__(self, width, height, device=0, even_odd=False, band_index=0, band_count=0):
+    def __init__(self, width, height, device=0, even_odd=False, band_index=0, band_count=0, contiguous_bands=False):
         self.L = load_library()
         self.width, self.height = int(width), int(height)
-        cfg = Config(int(device), FLAG_EVEN_ODD if even_odd else 0, band_index, band_count)
+        cfg = Config(int(device), (FLAG_EVEN_ODD if even_odd else 0) | (FLAG_BANDS_CONTIGUOUS if contiguous_bands else 0), band_index, band_count)
         h = C.c_void_p()
         rc = self.L.swfr_create(self.width, self.height, C.byref(cfg), C.byref(h))
         if rc != OK:
@@ -543,12 +552,30 @@ class Renderer:
     def copy_band_slab(self, device_ptr: int):
         self._check(self.L.swfr_copy_band_slab(self.h, device_ptr))
 
+    def set_targets(self, device_ptrs):
+        """Frame set k renders into device_ptrs[k] (full-frame device buffers, e.g. tensor.data_ptr()); upload the scene afterwards."""
+        arr = (C.c_void_p * max(len(device_ptrs), 1))(*[C.c_void_p(p) for p in device_ptrs])
+        self._check(self.L.swfr_set_targets(self.h, arr, len(device_ptrs)))
+
+    def render_resident_async(self) -> int:
+        """Queues one frame of the resident scene without waiting; returns the frame set (target / stream) it runs on."""
+        k = C.c_uint32()
+        self._check(self.L.swfr_render_resident_async(self.h, C.byref(k)))
+        return int(k.value)
+
+    def stream_handle(self, frame_set: int) -> int:
+        return int(self.L.swfr_stream_handle(self.h, frame_set) or 0)
+
+    def wait(self):
+        self._check(self.L.swfr_wait(self.h))
+
     def band_slab(self) -> np.ndarray:
         """This handle's packed tile-rows ([rows, width, 4] uint8, premultiplied) through swfr_copy_band_slab and a device
         buffer -- what a rank hands to the gather."""
         import torch
         rows = self.band_slab_bytes() // (self.width * 4)
-        t = torch.zeros((rows, self.width, 4), dtype=torch.uint8, device="cuda")
+        t = torch.empty((rows, self.width, 4), dtype=torch.uint8, device="cuda")   # (every byte is written by the copy, padding included)
+        torch.cuda.current_stream().synchronize()                                  # nothing of torch's still pending on that memory
         self.copy_band_slab(t.data_ptr())
         torch.cuda.synchronize()
         return t.cpu().numpy()

@@ -157,7 +157,8 @@ struct RowInfo2 {
     uint16_t n;              // cells
     uint16_t mode;           // ROW_* (diagnostics)
 };
-enum : uint32_t { ROW_DEFER = 3 };   // left to the slow-row kernel (coincident edges, or more active edges than the fast kernel keeps)
+enum : uint32_t { ROW_DEFER = 3,     // left to the slow-row kernel (coincident edges, or more active edges than the fast kernel keeps)
+                  ROW_FOREIGN = 4 }; // another handle's tile-row (multi-GPU): never decided here
 
 struct BandEntry2 {
     int16_t x_min, x_max, y_min, y_max;   // the converter's pixel rectangle
@@ -224,7 +225,8 @@ struct Frame2 {
     uint32_t chunk_rows;     // pixel rows per k2_rows wavefront (16, 32 or 64)
     uint32_t chunk_cap, slot_cap;   // capacities of chunks[] / band_slots[] and band_list[] (the host sizes them from the paths' rectangles)
     uint32_t strip_order;    // 0: strips in row-major order, 1: heaviest first
-    uint32_t pad[2];
+    uint32_t band_first, band_stride;   // the handle's tile-rows: band_first + l * band_stride, l < n_strips / (STRIPS_PER_TILE * tiles_x)
+                                        // (interleaved over the ranks: stride = ranks; one contiguous block per rank: stride = 1)
 };
 
 }  // namespace swfr

@@ -45,6 +45,14 @@ typedef const Frame2 __attribute__((address_space(4)))* FramePtr;
 #define FRAME_PTR(frames, i) ((FramePtr)((frames) + (i)))
 #endif
 
+// the handle's share of the frame's tile-rows (multi-GPU): local tile-row l is frame tile-row band_first + l * band_stride
+__device__ __forceinline__ uint32_t local_band_rows(FramePtr FR) { return FR->n_strips / (STRIPS_PER_TILE * (uint32_t)FR->tiles_x); }
+__device__ __forceinline__ bool owns_band(FramePtr FR, int band, uint32_t& local) {
+    const int d = band - (int)FR->band_first;
+    local = (uint32_t)d / FR->band_stride;
+    return d >= 0 && (uint32_t)d % FR->band_stride == 0u && local < local_band_rows(FR);
+}
+
 #define CLS_OPAQUE 32u                // the path is an opaque solid blended with the lerp rule: a full cover of it hides what lies below
 
 // ---------------------------------------------------------------------------------------------
@@ -231,6 +239,10 @@ __device__ __forceinline__ void bin_body(FramePtr F) {
 // name the same bucket (a frame whose strips all cost the same: sixty-four atomics on one LDS word would serialise, every time) one
 // lane adds for all of them; otherwise every lane adds for itself.
 __device__ __forceinline__ void wave_bucket_add(uint32_t* bucket, uint32_t k, bool valid, uint32_t* slot) {
+#ifdef SWFR_NO_AGG
+    if (valid) { const uint32_t old = atomicAdd(&bucket[k], 1u); if (slot) *slot = old; }
+    return;
+#endif
     const int lane = threadIdx.x & 63;
     const unsigned long long todo = __ballot(valid);
     if (!todo) return;                                                    // wave-uniform
@@ -253,7 +265,7 @@ __device__ __forceinline__ void order_body(FramePtr F) {
     __shared__ uint2 rowinfo[2048];                        // per tile-row of the handle: {first band list entry, entries}
     __shared__ uint8_t bkt[ORDER_LDS_STRIPS];
     const int tid = threadIdx.x;
-    const uint32_t n_strips = F->n_strips, bc = F->band_count > 1 ? F->band_count : 1, bi = F->band_count > 1 ? F->band_index : 0;
+    const uint32_t n_strips = F->n_strips, bc = F->band_stride, bi = F->band_first;
     const uint32_t per_row = STRIPS_PER_TILE * (uint32_t)F->tiles_x;
     const uint32_t n_local = n_strips / per_row;
     const bool cached = n_strips <= ORDER_LDS_STRIPS;
@@ -621,7 +633,7 @@ __device__ __forceinline__ void rows2_chunk_body(FramePtr FR, uint32_t block) {
     const DevPath P = FR->paths[lo];
     const int r = (int)ck.first_row + lane;
     const int chunk_rows = (int)ck.rows;                                 // 16, 32 or 64: whole tile-rows, starting on a tile-row boundary
-    const uint32_t band_index = FR->band_index, band_count = FR->band_count;
+
     // the band entry of this lane's tile-row: where its row headers and class bytes go
     const int g16 = lane >> 4;
     const int band = (int)ck.first_row / TILE_H + g16;
@@ -637,7 +649,12 @@ __device__ __forceinline__ void rows2_chunk_body(FramePtr FR, uint32_t block) {
     const uint32_t ri = band_ok ? cls_bs.slot * TILE_H + (uint32_t)(lane & (TILE_H - 1)) : ~0u;
     const bool in_path = P.kind == SWFR_PATH_TOR && lane < chunk_rows && r >= P.y_min && r < P.y_max;
     bool live = in_path;
-    if (live && band_count > 1 && (uint32_t)((r / TILE_H) % band_count) != band_index) live = false;
+    { uint32_t lb; if (live && !owns_band(FR, r / TILE_H, lb)) live = false; }         // another rank's tile-row
+    if (__ballot(live) == 0ull) {
+        // nothing of this chunk is this handle's (multi-GPU): its rows stay "not known here" for the slow rows' history look-ups
+        if (ri != ~0u && lane < chunk_rows) { RowInfo2 h; h.off = 0; h.n = 0; h.mode = (uint16_t)(in_path ? ROW_FOREIGN : ROW_EMPTY); FR->rows[ri] = h; }
+        return;
+    }
     int fast_limit = (int)FR->fast_limit;
     if (P.n_edges > 65535u) fast_limit = 0;                             // 16-bit local edge indices in the fast path
     R2PHASE(0);
@@ -671,7 +688,7 @@ __device__ __forceinline__ void rows2_chunk_body(FramePtr FR, uint32_t block) {
     // ---- FULL rows: cells of every boundary edge, densely packed behind the wavefront's allocation
     const bool emit = mode == ROW_FULL && ri != ~0u && !slow;
     if (ri != ~0u && lane < chunk_rows && mode != ROW_SUB) {            // (the SUB rows' headers were written with their cells)
-        RowInfo2 h; h.off = 0; h.n = 0; h.mode = (uint16_t)((slow || (in_path && !live)) ? ROW_DEFER : mode);   // (another rank's row: not known here)
+        RowInfo2 h; h.off = 0; h.n = 0; h.mode = (uint16_t)(slow ? ROW_DEFER : (in_path && !live) ? ROW_FOREIGN : mode);   // (another rank's row: not known here)
         if (emit && base != ~0u) {
             uint32_t off = base + incl - (uint32_t)n_cells;
             h.off = off; h.n = (uint16_t)n_cells;
@@ -768,9 +785,9 @@ __device__ __forceinline__ void rows2_chunk_body(FramePtr FR, uint32_t block) {
             // strips first): lanes 0 and 8 of the tile-row's sixteen add their half's rows
             if (FR->strip_order) {
                 const unsigned long long pb = __ballot(row_partial);
-                if ((lane & 7) == 0 && band_ok && (f & CLS_PARTIAL) && (band_count <= 1 || (uint32_t)band % band_count == band_index)) {
+                uint32_t local_trow = 0;
+                if ((lane & 7) == 0 && band_ok && (f & CLS_PARTIAL) && owns_band(FR, band, local_trow)) {
                     const uint32_t wgt = (uint32_t)__popcll((pb >> lane) & 0xffull);
-                    const uint32_t local_trow = band_count > 1 ? (uint32_t)band / band_count : (uint32_t)band;
                     if (wgt) atomicAdd(&FR->strip_cost[((size_t)local_trow * FR->tiles_x + tc) * STRIPS_PER_TILE + ((lane >> 3) & 1)], wgt);
                 }
             }
@@ -1505,7 +1522,7 @@ __device__ __forceinline__ void tiles2_body(FramePtr FR) {
         const int tile = (int)(wg / STRIPS_PER_TILE), strip = (int)(wg % STRIPS_PER_TILE);
         const int tcol = tile % tiles_x;
         int trow = tile / tiles_x;
-        if (FR->band_count > 1) trow = trow * (int)FR->band_count + (int)FR->band_index;
+        trow = (int)FR->band_first + trow * (int)FR->band_stride;
         const int tx0 = tcol * TILE_W, ty0 = trow * TILE_H + strip * STRIP_H;
         if (ty0 >= height) continue;
         const int cx = tx0 + lane;

@@ -411,7 +411,7 @@ __device__ __forceinline__ bool row_was_sampled(const PathEdges& PE, int rho) {
         const uint32_t m = PE.known_mode(rho);
         if (m == ROW_SUB) return true;
         if (m == ROW_FULL || m == ROW_EMPTY) return false;
-        if (PE.retry && rho >= PE.P->y_min && rho < PE.P->y_max) { *PE.retry = 1u; return false; }   // that row is queued, too: next pass
+        if (m == ROW_DEFER && PE.retry && rho >= PE.P->y_min && rho < PE.P->y_max) { *PE.retry = 1u; return false; }   // that row is queued, too: next pass
     }
     const int s = rho * 15;
     const uint32_t ne = PE.size();

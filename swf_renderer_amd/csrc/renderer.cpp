@@ -229,6 +229,8 @@ struct swfr_renderer {
     };
     BatchGroup groups[2];
     int batch_frames = 64;                  // SWFR_BATCH_FRAMES: frames per launch in swfr_render_batch
+    uint32_t* targets[4] = {nullptr, nullptr, nullptr, nullptr};   // swfr_set_targets: frame set k renders into targets[k]
+    uint32_t n_targets = 0, async_next = 0, async_used = 0;   // async_used: bit k = frame set k has run since the last wait
     Frame2* d_frames = nullptr;             // one descriptor per frame set, contiguous: a batch of frames is one launch
     Frame2* h_frames = nullptr;             // pinned staging of the same
 
@@ -283,12 +285,19 @@ int guarded(swfr_renderer* r, F&& f) {
     }
 }
 
-uint32_t local_tile_rows(const swfr_renderer* r) {
+// the handle's share of the frame's tile-rows: local tile-row l is frame tile-row first + l * stride, l < count; `padded` = the
+// share of the best-served rank (slabs are gathered at that common size)
+struct BandShare { uint32_t first, stride, count, padded; };
+BandShare band_share(const swfr_renderer* r) {
     const uint32_t tile_rows = (r->height + TILE_H - 1) / TILE_H;
     const uint32_t bc = r->cfg.band_count > 1 ? r->cfg.band_count : 1, bi = r->cfg.band_count > 1 ? r->cfg.band_index : 0;
-    if (tile_rows <= bi) return 0;
-    return (tile_rows - bi + bc - 1) / bc;
+    if (bc > 1 && (r->cfg.flags & SWFR_FLAG_BANDS_CONTIGUOUS)) {
+        const uint32_t n = (tile_rows + bc - 1) / bc, first = bi * n;
+        return BandShare{first, 1u, first >= tile_rows ? 0u : std::min(n, tile_rows - first), n};
+    }
+    return BandShare{bi, bc, tile_rows <= bi ? 0u : (tile_rows - bi + bc - 1) / bc, (tile_rows + bc - 1) / bc};
 }
+uint32_t local_tile_rows(const swfr_renderer* r) { return band_share(r).count; }
 
 // Validate a caller-supplied scene so that no kernel can index out of bounds.
 void validate_scene(const swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_path* paths, size_t n_paths,
@@ -617,6 +626,8 @@ void fill_frame_sizes(const swfr_renderer* r, const SceneLayout& L, size_t n_edg
     f.n_bands = uint32_t(L.n_bands); f.n_strips = uint32_t(L.n_strips); f.cell_slice = uint32_t(L.cell_total); f.slow_cap = uint32_t(L.n_rows + 64);
     f.width = int32_t(r->width); f.height = int32_t(r->height); f.tiles_x = int32_t((r->width + TILE_W - 1) / TILE_W);
     f.band_index = bi; f.band_count = bc; f.fast_limit = uint32_t(std::min(std::max(r->fast_limit, 0), 8)); f.any_shader = L.any_shader ? 1u : 0u;
+    const BandShare bs = band_share(r);
+    f.band_first = bs.first; f.band_stride = bs.stride;
     f.dbg = uint32_t(r->tiles_dbg); f.cell_heads = 1; f.cell_main = uint32_t(L.cell_main);
     f.chunk_rows = L.chunk_rows; f.chunk_cap = uint32_t(L.n_chunks + 1); f.slot_cap = uint32_t(L.n_slots + 1); f.strip_order = r->strip_order ? 1u : 0u;
 }
@@ -693,7 +704,7 @@ int upload2(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, siz
         f.edges = x.d_edges.ptr; f.band_list = x.d_band2.ptr; f.cls = x.d_cls.ptr; f.rows = x.d_rows2.ptr; f.cells = x.d_cells.ptr;
         f.slow = x.d_slow.ptr; f.huge = x.d_huge.ptr; f.counters = x.d_counters.ptr;
         f.path_flag = x.d_path_flag.ptr; f.path_queue = x.d_path_queue.ptr;
-        f.fb = (fb_override && k == si) ? fb_override : x.d_fb.ptr;
+        f.fb = (fb_override && k == si) ? fb_override : (r->n_targets ? r->targets[uint32_t(k) % r->n_targets] : x.d_fb.ptr);
     }
     sc.frames_dev = static_cast<Frame2*>(A.push(fr, sizeof fr));
     std::memcpy(sc.frames_host, fr, sizeof fr);
@@ -1550,18 +1561,77 @@ int swfr_last_timing(swfr_renderer* r, swfr_timing* out) {
 
 size_t swfr_band_slab_bytes(const swfr_renderer* r) {
     if (!r) return 0;
-    return size_t(local_tile_rows(r)) * TILE_H * r->width * 4;
+    const BandShare bs = band_share(r);
+    return size_t(bs.stride == 1 && r->cfg.band_count > 1 ? bs.padded : bs.count) * TILE_H * r->width * 4;    // (contiguous blocks: every rank's slab has the common size)
 }
 
 int swfr_copy_band_slab(swfr_renderer* r, void* device_dst) {
     if (!r || !device_dst) return fail(r, SWFR_ERR_INVALID, "null argument");
     if (!r->has_device) return fail(r, SWFR_ERR_NO_DEVICE, "host-only handle");
     return guarded(r, [&]() {
+        const BandShare bs = band_share(r);
+        if (bs.stride == 1 && r->cfg.band_count > 1) {         // one contiguous block of rows: a plain copy, zero padding behind it
+            const uint32_t* fb = r->fb_cur ? r->fb_cur : r->fs[0].d_fb.ptr;
+            const size_t row_bytes = size_t(r->width) * 4, y0 = size_t(bs.first) * TILE_H;
+            const size_t rows = y0 >= r->height ? 0 : std::min<size_t>(size_t(bs.count) * TILE_H, r->height - y0);
+            if (rows) HIP_CHECK(hipMemcpyAsync(device_dst, reinterpret_cast<const uint8_t*>(fb) + y0 * row_bytes, rows * row_bytes, hipMemcpyDeviceToDevice, r->stream));
+            const size_t total = size_t(bs.padded) * TILE_H;
+            if (total > rows) HIP_CHECK(hipMemsetAsync(static_cast<uint8_t*>(device_dst) + rows * row_bytes, 0, (total - rows) * row_bytes, r->stream));
+            HIP_CHECK(hipStreamSynchronize(r->stream));
+            return int(SWFR_OK);
+        }
         const uint32_t bc = r->cfg.band_count > 1 ? r->cfg.band_count : 1, bi = r->cfg.band_count > 1 ? r->cfg.band_index : 0;
         launch_pack_band(r->stream, r->fb_cur ? r->fb_cur : r->fs[0].d_fb.ptr, static_cast<uint32_t*>(device_dst), int(r->width), int(r->height), bi, bc, local_tile_rows(r));
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipStreamSynchronize(r->stream));
         return int(SWFR_OK);
+    });
+}
+
+int swfr_set_targets(swfr_renderer* r, void* const* device_targets, uint32_t n_targets) {
+    if (!r || n_targets > 4 || (n_targets && !device_targets)) return fail(r, SWFR_ERR_INVALID, "bad targets");
+    r->n_targets = n_targets;
+    for (uint32_t k = 0; k < n_targets; ++k) r->targets[k] = static_cast<uint32_t*>(device_targets[k]);
+    r->scene_ready = false;                               // the frame descriptors carry the framebuffer address: upload again
+    return SWFR_OK;
+}
+
+int swfr_render_resident_async(swfr_renderer* r, uint32_t* out_set) {
+    if (!r) return SWFR_ERR_INVALID;
+    if (!r->has_device) return fail(r, SWFR_ERR_NO_DEVICE, "host-only handle cannot rasterize");
+    if (!r->scene_ready || r->pipeline != 2) return fail(r, SWFR_ERR_INVALID, "no scene uploaded");
+    return guarded(r, [&]() {
+        uint32_t n_sets = 1;
+        while (n_sets < uint32_t(std::min(r->in_flight, 4)) && r->fs[n_sets].stream && r->fs[n_sets].d_cells.ptr) ++n_sets;
+        const uint32_t k = r->async_next++ % n_sets;
+        r->async_used |= 1u << k;
+        swfr_renderer::FrameSet& F = r->fs[k];
+        launch_frame(r, r->scn[0], F, nullptr, nullptr);
+        HIP_CHECK(hipGetLastError());
+        r->fb_cur = r->n_targets ? r->targets[k % r->n_targets] : F.d_fb.ptr;
+        if (out_set) *out_set = k;
+        return int(SWFR_OK);
+    });
+}
+
+void* swfr_stream_handle(swfr_renderer* r, uint32_t set) { return (r && r->has_device && set < 4) ? static_cast<void*>(r->fs[set].stream) : nullptr; }
+
+int swfr_wait(swfr_renderer* r) {
+    if (!r) return SWFR_ERR_INVALID;
+    if (!r->has_device) return fail(r, SWFR_ERR_NO_DEVICE, "host-only handle");
+    return guarded(r, [&]() {
+        if (!r->h_counters) HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&r->h_counters), 4 * COUNTER_WORDS * sizeof(uint32_t), hipHostMallocDefault));
+        int rc = SWFR_OK;
+        for (uint32_t k = 0; k < 4; ++k) {
+            if (!r->fs[k].stream || !r->fs[k].d_counters.ptr) continue;
+            if (!(r->async_used >> k & 1u)) { HIP_CHECK(hipStreamSynchronize(r->fs[k].stream)); continue; }
+            HIP_CHECK(hipMemcpyAsync(r->h_counters + k * COUNTER_WORDS, r->fs[k].d_counters.ptr, COUNTER_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, r->fs[k].stream));
+            HIP_CHECK(hipStreamSynchronize(r->fs[k].stream));
+            if (rc == SWFR_OK && r->pipeline == 2) rc = check_counters(r, r->h_counters + k * COUNTER_WORDS);
+        }
+        r->async_used = 0;
+        r->fb_valid = rc == SWFR_OK;
+        return rc;
     });
 }
 

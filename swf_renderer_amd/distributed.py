@@ -1,10 +1,14 @@
-"""Multi-GPU frame assembly: tile-row bands sharded over ranks, one gather to the root.
+"""Multi-GPU frame assembly: the frame's tile-rows sharded over the ranks, one gather to the root.
 
-The frame is cut into tile-rows of TILE_H pixel rows; rank k of N rasterizes the tile-rows t with
-t % N == k (interleaving balances edge density).  Every rank holds the whole (small) edge list, so the
-data path has exactly one exchange step: each rank's packed band slab goes to the root
-(`torch.distributed.gather`, RCCL over xGMI on GPUs, gloo on CPU tensors for tests) where the bands are
-de-interleaved into the final image.  There is no collective inside rasterization.
+The frame is cut into tile-rows of TILE_H pixel rows.  Every rank holds the whole (small) edge list and rasterizes only its share,
+so the data path has exactly one exchange step per frame: each rank's rows go to the root (`torch.distributed.gather`: RCCL over
+xGMI on GPUs, gloo on CPU tensors for tests).  There is no collective inside rasterization.
+
+Two ways to share the tile-rows out (swfr_config.band_index / band_count):
+  * contiguous blocks (SWFR_FLAG_BANDS_CONTIGUOUS; what FramePipeline uses): rank k owns tile-rows [k*n, (k+1)*n), n = ceil(T / N).
+    A rank's rows are one contiguous piece of the image, so it renders them straight into a tensor and the gather deposits them
+    in the root's image in place -- no pack kernel on the sender, no de-interleave pass on the root.
+  * interleaved (t % N == k): balances a scene whose edge density varies from top to bottom; needs `assemble` on the root.
 """
 from __future__ import annotations
 
@@ -13,11 +17,26 @@ import numpy as np
 TILE_H = 16
 
 
+def tile_rows(height: int) -> int:
+    return (height + TILE_H - 1) // TILE_H
+
+
 def local_tile_rows(height: int, rank: int, world: int) -> int:
-    tile_rows = (height + TILE_H - 1) // TILE_H
+    """Interleaved split: tile-rows t with t % world == rank."""
+    t = tile_rows(height)
     if world <= 1:
-        return tile_rows
-    return 0 if tile_rows <= rank else (tile_rows - rank + world - 1) // world
+        return t
+    return 0 if t <= rank else (t - rank + world - 1) // world
+
+
+def block_rows(height: int, world: int) -> int:
+    """Contiguous split: tile-rows per rank (the last ranks may own fewer, or none)."""
+    return (tile_rows(height) + max(world, 1) - 1) // max(world, 1)
+
+
+def padded_height(height: int, world: int) -> int:
+    """Pixel rows of an image that holds `world` equally sized contiguous blocks (>= height)."""
+    return block_rows(height, world) * TILE_H * max(world, 1)
 
 
 def slab_shape(width: int, height: int, rank: int, world: int):
@@ -29,7 +48,7 @@ def max_slab_rows(height: int, world: int) -> int:
 
 
 def extract_slab(image: np.ndarray, rank: int, world: int) -> np.ndarray:
-    """The band slab rank `rank` would produce from a full image (rows past the frame are zero)."""
+    """The interleaved band slab rank `rank` would produce from a full image (rows past the frame are zero)."""
     h, w = image.shape[:2]
     n = local_tile_rows(h, rank, world)
     out = np.zeros((n * TILE_H, w, 4), dtype=image.dtype)
@@ -41,7 +60,7 @@ def extract_slab(image: np.ndarray, rank: int, world: int) -> np.ndarray:
 
 
 def assemble(slabs, width: int, height: int):
-    """De-interleave per-rank slabs (numpy or torch, [rows, width, 4]) into the final HxWx4 image.
+    """De-interleave per-rank slabs of the interleaved split (numpy or torch, [rows, width, 4]) into the final HxWx4 image.
 
     With equally padded slabs this is one permute + copy: [world, n, TILE_H, W, 4] -> [n, world, TILE_H, W, 4].
     """
@@ -63,8 +82,17 @@ def assemble(slabs, width: int, height: int):
     return np.ascontiguousarray(stacked.transpose(1, 0, 2, 3, 4).reshape(n * world * TILE_H, width, 4)[:height])
 
 
+def assemble_blocks(slabs, width: int, height: int):
+    """Contiguous split: the padded per-rank slabs are simply stacked (what the in-place gather produces without any copy)."""
+    is_torch = hasattr(slabs[0], "new_zeros")
+    if is_torch:
+        import torch
+        return torch.cat(list(slabs))[:height].contiguous()
+    return np.ascontiguousarray(np.concatenate(list(slabs))[:height])
+
+
 def gather_slabs(slab, width: int, height: int, rank: int, world: int, dst: int = 0):
-    """One gather of the padded band slabs to `dst`; returns the assembled image there, None elsewhere.
+    """One gather of the padded interleaved band slabs to `dst`; returns the assembled image there, None elsewhere.
 
     `slab` is a torch tensor [rows, width, 4] uint8 on the device of the process group's backend.
     Slabs are padded to the largest rank's row count so the collective is uniform.
@@ -87,62 +115,95 @@ def gather_slabs(slab, width: int, height: int, rank: int, world: int, dst: int 
 
 
 class FramePipeline:
-    """N>1 step = render this rank's bands, pack them, gather to rank 0, assemble -- with the gather and the
-    assembly of frame k overlapping the rasterization of frame k+1.
+    """N>1 step = render this rank's block of tile-rows, gather the blocks to the root -- in place, and overlapped.
 
-    The renderer works on its own HIP stream; the collective and the de-interleave run on torch's streams.
-    `depth` slabs rotate; a slab is reused only after the event recorded behind its assembly has completed.
+    Every rank's handle (contiguous bands) renders straight into torch tensors (`swfr_set_targets`): `depth` full-frame buffers
+    that the handle's frame sets rotate over, each on its own HIP stream.  A step queues one frame (`swfr_render_resident_async`,
+    no host wait), lets torch's stream wait for that frame set's stream, and starts the gather of the rank's rows -- a contiguous
+    view of the buffer -- into the matching views of the root's padded image, where they land at their final place: no pack kernel,
+    no de-interleave pass.  The gather of frame f runs while frame f + 1 is rasterized into the next buffer; a buffer is rendered
+    into again only after the event behind its gather (the renderer's stream waits for it, not the host).
     """
 
-    def __init__(self, renderer, width, height, rank, world, device="cuda", depth=3, dst=0):
+    def __init__(self, renderer, width, height, rank, world, device="cuda", depth=None, dst=0, frames_device="cuda"):
+        import os
         import torch
+        if depth is None:                                            # one buffer per frame set of the handle (SWFR_FRAMES_IN_FLIGHT, default 3)
+            depth = min(4, max(1, int(os.environ.get("SWFR_FRAMES_IN_FLIGHT", "3"))))
         self.r, self.w, self.h, self.rank, self.world, self.dst = renderer, width, height, rank, world, dst
-        self.device = device
-        rows = max_slab_rows(height, world)
-        on_gpu = device != "cpu"
-        self.stage = [torch.zeros((rows, width, 4), dtype=torch.uint8, device="cuda") for _ in range(depth)]
-        self.cpu_slabs = None if on_gpu else [torch.zeros((rows, width, 4), dtype=torch.uint8) for _ in range(depth)]
-        self.bufs = None
+        self.on_gpu = device != "cpu"                                # where the collective runs (NCCL/RCCL on device tensors, gloo on CPU ones)
+        self.streams = frames_device != "cpu"                        # False only under tools/emu, whose "device" memory is host memory
+        self.rows = block_rows(height, world) * TILE_H               # pixel rows per rank (padded: the last block may reach past the frame)
+        self.hp = self.rows * world
+        self.depth = depth
+        self.frames = [torch.zeros((self.hp, width, 4), dtype=torch.uint8, device=frames_device) for _ in range(depth)]
+        renderer.set_targets([f.data_ptr() for f in self.frames])
+        self.image = None
         if rank == dst:
-            self.bufs = [[torch.empty((rows, width, 4), dtype=torch.uint8, device=device) for _ in range(world)] for _ in range(depth)]
+            self.image = [torch.zeros((self.hp, width, 4), dtype=torch.uint8, device=device) for _ in range(depth)]
+        self.cpu_send = None if self.on_gpu else [torch.zeros((self.rows, width, 4), dtype=torch.uint8) for _ in range(depth)]
+        self.ext = {}
         self.events = [None] * depth
-        self.works = [None] * depth
-        self.k = 0
         self.last = None
+        self.uploaded = False
+        self._n = 0
+
+    def upload(self, edges, paths, styles):
+        self.r.upload_edges(edges, paths, styles)                    # (after set_targets: the descriptors carry the buffers' addresses)
+        self.uploaded = True
+
+    def _stream(self, k):
+        import torch
+        if k not in self.ext:
+            self.ext[k] = torch.cuda.ExternalStream(self.r.stream_handle(k))
+        return self.ext[k]
 
     def step(self):
         import torch
         import torch.distributed as dist
-        i = self.k % len(self.stage)
-        self.k += 1
-        if self.works[i] is not None:
-            self.works[i].wait()
-            self.works[i] = None
-        if self.events[i] is not None:
-            self.events[i].synchronize()                   # the slab's previous gather + assembly are done
-        self.r.render_resident(1)                          # blocking on the renderer's stream
-        self.r.copy_band_slab(self.stage[i].data_ptr())    # packed tile-rows, zero padded to the common size
-        send = self.stage[i]
-        if self.cpu_slabs is not None:                     # gloo rehearsal: collectives on CPU tensors
-            self.cpu_slabs[i].copy_(send)
-            send = self.cpu_slabs[i]
-        work = dist.gather(send, gather_list=self.bufs[i] if self.rank == self.dst else None, dst=self.dst, async_op=True)
-        if self.cpu_slabs is not None:
-            work.wait()
+        k = self._queue()
+        i = k % self.depth
+        if self.streams:
+            cur = torch.cuda.current_stream()
+            cur.wait_stream(self._stream(k))                         # torch's stream: behind this frame's kernels
         else:
-            work.wait()                                    # NCCL: makes the current stream wait, not the host
+            self.r.wait()
+        y0 = self.rank * self.rows
+        send = self.frames[i][y0:y0 + self.rows]                     # this rank's rows: one contiguous view
+        out = None
         if self.rank == self.dst:
-            self.last = assemble(self.bufs[i], self.w, self.h)
-        if self.cpu_slabs is None:
+            out = self.image[i]
+            views = [out[q * self.rows:(q + 1) * self.rows] for q in range(self.world)]
+        else:
+            views = None
+        if not self.on_gpu:                                          # gloo rehearsal: the collective runs on CPU tensors
+            if self.streams:
+                self.cpu_send[i].copy_(send)                         # (blocking device-to-host copy on torch's stream)
+                send = self.cpu_send[i]
+            dist.gather(send, gather_list=views, dst=self.dst)
+        else:
+            dist.gather(send, gather_list=views, dst=self.dst)       # NCCL: queued on torch's stream, lands in place
             ev = torch.cuda.Event()
-            ev.record()
+            ev.record(cur)
             self.events[i] = ev
+        if self.rank == self.dst:
+            self.last = out[: self.h]
         return self.last
+
+    def _queue(self):
+        # order the next frame set's stream behind the gather that last read its buffer, then queue the frame
+        nxt = self._n
+        self._n = nxt + 1
+        i = nxt % self.depth
+        if self.streams and self.events[i] is not None:
+            self._stream(i).wait_event(self.events[i])
+        k = self.r.render_resident_async()
+        assert k % self.depth == i, "frame sets and buffers rotate together"
+        return k
 
     def finish(self):
         import torch
-        for w in self.works:
-            if w is not None:
-                w.wait()
-        torch.cuda.synchronize()
+        self.r.wait()
+        if self.streams:
+            torch.cuda.synchronize()
         return self.last

@@ -21,6 +21,40 @@ def test_band_bookkeeping_and_roundtrip():
         assert (D.assemble(slabs, w, h) == img).all()
 
 
+def test_contiguous_block_bookkeeping():
+    rng = np.random.default_rng(1)
+    for (w, h, world) in [(70, 45, 2), (64, 16, 4), (33, 200, 8), (10, 1, 2), (128, 2160, 8), (16, 4320, 8), (8, 100, 3)]:
+        n = D.block_rows(h, world)
+        assert 0 <= n * world - D.tile_rows(h) < world                # every tile-row has an owner, blocks as small as that allows
+        assert D.padded_height(h, world) == n * 16 * world >= h
+        img = np.zeros((D.padded_height(h, world), w, 4), dtype=np.uint8)
+        img[:h] = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        blocks = [img[k * n * 16:(k + 1) * n * 16] for k in range(world)]
+        assert (D.assemble_blocks(blocks, w, h) == img[:h]).all()
+
+
+def _spawn(script, world, timeout, args=()):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world))
+    procs = [subprocess.Popen([sys.executable, str(script), *args], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(world)]
+    outs = [p.communicate(timeout=timeout)[0].decode() for p in procs]
+    return procs, outs
+
+
+def test_gloo_world2_frame_pipeline_renders_blocks_and_gathers_in_place():
+    """The whole N>1 step on CPU, world_size 2: each rank's handle owns a contiguous block of tile-rows and rasterizes it with the
+    product's kernels under the wavefront emulator (tools/emu: the .hip sources compiled as C++), FramePipeline gathers the
+    blocks over gloo straight into the root's image, and the root compares four consecutive frames with the oracle."""
+    import shutil
+    if shutil.which("g++") is None:
+        import pytest
+        pytest.skip("the emulator build needs g++")
+    procs, outs = _spawn(os.path.join(ROOT, "tools", "emu", "dist_check.py"), 2, 900, ("stroke_curves",))
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "DIST_OK" in outs[0] and "stroke_curves 3 (0, 0)" in outs[0]
+
+
 def test_gloo_world2_gather_assembles_frame(tmp_path):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     script = tmp_path / "worker.py"

@@ -414,6 +414,68 @@ def test_s2_8k_sharded_over_eight_band_handles_vs_oracle():
     assert diff_stats(D.assemble(slabs, W, H), _oracle_polys(fx, cols, W, H)) == (0, 0)
 
 
+def test_s2_8k_eight_contiguous_block_handles_render_into_one_image():
+    """The N>1 data path FramePipeline uses, on one GPU: eight handles with SWFR_FLAG_BANDS_CONTIGUOUS, handle k owning tile-rows
+    [k*n, (k+1)*n), all rendering straight into ONE padded device image through swfr_set_targets + swfr_render_resident_async
+    (no slab copy, no assembly pass).  The image equals the CPU oracle's frame; rows past the frame stay zero."""
+    import torch
+    import swf_renderer_amd as S
+    from swf_renderer_amd import synth, distributed as D
+    W, H, fx, cols, (edges, paths, styles) = _s_scene(synth.S2)
+    world = 8
+    hp = D.padded_height(H, world)
+    image = torch.zeros((hp, W, 4), dtype=torch.uint8, device="cuda")
+    handles = []
+    for rank in range(world):
+        rb = S.Renderer(W, H, band_index=rank, band_count=world, contiguous_bands=True)
+        rb.set_targets([image.data_ptr()])
+        rb.upload_edges(edges, paths, styles)
+        assert rb.render_resident_async() == 0
+        handles.append(rb)
+    for rb in handles:
+        rb.wait()
+        rb.close()
+    torch.cuda.synchronize()
+    out = image.cpu().numpy()
+    assert not out[H:].any()
+    assert diff_stats(out[:H], _oracle_polys(fx, cols, W, H)) == (0, 0)
+
+
+def test_frame_pipeline_over_rccl_single_rank():
+    """FramePipeline on the real backend ("nccl" = RCCL) with the one rank this box has: set_targets, async frames on the handle's
+    streams, torch's stream waiting for them, the in-place gather (send-to-self here) and the buffer-release events, eight steps
+    over three buffers; the S1 frame equals the libcairo known answer.  (N>1 ranks: tests/test_distributed.py, gloo.)"""
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="1", RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "nccl_pipeline_worker.py")],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert p.returncode == 0 and b"PIPELINE_OK" in p.stdout, p.stdout.decode()[-3000:]
+
+
+def test_contiguous_blocks_three_handles_ragged_height_and_slab_copy():
+    """A frame whose tile-rows do not divide by the handle count (the last block is short, and one handle may own nothing):
+    per-handle block slabs (swfr_copy_band_slab) stacked by distributed.assemble_blocks equal the oracle."""
+    import swf_renderer_amd as S
+    from swf_renderer_amd import distributed as D
+    sc = SC["stroke_curves"]
+    w, h = sc["width"], sc["height"]
+    want = oracle_render(sc)
+    for world in (3, 7, D.tile_rows(h) + 2):
+        slabs = []
+        for rank in range(world):
+            rb = S.Renderer(w, h, band_index=rank, band_count=world, contiguous_bands=True)
+            rb.render(sc["stage"])
+            slab = rb.band_slab()
+            full = np.zeros((D.block_rows(h, world) * 16, w, 4), dtype=np.uint8)
+            full[:slab.shape[0]] = slab
+            slabs.append(full)
+            rb.close()
+        assert diff_stats(D.assemble_blocks(slabs, w, h), want) == (0, 0), world
+
+
 # ---- edge cases
 def test_empty_ragged_and_tiny_frames():
     import swf_renderer_amd as S
