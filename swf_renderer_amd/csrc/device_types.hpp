@@ -203,6 +203,12 @@ struct StripDesc {
 };
 
 // Everything the kernels need to know about one frame (device memory; blockIdx.y indexes an array of these).
+constexpr uint32_t XCDS = 8;            // a launch's workgroups go round-robin over the chip's eight XCDs, each with its own L2
+// slots of the tile pass's launch list: slot % XCDS = the XCD the hardware hands the workgroup to = (local tile-row) % XCDS, so that
+// everything the strips of one tile-row read (its band list, class bytes, row headers, cells) is fetched into ONE L2; the classes
+// are padded to the size of the largest (slots without a strip: wg = ~0u)
+inline uint32_t strip_slots(uint32_t local_tile_rows, uint32_t strips_per_row) { return XCDS * ((local_tile_rows + XCDS - 1) / XCDS) * strips_per_row; }
+
 struct Frame2 {
     // the scene (read-only)
     const swfr_edge* raw; const DevPath* paths; const swfr_style* styles;
@@ -225,6 +231,7 @@ struct Frame2 {
     uint32_t chunk_rows;     // pixel rows per k2_rows wavefront (16, 32 or 64)
     uint32_t chunk_cap, slot_cap;   // capacities of chunks[] / band_slots[] and band_list[] (the host sizes them from the paths' rectangles)
     uint32_t strip_order;    // 0: strips in row-major order, 1: heaviest first
+    uint32_t n_strip_slots;             // launch list slots of the tile pass: XCDS * ceil(local tile-rows / XCDS) * strips per tile-row (strip_slots())
     uint32_t band_first, band_stride;   // the handle's tile-rows: band_first + l * band_stride, l < n_strips / (STRIPS_PER_TILE * tiles_x)
                                         // (interleaved over the ranks: stride = ranks; one contiguous block per rank: stride = 1)
 };

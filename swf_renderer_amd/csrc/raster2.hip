@@ -45,6 +45,19 @@ typedef const Frame2 __attribute__((address_space(4)))* FramePtr;
 #define FRAME_PTR(frames, i) ((FramePtr)((frames) + (i)))
 #endif
 
+#ifdef SWFR_TRACE                  // -DSWFR_TRACE (diagnostic builds, tools/trace_wg.py): 100 MHz wall-clock stamps per workgroup of the three kernels
+#define TRACE_WGS 32768
+__device__ uint32_t swfr_trace_buf[3][TRACE_WGS][8];
+#define TRACE_DECL uint32_t tr_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define TRACE(i) do { __builtin_amdgcn_s_waitcnt(0); tr_[i] = (uint32_t)__builtin_amdgcn_s_memrealtime(); } while (0)
+#define TRACE_NOWAIT(i) do { tr_[i] = (uint32_t)__builtin_amdgcn_s_memrealtime(); } while (0)
+#define TRACE_OUT(k, slot) do { if ((threadIdx.x & 63) == 0 && (slot) < TRACE_WGS) { for (int i_ = 0; i_ < 8; ++i_) swfr_trace_buf[k][slot][i_] = tr_[i_]; } } while (0)
+#else
+#define TRACE_DECL do { } while (0)
+#define TRACE(i) do { } while (0)
+#define TRACE_NOWAIT(i) do { } while (0)
+#define TRACE_OUT(k, slot) do { } while (0)
+#endif
 // the handle's share of the frame's tile-rows (multi-GPU): local tile-row l is frame tile-row band_first + l * band_stride
 __device__ __forceinline__ uint32_t local_band_rows(FramePtr FR) { return FR->n_strips / (STRIPS_PER_TILE * (uint32_t)FR->tiles_x); }
 __device__ __forceinline__ bool owns_band(FramePtr FR, int band, uint32_t& local) {
@@ -260,8 +273,12 @@ __device__ __forceinline__ void wave_bucket_add(uint32_t* bucket, uint32_t k, bo
     }
 }
 #define ORDER_LDS_STRIPS 98304         // strips whose bucket numbers fit the workgroup's LDS (a 12288 x 8192 frame); larger frames re-read the costs
+// Slot of a strip in the launch list: XCDS * (its rank among the strips of its class) + class, class = local tile-row % XCDS.  The
+// hardware deals a launch's workgroups round-robin over the XCDs, so all strips of a tile-row run on one XCD and share its L2.
+// Ranks: heaviest first by the previous frame's costs (counting sort per class), or row-major when there is no cost history.
 __device__ __forceinline__ void order_body(FramePtr F) {
-    __shared__ uint32_t bucket[ORDER_BUCKETS + 1];
+    constexpr uint32_t NB = ORDER_BUCKETS + 1;
+    __shared__ uint32_t bucket[XCDS * NB];
     __shared__ uint2 rowinfo[2048];                        // per tile-row of the handle: {first band list entry, entries}
     __shared__ uint8_t bkt[ORDER_LDS_STRIPS];
     const int tid = threadIdx.x;
@@ -273,8 +290,17 @@ __device__ __forceinline__ void order_body(FramePtr F) {
         const uint32_t trow = l * bc + bi, b0 = F->band_off[trow];
         rowinfo[l] = make_uint2(b0, F->band_off[trow + 1] - b0);
     }
+    // slots of the smaller classes (one tile-row fewer than the largest) that stay without a strip
+    {
+        const uint32_t max_rows = (n_local + XCDS - 1) / XCDS;
+        for (uint32_t i = (uint32_t)tid; i < XCDS * per_row; i += 1024) {
+            const uint32_t x = i / per_row, j = i % per_row;
+            const uint32_t rows_x = (n_local + XCDS - 1 - x) / XCDS;
+            if (rows_x < max_rows) { StripDesc sd; sd.wg = ~0u; sd.band_begin = 0; sd.n_b = 0; sd.pad = 0; F->strips[(size_t)(rows_x * per_row + j) * XCDS + x] = sd; }
+        }
+    }
     if (F->strip_order) {
-        for (uint32_t b = (uint32_t)tid; b <= ORDER_BUCKETS; b += 1024) bucket[b] = 0;
+        for (uint32_t b = (uint32_t)tid; b < XCDS * NB; b += 1024) bucket[b] = 0;
         lds_barrier();
         // every cost is read once (four independent loads in flight per thread), its bucket number kept in LDS, the costs cleared
         for (uint32_t w0 = (uint32_t)tid; w0 < n_strips; w0 += 4096) {
@@ -286,18 +312,20 @@ __device__ __forceinline__ void order_body(FramePtr F) {
                 const uint32_t w = w0 + (uint32_t)u * 1024;
                 const bool valid = w < n_strips;
                 const uint32_t k = order_bucket(c[u]);
-                wave_bucket_add(bucket, k + 1, valid, nullptr);          // (one LDS atomic per distinct bucket of the wavefront)
+                const uint32_t x = (w / per_row) % XCDS;
+                wave_bucket_add(bucket, x * NB + k + 1, valid, nullptr);  // (one LDS atomic per wavefront when its lanes agree; k + 1 <= ORDER_BUCKETS)
                 if (valid && cached) { bkt[w] = (uint8_t)k; F->strip_cost[w] = 0; }
             }
         }
         lds_barrier();
-        if (tid < 64) {                                   // prefix of the 128 bucket sizes by one wavefront
+        if (tid < 64 * (int)XCDS) {                       // prefix of a class's bucket sizes: one wavefront per class
+            const uint32_t x = (uint32_t)tid >> 6, lane = (uint32_t)tid & 63u;
             uint32_t carry = 0;
-            for (uint32_t base = 0; base <= ORDER_BUCKETS; base += 64) {
-                const uint32_t b = base + (uint32_t)tid;
-                const uint32_t x = b <= ORDER_BUCKETS ? bucket[b] : 0u;
-                const uint32_t incl = (uint32_t)wave_scan_incl((int)x);
-                if (b <= ORDER_BUCKETS) bucket[b] = carry + incl;          // bucket[b] = first slot of bucket b (its size was stored at b + 1)
+            for (uint32_t base = 0; base < NB; base += 64) {
+                const uint32_t b = base + lane;
+                const uint32_t v = b < NB ? bucket[x * NB + b] : 0u;
+                const uint32_t incl = (uint32_t)wave_scan_incl((int)v);
+                if (b < NB) bucket[x * NB + b] = carry + incl;                 // bucket[b] = first rank of bucket b (its size was stored at b + 1)
                 carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             }
         }
@@ -306,21 +334,21 @@ __device__ __forceinline__ void order_body(FramePtr F) {
     for (uint32_t w0 = 0; w0 < n_strips; w0 += 1024) {                 // (workgroup-uniform trip count: the wavefronts vote inside)
         const uint32_t w = w0 + (uint32_t)tid;
         const bool valid = w < n_strips;
-        uint32_t at = w;
+        const uint32_t l = w / per_row, x = l % XCDS;
+        uint32_t rank = (l / XCDS) * per_row + (w - l * per_row);      // row-major inside the class
         if (F->strip_order) {
             uint32_t k = 0;
             if (valid) { if (cached) k = bkt[w]; else { k = order_bucket(F->strip_cost[w]); F->strip_cost[w] = 0; } }
-            wave_bucket_add(bucket, k, valid, &at);
+            wave_bucket_add(bucket, x * NB + k, valid, &rank);
         }
         if (!valid) continue;
-        const uint32_t l = w / per_row;
         uint2 ri;
         if (l < 2048u) ri = rowinfo[l]; else { const uint32_t trow = l * bc + bi, b0 = F->band_off[trow]; ri = make_uint2(b0, F->band_off[trow + 1] - b0); }
         StripDesc sd; sd.wg = w; sd.band_begin = ri.x; sd.n_b = ri.y; sd.pad = 0;
-        F->strips[at] = sd;
+        F->strips[(size_t)rank * XCDS + x] = sd;
     }
 }
-__global__ __launch_bounds__(1024) void k2_bin_b(const Frame2* __restrict__ frames) { bin_body(FRAME_PTR(frames, blockIdx.y)); }
+__global__ __launch_bounds__(1024) void k2_bin_b(const Frame2* __restrict__ frames) { TRACE_DECL; TRACE_NOWAIT(0); bin_body(FRAME_PTR(frames, blockIdx.y)); TRACE(7); TRACE_OUT(0, blockIdx.x); }
 
 // ---------------------------------------------------------------------------------------------
 // k2_rows
@@ -802,10 +830,20 @@ __device__ __forceinline__ void rows2_chunk_body(FramePtr FR, uint32_t block) {
 #endif
 }
 
-__global__ __launch_bounds__(64) void k2_rows_b(const Frame2* __restrict__ frames) {
+#ifdef R2_WAVES
+#define R2_ATTR __attribute__((amdgpu_waves_per_eu(R2_WAVES)))
+#else
+#define R2_ATTR
+#endif
+__global__ __launch_bounds__(64) R2_ATTR void k2_rows_b(const Frame2* __restrict__ frames) {
+    TRACE_DECL;
+    TRACE_NOWAIT(0);
     FramePtr FR = FRAME_PTR(frames, blockIdx.y);
     if (blockIdx.x >= FR->n_chunks) return;
+    TRACE(1);
     rows2_chunk_body(FR, blockIdx.x);
+    TRACE(7);
+    TRACE_OUT(1, blockIdx.x);
 }
 
 
@@ -1496,13 +1534,16 @@ __device__ __forceinline__ void blend_rows(uint32_t (&px)[STRIP_H], const uint32
 // ---------------------------------------------------------------------------------------------
 #define T2_LIST 32                     // band entries of a tile kept per round (lane = list position; lanes 32.. fetch the row headers)
 #define T2_PRE 1                       // rounds of 64 cells of a batch fetched ahead into registers
+#ifndef T2_ACC_STRIDE
+#define T2_ACC_STRIDE 65               // 64 cells + the carry slot (65 rather than 66: 28 wavefronts' LDS fit a CU)
+#endif
 
 // One wavefront per strip of the launch list (heaviest first when the scene has an order); lane = pixel column; the strip's eight
 // rows of pixels live in registers until the single store.  Dependent memory round trips per strip: strip descriptor -> class
 // bytes -> {band entries, row headers} -> cells.
 template <int SHADERS>
 __device__ __forceinline__ void tiles2_body(FramePtr FR) {
-    __shared__ __attribute__((aligned(16))) int acc[STRIP_H][ACC_STRIDE];   // also the queue of the compacted blend (8-byte pairs)
+    __shared__ __attribute__((aligned(16))) int acc[STRIP_H][T2_ACC_STRIDE];   // also the queue of the compacted blend (8-byte pairs)
     __shared__ __attribute__((aligned(16))) uint32_t ent[T2_LIST][8];       // BandEntry2 as dwords
     __shared__ __attribute__((aligned(16))) uint32_t rinfo[T2_LIST][2 * STRIP_H];   // the strip's eight RowInfo2 of a tor entry
     __shared__ uint32_t sel[T2_LIST];                                       // list position -> band list index | class << 24
@@ -1510,15 +1551,25 @@ __device__ __forceinline__ void tiles2_body(FramePtr FR) {
     __shared__ int plist[PBATCH];
 
     const int lane = threadIdx.x;
+    TRACE_DECL;
+    TRACE_NOWAIT(0);
     const int width = FR->width, height = FR->height, tiles_x = FR->tiles_x;
     const swfr_style* __restrict__ styles = FR->styles;
     const Sources bitmaps = {FR->src.bitmaps, FR->src.filters, FR->src.fparams, FR->src.gradients};
-    for (int i = lane; i < STRIP_H * ACC_STRIDE; i += 64) (&acc[0][0])[i] = 0;
+    for (int i = lane; i < STRIP_H * T2_ACC_STRIDE; i += 64) (&acc[0][0])[i] = 0;
     lds_barrier();
 
-    for (uint32_t w = blockIdx.x; w < FR->n_strips; w += gridDim.x) {
+#ifdef T2_PRIO_SHIFT
+    // the launch list is heaviest first: the strips at its head are the kernel's critical path, so their wavefronts take the
+    // issue slots ahead of the light ones they share a SIMD with
+    if (FR->strip_order && blockIdx.x < (FR->n_strip_slots >> T2_PRIO_SHIFT)) __builtin_amdgcn_s_setprio(3);
+#endif
+    for (uint32_t w = blockIdx.x; w < FR->n_strip_slots; w += gridDim.x) {
+        TRACE(1);                                                        // descriptor fields in
         const StripDesc sd = FR->strips[w];
         const uint32_t wg = sd.wg;
+        if (wg == ~0u) continue;                                         // a padding slot of the launch list
+        TRACE(2);                                                        // strip descriptor in
         const int tile = (int)(wg / STRIPS_PER_TILE), strip = (int)(wg % STRIPS_PER_TILE);
         const int tcol = tile % tiles_x;
         int trow = tile / tiles_x;
@@ -1553,6 +1604,7 @@ __device__ __forceinline__ void tiles2_body(FramePtr FR) {
                 ln += cnt;
             }
             lds_barrier();                                      // sel written by other lanes
+            TRACE(3);                                           // class bytes in
             // ---- occlusion, from the class bytes alone: everything below the last opaque full cover is invisible in this tile
             int start = 0;
             {
@@ -1581,6 +1633,7 @@ __device__ __forceinline__ void tiles2_body(FramePtr FR) {
                 }
             }
             lds_barrier();
+            TRACE(4);                                           // entries + row headers in
 
             // ---- painter's order walk
             int batch_n = 0, batch_i = 0;
@@ -1658,6 +1711,7 @@ __device__ __forceinline__ void tiles2_body(FramePtr FR) {
                                 if (g < (uint32_t)total) pre[u] = FR->cells[seg_off[lo] + (g - seg_start[lo])];
                             }
                         }
+                        TRACE(5);                                       // (last batch's) first cells in
                     }
                     const int bp = batch_i++;
                     const int g0 = (int)__builtin_amdgcn_readfirstlane((int)seg_start[bp * STRIP_H]);
@@ -1686,7 +1740,7 @@ __device__ __forceinline__ void tiles2_body(FramePtr FR) {
                         }
                     }
                     lds_barrier();                                       // acc complete
-                    int (*A)[ACC_STRIDE] = acc;
+                    int (*A)[T2_ACC_STRIDE] = acc;
                     // ---- prefix sum, alpha, blend; clears as it reads.  All eight rows in one straight-line block so that their LDS
                     //      round trips and DPP scan chains interleave; a row nothing was accumulated into scans zeros
                     {
@@ -1759,6 +1813,7 @@ __device__ __forceinline__ void tiles2_body(FramePtr FR) {
             }
             lds_barrier();                                               // ent / sel are rewritten by the next round
         }
+        TRACE_NOWAIT(6);
         // ---- one store per pixel: premultiplied R,G,B,A bytes; the wave writes 256 contiguous bytes per row
         if (cx < width) {
             uint32_t* rowp = FR->fb + (size_t)ty0 * (size_t)width + cx;
@@ -1771,6 +1826,8 @@ __device__ __forceinline__ void tiles2_body(FramePtr FR) {
                 rowp += width;
             }
         }
+        TRACE(7);                                                        // stores acknowledged
+        TRACE_OUT(2, w);
     }
 }
 
@@ -1812,3 +1869,11 @@ void launch2_tiles(hipStream_t st, const Frame2* frames, uint32_t n_frames, uint
 }
 
 }  // namespace swfr
+
+#ifdef SWFR_TRACE
+extern "C" __attribute__((visibility("default"))) int swfr_debug_trace(void* dst, size_t bytes) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    const size_t n = bytes < sizeof(swfr::swfr_trace_buf) ? bytes : sizeof(swfr::swfr_trace_buf);
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(swfr::swfr_trace_buf), n, 0, hipMemcpyDeviceToHost) == hipSuccess ? (int)(n / 32) : -1;
+}
+#endif

@@ -1921,7 +1921,9 @@ __global__ __launch_bounds__(64) void k_class(const BandEntry* __restrict__ band
 #define TLIST 32                       // tile list entries per round
 #define REC_STAGE 32                   // records staged in LDS per round
 #define P2B 8                          // rows scanned + blended per straight-line step
+#ifndef BLEND_QUEUE
 #define BLEND_QUEUE 256                // edge pixels of one (path, strip) blended in compacted form; the accumulator holds 264 pairs
+#endif
 #define PBATCH (64 / STRIP_H)           // partial paths whose row headers and records are fetched in one round trip each
 
 template <bool SHADERS>

@@ -167,7 +167,7 @@ struct swfr_renderer {
                chunk_rows = 64, n_band_entries = 0;
         bool any_shader = false, fused_class = false, fused_front = false, has_order = false;
         int shader_level = 0;
-        size_t n_incidences = 0, n_strips = 0;   // (edge, pixel row) pairs: bounds the cells of a frame; k_tiles wavefronts
+        size_t n_incidences = 0, n_strips = 0, n_strip_slots = 0;   // (edge, pixel row) pairs: bounds the cells of a frame; k_tiles wavefronts
         Frame2* frames_dev = nullptr;            // pipeline 2: one descriptor per frame set (contiguous, in the arena)
         Frame2 frames_host[4];                   // ... and on the host: a single frame's launches pass theirs by value
         StripDesc* strips = nullptr;
@@ -531,7 +531,7 @@ void prepare_sources(const swfr_path* paths, size_t n_paths, const swfr_style* s
 // and over the tile-rows) -- plus pixman's view of the bitmap / gradient styles.  No binning: that is the device's work, per frame.
 struct SceneLayout {
     uint32_t chunk_rows = ROWS_CHUNK;
-    size_t n_chunks = 0, n_slots = 0, n_rows = 0, n_bands = 0, n_strips = 0, incidences = 0, cell_main = 0, cell_total = 0;
+    size_t n_chunks = 0, n_slots = 0, n_rows = 0, n_bands = 0, n_strips = 0, n_strip_slots = 0, incidences = 0, cell_main = 0, cell_total = 0;
     bool any_shader = false;
     int shader_level = 0;       // 0 solid colours only, 1 + bitmap fills, 2 + gradients: picks the tile kernel's instance
     std::vector<uint32_t> chunk_base, slot_base, inc_base, band_off;
@@ -594,6 +594,7 @@ void layout_scene(const swfr_renderer* r, const swfr_edge* edges, size_t n_edges
     L.cell_total = L.cell_main * 2 + 4096;
     if (L.cell_total > 0xfffffff0ull) throw StatusError{SWFR_ERR_CAPACITY, "scene too large for 32-bit cell offsets"};
     L.n_strips = size_t(local_tile_rows(r)) * tiles_x * STRIPS_PER_TILE;
+    L.n_strip_slots = strip_slots(local_tile_rows(r), uint32_t(tiles_x * STRIPS_PER_TILE));
     L.filters.clear(); L.gradients.clear(); L.fparams.clear();
     prepare_sources(paths, n_paths, styles, n_styles, L.filters, L.gradients, L.fparams, r->bitmap_table);
 }
@@ -623,7 +624,7 @@ swfr_edge* push_scene(SceneArena& A, const SceneLayout& L, const swfr_edge* edge
 void fill_frame_sizes(const swfr_renderer* r, const SceneLayout& L, size_t n_edges, size_t n_paths, Frame2& f) {
     const uint32_t bc = r->cfg.band_count > 1 ? r->cfg.band_count : 1, bi = r->cfg.band_count > 1 ? r->cfg.band_index : 0;
     f.n_edges = uint32_t(n_edges); f.n_paths = uint32_t(n_paths); f.n_chunks = uint32_t(L.n_chunks); f.n_slots = uint32_t(L.n_slots);
-    f.n_bands = uint32_t(L.n_bands); f.n_strips = uint32_t(L.n_strips); f.cell_slice = uint32_t(L.cell_total); f.slow_cap = uint32_t(L.n_rows + 64);
+    f.n_bands = uint32_t(L.n_bands); f.n_strips = uint32_t(L.n_strips); f.n_strip_slots = uint32_t(L.n_strip_slots); f.cell_slice = uint32_t(L.cell_total); f.slow_cap = uint32_t(L.n_rows + 64);
     f.width = int32_t(r->width); f.height = int32_t(r->height); f.tiles_x = int32_t((r->width + TILE_W - 1) / TILE_W);
     f.band_index = bi; f.band_count = bc; f.fast_limit = uint32_t(std::min(std::max(r->fast_limit, 0), 8)); f.any_shader = L.any_shader ? 1u : 0u;
     const BandShare bs = band_share(r);
@@ -654,7 +655,7 @@ int upload2(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, siz
     layout_scene(r, edges, n_edges, paths, n_paths, styles, n_styles, L);
     sc.n_edges = n_edges; sc.n_paths = n_paths; sc.n_styles = n_styles; sc.any_shader = L.any_shader; sc.shader_level = L.shader_level;
     sc.n_chunks = L.n_chunks; sc.chunk_rows = L.chunk_rows; sc.n_bands = L.n_bands; sc.n_band_entries = L.n_slots; sc.n_tasks = L.n_rows;
-    sc.n_strips = L.n_strips; sc.n_incidences = L.incidences;
+    sc.n_strips = L.n_strips; sc.n_strip_slots = L.n_strip_slots; sc.n_incidences = L.incidences;
     sc.has_order = r->strip_order != 0;
     SceneArena& A = sc.arena;
     A.begin(scene_arena_bytes(L, n_edges, n_paths, n_styles) + SceneArena::padded(4 * sizeof(Frame2)) + 4096);
@@ -678,7 +679,7 @@ int upload2(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, siz
         x.d_edges.reserve(n_edges); x.d_band2.reserve(n_slots); x.d_rows2.reserve(n_slots * TILE_H + 64); x.d_cells.reserve(L.cell_total);
         x.d_slow.reserve(2 * (n_rows + 64)); x.d_huge.reserve(2 * (n_rows + 64));     // (two queues each: a pass reads one and refills the other)
         x.d_path_flag.reserve(n_paths + 64); x.d_path_queue.reserve(n_paths + 64);
-        x.d_chunks.reserve(n_chunks + 1); x.d_band_slots.reserve(n_slots + 1); x.d_strips.reserve(L.n_strips + 1);
+        x.d_chunks.reserve(n_chunks + 1); x.d_band_slots.reserve(n_slots + 1); x.d_strips.reserve(L.n_strip_slots + 1);
         reserve_zeroed(x.d_strip_cost, L.n_strips + 1);                                 // (zero between frames: the ordering workgroup clears what it has read)
         x.cell_slice = L.cell_total; x.slow_cap = n_rows + 64;
         x.d_counters.reserve(COUNTER_WORDS);
@@ -1002,7 +1003,7 @@ void launch_frame(swfr_renderer* r, const swfr_renderer::Scene& sc, swfr_rendere
         if (sc.n_chunks && sc.slow_state != 1) launch2_rows_slow(st, fh, 1, 1024u, sc.slow_state == 2 ? 0u : 256u, sc.slow_passes);
         if (e) HIP_CHECK(hipEventRecord(e[2], st));
         const uint32_t grid = r->tiles_grid > 0 ? uint32_t(r->tiles_grid) : ~0u;
-        launch2_tiles(st, fh, 1, uint32_t(sc.n_strips), grid, sc.shader_level);
+        launch2_tiles(st, fh, 1, uint32_t(sc.n_strip_slots), grid, sc.shader_level);
         if (e) HIP_CHECK(hipEventRecord(e[3], st));
         (void)fb;
         return;
@@ -1209,11 +1210,11 @@ int render_batch2(swfr_renderer* r, const swfr_stage* stages, uint32_t n, void* 
             const SceneLayout& L = F.L;
             work_bytes += pad(F.e.size() * sizeof(DevEdge)) + pad(L.n_slots * sizeof(BandEntry2)) + pad((L.n_slots * TILE_H + 64) * sizeof(RowInfo2)) +
                           pad(L.cell_total * sizeof(Cell)) + 2 * pad(2 * (L.n_rows + 64) * sizeof(SlowRow)) + 2 * pad((F.p.size() + 64) * sizeof(uint32_t)) +
-                          pad((L.n_chunks + 1) * sizeof(ChunkInfo)) + pad((L.n_slots + 1) * sizeof(BandSlot)) + pad((L.n_strips + 1) * sizeof(StripDesc)) +
+                          pad((L.n_chunks + 1) * sizeof(ChunkInfo)) + pad((L.n_slots + 1) * sizeof(BandSlot)) + pad((L.n_strip_slots + 1) * sizeof(StripDesc)) +
                           pad((L.n_strips + 1) * sizeof(uint32_t)) + pad(COUNTER_WORDS * sizeof(uint32_t));
             cls_bytes += pad(L.n_slots * tiles_x + 64);
             max_ep = std::max(max_ep, std::max(F.e.size(), F.p.size())); max_bands = std::max(max_bands, L.n_bands);
-            max_chunks = std::max(max_chunks, L.n_chunks); max_strips = std::max(max_strips, L.n_strips);
+            max_chunks = std::max(max_chunks, L.n_chunks); max_strips = std::max(max_strips, L.n_strip_slots);
             shader_level = std::max(shader_level, L.shader_level);
         }
         // ---- this group's previous use must be over before its staging and device buffers are rewritten
@@ -1251,7 +1252,7 @@ int render_batch2(swfr_renderer* r, const swfr_stage* stages, uint32_t n, void* 
             f.path_queue = reinterpret_cast<uint32_t*>(carve((F.p.size() + 64) * sizeof(uint32_t)));
             f.chunks = reinterpret_cast<ChunkInfo*>(carve((L.n_chunks + 1) * sizeof(ChunkInfo)));
             f.band_slots = reinterpret_cast<BandSlot*>(carve((L.n_slots + 1) * sizeof(BandSlot)));
-            f.strips = reinterpret_cast<StripDesc*>(carve((L.n_strips + 1) * sizeof(StripDesc)));
+            f.strips = reinterpret_cast<StripDesc*>(carve((L.n_strip_slots + 1) * sizeof(StripDesc)));
             f.strip_cost = reinterpret_cast<uint32_t*>(carve((L.n_strips + 1) * sizeof(uint32_t)));
             f.counters = reinterpret_cast<uint32_t*>(carve(COUNTER_WORDS * sizeof(uint32_t)));
             f.cls = c; c += pad(L.n_slots * tiles_x + 64);

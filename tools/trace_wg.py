@@ -1,0 +1,62 @@
+"""Workgroup timeline of k2_bin / k2_rows / k2_tiles from the -DSWFR_TRACE build (build/trace/libswfr.so): every workgroup stamps
+the 100 MHz wall clock at entry, after each dependent memory round trip (k2_tiles) and at exit.  One frame in flight, scene S1
+(or S2 with argv[1] = s2).  Prints, per kernel: workgroups, span first-entry -> last-exit, workgroup duration percentiles, and for
+k2_tiles the median time of each dependent step.      gpurun: bash tools/build_variant.sh trace -DSWFR_TRACE && python tools/trace_wg.py"""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["SWFR_FRAMES_IN_FLIGHT"] = "1"
+import numpy as np
+from swf_renderer_amd import api
+LIB = os.path.join(ROOT, "build", os.environ.get("TRACE_BUILD", "trace"), "libswfr.so")
+api.library_path = lambda: LIB
+import swf_renderer_amd as S
+from swf_renderer_amd import synth
+which = sys.argv[1] if len(sys.argv) > 1 else "s1"
+cfg = synth.S1 if which == "s1" else synth.S2
+W, H = cfg["width"], cfg["height"]
+pts, cols = synth.scene(**cfg)
+host = S.Renderer(W, H, device=api.DEVICE_HOST_ONLY)
+scene = host.build_frame(api.stars_to_stage(pts, cols)); host.close()
+share = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+r = S.Renderer(W, H, band_index=share // 2, band_count=share, contiguous_bands=True)
+r.upload_edges(*scene)
+r.render_resident(10)
+r.render_resident(1)
+tm = r.timing()
+L = ctypes.CDLL(LIB)
+buf = np.zeros((3, 32768, 8), dtype=np.uint32)
+L.swfr_debug_trace.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+n = L.swfr_debug_trace(buf.ctypes.data, buf.nbytes)
+assert n > 0
+print("events: k2_bin %.1f us, k2_rows %.1f us, k2_tiles %.1f us" % (tm["setup_ms"] * 1e3 / max(tm["timed_frames"], 1), tm["rows_ms"] * 1e3 / max(tm["timed_frames"], 1), tm["tiles_ms"] * 1e3 / max(tm["timed_frames"], 1)))
+t_all0 = None
+for k, name in enumerate(("k2_bin", "k2_rows", "k2_tiles")):
+    b = buf[k]
+    used = b[:, 7] != 0
+    b = b[used].astype(np.int64)
+    if not len(b):
+        continue
+    t0, t1 = b[:, 0].min(), b[:, 7].max()
+    if t_all0 is None: t_all0 = t0
+    dur = (b[:, 7] - b[:, 0]) * 0.01
+    print("%s: %d workgroups, starts at %.2f us, span %.2f us; workgroup duration us: p10 %.2f p50 %.2f p90 %.2f max %.2f; entries spread over %.2f us" %
+          (name, len(b), (t0 - t_all0) * 0.01, (t1 - t0) * 0.01, *np.percentile(dur, [10, 50, 90]), dur.max(), (b[:, 0].max() - t0) * 0.01))
+    if name == "k2_tiles":
+        names = ["descriptor fields", "strip descriptor", "class bytes", "entries + row headers", "first cells", "blend (to the store)", "stores acknowledged"]
+        prev = b[:, 0].copy()
+        for i in range(1, 8):
+            cur = b[:, i]
+            ok = cur != 0
+            d = (cur[ok] - prev[ok]) * 0.01
+            if len(d): print("   %-24s p50 %.2f  p90 %.2f us  (%d workgroups)" % (names[i - 1], *np.percentile(d, [50, 90]), len(d)))
+            prev = np.where(ok, cur, prev)
+        # concurrency: workgroups alive over time
+        ev = np.concatenate([np.stack([b[:, 0], np.ones(len(b), np.int64)], 1), np.stack([b[:, 7], -np.ones(len(b), np.int64)], 1)])
+        ev = ev[np.argsort(ev[:, 0], kind="stable")]
+        alive = np.cumsum(ev[:, 1])
+        print("   workgroups alive: max %d, time-weighted mean %.0f" % (alive.max(), float((alive[:-1] * np.diff(ev[:, 0])).sum() / max(ev[-1, 0] - ev[0, 0], 1))))
+    if name == "k2_rows":
+        d = (b[:, 1] - b[:, 0]) * 0.01
+        print("   descriptor + chunk count p50 %.2f p90 %.2f us" % tuple(np.percentile(d, [50, 90])))
+r.close()
