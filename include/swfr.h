@@ -243,6 +243,21 @@ typedef struct {
 } swfr_path_timing;
 int  swfr_last_path_timing(swfr_renderer *r, swfr_path_timing *out);
 
+/* What the row kernels met since the handle was created (summed over every frame whose counters came back): rows the fast kernel
+   left to the general ones, rows that needed the replay of Cairo's edge-list order for coincident edges, and how often a capacity
+   limit of that replay was reached -- each such frame was refused with SWFR_ERR_CAPACITY, never rendered approximately. */
+typedef struct swfr_stats {
+    uint64_t frames;                     /* frames whose counters were read back */
+    uint64_t queued_rows;                /* (path, pixel row) pairs left to k2_rows_slow (coincident edges or > 8 active edges) */
+    uint64_t crowded_rows;               /* ... of which handed on to k2_rows_huge (> 64 active edges) */
+    uint64_t tie_rows;                   /* rows whose edge order came from the list-order replay */
+    uint64_t pairtest_limit;             /* frames refused: crossing test over more than 2^21 edge pairs */
+    uint64_t start_group_limit;          /* frames refused: more than 2048 edges of a path start at one sample row / are active in a row */
+    uint64_t history_limit;              /* frames refused: order of two older coincident edges needs history deeper than one level */
+    uint64_t reserved;
+} swfr_stats;
+int  swfr_get_stats(swfr_renderer *r, swfr_stats *out);
+
 /* The reference's animation loop in one call: for (rep < repeat) for (i < n_stages) swfr_render(stages[i]) -- every frame built,
    uploaded, binned, rasterized and waited for exactly as by swfr_render -- timed on the host side of the C-ABI.  `seconds`
    receives the wall clock of the loop; `sum` (optional) the per-stage times added up. */

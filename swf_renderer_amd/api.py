@@ -27,7 +27,7 @@ EXPORTS = [
     "swfr_abi_version", "swfr_create", "swfr_destroy", "swfr_last_error", "swfr_register_shape",
     "swfr_register_morph_shape", "swfr_register_bitmap", "swfr_render", "swfr_render_batch", "swfr_read_image", "swfr_upload_edges",
     "swfr_render_resident", "swfr_render_edges", "swfr_build_frame", "swfr_shape_json", "swfr_last_timing",
-    "swfr_band_slab_bytes", "swfr_copy_band_slab", "swfr_device_framebuffer", "swfr_debug_copy", "swfr_last_path_timing",
+    "swfr_band_slab_bytes", "swfr_copy_band_slab", "swfr_device_framebuffer", "swfr_debug_copy", "swfr_last_path_timing", "swfr_get_stats",
     "swfr_render_sequence", "swfr_set_targets", "swfr_render_resident_async", "swfr_stream_handle", "swfr_wait",
 ]
 
@@ -128,6 +128,11 @@ class Timing(C.Structure):
                 ("n_records", C.c_uint64), ("timed_frames", C.c_uint32)]
 
 
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("frames", "queued_rows", "crowded_rows", "tie_rows", "pairtest_limit", "start_group_limit",
+                                          "history_limit", "reserved")]
+
+
 class PathTiming(C.Structure):
     _fields_ = [("build_ms", C.c_double), ("upload_host_ms", C.c_double), ("h2d_ms", C.c_double), ("device_ms", C.c_double),
                 ("total_ms", C.c_double), ("h2d_bytes", C.c_uint64)]
@@ -200,6 +205,8 @@ def load_library():
     L.swfr_stream_handle.argtypes = [P, U]
     L.swfr_wait.restype = I
     L.swfr_wait.argtypes = [P]
+    L.swfr_get_stats.restype = I
+    L.swfr_get_stats.argtypes = [P, C.POINTER(Stats)]
     L.swfr_last_path_timing.restype = I
     L.swfr_last_path_timing.argtypes = [P, C.POINTER(PathTiming)]
     L.swfr_render_sequence.restype = I
@@ -472,6 +479,12 @@ class Renderer:
         secs, acc = C.c_double(), PathTiming()
         self._check(self.L.swfr_render_sequence(self.h, arr, len(stages), int(repeat), C.byref(secs), C.byref(acc)))
         return secs.value, {n: getattr(acc, n) for n, _ in PathTiming._fields_}
+
+    def stats(self) -> dict:
+        """Rows the general row kernels handled and capacity limits reached since the handle was created (swfr_stats)."""
+        t = Stats()
+        self._check(self.L.swfr_get_stats(self.h, C.byref(t)))
+        return {n: int(getattr(t, n)) for n, _ in Stats._fields_ if n != "reserved"}
 
     def path_timing(self) -> dict:
         t = PathTiming()

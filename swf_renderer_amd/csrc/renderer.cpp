@@ -230,6 +230,7 @@ struct swfr_renderer {
     BatchGroup groups[2];
     int batch_frames = 64;                  // SWFR_BATCH_FRAMES: frames per launch in swfr_render_batch
     uint32_t* targets[4] = {nullptr, nullptr, nullptr, nullptr};   // swfr_set_targets: frame set k renders into targets[k]
+    swfr_stats stats = {};
     uint32_t n_targets = 0, async_next = 0, async_used = 0;   // async_used: bit k = frame set k has run since the last wait
     Frame2* d_frames = nullptr;             // one descriptor per frame set, contiguous: a batch of frames is one launch
     Frame2* h_frames = nullptr;             // pinned staging of the same
@@ -1032,6 +1033,11 @@ void launch_frame(swfr_renderer* r, const swfr_renderer::Scene& sc, swfr_rendere
 int check_counters(swfr_renderer* r, const uint32_t* counters) {
     if (r->pipeline == 2) {
         const uint32_t err = counters[C2_ERROR];
+        r->stats.frames += 1; r->stats.queued_rows += counters[C2_SLOW]; r->stats.crowded_rows += counters[C2_HUGE];
+        r->stats.tie_rows += counters[C2_TIE_ROWS];
+        r->stats.pairtest_limit += counters[C2_TIE_PAIRTEST_SKIPPED] ? 1 : 0;
+        r->stats.start_group_limit += ((err & (E2_ACTIVE_EDGES | E2_START_GROUP)) || counters[C2_TIE_SORT_OVERFLOW]) ? 1 : 0;
+        r->stats.history_limit += counters[C2_TIE_DEPTH] ? 1 : 0;
         if (err & ~(E2_ACTIVE_EDGES | E2_START_GROUP | E2_CELL_ARENA)) {
             r->fb_valid = false;
             return fail(r, SWFR_ERR_DEVICE, "internal consistency check failed in the raster kernels (code " + std::to_string(err) + ")");
@@ -1613,6 +1619,12 @@ int swfr_render_resident_async(swfr_renderer* r, uint32_t* out_set) {
         if (out_set) *out_set = k;
         return int(SWFR_OK);
     });
+}
+
+int swfr_get_stats(swfr_renderer* r, swfr_stats* out) {
+    if (!r || !out) return SWFR_ERR_INVALID;
+    *out = r->stats;
+    return SWFR_OK;
 }
 
 void* swfr_stream_handle(swfr_renderer* r, uint32_t set) { return (r && r->has_device && set < 4) ? static_cast<void*>(r->fs[set].stream) : nullptr; }

@@ -40,14 +40,19 @@ def oracle_render(sc):
     return out
 
 
-def product_render(sc, **kw):
-    """premultiplied RGBA of a scenario through libswfr.so (HIP path)"""
+def product_render(sc, stats=None, **kw):
+    """premultiplied RGBA of a scenario through libswfr.so (HIP path); `stats` (a dict) collects the handle's swfr_stats"""
     import swf_renderer_amd as S
     r = S.Renderer(sc["width"], sc["height"], even_odd=bool(sc.get("even_odd")), **kw)
     try:
         for b in sc.get("bitmaps", []):
             r.add_bitmap(b)
-        r.render(sc["stage"])
+        try:
+            r.render(sc["stage"])
+        finally:
+            if stats is not None:
+                for k, v in r.stats().items():
+                    stats[k] = stats.get(k, 0) + v
         return r.read_image(premultiplied=True)
     finally:
         r.close()

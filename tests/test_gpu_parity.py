@@ -515,6 +515,72 @@ def test_crowded_rows_vs_oracle(teeth):
         assert diff_stats(product_render(sc), oracle_render(sc)) == (0, 0), (teeth, eo)
 
 
+def _comb_points(teeth, width_twips, x0, y_top, y_bottom):
+    pts = []
+    step = width_twips / teeth
+    for k in range(teeth):
+        pts += [(x0 + step * k, y_top), (x0 + step * k + step / 2, y_bottom)]
+    pts += [(x0 + width_twips + 100, y_bottom + 50), (x0 - 50, y_bottom + 50)]
+    return pts
+
+
+def _multi_poly_shape(polys, fill):
+    """DefineShape with several closed polygons in ONE fill style (one path for the scan converter)."""
+    recs = []
+    xs, ys = [], []
+    for i, poly in enumerate(polys):
+        p = [(int(x), int(y)) for x, y in poly]
+        sc = {"type": "style-change", "move_to": {"x": p[0][0], "y": p[0][1]}}
+        if i == 0:
+            sc["left_fill"] = 1
+        recs.append(sc)
+        for k in range(1, len(p) + 1):
+            a, b = p[k - 1], p[k % len(p)]
+            recs.append({"type": "edge", "delta": {"x": b[0] - a[0], "y": b[1] - a[1]}})
+        xs += [q[0] for q in p]; ys += [q[1] for q in p]
+    return {"id": 1, "bounds": {"x_min": min(xs), "x_max": max(xs), "y_min": min(ys), "y_max": max(ys)},
+            "shape": {"initial_styles": {"fill": [fill], "line": []}, "records": recs}}
+
+
+@pytest.mark.parametrize("y_top", [0, -7, -300])
+@pytest.mark.parametrize("teeth", [9, 13, 16])
+def test_edges_arriving_together_at_the_frame_top_vs_oracle(teeth, y_top):
+    """18 ... 32 edges of one path that all become active at sample row 0 because the frame's top edge clips them (round 1
+    ordered at most sixteen such edges and silently fell back to path order beyond): the start ranks of k2_start_ranks replay
+    Cairo's merge sort for any group size.  y_top = 0 puts the teeth's shared vertices exactly on the first sample row (pairs of
+    edges coincide there), -7 twips a fraction of a pixel above it, -300 well outside."""
+    tag = scenarios._poly_shape(_comb_points(teeth, 2200, 60, y_top, 1700), {"type": "solid", "color": scenarios._rgba(200, 30, 90, 180)})
+    for eo in (False, True):
+        sc = dict(width=128, height=96, even_odd=eo, stage={"children": [{"type": "shape", "definition": tag}]})
+        stats = {}
+        assert diff_stats(product_render(sc, stats=stats), oracle_render(sc)) == (0, 0), (teeth, y_top, eo)
+        assert stats["pairtest_limit"] == stats["start_group_limit"] == stats["history_limit"] == 0
+
+
+def test_path_with_4k_edges_and_600_active_per_row_is_exact_or_refused():
+    """Seven stacked combs of 300 sub-pixel teeth in ONE path: 4200 edges, 600 of them active in every row, neighbouring edges
+    half a pixel apart so that rows with coincident edges abound.  The list-order replay either reproduces the oracle exactly or
+    the frame is refused with SWFR_ERR_CAPACITY and the limit shows in swfr_stats -- it is never rendered approximately."""
+    import swf_renderer_amd as S
+    from swf_renderer_amd import api
+    polys = [_comb_points(300, 6000, 100, 100 + 260 * k, 100 + 260 * k + 220) for k in range(7)]
+    tag = _multi_poly_shape(polys, {"type": "solid", "color": scenarios._rgba(10, 200, 120)})
+    sc = dict(width=320, height=100, stage={"children": [{"type": "shape", "definition": tag}]})
+    r = S.Renderer(sc["width"], sc["height"])
+    try:
+        try:
+            r.render(sc["stage"])
+        except S.SwfrError as e:
+            st = r.stats()
+            assert e.code == api.ERR_CAPACITY and (st["pairtest_limit"] or st["start_group_limit"] or st["history_limit"]), (e, st)
+            return
+        st = r.stats()
+        assert st["queued_rows"] > 0 and st["pairtest_limit"] == st["start_group_limit"] == st["history_limit"] == 0, st
+        assert diff_stats(r.read_image(premultiplied=True), oracle_render(sc)) == (0, 0)
+    finally:
+        r.close()
+
+
 def test_many_active_edges_fails_loudly_not_silently():
     import swf_renderer_amd as S
     from swf_renderer_amd import api
@@ -524,4 +590,5 @@ def test_many_active_edges_fails_loudly_not_silently():
     with pytest.raises(S.SwfrError) as e:
         r.render({"children": [{"type": "shape", "definition": tag}]})
     assert e.value.code == api.ERR_CAPACITY
+    assert r.stats()["start_group_limit"] == 1                    # the refusal is counted, too
     r.close()

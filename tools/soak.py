@@ -36,7 +36,8 @@ def main():
     seed0 = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
     if mode == "gpu":
         from helpers import product_render
-    bad = total = painted = 0
+    bad = total = painted = refused = 0
+    stats = {}
     for name, gen in GENS.items():
         rng = np.random.default_rng(seed0 + sum(map(ord, name)))
         for it in range(n):
@@ -45,14 +46,25 @@ def main():
                 ref = oracle_render(sc)
             except AssertionError:
                 continue                                   # stroker feature outside the restated subset (none expected)
-            got = product_render(sc) if mode == "gpu" else cairo_render(sc)
+            if mode == "gpu":
+                import swf_renderer_amd as S
+                try:
+                    got = product_render(sc, stats=stats)
+                except S.SwfrError as e:                   # a capacity limit, reported: never a silently different picture
+                    refused += 1
+                    print("REFUSED", name, "seed", seed0, "index", it, e, flush=True)
+                    continue
+            else:
+                got = cairo_render(sc)
             total += 1
             painted += int((ref[..., 3] > 0).sum())
             if not np.array_equal(np.asarray(got), np.asarray(ref)):
                 d = np.abs(np.asarray(got).astype(int) - np.asarray(ref).astype(int)).max(-1)
                 bad += 1
                 print("MISMATCH", mode, name, "seed", seed0, "index", it, "pixels", int((d > 0).sum()), "max", int(d.max()), flush=True)
-    print("%s: %d scenes, %d painted pixels, %d mismatching scenes" % (mode, total, painted, bad), flush=True)
+    print("%s: %d scenes, %d painted pixels, %d mismatching scenes, %d refused" % (mode, total, painted, bad, refused), flush=True)
+    if stats:
+        print("row kernels:", ", ".join("%s %d" % kv for kv in stats.items()), flush=True)
     sys.exit(1 if bad else 0)
 
 
