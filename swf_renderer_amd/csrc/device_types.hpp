@@ -9,7 +9,7 @@ namespace swfr {
 
 constexpr int TILE_W = 64;   // one wavefront lane per pixel column
 constexpr int TILE_H = 16;   // tile-rows ("bands") are the unit of band lists and of multi-GPU sharding
-constexpr int STRIP_H = 8;   // pixel rows per k_tiles wavefront: a 64x16 tile is rasterized as two independent 64x8 strips
+constexpr int STRIP_H = 8;   // pixel rows per k2_tiles wavefront: a 64x16 tile is rasterized as two independent 64x8 strips
 constexpr int STRIPS_PER_TILE = TILE_H / STRIP_H;
 
 // Per-edge constants of the tor scan converter (SURVEY.md A.5 make_edge), 64 bytes.
@@ -17,7 +17,7 @@ struct DevEdge {
     int32_t ytop, ybot;      // active sub-rows [ytop, ybot), 15 per pixel row, clamped to the path's rows
     int32_t x1, y1;          // upper end point of the line (24.8)
     int32_t dir;
-    int32_t pad;             // pipeline 2, paths with queued rows: position among the edges that start at the same sample row, in the order
+    int32_t pad;             // paths with queued rows: position among the edges that start at the same sample row, in the order
                              // Cairo's sort of that bucket gives them (k2_start_ranks)
     int64_t ex;              // (x2 - x1) * 256
     int64_t dy;              // (y2 - y1) * 15 * 512, 0 for vertical edges
@@ -29,53 +29,17 @@ static_assert(sizeof(DevEdge) == 64, "DevEdge layout");
 using DevPath = swfr_path;   // 40 bytes: first_edge, n_edges, kind, fill_rule, style, lerp, pixel rect
 
 enum : uint32_t { ROW_EMPTY = 0, ROW_FULL = 1, ROW_SUB = 2 };
-struct RowInfo {
-    uint32_t rec_off;
-    uint16_t n_rec;
-    uint16_t mode;
-};
-
-// record = {edge index, roles, column range}: FULL rows carry REC_FULL | 1 (left, +1) or | 2 (right, -1);
-// SUB rows carry 15 two-bit fields, field s = 1 (a span opens at this edge in sub-row s) or 2 (closes).
-// cols = lo | hi << 16: the pixel columns (clamped to [0, 65535]) this record's contributions fall in.
+// roles word of an (edge, row) pair inside the row kernels: FULL rows carry REC_FULL | 1 (left end of a span, +1) or | 2 (right
+// end, -1); SUB rows carry 15 two-bit fields, field s = 1 (a span opens at this edge in sample row s) or 2 (closes)
 constexpr uint32_t REC_FULL = 0x80000000u;
-// REC_CELLS: the contributions were precomputed by k_rows: roles = REC_CELLS | n_cells | (int8 net height) << 8, and the
-// 40 bytes after `cols` hold up to 10 cells {column - lo : 8, covered height : int8, uncovered area : int16}.
-constexpr uint32_t REC_CELLS = 0x40000000u;
-constexpr int REC_MAX_CELLS = 10;
-// The record is self-contained (no edge lookup in k_tiles): FULL rows carry the two end points of the edge over
-// the pixel row (x = q + r/dy at the row top and bottom); SUB rows carry x at the edge's first sample row in the
-// pixel row plus the per-sample slope.
-struct Rec {
-    uint32_t roles, cols;
-    int32_t q1;              // FULL: x quotient at the row top;    SUB: x quotient at the first sample row
-    int32_t q2;              // FULL: x quotient at the row bottom; SUB: slope quotient per sample row
-    int64_t r1;              // remainder of q1
-    int64_t r2;              // FULL: remainder of q2;              SUB: slope remainder
-    int64_t dy;              // denominator (0: vertical edge)
-    uint32_t span;           // SUB: first | (last+1) << 8, sample rows relative to the pixel row's first
-    uint32_t eid;            // edge index (diagnostics)
-};
-static_assert(sizeof(Rec) == 48, "Rec layout");
+constexpr uint32_t REC_CELLS = 0x40000000u;    // (net height in bits 8..15)
+constexpr int ROWS_CHUNK = 64;       // most pixel rows per k2_rows wavefront (one lane per row)
 
-enum : uint32_t { CNT_RECORDS = 0, CNT_ERROR = 1, CNT_OVERFLOW = 2, CNT_PAIRS = 3, CNT_PARTIAL = 4, CNT_FULL = 5, CNT_CULLED = 6, CNT_WORDS = 24 };
-constexpr int ROWS_CHUNK = 64;       // most pixel rows per k_rows workgroup (one lane per row)
-
-// Band list entry: everything a tile needs to bin, classify and cull a path without touching paths[]/styles[].
-struct BandEntry {
-    uint32_t path;
-    int16_t x_min, x_max, y_min, y_max;   // pixel rectangle (frames are at most 32768 wide/high)
-    uint32_t row_base;                    // first RowInfo of the path
-    uint32_t style;
-    uint32_t first_edge, n_edges;         // boxes paths
-    uint32_t flags;                       // BE_*
-    uint32_t solid;                       // premultiplied pixel of a solid style
-};
-static_assert(sizeof(BandEntry) == 36, "BandEntry layout");
+// flags of a band list entry (BandEntry2)
 enum : uint32_t { BE_BOXES = 1u, BE_LERP = 2u, BE_SOLID = 4u, BE_OPAQUE_COVER = 8u /* solid, alpha 255, lerp blend */ };
 
-// One k_rows workgroup: `rows` (<= 64) consecutive pixel rows of one path.  rec_base is the first record slot reserved for the
-// chunk (host-computed upper bound), so record allocation needs no global atomics.
+// One k2_rows wavefront: `rows` (<= 64) consecutive pixel rows of one path.  rec_base is the path's first (edge, row) incidence
+// (host-computed prefix): the chunk's cells go to a fixed region behind it, so cell allocation needs no global atomics.
 struct ChunkInfo {
     uint32_t path, first_row, rec_base, rows;
     uint32_t slot0;          // index into band_slots of the (path, tile-row) pair of the chunk's first tile-row; ~0u if none
@@ -88,14 +52,6 @@ struct BandSlot {
     uint32_t path;
     uint32_t slot;           // index into band_list; the tile-row is recovered from band_off
     uint32_t band;
-    uint32_t pad;
-};
-
-// A pixel row with more active edges than k_rows keeps in registers: handled by k_rows_big, one lane each.
-struct BigRow {
-    uint32_t path;
-    int32_t row;             // absolute pixel row
-    uint32_t rec_base;       // first of the row's record slots (one per active edge)
     uint32_t pad;
 };
 
@@ -115,7 +71,7 @@ struct DevFilter {
     int32_t m00, m01, m10, m11;
     int32_t pad;
     int64_t base_x, base_y;
-    // pipeline 2: what the bitmap shader needs of the style and of the bitmap table, so that one load of this record is all it waits for
+    // what the bitmap shader needs of the style and of the bitmap table, so that one load of this record is all it waits for
     const uint32_t* pixels;  // premultiplied ARGB, tight rows (bitmap styles)
     uint32_t width, height;
     uint32_t extend;         // 0 none, 1 repeat
@@ -139,7 +95,7 @@ struct DevGradient {
 };
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// Pipeline 2 (raster2.hip): the row pass hands the tile pass CELLS, not edges.  A cell is one entry of Cairo's per-row cell list
+// The row pass (raster2.hip) hands the tile pass CELLS, not edges.  A cell is one entry of Cairo's per-row cell list
 // (covered_height / uncovered_area of one pixel column), already clipped to the converter's column range; the cells
 // of one (path, pixel row) are contiguous, RowInfo2 says where.  The tile pass does no edge arithmetic at all.
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -178,7 +134,7 @@ struct SlowRow {
     uint32_t pad;
 };
 
-// counters of pipeline 2 (per frame in flight)
+// the kernels' counters (per frame in flight)
 enum : uint32_t { C2_ERROR = 0, C2_SLOW = 1, C2_HUGE = 2, C2_TIE_ROWS = 3, C2_TIE_PAIRTEST_SKIPPED = 4, C2_TIE_SORT_OVERFLOW = 5, C2_TIE_DEPTH = 6,
                   C2_CELLS = 7, C2_HEAD = 8 /* .. 15: cell allocation heads */, C2_PATHQ = 16,
                   C2_SLOWQ = 16 /* + pass (1..3): rows queued again for a later pass */, C2_HUGEQ = 20 /* + pass (1..3) */, C2_WORDS = 32 };

@@ -1,24 +1,28 @@
-// raster2.hip -- pipeline 2 of the hot path (edge list -> RGBA8 framebuffer in HBM), CDNA4 / gfx950.
+// raster2.hip -- the kernels of the hot path (raw edge list -> RGBA8 framebuffer in HBM), CDNA4 / gfx950.  The build's only device
+// translation unit; raster_common.hip (included below) holds the exact-arithmetic helpers, the replay of Cairo's edge-list order
+// and the shaders the kernels share.  Arithmetic: Cairo 1.16 "tor" scan conversion + pixman sampling.
 //
-// Same arithmetic as raster_kernels.hip (Cairo's "tor" scan conversion; the row routines below are
-// the ones of that file with another output format), different data flow:
-//
-//   k2_bin_a / _scan / _fill   binning on the device from the raw edge list: scan-converter constants per edge (A.5 make_edge),
-//              row chunks, band lists in painter's order, cell bases, the tile pass's launch list (heaviest strips first)
+// One frame = four launches on one stream (DESIGN.md section 3 has the data layout and the bytes):
+//   k2_bin     binning on the device from the raw edge list: scan-converter constants per edge (A.5 make_edge), the row chunks of
+//              every path, the band lists (paths per tile-row, painter's order), box class bytes, and -- its last workgroup -- the
+//              tile pass's launch list: per XCD class (tile-row % 8) the strips heaviest first by the previous frame's costs
 //   k2_rows    one wavefront per (path, <= 64 pixel rows), lane = row: active edges, FULL / SUB decision, roles -- and then the
 //              row's CELLS {column, covered height, uncovered area}, i.e. Cairo's cell list itself (A.5 render_edge /
-//              add_subspan), densely packed per wavefront (one allocation per wavefront from eight bump allocators), plus the
-//              class byte of every (tile, path) pair.  A row whose edge order needs Cairo's list history (coincident edges), or
-//              with more active edges than the registers hold, goes to a queue.
-//   k2_rows_slow / k2_rows_huge   the queued rows, one wavefront (workgroup) each, same output
-//   k2_tiles   persistent wavefronts, each walks 64x8-pixel strips: class bytes -> surviving band entries (everything under the
+//              add_subspan) in a fixed region per chunk (no allocator), plus the class byte of every (tile, path) pair and the
+//              strips' costs.  A row whose edge order needs Cairo's list history (coincident edges on different lines), or with
+//              more than eight active edges, goes to a queue.
+//   k2_start_ranks / k2_rows_slow / k2_rows_huge   the queued rows (launched only while a resident scene may have any): the order
+//              Cairo's bucket sort gives edges that start together, then one wavefront (<= 64 active edges) or one 256-thread
+//              workgroup (<= 2048) per row, up to SLOW_PASSES passes (a row whose history runs through another queued row waits)
+//   k2_tiles   one wavefront per 64x8-pixel strip of the launch list: class bytes -> surviving band entries (everything under the
 //              last opaque full cover is culled from the class bytes alone) -> the cells of the partial paths as one coalesced
 //              stream -> LDS accumulators -> wave64 prefix sum -> alpha -> shade -> blend in registers -> one store per pixel.
-//              No edge arithmetic, no 64-bit or floating-point instruction on the solid-colour path.
+//              No edge arithmetic, no 64-bit or floating-point instruction on the solid-colour path.  Three instances: solid
+//              colours only, + bitmaps, + gradients; a scene gets the lightest that covers its styles.
 //
-// Every kernel takes an array of frame descriptors (device memory) and blockIdx.y picks the frame: a batch of frames is one launch
-// per kernel.
-#include "raster_kernels.hip"
+// Every kernel takes an array of frame descriptors (Frame2, device memory, read through scalar loads) and blockIdx.y picks the
+// frame: a batch of frames is one launch per kernel (swfr_render_batch).
+#include "raster_common.hip"
 
 namespace swfr {
 
@@ -362,8 +366,8 @@ struct SubStage {
     uint32_t cells[4][ROWS_FAST_N * 15];   // the cells of the (up to four) SUB rows of one pass, packed: column << 16 | fraction << 1 | closes
     uint32_t cnt[4];
 };
-// (FastLds of raster_kernels.hip without the scratch of its loop-form FULL test: 7 KB instead of 8, and with the packed staging and
-//  the staged edges a k2_rows wavefront needs 12.9 KB of LDS -- twelve of them fit a CU, as many as its registers allow)
+// (per-row slots of the fast row routine: 7 KB; with the packed staging and the staged edges a k2_rows wavefront needs 12.9 KB of
+//  LDS -- twelve of them fit a CU, as many as its registers allow)
 struct FastLds2 {
     uint16_t eid[ROWS_FAST_N][64];
     int32_t roles[ROWS_FAST_N][64];
@@ -383,9 +387,9 @@ __device__ __forceinline__ Cell unpack_sub_cell(uint32_t w) {
     return c;
 }
 
-// fast_rows of raster_kernels.hip with two changes.  (1) A row in which two edges on different lines coincide at the first sample
-// row (their order is a matter of Cairo's list history) is not decided here: `defer_out`.  (2) The sample lanes of a SUB row do
-// not only set role bits, they produce the row's cells: staged in LDS per pass of four rows, then allocated and copied out by the
+// The fast row routine (rows with at most eight active edges, lane = row).  (1) A row in which two edges on different lines coincide
+// at the first sample row (their order is a matter of Cairo's list history) is not decided here: `defer_out`.  (2) The sample lanes
+// of a SUB row do not only set role bits, they produce the row's cells: staged in LDS per pass of four rows, then allocated and copied out by the
 // whole wavefront, and the rows' RowInfo2 written (index `ri` per row lane; ~0u: the path has no band entry, nothing is kept).
 template <class EPTR>
 __device__ __forceinline__ void rows2_fast(EPTR E, uint32_t n_list, const DevPath& P, int r, bool live, int fast_limit, FastLds2& F, SubStage& S, int lane,
@@ -852,7 +856,7 @@ __global__ __launch_bounds__(64) R2_ATTR void k2_rows_b(const Frame2* __restrict
 // merges of runs of 2, 4, ... where a merge keeps consuming the list it is on through ties), for any number of them: slot
 // numbers 0 .. cnt-1 (path order) in `a` / `b` (ping-pong), keys in `cell`.  merge_step merges the runs [s, s + width) and
 // [s + width, s + 2 width) of `src` into `dst`; the caller loops over widths (one lane for a wavefront's row, one thread per
-// merge for a workgroup's).  new_order_before of raster_kernels.hip is the same replay for up to sixteen edges in registers.
+// merge for a workgroup's).  new_order_before of raster_common.hip reads the ranks this produces (DevEdge::pad).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void sort_pairs(uint16_t* __restrict__ dst, const int* __restrict__ cell, int p, int cnt) {
     const int x = 2 * p, y = 2 * p + 1;
@@ -973,7 +977,7 @@ __global__ __launch_bounds__(256) void k2_start_ranks_b(const Frame2* __restrict
 
 // ---------------------------------------------------------------------------------------------
 // k2_rows_slow: the queued rows, one wavefront each, lane = active edge (up to 64; more: the huge queue).  big_row_body of
-// raster_kernels.hip -- including the replay of Cairo's list order for coincident edges (tied_order) -- with cells as output.
+// raster_common.hip -- including the replay of Cairo's list order for coincident edges (tied_order) -- with cells as output.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t slow_count_index(uint32_t pass) { return pass == 0 ? (uint32_t)C2_SLOW : C2_SLOWQ + pass; }
 __device__ __forceinline__ uint32_t huge_count_index(uint32_t pass) { return pass == 0 ? (uint32_t)C2_HUGE : C2_HUGEQ + pass; }
@@ -1157,8 +1161,8 @@ __device__ __forceinline__ void slow_rows_loop(FramePtr FR, uint32_t pass) {
 }
 __global__ __launch_bounds__(64) void k2_rows_slow_b(const Frame2* __restrict__ frames, uint32_t pass) { slow_rows_loop(FRAME_PTR(frames, blockIdx.y), pass); }
 
-// k2_rows_huge: rows with 65 .. 2048 active edges of one path, one 256-thread workgroup each (k_rows_huge of raster_kernels.hip
-// with cells as output): thread t owns the active edges t, t + 256, ... and ranks each against the row's sort keys in LDS.
+// k2_rows_huge: rows with 65 .. 2048 active edges of one path, one 256-thread workgroup each:
+// thread t owns the active edges t, t + 256, ... and ranks each against the row's sort keys in LDS.
 __device__ __forceinline__ void huge_row_body(FramePtr FR, const SlowRow sr, uint32_t pass) {
     __shared__ uint32_t retry;
     __shared__ uint32_t active[ROWS_HUGE_MAXA];
@@ -1387,8 +1391,8 @@ __device__ __forceinline__ void huge_rows_loop(FramePtr FR, uint32_t pass) {
 __global__ __launch_bounds__(256) void k2_rows_huge_b(const Frame2* __restrict__ frames, uint32_t pass) { huge_rows_loop(FRAME_PTR(frames, blockIdx.y), pass); }
 
 // ---------------------------------------------------------------------------------------------
-// shading in pipeline 2: three instances of the tile kernel -- solid colours only; + bitmap fills (integer arithmetic only: pixman's
-// 16.16 sample positions, bilinear or separable convolution -- the branch of raster_kernels.hip's shade() for bitmaps, inlined);
+// shading: three instances of the tile kernel -- solid colours only; + bitmap fills (integer arithmetic only: pixman's
+// 16.16 sample positions, bilinear or separable convolution -- the branch of raster_common.hip's shade() for bitmaps, inlined);
 // + gradients (that file's shade(): double precision, a call).  A scene gets the lightest instance that covers its styles.
 // ---------------------------------------------------------------------------------------------
 // the four texels of a bilinear sample (7-bit weights: what CAIRO_FILTER_GOOD becomes for scales > .75): where they are -- `p`, already

@@ -24,15 +24,6 @@
 #include "shape_decoder.hpp"
 
 namespace swfr {
-void launch_front(hipStream_t, const swfr_edge*, const DevPath*, DevEdge*, uint32_t, const BandSlot*, uint32_t, const uint32_t*, const swfr_style*,
-                  BandEntry*, uint32_t*);
-void launch_class(hipStream_t, const BandEntry*, uint32_t, const uint32_t*, uint32_t, const swfr_edge*, const RowInfo*, const Rec*, uint8_t*, int, int,
-                  uint32_t, uint32_t);
-void launch_rows(hipStream_t, const DevEdge*, const DevPath*, const uint32_t*, const ChunkInfo*, uint32_t, RowInfo*, Rec*, uint32_t*, const BigRow*,
-                 uint32_t, uint32_t, uint32_t, uint32_t, int, int, uint32_t, const BandSlot*, const uint32_t*, uint8_t*, int, int, int,
-                 const swfr_edge*, const swfr_style*, BandEntry*, const BigRow*, uint32_t);
-void launch_tiles(hipStream_t, const swfr_edge*, const uint32_t*, const BandEntry*, const uint8_t*, const RowInfo*, const Rec*, const swfr_style*,
-                  Sources, uint32_t*, int, int, uint32_t, uint32_t, int, uint32_t*, uint32_t, uint32_t, bool, const uint32_t*);
 void launch2_bin(hipStream_t, const Frame2*, uint32_t, uint32_t, uint32_t);
 void launch2_rows(hipStream_t, const Frame2*, uint32_t, uint32_t);
 void launch2_rows_slow(hipStream_t, const Frame2*, uint32_t, uint32_t, uint32_t, uint32_t);
@@ -45,7 +36,7 @@ using namespace swfr;
 
 namespace {
 
-constexpr size_t COUNTER_WORDS = C2_WORDS > CNT_WORDS ? C2_WORDS : CNT_WORDS;   // per frame set, whichever pipeline runs
+constexpr size_t COUNTER_WORDS = C2_WORDS;   // per frame set
 
 struct HipError {
     hipError_t code;
@@ -160,17 +151,12 @@ struct swfr_renderer {
     struct Scene {
         SceneArena arena;
         swfr_edge* raw = nullptr; DevPath* paths = nullptr; swfr_style* styles = nullptr;
-        uint32_t *row_base = nullptr, *band_off = nullptr, *order = nullptr;
-        BigRow *big_rows = nullptr, *huge_rows = nullptr; BandSlot* band_slots = nullptr; ChunkInfo* chunk_base = nullptr;
         DevFilter* filters = nullptr; int32_t* filter_params = nullptr; DevGradient* gradients = nullptr;
-        size_t n_edges = 0, n_paths = 0, n_styles = 0, n_tasks = 0, n_chunks = 0, n_bands = 0, rec_cap = 0, rec_main = 0, n_big = 0, n_huge = 0,
-               chunk_rows = 64, n_band_entries = 0;
-        bool any_shader = false, fused_class = false, fused_front = false, has_order = false;
+        size_t n_edges = 0, n_paths = 0, n_styles = 0, n_rows = 0, n_chunks = 0, n_bands = 0, chunk_rows = 64;
+        bool any_shader = false;
         int shader_level = 0;
-        size_t n_incidences = 0, n_strips = 0, n_strip_slots = 0;   // (edge, pixel row) pairs: bounds the cells of a frame; k_tiles wavefronts
-        Frame2* frames_dev = nullptr;            // pipeline 2: one descriptor per frame set (contiguous, in the arena)
-        Frame2 frames_host[4];                   // ... and on the host: a single frame's launches pass theirs by value
-        StripDesc* strips = nullptr;
+        size_t n_incidences = 0, n_strips = 0, n_strip_slots = 0;   // (edge, pixel row) pairs: bounds the cells of a frame; k2_tiles wavefronts / launch list slots
+        Frame2* frames_dev = nullptr;            // one descriptor per frame set (contiguous, in the arena)
         uint32_t slow_passes = SLOW_PASSES;      // passes of the slow-row kernels the scene needs (known after a frame of a resident scene)
         int slow_state = 0;                      // 0: unknown (both slow-row kernels are launched), 1: the scene has no queued rows, 2: none with > 64 edges
     };
@@ -180,12 +166,8 @@ struct swfr_renderer {
     struct FrameSet {
         hipStream_t stream = nullptr;
         DevBuf<DevEdge> d_edges;
-        DevBuf<BandEntry> d_band_list;
         DevBuf<uint8_t> d_cls;
-        DevBuf<RowInfo> d_rows;
-        DevBuf<Rec> d_records;
         DevBuf<uint32_t> d_counters, d_fb;
-        // pipeline 2
         DevBuf<BandEntry2> d_band2;
         DevBuf<RowInfo2> d_rows2;
         DevBuf<Cell> d_cells;
@@ -208,16 +190,12 @@ struct swfr_renderer {
     bool scene_ready = false, fb_valid = false;
     swfr_timing timing{};
     swfr_path_timing path_timing{};
-    int allow_fused = 2;                    // SWFR_FUSED_CLASS=0: always launch k_class (test knob)
     int force_chunk_rows = 0;               // SWFR_CHUNK_ROWS: test knob
-    int strip_order = 1;                    // SWFR_STRIP_ORDER=0: launch the k_tiles wavefronts in row-major order
+    int strip_order = 1;                    // SWFR_STRIP_ORDER=0: launch the k2_tiles wavefronts in row-major order (per XCD class)
     int event_stride = 16;                  // SWFR_EVENT_STRIDE: per-kernel HIP events on every n-th resident frame
-    int tiles_dbg = 0;                      // SWFR_TILES_DEBUG: timing-only ablations of k_tiles (wrong pixels)
-    int cell_mode = 3;                      // SWFR_CELL_MODE: 1 = FULL rows as precomputed cells, 2 = SUB rows (test knob)
-    int fast_limit = 8;                     // rows with more active edges go through k_rows_big (SWFR_FAST_LIMIT: test knob)
-    int pipeline = 2;                       // SWFR_PIPELINE=1: the round-1 kernels (edge records); 2: cells (raster2.hip)
+    int fast_limit = 8;                     // rows with more active edges go to k2_rows_slow (SWFR_FAST_LIMIT: test knob)
     int tiles_grid = 0;                     // SWFR_TILES_GRID: persistent k2_tiles wavefronts per frame (0 = default)
-    // swfr_render_batch, pipeline 2: groups of frames rendered by ONE launch per kernel (blockIdx.y = frame); two groups alternate,
+    // swfr_render_batch: groups of frames rendered by ONE launch per kernel (blockIdx.y = frame); two groups alternate,
     // the host builds one while the GPU works on the other
     struct BatchGroup {
         SceneArena arena;                   // the frames' edge lists, tables and descriptors: one H2D copy per group
@@ -232,8 +210,6 @@ struct swfr_renderer {
     uint32_t* targets[4] = {nullptr, nullptr, nullptr, nullptr};   // swfr_set_targets: frame set k renders into targets[k]
     swfr_stats stats = {};
     uint32_t n_targets = 0, async_next = 0, async_used = 0;   // async_used: bit k = frame set k has run since the last wait
-    Frame2* d_frames = nullptr;             // one descriptor per frame set, contiguous: a batch of frames is one launch
-    Frame2* h_frames = nullptr;             // pinned staging of the same
 
     ~swfr_renderer() {
         if (has_device) {
@@ -241,7 +217,7 @@ struct swfr_renderer {
             d_bitmap_table.release(); d_tmp.release();
             for (int k = 0; k < 4; ++k) {
                 FrameSet& x = fs[k];
-                x.d_edges.release(); x.d_band_list.release(); x.d_cls.release(); x.d_rows.release(); x.d_records.release(); x.d_counters.release(); x.d_fb.release();
+                x.d_edges.release(); x.d_cls.release(); x.d_counters.release(); x.d_fb.release();
                 x.d_band2.release(); x.d_rows2.release(); x.d_cells.release(); x.d_slow.release(); x.d_huge.release(); x.d_path_flag.release(); x.d_path_queue.release(); x.d_chunks.release(); x.d_band_slots.release(); x.d_strips.release();
                 x.d_band_off.release(); x.d_path_chunks.release(); x.d_path_slots.release(); x.d_path_inc.release(); x.d_band_cnt.release(); x.d_strip_cost.release();
                 if (k > 0 && x.stream) (void)hipStreamDestroy(x.stream);
@@ -254,8 +230,6 @@ struct swfr_renderer {
                 if (g.h_counters) (void)hipHostFree(g.h_counters);
                 if (g.ev_begin) { (void)hipEventDestroy(g.ev_begin); (void)hipEventDestroy(g.ev_end); }
             }
-            if (d_frames) (void)hipFree(d_frames);
-            if (h_frames) (void)hipHostFree(h_frames);
             for (auto& kv : bitmaps) if (kv.second.pixels) (void)hipFree(kv.second.pixels);
             for (auto& e : ev) if (e) (void)hipEventDestroy(e);
             if (stream) (void)hipStreamDestroy(stream);
@@ -527,7 +501,7 @@ void prepare_sources(const swfr_path* paths, size_t n_paths, const swfr_style* s
     }
 }
 
-// What the host works out about a scene for pipeline 2: the LAYOUT of the tables the device fills -- how many row chunks, band
+// What the host works out about a scene: the LAYOUT of the tables the device fills -- how many row chunks, band
 // entries and cells there can be and where each path's share starts (prefix sums over the paths' rectangles and edge row spans,
 // and over the tile-rows) -- plus pixman's view of the bitmap / gradient styles.  No binning: that is the device's work, per frame.
 struct SceneLayout {
@@ -630,11 +604,11 @@ void fill_frame_sizes(const swfr_renderer* r, const SceneLayout& L, size_t n_edg
     f.band_index = bi; f.band_count = bc; f.fast_limit = uint32_t(std::min(std::max(r->fast_limit, 0), 8)); f.any_shader = L.any_shader ? 1u : 0u;
     const BandShare bs = band_share(r);
     f.band_first = bs.first; f.band_stride = bs.stride;
-    f.dbg = uint32_t(r->tiles_dbg); f.cell_heads = 1; f.cell_main = uint32_t(L.cell_main);
+    f.dbg = 0; f.cell_heads = 1; f.cell_main = uint32_t(L.cell_main);
     f.chunk_rows = L.chunk_rows; f.chunk_cap = uint32_t(L.n_chunks + 1); f.slot_cap = uint32_t(L.n_slots + 1); f.strip_order = r->strip_order ? 1u : 0u;
 }
 
-// Pipeline 2: uploads a scene -- the raw edge list, the paths and the styles, plus the layout above -- and sizes the buffers the
+// Uploads a scene -- the raw edge list, the paths and the styles, plus the layout above -- and sizes the buffers the
 // kernels write.
 int upload2(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, size_t n_edges, const swfr_path* paths, size_t n_paths,
             const swfr_style* styles, size_t n_styles, uint32_t* fb_override, bool edges_tagged) {
@@ -655,9 +629,8 @@ int upload2(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, siz
     SceneLayout& L = layout_scratch;
     layout_scene(r, edges, n_edges, paths, n_paths, styles, n_styles, L);
     sc.n_edges = n_edges; sc.n_paths = n_paths; sc.n_styles = n_styles; sc.any_shader = L.any_shader; sc.shader_level = L.shader_level;
-    sc.n_chunks = L.n_chunks; sc.chunk_rows = L.chunk_rows; sc.n_bands = L.n_bands; sc.n_band_entries = L.n_slots; sc.n_tasks = L.n_rows;
+    sc.n_chunks = L.n_chunks; sc.chunk_rows = L.chunk_rows; sc.n_bands = L.n_bands; sc.n_rows = L.n_rows;
     sc.n_strips = L.n_strips; sc.n_strip_slots = L.n_strip_slots; sc.n_incidences = L.incidences;
-    sc.has_order = r->strip_order != 0;
     SceneArena& A = sc.arena;
     A.begin(scene_arena_bytes(L, n_edges, n_paths, n_styles) + SceneArena::padded(4 * sizeof(Frame2)) + 4096);
     Frame2 proto;
@@ -709,7 +682,6 @@ int upload2(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, siz
         f.fb = (fb_override && k == si) ? fb_override : (r->n_targets ? r->targets[uint32_t(k) % r->n_targets] : x.d_fb.ptr);
     }
     sc.frames_dev = static_cast<Frame2*>(A.push(fr, sizeof fr));
-    std::memcpy(sc.frames_host, fr, sizeof fr);
     A.flush(up_stream, si == 0 && all_sets);
     if (r->bitmap_table_dirty) {
         if (!r->bitmap_table.empty())
@@ -723,277 +695,18 @@ int upload2(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, siz
     return SWFR_OK;
 }
 
-// Uploads a scene into scene slot `si` (H2D on frame set `si`'s stream) and sizes the kernel-written buffers: of every frame
-// set in flight (`all_sets`, resident rendering: the sets share scene 0) or of set `si` only (batch rendering: one scene per set).
+// Uploads a caller-supplied scene (validated first) into scene slot `si`; see upload2.
 int upload(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, size_t n_edges, const swfr_path* paths, size_t n_paths,
            const swfr_style* styles, size_t n_styles, uint32_t* fb_override = nullptr) {
     if (!r->has_device) return fail(r, SWFR_ERR_NO_DEVICE, "host-only handle cannot rasterize");
     validate_scene(r, edges, n_edges, paths, n_paths, styles, n_styles);
-    if (r->pipeline == 2) return upload2(r, si, all_sets, edges, n_edges, paths, n_paths, styles, n_styles, fb_override, false);
-    swfr_renderer::Scene& sc = r->scn[si];
-    if (si == 0) r->scene_ready = false;
-    sc.slow_state = 0; sc.slow_passes = SLOW_PASSES;
-    if (si > 0 && !r->fs[si].stream) HIP_CHECK(hipStreamCreateWithFlags(&r->fs[si].stream, hipStreamNonBlocking));
-    const hipStream_t up_stream = r->fs[si].stream;
-    // stage: edges tagged with their path index; row prefix over tor paths; record capacity bound
-    std::vector<swfr_edge> staged(edges, edges + n_edges);
-    for (auto& e : staged) e.reserved = 0;            // overwritten below with the owning path's index
-    std::vector<uint32_t> row_base(n_paths + 1, 0);
-    std::vector<ChunkInfo> chunks;                    // one k_rows workgroup each
-    std::vector<uint32_t> chunk_cap;
-    std::vector<BandSlot> band_slots;
-    std::vector<BigRow> huge_rows;                    // rows with more than 64 active edges: one 256-thread workgroup each (k_rows_huge, up to 2048)
-    std::vector<BigRow> big_rows;                     // rec_base holds the row's slot count until the prefix pass below
-    std::vector<int32_t> active;
-    const uint32_t bc = r->cfg.band_count > 1 ? r->cfg.band_count : 1, bi = r->cfg.band_count > 1 ? r->cfg.band_index : 0;
-    const size_t n_bands = (r->height + TILE_H - 1) / TILE_H;
-    std::vector<uint32_t> band_off(n_bands + 1, 0);
-    size_t rec_cap = 0, pair_cap = 0;
-    // rows per k_rows workgroup: 64 when that already gives the GPU a thousand wavefronts, fewer for scenes made of a few tall
-    // paths (a wavefront's run time is set by its longest row loop, so those scenes want more, shorter wavefronts)
-    uint32_t chunk_rows = ROWS_CHUNK;
-    if ((r->force_chunk_rows == 8 && r->pipeline != 2) || r->force_chunk_rows == 16 || r->force_chunk_rows == 32 || r->force_chunk_rows == 64) {
-        chunk_rows = uint32_t(r->force_chunk_rows);           // SWFR_CHUNK_ROWS: test knob (8 selects the row x slot kernel)
-    } else {
-        for (;;) {
-            size_t n = 0;
-            for (size_t i = 0; i < n_paths; ++i)
-                if (paths[i].kind == SWFR_PATH_TOR) n += size_t(paths[i].y_max - paths[i].y_min + int(chunk_rows) - 1) / chunk_rows;
-            if (n >= 1024 || chunk_rows <= (r->pipeline == 2 ? uint32_t(TILE_H) : 8u)) break;   // (pipeline 2: chunks are whole tile-rows)
-            chunk_rows >>= 1;
-        }
-    }
-    bool any_boxes = false, any_flat = false;
-    size_t max_path_edges = 0;
-    for (size_t i = 0; i < n_paths; ++i) {
-        const swfr_path& p = paths[i];
-        for (uint32_t k = 0; k < p.n_edges; ++k) staged[p.first_edge + k].reserved = int32_t(i);
-        uint32_t rows = 0, chunk_a0 = 0;
-        if (p.kind != SWFR_PATH_TOR) any_boxes = true;
-        max_path_edges = std::max<size_t>(max_path_edges, p.n_edges);
-        if (!(p.y_max > p.y_min && p.x_max > p.x_min)) any_flat = true;
-        if (p.kind == SWFR_PATH_TOR) {
-            rows = uint32_t(p.y_max - p.y_min);
-            // chunks of 16+ rows start on tile-row boundaries, so that a chunk holds whole tile-rows of the path and can
-            // classify its (tile, path) pairs itself (see fused_class)
-            const uint32_t a0 = chunk_rows >= uint32_t(TILE_H) ? uint32_t(p.y_min) / TILE_H * TILE_H : uint32_t(p.y_min);
-            const bool has_area = p.y_max > p.y_min && p.x_max > p.x_min;
-            const size_t c0 = chunks.size(), nc = (uint32_t(p.y_max) - a0 + chunk_rows - 1) / chunk_rows;
-            for (size_t c = 0; c < nc; ++c) {
-                const uint32_t first = a0 + uint32_t(c) * chunk_rows;
-                const uint32_t slot0 = has_area ? uint32_t(band_slots.size()) + (first / TILE_H - uint32_t(p.y_min) / TILE_H) : ~0u;
-                chunks.push_back(ChunkInfo{uint32_t(i), first, 0, chunk_rows, slot0, {0, 0, 0}});
-            }
-            chunk_a0 = a0;
-            chunk_cap.resize(chunks.size(), 0);
-            // active edges per pixel row, exactly as k_setup / k_rows count them (sample rows [ytop, ybot) clamped to the
-            // path): a row yields at most one record per active edge, so these counts size the record slots; rows
-            // with more than the register capacity of k_rows are listed for k_rows_big
-            active.assign(size_t(rows) + 1, 0);
-            for (uint32_t k = 0; k < p.n_edges; ++k) {
-                const swfr_edge& e = edges[p.first_edge + k];
-                int64_t ytop = (15ll * e.top + 128) >> 8, ybot = (15ll * e.bottom + 128) >> 8;
-                ytop = std::max<int64_t>(ytop, int64_t(p.y_min) * 15);
-                ybot = std::min<int64_t>(ybot, int64_t(p.y_max) * 15);
-                if (ybot <= ytop) continue;
-                ++active[size_t(ytop / 15 - p.y_min)];
-                --active[size_t((ybot - 1) / 15 - p.y_min) + 1];
-            }
-            const int limit = p.n_edges > 65535u ? 0 : std::min(std::max(r->fast_limit, 0), 8);
-            int32_t run = 0;
-            for (uint32_t y = 0; y < rows; ++y) {
-                run += active[y];
-                const uint32_t band = (uint32_t(p.y_min) + y) / TILE_H;
-                if (bc > 1 && band % bc != bi) continue;          // another rank's tile-row: k_rows leaves it empty
-                if (run > 64) huge_rows.push_back(BigRow{uint32_t(i), int32_t(p.y_min) + int32_t(y), uint32_t(run), 0});   // k_rows_huge (<= 2048)
-                else if (run > limit) big_rows.push_back(BigRow{uint32_t(i), int32_t(p.y_min) + int32_t(y), uint32_t(run), 0});
-                else chunk_cap[c0 + (uint32_t(p.y_min) + y - chunk_a0) / chunk_rows] += uint32_t(run);
-            }
-        }
-        row_base[i + 1] = row_base[i] + rows;
-        if (p.y_max > p.y_min && p.x_max > p.x_min) {
-            // slot of this path in every tile-row list it touches: its rank among the paths seen so far (painter's order)
-            for (int b = p.y_min / TILE_H; b <= (p.y_max - 1) / TILE_H; ++b)
-                band_slots.push_back(BandSlot{uint32_t(i), band_off[size_t(b) + 1]++, uint32_t(b), 0});
-            pair_cap += size_t((p.y_max - 1) / TILE_H - p.y_min / TILE_H + 1) * size_t((p.x_max - 1) / TILE_W - p.x_min / TILE_W + 1);
-        }
-    }
-    for (size_t b = 0; b < n_bands; ++b) band_off[b + 1] += band_off[b];   // exact sizes
-    for (BandSlot& bs : band_slots) bs.slot += band_off[bs.band];
-    // ---- launch order of the k_tiles wavefronts: strips crossed by many edges first (a scheduling hint from edge
-    //      end points only: x of the edge at the strip's top and bottom by linear interpolation, one column of slack)
-    std::vector<uint32_t> order;
-    if (r->strip_order) {
-        const uint32_t tiles_x = (r->width + TILE_W - 1) / TILE_W, n_local = local_tile_rows(r);
-        const uint32_t strip_rows = uint32_t(n_bands) * STRIPS_PER_TILE;
-        std::vector<uint32_t> cost(size_t(strip_rows) * tiles_x, 0);
-        for (size_t i = 0; i < n_paths; ++i) {
-            const swfr_path& p = paths[i];
-            if (p.kind != SWFR_PATH_TOR) continue;
-            for (uint32_t k = 0; k < p.n_edges; ++k) {
-                const swfr_edge& e = edges[p.first_edge + k];
-                const int64_t top = std::max<int64_t>(e.top, int64_t(p.y_min) * 256), bot = std::min<int64_t>(e.bottom, int64_t(p.y_max) * 256);
-                if (bot <= top || e.y2 == e.y1) continue;
-                const double slope = double(e.x2 - e.x1) / double(e.y2 - e.y1);
-                for (int64_t sr = (top >> 8) / STRIP_H; sr <= ((bot - 1) >> 8) / STRIP_H && sr < int64_t(strip_rows); ++sr) {
-                    const int64_t ya = std::max<int64_t>(top, sr * STRIP_H * 256), yb = std::min<int64_t>(bot, (sr + 1) * STRIP_H * 256);
-                    const double xa = e.x1 + slope * double(ya - e.y1), xb = e.x1 + slope * double(yb - e.y1);
-                    int64_t ca = int64_t(std::floor(std::min(xa, xb) / 256.0)) - 1, cb = int64_t(std::floor(std::max(xa, xb) / 256.0)) + 1;
-                    ca = std::max<int64_t>(ca, p.x_min); cb = std::min<int64_t>(cb, int64_t(p.x_max) - 1);
-                    const uint32_t w = uint32_t((yb - ya + 255) >> 8);
-                    for (int64_t tc = ca / TILE_W; tc <= cb / TILE_W && tc < int64_t(tiles_x); ++tc) cost[size_t(sr) * tiles_x + size_t(tc)] += w;
-                }
-            }
-        }
-        constexpr uint32_t NBUCKET = 128;
-        std::vector<uint32_t> bucket_n(NBUCKET + 1, 0);
-        auto bucket_of = [&](uint32_t c) { return NBUCKET - 1 - std::min<uint32_t>(c / 2, NBUCKET - 1); };   // bucket 0 = heaviest
-        const uint32_t n_wg = n_local * tiles_x * STRIPS_PER_TILE;
-        auto cost_of = [&](uint32_t wg) {
-            const uint32_t tile = wg / STRIPS_PER_TILE, strip = wg % STRIPS_PER_TILE, tcol = tile % tiles_x, trow = (tile / tiles_x) * bc + bi;
-            return cost[size_t(trow * STRIPS_PER_TILE + strip) * tiles_x + tcol];
-        };
-        for (uint32_t wg = 0; wg < n_wg; ++wg) ++bucket_n[bucket_of(cost_of(wg)) + 1];
-        for (uint32_t b = 0; b < NBUCKET; ++b) bucket_n[b + 1] += bucket_n[b];
-        order.resize(n_wg);
-        for (uint32_t wg = 0; wg < n_wg; ++wg) order[bucket_n[bucket_of(cost_of(wg))]++] = wg;   // row-major inside a bucket
-    }
-    sc.n_edges = n_edges; sc.n_paths = n_paths; sc.n_styles = n_styles;
-    sc.any_shader = false;
-    for (size_t i = 0; i < n_styles; ++i) sc.any_shader = sc.any_shader || styles[i].kind != SWFR_STYLE_SOLID;
-    for (size_t c = 0; c < chunks.size(); ++c) { chunks[c].rec_base = uint32_t(rec_cap); rec_cap += chunk_cap[c]; }
-    sc.n_tasks = row_base[n_paths];
-    sc.n_chunks = chunks.size();
-    sc.chunk_rows = chunk_rows;
-    sc.n_bands = n_bands;
-    sc.rec_main = rec_cap;                            // chunk-owned region; the rows of k_rows_big own slots behind it
-    for (auto& b : big_rows) { const uint32_t n = b.rec_base; b.rec_base = uint32_t(rec_cap); rec_cap += n; }
-    for (auto& b : huge_rows) { const uint32_t n = b.rec_base; b.rec_base = uint32_t(rec_cap); rec_cap += n; }
-    sc.n_huge = huge_rows.size();
-    sc.rec_cap = rec_cap + 64;
-    sc.n_big = big_rows.size();
-    // the chunk workgroups of k_rows classify their own (tile, path) pairs when every row of the scene is theirs (no crowded
-    // rows, no box paths, no other rank's tile-rows): k_class is then not launched at all
-    sc.fused_class = r->allow_fused && chunk_rows >= uint32_t(TILE_H) && big_rows.empty() && huge_rows.empty() && !any_boxes && bc == 1;
-    // ... and when, besides, every path's edges fit the chunk staging area and every path has an area (so that every band entry
-    // belongs to a chunk), the chunks also compute their edges' constants and write their band entries: k_front is not launched
-    sc.fused_front = sc.fused_class && r->allow_fused > 1 && max_path_edges <= 64 && !any_flat;
-    sc.n_band_entries = band_off[n_bands];
-    sc.n_incidences = rec_cap;
-    sc.n_strips = size_t(local_tile_rows(r)) * ((r->width + TILE_W - 1) / TILE_W) * STRIPS_PER_TILE;
-    (void)pair_cap;
-    // per-frame (kernel-written) buffers: grow-only allocations
-    const int n_sets = std::max(1, std::min(r->in_flight, 4));
-    for (int k = 0; k < 4; ++k) {
-        if (all_sets ? k >= n_sets : k != si) continue;
-        auto& x = r->fs[k];
-        x.d_edges.reserve(n_edges); x.d_rows.reserve(sc.n_tasks); x.d_records.reserve(sc.rec_cap); x.d_band_list.reserve(sc.n_band_entries);
-        x.d_cls.reserve(sc.n_band_entries * ((r->width + TILE_W - 1) / TILE_W) + 64);   // class byte per (band entry, tile column)
-        x.d_counters.reserve(COUNTER_WORDS);
-        if (r->pipeline == 2) {
-            // every (edge, pixel row) pair yields at most MAX_CELLS_PER_EDGE_ROW cells; the arena is cut into C2_HEADS slices, one per
-            // bump allocator (wavefronts pick theirs by workgroup number), with a factor two for uneven shares
-            // (a scene of a few wavefronts uses one allocator: shares of a handful of wavefronts are not even)
-            // the chunk wavefronts of k2_rows write at fixed places (their share of that bound, from the chunk table); the rows of the
-            // slow-row kernels take theirs from one bump allocator behind that region
-            const size_t heads = 1;
-            const size_t slice = sc.n_incidences * MAX_CELLS_PER_EDGE_ROW * 2 + 2048;
-            x.d_band2.reserve(sc.n_band_entries); x.d_rows2.reserve(sc.n_band_entries * TILE_H + 64); x.d_cells.reserve(slice * heads);
-            x.cell_heads = heads;
-            x.d_slow.reserve(2 * (sc.n_tasks + 64)); x.d_huge.reserve(2 * (sc.n_tasks + 64));     // (two queues each: a pass reads one and refills the other)
-            x.d_path_flag.reserve(n_paths + 64); x.d_path_queue.reserve(n_paths + 64);
-            x.cell_slice = slice; x.slow_cap = sc.n_tasks + 64;
-            // class bytes outside the paths' rectangles are never written by a kernel: cleared once per uploaded scene
-            HIP_CHECK(hipMemsetAsync(x.d_cls.ptr, 0, sc.n_band_entries * ((r->width + TILE_W - 1) / TILE_W) + 64, up_stream));
-        }
-        if (!x.d_fb.ptr) {
-            x.d_fb.reserve(size_t(r->width) * r->height);
-            HIP_CHECK(hipMemsetAsync(x.d_fb.ptr, 0, size_t(r->width) * r->height * 4, up_stream));
-        }
-        if (!x.stream) HIP_CHECK(hipStreamCreateWithFlags(&x.stream, hipStreamNonBlocking));
-    }
-    // the scene's read-only arrays: one pinned staging buffer, one H2D copy, views into one device arena
-    std::vector<DevFilter> filters;
-    std::vector<DevGradient> gradients;
-    std::vector<int32_t> fparams;
-    prepare_sources(paths, n_paths, styles, n_styles, filters, gradients, fparams, r->bitmap_table);
-    sc.has_order = !order.empty();
-    // the launch list of the tile pass: every strip of this handle's tile-rows with its tile-row's slice of the band list
-    std::vector<StripDesc> strips;
-    if (r->pipeline == 2) {
-        const uint32_t tiles_x = (r->width + TILE_W - 1) / TILE_W;
-        strips.resize(sc.n_strips);
-        for (uint32_t w = 0; w < strips.size(); ++w) {
-            const uint32_t wg = order.empty() ? w : order[w];
-            const uint32_t trow = (wg / STRIPS_PER_TILE / tiles_x) * bc + bi;
-            strips[w] = StripDesc{wg, band_off[trow], band_off[trow + 1] - band_off[trow], 0};
-        }
-    }
-    {
-        SceneArena& A = sc.arena;
-        auto P = SceneArena::padded;
-        A.begin(P(n_edges * sizeof(swfr_edge)) + P(n_paths * sizeof(swfr_path)) + P(n_styles * sizeof(swfr_style)) +
-                P((n_paths + 1) * sizeof(uint32_t)) + P(band_slots.size() * sizeof(BandSlot)) + P(order.size() * sizeof(uint32_t)) +
-                P(big_rows.size() * sizeof(BigRow)) + P(huge_rows.size() * sizeof(BigRow)) + P(chunks.size() * sizeof(ChunkInfo)) + P((n_bands + 1) * sizeof(uint32_t)) +
-                P(n_styles * sizeof(DevFilter)) + P(fparams.size() * sizeof(int32_t)) + P(gradients.size() * sizeof(DevGradient)) + P(4 * sizeof(Frame2)) + P(strips.size() * sizeof(StripDesc)) + 4096);
-        sc.raw = static_cast<swfr_edge*>(A.push(staged.data(), n_edges * sizeof(swfr_edge)));
-        sc.paths = static_cast<DevPath*>(A.push(paths, n_paths * sizeof(swfr_path)));
-        sc.styles = static_cast<swfr_style*>(A.push(styles, n_styles * sizeof(swfr_style)));
-        sc.row_base = static_cast<uint32_t*>(A.push(row_base.data(), (n_paths + 1) * sizeof(uint32_t)));
-        sc.band_slots = static_cast<BandSlot*>(A.push(band_slots.data(), band_slots.size() * sizeof(BandSlot)));
-        sc.order = static_cast<uint32_t*>(A.push(order.data(), order.size() * sizeof(uint32_t)));
-        sc.big_rows = static_cast<BigRow*>(A.push(big_rows.data(), big_rows.size() * sizeof(BigRow)));
-        sc.huge_rows = static_cast<BigRow*>(A.push(huge_rows.data(), huge_rows.size() * sizeof(BigRow)));
-        sc.chunk_base = static_cast<ChunkInfo*>(A.push(chunks.data(), chunks.size() * sizeof(ChunkInfo)));
-        sc.band_off = static_cast<uint32_t*>(A.push(band_off.data(), (n_bands + 1) * sizeof(uint32_t)));
-        sc.filters = static_cast<DevFilter*>(A.push(filters.data(), n_styles * sizeof(DevFilter)));
-        sc.filter_params = static_cast<int32_t*>(A.push(fparams.data(), fparams.size() * sizeof(int32_t)));
-        sc.gradients = static_cast<DevGradient*>(A.push(gradients.data(), gradients.size() * sizeof(DevGradient)));
-        if (r->pipeline == 2) {
-            sc.strips = static_cast<StripDesc*>(A.push(strips.data(), strips.size() * sizeof(StripDesc)));
-            if (r->bitmap_table_dirty) r->d_bitmap_table.reserve(r->bitmap_table.size());     // (filled below; the address is what the descriptor needs)
-            Frame2 fr[4];
-            std::memset(fr, 0, sizeof fr);
-            for (int k = 0; k < 4; ++k) {
-                if (all_sets ? k >= n_sets : k != si) continue;
-                auto& x = r->fs[k];
-                Frame2& f = fr[k];
-                f.raw = sc.raw; f.paths = sc.paths; f.styles = sc.styles; f.chunks = sc.chunk_base; f.band_slots = sc.band_slots; f.band_off = sc.band_off;
-                f.strips = sc.strips;
-                f.src = Sources{r->d_bitmap_table.ptr, sc.filters, sc.filter_params, sc.gradients};
-                f.edges = x.d_edges.ptr; f.band_list = x.d_band2.ptr; f.cls = x.d_cls.ptr; f.rows = x.d_rows2.ptr; f.cells = x.d_cells.ptr;
-                f.slow = x.d_slow.ptr; f.huge = x.d_huge.ptr; f.counters = x.d_counters.ptr;
-                f.path_flag = x.d_path_flag.ptr; f.path_queue = x.d_path_queue.ptr;
-                f.fb = (fb_override && k == si) ? fb_override : x.d_fb.ptr;
-                f.n_edges = uint32_t(n_edges); f.n_paths = uint32_t(n_paths); f.n_chunks = uint32_t(sc.n_chunks); f.n_slots = uint32_t(sc.n_band_entries);
-                f.n_bands = uint32_t(n_bands); f.n_strips = uint32_t(sc.n_strips); f.cell_slice = uint32_t(x.cell_slice); f.slow_cap = uint32_t(x.slow_cap);
-                f.width = int32_t(r->width); f.height = int32_t(r->height); f.tiles_x = int32_t((r->width + TILE_W - 1) / TILE_W);
-                f.band_index = bi; f.band_count = bc; f.fast_limit = uint32_t(std::min(std::max(r->fast_limit, 0), 8)); f.any_shader = sc.any_shader ? 1u : 0u;
-                f.dbg = uint32_t(r->tiles_dbg); f.cell_heads = 1; f.cell_main = uint32_t(sc.n_incidences * MAX_CELLS_PER_EDGE_ROW);
-            }
-            sc.frames_dev = static_cast<Frame2*>(A.push(fr, sizeof fr));
-            std::memcpy(sc.frames_host, fr, sizeof fr);
-        }
-        A.flush(up_stream);
-    }
-    if (r->bitmap_table_dirty) {
-        r->d_bitmap_table.reserve(r->bitmap_table.size());
-        if (!r->bitmap_table.empty())
-            HIP_CHECK(hipMemcpyAsync(r->d_bitmap_table.ptr, r->bitmap_table.data(), r->bitmap_table.size() * sizeof(DevBitmap),
-                                     hipMemcpyHostToDevice, r->stream));
-        r->bitmap_table_dirty = false;
-        r->bitmap_table_dirty_copied = true;
-    }
-    if (r->bitmap_table_dirty_copied) { HIP_CHECK(hipStreamSynchronize(r->stream)); r->bitmap_table_dirty_copied = false; }   // bitmap_table may be edited next
-    if (si == 0) r->scene_ready = true;
-    return SWFR_OK;
+    return upload2(r, si, all_sets, edges, n_edges, paths, n_paths, styles, n_styles, fb_override, false);
 }
 
 // the kernels of one frame of scene `sc` on frame set `F`, writing the framebuffer `fb`; e (optional): four events around them
 void launch_frame(swfr_renderer* r, const swfr_renderer::Scene& sc, swfr_renderer::FrameSet& F, uint32_t* fb, hipEvent_t* e) {
-    const uint32_t bc = r->cfg.band_count > 1 ? r->cfg.band_count : 1, bi = r->cfg.band_count > 1 ? r->cfg.band_index : 0;
     const hipStream_t st = F.stream;
-    if (r->pipeline == 2) {
+    {
         // the frame's descriptor (scene arrays, this set's buffers, the framebuffer) was written with the scene
         const Frame2* fh = sc.frames_dev + (&F - r->fs);        // the set's descriptor, uploaded with the scene
         if (e) HIP_CHECK(hipEventRecord(e[0], st));
@@ -1006,32 +719,12 @@ void launch_frame(swfr_renderer* r, const swfr_renderer::Scene& sc, swfr_rendere
         const uint32_t grid = r->tiles_grid > 0 ? uint32_t(r->tiles_grid) : ~0u;
         launch2_tiles(st, fh, 1, uint32_t(sc.n_strip_slots), grid, sc.shader_level);
         if (e) HIP_CHECK(hipEventRecord(e[3], st));
-        (void)fb;
-        return;
+        (void)fb;                                            // (the descriptor carries the framebuffer's address)
     }
-    if (e) HIP_CHECK(hipEventRecord(e[0], st));
-    if (sc.n_paths && !sc.fused_front)   // edge constants + band lists (the row kernel does both itself when fused_front)
-        launch_front(st, sc.raw, sc.paths, F.d_edges.ptr, uint32_t(sc.n_edges), sc.band_slots, uint32_t(sc.n_band_entries),
-                     sc.row_base, sc.styles, F.d_band_list.ptr, F.d_counters.ptr);
-    if (e) HIP_CHECK(hipEventRecord(e[1], st));
-    if (sc.n_paths) {
-        launch_rows(st, F.d_edges.ptr, sc.paths, sc.row_base, sc.chunk_base, uint32_t(sc.n_paths), F.d_rows.ptr,
-                    F.d_records.ptr, F.d_counters.ptr, sc.big_rows, uint32_t(sc.n_big), uint32_t(sc.n_chunks), bi, bc, r->fast_limit,
-                    r->cell_mode, uint32_t(sc.chunk_rows), sc.band_slots, sc.band_off, F.d_cls.ptr, int(r->width), int(r->height),
-                    (sc.fused_class ? 1 : 0) | (sc.fused_front ? 2 : 0), sc.raw, sc.styles, F.d_band_list.ptr, sc.huge_rows, uint32_t(sc.n_huge));
-        if (!sc.fused_class)
-            launch_class(st, F.d_band_list.ptr, uint32_t(sc.n_band_entries), sc.band_off, uint32_t(sc.n_bands), sc.raw,
-                         F.d_rows.ptr, F.d_records.ptr, F.d_cls.ptr, int(r->width), int(r->height), bi, bc);
-    }
-    if (e) HIP_CHECK(hipEventRecord(e[2], st));
-    launch_tiles(st, sc.raw, sc.band_off, F.d_band_list.ptr, F.d_cls.ptr, F.d_rows.ptr, F.d_records.ptr, sc.styles,
-                 Sources{r->d_bitmap_table.ptr, sc.filters, sc.filter_params, sc.gradients}, fb, int(r->width), int(r->height), bi, bc, r->tiles_dbg,
-                 F.d_counters.ptr, uint32_t(sc.n_tasks), uint32_t(sc.rec_cap), sc.any_shader, sc.has_order ? sc.order : nullptr);
-    if (e) HIP_CHECK(hipEventRecord(e[3], st));
 }
 
 int check_counters(swfr_renderer* r, const uint32_t* counters) {
-    if (r->pipeline == 2) {
+    {
         const uint32_t err = counters[C2_ERROR];
         r->stats.frames += 1; r->stats.queued_rows += counters[C2_SLOW]; r->stats.crowded_rows += counters[C2_HUGE];
         r->stats.tie_rows += counters[C2_TIE_ROWS];
@@ -1058,15 +751,6 @@ int check_counters(swfr_renderer* r, const uint32_t* counters) {
         }
         return SWFR_OK;
     }
-    if (counters[CNT_ERROR] & ~1u) {
-        r->fb_valid = false;
-        return fail(r, SWFR_ERR_DEVICE, "internal consistency check failed in k_tiles (code " + std::to_string(counters[CNT_ERROR]) + ")");
-    }
-    if (counters[CNT_ERROR]) {
-        r->fb_valid = false;
-        return fail(r, SWFR_ERR_CAPACITY, "a pixel row has more than 2048 active edges of one path (scan converter capacity)");
-    }
-    return SWFR_OK;
 }
 
 int render_resident(swfr_renderer* r, uint32_t frames) {
@@ -1123,30 +807,20 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
     }
     HIP_CHECK(hipEventElapsedTime(&total_ms, ev_begin, ev_end));
     std::memcpy(counters, r->h_counters, sizeof counters);
-    for (uint32_t k = 1; k < n_sets; ++k) {
-        counters[CNT_ERROR] |= r->h_counters[k * COUNTER_WORDS + CNT_ERROR];
-        counters[C2_ERROR] |= r->h_counters[k * COUNTER_WORDS + C2_ERROR];
-    }
-    r->timing = swfr_timing{total_ms, setup_ms, rows_ms, tiles_ms, frames, sc.n_edges, sc.n_paths, sc.n_tasks, sc.rec_main, timed_frames};
-    if (r->tiles_dbg == 9)
-        std::fprintf(stderr, "[swfr] tile/path pairs %u, partial %u, full %u, culled entries %u\n", counters[CNT_PAIRS],
-                     counters[CNT_PARTIAL], counters[CNT_FULL], counters[CNT_CULLED]);
+    for (uint32_t k = 1; k < n_sets; ++k)                  // (set 0's counts, every set's error and limit flags)
+        for (uint32_t w : {uint32_t(C2_ERROR), uint32_t(C2_TIE_PAIRTEST_SKIPPED), uint32_t(C2_TIE_SORT_OVERFLOW), uint32_t(C2_TIE_DEPTH)})
+            counters[w] |= r->h_counters[k * COUNTER_WORDS + w];
+    r->timing = swfr_timing{total_ms, setup_ms, rows_ms, tiles_ms, frames, sc.n_edges, sc.n_paths, sc.n_rows, 0, timed_frames};
 #ifdef SWFR_PHASES
-    if (std::getenv("SWFR_PRINT_PHASES") && r->pipeline == 2 && counters[C2_CELLS]) {
+    if (std::getenv("SWFR_PRINT_PHASES") && counters[C2_CELLS]) {
         static const char* names[8] = {"descriptors", "stage edges", "gather", "evaluate", "full test + alloc", "sample rows", "full cells", "queue + class"};
         std::fprintf(stderr, "[swfr] k2_rows phases, clocks per wavefront (%u wavefronts):", counters[C2_CELLS]);
         for (int i = 0; i < 8; ++i) std::fprintf(stderr, " %s %.0f", names[i], 16.0 * counters[24 + i] / counters[C2_CELLS]);
         std::fprintf(stderr, "\n");
     }
-    if (std::getenv("SWFR_PRINT_PHASES") && r->pipeline != 2 && counters[16]) {
-        static const char* names[8] = {"descriptors", "stage edges", "gather", "evaluate", "full test", "sample rows", "records", "bands+class"};
-        std::fprintf(stderr, "[swfr] k_rows phases, clocks per wavefront (%u wavefronts):", counters[16]);
-        for (int i = 0; i < 8; ++i) std::fprintf(stderr, " %s %.0f", names[i], 16.0 * counters[8 + i] / counters[16]);
-        std::fprintf(stderr, "\n");
-    }
 #endif
     r->fb_valid = true;
-    if (r->pipeline == 2) {
+    {
         uint32_t slow = 0, huge = 0;
         for (uint32_t k = 0; k < n_sets; ++k) { slow |= r->h_counters[k * COUNTER_WORDS + C2_SLOW]; huge |= r->h_counters[k * COUNTER_WORDS + C2_HUGE]; }
         uint32_t passes = 1;
@@ -1167,7 +841,7 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
 // of frame set i mod n and rasterized on that set's stream straight into device_dst + i * frame_stride, while the host already
 // builds frame i+1.  Nothing waits for the GPU until the end (a scene slot's pinned staging buffer is reused only after its
 // previous H2D copy has completed).
-// swfr_render_batch for pipeline 2 with a device destination: the frames are rendered in groups of SWFR_BATCH_FRAMES (default 64) by
+// swfr_render_batch with a device destination: the frames are rendered in groups of SWFR_BATCH_FRAMES (default 64) by
 // one launch per kernel and group (blockIdx.y = frame of the group, every frame with its own descriptor, tables and buffers), so a
 // batch of small frames -- the 256 ratios of a morph shape -- fills the GPU instead of paying a launch chain per frame.  Two groups
 // alternate: the host builds group g + 1 (scene walk, flattening, layout) while the GPU rasterizes group g.
@@ -1292,7 +966,7 @@ int render_batch(swfr_renderer* r, const swfr_stage* stages, uint32_t n, void* d
     if (!r->has_device) return fail(r, SWFR_ERR_NO_DEVICE, "host-only handle cannot rasterize");
     if (n == 0) return SWFR_OK;
     if (device_dst && frame_stride < size_t(r->width) * r->height * 4) return fail(r, SWFR_ERR_INVALID, "frame stride smaller than a frame");
-    if (r->pipeline == 2 && device_dst && r->batch_frames > 1) return render_batch2(r, stages, n, device_dst, frame_stride);
+    if (device_dst && r->batch_frames > 1) return render_batch2(r, stages, n, device_dst, frame_stride);
     const uint32_t n_sets = uint32_t(std::max(1, std::min(r->in_flight, 4)));
     std::vector<uint32_t*> pinned_counters;
     uint32_t* hc = nullptr;
@@ -1306,10 +980,8 @@ int render_batch(swfr_renderer* r, const swfr_stage* stages, uint32_t n, void* d
             const auto& p = r->builder->paths();
             const auto& s = r->builder->styles();
             uint32_t* fb_dst = device_dst ? reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(device_dst) + size_t(i) * frame_stride) : nullptr;
-            if (r->pipeline == 2) {
-                validate_scene(r, e.data(), e.size(), p.data(), p.size(), s.data(), s.size());
-                rc = upload2(r, k, false, e.data(), e.size(), p.data(), p.size(), s.data(), s.size(), fb_dst, true);
-            } else rc = upload(r, k, false, e.data(), e.size(), p.data(), p.size(), s.data(), s.size(), fb_dst);
+            validate_scene(r, e.data(), e.size(), p.data(), p.size(), s.data(), s.size());
+            rc = upload2(r, k, false, e.data(), e.size(), p.data(), p.size(), s.data(), s.size(), fb_dst, true);   // (the builder's edges carry their path index)
             if (rc != SWFR_OK) break;
             swfr_renderer::FrameSet& F = r->fs[k];
             if (k > 0 && i < n_sets) HIP_CHECK(hipStreamSynchronize(r->stream));   // first use of the set: bitmap table etc. are in place
@@ -1355,16 +1027,12 @@ int swfr_create(uint32_t width, uint32_t height, const swfr_config* cfg, swfr_re
     if (r->cfg.band_count > 1 && r->cfg.band_index >= r->cfg.band_count) return SWFR_ERR_INVALID;
     r->builder.reset(new FrameBuilder(width, height, (r->cfg.flags & SWFR_FLAG_EVEN_ODD) != 0));
     if (const char* fl = std::getenv("SWFR_FAST_LIMIT")) r->fast_limit = std::atoi(fl);
-    if (const char* pl = std::getenv("SWFR_PIPELINE")) r->pipeline = std::atoi(pl) == 1 ? 1 : 2;
     if (const char* tg = std::getenv("SWFR_TILES_GRID")) r->tiles_grid = std::atoi(tg);
     if (const char* bf = std::getenv("SWFR_BATCH_FRAMES")) r->batch_frames = std::max(1, std::atoi(bf));
-    if (const char* td = std::getenv("SWFR_TILES_DEBUG")) r->tiles_dbg = std::atoi(td);
-    if (const char* fc = std::getenv("SWFR_FUSED_CLASS")) r->allow_fused = std::atoi(fc);
     if (const char* cr = std::getenv("SWFR_CHUNK_ROWS")) r->force_chunk_rows = std::atoi(cr);
     if (const char* so = std::getenv("SWFR_STRIP_ORDER")) r->strip_order = std::atoi(so);
     if (const char* fi = std::getenv("SWFR_FRAMES_IN_FLIGHT")) r->in_flight = std::atoi(fi);
     if (const char* es = std::getenv("SWFR_EVENT_STRIDE")) r->event_stride = std::atoi(es);
-    if (const char* cm = std::getenv("SWFR_CELL_MODE")) r->cell_mode = std::atoi(cm);
     if (r->cfg.device == SWFR_DEVICE_HOST_ONLY) {
         *out = r.release();
         return SWFR_OK;
@@ -1481,11 +1149,8 @@ int swfr_render(swfr_renderer* r, const swfr_stage* stage) {
         const auto& e = r->builder->edges();
         const auto& p = r->builder->paths();
         const auto& s = r->builder->styles();
-        int rc;
-        if (r->pipeline == 2) {                             // (the builder's edges carry their path index already)
-            validate_scene(r, e.data(), e.size(), p.data(), p.size(), s.data(), s.size());
-            rc = upload2(r, 0, true, e.data(), e.size(), p.data(), p.size(), s.data(), s.size(), nullptr, true);
-        } else rc = upload(r, 0, true, e.data(), e.size(), p.data(), p.size(), s.data(), s.size());
+        validate_scene(r, e.data(), e.size(), p.data(), p.size(), s.data(), s.size());
+        int rc = upload2(r, 0, true, e.data(), e.size(), p.data(), p.size(), s.data(), s.size(), nullptr, true);   // (the builder's edges carry their path index)
         const auto t2 = clk::now();
         if (rc != SWFR_OK) return rc;
         rc = render_resident(r, 1);
@@ -1493,7 +1158,7 @@ int swfr_render(swfr_renderer* r, const swfr_stage* stage) {
         swfr_path_timing& pt = r->path_timing;
         pt.build_ms = ms(t0, t1); pt.upload_host_ms = ms(t1, t2); pt.device_ms = r->timing.total_ms; pt.total_ms = ms(t0, t3);
         pt.h2d_bytes = r->scn[0].arena.used; pt.h2d_ms = 0;
-        if (r->pipeline == 2 && r->scn[0].arena.copy_begin) {
+        if (r->scn[0].arena.copy_begin) {
             float h = 0;
             if (hipEventElapsedTime(&h, r->scn[0].arena.copy_begin, r->scn[0].arena.copy_end) == hipSuccess) pt.h2d_ms = h;
         }
@@ -1606,7 +1271,7 @@ int swfr_set_targets(swfr_renderer* r, void* const* device_targets, uint32_t n_t
 int swfr_render_resident_async(swfr_renderer* r, uint32_t* out_set) {
     if (!r) return SWFR_ERR_INVALID;
     if (!r->has_device) return fail(r, SWFR_ERR_NO_DEVICE, "host-only handle cannot rasterize");
-    if (!r->scene_ready || r->pipeline != 2) return fail(r, SWFR_ERR_INVALID, "no scene uploaded");
+    if (!r->scene_ready) return fail(r, SWFR_ERR_INVALID, "no scene uploaded");
     return guarded(r, [&]() {
         uint32_t n_sets = 1;
         while (n_sets < uint32_t(std::min(r->in_flight, 4)) && r->fs[n_sets].stream && r->fs[n_sets].d_cells.ptr) ++n_sets;
@@ -1640,7 +1305,7 @@ int swfr_wait(swfr_renderer* r) {
             if (!(r->async_used >> k & 1u)) { HIP_CHECK(hipStreamSynchronize(r->fs[k].stream)); continue; }
             HIP_CHECK(hipMemcpyAsync(r->h_counters + k * COUNTER_WORDS, r->fs[k].d_counters.ptr, COUNTER_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, r->fs[k].stream));
             HIP_CHECK(hipStreamSynchronize(r->fs[k].stream));
-            if (rc == SWFR_OK && r->pipeline == 2) rc = check_counters(r, r->h_counters + k * COUNTER_WORDS);
+            if (rc == SWFR_OK) rc = check_counters(r, r->h_counters + k * COUNTER_WORDS);
         }
         r->async_used = 0;
         r->fb_valid = rc == SWFR_OK;
@@ -1652,8 +1317,8 @@ long swfr_debug_copy(swfr_renderer* r, int what, void* dst, size_t bytes) {
     if (!r || !dst) return -long(SWFR_ERR_INVALID);
     if (!r->has_device) return -long(SWFR_ERR_NO_DEVICE);
     const swfr_renderer::FrameSet& F = r->fs[0];
-    const void* src = what == 0 ? static_cast<const void*>(F.d_rows.ptr) : static_cast<const void*>(F.d_records.ptr);
-    const size_t have = what == 0 ? F.d_rows.cap * sizeof(RowInfo) : F.d_records.cap * sizeof(Rec);
+    const void* src = what == 0 ? static_cast<const void*>(F.d_rows2.ptr) : static_cast<const void*>(F.d_cells.ptr);
+    const size_t have = what == 0 ? F.d_rows2.cap * sizeof(RowInfo2) : F.d_cells.cap * sizeof(Cell);
     const size_t n = std::min(bytes, have);
     if (!src || !n) return 0;
     if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(dst, src, n, hipMemcpyDeviceToHost) != hipSuccess) return -long(SWFR_ERR_DEVICE);

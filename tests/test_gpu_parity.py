@@ -268,17 +268,15 @@ def test_tile_with_an_uncovered_path_row_is_not_a_full_cover():
 
 
 # ---- every internal route of the row/tile kernels gives the same pixels
-@pytest.mark.parametrize("env", [{"SWFR_FAST_LIMIT": "0"}, {"SWFR_FAST_LIMIT": "3"}, {"SWFR_CELL_MODE": "0"}, {"SWFR_CHUNK_ROWS": "64"},
-                                 {"SWFR_CHUNK_ROWS": "8"}, {"SWFR_CHUNK_ROWS": "8", "SWFR_FAST_LIMIT": "3"}, {"SWFR_CHUNK_ROWS": "16", "SWFR_CELL_MODE": "0"},
-                                 {"SWFR_FUSED_CLASS": "0"}, {"SWFR_FUSED_CLASS": "1"}, {"SWFR_CHUNK_ROWS": "32", "SWFR_FAST_LIMIT": "8"},
-                                 {"SWFR_TILES_DEBUG": "14"}, {"SWFR_TILES_DEBUG": "15"}])
+@pytest.mark.parametrize("env", [{"SWFR_FAST_LIMIT": "0"}, {"SWFR_FAST_LIMIT": "3"}, {"SWFR_CHUNK_ROWS": "64"}, {"SWFR_CHUNK_ROWS": "16"},
+                                 {"SWFR_CHUNK_ROWS": "32", "SWFR_FAST_LIMIT": "3"}, {"SWFR_STRIP_ORDER": "0"}, {"SWFR_FRAMES_IN_FLIGHT": "1"},
+                                 {"SWFR_FRAMES_IN_FLIGHT": "4", "SWFR_CHUNK_ROWS": "16"}, {"SWFR_BATCH_FRAMES": "1"}])
 def test_kernel_route_knobs_are_pixel_identical(env, monkeypatch):
-    """SWFR_FAST_LIMIT routes rows with more active edges than the limit through k_rows_big (the generic LDS-list
-    routine); SWFR_CELL_MODE=0 keeps analytic records instead of precomputed cells; SWFR_CHUNK_ROWS picks the rows per k_rows
-    wavefront (8 = the row x slot kernel that small scenes use by default, 64 = the row-per-lane kernel of crowded scenes);
-    SWFR_FUSED_CLASS=0 forces the separate k_class launch where the row kernel would classify its own tiles;
-    SWFR_TILES_DEBUG=14 blends edge pixels row by row instead of in compacted form, 15 caps the compacted queue at 12 pixels
-    so that both forms run within one frame.  Same bytes either way."""
+    """SWFR_FAST_LIMIT sends rows with more active edges than the limit (0: every row) to the queued-row kernels (k2_rows_slow /
+    k2_rows_huge) instead of the fast routine of k2_rows; SWFR_CHUNK_ROWS picks the pixel rows per k2_rows wavefront (16, 32 or 64;
+    by default the largest that still gives a thousand wavefronts); SWFR_STRIP_ORDER=0 launches the strips of k2_tiles row-major
+    instead of heaviest first; SWFR_FRAMES_IN_FLIGHT is the number of frame sets (streams, intermediate buffers) consecutive
+    frames rotate over; SWFR_BATCH_FRAMES=1 makes swfr_render_batch launch every frame by itself.  Same bytes either way."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     for name in ("config2_homestuck-beta-1", "translucent_stack", "evenodd_pentagram", "offframe_fill_stroke", "morph_128",

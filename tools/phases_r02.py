@@ -1,4 +1,4 @@
-"""k_rows phase clocks of S1 from the -DSWFR_PHASES build (build/phases/libswfr.so), gpurun."""
+"""k2_rows phase clocks of S1 from the -DSWFR_PHASES build (build/phases/libswfr.so), gpurun."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -61,7 +61,7 @@ def main():
                 ys, xs = np.nonzero(d)
                 for y, x in list(zip(ys, xs))[:12]:
                     print("   px", x, y, "hip", got[y, x], "oracle", ref[y, x])
-                for env in ({"SWFR_TILES_DEBUG": "14"}, {"SWFR_FUSED_CLASS": "0"}, {"SWFR_CELL_MODE": "0"}, {"SWFR_FAST_LIMIT": "0"}, {"SWFR_CHUNK_ROWS": "64"}, {"SWFR_CHUNK_ROWS": "8"}):
+                for env in ({"SWFR_FAST_LIMIT": "0"}, {"SWFR_CHUNK_ROWS": "64"}, {"SWFR_CHUNK_ROWS": "16"}, {"SWFR_STRIP_ORDER": "0"}):
                     os.environ.update(env)
                     g2 = np.asarray(product_render(sub)).astype(int)
                     for kk in env: del os.environ[kk]
