@@ -244,6 +244,23 @@ def main():
         extra["config5_s2_bands"] = {"workload": "S2: 7680x4320, 10000 stars (99909 edges), tile-rows sharded over %d ranks, one gather per frame" % world,
                                      "value": round(W5 * H5 * k5 / float(t5.item()) / 1e6, 2), "unit": "Mpixels/s",
                                      "frames_per_sec": round(k5 / float(t5.item()), 1), "steps": k5}
+    if bands:
+        # the same ranks with NO exchange step: every rank rasterizes whole frames of its own (weak scaling), for comparison with the
+        # gather-bound figure above -- `--sharding frames` makes this the headline instead
+        scene_w = scene
+        rw = S.Renderer(W, H, device=local_rank)
+        rw.upload_edges(*scene_w)
+        rw.render_resident(max(args.warmup, 2))
+        sync_all()
+        tw0 = time.perf_counter()
+        rw.render_resident(min(args.steps, 2048))
+        sync_all()
+        tw = torch.tensor([time.perf_counter() - tw0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        rw.close()
+        kw = min(args.steps, 2048)
+        extra["whole_frames_per_rank"] = {"what": "no data-path collective: every rank renders %d whole %s frames of its own" % (kw, args.workload.upper()),
+                                          "value": round(W * H * kw * world / float(tw.item()) / 1e6, 2), "unit": "Mpixels/s", "scaling": "weak"}
     if rank == 0:
         n_edges, n_paths = len(edges), len(paths)
         algo_bytes = 4 * W * H + 16 * n_edges + 16 * n_paths           # SURVEY.md 8(d), per frame = per tile-kernel launch

@@ -158,6 +158,7 @@ struct swfr_renderer {
         size_t n_incidences = 0, n_strips = 0, n_strip_slots = 0;   // (edge, pixel row) pairs: bounds the cells of a frame; k2_tiles wavefronts / launch list slots
         Frame2* frames_dev = nullptr;            // one descriptor per frame set (contiguous, in the arena)
         uint32_t slow_passes = SLOW_PASSES;      // passes of the slow-row kernels the scene needs (known after a frame of a resident scene)
+        bool slow_verified = false;              // slow_state / slow_passes come from this scene's own counters, not from the previous scene
         int slow_state = 0;                      // 0: unknown (both slow-row kernels are launched), 1: the scene has no queued rows, 2: none with > 64 edges
     };
     Scene scn[4];
@@ -183,6 +184,7 @@ struct swfr_renderer {
     DevBuf<DevBitmap> d_bitmap_table;
     DevBuf<uint32_t> d_tmp;
     int in_flight = 3;
+    int hint_slow_state = 0; uint32_t hint_slow_passes = SLOW_PASSES;   // what the last rendered scene needed of the queued-row kernels
     uint32_t* fb_cur = nullptr;             // framebuffer of the last completed frame
     std::map<uint32_t, DeviceBitmap> bitmaps;
     std::vector<DevBitmap> bitmap_table;   // indexed by bitmap id
@@ -614,7 +616,10 @@ int upload2(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, siz
             const swfr_style* styles, size_t n_styles, uint32_t* fb_override, bool edges_tagged) {
     swfr_renderer::Scene& sc = r->scn[si];
     if (si == 0) r->scene_ready = false;
-    sc.slow_state = 0; sc.slow_passes = SLOW_PASSES;
+    // which of the queued-row kernels the frame needs: assumed to be what the previous frame needed (an animation's frames are
+    // alike), checked against the frame's own counters afterwards (render_resident renders again with everything if not)
+    sc.slow_verified = false;
+    sc.slow_state = si == 0 ? r->hint_slow_state : 0; sc.slow_passes = si == 0 ? r->hint_slow_passes : SLOW_PASSES;
     if (si > 0 && !r->fs[si].stream) HIP_CHECK(hipStreamCreateWithFlags(&r->fs[si].stream, hipStreamNonBlocking));
     const hipStream_t up_stream = r->fs[si].stream;
     const uint32_t tiles_x = (r->width + TILE_W - 1) / TILE_W;
@@ -829,8 +834,17 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
                 const uint32_t* c = r->h_counters + k * COUNTER_WORDS;
                 if (c[C2_SLOWQ + q] | c[C2_HUGEQ + q]) { passes = std::max(passes, q + 1); huge |= c[C2_HUGEQ + q]; }
             }
+        // were the launches enough?  (a resident scene starts with everything, or with the previous scene's needs as a guess)
+        const bool short_launch = (sc.slow_state == 1 && slow) || (sc.slow_state == 2 && huge) || passes > sc.slow_passes;
         r->scn[0].slow_state = slow == 0 ? 1 : (huge == 0 ? 2 : 0);     // what the next frames of this resident scene can skip
         r->scn[0].slow_passes = passes;
+        r->hint_slow_state = r->scn[0].slow_state; r->hint_slow_passes = passes;
+        r->scn[0].slow_verified = !short_launch;
+        if (short_launch) {                                    // rows were left in a queue nobody read: the frames are not valid
+            r->scn[0].slow_state = 0; r->scn[0].slow_passes = SLOW_PASSES;
+            r->fb_valid = false;
+            return render_resident(r, frames);
+        }
         r->timing.n_records = 0;
         for (uint32_t h = 0; h < C2_HEADS; ++h) r->timing.n_records += counters[C2_HEAD + h];     // cells of the last frame of set 0
     }
@@ -1278,6 +1292,7 @@ int swfr_render_resident_async(swfr_renderer* r, uint32_t* out_set) {
         const uint32_t k = r->async_next++ % n_sets;
         r->async_used |= 1u << k;
         swfr_renderer::FrameSet& F = r->fs[k];
+        if (!r->scn[0].slow_verified) { r->scn[0].slow_state = 0; r->scn[0].slow_passes = SLOW_PASSES; }   // (nothing checks an async frame's queues: launch everything unless a blocking frame of this scene has shown what it needs)
         launch_frame(r, r->scn[0], F, nullptr, nullptr);
         HIP_CHECK(hipGetLastError());
         r->fb_cur = r->n_targets ? r->targets[k % r->n_targets] : F.d_fb.ptr;

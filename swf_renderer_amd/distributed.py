@@ -150,6 +150,7 @@ class FramePipeline:
 
     def upload(self, edges, paths, styles):
         self.r.upload_edges(edges, paths, styles)                    # (after set_targets: the descriptors carry the buffers' addresses)
+        self.r.render_resident(1)                                    # one blocking frame: the handle learns which queued-row kernels this scene needs
         self.uploaded = True
 
     def _stream(self, k):

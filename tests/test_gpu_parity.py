@@ -579,6 +579,42 @@ def test_path_with_4k_edges_and_600_active_per_row_is_exact_or_refused():
         r.close()
 
 
+def test_one_handle_alternating_plain_and_crowded_frames():
+    """swfr_render launches the queued-row kernels (and their passes) the PREVIOUS frame needed and checks the frame's own counters
+    afterwards: a frame that needed more is rendered again with everything.  One handle, frames alternating between scenes without
+    queued rows, with crowded rows (9..64 active edges: k2_rows_slow), with rows beyond 64 (k2_rows_huge) and with coincident
+    edges whose history spans several passes -- every frame equals the oracle."""
+    import swf_renderer_amd as S
+    w, h = 128, 100
+    plain = {"children": [{"type": "shape", "definition": scenarios._poly_shape([(200, 200), (2200, 300), (1200, 1800)], {"type": "solid", "color": scenarios._rgba(9, 99, 199, 200)})}]}
+    crowded = {"children": [{"type": "shape", "definition": _comb(12, 2000)}]}
+    huge = {"children": [{"type": "shape", "definition": _comb(40, 2000)}]}
+    order = [plain, crowded, plain, huge, crowded, plain, plain, huge, huge, plain]
+    r = S.Renderer(w, h)
+    try:
+        for i, stage in enumerate(order):
+            r.render(stage)
+            want = oracle_render(dict(width=w, height=h, stage=stage))
+            assert diff_stats(r.read_image(premultiplied=True), want) == (0, 0), i
+        st = r.stats()
+        assert st["queued_rows"] > 0 and st["crowded_rows"] > 0
+    finally:
+        r.close()
+    # the soak's tie scenes on one handle between plain frames (their rows need the list-order replay, some over several passes)
+    from helpers import soak_scene
+    for case in (("mixed", 23000, 196), ("big", 300, 146), ("long", 300, 171)):
+        sc = soak_scene(*case)
+        r = S.Renderer(sc["width"], sc["height"])
+        try:
+            for b in sc.get("bitmaps", []):
+                r.add_bitmap(b)
+            for stage in (plain, sc["stage"], plain, sc["stage"]):
+                r.render(stage)
+                assert diff_stats(r.read_image(premultiplied=True), oracle_render(dict(sc, stage=stage))) == (0, 0), case
+        finally:
+            r.close()
+
+
 def test_many_active_edges_fails_loudly_not_silently():
     import swf_renderer_amd as S
     from swf_renderer_amd import api
