@@ -196,6 +196,7 @@ def main():
     bands = world > 1 and args.sharding == "bands"
     cfg = synth.S1 if args.workload == "s1" else synth.S2
     extra = {}
+    t1 = None
     if bands:
         dt, out, (W, H, fx, cols, scene), tm = run_bands(args.workload, cfg, args.steps, args.warmup)
         edges, paths, styles = scene
@@ -203,6 +204,18 @@ def main():
         r = None
     else:
         W, H, pts, cols, fx, stage, (edges, paths, styles), t_host = scene_of(cfg)
+        if world == 1 and in_flight > 1:
+            # the timed region below overlaps consecutive frames on several streams, which stretches every kernel's own duration;
+            # the same kernels timed with one frame in flight (a second handle, its own 80 frames, before the timed region so that
+            # the device is out of its idle clocks when the W warm-up frames start) are reported beside it
+            os.environ["SWFR_FRAMES_IN_FLIGHT"] = "1"
+            r1 = S.Renderer(W, H, device=local_rank)
+            r1.upload_edges(edges, paths, styles)
+            r1.render_resident(16)
+            r1.render_resident(64)
+            t1 = r1.timing()
+            r1.close()
+            os.environ["SWFR_FRAMES_IN_FLIGHT"] = str(in_flight)
         r = S.Renderer(W, H, device=local_rank)
         r.upload_edges(edges, paths, styles)                      # inputs resident in HBM before the timed region
         r.render_resident(min(max(args.warmup, 1), 2048))
@@ -297,17 +310,7 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes},
         }
         line.update(extra)
-        if world == 1 and in_flight > 1:
-            # the timed region overlaps consecutive frames on several streams, which stretches every kernel's own duration;
-            # the same kernels timed with one frame in flight (a second handle, outside the timed region) are reported beside it
-            os.environ["SWFR_FRAMES_IN_FLIGHT"] = "1"
-            r1 = S.Renderer(W, H, device=local_rank)
-            r1.upload_edges(edges, paths, styles)
-            r1.render_resident(16)
-            r1.render_resident(64)
-            t1 = r1.timing()
-            r1.close()
-            os.environ["SWFR_FRAMES_IN_FLIGHT"] = str(in_flight)
+        if t1 is not None:
             n1 = max(t1["timed_frames"], 1)
             iso_ms = t1["tiles_ms"] / n1
             iso = algo_bytes / (iso_ms * 1e-3) / 1e9 if iso_ms > 0 else 0.0
