@@ -1680,7 +1680,9 @@ __device__ __forceinline__ void tiles2_body(FramePtr FR) {
                         // in LDS: lane = (path of the batch, row of the strip) forms the flat cell sequence and fetches its first cells
                         bool isp = lane >= li && lane < ln && ((sel[lane & (T2_LIST - 1)] >> 24) & (CLS_PARTIAL | CLS_BOX)) == CLS_PARTIAL;
                         if (isp) {
-                            const uint32_t lyw = ent[lane][1];
+                            int le = lane;
+                            SWFR_OPAQUE(le);                               // (the address is formed here, not kept in a register from the kernel's prologue on: that register was spilled)
+                            const uint32_t lyw = ent[le][1];
                             const int l_ymin = (int)(int16_t)(lyw & 0xffffu), l_ymax = (int)(int16_t)(lyw >> 16);
                             isp = min(min(l_ymax, ty0 + STRIP_H), height) > max(l_ymin, ty0);
                         }
