@@ -491,13 +491,20 @@ class Renderer:
         self.L.swfr_last_path_timing(self.h, C.byref(t))
         return {n: getattr(t, n) for n, _ in PathTiming._fields_}
 
-    def render_batch(self, stages, device_ptr=None, frame_stride=0):
-        """A batch of different frames in one call (e.g. the 256 ratios of a morph shape), pipelined over the handle's streams.
-        Frame i lands at device_ptr + i * frame_stride (device memory: pass tensor.data_ptr()); without a destination only the
-        last frame is kept for read_image().  Blocking."""
+    def marshal_stages(self, stages):
+        """The ctypes form of a list of stages, reusable across render_batch / render_sequence calls (marshalling a Stage of a
+        thousand display objects costs Python half a millisecond; a native caller has the structs already)."""
         arena = _Arena()
         arr = (Stage * max(len(stages), 1))(*[self._stage(arena, st) for st in stages])
-        self._check(self.L.swfr_render_batch(self.h, arr, len(stages), C.c_void_p(device_ptr) if device_ptr else None,
+        return (arena, arr, len(stages))
+
+    def render_batch(self, stages, device_ptr=None, frame_stride=0):
+        """A batch of different frames in one call (e.g. the 256 ratios of a morph shape): with a device destination the frames
+        are rendered in groups, one launch per kernel and group, the host building one group while the GPU renders the other.
+        Frame i lands at device_ptr + i * frame_stride (device memory: pass tensor.data_ptr()); without a destination only the
+        last frame is kept for read_image().  `stages`: a list of stage dicts, or the result of marshal_stages().  Blocking."""
+        _, arr, n = stages if isinstance(stages, tuple) else self.marshal_stages(stages)
+        self._check(self.L.swfr_render_batch(self.h, arr, n, C.c_void_p(device_ptr) if device_ptr else None,
                                              int(frame_stride) if device_ptr else 0))
 
     def build_frame(self, stage):

@@ -1,6 +1,9 @@
 // frame_builder.cpp -- see frame_builder.hpp.
 #include "frame_builder.hpp"
 
+#include <functional>
+#include <cstdlib>
+
 #include <algorithm>
 #include <cstring>
 
@@ -50,21 +53,139 @@ Affine FrameBuilder::matrix_of(const swfr_matrix& m) {
 }
 
 const DecodedShape* FrameBuilder::shape(uint32_t id, bool morph) const {
-    const auto& v = morph ? morphs_ : shapes_;
+    const auto& v = morph ? store()->morphs_ : store()->shapes_;
     return id < v.size() ? &v[id] : nullptr;
 }
 
-void FrameBuilder::build(const swfr_stage& stage) {
+// ---- worker threads: a fixed set, woken per frame (generation counter), each running one job index of the current task
+struct FrameBuilder::Pool {
+    std::vector<std::thread> threads;                          // thread i (1-based) runs job i of a task when the task has that many jobs
+    std::vector<std::unique_ptr<FrameBuilder>> builders;       // one builder per piece
+    std::mutex m;
+    std::condition_variable cv_go, cv_done;
+    uint64_t generation = 0;
+    int n_jobs = 0, pending = 0;
+    bool quit = false;
+    std::function<void(int)> task;
+    void run(int jobs, std::function<void(int)> fn) {           // jobs 1 .. jobs-1 on the pool, job 0 here; returns when all are done
+        {
+            std::lock_guard<std::mutex> lk(m);
+            task = std::move(fn);
+            n_jobs = jobs;
+            pending = jobs - 1;
+            ++generation;
+        }
+        cv_go.notify_all();
+        task(0);
+        std::unique_lock<std::mutex> lk(m);
+        cv_done.wait(lk, [&] { return pending == 0; });
+    }
+    void worker(int index) {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv_go.wait(lk, [&] { return quit || generation != seen; });
+            if (quit) return;
+            seen = generation;
+            if (index >= n_jobs) continue;                      // this task has fewer jobs
+            lk.unlock();
+            task(index);
+            lk.lock();
+            if (--pending == 0) cv_done.notify_one();
+        }
+    }
+};
+
+FrameBuilder::FrameBuilder(uint32_t width, uint32_t height, bool even_odd) : w_(width), h_(height), even_odd_(even_odd) {}
+
+FrameBuilder::~FrameBuilder() {
+    if (pool_) {
+        { std::lock_guard<std::mutex> lk(pool_->m); pool_->quit = true; }
+        pool_->cv_go.notify_all();
+        for (auto& t : pool_->threads) t.join();
+    }
+}
+
+void FrameBuilder::build_range(const swfr_stage& stage, uint32_t lo, uint32_t hi) {
     edges_.clear();
     paths_.clear();
     styles_.clear();
     stack_.clear();
-    surface_clear_ = true;  // clearRect over the whole canvas (canvas-renderer.ts:70-71)
+    failed_ = false;
+    surface_clear_ = true;  // clearRect over the whole canvas (canvas-renderer.ts:70-71); a later piece learns the truth when joined
     State s;
     s.ctm = Affine::scale(1.0 / 20.0, 1.0 / 20.0);  // twips -> px (:74)
     s.inv = Affine::scale(1.0 / (1.0 / 20.0), 1.0 / (1.0 / 20.0));  // cairo_scale: ctm_inverse *= scale(1/sx, 1/sy)
     stack_.push_back(s);
-    for (uint32_t i = 0; i < stage.n_children; ++i) draw(stage.children[i], 0);
+    try {
+        for (uint32_t i = lo; i < hi; ++i) draw(stage.children[i], 0);
+    } catch (const StatusError& e) {
+        failed_ = true;
+        failure_ = e;
+    }
+}
+
+// this piece's arrays into their place in the joined frame: indices shifted, the "still clear?" lerps settled
+void FrameBuilder::copy_piece(FrameBuilder& dst, size_t edge_off, size_t path_off, size_t style_off, bool clear_at_start) const {
+    for (size_t i = 0; i < edges_.size(); ++i) {
+        swfr_edge e = edges_[i];
+        e.reserved += int32_t(path_off);
+        dst.edges_[edge_off + i] = e;
+    }
+    for (size_t i = 0; i < paths_.size(); ++i) {
+        swfr_path p = paths_[i];
+        p.first_edge += uint32_t(edge_off);
+        p.style += uint32_t(style_off);
+        if (p.lerp == 2) p.lerp = clear_at_start ? 1 : 0;       // (inside the piece the flag is only ever 2 while nothing was painted)
+        dst.paths_[path_off + i] = p;
+    }
+    if (!styles_.empty()) std::memcpy(&dst.styles_[style_off], styles_.data(), styles_.size() * sizeof(swfr_style));
+}
+
+void FrameBuilder::build(const swfr_stage& stage) {
+    int want = threads_;
+    if (want < 0) {
+        const char* env = std::getenv("SWFR_BUILD_THREADS");
+        want = env ? std::atoi(env) : int(std::min(8u, std::max(1u, std::thread::hardware_concurrency())));
+        threads_ = want;
+    }
+    // pieces of at least 64 top-level display objects each
+    const int pieces = int(std::min<uint32_t>(uint32_t(std::max(want, 1)), stage.n_children / 64));
+    if (pieces < 2) {
+        build_range(stage, 0, stage.n_children);
+        if (failed_) throw failure_;
+        for (swfr_path& p : paths_) if (p.lerp == 2) p.lerp = 1;
+        return;
+    }
+    if (!pool_) pool_.reset(new Pool);
+    Pool& P = *pool_;
+    while (int(P.builders.size()) < pieces) {                 // (piece k is built by builders[k-1] for k >= 1; piece 0 needs a scratch builder, too)
+        P.builders.emplace_back(new FrameBuilder(w_, h_, even_odd_));
+        P.builders.back()->parent_ = this;
+        P.builders.back()->threads_ = 0;
+    }
+    while (int(P.threads.size()) < pieces - 1) {
+        const int index = int(P.threads.size()) + 1;
+        P.threads.emplace_back([&P, index] { P.worker(index); });
+    }
+    auto lo_of = [&](int k) { return uint32_t(uint64_t(stage.n_children) * uint64_t(k) / uint64_t(pieces)); };
+    // ---- phase A: every piece into its own builder
+    P.run(pieces, [&](int k) { P.builders[k]->build_range(stage, lo_of(k), lo_of(k + 1)); });
+    size_t ne = 0, np = 0, ns = 0;
+    std::vector<size_t> eo(pieces), po(pieces), so(pieces);
+    std::vector<char> clear_at(pieces);
+    bool clear = true;
+    for (int k = 0; k < pieces; ++k) {
+        const FrameBuilder& B = *P.builders[k];
+        if (B.failed_) throw B.failure_;                      // the first failing display object in painter's order, as a single walk would report
+        eo[k] = ne; po[k] = np; so[k] = ns; clear_at[k] = clear;
+        ne += B.edges_.size(); np += B.paths_.size(); ns += B.styles_.size();
+        clear = clear && B.surface_clear_;
+    }
+    edges_.resize(ne); paths_.resize(np); styles_.resize(ns);
+    surface_clear_ = clear;
+    // ---- phase B: the pieces copied to their places, in parallel
+    P.run(pieces, [&](int k) { P.builders[k]->copy_piece(*this, eo[k], po[k], so[k], clear_at[k] != 0); });
 }
 
 void FrameBuilder::draw(const swfr_display_object& obj, int depth) {
@@ -187,7 +308,8 @@ void FrameBuilder::emit_polygon(Polygon& poly, bool rectilinear, uint32_t style,
     p.first_edge = uint32_t(edges_.size());
     p.fill_rule = even_odd_ ? 1 : 0;
     p.style = style;
-    p.lerp = lerp_blend ? 1 : 0;
+    p.lerp = opaque_solid ? 1 : (surface_clear_ ? 2 : 0);      // 2: a lerp only because the surface is still clear (settled by build())
+    (void)lerp_blend;
     // converter rectangle: the polygon's extents inside the operation's bounded rectangle (the frame for fills)
     p.x_min = std::max(floor_px(poly.ext_min().x), std::max(bx0, 0));
     p.y_min = std::max(floor_px(poly.ext_min().y), std::max(by0, 0));
@@ -220,8 +342,8 @@ void FrameBuilder::emit_fill(const OwnedFill& f, bool morph, double ratio) {
         opaque_solid = (px >> 24) == 0xff;
         style_index = push_solid(px);
     } else if (s.type == SWFR_FILL_BITMAP) {
-        auto it = bitmaps_.find(s.bitmap_id);
-        if (it == bitmaps_.end()) throw StatusError{SWFR_ERR_NOT_FOUND, "BitmapNotFound: " + std::to_string(s.bitmap_id)};
+        auto it = store()->bitmaps_.find(s.bitmap_id);
+        if (it == store()->bitmaps_.end()) throw StatusError{SWFR_ERR_NOT_FOUND, "BitmapNotFound: " + std::to_string(s.bitmap_id)};
         swfr_style st;
         std::memset(&st, 0, sizeof st);
         st.kind = SWFR_STYLE_BITMAP;
@@ -293,7 +415,7 @@ void FrameBuilder::emit_fill(const OwnedFill& f, bool morph, double ratio) {
         const swfr_style& st = styles_[style_index];
         Affine pm;
         pm.xx = st.inv[0]; pm.yx = st.inv[1]; pm.xy = st.inv[2]; pm.yy = st.inv[3]; pm.x0 = st.inv[4]; pm.y0 = st.inv[5];
-        const BitmapInfo& bi = bitmaps_.find(s.bitmap_id)->second;
+        const BitmapInfo& bi = store()->bitmaps_.find(s.bitmap_id)->second;
         double sx0 = 0, sy0 = 0, sx1 = bi.width, sy1 = bi.height;
         bool round_x = false, round_y = false;
         if (std::hypot(pm.xx, pm.yx) < 1.0) { sx0 -= 0.5; sx1 += 0.5; round_x = true; }

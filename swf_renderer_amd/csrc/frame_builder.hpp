@@ -5,8 +5,12 @@
 // fill() / stroke().  Instead of calling a Canvas it emits what the GPU scan converter consumes.
 #pragma once
 
+#include <condition_variable>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/swfr.h"
@@ -24,9 +28,17 @@ struct StatusError {
     std::string message;
 };
 
+// Frames with many top-level display objects are built by several threads: the children are cut into contiguous ranges, every range
+// is walked by a worker builder of its own (same code, its own output arrays), and the pieces are joined in painter's order.  The one
+// thing a display object's output depends on besides itself -- whether the surface is still clear, which turns the first translucent
+// paint into a SOURCE-rule lerp -- is marked in the paths (`lerp` = 2) and settled when the pieces are joined.
 class FrameBuilder {
 public:
-    FrameBuilder(uint32_t width, uint32_t height, bool even_odd) : w_(width), h_(height), even_odd_(even_odd) {}
+    FrameBuilder(uint32_t width, uint32_t height, bool even_odd);
+    ~FrameBuilder();
+    FrameBuilder(const FrameBuilder&) = delete;
+    FrameBuilder& operator=(const FrameBuilder&) = delete;
+    void set_threads(int n) { threads_ = n; }          // 0 / 1: single thread; default: SWFR_BUILD_THREADS or min(8, cores)
 
     uint32_t add_shape(DecodedShape s) { shapes_.push_back(std::move(s)); return uint32_t(shapes_.size() - 1); }
     uint32_t add_morph_shape(DecodedShape s) { morphs_.push_back(std::move(s)); return uint32_t(morphs_.size() - 1); }
@@ -56,6 +68,17 @@ private:
     bool frame_bounds(Pt lo, Pt hi, bool& needs_clip) const;
     bool transform(const Affine& m);  // context.transform(m); false: singular
     static Affine matrix_of(const swfr_matrix& m);
+
+    // ---- multi-threaded build
+    struct Pool;                                         // the worker threads (created on first use)
+    void build_range(const swfr_stage& stage, uint32_t lo, uint32_t hi);    // worker: children [lo, hi) into this builder's arrays
+    void copy_piece(FrameBuilder& dst, size_t edge_off, size_t path_off, size_t style_off, bool clear_at_start) const;
+    const FrameBuilder* store() const { return parent_ ? parent_ : this; }  // where shapes and bitmaps are registered
+    const FrameBuilder* parent_ = nullptr;
+    std::unique_ptr<Pool> pool_;
+    int threads_ = -1;
+    bool failed_ = false;
+    StatusError failure_{0, ""};
 
     uint32_t w_, h_;
     bool even_odd_;

@@ -862,9 +862,14 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
 int render_batch2(swfr_renderer* r, const swfr_stage* stages, uint32_t n, void* device_dst, size_t frame_stride) {
     struct FrameData { std::vector<swfr_edge> e; std::vector<swfr_path> p; std::vector<swfr_style> s; SceneLayout L; };
     static thread_local std::vector<FrameData> fd;
-    const uint32_t B = uint32_t(std::max(1, r->batch_frames));
+    // frames per group: SWFR_BATCH_FRAMES, but at least four groups per call so that building group g + 1 overlaps rasterizing group g
+    const uint32_t B = std::min(uint32_t(std::max(1, r->batch_frames)), std::max(1u, (n + 3) / 4));
     const uint32_t tiles_x = (r->width + TILE_W - 1) / TILE_W;
     auto pad = [](size_t b) { return (b + 255) & ~size_t(255); };
+    using clk = std::chrono::steady_clock;
+    auto ms_since = [](clk::time_point a) { return std::chrono::duration<double, std::milli>(clk::now() - a).count(); };
+    double t_build = 0, t_wait = 0, t_stage = 0, t_launch = 0;
+    const bool trace = std::getenv("SWFR_BATCH_TRACE") != nullptr;          // host time per stage of the call, to stderr
     if (r->bitmap_table_dirty) {
         r->d_bitmap_table.reserve(r->bitmap_table.size());
         if (!r->bitmap_table.empty()) HIP_CHECK(hipMemcpy(r->d_bitmap_table.ptr, r->bitmap_table.data(), r->bitmap_table.size() * sizeof(DevBitmap), hipMemcpyHostToDevice));
@@ -894,6 +899,7 @@ int render_batch2(swfr_renderer* r, const swfr_stage* stages, uint32_t n, void* 
         size_t arena_bytes = pad(cnt * sizeof(Frame2)) + 4096, work_bytes = 0, cls_bytes = 0;
         size_t max_ep = 0, max_bands = 0, max_chunks = 0, max_strips = 0;
         int shader_level = 0;
+        auto t0 = clk::now();
         for (uint32_t k = 0; k < cnt; ++k) {
             FrameData& F = fd[k];
             r->builder->build(stages[first + k]);
@@ -911,8 +917,10 @@ int render_batch2(swfr_renderer* r, const swfr_stage* stages, uint32_t n, void* 
             max_chunks = std::max(max_chunks, L.n_chunks); max_strips = std::max(max_strips, L.n_strip_slots);
             shader_level = std::max(shader_level, L.shader_level);
         }
+        t_build += ms_since(t0); t0 = clk::now();
         // ---- this group's previous use must be over before its staging and device buffers are rewritten
         finish_group(g);
+        t_wait += ms_since(t0); t0 = clk::now();
         if (rc != SWFR_OK) break;
         G.arena.begin(arena_bytes);
         const uint8_t* work_before = G.work.ptr;
@@ -955,6 +963,7 @@ int render_batch2(swfr_renderer* r, const swfr_stage* stages, uint32_t n, void* 
         }
         const Frame2* frames_dev = static_cast<Frame2*>(G.arena.push(fr.data(), cnt * sizeof(Frame2)));
         G.arena.flush(G.stream);
+        t_stage += ms_since(t0); t0 = clk::now();
         if (!G.ev_begin) { HIP_CHECK(hipEventCreate(&G.ev_begin)); HIP_CHECK(hipEventCreate(&G.ev_end)); }
         HIP_CHECK(hipEventRecord(G.ev_begin, G.stream));
         launch2_bin(G.stream, frames_dev, cnt, uint32_t(max_ep), uint32_t(max_bands));
@@ -967,9 +976,13 @@ int render_batch2(swfr_renderer* r, const swfr_stage* stages, uint32_t n, void* 
         HIP_CHECK(hipGetLastError());
         pend[g] = Pending{first, cnt};
         r->fb_cur = fr[cnt - 1].fb;
+        t_launch += ms_since(t0);
     }
+    auto t_end = clk::now();
     finish_group(0);
     finish_group(1);
+    if (trace) std::fprintf(stderr, "[swfr] batch of %u frames in groups of %u: build+layout %.3f ms, waiting for a group's buffers %.3f, staging %.3f, launches %.3f, final wait %.3f, kernels %.3f\n",
+                            n, B, t_build, t_wait, t_stage, t_launch, ms_since(t_end), device_ms);
     r->scene_ready = false;
     r->fb_valid = rc == SWFR_OK;
     r->timing = swfr_timing{float(device_ms), 0, 0, 0, n, 0, 0, 0, 0, 0};     // (swfr_last_timing: total_ms = the groups' kernel time)

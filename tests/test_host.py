@@ -286,3 +286,53 @@ def test_fuzz_stroked_shapes_edges_equal_oracle():
             got = np.stack([e[k] for k in ("x1", "y1", "x2", "y2", "top", "bottom", "dir")], 1)
             assert got.shape == pe.shape and (got == pe).all(), it
         tap.close()
+
+def test_frame_build_on_several_threads_equals_single_thread(monkeypatch):
+    """A frame with many top-level display objects is built by several threads (contiguous ranges of children, joined in painter's
+    order).  Same edge list, paths and styles as one thread -- including the one cross-object rule, the SOURCE-rule lerp of the first
+    translucent paint on a still-clear surface: scenes whose first painted object lies in a later piece, scenes that start with
+    objects entirely off the frame (they leave the surface clear), S1, and the error of the first bad display object."""
+    import swf_renderer_amd as S
+    from swf_renderer_amd import api, synth
+
+    def build(stage, w, h, threads):
+        monkeypatch.setenv("SWFR_BUILD_THREADS", str(threads))
+        r = S.Renderer(w, h, device=api.DEVICE_HOST_ONLY)
+        try:
+            e, p, st = r.build_frame(stage)
+            return e.tobytes(), p.tobytes(), b"".join(bytes(x) for x in st)
+        finally:
+            r.close()
+
+    rng = np.random.default_rng(11)
+    def tri(x, y, size, color):
+        pts = [(x, y), (x + size, y + size * 0.3), (x + size * 0.4, y + size)]
+        return {"type": "shape", "definition": scenarios._poly_shape(pts, {"type": "solid", "color": color})}
+    w, h = 200, 160
+    for case in range(6):
+        kids = []
+        n = 300 + 67 * case
+        first_visible = [0, 70, 150, n - 1, 64, 128][case]
+        for i in range(n):
+            off_frame = i < first_visible
+            x = -9000 if off_frame else int(rng.integers(0, w * 20 - 400))
+            y = -9000 if off_frame else int(rng.integers(0, h * 20 - 400))
+            a = 255 if rng.random() < 0.3 else int(rng.integers(1, 255))
+            kids.append(tri(x, y, int(rng.integers(60, 900)), scenarios._rgba(int(rng.integers(0, 256)), int(rng.integers(0, 256)), int(rng.integers(0, 256)), a)))
+        stage = {"children": kids}
+        one = build(stage, w, h, 1)
+        for threads in (2, 3, 8):
+            assert build(stage, w, h, threads) == one, (case, threads)
+        assert any(p for p in np.frombuffer(one[1], dtype=api.PATH_DTYPE)["lerp"])          # the scenes do exercise the rule
+    cfg = synth.S1
+    pts, cols = synth.scene(**cfg)
+    stage = api.stars_to_stage(pts, cols)
+    assert build(stage, cfg["width"], cfg["height"], 8) == build(stage, cfg["width"], cfg["height"], 1)
+    # errors: the first failing display object in painter's order decides, whichever thread meets it
+    bad = {"children": [tri(100, 100, 300, scenarios._rgba(1, 2, 3))] * 200 + [{"type": "shape", "id": 12345}] + [tri(100, 100, 300, scenarios._rgba(1, 2, 3))] * 200}
+    for threads in (1, 4):
+        monkeypatch.setenv("SWFR_BUILD_THREADS", str(threads))
+        r = S.Renderer(64, 64, device=api.DEVICE_HOST_ONLY)
+        with pytest.raises(S.SwfrError) as e:
+            r.build_frame(bad)
+        r.close()
