@@ -177,13 +177,13 @@ __device__ __forceinline__ uint32_t path_chunk_count(const DevPath& P, uint32_t 
 constexpr uint32_t ORDER_BUCKETS = 128;
 __device__ __forceinline__ uint32_t order_bucket(uint32_t cost) { return ORDER_BUCKETS - 1 - min(cost / 2, ORDER_BUCKETS - 1); }   // bucket 0 = heaviest
 
-__device__ __forceinline__ void order_body(FramePtr F);
+__device__ __forceinline__ void order_body(FramePtr F, uint32_t xcd_class);
 constexpr uint32_t BIN_THREADS = 1024;
 __device__ __forceinline__ void bin_body(FramePtr F) {
     __shared__ uint32_t wave_cnt[BIN_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (blockIdx.x == 0 && tid < C2_WORDS) F->counters[tid] = 0;
-    if (blockIdx.x == gridDim.x - 1) { order_body(F); return; }          // the last workgroup: the tile pass's launch list
+    if (blockIdx.x >= gridDim.x - XCDS) { order_body(F, blockIdx.x - (gridDim.x - XCDS)); return; }   // the last eight workgroups: the tile pass's launch list
     if (blockIdx.x < F->n_bands) {
         // ---- the paths that touch tile-row `band`, in painter's order
         const int band = (int)blockIdx.x;
@@ -276,79 +276,79 @@ __device__ __forceinline__ void wave_bucket_add(uint32_t* bucket, uint32_t k, bo
         if (slot) *slot = old;
     }
 }
-#define ORDER_LDS_STRIPS 98304         // strips whose bucket numbers fit the workgroup's LDS (a 12288 x 8192 frame); larger frames re-read the costs
+#define ORDER_LDS_STRIPS 16384         // strips of one class whose bucket numbers fit the workgroup's LDS (a 16K x 8K frame); larger frames re-read the costs
 // Slot of a strip in the launch list: XCDS * (its rank among the strips of its class) + class, class = local tile-row % XCDS.  The
 // hardware deals a launch's workgroups round-robin over the XCDs, so all strips of a tile-row run on one XCD and share its L2.
 // Ranks: heaviest first by the previous frame's costs (counting sort per class), or row-major when there is no cost history.
-__device__ __forceinline__ void order_body(FramePtr F) {
+// One 1024-thread workgroup per class (the last XCDS workgroups of the k2_bin launch): the eight sorts run side by side.
+__device__ __forceinline__ void order_body(FramePtr F, uint32_t x) {
     constexpr uint32_t NB = ORDER_BUCKETS + 1;
-    __shared__ uint32_t bucket[XCDS * NB];
-    __shared__ uint2 rowinfo[2048];                        // per tile-row of the handle: {first band list entry, entries}
+    __shared__ uint32_t bucket[NB];
+    __shared__ uint2 rowinfo[256];                         // per tile-row of the class: {first band list entry, entries}
     __shared__ uint8_t bkt[ORDER_LDS_STRIPS];
     const int tid = threadIdx.x;
     const uint32_t n_strips = F->n_strips, bc = F->band_stride, bi = F->band_first;
     const uint32_t per_row = STRIPS_PER_TILE * (uint32_t)F->tiles_x;
     const uint32_t n_local = n_strips / per_row;
-    const bool cached = n_strips <= ORDER_LDS_STRIPS;
-    for (uint32_t l = (uint32_t)tid; l < n_local && l < 2048u; l += 1024) {
-        const uint32_t trow = l * bc + bi, b0 = F->band_off[trow];
-        rowinfo[l] = make_uint2(b0, F->band_off[trow + 1] - b0);
+    const uint32_t rows_x = (n_local + XCDS - 1 - x) / XCDS, max_rows = (n_local + XCDS - 1) / XCDS;     // tile-rows x, x + 8, ... of this class
+    const uint32_t n_mine = rows_x * per_row;
+    const bool cached = n_mine <= ORDER_LDS_STRIPS;
+    for (uint32_t j = (uint32_t)tid; j < rows_x && j < 256u; j += 1024) {
+        const uint32_t trow = (x + j * XCDS) * bc + bi, b0 = F->band_off[trow];
+        rowinfo[j] = make_uint2(b0, F->band_off[trow + 1] - b0);
     }
-    // slots of the smaller classes (one tile-row fewer than the largest) that stay without a strip
-    {
-        const uint32_t max_rows = (n_local + XCDS - 1) / XCDS;
-        for (uint32_t i = (uint32_t)tid; i < XCDS * per_row; i += 1024) {
-            const uint32_t x = i / per_row, j = i % per_row;
-            const uint32_t rows_x = (n_local + XCDS - 1 - x) / XCDS;
-            if (rows_x < max_rows) { StripDesc sd; sd.wg = ~0u; sd.band_begin = 0; sd.n_b = 0; sd.pad = 0; F->strips[(size_t)(rows_x * per_row + j) * XCDS + x] = sd; }
+    // a class one tile-row short of the largest: its last slots stay without a strip
+    if (rows_x < max_rows)
+        for (uint32_t j = (uint32_t)tid; j < per_row; j += 1024) {
+            StripDesc sd; sd.wg = ~0u; sd.band_begin = 0; sd.n_b = 0; sd.pad = 0;
+            F->strips[(size_t)(n_mine + j) * XCDS + x] = sd;
         }
-    }
+    // strip i of the class: tile-row x + 8 * (i / per_row), position i % per_row in it
+    auto strip_of = [&](uint32_t i) { const uint32_t j = i / per_row; return (x + j * XCDS) * per_row + (i - j * per_row); };
     if (F->strip_order) {
-        for (uint32_t b = (uint32_t)tid; b < XCDS * NB; b += 1024) bucket[b] = 0;
+        for (uint32_t b = (uint32_t)tid; b < NB; b += 1024) bucket[b] = 0;
         lds_barrier();
         // every cost is read once (four independent loads in flight per thread), its bucket number kept in LDS, the costs cleared
-        for (uint32_t w0 = (uint32_t)tid; w0 < n_strips; w0 += 4096) {
-            uint32_t c[4];
+        for (uint32_t i0 = (uint32_t)tid; i0 < n_mine; i0 += 4096) {
+            uint32_t c[4], w[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const uint32_t w = w0 + (uint32_t)u * 1024; c[u] = w < n_strips ? F->strip_cost[w] : 0u; }
+            for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + (uint32_t)u * 1024; w[u] = i < n_mine ? strip_of(i) : 0u; c[u] = i < n_mine ? F->strip_cost[w[u]] : 0u; }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const uint32_t w = w0 + (uint32_t)u * 1024;
-                const bool valid = w < n_strips;
+                const uint32_t i = i0 + (uint32_t)u * 1024;
+                const bool valid = i < n_mine;
                 const uint32_t k = order_bucket(c[u]);
-                const uint32_t x = (w / per_row) % XCDS;
-                wave_bucket_add(bucket, x * NB + k + 1, valid, nullptr);  // (one LDS atomic per wavefront when its lanes agree; k + 1 <= ORDER_BUCKETS)
-                if (valid && cached) { bkt[w] = (uint8_t)k; F->strip_cost[w] = 0; }
+                wave_bucket_add(bucket, k + 1, valid, nullptr);          // (one LDS atomic per wavefront when its lanes agree; k + 1 <= ORDER_BUCKETS)
+                if (valid && cached) { bkt[i] = (uint8_t)k; F->strip_cost[w[u]] = 0; }       // (not cached: read again below, cleared there)
             }
         }
         lds_barrier();
-        if (tid < 64 * (int)XCDS) {                       // prefix of a class's bucket sizes: one wavefront per class
-            const uint32_t x = (uint32_t)tid >> 6, lane = (uint32_t)tid & 63u;
+        if (tid < 64) {                                   // prefix of the bucket sizes by one wavefront
             uint32_t carry = 0;
             for (uint32_t base = 0; base < NB; base += 64) {
-                const uint32_t b = base + lane;
-                const uint32_t v = b < NB ? bucket[x * NB + b] : 0u;
+                const uint32_t b = base + (uint32_t)tid;
+                const uint32_t v = b < NB ? bucket[b] : 0u;
                 const uint32_t incl = (uint32_t)wave_scan_incl((int)v);
-                if (b < NB) bucket[x * NB + b] = carry + incl;                 // bucket[b] = first rank of bucket b (its size was stored at b + 1)
+                if (b < NB) bucket[b] = carry + incl;                    // bucket[b] = first rank of bucket b (its size was stored at b + 1)
                 carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             }
         }
     }
     lds_barrier();
-    for (uint32_t w0 = 0; w0 < n_strips; w0 += 1024) {                 // (workgroup-uniform trip count: the wavefronts vote inside)
-        const uint32_t w = w0 + (uint32_t)tid;
-        const bool valid = w < n_strips;
-        const uint32_t l = w / per_row, x = l % XCDS;
-        uint32_t rank = (l / XCDS) * per_row + (w - l * per_row);      // row-major inside the class
+    for (uint32_t i0 = 0; i0 < n_mine; i0 += 1024) {                    // (workgroup-uniform trip count: the wavefronts vote inside)
+        const uint32_t i = i0 + (uint32_t)tid;
+        const bool valid = i < n_mine;
+        uint32_t rank = i;                                               // row-major inside the class
         if (F->strip_order) {
             uint32_t k = 0;
-            if (valid) { if (cached) k = bkt[w]; else { k = order_bucket(F->strip_cost[w]); F->strip_cost[w] = 0; } }
-            wave_bucket_add(bucket, x * NB + k, valid, &rank);
+            if (valid) { if (cached) k = bkt[i]; else { const uint32_t w = strip_of(i); k = order_bucket(F->strip_cost[w]); F->strip_cost[w] = 0; } }
+            wave_bucket_add(bucket, k, valid, &rank);
         }
         if (!valid) continue;
+        const uint32_t j = i / per_row;
         uint2 ri;
-        if (l < 2048u) ri = rowinfo[l]; else { const uint32_t trow = l * bc + bi, b0 = F->band_off[trow]; ri = make_uint2(b0, F->band_off[trow + 1] - b0); }
-        StripDesc sd; sd.wg = w; sd.band_begin = ri.x; sd.n_b = ri.y; sd.pad = 0;
+        if (j < 256u) ri = rowinfo[j]; else { const uint32_t trow = (x + j * XCDS) * bc + bi, b0 = F->band_off[trow]; ri = make_uint2(b0, F->band_off[trow + 1] - b0); }
+        StripDesc sd; sd.wg = strip_of(i); sd.band_begin = ri.x; sd.n_b = ri.y; sd.pad = 0;
         F->strips[(size_t)rank * XCDS + x] = sd;
     }
 }
@@ -1850,7 +1850,7 @@ __global__ __launch_bounds__(64) void k2_tiles_shaded_b(const Frame2* __restrict
 // launchers: `frames` is a device array of n_frames descriptors, blockIdx.y picks one
 // ---------------------------------------------------------------------------------------------
 void launch2_bin(hipStream_t st, const Frame2* frames, uint32_t n_frames, uint32_t max_edges_or_paths, uint32_t max_bands) {
-    const uint32_t g = max_bands + (max_edges_or_paths + BIN_THREADS - 1) / BIN_THREADS + 1;      // + the workgroup that orders the strips
+    const uint32_t g = max_bands + (max_edges_or_paths + BIN_THREADS - 1) / BIN_THREADS + XCDS;   // + the workgroups that order the strips
     hipLaunchKernelGGL(k2_bin_b, dim3(g, n_frames), dim3(BIN_THREADS), 0, st, frames);
 }
 void launch2_rows(hipStream_t st, const Frame2* frames, uint32_t n_frames, uint32_t max_chunks) {
