@@ -862,8 +862,11 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
 int render_batch2(swfr_renderer* r, const swfr_stage* stages, uint32_t n, void* device_dst, size_t frame_stride) {
     struct FrameData { std::vector<swfr_edge> e; std::vector<swfr_path> p; std::vector<swfr_style> s; SceneLayout L; };
     static thread_local std::vector<FrameData> fd;
-    // frames per group: SWFR_BATCH_FRAMES, but at least four groups per call so that building group g + 1 overlaps rasterizing group g
-    const uint32_t B = std::min(uint32_t(std::max(1, r->batch_frames)), std::max(1u, (n + 3) / 4));
+    // frames per group: SWFR_BATCH_FRAMES at most; a call with fewer frames is still cut into four groups, so that building group
+    // g + 1 overlaps rasterizing group g, as long as a group keeps enough pixels (32 Mpx: four 4K frames, thirty-two 1024x1024 ones)
+    // for one launch per kernel to fill the GPU
+    const uint32_t fill = uint32_t((size_t(32) << 20) / std::max<size_t>(size_t(r->width) * r->height, 1)) + 1;
+    const uint32_t B = std::min(uint32_t(std::max(1, r->batch_frames)), std::max((n + 3) / 4, fill));
     const uint32_t tiles_x = (r->width + TILE_W - 1) / TILE_W;
     auto pad = [](size_t b) { return (b + 255) & ~size_t(255); };
     using clk = std::chrono::steady_clock;

@@ -10,7 +10,8 @@ bash tools/profile_shaded.sh ${TAG}_magnified magnified > /dev/null 2>&1
 cd $R
 timeout -k 10 300 python tools/config_bench.py > gpurun_out/${TAG}_config_bench.txt 2>&1; tail -3 gpurun_out/${TAG}_config_bench.txt
 for w in s1 s2; do TRACE_BUILD=trace timeout -k 10 120 python tools/trace_wg.py $w 2>&1 | grep -v amdgpu > gpurun_out/${TAG}_wg_timeline_$w.txt; done
-SWFR_FRAMES_IN_FLIGHT=1 timeout -k 10 300 python tools/pipeline_timing.py > gpurun_out/${TAG}_blocks_timing.json 2>/dev/null
+SWFR_FRAMES_IN_FLIGHT=1 timeout -k 10 300 python tools/pipeline_timing.py 2>/dev/null | tail -1 > gpurun_out/${TAG}_blocks_timing.json
+timeout -k 10 300 python bench.py --workload s2 --steps 100 --warmup 10 --no-cpu-baseline > gpurun_out/${TAG}_bench_s2.json 2>/dev/null; cut -c1-330 gpurun_out/${TAG}_bench_s2.json
 timeout -k 10 300 python tools/soak.py gpu 150 777 > gpurun_out/${TAG}_soak.txt 2>&1
 SOAK_LONG=1 timeout -k 10 300 python tools/soak.py gpu 60 778 >> gpurun_out/${TAG}_soak.txt 2>&1
 SOAK_BIG=1 timeout -k 10 300 python tools/soak.py gpu 40 779 >> gpurun_out/${TAG}_soak.txt 2>&1
