@@ -364,14 +364,13 @@ __global__ __launch_bounds__(1024) void k2_bin_b(const Frame2* __restrict__ fram
 #endif
 struct SubStage {
     uint32_t cells[4][ROWS_FAST_N * 15];   // the cells of the (up to four) SUB rows of one pass, packed: column << 16 | fraction << 1 | closes
-    uint32_t cnt[4];
 };
 // (per-row slots of the fast row routine: 7 KB; with the packed staging and the staged edges a k2_rows wavefront needs 12.9 KB of
 //  LDS -- twelve of them fit a CU, as many as its registers allow)
 struct FastLds2 {
     uint16_t eid[ROWS_FAST_N][64];
     int32_t roles[ROWS_FAST_N][64];
-    int32_t clo[ROWS_FAST_N][64], chi[ROWS_FAST_N][64];
+    uint16_t clo[ROWS_FAST_N][64], chi[ROWS_FAST_N][64];   // pixel columns, clamped to [0, 65535]
 };
 // a staged SUB cell: the span end at cell position x (24.8) opens (sgn > 0) or closes a span
 __device__ __forceinline__ uint32_t pack_sub_cell(int x, int sgn, int xminp, int xmaxp) {
@@ -541,17 +540,34 @@ __device__ __forceinline__ void rows2_fast(EPTR E, uint32_t n_list, const DevPat
     const uint32_t wave_base = ((uint64_t)chunk_cell_base + total_cells <= (uint64_t)FR->cell_slice) ? chunk_cell_base : ~0u;
     if (wave_base == ~0u && lane == 0) atomicOr(&FR->counters[C2_ERROR], E2_CELL_ARENA);
     R2PHASE(4);
-    if (lane < 4) S.cnt[lane] = 0;
+    // ---- FULL rows: the cells of every boundary edge, from the exact end points, into the row's room -- before the sample passes, so
+    //      that the end points' registers are free while those run
+    if (mode == ROW_FULL && ri != ~0u && live && !overflow && !defer && wave_base != ~0u) {
+        uint32_t off = wave_base + incl_cells - (uint32_t)room;
+#pragma unroll
+        for (int s = 0; s < ROWS_FAST_N; ++s) {
+            if (s >= nmax) continue;
+            if (s < n && roles[s] != 0) {
+                const int64_t edy = E[el[s]].dy;
+                full_cells(Q1[s], R1[s], Q2[s], R2[s], edy, ((uint32_t)roles[s] & 1u) ? +1 : -1, P.x_min, P.x_max, &FR->cells[off]);
+                off += (uint32_t)full_span(Q1[s], Q2[s]);
+            }
+        }
+    }
+    R2PHASE(6);
     lds_barrier();                                          // F.* written by the row owners, read by the sample lanes
-    // ---- the wave's SUB rows, 4 rows x 15 sample rows per pass: roles for the classification, cells for the tile pass
+    // ---- the wave's SUB rows, 4 rows per pass: lanes 16g .. 16g + 14 are the fifteen sample rows of the pass's g-th row (lane 16g + 15
+    //      idles), so everything the samples of one row have to combine -- role bits, column range, cell positions -- is a reduction
+    //      over one DPP row or a ballot: no LDS atomics.  Roles for the classification, cells for the tile pass.
     unsigned long long pending = __ballot(is_sub);
-    const int g = lane / 15, sub = lane - g * 15;
+    const int g = lane >> 4, sub = lane & 15;
+    const unsigned long long group_mask = 0xffffull << (16 * g);
+    const unsigned long long below = group_mask & ((1ull << lane) - 1ull);
     const int n_all = n;
     while (pending) {
         unsigned long long m = pending;
         int R = -1;
-        for (int t = 0; t <= g && t < 4; ++t) { if (!m) { R = -1; break; } R = __ffsll((long long)m) - 1; m &= m - 1; }
-        if (g >= 4) R = -1;
+        for (int t = 0; t <= g; ++t) { if (!m) { R = -1; break; } R = __ffsll((long long)m) - 1; m &= m - 1; }
         const unsigned long long pass_rows = pending;           // its four lowest bits set are this pass's rows
         for (int t = 0; t < 4 && pending; ++t) pending &= pending - 1;
         // cross-lane reads must run with every lane active: ds_bpermute returns 0 for a disabled source lane
@@ -559,27 +575,29 @@ __device__ __forceinline__ void rows2_fast(EPTR E, uint32_t n_list, const DevPat
         const int nR = __shfl(n_all, Rsrc);
         const int rR = __shfl(r, Rsrc);
         const uint32_t riR = (uint32_t)__shfl((int)ri, Rsrc);
-        if (R >= 0) {
-            const int ss = rR * 15 + sub;
-            int cc[ROWS_FAST_N], dd[ROWS_FAST_N];
-            unsigned act = 0;
+        const bool sampling = R >= 0 && sub < 15;
+        const int ss = rR * 15 + sub;
+        int cc[ROWS_FAST_N], dd[ROWS_FAST_N];
+        unsigned act = 0;
 #pragma unroll
-            for (int s = 0; s < ROWS_FAST_N; ++s) {
-                cc[s] = 0; dd[s] = 0;
-                if (s >= nmax) continue;
-                if (s < nR) {
-                    const DevEdge e = E[F.eid[s][R]];
-                    if (e.ytop <= ss && ss < e.ybot) {
-                        act |= 1u << s;
-                        dd[s] = e.dir;
-                        if (e.dy) { int32_t q; int64_t rm; edge_x_at(e, ss, q, rm); cc[s] = cell_of(q, rm, e.dy); } else cc[s] = e.x1;
-                    }
+        for (int s = 0; s < ROWS_FAST_N; ++s) {
+            cc[s] = 0; dd[s] = 0;
+            if (s >= nmax) continue;
+            if (sampling && s < nR) {
+                const DevEdge e = E[F.eid[s][Rsrc]];
+                if (e.ytop <= ss && ss < e.ybot) {
+                    act |= 1u << s;
+                    dd[s] = e.dir;
+                    if (e.dy) { int32_t q; int64_t rm; edge_x_at(e, ss, q, rm); cc[s] = cell_of(q, rm, e.dy); } else cc[s] = e.x1;
                 }
             }
+        }
+        uint32_t cnt_g = 0;                                 // cells of this lane's row so far (the same number in the row's sixteen lanes)
 #pragma unroll
-            for (int j = 0; j < ROWS_FAST_N; ++j) {
-                if (j >= nmax) continue;
-                if (!((act >> j) & 1u)) continue;
+        for (int j = 0; j < ROWS_FAST_N; ++j) {
+            if (j >= nmax) continue;                         // wave-uniform: every lane runs the reductions below
+            bool contributes = false, in_a = false;
+            if ((act >> j) & 1u) {
                 int wbj = 0, gsum = dd[j]; bool rep = true;
 #pragma unroll
                 for (int i = 0; i < ROWS_FAST_N; ++i) {
@@ -588,33 +606,47 @@ __device__ __forceinline__ void rows2_fast(EPTR E, uint32_t n_list, const DevPat
                     if (cc[i] < cc[j]) wbj += dd[i];
                     else if (cc[i] == cc[j]) { gsum += dd[i]; if (i < j) rep = false; }
                 }
-                if (!rep) continue;                      // one edge per group of equal cells carries the role
-                const bool in_b = ((unsigned)wbj & mask) != 0, in_a = ((unsigned)(wbj + gsum) & mask) != 0;
-                if (in_a != in_b) {
-                    atomicOr(&F.roles[j][R], (in_a ? 1 : 2) << (2 * sub));
-                    const int col = (int)clamp_col(cc[j] >> 8);
-                    atomicMin(&F.clo[j][R], col);
-                    atomicMax(&F.chi[j][R], col);
-                    if (riR != ~0u) {
-                        const uint32_t at = atomicAdd(&S.cnt[g], 1u);
-                        S.cells[g][at] = pack_sub_cell(cc[j], in_a ? 1 : -1, P.x_min, P.x_max);
-                    }
+                if (rep) {                                   // one edge per group of equal cells carries the role
+                    const bool in_b = ((unsigned)wbj & mask) != 0;
+                    in_a = ((unsigned)(wbj + gsum) & mask) != 0;
+                    contributes = in_a != in_b;
                 }
             }
+            const int col = (int)clamp_col(cc[j] >> 8);
+            int rb = contributes ? (int)((in_a ? 1u : 2u) << (2 * sub)) : 0;
+            int lo = contributes ? col : 65535, hi = contributes ? col : 0;
+            // all-reduce over the row's sixteen lanes: four rotations each
+            rb |= __builtin_amdgcn_update_dpp(0, rb, 0x128, 0xf, 0xf, false);
+            lo = min(lo, __builtin_amdgcn_update_dpp(0, lo, 0x128, 0xf, 0xf, false));
+            hi = max(hi, __builtin_amdgcn_update_dpp(0, hi, 0x128, 0xf, 0xf, false));
+            rb |= __builtin_amdgcn_update_dpp(0, rb, 0x124, 0xf, 0xf, false);
+            lo = min(lo, __builtin_amdgcn_update_dpp(0, lo, 0x124, 0xf, 0xf, false));
+            hi = max(hi, __builtin_amdgcn_update_dpp(0, hi, 0x124, 0xf, 0xf, false));
+            rb |= __builtin_amdgcn_update_dpp(0, rb, 0x122, 0xf, 0xf, false);
+            lo = min(lo, __builtin_amdgcn_update_dpp(0, lo, 0x122, 0xf, 0xf, false));
+            hi = max(hi, __builtin_amdgcn_update_dpp(0, hi, 0x122, 0xf, 0xf, false));
+            rb |= __builtin_amdgcn_update_dpp(0, rb, 0x121, 0xf, 0xf, false);
+            lo = min(lo, __builtin_amdgcn_update_dpp(0, lo, 0x121, 0xf, 0xf, false));
+            hi = max(hi, __builtin_amdgcn_update_dpp(0, hi, 0x121, 0xf, 0xf, false));
+            if (sub == 0 && R >= 0) { F.roles[j][R] = rb; F.clo[j][R] = (uint16_t)lo; F.chi[j][R] = (uint16_t)hi; }
+            const bool cell = contributes && riR != ~0u;
+            const unsigned long long cb = __ballot(cell);
+            if (cell) S.cells[g][cnt_g + (uint32_t)__popcll(cb & below)] = pack_sub_cell(cc[j], in_a ? 1 : -1, P.x_min, P.x_max);
+            cnt_g += (uint32_t)__popcll(cb & group_mask);
         }
         lds_barrier();                                      // the pass's cells are staged
         // ---- copy out (coalesced) into the rows' room, row headers
         {
-            const uint32_t c0 = S.cnt[0], c1 = S.cnt[1], c2 = S.cnt[2], c3 = S.cnt[3];
+            const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)cnt_g, 0), c1 = (uint32_t)__builtin_amdgcn_readlane((int)cnt_g, 16);
+            const uint32_t c2 = (uint32_t)__builtin_amdgcn_readlane((int)cnt_g, 32), c3 = (uint32_t)__builtin_amdgcn_readlane((int)cnt_g, 48);
             const uint32_t total = c0 + c1 + c2 + c3;
             // where the rooms of the pass's rows start: the row lanes know (exclusive prefix of the rooms), every lane asks
             const uint32_t my_room = wave_base + incl_cells - (uint32_t)room;
-            uint32_t pm2 = 0; int Rg[4];
+            int Rg[4];
             {
                 unsigned long long m2 = pass_rows;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) { Rg[t] = m2 ? __ffsll((long long)m2) - 1 : 0; m2 &= m2 - 1; }
-                (void)pm2;
             }
             const uint32_t b0 = (uint32_t)__shfl((int)my_room, Rg[0]), b1 = (uint32_t)__shfl((int)my_room, Rg[1]);
             const uint32_t b2 = (uint32_t)__shfl((int)my_room, Rg[2]), b3 = (uint32_t)__shfl((int)my_room, Rg[3]);
@@ -628,13 +660,11 @@ __device__ __forceinline__ void rows2_fast(EPTR E, uint32_t n_list, const DevPat
             }
             if (sub == 0 && R >= 0 && riR != ~0u) {          // the first sample lane of each of the pass's rows writes its header
                 const uint32_t bb = g == 0 ? b0 : (g == 1 ? b1 : (g == 2 ? b2 : b3));
-                RowInfo2 h; h.off = wave_base == ~0u ? 0u : bb; h.n = wave_base == ~0u ? (uint16_t)0 : (uint16_t)S.cnt[g]; h.mode = (uint16_t)ROW_SUB;
+                RowInfo2 h; h.off = wave_base == ~0u ? 0u : bb; h.n = wave_base == ~0u ? (uint16_t)0 : (uint16_t)cnt_g; h.mode = (uint16_t)ROW_SUB;
                 FR->rows[riR] = h;
             }
         }
-        lds_barrier();                                      // staging read: reset the counters for the next pass
-        if (lane < 4) S.cnt[lane] = 0;
-        lds_barrier();
+        lds_barrier();                                      // the staging has been read: the next pass may overwrite it
     }
     lds_barrier();                                          // role bits OR-ed in by the sample lanes
     if (is_sub) {
@@ -717,26 +747,13 @@ __device__ __forceinline__ void rows2_chunk_body(FramePtr FR, uint32_t block) {
     if (use_lds) rows2_fast((const DevEdge*)staged, n_list, P, r, live, fast_limit, F, S, lane, mode, n, overflow, defer, roles, cols, el, Q1, R1, Q2, R2, nmax, ri, FR, n_cells, incl, base, r2ph, r2ph_t, chunk_cell_base);
     else rows2_fast(FR->edges + P.first_edge, P.n_edges, P, r, live, fast_limit, F, S, lane, mode, n, overflow, defer, roles, cols, el, Q1, R1, Q2, R2, nmax, ri, FR, n_cells, incl, base, r2ph, r2ph_t, chunk_cell_base);
     const bool slow = live && (overflow || defer);
-    // ---- FULL rows: cells of every boundary edge, densely packed behind the wavefront's allocation
+    // ---- headers of the rows that are not SUB (those were written with their cells); a FULL row's cells are in place already
     const bool emit = mode == ROW_FULL && ri != ~0u && !slow;
-    if (ri != ~0u && lane < chunk_rows && mode != ROW_SUB) {            // (the SUB rows' headers were written with their cells)
+    if (ri != ~0u && lane < chunk_rows && mode != ROW_SUB) {
         RowInfo2 h; h.off = 0; h.n = 0; h.mode = (uint16_t)(slow ? ROW_DEFER : (in_path && !live) ? ROW_FOREIGN : mode);   // (another rank's row: not known here)
-        if (emit && base != ~0u) {
-            uint32_t off = base + incl - (uint32_t)n_cells;
-            h.off = off; h.n = (uint16_t)n_cells;
-#pragma unroll
-            for (int s = 0; s < ROWS_FAST_N; ++s) {
-                if (s >= nmax) continue;
-                if (s < n && roles[s] != 0) {
-                    const int64_t edy = use_lds ? staged[el[s]].dy : FR->edges[P.first_edge + el[s]].dy;
-                    full_cells(Q1[s], R1[s], Q2[s], R2[s], edy, ((uint32_t)roles[s] & 1u) ? +1 : -1, P.x_min, P.x_max, &FR->cells[off]);
-                    off += (uint32_t)full_span(Q1[s], Q2[s]);
-                }
-            }
-        }
+        if (emit && base != ~0u) { h.off = base + incl - (uint32_t)n_cells; h.n = (uint16_t)n_cells; }
         FR->rows[ri] = h;
     }
-    R2PHASE(6);
     // ---- rows left to the slow-row kernel
     {
         const bool q = slow && ri != ~0u;

@@ -113,7 +113,7 @@ __device__ __forceinline__ DevEdge make_dev_edge(const swfr_edge& e, const DevPa
 
 #define ROWS_FAST_N 8            // active edges per row handled in registers by k2_rows
 #define ROWS_BIG_MAXA 64         // capacity of the generic (LDS list) routine of k2_rows_slow
-#define ROWS_STAGE 64            // paths with at most this many edges are staged into LDS
+#define ROWS_STAGE 48            // chunks with at most this many edges of their path in reach are staged into LDS
 
 // All edges of one path, whichever form the kernel has them in (k_front's DevEdge array, or the raw edges when the row pass
 // computes the constants itself).
