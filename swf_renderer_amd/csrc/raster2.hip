@@ -1555,6 +1555,9 @@ __device__ __forceinline__ void blend_rows(uint32_t (&px)[STRIP_H], const uint32
 // ---------------------------------------------------------------------------------------------
 #define T2_LIST 32                     // band entries of a tile kept per round (lane = list position; lanes 32.. fetch the row headers)
 #define T2_PRE 1                       // rounds of 64 cells of a batch fetched ahead into registers
+#ifndef CLS_PRE
+#define CLS_PRE 3                      // x 64 class bytes of a tile fetched at once
+#endif
 #ifndef T2_ACC_STRIDE
 #define T2_ACC_STRIDE 65               // 64 cells + the carry slot (65 rather than 66: 28 wavefronts' LDS fit a CU)
 #endif
@@ -1604,13 +1607,23 @@ __device__ __forceinline__ void tiles2_body(FramePtr FR) {
 
         const uint32_t band_begin = sd.band_begin, n_b = sd.n_b;
         const uint8_t* mycls = FR->cls + (size_t)tiles_x * band_begin + (size_t)tcol * n_b;   // this tile's class byte per band entry
+        // the tile's first CLS_PRE x 64 class bytes in one round trip (the rounds of the loop below would fetch them one after the other,
+        // each waiting for its own load)
+        uint32_t cpre[CLS_PRE];
+#pragma unroll
+        for (int u = 0; u < CLS_PRE; ++u) cpre[u] = (uint32_t)(u * 64 + lane) < n_b ? (uint32_t)mycls[u * 64 + lane] : 0u;
         uint32_t next = 0;
         while (next < n_b) {
             // ---- bin: band entries with a non-empty class for this tile, painter's order kept (wave-local compaction)
             int ln = 0;
             while (next < n_b && ln < T2_LIST) {
                 const uint32_t bi = next + lane;
-                const uint32_t f = bi < n_b ? (uint32_t)mycls[bi] : 0u;
+                uint32_t f;
+                if ((next & 63u) == 0u && next < 64u * CLS_PRE) {          // wave-uniform
+                    f = cpre[0];
+#pragma unroll
+                    for (int u = 1; u < CLS_PRE; ++u) if (next == 64u * (uint32_t)u) f = cpre[u];
+                } else f = bi < n_b ? (uint32_t)mycls[bi] : 0u;
                 bool hit = (f & CLS_NONEMPTY) != 0;
                 unsigned long long b = __ballot(hit);
                 const int room = T2_LIST - ln;
@@ -1636,7 +1649,8 @@ __device__ __forceinline__ void tiles2_body(FramePtr FR) {
             // ---- the surviving entries (lanes 0..31: 32 bytes as two 16-byte loads) and, for the partial tor paths among them, the
             //      headers of this strip's eight rows (lanes 32..63: 64 bytes) -- both addressed by the band list position alone
             {
-                const int li = lane & (T2_LIST - 1);
+                int li = lane & (T2_LIST - 1);
+                SWFR_OPAQUE(li);                                  // (the LDS addresses below are formed here, not carried from the prologue in spilled registers)
                 if (li >= start && li < ln) {
                     const uint32_t sv = sel[li];
                     const uint32_t bidx = band_begin + (sv & 0xffffffu);
