@@ -172,20 +172,19 @@ struct Frame2 {
     // layout of the tables below, from the paths' rectangles alone (host: prefix sums over the paths / the tile-rows)
     const uint32_t* path_chunks; const uint32_t* path_slots; const uint32_t* path_inc;   // per path: first chunk, first band slot, first (edge, row) pair
     const uint32_t* band_off;                                          // per tile-row: first entry of its band list
-    // binning, per frame in flight (kernel-written: k2_bin, k2_rows, k2_order)
+    // binning, per frame in flight (kernel-written: k2_bin, k2_rows)
     ChunkInfo* chunks; BandSlot* band_slots; StripDesc* strips;
-    uint32_t* band_cnt; uint32_t* strip_cost;                          // strip_cost: zero between frames (k2_order clears what it has read)
+    uint32_t* strip_cost;                                              // zero between frames (the ordering workgroups of k2_bin clear what they have read)
     // per frame in flight (kernel-written)
     DevEdge* edges; BandEntry2* band_list; uint8_t* cls; RowInfo2* rows; Cell* cells; SlowRow* slow; SlowRow* huge; uint32_t* counters;
     uint32_t* path_flag; uint32_t* path_queue;     // paths with queued rows: their edges get start ranks (k2_start_ranks)
     uint32_t* fb;
-    uint32_t n_edges, n_paths, n_chunks, n_slots, n_bands, n_strips, cell_slice, slow_cap;
+    uint32_t n_edges, n_paths, n_chunks, n_bands, n_strips, cell_slice, slow_cap;
     int32_t width, height, tiles_x;
-    uint32_t band_index, band_count, fast_limit, any_shader, dbg;
-    uint32_t cell_heads;     // (unused)
+    uint32_t fast_limit;     // active edges per row the fast routine of k2_rows keeps (<= 8)
     uint32_t cell_main;      // cells [0, cell_main) belong to the chunk wavefronts of k2_rows, the rest to the slow rows' bump allocator
     uint32_t chunk_rows;     // pixel rows per k2_rows wavefront (16, 32 or 64)
-    uint32_t chunk_cap, slot_cap;   // capacities of chunks[] / band_slots[] and band_list[] (the host sizes them from the paths' rectangles)
+    uint32_t chunk_cap;      // capacity of chunks[] (the host sizes it from the paths' rectangles)
     uint32_t strip_order;    // 0: strips in row-major order, 1: heaviest first
     uint32_t n_strip_slots;             // launch list slots of the tile pass: XCDS * ceil(local tile-rows / XCDS) * strips per tile-row (strip_slots())
     uint32_t band_first, band_stride;   // the handle's tile-rows: band_first + l * band_stride, l < n_strips / (STRIPS_PER_TILE * tiles_x)

@@ -909,7 +909,7 @@ __device__ __forceinline__ void start_ranks_body(FramePtr FR, uint32_t p) {
     __shared__ uint16_t sort_a[START_MAX], sort_b[START_MAX];
     __shared__ uint32_t member[START_MAX];
     __shared__ uint32_t wave_cnt[4];
-    __shared__ int next_y, grp_n;
+    __shared__ int next_y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const DevPath P = FR->paths[p];
     if (P.kind != SWFR_PATH_TOR) return;
@@ -967,7 +967,6 @@ __device__ __forceinline__ void start_ranks_body(FramePtr FR, uint32_t p) {
             n += (int)(wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3]);
             __syncthreads();
         }
-        if (tid == 0) grp_n = n;
         __syncthreads();
         if (n > START_MAX) { if (tid == 0) atomicOr(&FR->counters[C2_ERROR], E2_START_GROUP); return; }     // workgroup-uniform
         for (int q = tid; q < (n + 1) / 2; q += 256) sort_pairs(sort_a, sort_cell, q, n);

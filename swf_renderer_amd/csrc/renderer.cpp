@@ -177,8 +177,7 @@ struct swfr_renderer {
         DevBuf<ChunkInfo> d_chunks;
         DevBuf<BandSlot> d_band_slots;
         DevBuf<StripDesc> d_strips;
-        DevBuf<uint32_t> d_band_off, d_path_chunks, d_path_slots, d_path_inc, d_band_cnt, d_strip_cost;
-        size_t cell_slice = 0, slow_cap = 0, cell_heads = 1;
+        DevBuf<uint32_t> d_strip_cost;
     };
     FrameSet fs[4];
     DevBuf<DevBitmap> d_bitmap_table;
@@ -221,7 +220,7 @@ struct swfr_renderer {
                 FrameSet& x = fs[k];
                 x.d_edges.release(); x.d_cls.release(); x.d_counters.release(); x.d_fb.release();
                 x.d_band2.release(); x.d_rows2.release(); x.d_cells.release(); x.d_slow.release(); x.d_huge.release(); x.d_path_flag.release(); x.d_path_queue.release(); x.d_chunks.release(); x.d_band_slots.release(); x.d_strips.release();
-                x.d_band_off.release(); x.d_path_chunks.release(); x.d_path_slots.release(); x.d_path_inc.release(); x.d_band_cnt.release(); x.d_strip_cost.release();
+                x.d_strip_cost.release();
                 if (k > 0 && x.stream) (void)hipStreamDestroy(x.stream);
                 scn[k].arena.release();
             }
@@ -599,15 +598,14 @@ swfr_edge* push_scene(SceneArena& A, const SceneLayout& L, const swfr_edge* edge
     return staged;
 }
 void fill_frame_sizes(const swfr_renderer* r, const SceneLayout& L, size_t n_edges, size_t n_paths, Frame2& f) {
-    const uint32_t bc = r->cfg.band_count > 1 ? r->cfg.band_count : 1, bi = r->cfg.band_count > 1 ? r->cfg.band_index : 0;
-    f.n_edges = uint32_t(n_edges); f.n_paths = uint32_t(n_paths); f.n_chunks = uint32_t(L.n_chunks); f.n_slots = uint32_t(L.n_slots);
+    f.n_edges = uint32_t(n_edges); f.n_paths = uint32_t(n_paths); f.n_chunks = uint32_t(L.n_chunks);
     f.n_bands = uint32_t(L.n_bands); f.n_strips = uint32_t(L.n_strips); f.n_strip_slots = uint32_t(L.n_strip_slots); f.cell_slice = uint32_t(L.cell_total); f.slow_cap = uint32_t(L.n_rows + 64);
     f.width = int32_t(r->width); f.height = int32_t(r->height); f.tiles_x = int32_t((r->width + TILE_W - 1) / TILE_W);
-    f.band_index = bi; f.band_count = bc; f.fast_limit = uint32_t(std::min(std::max(r->fast_limit, 0), 8)); f.any_shader = L.any_shader ? 1u : 0u;
+    f.fast_limit = uint32_t(std::min(std::max(r->fast_limit, 0), 8));
     const BandShare bs = band_share(r);
     f.band_first = bs.first; f.band_stride = bs.stride;
-    f.dbg = 0; f.cell_heads = 1; f.cell_main = uint32_t(L.cell_main);
-    f.chunk_rows = L.chunk_rows; f.chunk_cap = uint32_t(L.n_chunks + 1); f.slot_cap = uint32_t(L.n_slots + 1); f.strip_order = r->strip_order ? 1u : 0u;
+    f.cell_main = uint32_t(L.cell_main);
+    f.chunk_rows = L.chunk_rows; f.chunk_cap = uint32_t(L.n_chunks + 1); f.strip_order = r->strip_order ? 1u : 0u;
 }
 
 // Uploads a scene -- the raw edge list, the paths and the styles, plus the layout above -- and sizes the buffers the
@@ -660,7 +658,6 @@ int upload2(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, siz
         x.d_path_flag.reserve(n_paths + 64); x.d_path_queue.reserve(n_paths + 64);
         x.d_chunks.reserve(n_chunks + 1); x.d_band_slots.reserve(n_slots + 1); x.d_strips.reserve(L.n_strip_slots + 1);
         reserve_zeroed(x.d_strip_cost, L.n_strips + 1);                                 // (zero between frames: the ordering workgroup clears what it has read)
-        x.cell_slice = L.cell_total; x.slow_cap = n_rows + 64;
         x.d_counters.reserve(COUNTER_WORDS);
         x.d_cls.reserve(n_slots * tiles_x + 64);
         // class bytes outside the paths' rectangles are never written by a kernel: cleared once per uploaded scene
@@ -680,7 +677,7 @@ int upload2(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, siz
         Frame2& f = fr[k];
         f = proto;
         f.chunks = x.d_chunks.ptr; f.band_slots = x.d_band_slots.ptr; f.strips = x.d_strips.ptr;
-        f.band_cnt = nullptr; f.strip_cost = x.d_strip_cost.ptr;
+        f.strip_cost = x.d_strip_cost.ptr;
         f.edges = x.d_edges.ptr; f.band_list = x.d_band2.ptr; f.cls = x.d_cls.ptr; f.rows = x.d_rows2.ptr; f.cells = x.d_cells.ptr;
         f.slow = x.d_slow.ptr; f.huge = x.d_huge.ptr; f.counters = x.d_counters.ptr;
         f.path_flag = x.d_path_flag.ptr; f.path_queue = x.d_path_queue.ptr;
