@@ -207,7 +207,7 @@ __device__ __forceinline__ void bin_body(FramePtr F) {
                 BandSlot bs; bs.path = p; bs.slot = slot; bs.band = (uint32_t)band; bs.pad = 0;
                 F->band_slots[F->path_slots[p] + (uint32_t)(band - P.y_min / TILE_H)] = bs;
                 if (P.kind == SWFR_PATH_BOXES) {
-                    uint8_t* out = F->cls + (size_t)F->tiles_x * b0 + at;
+                    uint8_t* out = F->cls + (size_t)STRIPS_PER_TILE * F->tiles_x * b0 + at;    // [tile column][strip][entry] inside the tile-row
                     const int ty0 = band * TILE_H, tile_y1 = min(ty0 + TILE_H, F->height);
                     const uint32_t opq = (e.flags & BE_OPAQUE_COVER) ? CLS_OPAQUE : 0u;
                     const swfr_edge bx = F->raw[P.first_edge];             // (only looked at when the path is a single box)
@@ -216,7 +216,7 @@ __device__ __forceinline__ void bin_body(FramePtr F) {
                         const int tx0 = tc * TILE_W, tile_x1 = min(tx0 + TILE_W, F->width);
                         uint32_t f = CLS_BOX | CLS_NONEMPTY | CLS_NOTFULL;
                         if (one_box && bx.x1 <= tx0 * 256 && bx.x2 >= tile_x1 * 256) f = CLS_NONEMPTY | opq;     // the box contains the whole tile: full cover
-                        out[(size_t)tc * n_b] = (uint8_t)f;
+                        for (int sp = 0; sp < STRIPS_PER_TILE; ++sp) out[(size_t)(tc * STRIPS_PER_TILE + sp) * n_b] = (uint8_t)f;
                     }
                 }
             }
@@ -786,7 +786,7 @@ __device__ __forceinline__ void rows2_chunk_body(FramePtr FR, uint32_t block) {
         uint32_t n_b = 0;
         if (band_ok) {
             n_b = cls_b1 - cls_b0;
-            out = FR->cls + (size_t)FR->tiles_x * cls_b0 + (cls_bs.slot - cls_b0);
+            out = FR->cls + (size_t)STRIPS_PER_TILE * FR->tiles_x * cls_b0 + (cls_bs.slot - cls_b0);
         }
         const swfr_style& st = FR->styles[P.style];
         const uint32_t opq = (st.kind == SWFR_STYLE_SOLID && P.lerp && (st.pixel >> 24) == 0xffu) ? CLS_OPAQUE : 0u;
@@ -821,15 +821,14 @@ __device__ __forceinline__ void rows2_chunk_body(FramePtr FR, uint32_t block) {
                     row_partial = inter;
                 }
             }
-            // OR over the tile-row's sixteen lanes (one DPP row): four rotations; every lane is active here
-            f |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f, 0x128, 0xf, 0xf, false);   // row_ror:8
-            f |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f, 0x124, 0xf, 0xf, false);   // row_ror:4
-            f |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f, 0x122, 0xf, 0xf, false);   // row_ror:2
-            f |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f, 0x121, 0xf, 0xf, false);   // row_ror:1
+            // OR over the strip's eight lanes (half a DPP row): mirror the half, then two quad permutations; every lane is active here
+            f |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f, 0x141, 0xf, 0xf, false);   // row_half_mirror
+            f |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f, 0xb1, 0xf, 0xf, false);    // quad_perm:[1,0,3,2]
+            f |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f, 0x4e, 0xf, 0xf, false);    // quad_perm:[2,3,0,1]
             if ((f & (CLS_HOLE | CLS_NONEMPTY)) == (CLS_HOLE | CLS_NONEMPTY)) f |= CLS_PARTIAL;
             f &= ~CLS_HOLE;
             if ((f & (CLS_PARTIAL | CLS_NOTFULL | CLS_NONEMPTY)) == CLS_NONEMPTY) f |= opq;        // a full cover that hides what lies below
-            if ((lane & 15) == 0 && band_ok) out[(size_t)tc * n_b] = (uint8_t)f;
+            if ((lane & 7) == 0 && band_ok) out[(size_t)(tc * STRIPS_PER_TILE + ((lane >> 3) & 1)) * n_b] = (uint8_t)f;
             // the tile's strips get heavier by the rows of this path with a boundary in the tile (the tile pass starts its heaviest
             // strips first): lanes 0 and 8 of the tile-row's sixteen add their half's rows
             if (FR->strip_order) {
@@ -1605,7 +1604,7 @@ __device__ __forceinline__ void tiles2_body(FramePtr FR) {
         for (int rr = 0; rr < STRIP_H; ++rr) px[rr] = 0u;
 
         const uint32_t band_begin = sd.band_begin, n_b = sd.n_b;
-        const uint8_t* mycls = FR->cls + (size_t)tiles_x * band_begin + (size_t)tcol * n_b;   // this tile's class byte per band entry
+        const uint8_t* mycls = FR->cls + (size_t)STRIPS_PER_TILE * tiles_x * band_begin + (size_t)(tcol * STRIPS_PER_TILE + strip) * n_b;   // this strip's class byte per band entry
         // the tile's first CLS_PRE x 64 class bytes in one round trip (the rounds of the loop below would fetch them one after the other,
         // each waiting for its own load)
         uint32_t cpre[CLS_PRE];

@@ -659,9 +659,9 @@ int upload2(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, siz
         x.d_chunks.reserve(n_chunks + 1); x.d_band_slots.reserve(n_slots + 1); x.d_strips.reserve(L.n_strip_slots + 1);
         reserve_zeroed(x.d_strip_cost, L.n_strips + 1);                                 // (zero between frames: the ordering workgroup clears what it has read)
         x.d_counters.reserve(COUNTER_WORDS);
-        x.d_cls.reserve(n_slots * tiles_x + 64);
+        x.d_cls.reserve(STRIPS_PER_TILE * n_slots * tiles_x + 64);
         // class bytes outside the paths' rectangles are never written by a kernel: cleared once per uploaded scene
-        HIP_CHECK(hipMemsetAsync(x.d_cls.ptr, 0, n_slots * tiles_x + 64, up_stream));
+        HIP_CHECK(hipMemsetAsync(x.d_cls.ptr, 0, STRIPS_PER_TILE * n_slots * tiles_x + 64, up_stream));
         if (!x.d_fb.ptr) {
             x.d_fb.reserve(size_t(r->width) * r->height);
             HIP_CHECK(hipMemsetAsync(x.d_fb.ptr, 0, size_t(r->width) * r->height * 4, up_stream));
@@ -912,7 +912,7 @@ int render_batch2(swfr_renderer* r, const swfr_stage* stages, uint32_t n, void* 
                           pad(L.cell_total * sizeof(Cell)) + 2 * pad(2 * (L.n_rows + 64) * sizeof(SlowRow)) + 2 * pad((F.p.size() + 64) * sizeof(uint32_t)) +
                           pad((L.n_chunks + 1) * sizeof(ChunkInfo)) + pad((L.n_slots + 1) * sizeof(BandSlot)) + pad((L.n_strip_slots + 1) * sizeof(StripDesc)) +
                           pad((L.n_strips + 1) * sizeof(uint32_t)) + pad(COUNTER_WORDS * sizeof(uint32_t));
-            cls_bytes += pad(L.n_slots * tiles_x + 64);
+            cls_bytes += pad(STRIPS_PER_TILE * L.n_slots * tiles_x + 64);
             max_ep = std::max(max_ep, std::max(F.e.size(), F.p.size())); max_bands = std::max(max_bands, L.n_bands);
             max_chunks = std::max(max_chunks, L.n_chunks); max_strips = std::max(max_strips, L.n_strip_slots);
             shader_level = std::max(shader_level, L.shader_level);
@@ -957,7 +957,7 @@ int render_batch2(swfr_renderer* r, const swfr_stage* stages, uint32_t n, void* 
             f.strips = reinterpret_cast<StripDesc*>(carve((L.n_strip_slots + 1) * sizeof(StripDesc)));
             f.strip_cost = reinterpret_cast<uint32_t*>(carve((L.n_strips + 1) * sizeof(uint32_t)));
             f.counters = reinterpret_cast<uint32_t*>(carve(COUNTER_WORDS * sizeof(uint32_t)));
-            f.cls = c; c += pad(L.n_slots * tiles_x + 64);
+            f.cls = c; c += pad(STRIPS_PER_TILE * L.n_slots * tiles_x + 64);
             f.strip_order = 0;                              // (a frame's buffers held another frame before: no cost history to order by)
             f.fb = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(device_dst) + size_t(first + k) * frame_stride);
         }
