@@ -168,7 +168,8 @@ struct swfr_renderer {
         hipStream_t stream = nullptr;
         DevBuf<DevEdge> d_edges;
         DevBuf<uint8_t> d_cls;
-        DevBuf<uint32_t> d_counters, d_fb;
+        uint32_t* counters = nullptr;            // this set's COUNTER_WORDS of swfr_renderer::d_counters (one buffer: one copy brings all sets' back)
+        DevBuf<uint32_t> d_fb;
         DevBuf<BandEntry2> d_band2;
         DevBuf<RowInfo2> d_rows2;
         DevBuf<Cell> d_cells;
@@ -182,6 +183,7 @@ struct swfr_renderer {
     FrameSet fs[4];
     DevBuf<DevBitmap> d_bitmap_table;
     DevBuf<uint32_t> d_tmp;
+    DevBuf<uint32_t> d_counters;            // 4 x COUNTER_WORDS: the frame sets' counters, contiguous
     int in_flight = 3;
     int hint_slow_state = 0; uint32_t hint_slow_passes = SLOW_PASSES;   // what the last rendered scene needed of the queued-row kernels
     uint32_t* fb_cur = nullptr;             // framebuffer of the last completed frame
@@ -215,10 +217,10 @@ struct swfr_renderer {
     ~swfr_renderer() {
         if (has_device) {
             (void)hipSetDevice(cfg.device);
-            d_bitmap_table.release(); d_tmp.release();
+            d_bitmap_table.release(); d_tmp.release(); d_counters.release();
             for (int k = 0; k < 4; ++k) {
                 FrameSet& x = fs[k];
-                x.d_edges.release(); x.d_cls.release(); x.d_counters.release(); x.d_fb.release();
+                x.d_edges.release(); x.d_cls.release(); x.d_fb.release();
                 x.d_band2.release(); x.d_rows2.release(); x.d_cells.release(); x.d_slow.release(); x.d_huge.release(); x.d_path_flag.release(); x.d_path_queue.release(); x.d_chunks.release(); x.d_band_slots.release(); x.d_strips.release();
                 x.d_strip_cost.release();
                 if (k > 0 && x.stream) (void)hipStreamDestroy(x.stream);
@@ -658,7 +660,8 @@ int upload2(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, siz
         x.d_path_flag.reserve(n_paths + 64); x.d_path_queue.reserve(n_paths + 64);
         x.d_chunks.reserve(n_chunks + 1); x.d_band_slots.reserve(n_slots + 1); x.d_strips.reserve(L.n_strip_slots + 1);
         reserve_zeroed(x.d_strip_cost, L.n_strips + 1);                                 // (zero between frames: the ordering workgroup clears what it has read)
-        x.d_counters.reserve(COUNTER_WORDS);
+        r->d_counters.reserve(4 * COUNTER_WORDS);
+        x.counters = r->d_counters.ptr + size_t(k) * COUNTER_WORDS;
         x.d_cls.reserve(STRIPS_PER_TILE * n_slots * tiles_x + 64);
         // class bytes outside the paths' rectangles are never written by a kernel: cleared once per uploaded scene
         HIP_CHECK(hipMemsetAsync(x.d_cls.ptr, 0, STRIPS_PER_TILE * n_slots * tiles_x + 64, up_stream));
@@ -679,7 +682,7 @@ int upload2(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, siz
         f.chunks = x.d_chunks.ptr; f.band_slots = x.d_band_slots.ptr; f.strips = x.d_strips.ptr;
         f.strip_cost = x.d_strip_cost.ptr;
         f.edges = x.d_edges.ptr; f.band_list = x.d_band2.ptr; f.cls = x.d_cls.ptr; f.rows = x.d_rows2.ptr; f.cells = x.d_cells.ptr;
-        f.slow = x.d_slow.ptr; f.huge = x.d_huge.ptr; f.counters = x.d_counters.ptr;
+        f.slow = x.d_slow.ptr; f.huge = x.d_huge.ptr; f.counters = x.counters;
         f.path_flag = x.d_path_flag.ptr; f.path_queue = x.d_path_queue.ptr;
         f.fb = (fb_override && k == si) ? fb_override : (r->n_targets ? r->targets[uint32_t(k) % r->n_targets] : x.d_fb.ptr);
     }
@@ -772,18 +775,17 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
         HIP_CHECK(hipEventCreate(&e));
         r->ev.push_back(e);
     }
-    const uint32_t stride = r->event_stride < 1 ? 1u : uint32_t(r->event_stride);
+    uint32_t stride = r->event_stride < 1 ? 1u : uint32_t(r->event_stride);
+    if (frames < 64) stride = std::min(stride, 8u);        // (a short run still gets two or three frames with per-kernel times)
     hipEvent_t ev_begin = r->ev[size_t(frames) * 4], ev_end = r->ev[size_t(frames) * 4 + 1];
     hipEvent_t* ev_join = &r->ev[size_t(frames) * 4 + 2];
-    HIP_CHECK(hipMemsetAsync(r->fs[0].d_counters.ptr, 0, COUNTER_WORDS * sizeof(uint32_t), r->stream));
+    // (no clearing of the counters here: k2_bin zeroes its frame's counters itself)
     HIP_CHECK(hipEventRecord(ev_begin, r->stream));
-    for (uint32_t k = 1; k < n_sets; ++k) {
-        HIP_CHECK(hipStreamWaitEvent(r->fs[k].stream, ev_begin, 0));
-        HIP_CHECK(hipMemsetAsync(r->fs[k].d_counters.ptr, 0, COUNTER_WORDS * sizeof(uint32_t), r->fs[k].stream));
-    }
+    for (uint32_t k = 1; k < n_sets; ++k) HIP_CHECK(hipStreamWaitEvent(r->fs[k].stream, ev_begin, 0));
+    const uint32_t first_timed = std::min(stride / 2, frames - 1);      // (not frame 0: the first frames run before the pipeline is full)
     for (uint32_t f = 0; f < frames; ++f) {
         swfr_renderer::FrameSet& F = r->fs[f % n_sets];
-        const bool timed = f % stride == 0;        // per-kernel events on every stride-th frame (each costs a queue packet)
+        const bool timed = f >= first_timed && (f - first_timed) % stride == 0;   // per-kernel events on every stride-th frame (each costs a queue packet)
         launch_frame(r, sc, F, F.d_fb.ptr, timed ? &r->ev[size_t(f) * 4] : nullptr);
     }
     for (uint32_t k = 1; k < n_sets; ++k) {
@@ -794,12 +796,12 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
     HIP_CHECK(hipGetLastError());
     // the counters of every set come back through pinned memory behind the last kernel: one synchronisation for everything
     if (!r->h_counters) HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&r->h_counters), 4 * COUNTER_WORDS * sizeof(uint32_t), hipHostMallocDefault));
-    for (uint32_t k = 0; k < n_sets; ++k)
-        HIP_CHECK(hipMemcpyAsync(r->h_counters + k * COUNTER_WORDS, r->fs[k].d_counters.ptr, COUNTER_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
+    const uint32_t used_sets = std::min(frames, n_sets);               // (a set that rendered no frame of this call holds an older frame's counters)
+    HIP_CHECK(hipMemcpyAsync(r->h_counters, r->d_counters.ptr, size_t(used_sets) * COUNTER_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
     HIP_CHECK(hipStreamSynchronize(r->stream));
     r->fb_cur = r->fs[(frames - 1) % n_sets].d_fb.ptr;
     uint32_t timed_frames = 0;
-    for (uint32_t f = 0; f < frames; f += stride, ++timed_frames) {
+    for (uint32_t f = first_timed; f < frames; f += stride, ++timed_frames) {
         hipEvent_t* e = &r->ev[size_t(f) * 4];
         float a = 0, b = 0, c = 0;
         HIP_CHECK(hipEventElapsedTime(&a, e[0], e[1]));
@@ -809,7 +811,7 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
     }
     HIP_CHECK(hipEventElapsedTime(&total_ms, ev_begin, ev_end));
     std::memcpy(counters, r->h_counters, sizeof counters);
-    for (uint32_t k = 1; k < n_sets; ++k)                  // (set 0's counts, every set's error and limit flags)
+    for (uint32_t k = 1; k < used_sets; ++k)               // (set 0's counts, every set's error and limit flags)
         for (uint32_t w : {uint32_t(C2_ERROR), uint32_t(C2_TIE_PAIRTEST_SKIPPED), uint32_t(C2_TIE_SORT_OVERFLOW), uint32_t(C2_TIE_DEPTH)})
             counters[w] |= r->h_counters[k * COUNTER_WORDS + w];
     r->timing = swfr_timing{total_ms, setup_ms, rows_ms, tiles_ms, frames, sc.n_edges, sc.n_paths, sc.n_rows, 0, timed_frames};
@@ -824,9 +826,9 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
     r->fb_valid = true;
     {
         uint32_t slow = 0, huge = 0;
-        for (uint32_t k = 0; k < n_sets; ++k) { slow |= r->h_counters[k * COUNTER_WORDS + C2_SLOW]; huge |= r->h_counters[k * COUNTER_WORDS + C2_HUGE]; }
+        for (uint32_t k = 0; k < used_sets; ++k) { slow |= r->h_counters[k * COUNTER_WORDS + C2_SLOW]; huge |= r->h_counters[k * COUNTER_WORDS + C2_HUGE]; }
         uint32_t passes = 1;
-        for (uint32_t k = 0; k < n_sets; ++k)
+        for (uint32_t k = 0; k < used_sets; ++k)
             for (uint32_t q = 1; q < SLOW_PASSES; ++q) {
                 const uint32_t* c = r->h_counters + k * COUNTER_WORDS;
                 if (c[C2_SLOWQ + q] | c[C2_HUGEQ + q]) { passes = std::max(passes, q + 1); huge |= c[C2_HUGEQ + q]; }
@@ -1012,10 +1014,9 @@ int render_batch(swfr_renderer* r, const swfr_stage* stages, uint32_t n, void* d
             if (rc != SWFR_OK) break;
             swfr_renderer::FrameSet& F = r->fs[k];
             if (k > 0 && i < n_sets) HIP_CHECK(hipStreamSynchronize(r->stream));   // first use of the set: bitmap table etc. are in place
-            HIP_CHECK(hipMemsetAsync(F.d_counters.ptr, 0, COUNTER_WORDS * sizeof(uint32_t), F.stream));
             uint32_t* fb = device_dst ? reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(device_dst) + size_t(i) * frame_stride) : F.d_fb.ptr;
             launch_frame(r, r->scn[k], F, fb, nullptr);
-            HIP_CHECK(hipMemcpyAsync(hc + size_t(i) * COUNTER_WORDS, F.d_counters.ptr, COUNTER_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, F.stream));
+            HIP_CHECK(hipMemcpyAsync(hc + size_t(i) * COUNTER_WORDS, F.counters, COUNTER_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, F.stream));
             r->fb_cur = fb;
         }
         HIP_CHECK(hipGetLastError());
@@ -1074,7 +1075,8 @@ int swfr_create(uint32_t width, uint32_t height, const swfr_config* cfg, swfr_re
         raw->fs[0].stream = raw->stream;
         raw->fs[0].d_fb.reserve(size_t(width) * height);
         HIP_CHECK(hipMemsetAsync(raw->fs[0].d_fb.ptr, 0, size_t(width) * height * 4, raw->stream));
-        raw->fs[0].d_counters.reserve(COUNTER_WORDS);
+        raw->d_counters.reserve(4 * COUNTER_WORDS);
+        raw->fs[0].counters = raw->d_counters.ptr;
         HIP_CHECK(hipStreamSynchronize(raw->stream));
         return int(SWFR_OK);
     });
@@ -1329,9 +1331,9 @@ int swfr_wait(swfr_renderer* r) {
         if (!r->h_counters) HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&r->h_counters), 4 * COUNTER_WORDS * sizeof(uint32_t), hipHostMallocDefault));
         int rc = SWFR_OK;
         for (uint32_t k = 0; k < 4; ++k) {
-            if (!r->fs[k].stream || !r->fs[k].d_counters.ptr) continue;
+            if (!r->fs[k].stream || !r->fs[k].counters) continue;
             if (!(r->async_used >> k & 1u)) { HIP_CHECK(hipStreamSynchronize(r->fs[k].stream)); continue; }
-            HIP_CHECK(hipMemcpyAsync(r->h_counters + k * COUNTER_WORDS, r->fs[k].d_counters.ptr, COUNTER_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, r->fs[k].stream));
+            HIP_CHECK(hipMemcpyAsync(r->h_counters + k * COUNTER_WORDS, r->fs[k].counters, COUNTER_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, r->fs[k].stream));
             HIP_CHECK(hipStreamSynchronize(r->fs[k].stream));
             if (rc == SWFR_OK) rc = check_counters(r, r->h_counters + k * COUNTER_WORDS);
         }
