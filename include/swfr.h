@@ -283,7 +283,7 @@ int  swfr_wait(swfr_renderer *r);
 
 /* Diagnostics (tools/soak_case.py): copies an intermediate buffer of the last rendered frame to the host.
    what = 0: row headers (8 bytes per (band list entry, row of its tile-row): first cell u32, cells u16, mode u16);
-   1: cells (8 bytes each: column i16, covered height i16, uncovered area i32).
+   1: cells (4 bytes each: column relative to the path's x_min << 19 | covered height (5 bits signed) << 14 | uncovered area (14 bits signed)).
    Returns the number of bytes copied (at most `bytes`), or a negative SWFR_ERR_*. */
 long swfr_debug_copy(swfr_renderer *r, int what, void *dst, size_t bytes);
 /* Device pointer of the premultiplied RGBA8 framebuffer (width*height*4 bytes, tight rows). */

@@ -80,8 +80,7 @@ __device__ __forceinline__ bool owns_band(FramePtr FR, int band, uint32_t& local
 __device__ __forceinline__ void put_cell(Cell* __restrict__ dst, int col, int ch, int ua, int xminp, int xmaxp) {
     if (col >= xmaxp) { col = xmaxp - 1; ch = 0; ua = 0; }
     else if (col < xminp) { col = xminp; ua = 0; }
-    Cell c; c.col = (int16_t)col; c.ch = (int16_t)ch; c.ua = ua;
-    *dst = c;
+    *dst = make_cell(col - xminp, ch, ua);
 }
 // number of cell slots a FULL-row edge with end-point quotients q1 (row top), q2 (row bottom) gets
 __device__ __forceinline__ int full_span(int32_t q1, int32_t q2) {
@@ -363,7 +362,7 @@ __global__ __launch_bounds__(1024) void k2_bin_b(const Frame2* __restrict__ fram
 #define R2PHASE(i) do { } while (0)
 #endif
 struct SubStage {
-    uint32_t cells[4][ROWS_FAST_N * 15];   // the cells of the (up to four) SUB rows of one pass, packed: column << 16 | fraction << 1 | closes
+    uint32_t cells[4][ROWS_FAST_N * 15];   // the cells (Cell::w) of the (up to four) SUB rows of one pass
 };
 // (per-row slots of the fast row routine: 7 KB; with the packed staging and the staged edges a k2_rows wavefront needs 12.9 KB of
 //  LDS -- twelve of them fit a CU, as many as its registers allow)
@@ -372,18 +371,12 @@ struct FastLds2 {
     int32_t roles[ROWS_FAST_N][64];
     uint16_t clo[ROWS_FAST_N][64], chi[ROWS_FAST_N][64];   // pixel columns, clamped to [0, 65535]
 };
-// a staged SUB cell: the span end at cell position x (24.8) opens (sgn > 0) or closes a span
+// a SUB cell: the span end at cell position x (24.8) opens (sgn > 0) or closes a span
 __device__ __forceinline__ uint32_t pack_sub_cell(int x, int sgn, int xminp, int xmaxp) {
     int col = x >> 8, f = x & 255, live = 1;
     if (col >= xmaxp) { col = xmaxp - 1; f = 0; live = 0; }
     else if (col < xminp) { col = xminp; f = 0; }
-    return ((uint32_t)col << 16) | ((uint32_t)live << 15) | ((uint32_t)f << 1) | (sgn < 0 ? 1u : 0u);
-}
-__device__ __forceinline__ Cell unpack_sub_cell(uint32_t w) {
-    Cell c;
-    const int sgn = (w & 1u) ? -1 : 1, live = (int)((w >> 15) & 1u);
-    c.col = (int16_t)(w >> 16); c.ch = (int16_t)(sgn * live); c.ua = sgn * 2 * (int)((w >> 1) & 255u);
-    return c;
+    return make_cell(col - xminp, sgn * live, sgn * 2 * f).w;          // (the staged word is the cell itself)
 }
 
 // The fast row routine (rows with at most eight active edges, lane = row).  (1) A row in which two edges on different lines coincide
@@ -655,7 +648,7 @@ __device__ __forceinline__ void rows2_fast(EPTR E, uint32_t n_list, const DevPat
                     const int gg = t < c0 ? 0 : (t < c0 + c1 ? 1 : (t < c0 + c1 + c2 ? 2 : 3));
                     const uint32_t pre = gg == 0 ? 0u : (gg == 1 ? c0 : (gg == 2 ? c0 + c1 : c0 + c1 + c2));
                     const uint32_t bb = gg == 0 ? b0 : (gg == 1 ? b1 : (gg == 2 ? b2 : b3));
-                    FR->cells[bb + (t - pre)] = unpack_sub_cell(S.cells[gg][t - pre]);
+                    FR->cells[bb + (t - pre)] = Cell{S.cells[gg][t - pre]};
                 }
             }
             if (sub == 0 && R >= 0 && riR != ~0u) {          // the first sample lane of each of the pass's rows writes its header
@@ -1738,7 +1731,7 @@ __device__ __forceinline__ void tiles2_body(FramePtr FR) {
 #pragma unroll
                         for (int u = 0; u < T2_PRE; ++u) {
                             const uint32_t g = (uint32_t)(u * 64 + lane);
-                            pre[u].col = 0; pre[u].ch = 0; pre[u].ua = 0; pre_seg[u] = 0;
+                            pre[u].w = 0; pre_seg[u] = 0;
                             if (u * 64 < total) {                          // wave-uniform
                                 int lo = 0, hi = 64;                        // last segment with seg_start <= g
                                 while (lo + 1 < hi) { const int mid = (lo + hi) >> 1; if (seg_start[mid] <= g) lo = mid; else hi = mid; }
@@ -1759,7 +1752,7 @@ __device__ __forceinline__ void tiles2_body(FramePtr FR) {
 #pragma unroll
                             for (int u = 1; u < T2_PRE; ++u) if (gb == u * 64) { c = pre[u]; sg = pre_seg[u]; } }
                         else {
-                            c.col = 0; c.ch = 0; c.ua = 0; sg = 0;
+                            c.w = 0; sg = 0;
                             if (g >= g0 && g < g1) {
                                 int lo = bp * STRIP_H, hi = (bp + 1) * STRIP_H;
                                 while (lo + 1 < hi) { const int mid = (lo + hi) >> 1; if (seg_start[mid] <= (uint32_t)g) lo = mid; else hi = mid; }
@@ -1769,9 +1762,9 @@ __device__ __forceinline__ void tiles2_body(FramePtr FR) {
                         }
                         if (g >= g0 && g < g1) {
                             int* arow = acc[sg % STRIP_H];
-                            const int i = (int)c.col - tx0;
-                            if (i < 0) atomicAdd(&arow[ACC_CARRY], (int)c.ch);
-                            else if (i < TILE_W) atomicAdd(&arow[i], (int)c.ch * (1 << 20) + c.ua);
+                            const int i = cell_col(c) + e_xmin - tx0;         // (columns are stored relative to the path's x_min)
+                            if (i < 0) atomicAdd(&arow[ACC_CARRY], cell_ch(c));
+                            else if (i < TILE_W) atomicAdd(&arow[i], cell_ch(c) * (1 << 20) + cell_ua(c));
                         }
                     }
                     lds_barrier();                                       // acc complete

@@ -546,6 +546,8 @@ void layout_scene(const swfr_renderer* r, const swfr_edge* edges, size_t n_edges
     for (size_t i = 0; i < n_paths; ++i) {
         const swfr_path& p = paths[i];
         L.chunk_base[i] = uint32_t(L.n_chunks); L.slot_base[i] = uint32_t(L.n_slots);
+        if (p.kind == SWFR_PATH_TOR && p.x_max - p.x_min > MAX_PATH_WIDTH)
+            throw StatusError{SWFR_ERR_CAPACITY, "a path wider than 8192 px (cell columns are kept in 13 bits relative to the path)"};
         if (p.kind == SWFR_PATH_TOR && p.y_max > p.y_min) L.n_chunks += (size_t(p.y_max) - size_t(p.y_min) / TILE_H * TILE_H + L.chunk_rows - 1) / L.chunk_rows;
         if (p.y_max > p.y_min && p.x_max > p.x_min) {
             const size_t b0 = size_t(p.y_min / TILE_H), b1 = size_t((p.y_max - 1) / TILE_H);

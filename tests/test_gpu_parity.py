@@ -615,6 +615,24 @@ def test_one_handle_alternating_plain_and_crowded_frames():
             r.close()
 
 
+def test_frames_wider_than_a_cell_column_field():
+    """Cells keep their column in 13 bits relative to the path's left edge: in a frame wider than 8192 px a path may lie anywhere
+    (here: beyond column 9000) and is bit-exact, a single path wider than 8192 px is refused with SWFR_ERR_CAPACITY."""
+    import swf_renderer_amd as S
+    from swf_renderer_amd import api
+    w, h = 9600, 48
+    far = scenarios._poly_shape([(9000 * 20 + 7, 100), (9500 * 20 + 3, 300), (9200 * 20, 900)], {"type": "solid", "color": scenarios._rgba(200, 100, 50, 160)})
+    near = scenarios._poly_shape([(50, 60), (4000, 130), (900, 880)], {"type": "solid", "color": scenarios._rgba(20, 200, 50)})
+    sc = dict(width=w, height=h, stage={"children": [{"type": "shape", "definition": near}, {"type": "shape", "definition": far}]})
+    assert diff_stats(product_render(sc), oracle_render(sc)) == (0, 0)
+    wide = scenarios._poly_shape([(100, 100), (9400 * 20, 200), (9400 * 20, 700), (100, 600), (3000 * 20, 350)], {"type": "solid", "color": scenarios._rgba(1, 2, 3)})
+    r = S.Renderer(w, h)
+    with pytest.raises(S.SwfrError) as e:
+        r.render({"children": [{"type": "shape", "definition": wide}]})
+    assert e.value.code == api.ERR_CAPACITY
+    r.close()
+
+
 def test_many_active_edges_fails_loudly_not_silently():
     import swf_renderer_amd as S
     from swf_renderer_amd import api

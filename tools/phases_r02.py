@@ -7,7 +7,7 @@ os.environ["SWFR_FRAMES_IN_FLIGHT"] = "1"
 import torch
 assert torch.cuda.is_available()
 from swf_renderer_amd import api
-api.library_path = lambda: os.path.join(ROOT, "build", "phases", "libswfr.so")
+api.library_path = lambda: os.path.join(ROOT, "build", os.environ.get("PHASES_BUILD", "phases"), "libswfr.so")
 import swf_renderer_amd as S
 from swf_renderer_amd import synth
 import numpy as np
