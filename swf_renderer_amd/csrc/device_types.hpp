@@ -99,17 +99,21 @@ struct DevGradient {
 // (covered_height / uncovered_area of one pixel column), already clipped to the converter's column range; the cells
 // of one (path, pixel row) are contiguous, RowInfo2 says where.  The tile pass does no edge arithmetic at all.
 // ---------------------------------------------------------------------------------------------------------------------------
-// Packed into one word: column relative to the path's x_min (13 bits: a path is at most 8192 px wide -- the host refuses wider ones),
-// covered height in sample rows (5 bits signed: -15 .. 15 per edge), uncovered area (14 bits signed: |2 * 255 * 15| at most per edge).
+// Packed into one word: column relative to the path's x_min (13 bits: a path is at most 8192 px wide -- the host refuses wider ones)
+// and, in the low 19 bits, V = covered height * 16384 + uncovered area as one signed number (height: -15 .. 15 sample rows per edge,
+// |area| <= 2 * 255 * 15 < 8192, so the area is V's low 14 bits sign-extended and the height what remains).  A producer whose area
+// is a multiple of its height gets V with one multiplication.
 struct Cell {
     uint32_t w;
 };
 static_assert(sizeof(Cell) == 4, "Cell layout");
 constexpr int MAX_PATH_WIDTH = 8192;
-constexpr Cell make_cell(int col_rel, int ch, int ua) { return Cell{((uint32_t)col_rel << 19) | (((uint32_t)ch & 31u) << 14) | ((uint32_t)ua & 0x3fffu)}; }
+constexpr int CELL_H = 16384;                                                 // V = height * CELL_H + area
+constexpr Cell make_cell_v(int col_rel, int v) { return Cell{((uint32_t)col_rel << 19) | ((uint32_t)v & 0x7ffffu)}; }
+constexpr Cell make_cell(int col_rel, int ch, int ua) { return make_cell_v(col_rel, ch * CELL_H + ua); }
 constexpr int cell_col(Cell c) { return (int)(c.w >> 19); }                  // relative to the path's x_min
-constexpr int cell_ch(Cell c) { return (int)(c.w << 13) >> 27; }
 constexpr int cell_ua(Cell c) { return (int)(c.w << 18) >> 18; }
+constexpr int cell_ch(Cell c) { return (((int)(c.w << 13) >> 13) - cell_ua(c)) >> 14; }
 constexpr int MAX_CELLS_PER_EDGE_ROW = 17;   // a FULL-row edge has at most 15 + 2 cells with a non-zero height, a sampled one 15
 
 // per (band entry, pixel row of its tile-row): indexed entry * TILE_H + (y % TILE_H), so a tile finds it from the band list position

@@ -82,6 +82,13 @@ __device__ __forceinline__ void put_cell(Cell* __restrict__ dst, int col, int ch
     else if (col < xminp) { col = xminp; ua = 0; }
     *dst = make_cell(col - xminp, ch, ua);
 }
+// the same for a cell whose area is `area_per_h` times its height: V = h * (CELL_H + area_per_h), one multiplication
+__device__ __forceinline__ void put_cell_h(Cell* __restrict__ dst, int col, int h, int area_per_h, int xminp, int xmaxp) {
+    int v = h * (CELL_H + area_per_h);
+    if (col >= xmaxp) { col = xmaxp - 1; v = 0; }
+    else if (col < xminp) { col = xminp; v = h * CELL_H; }
+    *dst = make_cell_v(col - xminp, v);
+}
 // number of cell slots a FULL-row edge with end-point quotients q1 (row top), q2 (row bottom) gets
 __device__ __forceinline__ int full_span(int32_t q1, int32_t q2) {
     const int a = q1 >> 8, b = q2 >> 8;
@@ -93,7 +100,7 @@ __device__ __forceinline__ int full_span(int32_t q1, int32_t q2) {
 // up to the row's fifteen sample rows): the zero ones are skipped.
 __device__ __forceinline__ void full_cells(int32_t q1, int64_t r1, int32_t q2, int64_t r2, int64_t edy, int sign, int xminp, int xmaxp, Cell* __restrict__ dst) {
     int ix1 = q1 >> 8, f1 = q1 & 255, ix2 = q2 >> 8, f2 = q2 & 255;
-    if (ix1 == ix2) { put_cell(dst, ix1, sign * 15, sign * (f1 + f2) * 15, xminp, xmaxp); return; }
+    if (ix1 == ix2) { put_cell_h(dst, ix1, sign * 15, f1 + f2, xminp, xmaxp); return; }
     if (ix2 < ix1) { int t = ix1; ix1 = ix2; ix2 = t; t = f1; f1 = f2; f2 = t; int32_t tq = q1; q1 = q2; q2 = tq; int64_t tr = r1; r1 = r2; r2 = tr; }
     const int span = ix2 - ix1 + 1;
     const int64_t dx = (int64_t)(q2 - q1) * edy + (r2 - r1);
@@ -103,27 +110,27 @@ __device__ __forceinline__ void full_cells(int32_t q1, int64_t r1, int32_t q2, i
     if (span > 2) floor_div(15ll * 256 * edy, dx, fq, fr);
     int y_prev = (int)yq;
     if (span <= MAX_CELLS_PER_EDGE_ROW) {
-        put_cell(dst, ix1, sign * y_prev, sign * y_prev * (256 + f1), xminp, xmaxp);
+        put_cell_h(dst, ix1, sign * y_prev, 256 + f1, xminp, xmaxp);
 #pragma unroll 1
         for (int k = 1; k < span - 1; ++k) {
             yq += fq; yr += fr; if (yr >= dx) { ++yq; yr -= dx; }
             const int h = (int)yq - y_prev;
-            put_cell(dst + k, ix1 + k, sign * h, sign * h * 256, xminp, xmaxp);
+            put_cell_h(dst + k, ix1 + k, sign * h, 256, xminp, xmaxp);
             y_prev = (int)yq;
         }
-        put_cell(dst + span - 1, ix2, sign * (15 - y_prev), sign * (15 - y_prev) * f2, xminp, xmaxp);
+        put_cell_h(dst + span - 1, ix2, sign * (15 - y_prev), f2, xminp, xmaxp);
         return;
     }
     int n = 0;
-    if (y_prev) put_cell(dst + n++, ix1, sign * y_prev, sign * y_prev * (256 + f1), xminp, xmaxp);
+    if (y_prev) put_cell_h(dst + n++, ix1, sign * y_prev, 256 + f1, xminp, xmaxp);
 #pragma unroll 1
     for (int c = ix1 + 1; c < ix2; ++c) {
         yq += fq; yr += fr; if (yr >= dx) { ++yq; yr -= dx; }
         const int h = (int)yq - y_prev;
-        if (h && n < MAX_CELLS_PER_EDGE_ROW - 1) put_cell(dst + n++, c, sign * h, sign * h * 256, xminp, xmaxp);
+        if (h && n < MAX_CELLS_PER_EDGE_ROW - 1) put_cell_h(dst + n++, c, sign * h, 256, xminp, xmaxp);
         y_prev = (int)yq;
     }
-    if (15 - y_prev) put_cell(dst + n++, ix2, sign * (15 - y_prev), sign * (15 - y_prev) * f2, xminp, xmaxp);
+    if (15 - y_prev) put_cell_h(dst + n++, ix2, sign * (15 - y_prev), f2, xminp, xmaxp);
     while (n < MAX_CELLS_PER_EDGE_ROW) put_cell(dst + n++, xminp, 0, 0, xminp, xmaxp);
 }
 // one end of a sample-row span at cell position x (24.8, already rounded to the sample grid): A.5 add_subspan
