@@ -50,6 +50,9 @@ def test_gloo_world2_frame_pipeline_renders_blocks_and_gathers_in_place():
     if shutil.which("g++") is None:
         import pytest
         pytest.skip("the emulator build needs g++")
+    sys.path.insert(0, os.path.join(ROOT, "tools", "emu"))
+    import build as emu_build
+    emu_build.build()                                          # once, here: the ranks then find it up to date
     procs, outs = _spawn(os.path.join(ROOT, "tools", "emu", "dist_check.py"), 2, 900, ("stroke_curves",))
     assert all(p.returncode == 0 for p in procs), outs
     assert "DIST_OK" in outs[0] and "stroke_curves 3 (0, 0)" in outs[0]

@@ -11,6 +11,15 @@ LIB = os.path.join(HERE, "libswfr_emu.so")
 
 
 def build(sanitize=False, opt="-O1"):
+    """Compiles what is out of date and links; concurrent callers (the ranks of a multi-process test) take turns."""
+    import fcntl
+    os.makedirs(os.path.join(HERE, "obj"), exist_ok=True)
+    with open(os.path.join(HERE, "obj", ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        return _build(sanitize, opt)
+
+
+def _build(sanitize, opt):
     sys.path.insert(0, ROOT)
     from swf_renderer_amd.build import SOURCES
     objs = []
@@ -25,14 +34,17 @@ def build(sanitize=False, opt="-O1"):
     for s in srcs:
         o = os.path.join(HERE, "obj", os.path.basename(s) + ".o")
         objs.append(o)
-        deps = [s] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")] + [os.path.join(HERE, "include", "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "swfr.h")]
+        deps = [s] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".hip"))] + [os.path.join(HERE, "include", "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "swfr.h")]
         if os.path.exists(o) and all(os.path.getmtime(d) < os.path.getmtime(o) for d in deps) and not sanitize:
             continue
         procs.append(subprocess.Popen(["g++", "-x", "c++"] + flags + ["-c", s, "-o", o]))
     for p in procs:
         if p.wait() != 0:
             raise SystemExit("emu build failed")
-    subprocess.check_call(["g++", "-shared", "-o", LIB] + objs + ["-ldl"] + (["-fsanitize=undefined"] if sanitize else []))
+    if procs or not os.path.exists(LIB):
+        tmp = LIB + ".tmp%d" % os.getpid()
+        subprocess.check_call(["g++", "-shared", "-o", tmp] + objs + ["-ldl"] + (["-fsanitize=undefined"] if sanitize else []))
+        os.replace(tmp, LIB)                              # (atomic: a process that has the old library mapped keeps it)
     return LIB
 
 
