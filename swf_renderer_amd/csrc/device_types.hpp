@@ -176,7 +176,8 @@ inline uint32_t strip_slots(uint32_t local_tile_rows, uint32_t strips_per_row) {
 
 struct Frame2 {
     // the scene (read-only)
-    const swfr_edge* raw; const DevPath* paths; const swfr_style* styles;
+    const swfr_edge* raw; const DevPath* paths;
+    const swfr_style* styles;            // style i at byte offset i * style_stride: whole swfr_style records, or -- a scene of solid colours only -- just their first eight bytes {kind, pixel}
     Sources src;
     // layout of the tables below, from the paths' rectangles alone (host: prefix sums over the paths / the tile-rows)
     const uint32_t* path_chunks; const uint32_t* path_slots; const uint32_t* path_inc;   // per path: first chunk, first band slot, first (edge, row) pair
@@ -191,6 +192,7 @@ struct Frame2 {
     uint32_t n_edges, n_paths, n_chunks, n_bands, n_strips, cell_slice, slow_cap;
     int32_t width, height, tiles_x;
     uint32_t fast_limit;     // active edges per row the fast routine of k2_rows keeps (<= 8)
+    uint32_t style_stride;   // bytes between two styles (sizeof(swfr_style) or 8)
     uint32_t cell_main;      // cells [0, cell_main) belong to the chunk wavefronts of k2_rows, the rest to the slow rows' bump allocator
     uint32_t chunk_rows;     // pixel rows per k2_rows wavefront (16, 32 or 64)
     uint32_t chunk_cap;      // capacity of chunks[] (the host sizes it from the paths' rectangles)

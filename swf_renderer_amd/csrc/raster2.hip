@@ -160,11 +160,15 @@ __device__ __forceinline__ uint32_t alloc_cells(FramePtr FR, uint32_t n, int lan
 // The host contributes the LAYOUT of the tables only -- prefix sums over the paths' rectangles (chunks, band slots) and row spans
 // (cells), and over the tile-rows (band list offsets): O(paths) additions, no per-row, per-edge-row or per-tile work.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ BandEntry2 make_band_entry2(const DevPath& P, uint32_t p, uint32_t band, const swfr_style* __restrict__ styles) {
+// style i of the frame (whole records or their {kind, pixel} heads: Frame2::style_stride)
+__device__ __forceinline__ const swfr_style& style_at(FramePtr FR, uint32_t i) {
+    return *reinterpret_cast<const swfr_style*>(reinterpret_cast<const char*>(FR->styles) + (size_t)i * FR->style_stride);
+}
+__device__ __forceinline__ BandEntry2 make_band_entry2(const DevPath& P, uint32_t p, uint32_t band, FramePtr FR) {
     BandEntry2 e;
     e.x_min = (int16_t)P.x_min; e.x_max = (int16_t)P.x_max; e.y_min = (int16_t)P.y_min; e.y_max = (int16_t)P.y_max;
     e.style = P.style; e.first_edge = P.first_edge; e.n_edges = P.n_edges; e.path = p;
-    const uint32_t kind = styles[P.style].kind, pixel = styles[P.style].pixel;
+    const uint32_t kind = style_at(FR, P.style).kind, pixel = style_at(FR, P.style).pixel;
     uint32_t fl = 0;
     if (P.kind == SWFR_PATH_BOXES) fl |= BE_BOXES;
     if (P.lerp) fl |= BE_LERP;
@@ -208,7 +212,7 @@ __device__ __forceinline__ void bin_body(FramePtr F) {
             at += (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
             if (hit && at < n_b) {
                 const uint32_t slot = b0 + at;
-                const BandEntry2 e = make_band_entry2(P, p, (uint32_t)band, F->styles);
+                const BandEntry2 e = make_band_entry2(P, p, (uint32_t)band, F);
                 F->band_list[slot] = e;
                 BandSlot bs; bs.path = p; bs.slot = slot; bs.band = (uint32_t)band; bs.pad = 0;
                 F->band_slots[F->path_slots[p] + (uint32_t)(band - P.y_min / TILE_H)] = bs;
@@ -788,7 +792,7 @@ __device__ __forceinline__ void rows2_chunk_body(FramePtr FR, uint32_t block) {
             n_b = cls_b1 - cls_b0;
             out = FR->cls + (size_t)STRIPS_PER_TILE * FR->tiles_x * cls_b0 + (cls_bs.slot - cls_b0);
         }
-        const swfr_style& st = FR->styles[P.style];
+        const swfr_style& st = style_at(FR, P.style);           // (kind and pixel only)
         const uint32_t opq = (st.kind == SWFR_STYLE_SOLID && P.lerp && (st.pixel >> 24) == 0xffu) ? CLS_OPAQUE : 0u;
         const int tc0 = P.x_min / TILE_W, tc1 = (P.x_max - 1) / TILE_W;
         const int y = r;

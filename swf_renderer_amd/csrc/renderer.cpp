@@ -104,7 +104,7 @@ struct SceneArena {
     // copies `bytes` into the staging buffer and returns the device address they will land at
     void* push(const void* src, size_t bytes) {
         void* d = dev + used;
-        if (bytes) std::memcpy(host + used, src, bytes);
+        if (bytes && src) std::memcpy(host + used, src, bytes);     // (src == nullptr: the caller has written the bytes in place)
         used += padded(bytes);
         return d;
     }
@@ -185,6 +185,8 @@ struct swfr_renderer {
     DevBuf<uint32_t> d_tmp;
     DevBuf<uint32_t> d_counters;            // 4 x COUNTER_WORDS: the frame sets' counters, contiguous
     int in_flight = 3;
+    bool scene_from_builder = false;        // the scene in slot 0 is the frame builder's last frame (its arrays are still there)
+    uint32_t sets_ready = 0;                // frame sets whose descriptors belong to the scene in slot 0 (swfr_render prepares one, swfr_upload_edges all)
     int hint_slow_state = 0; uint32_t hint_slow_passes = SLOW_PASSES;   // what the last rendered scene needed of the queued-row kernels
     uint32_t* fb_cur = nullptr;             // framebuffer of the last completed frame
     std::map<uint32_t, DeviceBitmap> bitmaps;
@@ -581,7 +583,8 @@ void layout_scene(const swfr_renderer* r, const swfr_edge* edges, size_t n_edges
 // bytes of the scene's read-only part in an arena (raw arrays + layout prefixes + sources), each piece padded
 size_t scene_arena_bytes(const SceneLayout& L, size_t n_edges, size_t n_paths, size_t n_styles) {
     auto P = SceneArena::padded;
-    return P(n_edges * sizeof(swfr_edge)) + P(n_paths * sizeof(swfr_path)) + P(n_styles * sizeof(swfr_style)) + P(n_styles * sizeof(DevFilter)) +
+    // (a scene of solid colours only: the styles' {kind, pixel} heads, no filter records)
+    return P(n_edges * sizeof(swfr_edge)) + P(n_paths * sizeof(swfr_path)) + (L.shader_level == 0 ? P(n_styles * 8) : P(n_styles * sizeof(swfr_style)) + P(n_styles * sizeof(DevFilter))) +
            P(L.fparams.size() * sizeof(int32_t)) + P(L.gradients.size() * sizeof(DevGradient)) + 3 * P((n_paths + 1) * sizeof(uint32_t)) +
            P((L.n_bands + 2) * sizeof(uint32_t));
 }
@@ -591,8 +594,19 @@ swfr_edge* push_scene(SceneArena& A, const SceneLayout& L, const swfr_edge* edge
     swfr_edge* staged = reinterpret_cast<swfr_edge*>(A.host + A.used);
     f.raw = static_cast<swfr_edge*>(A.push(edges, n_edges * sizeof(swfr_edge)));
     f.paths = static_cast<DevPath*>(A.push(paths, n_paths * sizeof(swfr_path)));
-    f.styles = static_cast<swfr_style*>(A.push(styles, n_styles * sizeof(swfr_style)));
-    f.src.filters = static_cast<DevFilter*>(A.push(L.filters.data(), n_styles * sizeof(DevFilter)));
+    static_assert(offsetof(swfr_style, kind) == 0 && offsetof(swfr_style, pixel) == 4, "the head of a style is {kind, pixel}");
+    if (L.shader_level == 0) {
+        // solid colours only: the kernels read a style's kind and pixel and nothing else, so only those eight bytes travel
+        uint32_t* heads = reinterpret_cast<uint32_t*>(A.host + A.used);
+        for (size_t i = 0; i < n_styles; ++i) { heads[2 * i] = styles[i].kind; heads[2 * i + 1] = styles[i].pixel; }
+        f.styles = reinterpret_cast<const swfr_style*>(A.push(nullptr, n_styles * 8));
+        f.style_stride = 8;
+        f.src.filters = nullptr;
+    } else {
+        f.styles = static_cast<swfr_style*>(A.push(styles, n_styles * sizeof(swfr_style)));
+        f.style_stride = uint32_t(sizeof(swfr_style));
+        f.src.filters = static_cast<DevFilter*>(A.push(L.filters.data(), n_styles * sizeof(DevFilter)));
+    }
     f.src.fparams = static_cast<int32_t*>(A.push(L.fparams.data(), L.fparams.size() * sizeof(int32_t)));
     f.src.gradients = static_cast<DevGradient*>(A.push(L.gradients.data(), L.gradients.size() * sizeof(DevGradient)));
     f.path_chunks = static_cast<uint32_t*>(A.push(L.chunk_base.data(), (n_paths + 1) * sizeof(uint32_t)));
@@ -689,7 +703,7 @@ int upload2(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, siz
         f.fb = (fb_override && k == si) ? fb_override : (r->n_targets ? r->targets[uint32_t(k) % r->n_targets] : x.d_fb.ptr);
     }
     sc.frames_dev = static_cast<Frame2*>(A.push(fr, sizeof fr));
-    A.flush(up_stream, si == 0 && all_sets);
+    A.flush(up_stream, si == 0);
     if (r->bitmap_table_dirty) {
         if (!r->bitmap_table.empty())
             HIP_CHECK(hipMemcpyAsync(r->d_bitmap_table.ptr, r->bitmap_table.data(), r->bitmap_table.size() * sizeof(DevBitmap),
@@ -698,7 +712,7 @@ int upload2(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, siz
         r->bitmap_table_dirty_copied = true;
     }
     if (r->bitmap_table_dirty_copied) { HIP_CHECK(hipStreamSynchronize(r->stream)); r->bitmap_table_dirty_copied = false; }   // bitmap_table may be edited next
-    if (si == 0) r->scene_ready = true;
+    if (si == 0) { r->scene_ready = true; r->sets_ready = all_sets ? uint32_t(n_sets) : 1u; r->scene_from_builder = edges_tagged; }
     return SWFR_OK;
 }
 
@@ -764,6 +778,12 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
     if (!r->has_device) return fail(r, SWFR_ERR_NO_DEVICE, "host-only handle cannot rasterize");
     if (!r->scene_ready) return fail(r, SWFR_ERR_INVALID, "no scene uploaded");
     if (frames == 0) frames = 1;
+    if (frames > 1 && r->scene_from_builder && r->sets_ready < uint32_t(std::max(1, std::min(r->in_flight, 4)))) {
+        // swfr_render prepared one frame set for its one frame; several frames of the same scene rotate over all of them
+        const auto& e = r->builder->edges(); const auto& p = r->builder->paths(); const auto& st = r->builder->styles();
+        const int rc = upload2(r, 0, true, e.data(), e.size(), p.data(), p.size(), st.data(), st.size(), nullptr, true);
+        if (rc != SWFR_OK) return rc;
+    }
     const swfr_renderer::Scene& sc = r->scn[0];
     float setup_ms = 0, rows_ms = 0, tiles_ms = 0, total_ms = 0;
     uint32_t counters[COUNTER_WORDS] = {};
@@ -771,7 +791,7 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
     // all frames are queued back to back, rotating over the frame sets; events bracket every kernel on the stream the frame runs on
     uint32_t n_sets = 1;
     if (frames > 1)
-        while (n_sets < uint32_t(std::min(r->in_flight, 4)) && r->fs[n_sets].stream && r->fs[n_sets].d_fb.ptr) ++n_sets;
+        while (n_sets < uint32_t(std::min(r->in_flight, 4)) && n_sets < r->sets_ready && r->fs[n_sets].stream && r->fs[n_sets].d_fb.ptr) ++n_sets;
     while (r->ev.size() < size_t(frames) * 4 + 5) {
         hipEvent_t e = nullptr;
         HIP_CHECK(hipEventCreate(&e));
@@ -1075,6 +1095,8 @@ int swfr_create(uint32_t width, uint32_t height, const swfr_config* cfg, swfr_re
     const int rc = guarded(raw, [&]() {
         HIP_CHECK(hipStreamCreateWithFlags(&raw->stream, hipStreamNonBlocking));
         raw->fs[0].stream = raw->stream;
+        // the frame sets' streams first: HIP deals streams onto a few hardware queues in creation order, and the sets must not share one
+        for (int k = 1; k < std::max(1, std::min(raw->in_flight, 4)); ++k) HIP_CHECK(hipStreamCreateWithFlags(&raw->fs[k].stream, hipStreamNonBlocking));
         raw->fs[0].d_fb.reserve(size_t(width) * height);
         HIP_CHECK(hipMemsetAsync(raw->fs[0].d_fb.ptr, 0, size_t(width) * height * 4, raw->stream));
         raw->d_counters.reserve(4 * COUNTER_WORDS);
@@ -1139,6 +1161,7 @@ int swfr_build_frame(swfr_renderer* r, const swfr_stage* stage, const swfr_edge*
                      size_t* n_paths, const swfr_style** styles, size_t* n_styles) {
     if (!r || !stage) return fail(r, SWFR_ERR_INVALID, "null argument");
     return guarded(r, [&]() {
+        r->scene_from_builder = false;                          // (the builder's arrays are about to hold another frame than scene 0)
         r->builder->build(*stage);
         if (edges) *edges = r->builder->edges().data();
         if (n_edges) *n_edges = r->builder->edges().size();
@@ -1181,7 +1204,8 @@ int swfr_render(swfr_renderer* r, const swfr_stage* stage) {
         const auto& p = r->builder->paths();
         const auto& s = r->builder->styles();
         validate_scene(r, e.data(), e.size(), p.data(), p.size(), s.data(), s.size());
-        int rc = upload2(r, 0, true, e.data(), e.size(), p.data(), p.size(), s.data(), s.size(), nullptr, true);   // (the builder's edges carry their path index)
+        // (one frame set: this frame is rendered alone; the builder's edges carry their path index)
+        int rc = upload2(r, 0, false, e.data(), e.size(), p.data(), p.size(), s.data(), s.size(), nullptr, true);
         const auto t2 = clk::now();
         if (rc != SWFR_OK) return rc;
         rc = render_resident(r, 1);
@@ -1305,7 +1329,7 @@ int swfr_render_resident_async(swfr_renderer* r, uint32_t* out_set) {
     if (!r->scene_ready) return fail(r, SWFR_ERR_INVALID, "no scene uploaded");
     return guarded(r, [&]() {
         uint32_t n_sets = 1;
-        while (n_sets < uint32_t(std::min(r->in_flight, 4)) && r->fs[n_sets].stream && r->fs[n_sets].d_cells.ptr) ++n_sets;
+        while (n_sets < uint32_t(std::min(r->in_flight, 4)) && n_sets < r->sets_ready && r->fs[n_sets].stream && r->fs[n_sets].d_cells.ptr) ++n_sets;
         const uint32_t k = r->async_next++ % n_sets;
         r->async_used |= 1u << k;
         swfr_renderer::FrameSet& F = r->fs[k];
