@@ -1,8 +1,10 @@
 // frame_builder.cpp -- see frame_builder.hpp.
 #include "frame_builder.hpp"
 
-#include <functional>
+#include <atomic>
+#include <chrono>
 #include <cstdlib>
+#include <functional>
 
 #include <algorithm>
 #include <cstring>
@@ -63,35 +65,58 @@ struct FrameBuilder::Pool {
     std::vector<std::unique_ptr<FrameBuilder>> builders;       // one builder per piece
     std::mutex m;
     std::condition_variable cv_go, cv_done;
-    uint64_t generation = 0;
-    int n_jobs = 0, pending = 0;
-    bool quit = false;
+    std::atomic<uint64_t> generation{0};
+    std::atomic<int> pending{0};
+    std::atomic<bool> quit{false};
+    int n_jobs = 0;
     std::function<void(int)> task;
+    // Frames arrive a few hundred microseconds apart while an animation is rendered: a worker that has just finished keeps polling for
+    // that long before it blocks (a sleeping core takes longer to wake than a piece takes to build), and the caller polls for the
+    // pieces' completion likewise.
+    static constexpr long SPIN_NS = 400000;
+    static long now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    static void relax() {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#endif
+    }
     void run(int jobs, std::function<void(int)> fn) {           // jobs 1 .. jobs-1 on the pool, job 0 here; returns when all are done
-        {
-            std::lock_guard<std::mutex> lk(m);
-            task = std::move(fn);
-            n_jobs = jobs;
-            pending = jobs - 1;
-            ++generation;
-        }
+        task = std::move(fn);
+        n_jobs = jobs;
+        pending.store(jobs - 1, std::memory_order_relaxed);
+        generation.fetch_add(1, std::memory_order_release);    // (publishes task / n_jobs / pending)
+        { std::lock_guard<std::mutex> lk(m); }                  // a worker between its predicate check and its wait sees the new generation or gets the notification
         cv_go.notify_all();
         task(0);
-        std::unique_lock<std::mutex> lk(m);
-        cv_done.wait(lk, [&] { return pending == 0; });
+        const long t0 = now_ns();
+        while (pending.load(std::memory_order_acquire) != 0) {
+            if (now_ns() - t0 > SPIN_NS) {
+                std::unique_lock<std::mutex> lk(m);
+                cv_done.wait(lk, [&] { return pending.load(std::memory_order_acquire) == 0; });
+                break;
+            }
+            relax();
+        }
     }
     void worker(int index) {
         uint64_t seen = 0;
-        std::unique_lock<std::mutex> lk(m);
         for (;;) {
-            cv_go.wait(lk, [&] { return quit || generation != seen; });
-            if (quit) return;
-            seen = generation;
+            const long t0 = now_ns();
+            uint64_t g;
+            while ((g = generation.load(std::memory_order_acquire)) == seen && !quit.load(std::memory_order_relaxed)) {
+                if (now_ns() - t0 > SPIN_NS) {
+                    std::unique_lock<std::mutex> lk(m);
+                    cv_go.wait(lk, [&] { return quit.load() || generation.load(std::memory_order_acquire) != seen; });
+                } else relax();
+            }
+            if (quit.load()) return;
+            seen = g;
             if (index >= n_jobs) continue;                      // this task has fewer jobs
-            lk.unlock();
             task(index);
-            lk.lock();
-            if (--pending == 0) cv_done.notify_one();
+            if (pending.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+                { std::lock_guard<std::mutex> lk(m); }
+                cv_done.notify_one();
+            }
         }
     }
 };
@@ -100,7 +125,8 @@ FrameBuilder::FrameBuilder(uint32_t width, uint32_t height, bool even_odd) : w_(
 
 FrameBuilder::~FrameBuilder() {
     if (pool_) {
-        { std::lock_guard<std::mutex> lk(pool_->m); pool_->quit = true; }
+        pool_->quit.store(true);
+        { std::lock_guard<std::mutex> lk(pool_->m); }
         pool_->cv_go.notify_all();
         for (auto& t : pool_->threads) t.join();
     }
