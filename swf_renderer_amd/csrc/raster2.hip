@@ -1471,8 +1471,8 @@ __device__ __forceinline__ uint32_t shade_bitmap(uint32_t style_index, const Sou
         long long x = fxp, y = fyp;
         const int xsh = 16 - flt.xbits, ysh = 16 - flt.ybits;
         const long long x_off = (((long long)flt.cw << 16) - 65536) >> 1, y_off = (((long long)flt.ch << 16) - 65536) >> 1;
-        x = ((x >> xsh) << xsh) + ((1 << xsh) >> 1);          // the middle of the closest phase
-        y = ((y >> ysh) << ysh) + ((1 << ysh) >> 1);
+        x = (x & ~((1ll << xsh) - 1)) + ((1 << xsh) >> 1);          // the middle of the closest phase
+        y = (y & ~((1ll << ysh) - 1)) + ((1 << ysh) >> 1);
         const int phx = (int)((x & 0xffff) >> xsh), phy = (int)((y & 0xffff) >> ysh);
         const int32_t* yp = src.fparams + flt.y_off + phy * flt.ch;
         const int32_t* xp0 = src.fparams + flt.x_off + phx * flt.cw;
@@ -1793,13 +1793,13 @@ __device__ __forceinline__ void tiles2_body(FramePtr FR) {
                         uint32_t al[STRIP_H];
 #pragma unroll
                         for (int u = 0; u < STRIP_H; ++u) {
-                            const int ua = (v[u] << 12) >> 12;             // low 20 bits, sign-extended
+                            const int ua = (int)((uint32_t)v[u] << 12) >> 12;   // low 20 bits, sign-extended
                             int ch = (v[u] - ua) >> 20;
                             const int carry_u = __builtin_amdgcn_readlane(carries, u);
                             if (lane == 0) ch += carry_u;
                             const int scan = wave_scan_incl(ch);
                             const int area = scan * 512 - ua;
-                            al[u] = (uint32_t)((((area << 4) + area) + 256) >> 9) & 255u;   // area * 17
+                            al[u] = (uint32_t)((area * 17 + 256) >> 9) & 255u;
                             if (cx < e_xmin || cx >= e_xmax || u < row_lo || u >= row_hi) al[u] = 0;
                         }
                         bool blended = false;

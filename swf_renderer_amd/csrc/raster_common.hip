@@ -500,8 +500,8 @@ __device__ __noinline__ uint32_t shade(const swfr_style& s, uint32_t style_index
         long long x = fxp, y = fyp;
         const int xsh = 16 - flt.xbits, ysh = 16 - flt.ybits;
         const long long x_off = (((long long)flt.cw << 16) - 65536) >> 1, y_off = (((long long)flt.ch << 16) - 65536) >> 1;
-        x = ((x >> xsh) << xsh) + ((1 << xsh) >> 1);          // the middle of the closest phase
-        y = ((y >> ysh) << ysh) + ((1 << ysh) >> 1);
+        x = (x & ~((1ll << xsh) - 1)) + ((1 << xsh) >> 1);          // the middle of the closest phase
+        y = (y & ~((1ll << ysh) - 1)) + ((1 << ysh) >> 1);
         const int phx = (int)((x & 0xffff) >> xsh), phy = (int)((y & 0xffff) >> ysh);
         const int32_t* yp = bitmaps.fparams + flt.y_off + phy * flt.ch;
         const int32_t* xp0 = bitmaps.fparams + flt.x_off + phx * flt.cw;

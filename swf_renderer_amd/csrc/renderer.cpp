@@ -391,7 +391,7 @@ PixmanPosition pixman_transform_of(Affine m, const int rect[4]) {
     }
     // pixman_transform_point_3d of pixel (px, py)'s centre: (p·(X, Y, 1) + 0x8000) >> 16 with X = (px + ox + .5) in 16.16; the
     // per-pixel and per-row steps are whole multiples of 65536 inside the sum, so they come out of the shift exactly
-    const int64_t X0 = (ox << 16) + 0x8000, Y0 = (oy << 16) + 0x8000;
+    const int64_t X0 = ox * 65536 + 0x8000, Y0 = oy * 65536 + 0x8000;
     f.base_x = (p[0][0] * X0 + p[0][1] * Y0 + p[0][2] * 65536 + 0x8000) >> 16;
     f.base_y = (p[1][0] * X0 + p[1][1] * Y0 + p[1][2] * 65536 + 0x8000) >> 16;
     f.m00 = int32_t(p[0][0]); f.m01 = int32_t(p[0][1]); f.m10 = int32_t(p[1][0]); f.m11 = int32_t(p[1][1]);
