@@ -792,23 +792,26 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
     uint32_t n_sets = 1;
     if (frames > 1)
         while (n_sets < uint32_t(std::min(r->in_flight, 4)) && n_sets < r->sets_ready && r->fs[n_sets].stream && r->fs[n_sets].d_fb.ptr) ++n_sets;
-    while (r->ev.size() < size_t(frames) * 4 + 5) {
+    uint32_t stride = r->event_stride < 1 ? 1u : uint32_t(r->event_stride);
+    if (frames < 64) stride = std::min(stride, 8u);        // (a short run still gets two or three frames with per-kernel times)
+    const uint32_t first_timed = std::min(stride / 2, frames - 1);      // (not frame 0: the first frames run before the pipeline is full)
+    const uint32_t n_timed = (frames - first_timed + stride - 1) / stride;
+    // events: four per timed frame (indexed by the timed frame's ordinal), then begin, end and the joins; created once, never inside
+    // a later call's timed region unless it times more frames than any call before
+    while (r->ev.size() < size_t(n_timed) * 4 + 5) {
         hipEvent_t e = nullptr;
         HIP_CHECK(hipEventCreate(&e));
         r->ev.push_back(e);
     }
-    uint32_t stride = r->event_stride < 1 ? 1u : uint32_t(r->event_stride);
-    if (frames < 64) stride = std::min(stride, 8u);        // (a short run still gets two or three frames with per-kernel times)
-    hipEvent_t ev_begin = r->ev[size_t(frames) * 4], ev_end = r->ev[size_t(frames) * 4 + 1];
-    hipEvent_t* ev_join = &r->ev[size_t(frames) * 4 + 2];
+    hipEvent_t ev_begin = r->ev[size_t(n_timed) * 4], ev_end = r->ev[size_t(n_timed) * 4 + 1];
+    hipEvent_t* ev_join = &r->ev[size_t(n_timed) * 4 + 2];
     // (no clearing of the counters here: k2_bin zeroes its frame's counters itself)
     HIP_CHECK(hipEventRecord(ev_begin, r->stream));
     for (uint32_t k = 1; k < n_sets; ++k) HIP_CHECK(hipStreamWaitEvent(r->fs[k].stream, ev_begin, 0));
-    const uint32_t first_timed = std::min(stride / 2, frames - 1);      // (not frame 0: the first frames run before the pipeline is full)
     for (uint32_t f = 0; f < frames; ++f) {
         swfr_renderer::FrameSet& F = r->fs[f % n_sets];
         const bool timed = f >= first_timed && (f - first_timed) % stride == 0;   // per-kernel events on every stride-th frame (each costs a queue packet)
-        launch_frame(r, sc, F, F.d_fb.ptr, timed ? &r->ev[size_t(f) * 4] : nullptr);
+        launch_frame(r, sc, F, F.d_fb.ptr, timed ? &r->ev[size_t((f - first_timed) / stride) * 4] : nullptr);
     }
     for (uint32_t k = 1; k < n_sets; ++k) {
         HIP_CHECK(hipEventRecord(ev_join[k - 1], r->fs[k].stream));
@@ -824,7 +827,7 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
     r->fb_cur = r->fs[(frames - 1) % n_sets].d_fb.ptr;
     uint32_t timed_frames = 0;
     for (uint32_t f = first_timed; f < frames; f += stride, ++timed_frames) {
-        hipEvent_t* e = &r->ev[size_t(f) * 4];
+        hipEvent_t* e = &r->ev[size_t(timed_frames) * 4];
         float a = 0, b = 0, c = 0;
         HIP_CHECK(hipEventElapsedTime(&a, e[0], e[1]));
         HIP_CHECK(hipEventElapsedTime(&b, e[1], e[2]));
@@ -1097,6 +1100,7 @@ int swfr_create(uint32_t width, uint32_t height, const swfr_config* cfg, swfr_re
         raw->fs[0].stream = raw->stream;
         // the frame sets' streams first: HIP deals streams onto a few hardware queues in creation order, and the sets must not share one
         for (int k = 1; k < std::max(1, std::min(raw->in_flight, 4)); ++k) HIP_CHECK(hipStreamCreateWithFlags(&raw->fs[k].stream, hipStreamNonBlocking));
+        for (int i = 0; i < 4 * 32 + 5; ++i) { hipEvent_t e = nullptr; HIP_CHECK(hipEventCreate(&e)); raw->ev.push_back(e); }   // (so that no render call has to create its timing events inside somebody's timed region)
         raw->fs[0].d_fb.reserve(size_t(width) * height);
         HIP_CHECK(hipMemsetAsync(raw->fs[0].d_fb.ptr, 0, size_t(width) * height * 4, raw->stream));
         raw->d_counters.reserve(4 * COUNTER_WORDS);
