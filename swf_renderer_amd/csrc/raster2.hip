@@ -1582,8 +1582,7 @@ __device__ __forceinline__ void tiles2_body(FramePtr FR) {
     const int width = FR->width, height = FR->height, tiles_x = FR->tiles_x;
     const swfr_style* __restrict__ styles = FR->styles;
     const Sources bitmaps = {FR->src.bitmaps, FR->src.filters, FR->src.fparams, FR->src.gradients};
-    for (int i = lane; i < STRIP_H * T2_ACC_STRIDE; i += 64) (&acc[0][0])[i] = 0;
-    lds_barrier();
+    bool acc_clean = false;                                // the accumulators are zeroed before the first partial path needs them (many strips have none)
 
 #ifdef T2_PRIO_SHIFT
     // the launch list is heaviest first: the strips at its head are the kernel's critical path, so their wavefronts take the
@@ -1708,6 +1707,11 @@ __device__ __forceinline__ void tiles2_body(FramePtr FR) {
                     blend_rows<SHADERS>(px, al, eflags, solid, styles, style, bitmaps, cx, ty0);
                 } else if (f & CLS_PARTIAL) {
                     // ---- tor (A.5): the path's cells of this strip's rows
+                    if (!acc_clean) {                                    // (wave-uniform)
+                        for (int i = lane; i < STRIP_H * T2_ACC_STRIDE; i += 64) (&acc[0][0])[i] = 0;
+                        lds_barrier();
+                        acc_clean = true;                               // every path leaves them empty behind itself
+                    }
                     if (batch_i == batch_n) {
                         // the next PBATCH partial tor paths of the list, this one first (lane = list position); their row headers are
                         // in LDS: lane = (path of the batch, row of the strip) forms the flat cell sequence and fetches its first cells
