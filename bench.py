@@ -98,9 +98,11 @@ def latest_traffic():
     """HBM bytes per launch of the tile kernel from the newest committed PMC profile (FETCH_SIZE / WRITE_SIZE passes,
     gfx950 corrections: tools/profile_r02.py), with its source; (None, None) when there is none."""
     import glob
+    import re
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_k_tiles.json"))):
-        best = f
+        if re.fullmatch(r"r\d+[a-z]_pmc_k_tiles\.json", os.path.basename(f)):      # (the S1 profiles, not the shaded-kernel ones)
+            best = f
     if not best:
         return None, None
     try:
