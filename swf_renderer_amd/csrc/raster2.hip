@@ -907,10 +907,12 @@ __device__ __forceinline__ void merge_step(const uint16_t* __restrict__ src, uin
 // one after the other with the merge sort above.
 #define START_MAX 2048                 // edges of one path that may start at one sample row (more: the frame fails loudly)
 __device__ __forceinline__ void rank_tmp(DevEdge* E, int i, int rank) { E[i].pad = rank; }
+#define START_LDS 1024                 // paths with at most this many edges keep their start rows and marks in LDS while they are ranked
 __device__ __forceinline__ void start_ranks_body(FramePtr FR, uint32_t p) {
     __shared__ int sort_cell[START_MAX];
     __shared__ uint16_t sort_a[START_MAX], sort_b[START_MAX];
     __shared__ uint32_t member[START_MAX];
+    __shared__ int yt_l[START_LDS], mark_l[START_LDS];    // first sample row of an edge (INT_MAX: never active); its rank, -1 = member of a group still to be sorted
     __shared__ uint32_t wave_cnt[4];
     __shared__ int next_y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -918,13 +920,20 @@ __device__ __forceinline__ void start_ranks_body(FramePtr FR, uint32_t p) {
     if (P.kind != SWFR_PATH_TOR) return;
     DevEdge* E = FR->edges + P.first_edge;
     const int ne = (int)P.n_edges;
+    const bool staged = ne <= START_LDS;                    // (workgroup-uniform) otherwise every look-up below goes to the edge array
+    auto start_row = [&](int i) { if (staged) return yt_l[i]; const int yt = E[i].ytop; return E[i].ybot > yt ? yt : INT_MAX; };
+    auto mark = [&](int i) { return staged ? mark_l[i] : E[i].pad; };
+    if (staged) {
+        for (int i = tid; i < ne; i += 256) { const int yt = E[i].ytop; yt_l[i] = E[i].ybot > yt ? yt : INT_MAX; }
+        __syncthreads();
+    }
     // edges alone at their sample row keep rank 0, pairs are ordered directly; members of larger groups are marked (-1)
     for (int i = tid; i < ne; i += 256) {
-        const int yt = E[i].ytop;
+        const int yt = start_row(i);
         int cnt = 0, partner = -1;
-        if (E[i].ybot > yt)
+        if (yt != INT_MAX)
             for (int j = 0; j < ne; ++j)
-                if (j != i && E[j].ytop == yt && E[j].ybot > yt) { ++cnt; partner = j; }
+                if (j != i && start_row(j) == yt) { ++cnt; partner = j; }
         int rank = 0;
         if (cnt == 1) {
             const DevEdge a = E[i], b = E[partner];
@@ -934,6 +943,7 @@ __device__ __forceinline__ void start_ranks_body(FramePtr FR, uint32_t p) {
             rank = i < partner ? (ca <= cb ? 0 : 1) : (cb <= ca ? 1 : 0);      // sort_edges on a pair: the first stays first unless its cell is larger
         } else if (cnt > 1) rank = -1;
         rank_tmp(E, i, rank);
+        if (staged) mark_l[i] = rank;
     }
     __syncthreads();
     // the larger groups, in ascending order of their sample row; `done_y`: everything up to it has been handled
@@ -942,8 +952,8 @@ __device__ __forceinline__ void start_ranks_body(FramePtr FR, uint32_t p) {
         if (tid == 0) next_y = INT_MAX;
         __syncthreads();
         for (int i = tid; i < ne; i += 256) {
-            const int yt = E[i].ytop;
-            if (E[i].pad == -1 && yt > done_y) atomicMin(&next_y, yt);
+            const int yt = start_row(i);
+            if (yt != INT_MAX && mark(i) == -1 && yt > done_y) atomicMin(&next_y, yt);
         }
         __syncthreads();
         const int y = next_y;
@@ -953,7 +963,7 @@ __device__ __forceinline__ void start_ranks_body(FramePtr FR, uint32_t p) {
         int n = 0;
         for (int base = 0; base < ne; base += 256) {
             const int i = base + tid;
-            const bool is = i < ne && E[i].ytop == y && E[i].pad == -1;
+            const bool is = i < ne && start_row(i) == y && mark(i) == -1;
             const unsigned long long b = __ballot(is);
             if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(b);
             __syncthreads();
@@ -980,7 +990,7 @@ __device__ __forceinline__ void start_ranks_body(FramePtr FR, uint32_t p) {
             __syncthreads();
             uint16_t* t = src; src = dst; dst = t;
         }
-        for (int q = tid; q < n; q += 256) E[member[src[q]]].pad = q;
+        for (int q = tid; q < n; q += 256) { const uint32_t m = member[src[q]]; E[m].pad = q; if (staged) mark_l[m] = q; }
         __syncthreads();
         done_y = y;
     }
