@@ -50,7 +50,9 @@ enum {
     SWFR_ERR_NOT_FOUND = 3,        /* unknown shape / bitmap id (reference: BitmapNotFound) */
     SWFR_ERR_NO_DEVICE = 4,        /* no HIP device, or a host-only handle was asked to rasterize */
     SWFR_ERR_DEVICE = 5,           /* HIP runtime error */
-    SWFR_ERR_CAPACITY = 6          /* a row exceeds the scan converter's active-edge capacity */
+    SWFR_ERR_CAPACITY = 6          /* a capacity limit of the scan converter: more than 2048 active edges of one path in a pixel row (or
+                                      starting at one sample row), a single path wider than 8192 px, or a limit of the replay of Cairo's
+                                      edge-list order for coincident edges (swfr_get_stats) -- the frame is refused, never approximated */
 };
 
 /* ---- swf-tree value types ---------------------------------------------------------------- */
@@ -216,10 +218,11 @@ int  swfr_build_frame(swfr_renderer *r, const swfr_stage *stage,
 int  swfr_shape_json(swfr_renderer *r, uint32_t id, int morph, const char **json);
 
 /* A batch of different frames in one call (the reference renders its 256 morph ratios by calling render 256 times,
-   ts/src/test/node-canvas-renderer.spec.ts:86-113; rs/src/lib.rs:116-130): frame i is built on the host, uploaded and
-   rasterized on one of SWFR_FRAMES_IN_FLIGHT streams while the host builds frame i+1.  Frame i lands, premultiplied RGBA8
-   with tight rows, at device_dst + i * frame_stride (DEVICE memory, e.g. a torch tensor); with device_dst == NULL only the
-   last frame is kept for swfr_read_image.  Blocking: returns when every frame is finished. */
+   ts/src/test/node-canvas-renderer.spec.ts:86-113; rs/src/lib.rs:116-130).  With a device destination the frames are rendered
+   in groups of up to SWFR_BATCH_FRAMES (default 64) by ONE launch per kernel and group, two groups alternating so that the host
+   builds one while the GPU renders the other; frame i lands, premultiplied RGBA8 with tight rows, at device_dst + i * frame_stride
+   (DEVICE memory, e.g. a torch tensor).  With device_dst == NULL the frames are rendered one after the other and only the last is
+   kept for swfr_read_image.  Blocking: returns when every frame is finished. */
 int  swfr_render_batch(swfr_renderer *r, const swfr_stage *stages, uint32_t n_stages, void *device_dst, size_t frame_stride);
 
 /* Timing of the last swfr_render / swfr_render_resident, from HIP events on the handle's stream. */
