@@ -256,7 +256,7 @@ typedef struct swfr_stats {
     uint64_t tie_rows;                   /* rows whose edge order came from the list-order replay */
     uint64_t pairtest_limit;             /* frames refused: crossing test over more than 2^21 edge pairs */
     uint64_t start_group_limit;          /* frames refused: more than 2048 edges of a path start at one sample row / are active in a row */
-    uint64_t history_limit;              /* frames refused: order of two older coincident edges needs history deeper than one level */
+    uint64_t history_limit;              /* frames refused: order of two older coincident edges needs history deeper than two levels */
     uint64_t reserved;
 } swfr_stats;
 int  swfr_get_stats(swfr_renderer *r, swfr_stats *out);

@@ -796,21 +796,40 @@ __device__ __forceinline__ void rows2_chunk_body(FramePtr FR, uint32_t block) {
         const uint32_t opq = (st.kind == SWFR_STYLE_SOLID && P.lerp && (st.pixel >> 24) == 0xffu) ? CLS_OPAQUE : 0u;
         const int tc0 = P.x_min / TILE_W, tc1 = (P.x_max - 1) / TILE_W;
         const int y = r;
-        const bool in_frame = y < height && band_ok, in_rows = in_frame && in_path;
-        for (int tc = tc0; tc <= tc1; ++tc) {                 // wave-uniform
+        bool in_frame = y < height && band_ok, in_rows = in_frame && in_path;
+        // A chunk of 16 or 32 rows leaves three quarters or half of the wavefront idle here: the idle lanes take copies of the rows'
+        // summaries and the wavefront classifies 4 or 2 tile columns per step (lane = (tile column of the step, row)).
+        const int groups = 64 / chunk_rows, gi = lane / chunk_rows;   // (wave-uniform / this lane's column within a step)
+        bool slow_c = slow, band_ok_c = band_ok;
+        int band_c = band, n_c = n;
+        uint32_t n_b_c = n_b;
+        if (groups > 1) {
+            const int src = lane % chunk_rows;
+            in_frame = __shfl((int)in_frame, src) != 0; in_rows = __shfl((int)in_rows, src) != 0;
+            slow_c = __shfl((int)slow, src) != 0; band_ok_c = __shfl((int)band_ok, src) != 0;
+            band_c = __shfl(band, src); n_c = __shfl(n, src); n_b_c = (uint32_t)__shfl((int)n_b, src);
+            const unsigned long long o = (unsigned long long)(uintptr_t)out;
+            const uint32_t olo = (uint32_t)__shfl((int)(uint32_t)o, src), ohi = (uint32_t)__shfl((int)(uint32_t)(o >> 32), src);
+            out = (uint8_t*)(uintptr_t)(((unsigned long long)ohi << 32) | olo);
+#pragma unroll
+            for (int s2 = 0; s2 < ROWS_FAST_N; ++s2) { roles[s2] = __shfl(roles[s2], src); cols[s2] = __shfl(cols[s2], src); }
+        }
+        for (int tcb = tc0; tcb <= tc1; tcb += groups) {      // wave-uniform
+            const int tc = tcb + gi;
+            const bool tcv = tc <= tc1;
             const int tx0 = tc * TILE_W, tile_x1 = min(tx0 + TILE_W, width);
             uint32_t f = 0;
             bool row_partial = false;                                    // this lane's row has a boundary of the path in this tile
-            if (in_frame) {
+            if (in_frame && tcv) {
                 if (!in_rows) f = CLS_NOTFULL;
-                else if (slow) { f = CLS_PARTIAL | CLS_NOTFULL | CLS_NONEMPTY; row_partial = true; }      // not known yet: the general route is always right
+                else if (slow_c) { f = CLS_PARTIAL | CLS_NOTFULL | CLS_NONEMPTY; row_partial = true; }    // not known yet: the general route is always right
                 else {
                     int carry = 0;
                     bool inter = false;
 #pragma unroll
                     for (int s2 = 0; s2 < ROWS_FAST_N; ++s2) {
                         if (s2 >= nmax) continue;                        // wave-uniform
-                        if (s2 >= n || roles[s2] == 0) continue;
+                        if (s2 >= n_c || roles[s2] == 0) continue;
                         const int clo = (int)((uint32_t)cols[s2] & 0xffffu), chi = (int)((uint32_t)cols[s2] >> 16);
                         if (chi < tx0 && chi < 65535) carry += record_height((uint32_t)roles[s2]);
                         else if (clo >= tx0 + TILE_W && clo < 65535) { /* right of the tile */ }
@@ -832,13 +851,13 @@ __device__ __forceinline__ void rows2_chunk_body(FramePtr FR, uint32_t block) {
             if ((f & (CLS_HOLE | CLS_NONEMPTY)) == (CLS_HOLE | CLS_NONEMPTY)) f |= CLS_PARTIAL;
             f &= ~CLS_HOLE;
             if ((f & (CLS_PARTIAL | CLS_NOTFULL | CLS_NONEMPTY)) == CLS_NONEMPTY) f |= opq;        // a full cover that hides what lies below
-            if ((lane & 7) == 0 && band_ok) out[(size_t)(tc * STRIPS_PER_TILE + ((lane >> 3) & 1)) * n_b] = (uint8_t)f;
+            if ((lane & 7) == 0 && band_ok_c && tcv) out[(size_t)(tc * STRIPS_PER_TILE + ((lane >> 3) & 1)) * n_b_c] = (uint8_t)f;
             // the tile's strips get heavier by the rows of this path with a boundary in the tile (the tile pass starts its heaviest
             // strips first): lanes 0 and 8 of the tile-row's sixteen add their half's rows
             if (FR->strip_order) {
                 const unsigned long long pb = __ballot(row_partial);
                 uint32_t local_trow = 0;
-                if ((lane & 7) == 0 && band_ok && (f & CLS_PARTIAL) && owns_band(FR, band, local_trow)) {
+                if ((lane & 7) == 0 && band_ok_c && tcv && (f & CLS_PARTIAL) && owns_band(FR, band_c, local_trow)) {
                     const uint32_t wgt = (uint32_t)__popcll((pb >> lane) & 0xffull);
                     if (wgt) atomicAdd(&FR->strip_cost[((size_t)local_trow * FR->tiles_x + tc) * STRIPS_PER_TILE + ((lane >> 3) & 1)], wgt);
                 }

@@ -261,9 +261,9 @@ __device__ __forceinline__ bool arrival_order(const PathEdges& PE, const DevEdge
 // analytically (the list is looked at only at the row's first sample row)?  Sampled iff an edge becomes active after the first
 // sample row, an active edge ends before the last, or two edges swap places over the row.  Edges that tie at the row's first
 // sample row swap when the one in front ends up behind: their order is known when at least one of them became active at that
-// sample row (the sort / merge rules above); two older edges are ordered by their own history, one level deep (DEPTH), and
-// taken as not swapping beyond that.  The pair test is skipped
-// when (active edges of the row) x (edges of the path) exceeds 2^21 -- thousands of edges in one row.
+// sample row (the sort / merge rules above); two older edges are ordered by their own history, DEPTH levels deep (two: tied_order);
+// beyond that, and when (active edges of the row) x (edges of the path) exceeds 2^21 -- thousands of edges in one row -- the limit is
+// counted (PathEdges::limit_hit) and the frame refused.
 template <int DEPTH>
 __device__ __forceinline__ bool tied_order_at(const PathEdges& PE, const DevEdge& a, const DevEdge& b, uint32_t ka, uint32_t kb, int s0, bool path_order);
 template <int DEPTH>
@@ -335,9 +335,9 @@ __device__ __forceinline__ bool tied_order_at(const PathEdges& PE, const DevEdge
     if (a.ytop != b.ytop) return arrival_order(PE, a, b, ka, kb);
     return new_order_before(PE, ka, kb, a.ytop, path_order);
 }
-// one level of history behind the history: whether an earlier row was sampled may itself hinge on a tie of two older edges
+// two levels of history behind the history: whether an earlier row was sampled may itself hinge on a tie of two older edges
 __device__ __forceinline__ bool tied_order(const PathEdges& PE, const DevEdge& a, const DevEdge& b, uint32_t ka, uint32_t kb, int s0, bool path_order) {
-    return tied_order_at<1>(PE, a, b, ka, kb, s0, path_order);
+    return tied_order_at<2>(PE, a, b, ka, kb, s0, path_order);
 }
 
 // Rows with more than ROWS_BIG_MAXA (64) and up to ROWS_HUGE_MAXA (2048) active edges of one path (a line of text outlines

@@ -768,7 +768,7 @@ int check_counters(swfr_renderer* r, const uint32_t* counters) {
             return fail(r, SWFR_ERR_CAPACITY, std::string("coincident edges beyond the capacity of the list-order replay (") +
                         (counters[C2_TIE_PAIRTEST_SKIPPED] ? "crossing test over more than 2^21 edge pairs; " : "") +
                         (counters[C2_TIE_SORT_OVERFLOW] ? "more than 16 edges starting at one sample row; " : "") +
-                        (counters[C2_TIE_DEPTH] ? "tie history deeper than one level; " : "") + ")");
+                        (counters[C2_TIE_DEPTH] ? "tie history deeper than two levels; " : "") + ")");
         }
         return SWFR_OK;
     }

@@ -222,7 +222,7 @@ def test_fuzz_radial_gradients_vs_oracle():
 @pytest.mark.parametrize("case", [("radial", 1000, 940), ("mixed", 1000, 445), ("mixed", 1000, 607), ("mixed", 1000, 688), ("bitmap", 1000, 820),
                                   ("mixed", 2000, 755), ("mixed", 2000, 1130), ("mixed", 2000, 1265), ("mixed", 4000, 241), ("mixed", 4000, 1424),
                                   ("mixed", 5000, 507), ("radial", 7000, 670), ("bitmap", 7000, 816), ("mixed", 7000, 101), ("mixed", 7000, 388),
-                                  ("mixed", 8000, 995), ("mixed", 8000, 1018), ("mixed", 23000, 196), ("big", 300, 146), ("big", 300, 9), ("big", 5000, 854), ("long", 300, 171)])
+                                  ("mixed", 8000, 995), ("mixed", 8000, 1018), ("mixed", 23000, 196), ("big", 300, 146), ("big", 300, 9), ("big", 5000, 854), ("long", 300, 171), ("mixed", 777777, 722)])
 def test_soak_regressions_tied_edges(case):
     """Scenes soak runs (tools/soak.py gpu) found: edges whose cells coincide at a pixel row's first sample row.  Their order in
     Cairo's list decides whether the row is converted analytically: two active edges keep the order of the last time the list was
@@ -234,7 +234,9 @@ def test_soak_regressions_tied_edges(case):
     decided with these rules when edges tie at its first sample row and at least one of them is new there (big 300/146: three
     edges of a round join start in one cell and leave it in the opposite order).  The last two are host-side findings of the
     oracle-vs-libcairo soak (tests/test_oracle_vs_cairo.py): the gradient translation fix that is skipped when the centre of the
-    operation leaves 16.16, and a gradient with only transparent stops as a clear source."""
+    operation leaves 16.16, and a gradient with only transparent stops as a clear source.  mixed 777777/722 is the one scene of
+    20 000 that the replay refused while it followed the history of two older coincident edges one level deep only (round 2's soak);
+    it follows two levels now and the scene is exact."""
     from helpers import soak_scene
     sc = soak_scene(*case)
     assert diff_stats(product_render(sc), oracle_render(sc)) == (0, 0), case
