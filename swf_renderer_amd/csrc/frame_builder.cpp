@@ -83,7 +83,9 @@ struct FrameBuilder::Pool {
     void run(int jobs, std::function<void(int)> fn) {           // jobs 1 .. jobs-1 on the pool, job 0 here; returns when all are done
         task = std::move(fn);
         n_jobs = jobs;
-        pending.store(jobs - 1, std::memory_order_relaxed);
+        // every worker takes part in every generation (one without a job only counts itself off): run() cannot return -- and the next
+        // run() cannot rewrite task / n_jobs -- while a worker is still between noticing the generation and reading them
+        pending.store(int(threads.size()), std::memory_order_relaxed);
         generation.fetch_add(1, std::memory_order_release);    // (publishes task / n_jobs / pending)
         { std::lock_guard<std::mutex> lk(m); }                  // a worker between its predicate check and its wait sees the new generation or gets the notification
         cv_go.notify_all();
@@ -111,8 +113,7 @@ struct FrameBuilder::Pool {
             }
             if (quit.load()) return;
             seen = g;
-            if (index >= n_jobs) continue;                      // this task has fewer jobs
-            task(index);
+            if (index < n_jobs) task(index);                    // (a task with fewer jobs: nothing to do but to count off)
             if (pending.fetch_sub(1, std::memory_order_acq_rel) == 1) {
                 { std::lock_guard<std::mutex> lk(m); }
                 cv_done.notify_one();

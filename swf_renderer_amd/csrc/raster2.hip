@@ -49,7 +49,15 @@ typedef const Frame2 __attribute__((address_space(4)))* FramePtr;
 #define FRAME_PTR(frames, i) ((FramePtr)((frames) + (i)))
 #endif
 
-#ifdef SWFR_TRACE                  // -DSWFR_TRACE (diagnostic builds, tools/trace_wg.py): 100 MHz wall-clock stamps per workgroup of the three kernels
+#ifdef SWFR_TSTATS                 // -DSWFR_TSTATS (diagnostic builds, tools/tile_stats.py): per-strip work counts of k2_tiles through the trace buffer
+#define TRACE_WGS 32768
+__device__ uint32_t swfr_trace_buf[3][TRACE_WGS][8];
+#define TRACE_DECL uint32_t tr_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define TRACE(i) do { } while (0)
+#define TRACE_NOWAIT(i) do { } while (0)
+#define STAT(i, x) do { tr_[i] += (uint32_t)(x); } while (0)
+#define TRACE_OUT(k, slot) do { if ((k) == 2 && (threadIdx.x & 63) == 0 && (slot) < TRACE_WGS) { tr_[7] = 1; for (int i_ = 0; i_ < 8; ++i_) swfr_trace_buf[k][slot][i_] = tr_[i_]; for (int i_ = 0; i_ < 8; ++i_) tr_[i_] = 0; } } while (0)
+#elif defined(SWFR_TRACE)         // -DSWFR_TRACE (diagnostic builds, tools/trace_wg.py): 100 MHz wall-clock stamps per workgroup of the three kernels
 #define TRACE_WGS 32768
 __device__ uint32_t swfr_trace_buf[3][TRACE_WGS][8];
 #define TRACE_DECL uint32_t tr_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
@@ -61,6 +69,9 @@ __device__ uint32_t swfr_trace_buf[3][TRACE_WGS][8];
 #define TRACE(i) do { } while (0)
 #define TRACE_NOWAIT(i) do { } while (0)
 #define TRACE_OUT(k, slot) do { } while (0)
+#endif
+#ifndef STAT
+#define STAT(i, x) do { } while (0)
 #endif
 // the handle's share of the frame's tile-rows (multi-GPU): local tile-row l is frame tile-row band_first + l * band_stride
 __device__ __forceinline__ uint32_t local_band_rows(FramePtr FR) { return FR->n_strips / (STRIPS_PER_TILE * (uint32_t)FR->tiles_x); }
@@ -1668,6 +1679,7 @@ __device__ __forceinline__ void tiles2_body(FramePtr FR) {
                 ln += cnt;
             }
             lds_barrier();                                      // sel written by other lanes
+            STAT(0, n_b); STAT(1, ln);
             TRACE(3);                                           // class bytes in
             // ---- occlusion, from the class bytes alone: everything below the last opaque full cover is invisible in this tile
             int start = 0;
@@ -1715,6 +1727,10 @@ __device__ __forceinline__ void tiles2_body(FramePtr FR) {
                 const uint32_t style = (uint32_t)__builtin_amdgcn_readfirstlane((int)ent[li][4]);
                 const int row_lo = max(e_ymin, ty0) - ty0, row_hi = min(min(e_ymax, ty0 + STRIP_H), height) - ty0;
                 if (row_hi <= row_lo) continue;                    // the path misses this strip of the tile
+                STAT(2, 1);
+#ifdef ABL_T_NOPARTIAL
+                if ((f & (CLS_PARTIAL | CLS_BOX)) == CLS_PARTIAL) continue;
+#endif
                 if (f & CLS_BOX) {
                     // ---- rectilinear (A.6): exact area of disjoint boxes, alpha = (c>>8) - (c>>16)
                     const uint32_t e_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)ent[li][5]), e_nedges = (uint32_t)__builtin_amdgcn_readfirstlane((int)ent[li][6]);
@@ -1786,9 +1802,14 @@ __device__ __forceinline__ void tiles2_body(FramePtr FR) {
                         TRACE(5);                                       // (last batch's) first cells in
                     }
                     const int bp = batch_i++;
+                    STAT(3, 1);
                     const int g0 = (int)__builtin_amdgcn_readfirstlane((int)seg_start[bp * STRIP_H]);
                     const int g1 = (int)__builtin_amdgcn_readfirstlane((int)seg_start[(bp + 1) * STRIP_H]);   // this path's cells [g0, g1) of the batch sequence
                     // ---- accumulate: cells left of the tile fold into the row's carry, cells right of it do not matter
+                    STAT(4, g1 - g0);
+#ifdef ABL_T_NOACC
+                    if (g1 < 0)
+#endif
                     for (int gb = g0 & ~63; gb < g1; gb += 64) {           // wave-uniform
                         const int g = gb + lane;
                         Cell c; uint32_t sg;
@@ -1830,7 +1851,11 @@ __device__ __forceinline__ void tiles2_body(FramePtr FR) {
                             int ch = (v[u] - ua) >> 20;
                             const int carry_u = __builtin_amdgcn_readlane(carries, u);
                             if (lane == 0) ch += carry_u;
+#ifdef ABL_T_NOSCAN
+                            const int scan = ch;
+#else
                             const int scan = wave_scan_incl(ch);
+#endif
                             const int area = scan * 512 - ua;
                             al[u] = (uint32_t)((area * 17 + 256) >> 9) & 255u;
                             if (cx < e_xmin || cx >= e_xmax || u < row_lo || u >= row_hi) al[u] = 0;
@@ -1849,6 +1874,11 @@ __device__ __forceinline__ void tiles2_body(FramePtr FR) {
                                 nq += (int)__popcll(pmask[u]);
                                 px[u] = al[u] == 255u ? solid : px[u];
                             }
+                            STAT(5, nq);
+#ifdef ABL_T_NOQUEUE
+                            blended = true;
+                            if (nq < 0)
+#endif
                             if (nq <= BLEND_QUEUE) {                       // wave-uniform; more edge pixels: the per-row path below
                                 uint2* q = reinterpret_cast<uint2*>(&A[0][0]);
 #pragma unroll
@@ -1942,7 +1972,7 @@ void launch2_tiles(hipStream_t st, const Frame2* frames, uint32_t n_frames, uint
 
 }  // namespace swfr
 
-#ifdef SWFR_TRACE
+#if defined(SWFR_TRACE) || defined(SWFR_TSTATS)
 extern "C" __attribute__((visibility("default"))) int swfr_debug_trace(void* dst, size_t bytes) {
     if (hipDeviceSynchronize() != hipSuccess) return -1;
     const size_t n = bytes < sizeof(swfr::swfr_trace_buf) ? bytes : sizeof(swfr::swfr_trace_buf);

@@ -289,6 +289,22 @@ void validate_scene(const swfr_renderer* r, const swfr_edge* edges, size_t n_edg
         if (e.x1 < -lim || e.x1 > lim || e.x2 < -lim || e.x2 > lim || e.y1 < -lim || e.y1 > lim || e.y2 < -lim || e.y2 > lim)
             throw StatusError{SWFR_ERR_INVALID, "edge end point outside +-32768 px"};
     }
+    // every edge belongs to exactly one path: the paths' edge ranges are disjoint and cover the edge list (the kernels and the host
+    // layout index the path table with the edge's owner)
+    {
+        static thread_local std::vector<uint8_t> owned;
+        owned.assign(n_edges, 0);
+        for (size_t i = 0; i < n_paths; ++i) {
+            const swfr_path& p = paths[i];
+            if (size_t(p.first_edge) + p.n_edges > n_edges) throw StatusError{SWFR_ERR_INVALID, "path edge range out of bounds"};
+            for (size_t k = 0; k < p.n_edges; ++k) {
+                if (owned[p.first_edge + k]) throw StatusError{SWFR_ERR_INVALID, "paths share an edge (their edge ranges overlap)"};
+                owned[p.first_edge + k] = 1;
+            }
+        }
+        for (size_t i = 0; i < n_edges; ++i)
+            if (!owned[i]) throw StatusError{SWFR_ERR_INVALID, "an edge belongs to no path"};
+    }
     for (size_t i = 0; i < n_paths; ++i) {
         const swfr_path& p = paths[i];
         if (size_t(p.first_edge) + p.n_edges > n_edges) throw StatusError{SWFR_ERR_INVALID, "path edge range out of bounds"};
@@ -632,6 +648,10 @@ int upload2(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, siz
             const swfr_style* styles, size_t n_styles, uint32_t* fb_override, bool edges_tagged) {
     swfr_renderer::Scene& sc = r->scn[si];
     if (si == 0) r->scene_ready = false;
+    if (r->async_used) {
+        // frames queued by swfr_render_resident_async may still read the scene and the buffers this call rewrites
+        for (int k = 0; k < 4; ++k) if (r->fs[k].stream) HIP_CHECK(hipStreamSynchronize(r->fs[k].stream));
+    }
     // which of the queued-row kernels the frame needs: assumed to be what the previous frame needed (an animation's frames are
     // alike), checked against the frame's own counters afterwards (render_resident renders again with everything if not)
     sc.slow_verified = false;
@@ -681,7 +701,7 @@ int upload2(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, siz
         x.d_cls.reserve(STRIPS_PER_TILE * n_slots * tiles_x + 64);
         // class bytes outside the paths' rectangles are never written by a kernel: cleared once per uploaded scene
         HIP_CHECK(hipMemsetAsync(x.d_cls.ptr, 0, STRIPS_PER_TILE * n_slots * tiles_x + 64, up_stream));
-        if (!x.d_fb.ptr) {
+        if (!x.d_fb.ptr && !r->n_targets) {                                             // (a handle with caller targets never renders into a buffer of its own)
             x.d_fb.reserve(size_t(r->width) * r->height);
             HIP_CHECK(hipMemsetAsync(x.d_fb.ptr, 0, size_t(r->width) * r->height * 4, up_stream));
         }
@@ -704,6 +724,11 @@ int upload2(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, siz
     }
     sc.frames_dev = static_cast<Frame2*>(A.push(fr, sizeof fr));
     A.flush(up_stream, si == 0);
+    if (all_sets) {
+        // the copy and the memsets above ran on set `si`'s stream: the other sets' streams start their frames behind them
+        for (int k = 0; k < n_sets; ++k)
+            if (k != si && r->fs[k].stream) HIP_CHECK(hipStreamWaitEvent(r->fs[k].stream, A.copied, 0));
+    }
     if (r->bitmap_table_dirty) {
         if (!r->bitmap_table.empty())
             HIP_CHECK(hipMemcpyAsync(r->d_bitmap_table.ptr, r->bitmap_table.data(), r->bitmap_table.size() * sizeof(DevBitmap),
@@ -791,7 +816,7 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
     // all frames are queued back to back, rotating over the frame sets; events bracket every kernel on the stream the frame runs on
     uint32_t n_sets = 1;
     if (frames > 1)
-        while (n_sets < uint32_t(std::min(r->in_flight, 4)) && n_sets < r->sets_ready && r->fs[n_sets].stream && r->fs[n_sets].d_fb.ptr) ++n_sets;
+        while (n_sets < uint32_t(std::min(r->in_flight, 4)) && n_sets < r->sets_ready && r->fs[n_sets].stream && (r->n_targets || r->fs[n_sets].d_fb.ptr)) ++n_sets;
     uint32_t stride = r->event_stride < 1 ? 1u : uint32_t(r->event_stride);
     if (frames < 64) stride = std::min(stride, 8u);        // (a short run still gets two or three frames with per-kernel times)
     const uint32_t first_timed = std::min(stride / 2, frames - 1);      // (not frame 0: the first frames run before the pipeline is full)
@@ -824,7 +849,7 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
     const uint32_t used_sets = std::min(frames, n_sets);               // (a set that rendered no frame of this call holds an older frame's counters)
     HIP_CHECK(hipMemcpyAsync(r->h_counters, r->d_counters.ptr, size_t(used_sets) * COUNTER_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
     HIP_CHECK(hipStreamSynchronize(r->stream));
-    r->fb_cur = r->fs[(frames - 1) % n_sets].d_fb.ptr;
+    r->fb_cur = r->n_targets ? r->targets[((frames - 1) % n_sets) % r->n_targets] : r->fs[(frames - 1) % n_sets].d_fb.ptr;
     uint32_t timed_frames = 0;
     for (uint32_t f = first_timed; f < frames; f += stride, ++timed_frames) {
         hipEvent_t* e = &r->ev[size_t(timed_frames) * 4];
@@ -1037,6 +1062,9 @@ int render_batch(swfr_renderer* r, const swfr_stage* stages, uint32_t n, void* d
             validate_scene(r, e.data(), e.size(), p.data(), p.size(), s.data(), s.size());
             rc = upload2(r, k, false, e.data(), e.size(), p.data(), p.size(), s.data(), s.size(), fb_dst, true);   // (the builder's edges carry their path index)
             if (rc != SWFR_OK) break;
+            // nothing renders a frame of a batch again: every frame launches all the queued-row kernels (upload2 seeds set 0 with what
+            // the previous scene needed, a guess only render_resident checks against the frame's counters)
+            r->scn[k].slow_state = 0; r->scn[k].slow_passes = SLOW_PASSES;
             swfr_renderer::FrameSet& F = r->fs[k];
             if (k > 0 && i < n_sets) HIP_CHECK(hipStreamSynchronize(r->stream));   // first use of the set: bitmap table etc. are in place
             uint32_t* fb = device_dst ? reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(device_dst) + size_t(i) * frame_stride) : F.d_fb.ptr;

@@ -20,8 +20,11 @@ int main() {
     tag.initial_styles.n_fill = 1; tag.initial_styles.fill = &fs; tag.n_records = 4; tag.records = rec;
     uint32_t id = 0;
     if (swfr_register_shape(r, &tag, &id) != 0) { std::printf("register: %s\n", swfr_last_error(r)); return 1; }
-    std::vector<swfr_display_object> kids(1000);
+    std::vector<swfr_display_object> kids;
     for (int frame = 0; frame < 300; ++frame) {
+        // the child count -- and with it the number of pieces the pool builds -- changes from frame to frame
+        static const size_t counts[5] = {1000, 130, 400, 70, 1000};
+        kids.resize(counts[frame % 5]);
         for (size_t i = 0; i < kids.size(); ++i) {
             std::memset(&kids[i], 0, sizeof kids[i]);
             kids[i].type = SWFR_OBJECT_SHAPE; kids[i].id = id; kids[i].has_matrix = 1;
@@ -31,7 +34,7 @@ int main() {
         swfr_stage st; std::memset(&st, 0, sizeof st); st.n_children = uint32_t(kids.size()); st.children = kids.data();
         const swfr_edge* e; const swfr_path* p; const swfr_style* s; size_t ne, np, ns;
         if (swfr_build_frame(r, &st, &e, &ne, &p, &np, &s, &ns) != 0) { std::printf("build: %s\n", swfr_last_error(r)); return 1; }
-        if (frame == 0) std::printf("edges %zu paths %zu styles %zu\n", ne, np, ns);
+        if (frame < 5) std::printf("edges %zu paths %zu styles %zu\n", ne, np, ns);
     }
     swfr_destroy(r);
     std::puts("tsan harness done");
