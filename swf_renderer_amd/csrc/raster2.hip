@@ -1557,66 +1557,139 @@ __device__ __forceinline__ uint32_t blend2(uint32_t dst, uint32_t a, uint32_t ef
     return (eflags & BE_LERP) ? s : over_pixel(s, dst);
 }
 
-// the strip's eight rows of one lane blended with coverages al[]: a bilinear bitmap's texel loads are issued for four rows at a time
-// (thirty-two independent loads in flight per wavefront instead of four), everything else row by row
+// ---------------------------------------------------------------------------------------------
+// k2_tiles
+// ---------------------------------------------------------------------------------------------
+// One wavefront per 64x8-pixel strip of the launch list.  Lane layout: lane = 16 * g + cg owns the pixels of columns 4 cg .. 4 cg + 3
+// in the rows g and g + 4 of the strip (slot j = 4 h + i: row g + 4 h, column 4 cg + i), so
+//   * a DPP row (16 lanes) is one pixel row: the prefix sums of FOUR pixel rows are one row_shr sequence (no row broadcasts),
+//   * the accumulators of a lane's four columns are one 16-byte LDS read, its four pixels of a row one 16-byte store.
+// Dependent memory round trips per strip: strip descriptor -> class bytes -> {band entries, row headers} -> cells -> stores.
+#define T3_LIST 16                     // non-empty band entries of a strip staged per round (painter's order)
+#define T3_ACC_STRIDE 68               // ints per accumulator row: 64 columns, padded so that every row starts 16-byte aligned
+#define T3_UNITS 32                    // units (a lane's four pixels of a row) of one (path, strip) blended in compacted form per round
+#define T3_CLS_PRE 2                   // x 64 class bytes of a strip fetched up front
+
+// 24-bit multiplies (v_mul_u32_u24 / v_mad_u32_u24 issue at full rate, v_mul_lo_u32 at a quarter): two 8-bit channels in the
+// 0x00ff00ff layout times an 8-bit factor fit
+__device__ __forceinline__ uint32_t mul8x2_7f_24(uint32_t a, uint32_t b) {
+    uint32_t t = __umul24(a & 0xff00ffu, b) + 0x7f007fu;
+    return ((t + ((t >> 8) & 0xff00ffu)) >> 8) & 0xff00ffu;
+}
+__device__ __forceinline__ uint32_t mul_un8_24(uint32_t x, uint32_t a) {
+    uint32_t rb = __umul24(x & 0xff00ffu, a) + 0x800080u;
+    rb = ((rb + ((rb >> 8) & 0xff00ffu)) >> 8) & 0xff00ffu;
+    uint32_t ag = __umul24((x >> 8) & 0xff00ffu, a) + 0x800080u;
+    ag = ((ag + ((ag >> 8) & 0xff00ffu)) >> 8) & 0xff00ffu;
+    return rb | (ag << 8);
+}
+// what the compacted blend does with a queued pixel of a solid-colour path: Cairo's SOURCE lerp (0x7f rounding: lerp_pixel) or
+// pixman's OVER (0x80 rounding: over_pixel of the colour times the coverage); coverage 0 keeps the pixel
+__device__ __forceinline__ uint32_t solid_blend(uint32_t solid, uint32_t a, uint32_t dst, bool lerp) {
+    uint32_t out;
+    if (lerp) {
+        const uint32_t ia = 255u - a;
+        out = (mul8x2_7f_24(solid, a) + mul8x2_7f_24(dst, ia)) | ((mul8x2_7f_24(solid >> 8, a) + mul8x2_7f_24(dst >> 8, ia)) << 8);
+    } else {
+        const uint32_t sc = a == 255u ? solid : mul_un8_24(solid, a);
+        const uint32_t m = mul_un8_24(dst, 255u - (sc >> 24));
+        out = add8x2_sat(m & 0xff00ffu, sc & 0xff00ffu) | (add8x2_sat((m >> 8) & 0xff00ffu, (sc >> 8) & 0xff00ffu) << 8);
+    }
+    return a == 0u ? dst : out;
+}
+
+// The strip's eight pixels of one lane blended with coverages al[] (slot j: pixel (cx0 + (j & 3), cy0 + 4 * (j >> 2))).
+// Solid colours: coverage 255 of an opaque colour is a select, coverage 0 keeps the pixel, and the pixels that need the rounded
+// products -- the few on an edge -- are compacted through LDS and blended with lanes = queued pixels: the unit of the compaction
+// is a lane's four pixels of one row (two 16-byte LDS writes per unit that has an edge pixel, one ballot + mbcnt per row half).
+// Bitmaps: the texel loads of a lane's four pixels of a row are issued together.  Gradients: pixel by pixel (f64, a call).
 template <int SHADERS>
-__device__ __forceinline__ void blend_rows(uint32_t (&px)[STRIP_H], const uint32_t (&al)[STRIP_H], uint32_t eflags, uint32_t solid,
-                                           const swfr_style* __restrict__ styles, uint32_t style, const Sources& src, int cx, int ty0) {
+__device__ __forceinline__ void blend8(uint32_t (&px)[8], const uint32_t (&al)[8], uint32_t eflags, uint32_t solid, const swfr_style* __restrict__ styles,
+                                       uint32_t style, const Sources& src, int cx0, int cy0, uint32_t* __restrict__ bq, int lane) {
     if (SHADERS == 0 || (eflags & BE_SOLID)) {
+        const bool lerp = (eflags & BE_LERP) != 0;
+        const bool sel255 = lerp || (solid >> 24) == 0xffu;       // coverage 255 puts the colour itself (wave-uniform)
+        bool need[2];
 #pragma unroll
-        for (int u = 0; u < STRIP_H; ++u) { const uint32_t b = blend2<0>(px[u], al[u], eflags, solid, styles, style, src, cx, ty0 + u); px[u] = al[u] ? b : px[u]; }
+        for (int h = 0; h < 2; ++h) {
+            // some pixel of the unit has a coverage in 1..254 (1..255 when the colour is translucent): al - 1 wraps 0 to the top
+            const uint32_t t0 = al[4 * h] - 1u, t1 = al[4 * h + 1] - 1u, t2 = al[4 * h + 2] - 1u, t3 = al[4 * h + 3] - 1u;
+            need[h] = min(min(t0, t1), min(t2, t3)) < (sel255 ? 254u : 255u);
+        }
+        if (sel255) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) px[j] = al[j] == 255u ? solid : px[j];
+        }
+        const unsigned long long m0 = __ballot(need[0]), m1 = __ballot(need[1]);
+        if ((m0 | m1) == 0ull) return;                           // wave-uniform: no edge pixel in this strip
+        const int n0 = (int)__popcll(m0), nu = n0 + (int)__popcll(m1);          // units queued
+        // queue: unit u holds {coverage[4]} at bq[8 u .. 8 u + 3] and {pixel[4]} at bq[8 u + 4 .. 8 u + 7]
+        const int u0 = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u));
+        const int u1 = n0 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
+        for (int ub = 0; ub < nu; ub += T3_UNITS) {                // wave-uniform; one round unless more than T3_UNITS units have an edge pixel
+            if (need[0] && u0 >= ub && u0 < ub + T3_UNITS) {
+                uint4* q = reinterpret_cast<uint4*>(bq + 8 * (u0 - ub));
+                q[0] = make_uint4(al[0], al[1], al[2], al[3]); q[1] = make_uint4(px[0], px[1], px[2], px[3]);
+            }
+            if (need[1] && u1 >= ub && u1 < ub + T3_UNITS) {
+                uint4* q = reinterpret_cast<uint4*>(bq + 8 * (u1 - ub));
+                q[0] = make_uint4(al[4], al[5], al[6], al[7]); q[1] = make_uint4(px[4], px[5], px[6], px[7]);
+            }
+            lds_barrier();
+            const int ne = 4 * min(nu - ub, T3_UNITS);             // queued pixels of this round
+            for (int b = lane; b < ne; b += 64) {
+                uint32_t* e = bq + 8 * (b >> 2) + (b & 3);
+                e[4] = solid_blend(solid, e[0], e[4], lerp);
+            }
+            lds_barrier();
+            if (need[0] && u0 >= ub && u0 < ub + T3_UNITS) {
+                const uint4 r = reinterpret_cast<const uint4*>(bq + 8 * (u0 - ub))[1];
+                px[0] = r.x; px[1] = r.y; px[2] = r.z; px[3] = r.w;
+            }
+            if (need[1] && u1 >= ub && u1 < ub + T3_UNITS) {
+                const uint4 r = reinterpret_cast<const uint4*>(bq + 8 * (u1 - ub))[1];
+                px[4] = r.x; px[5] = r.y; px[6] = r.z; px[7] = r.w;
+            }
+            lds_barrier();                                        // (the queue is rewritten by the next round / the next path)
+        }
         return;
     }
     const DevFilter& flt = src.filters[style];
     if (flt.kind == SWFR_STYLE_BITMAP && !flt.on) {
 #pragma unroll
-        for (int r4 = 0; r4 < STRIP_H; r4 += 4) {
-            if (!(__ballot((al[r4] | al[r4 + 1] | al[r4 + 2] | al[r4 + 3]) != 0u))) continue;       // wave-uniform: nothing to paint in these rows
+        for (int h = 0; h < 2; ++h) {
+            if (!(__ballot((al[4 * h] | al[4 * h + 1] | al[4 * h + 2] | al[4 * h + 3]) != 0u))) continue;       // wave-uniform: nothing to paint in these rows
             BilinearTap t[4];
             uint32_t c[4][4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) bilinear_taps(flt, cx, ty0 + r4 + u, t[u]);
+            for (int i = 0; i < 4; ++i) bilinear_taps(flt, cx0 + i, cy0 + 4 * h, t[i]);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { c[u][0] = *t[u].p[0][0]; c[u][1] = *t[u].p[1][0]; c[u][2] = *t[u].p[0][1]; c[u][3] = *t[u].p[1][1]; }
+            for (int i = 0; i < 4; ++i) { c[i][0] = *t[i].p[0][0]; c[i][1] = *t[i].p[1][0]; c[i][2] = *t[i].p[0][1]; c[i][3] = *t[i].p[1][1]; }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t col = bilinear_mix(t[u], &c[u][0], &c[u][1], &c[u][2], &c[u][3]);
-                const uint32_t sc = mul_un8(col, al[r4 + u]);
-                const uint32_t b = (eflags & BE_LERP) ? sc : over_pixel(sc, px[r4 + u]);
-                px[r4 + u] = al[r4 + u] ? b : px[r4 + u];
+            for (int i = 0; i < 4; ++i) {
+                const int j = 4 * h + i;
+                const uint32_t col = bilinear_mix(t[i], &c[i][0], &c[i][1], &c[i][2], &c[i][3]);
+                const uint32_t sc = mul_un8(col, al[j]);
+                const uint32_t b = (eflags & BE_LERP) ? sc : over_pixel(sc, px[j]);
+                px[j] = al[j] ? b : px[j];
             }
         }
         return;
     }
 #pragma unroll
-    for (int u = 0; u < STRIP_H; ++u) if (al[u]) px[u] = blend2<SHADERS>(px[u], al[u], eflags, solid, styles, style, src, cx, ty0 + u);
+    for (int j = 0; j < 8; ++j) if (al[j]) px[j] = blend2<SHADERS>(px[j], al[j], eflags, solid, styles, style, src, cx0 + (j & 3), cy0 + 4 * (j >> 2));
 }
 
-// ---------------------------------------------------------------------------------------------
-// k2_tiles
-// ---------------------------------------------------------------------------------------------
-#define T2_LIST 32                     // band entries of a tile kept per round (lane = list position; lanes 32.. fetch the row headers)
-#define T2_PRE 1                       // rounds of 64 cells of a batch fetched ahead into registers
-#ifndef CLS_PRE
-#define CLS_PRE 3                      // x 64 class bytes of a tile fetched at once
-#endif
-#ifndef T2_ACC_STRIDE
-#define T2_ACC_STRIDE 65               // 64 cells + the carry slot (65 rather than 66: 28 wavefronts' LDS fit a CU)
-#endif
-
-// One wavefront per strip of the launch list (heaviest first when the scene has an order); lane = pixel column; the strip's eight
-// rows of pixels live in registers until the single store.  Dependent memory round trips per strip: strip descriptor -> class
-// bytes -> {band entries, row headers} -> cells.
 template <int SHADERS>
-__device__ __forceinline__ void tiles2_body(FramePtr FR) {
-    __shared__ __attribute__((aligned(16))) int acc[STRIP_H][T2_ACC_STRIDE];   // also the queue of the compacted blend (8-byte pairs)
-    __shared__ __attribute__((aligned(16))) uint32_t ent[T2_LIST][8];       // BandEntry2 as dwords
-    __shared__ __attribute__((aligned(16))) uint32_t rinfo[T2_LIST][2 * STRIP_H];   // the strip's eight RowInfo2 of a tor entry
-    __shared__ uint32_t sel[T2_LIST];                                       // list position -> band list index | class << 24
-    __shared__ uint32_t seg_off[64], seg_start[64 + 1];                     // per (batch path, strip row): first cell, exclusive prefix of counts
-    __shared__ int plist[PBATCH];
+__device__ __forceinline__ void tiles3_body(FramePtr FR) {
+    __shared__ __attribute__((aligned(16))) int acc[STRIP_H][T3_ACC_STRIDE];     // per pixel: covered height << 20 | uncovered area (20 bits, signed)
+    __shared__ __attribute__((aligned(16))) uint32_t ent[T3_LIST][12];         // BandEntry2 as dwords, [8] = its class byte for this strip
+    __shared__ __attribute__((aligned(16))) uint32_t hdr[T3_LIST][2 * STRIP_H]; // the strip's eight RowInfo2 of a partial tor entry
+    __shared__ __attribute__((aligned(16))) uint32_t bq[8 * T3_UNITS];         // the compacted blend's queue: per unit {coverage[4], pixel[4]}
 
     const int lane = threadIdx.x;
+    const int g = lane >> 4, cg = lane & 15;                   // pixel rows g, g + 4; columns 4 cg .. 4 cg + 3
+    const int cr = lane >> 3, ck = lane & 7;                   // cell fetch: lane = (row of the strip, k-th cell of the row)
     TRACE_DECL;
     TRACE_NOWAIT(0);
     const int width = FR->width, height = FR->height, tiles_x = FR->tiles_x;
@@ -1624,11 +1697,6 @@ __device__ __forceinline__ void tiles2_body(FramePtr FR) {
     const Sources bitmaps = {FR->src.bitmaps, FR->src.filters, FR->src.fparams, FR->src.gradients};
     bool acc_clean = false;                                // the accumulators are zeroed before the first partial path needs them (many strips have none)
 
-#ifdef T2_PRIO_SHIFT
-    // the launch list is heaviest first: the strips at its head are the kernel's critical path, so their wavefronts take the
-    // issue slots ahead of the light ones they share a SIMD with
-    if (FR->strip_order && blockIdx.x < (FR->n_strip_slots >> T2_PRIO_SHIFT)) __builtin_amdgcn_s_setprio(3);
-#endif
     for (uint32_t w = blockIdx.x; w < FR->n_strip_slots; w += gridDim.x) {
         TRACE(1);                                                        // descriptor fields in
         const StripDesc sd = FR->strips[w];
@@ -1641,291 +1709,230 @@ __device__ __forceinline__ void tiles2_body(FramePtr FR) {
         trow = (int)FR->band_first + trow * (int)FR->band_stride;
         const int tx0 = tcol * TILE_W, ty0 = trow * TILE_H + strip * STRIP_H;
         if (ty0 >= height) continue;
-        const int cx = tx0 + lane;
-        uint32_t px[STRIP_H];
+        const int cx0 = tx0 + 4 * cg, cy0 = ty0 + g;
+        uint32_t px[8];
 #pragma unroll
-        for (int rr = 0; rr < STRIP_H; ++rr) px[rr] = 0u;
+        for (int j = 0; j < 8; ++j) px[j] = 0u;
 
         const uint32_t band_begin = sd.band_begin, n_b = sd.n_b;
         const uint8_t* mycls = FR->cls + (size_t)STRIPS_PER_TILE * tiles_x * band_begin + (size_t)(tcol * STRIPS_PER_TILE + strip) * n_b;   // this strip's class byte per band entry
-        // the tile's first CLS_PRE x 64 class bytes in one round trip (the rounds of the loop below would fetch them one after the other,
-        // each waiting for its own load)
-        uint32_t cpre[CLS_PRE];
+        uint32_t cpre[T3_CLS_PRE];
 #pragma unroll
-        for (int u = 0; u < CLS_PRE; ++u) cpre[u] = (uint32_t)(u * 64 + lane) < n_b ? (uint32_t)mycls[u * 64 + lane] : 0u;
-        uint32_t next = 0;
-        while (next < n_b) {
-            // ---- bin: band entries with a non-empty class for this tile, painter's order kept (wave-local compaction)
-            int ln = 0;
-            while (next < n_b && ln < T2_LIST) {
-                const uint32_t bi = next + lane;
-                uint32_t f;
-                if ((next & 63u) == 0u && next < 64u * CLS_PRE) {          // wave-uniform
-                    f = cpre[0];
+        for (int u = 0; u < T3_CLS_PRE; ++u) cpre[u] = (uint32_t)(u * 64 + lane) < n_b ? (uint32_t)mycls[u * 64 + lane] : 0u;
+        auto cls_chunk = [&](uint32_t c0) -> uint32_t {               // the class bytes of entries c0 .. c0 + 63 (c0 a multiple of 64, wave-uniform)
+            if (c0 < 64u * T3_CLS_PRE) {
+                uint32_t f = cpre[0];
 #pragma unroll
-                    for (int u = 1; u < CLS_PRE; ++u) if (next == 64u * (uint32_t)u) f = cpre[u];
-                } else f = bi < n_b ? (uint32_t)mycls[bi] : 0u;
-                bool hit = (f & CLS_NONEMPTY) != 0;
-                unsigned long long b = __ballot(hit);
-                const int room = T2_LIST - ln;
-                int cnt = __popcll(b);
-                if (cnt > room) {                                 // keep the first `room` hits, rescan the rest next round
-                    int keep = room; unsigned long long m = b, kept = 0ull; uint32_t last = 0;
-                    while (keep--) { const int bit = __ffsll((long long)m) - 1; kept |= 1ull << bit; m &= m - 1; last = (uint32_t)bit; }
-                    b = kept; hit = hit && ((kept >> lane) & 1ull); cnt = room;
-                    next += last + 1;
-                } else next += 64;
-                if (hit) sel[ln + __popcll(b & ((1ull << lane) - 1ull))] = bi | (f << 24);
-                ln += cnt;
+                for (int u = 1; u < T3_CLS_PRE; ++u) if (c0 == 64u * (uint32_t)u) f = cpre[u];
+                return f;
             }
-            lds_barrier();                                      // sel written by other lanes
-            STAT(0, n_b); STAT(1, ln);
-            TRACE(3);                                           // class bytes in
-            // ---- occlusion, from the class bytes alone: everything below the last opaque full cover is invisible in this tile
-            int start = 0;
-            {
-                const uint32_t f = lane < ln ? sel[lane] >> 24 : 0u;
-                const unsigned long long b = __ballot((f & (CLS_PARTIAL | CLS_NOTFULL | CLS_BOX | CLS_OPAQUE)) == CLS_OPAQUE);
-                if (b) start = 63 - __clzll((long long)b);
-            }
-            // ---- the surviving entries (lanes 0..31: 32 bytes as two 16-byte loads) and, for the partial tor paths among them, the
-            //      headers of this strip's eight rows (lanes 32..63: 64 bytes) -- both addressed by the band list position alone
-            {
-                int li = lane & (T2_LIST - 1);
-                SWFR_OPAQUE(li);                                  // (the LDS addresses below are formed here, not carried from the prologue in spilled registers)
-                if (li >= start && li < ln) {
-                    const uint32_t sv = sel[li];
-                    const uint32_t bidx = band_begin + (sv & 0xffffffu);
-                    if (lane < T2_LIST) {
-                        const uint4* src = reinterpret_cast<const uint4*>(&FR->band_list[bidx]);
-                        const uint4 q0 = src[0], q1 = src[1];
-                        *reinterpret_cast<uint4*>(&ent[li][0]) = q0;
-                        *reinterpret_cast<uint4*>(&ent[li][4]) = q1;
-                    } else if (((sv >> 24) & (CLS_PARTIAL | CLS_BOX)) == CLS_PARTIAL) {
-                        const uint4* src = reinterpret_cast<const uint4*>(&FR->rows[(size_t)bidx * TILE_H + (uint32_t)(strip * STRIP_H)]);
-                        const uint4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
-                        uint4* dst = reinterpret_cast<uint4*>(&rinfo[li][0]);
-                        dst[0] = q0; dst[1] = q1; dst[2] = q2; dst[3] = q3;
+            return c0 + lane < n_b ? (uint32_t)mycls[c0 + lane] : 0u;
+        };
+        // ---- occlusion, from the class bytes alone: everything below the last opaque full cover is invisible in this strip
+        uint32_t start = 0;
+        for (uint32_t c0 = (n_b + 63u) & ~63u; c0 != 0u;) {              // chunks from the top of the painter's order down
+            c0 -= 64u;
+            const uint32_t f = cls_chunk(c0);
+            const unsigned long long b = __ballot((f & (CLS_PARTIAL | CLS_NOTFULL | CLS_BOX | CLS_OPAQUE)) == CLS_OPAQUE);
+            if (b) { start = c0 + 63u - (uint32_t)__clzll((long long)b); break; }
+        }
+        TRACE(3);                                                        // class bytes in
+        for (uint32_t c0 = start & ~63u; c0 < n_b; c0 += 64u) {
+            const uint32_t f = cls_chunk(c0);
+            const uint32_t bi = c0 + (uint32_t)lane;
+            const bool hit = (f & CLS_NONEMPTY) != 0u && bi >= start;
+            unsigned long long todo = __ballot(hit);
+            STAT(0, n_b); STAT(1, __popcll(todo));
+            while (todo) {                                               // wave-uniform
+                // ---- stage the next T3_LIST non-empty entries (the lane that holds an entry's class byte fetches the entry -- two
+                //      16-byte loads -- and, for a partial tor path, the headers of this strip's eight rows -- four more)
+                const int rank = (int)__popcll(todo & ((1ull << lane) - 1ull));
+                const bool take = ((todo >> lane) & 1ull) != 0ull && rank < T3_LIST;
+                const unsigned long long taken = __ballot(take);
+                const int n_st = (int)__popcll(taken);
+                todo &= ~taken;
+                if (take) {
+                    const uint32_t bidx = band_begin + bi;
+                    const uint4* s4 = reinterpret_cast<const uint4*>(&FR->band_list[bidx]);
+                    const uint4 q0 = s4[0], q1 = s4[1];
+                    uint4 h0 = make_uint4(0u, 0u, 0u, 0u), h1 = h0, h2 = h0, h3 = h0;
+                    const bool part = (f & (CLS_PARTIAL | CLS_BOX)) == CLS_PARTIAL;
+                    if (part) {
+                        const uint4* r4 = reinterpret_cast<const uint4*>(&FR->rows[(size_t)bidx * TILE_H + (uint32_t)(strip * STRIP_H)]);
+                        h0 = r4[0]; h1 = r4[1]; h2 = r4[2]; h3 = r4[3];
                     }
+                    uint4* e4 = reinterpret_cast<uint4*>(&ent[rank][0]);
+                    e4[0] = q0; e4[1] = q1; ent[rank][8] = f;
+                    if (part) { uint4* d4 = reinterpret_cast<uint4*>(&hdr[rank][0]); d4[0] = h0; d4[1] = h1; d4[2] = h2; d4[3] = h3; }
                 }
-            }
-            lds_barrier();
-            TRACE(4);                                           // entries + row headers in
-
-            // ---- painter's order walk
-            int batch_n = 0, batch_i = 0;
-            int total = 0;
-            Cell pre[T2_PRE];                                     // cells lane, lane + 64 of the batch's flat sequence
-            uint32_t pre_seg[T2_PRE];                             // ... and the (path, row) segment each belongs to
-            for (int li = start; li < ln; ++li) {
-                // per-entry fields are wave-uniform: readfirstlane moves them (and everything computed from them) to the scalar unit
-                const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)sel[li]) >> 24;
-                const uint32_t xw = (uint32_t)__builtin_amdgcn_readfirstlane((int)ent[li][0]), yw = (uint32_t)__builtin_amdgcn_readfirstlane((int)ent[li][1]);
-                const int e_xmin = (int)(int16_t)(xw & 0xffffu), e_xmax = (int)(int16_t)(xw >> 16);
-                const int e_ymin = (int)(int16_t)(yw & 0xffffu), e_ymax = (int)(int16_t)(yw >> 16);
-                const uint32_t eflags = (uint32_t)__builtin_amdgcn_readfirstlane((int)ent[li][2]), solid = (uint32_t)__builtin_amdgcn_readfirstlane((int)ent[li][3]);
-                const uint32_t style = (uint32_t)__builtin_amdgcn_readfirstlane((int)ent[li][4]);
-                const int row_lo = max(e_ymin, ty0) - ty0, row_hi = min(min(e_ymax, ty0 + STRIP_H), height) - ty0;
-                if (row_hi <= row_lo) continue;                    // the path misses this strip of the tile
-                STAT(2, 1);
-#ifdef ABL_T_NOPARTIAL
-                if ((f & (CLS_PARTIAL | CLS_BOX)) == CLS_PARTIAL) continue;
+                lds_barrier();
+                TRACE(4);                                               // entries + row headers in
+                // ---- painter's order walk
+#ifdef ABL_T_NOWALK
+                if (n_st < 0)
 #endif
-                if (f & CLS_BOX) {
-                    // ---- rectilinear (A.6): exact area of disjoint boxes, alpha = (c>>8) - (c>>16)
-                    const uint32_t e_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)ent[li][5]), e_nedges = (uint32_t)__builtin_amdgcn_readfirstlane((int)ent[li][6]);
-                    uint32_t al[STRIP_H];
+                for (int li = 0; li < n_st; ++li) {
+                    // per-entry fields are wave-uniform: readfirstlane moves them (and everything computed from them) to the scalar unit
+                    const uint4 ea = *reinterpret_cast<const uint4*>(&ent[li][0]);
+                    const uint4 eb = *reinterpret_cast<const uint4*>(&ent[li][4]);
+                    const uint32_t fe = (uint32_t)__builtin_amdgcn_readfirstlane((int)ent[li][8]);
+                    const uint32_t xw = (uint32_t)__builtin_amdgcn_readfirstlane((int)ea.x), yw = (uint32_t)__builtin_amdgcn_readfirstlane((int)ea.y);
+                    const int e_xmin = (int)(int16_t)(xw & 0xffffu), e_xmax = (int)(int16_t)(xw >> 16);
+                    const int e_ymin = (int)(int16_t)(yw & 0xffffu), e_ymax = (int)(int16_t)(yw >> 16);
+                    const uint32_t eflags = (uint32_t)__builtin_amdgcn_readfirstlane((int)ea.z), solid = (uint32_t)__builtin_amdgcn_readfirstlane((int)ea.w);
+                    const uint32_t style = (uint32_t)__builtin_amdgcn_readfirstlane((int)eb.x);
+                    const int row_lo = max(e_ymin, ty0) - ty0, row_hi = min(min(e_ymax, ty0 + STRIP_H), height) - ty0;
+                    if (row_hi <= row_lo) continue;                    // the path misses this strip of the tile
+                    STAT(2, 1);
+#ifdef ABL_T_NOPARTIAL
+                    if ((fe & (CLS_PARTIAL | CLS_BOX)) == CLS_PARTIAL) continue;
+#endif
+                    uint32_t al[8];
+                    if (fe & CLS_BOX) {
+                        // ---- rectilinear (A.6): exact area of disjoint boxes, alpha = (c>>8) - (c>>16)
+                        const uint32_t e_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)eb.y), e_nedges = (uint32_t)__builtin_amdgcn_readfirstlane((int)eb.z);
+                        uint32_t cov[8];
 #pragma unroll
-                    for (int rr = 0; rr < STRIP_H; ++rr) {
-                        al[rr] = 0;
-                        if (rr < row_lo || rr >= row_hi) continue;         // wave-uniform
-                        const int cy = ty0 + rr;
-                        uint32_t cov = 0u;
+                        for (int j = 0; j < 8; ++j) cov[j] = 0u;
                         for (uint32_t k = 0; k < e_nedges; ++k) {
                             const swfr_edge bx = FR->raw[e_first + k];
-                            const int wx = min(bx.x2, (cx + 1) * 256) - max(bx.x1, cx * 256);
-                            const int wy = min(bx.y2, (cy + 1) * 256) - max(bx.y1, cy * 256);
-                            if (wx > 0 && wy > 0) cov += (uint32_t)(wx * wy);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const int cx = cx0 + (j & 3), cy = cy0 + 4 * (j >> 2);
+                                const int wx = min(bx.x2, (cx + 1) * 256) - max(bx.x1, cx * 256);
+                                const int wy = min(bx.y2, (cy + 1) * 256) - max(bx.y1, cy * 256);
+                                if (wx > 0 && wy > 0) cov[j] += (uint32_t)(wx * wy);
+                            }
                         }
-                        al[rr] = ((cov >> 8) - (cov >> 16)) & 255u;
-                    }
-                    blend_rows<SHADERS>(px, al, eflags, solid, styles, style, bitmaps, cx, ty0);
-                } else if (f & CLS_PARTIAL) {
-                    // ---- tor (A.5): the path's cells of this strip's rows
-                    if (!acc_clean) {                                    // (wave-uniform)
-                        for (int i = lane; i < STRIP_H * T2_ACC_STRIDE; i += 64) (&acc[0][0])[i] = 0;
-                        lds_barrier();
-                        acc_clean = true;                               // every path leaves them empty behind itself
-                    }
-                    if (batch_i == batch_n) {
-                        // the next PBATCH partial tor paths of the list, this one first (lane = list position); their row headers are
-                        // in LDS: lane = (path of the batch, row of the strip) forms the flat cell sequence and fetches its first cells
-                        bool isp = lane >= li && lane < ln && ((sel[lane & (T2_LIST - 1)] >> 24) & (CLS_PARTIAL | CLS_BOX)) == CLS_PARTIAL;
-                        if (isp) {
-                            int le = lane;
-                            SWFR_OPAQUE(le);                               // (the address is formed here, not kept in a register from the kernel's prologue on: that register was spilled)
-                            const uint32_t lyw = ent[le][1];
-                            const int l_ymin = (int)(int16_t)(lyw & 0xffffu), l_ymax = (int)(int16_t)(lyw >> 16);
-                            isp = min(min(l_ymax, ty0 + STRIP_H), height) > max(l_ymin, ty0);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int rr = g + 4 * (j >> 2);
+                            al[j] = (rr >= row_lo && rr < row_hi) ? (((cov[j] >> 8) - (cov[j] >> 16)) & 255u) : 0u;
                         }
-                        const unsigned long long pm = __ballot(isp);
-                        const int rank = __popcll(pm & ((1ull << lane) - 1ull));
-                        if (isp && rank < PBATCH) plist[rank] = lane;
-                        batch_n = min((int)__popcll(pm), PBATCH); batch_i = 0;
-                        lds_barrier();                                   // plist visible
-                        uint32_t my_cnt = 0, off = 0;
+                    } else if (fe & CLS_PARTIAL) {
+                        // ---- tor (A.5): the cells of this strip's eight rows of the path, lane = (row, k-th cell)
+                        STAT(3, 1);
+                        if (!acc_clean) {                                    // (wave-uniform)
+                            *reinterpret_cast<int4*>(&acc[g][4 * cg]) = make_int4(0, 0, 0, 0);     // (the padding columns are never touched)
+                            *reinterpret_cast<int4*>(&acc[g + 4][4 * cg]) = make_int4(0, 0, 0, 0);
+                            acc_clean = true;                               // every path leaves them empty behind itself
+                            lds_barrier();
+                        }
+                        uint32_t off = 0; int n_c = 0;
+                        if (ty0 + cr < height) {
+                            const uint2 hq = *reinterpret_cast<const uint2*>(&hdr[li][2 * cr]);
+                            off = hq.x; n_c = (int)(hq.y & 0xffffu);
+                            if ((uint64_t)off + (uint32_t)n_c > (uint64_t)FR->cell_slice) { atomicOr(&FR->counters[C2_ERROR], E2_CELL_RANGE); n_c = 0; }
+                        }
+                        const Cell* __restrict__ cp = FR->cells + off;
+                        // the first sixteen cells of every row in one round trip, the rest (long shallow edges) eight per round
+                        Cell c0c, c1c; c0c.w = 0; c1c.w = 0;
+                        if (ck < n_c) c0c = cp[ck];
+                        if (ck + 8 < n_c) c1c = cp[ck + 8];
+                        STAT(4, n_c);
+                        int* arow = acc[cr];
+                        const int xrel = e_xmin - tx0;
+                        auto add_cell = [&](Cell c, bool valid) {
+                            const int i = cell_col(c) + xrel;                 // (columns are stored relative to the path's x_min)
+                            const int v = (int)(c.w << 13) >> 13;             // covered height * 16384 + uncovered area
+                            const int ua = (v << 18) >> 18;
+                            const int hgt = (v - ua) << 6;                    // height << 20
+                            // a cell left of the tile only adds its height to everything right of it: to column 0, without an area
+                            if (valid && i < TILE_W) atomicAdd(&arow[max(i, 0)], i < 0 ? hgt : hgt + ua);
+                        };
+#ifndef ABL_T_NOACC
+                        add_cell(c0c, ck < n_c);
+                        add_cell(c1c, ck + 8 < n_c);
+#endif
+                        for (int kb = 16; __ballot(kb < n_c) != 0ull; kb += 8) {   // wave-uniform
+                            Cell cc; cc.w = 0;
+                            if (kb + ck < n_c) cc = cp[kb + ck];
+                            add_cell(cc, kb + ck < n_c);
+                        }
+                        TRACE(5);                                           // cells in
+                        lds_barrier();                                       // acc complete
+                        // ---- prefix sums, coverage: four pixel rows per DPP sequence; the accumulators are cleared as they are read
                         {
-                            const int bp = lane / STRIP_H, row = lane % STRIP_H;
-                            if (bp < batch_n && ty0 + row < height) {
-                                const int pl = plist[bp];
-                                off = rinfo[pl][2 * row]; my_cnt = rinfo[pl][2 * row + 1] & 0xffffu;
-                                if ((uint64_t)off + my_cnt > (uint64_t)FR->cell_slice) { atomicOr(&FR->counters[C2_ERROR], E2_CELL_RANGE); my_cnt = 0; }
-                            }
-                        }
-                        const int incl = wave_scan_incl((int)my_cnt);       // every lane active
-                        total = __builtin_amdgcn_readlane(incl, 63);
-                        seg_off[lane] = off;
-                        seg_start[lane] = (uint32_t)(incl - (int)my_cnt);
-                        seg_start[64] = (uint32_t)total;
-                        lds_barrier();                                   // seg_off / seg_start visible to every lane
+                            int4* a0 = reinterpret_cast<int4*>(&acc[g][4 * cg]);
+                            int4* a1 = reinterpret_cast<int4*>(&acc[g + 4][4 * cg]);
+                            const int4 v0 = *a0, v1 = *a1;
+                            *a0 = make_int4(0, 0, 0, 0); *a1 = make_int4(0, 0, 0, 0);
+                            const int v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                            int ua[8], ch[8];
 #pragma unroll
-                        for (int u = 0; u < T2_PRE; ++u) {
-                            const uint32_t g = (uint32_t)(u * 64 + lane);
-                            pre[u].w = 0; pre_seg[u] = 0;
-                            if (u * 64 < total) {                          // wave-uniform
-                                int lo = 0, hi = 64;                        // last segment with seg_start <= g
-                                while (lo + 1 < hi) { const int mid = (lo + hi) >> 1; if (seg_start[mid] <= g) lo = mid; else hi = mid; }
-                                pre_seg[u] = (uint32_t)lo;
-                                if (g < (uint32_t)total) pre[u] = FR->cells[seg_off[lo] + (g - seg_start[lo])];
-                            }
-                        }
-                        TRACE(5);                                       // (last batch's) first cells in
-                    }
-                    const int bp = batch_i++;
-                    STAT(3, 1);
-                    const int g0 = (int)__builtin_amdgcn_readfirstlane((int)seg_start[bp * STRIP_H]);
-                    const int g1 = (int)__builtin_amdgcn_readfirstlane((int)seg_start[(bp + 1) * STRIP_H]);   // this path's cells [g0, g1) of the batch sequence
-                    // ---- accumulate: cells left of the tile fold into the row's carry, cells right of it do not matter
-                    STAT(4, g1 - g0);
-#ifdef ABL_T_NOACC
-                    if (g1 < 0)
-#endif
-                    for (int gb = g0 & ~63; gb < g1; gb += 64) {           // wave-uniform
-                        const int g = gb + lane;
-                        Cell c; uint32_t sg;
-                        if (gb < T2_PRE * 64) { c = pre[0]; sg = pre_seg[0];
+                            for (int j = 0; j < 8; ++j) { ua[j] = (int)((uint32_t)v[j] << 12) >> 12; ch[j] = (v[j] - ua[j]) >> 20; }
 #pragma unroll
-                            for (int u = 1; u < T2_PRE; ++u) if (gb == u * 64) { c = pre[u]; sg = pre_seg[u]; } }
-                        else {
-                            c.w = 0; sg = 0;
-                            if (g >= g0 && g < g1) {
-                                int lo = bp * STRIP_H, hi = (bp + 1) * STRIP_H;
-                                while (lo + 1 < hi) { const int mid = (lo + hi) >> 1; if (seg_start[mid] <= (uint32_t)g) lo = mid; else hi = mid; }
-                                sg = (uint32_t)lo;
-                                c = FR->cells[seg_off[lo] + ((uint32_t)g - seg_start[lo])];
-                            }
-                        }
-                        if (g >= g0 && g < g1) {
-                            int* arow = acc[sg % STRIP_H];
-                            const int i = cell_col(c) + e_xmin - tx0;         // (columns are stored relative to the path's x_min)
-                            if (i < 0) atomicAdd(&arow[ACC_CARRY], cell_ch(c));
-                            else if (i < TILE_W) atomicAdd(&arow[i], cell_ch(c) * (1 << 20) + cell_ua(c));
-                        }
-                    }
-                    lds_barrier();                                       // acc complete
-                    int (*A)[T2_ACC_STRIDE] = acc;
-                    // ---- prefix sum, alpha, blend; clears as it reads.  All eight rows in one straight-line block so that their LDS
-                    //      round trips and DPP scan chains interleave; a row nothing was accumulated into scans zeros
-                    {
-                        int v[STRIP_H];
-#pragma unroll
-                        for (int u = 0; u < STRIP_H; ++u) v[u] = A[u][lane];
-                        const int carries = A[lane & (STRIP_H - 1)][ACC_CARRY];   // lane u holds row u's carry: one register for the eight
-#pragma unroll
-                        for (int u = 0; u < STRIP_H; ++u) A[u][lane] = 0;
-                        if (lane < STRIP_H) A[lane][ACC_CARRY] = 0;
-                        uint32_t al[STRIP_H];
-#pragma unroll
-                        for (int u = 0; u < STRIP_H; ++u) {
-                            const int ua = (int)((uint32_t)v[u] << 12) >> 12;   // low 20 bits, sign-extended
-                            int ch = (v[u] - ua) >> 20;
-                            const int carry_u = __builtin_amdgcn_readlane(carries, u);
-                            if (lane == 0) ch += carry_u;
+                            for (int h = 0; h < 2; ++h) {
+                                ch[4 * h + 1] += ch[4 * h]; ch[4 * h + 2] += ch[4 * h + 1]; ch[4 * h + 3] += ch[4 * h + 2];
+                                int t = ch[4 * h + 3];                       // this lane's four columns; inclusive scan over the DPP row = the pixel row
 #ifdef ABL_T_NOSCAN
-                            const int scan = ch;
+                                const int ex = 0;
 #else
-                            const int scan = wave_scan_incl(ch);
+                                t += __builtin_amdgcn_update_dpp(0, t, 0x111, 0xf, 0xf, false);   // row_shr:1
+                                t += __builtin_amdgcn_update_dpp(0, t, 0x112, 0xf, 0xf, false);   // row_shr:2
+                                t += __builtin_amdgcn_update_dpp(0, t, 0x114, 0xf, 0xf, false);   // row_shr:4
+                                t += __builtin_amdgcn_update_dpp(0, t, 0x118, 0xf, 0xf, false);   // row_shr:8
+                                const int ex = t - ch[4 * h + 3];
 #endif
-                            const int area = scan * 512 - ua;
-                            al[u] = (uint32_t)((area * 17 + 256) >> 9) & 255u;
-                            if (cx < e_xmin || cx >= e_xmax || u < row_lo || u >= row_hi) al[u] = 0;
-                        }
-                        bool blended = false;
-                        if (SHADERS == 0 && (eflags & BE_LERP)) {
-                            // Solid colour, SOURCE-lerp: coverage 255 takes the colour, 0 keeps the pixel, and only the few edge pixels
-                            // need the two rounded products: queued -- {coverage, pixel} through the (now empty) accumulator -- and
-                            // blended with lanes = queued pixels, one pass for the strip's eight rows
-                            unsigned long long pmask[STRIP_H];
-                            int qbase[STRIP_H], nq = 0;
 #pragma unroll
-                            for (int u = 0; u < STRIP_H; ++u) {
-                                pmask[u] = __ballot(al[u] - 1u < 254u);
-                                qbase[u] = nq;
-                                nq += (int)__popcll(pmask[u]);
-                                px[u] = al[u] == 255u ? solid : px[u];
+                                for (int i = 0; i < 4; ++i) {
+                                    const int j = 4 * h + i;
+                                    al[j] = (uint32_t)((__mul24(ch[j] + ex, 512 * 17) - __mul24(ua[j], 17) + 256) >> 9) & 255u;
+                                }
                             }
-                            STAT(5, nq);
-#ifdef ABL_T_NOQUEUE
-                            blended = true;
-                            if (nq < 0)
-#endif
-                            if (nq <= BLEND_QUEUE) {                       // wave-uniform; more edge pixels: the per-row path below
-                                uint2* q = reinterpret_cast<uint2*>(&A[0][0]);
+                            // the converter's rectangle bounds what is painted (a cell at or beyond x_max is never emitted, so the coverage
+                            // may not return to zero there); wave-uniform tests: most pairs lie inside
+                            if (tx0 < e_xmin || tx0 + TILE_W > e_xmax) {
 #pragma unroll
-                                for (int u = 0; u < STRIP_H; ++u) {
-                                    const int qi = qbase[u] + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(pmask[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pmask[u], 0u));
-                                    if ((pmask[u] >> lane) & 1ull) q[qi] = make_uint2(al[u], px[u]);
-                                }
-                                lds_barrier();
-                                for (int b = lane; b < nq; b += 64) {
-                                    const uint2 e = q[b];
-                                    q[b].x = lerp_pixel(solid, e.x, e.y);
-                                }
-                                lds_barrier();
+                                for (int j = 0; j < 8; ++j) { const int cx = cx0 + (j & 3); if (cx < e_xmin || cx >= e_xmax) al[j] = 0u; }
+                            }
+                            if (row_lo > 0 || row_hi < STRIP_H) {
 #pragma unroll
-                                for (int u = 0; u < STRIP_H; ++u) {
-                                    const int qi = qbase[u] + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(pmask[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pmask[u], 0u));
-                                    if ((pmask[u] >> lane) & 1ull) px[u] = q[qi].x;
-                                }
-                                lds_barrier();
-                                for (int b = lane; b < nq; b += 64) q[b] = make_uint2(0u, 0u);   // the accumulator is handed back empty
-                                blended = true;
+                                for (int j = 0; j < 8; ++j) { const int rr = g + 4 * (j >> 2); if (rr < row_lo || rr >= row_hi) al[j] = 0u; }
                             }
                         }
-                        if (!blended) blend_rows<SHADERS>(px, al, eflags, solid, styles, style, bitmaps, cx, ty0);
+                    } else {
+                        // full cover: every in-frame pixel of the path's rows in this tile has coverage 255
+                        const bool in0 = g >= row_lo && g < row_hi, in1 = g + 4 >= row_lo && g + 4 < row_hi;
+                        if ((SHADERS == 0 || (eflags & BE_SOLID)) && ((eflags & BE_LERP) || (solid >> 24) == 0xffu)) {     // (wave-uniform) the colour itself
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) { px[j] = in0 ? solid : px[j]; px[4 + j] = in1 ? solid : px[4 + j]; }
+                            continue;
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { al[j] = in0 ? 255u : 0u; al[4 + j] = in1 ? 255u : 0u; }
                     }
-                    lds_barrier();                                       // acc cleared before the next path accumulates
-                } else {
-                    // full cover: every in-frame pixel of the path's rows in this tile has coverage 255
-                    uint32_t al[STRIP_H];
-#pragma unroll
-                    for (int rr = 0; rr < STRIP_H; ++rr) al[rr] = (rr >= row_lo && rr < row_hi) ? 255u : 0u;
-                    blend_rows<SHADERS>(px, al, eflags, solid, styles, style, bitmaps, cx, ty0);
+#ifdef ABL_T_NOBLEND
+                    for (int j = 0; j < 8; ++j) px[j] = al[j] == 255u ? solid : px[j];
+#else
+                    blend8<SHADERS>(px, al, eflags, solid, styles, style, bitmaps, cx0, cy0, bq, lane);
+#endif
                 }
+                lds_barrier();                                           // ent / hdr are rewritten by the next round
             }
-            lds_barrier();                                               // ent / sel are rewritten by the next round
         }
         TRACE_NOWAIT(6);
-        // ---- one store per pixel: premultiplied R,G,B,A bytes; the wave writes 256 contiguous bytes per row
-        if (cx < width) {
-            uint32_t* rowp = FR->fb + (size_t)ty0 * (size_t)width + cx;
+        // ---- one store per pixel: premultiplied R,G,B,A bytes; a lane's four pixels of a row are one 16-byte store, the wavefront
+        //      writes 256 contiguous bytes in each of four rows per instruction
 #pragma unroll
-            for (int rr = 0; rr < STRIP_H; ++rr) {
-                if (ty0 + rr < height) {
-                    const uint32_t p = px[rr];
-                    *rowp = (p & 0xff00ff00u) | ((p >> 16) & 0xffu) | ((p & 0xffu) << 16);
-                }
-                rowp += width;
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t p = px[j];
+#ifdef SWFR_EMU
+            px[j] = (p & 0xff00ff00u) | ((p >> 16) & 0xffu) | ((p & 0xffu) << 16);
+#else
+            px[j] = __builtin_amdgcn_perm(p, p, 0x03000102u);          // bytes 0 and 2 swapped
+#endif
+        }
+        const bool vec_ok = (width & 3) == 0 && ((uintptr_t)FR->fb & 15u) == 0u;      // (wave-uniform) every row of the frame starts 16-byte aligned
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int y = cy0 + 4 * h;
+            if (y >= height) continue;
+            uint32_t* rowp = FR->fb + (size_t)y * (size_t)width + cx0;
+            if (vec_ok && cx0 + 4 <= width) *reinterpret_cast<uint4*>(rowp) = make_uint4(px[4 * h], px[4 * h + 1], px[4 * h + 2], px[4 * h + 3]);
+            else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (cx0 + i < width) rowp[i] = px[4 * h + i];
             }
         }
         TRACE(7);                                                        // stores acknowledged
@@ -1933,14 +1940,15 @@ __device__ __forceinline__ void tiles2_body(FramePtr FR) {
     }
 }
 
+
 #ifndef T2_WAVES
 #define T2_WAVES 6
 #endif
 // (two entry points per kernel: one frame, its descriptor passed by value -- the fields arrive with the kernel arguments, no memory
 //  round trip -- and a batch of frames, blockIdx.y indexing an array of descriptors in device memory)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(T2_WAVES))) void k2_tiles_solid_b(const Frame2* __restrict__ frames) { tiles2_body<0>(FRAME_PTR(frames, blockIdx.y)); }
-__global__ __launch_bounds__(64) void k2_tiles_bitmap_b(const Frame2* __restrict__ frames) { tiles2_body<1>(FRAME_PTR(frames, blockIdx.y)); }
-__global__ __launch_bounds__(64) void k2_tiles_shaded_b(const Frame2* __restrict__ frames) { tiles2_body<2>(FRAME_PTR(frames, blockIdx.y)); }
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(T2_WAVES))) void k2_tiles_solid_b(const Frame2* __restrict__ frames) { tiles3_body<0>(FRAME_PTR(frames, blockIdx.y)); }
+__global__ __launch_bounds__(64) void k2_tiles_bitmap_b(const Frame2* __restrict__ frames) { tiles3_body<1>(FRAME_PTR(frames, blockIdx.y)); }
+__global__ __launch_bounds__(64) void k2_tiles_shaded_b(const Frame2* __restrict__ frames) { tiles3_body<2>(FRAME_PTR(frames, blockIdx.y)); }
 
 // ---------------------------------------------------------------------------------------------
 // launchers: `frames` is a device array of n_frames descriptors, blockIdx.y picks one

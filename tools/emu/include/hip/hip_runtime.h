@@ -29,6 +29,10 @@ struct dim3 {
 };
 struct uint2 { uint32_t x, y; };
 struct uint4 { uint32_t x, y, z, w; };
+static inline uint32_t __umul24(uint32_t a, uint32_t b) { return (a & 0xffffffu) * (b & 0xffffffu); }
+static inline int32_t __mul24(int32_t a, int32_t b) { return (int32_t)(((int32_t)(a << 8) >> 8) * (int64_t)((int32_t)(b << 8) >> 8)); }
+struct int4 { int32_t x, y, z, w; };
+static inline int4 make_int4(int32_t x, int32_t y, int32_t z, int32_t w) { return int4{x, y, z, w}; }
 static inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
 static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
 
