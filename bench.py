@@ -33,6 +33,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured ceiling
 DEFAULT_IN_FLIGHT = 3
+BATCH_FRAMES, BATCH_LAUNCHES = 8, 12     # roofline.batched: frames per kernel launch, timed launches
 
 
 def _oracle_args(fx, cols):
@@ -118,6 +119,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-path", action="store_true", help="skip the reference-style full path (new Stage per frame) measurement")
+    ap.add_argument("--no-batched", action="store_true", help="skip the saturated-GPU (frames per launch) and S0 store-roof measurements")
     ap.add_argument("--no-verify", action="store_true", help="skip the check of the frame against the known answer after the timed region")
     ap.add_argument("--verify", action="store_true", help="(default) kept for compatibility")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -129,6 +131,19 @@ def main():
                     help="s1 = BASELINE.json's metric configuration (4K, 10k edges; the default and the judged line); s2 = 8K, 100k edges")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launched like the single-GPU line (python bench.py --gpus N ...): this process never touches the GPU; it starts the N
+        # ranks as fresh child processes under torch.distributed.run, relays rank 0's JSON line and exits with the launcher's code
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        raise SystemExit(subprocess.call(cmd, env=env))
+
     import numpy as np
     import torch
     import swf_renderer_amd as S
@@ -138,8 +153,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     rehearsal = args.backend == "gloo"
@@ -199,6 +213,8 @@ def main():
     cfg = synth.S1 if args.workload == "s1" else synth.S2
     extra = {}
     t1 = None
+    bms = None
+    s0_info = None
     if bands:
         dt, out, (W, H, fx, cols, scene), tm = run_bands(args.workload, cfg, args.steps, args.warmup)
         edges, paths, styles = scene
@@ -211,13 +227,36 @@ def main():
             # the same kernels timed with one frame in flight (a second handle, its own 80 frames, before the timed region so that
             # the device is out of its idle clocks when the W warm-up frames start) are reported beside it
             os.environ["SWFR_FRAMES_IN_FLIGHT"] = "1"
+            os.environ["SWFR_EVENT_STRIDE"] = "4"
             r1 = S.Renderer(W, H, device=local_rank)
             r1.upload_edges(edges, paths, styles)
             r1.render_resident(16)
             r1.render_resident(64)
             t1 = r1.timing()
+            # the saturated GPU: the same resident scene as 8 frames per kernel launch (blockIdx.y = frame), 12 launches
+            if not args.no_batched:
+                bms = r1.render_resident_batched(BATCH_FRAMES, BATCH_LAUNCHES)
+                if not args.no_verify and args.workload == "s1":
+                    import hashlib
+                    batched_ok = hashlib.sha256(np.ascontiguousarray(r1.read_image(premultiplied=True)).tobytes()).hexdigest() == synth.S1_SHA256_PREMUL
+                    if not batched_ok:
+                        print("verify: the last frame of the batched launches DOES NOT match the libcairo known answer", file=sys.stderr, flush=True)
+                        raise SystemExit(3)
+            # S0: one full-frame opaque rectangle through the same path -- the store roof of the tile pass
+            if not args.no_batched:
+                rect = np.array([[[0, 0], [W * 256, 0], [W * 256, H * 256], [0, H * 256]]], dtype=np.int32)
+                e0, p0, s0 = api.polygons_to_scene(rect, np.array([[30, 60, 90, 255]], dtype=np.uint8), W, H)
+                r1.upload_edges(e0, p0, s0)
+                r1.render_resident(16)
+                r1.render_resident(64)
+                t0s = r1.timing()
+                px0 = r1.read_image(premultiplied=True)
+                s0_ok = bool((px0 == np.array([30, 60, 90, 255], dtype=np.uint8)).all())
+                b0ms = r1.render_resident_batched(BATCH_FRAMES, BATCH_LAUNCHES)
+                s0_info = (t0s, b0ms, len(e0), len(p0), s0_ok)
             r1.close()
             os.environ["SWFR_FRAMES_IN_FLIGHT"] = str(in_flight)
+            os.environ["SWFR_EVENT_STRIDE"] = "1000000"           # (the timed region carries no per-kernel events: each costs a queue packet)
         r = S.Renderer(W, H, device=local_rank)
         r.upload_edges(edges, paths, styles)                      # inputs resident in HBM before the timed region
         r.render_resident(min(max(args.warmup, 1), 2048))
@@ -247,7 +286,15 @@ def main():
             verified = bool(np.array_equal(np.asarray(img), oracle_frame(fx, cols, W, H)))
         if not verified:
             print("verify: the frame of the timed region DOES NOT match the %s" % ("libcairo known answer" if args.workload == "s1" else "CPU oracle"), file=sys.stderr, flush=True)
+    if world > 1:
+        # every rank learns the verdict and leaves together (a rank that exits alone leaves the others in their next collective)
+        flag = torch.tensor([0 if verified is False else 1], dtype=torch.int32, device="cpu" if rehearsal else "cuda")
+        dist.broadcast(flag, src=0)
+        if int(flag.item()) == 0:
+            dist.destroy_process_group()
             raise SystemExit(3)
+    elif verified is False:
+        raise SystemExit(3)
 
     # ---- secondary measurements of the same run (outside the timed region)
     if bands and args.workload == "s1":
@@ -256,7 +303,12 @@ def main():
         t5 = torch.tensor([dt5], dtype=torch.float64, device="cuda")
         dist.all_reduce(t5, op=dist.ReduceOp.MAX)
         k5 = max(5, min(args.steps, 40))
-        extra["config5_s2_bands"] = {"workload": "S2: 7680x4320, 10000 stars (99909 edges), tile-rows sharded over %d ranks, one gather per frame" % world,
+        v5 = None
+        if rank == 0 and not args.no_verify and out5 is not None:
+            v5 = bool(np.array_equal(out5.cpu().numpy(), oracle_frame(fx5, cols5, W5, H5)))
+            if not v5:
+                print("verify: the gathered S2 frame of config 5 DOES NOT match the CPU oracle", file=sys.stderr, flush=True)
+        extra["config5_s2_bands"] = {"workload": "S2: 7680x4320, 10000 stars (99909 edges), tile-rows sharded over %d ranks, one gather per frame" % world, "verified": v5,
                                      "value": round(W5 * H5 * k5 / float(t5.item()) / 1e6, 2), "unit": "Mpixels/s",
                                      "frames_per_sec": round(k5 / float(t5.item()), 1), "steps": k5}
     if bands:
@@ -281,18 +333,24 @@ def main():
         algo_bytes = 4 * W * H + 16 * n_edges + 16 * n_paths           # SURVEY.md 8(d), per frame = per tile-kernel launch
         if bands:
             algo_bytes = 4 * W * min(D.block_rows(H, world) * D.TILE_H, H) + 16 * n_edges + 16 * n_paths
-        nt = max(tm["timed_frames"], 1)
-        tiles_ms = tm["tiles_ms"] / nt
-        achieved = algo_bytes / (tiles_ms * 1e-3) / 1e9 if tiles_ms > 0 else 0.0
-        traffic, traffic_src = latest_traffic() if (not bands and args.workload == "s1") else (None, None)
         frames_total = args.steps * (1 if bands or world == 1 else world)
+        ms_per_step = dt / args.steps * 1e3
+        # per-kernel durations: HIP events on the kernels' own stream with ONE frame in flight (a kernel has the GPU to itself, so the
+        # interval between its events is its duration; under several frames in flight an event interval also holds queue waits).
+        # N > 1: this rank's share of the frame, eight frames after the timed region.
+        tk = t1 if t1 is not None else tm
+        nk = max(tk["timed_frames"], 1)
+        bin_ms, rows_ms, tiles_ms = tk["setup_ms"] / nk, tk["rows_ms"] / nk, tk["tiles_ms"] / nk
+        gbs = lambda nbytes, ms: nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        achieved = gbs(algo_bytes, tiles_ms)
+        traffic, traffic_src = latest_traffic() if (not bands and args.workload == "s1") else (None, None)
         line = {
             "metric": "Mpixels/sec rasterized @ 4K, 10k-edge synthetic shape set" if args.workload == "s1" else "Mpixels/sec rasterized @ 8K, 100k-edge synthetic shape set",
             # bands sharding: one frame over all ranks per step; frames sharding: a step is one frame on every rank (N frames)
             "value": round(W * H * frames_total / dt / 1e6, 2),
             "unit": "Mpixels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "ms_per_step": round(ms_per_step, 4),
             "frames_per_sec": round(frames_total / dt, 1),
             "higher_is_better": True,
             "scaling": "strong" if bands else "weak",
@@ -306,19 +364,41 @@ def main():
                                    ("whole frames, one per rank and step, no data-path collective" if world > 1 else "single GPU"),
                        "frames_in_flight": in_flight,
                        "device_path": "raw edge list -> k2_bin -> k2_rows -> k2_tiles, every frame"},
-            "kernel_ms_per_frame": {"k2_bin": round(tm["setup_ms"] / nt, 4), "k2_rows": round(tm["rows_ms"] / nt, 4), "k2_tiles": round(tiles_ms, 4)},
+            "kernel_ms_per_frame": {"k2_bin": round(bin_ms, 4), "k2_rows": round(rows_ms, 4), "k2_tiles": round(tiles_ms, 4),
+                                    "how": "HIP events on the kernels' stream, one frame in flight (each kernel alone on the GPU), %d frames; in the timed region "
+                                           "%d frames overlap, so these add up to more than ms_per_step" % (nk, in_flight)},
             "roofline": {"bound": "hbm", "kernel": "k2_tiles", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": algo_bytes},
+                         "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": traffic, "traffic_source": ("committed profile %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench; not measured in this run)" % traffic_src) if traffic_src else None,
+                         "algorithmic_bytes_per_launch": algo_bytes,
+                         "kernel_ms": round(tiles_ms, 4), "kernel_ms_how": "one frame in flight, HIP events around the kernel on its own stream",
+                         # the co-dominant kernel and the whole step against the same roof
+                         "k2_rows": {"kernel_ms": round(rows_ms, 4), "achieved": round(gbs(algo_bytes, rows_ms), 2), "frac": round(gbs(algo_bytes, rows_ms) / HBM_PEAK_GBS, 5)},
+                         "step_achieved": round(gbs(algo_bytes * (frames_total / args.steps), ms_per_step), 2),
+                         "step_frac": round(gbs(algo_bytes * (frames_total / args.steps), ms_per_step) / HBM_PEAK_GBS, 5)},
         }
         line.update(extra)
         if t1 is not None:
-            n1 = max(t1["timed_frames"], 1)
-            iso_ms = t1["tiles_ms"] / n1
-            iso = algo_bytes / (iso_ms * 1e-3) / 1e9 if iso_ms > 0 else 0.0
-            line["roofline"]["one_frame_in_flight"] = {"k2_tiles_ms": round(iso_ms, 4), "k2_rows_ms": round(t1["rows_ms"] / n1, 4),
-                                                       "k2_bin_ms": round(t1["setup_ms"] / n1, 4), "achieved": round(iso, 2),
-                                                       "frac": round(iso / HBM_PEAK_GBS, 5), "value": round(W * H * 64 / (t1["total_ms"] * 1e-3) / 1e6, 2)}
+            line["roofline"]["one_frame_in_flight"] = {"k2_tiles_ms": round(tiles_ms, 4), "k2_rows_ms": round(rows_ms, 4), "k2_bin_ms": round(bin_ms, 4),
+                                                       "achieved": round(achieved, 2), "frac": round(achieved / HBM_PEAK_GBS, 5),
+                                                       "value": round(W * H * 64 / (t1["total_ms"] * 1e-3) / 1e6, 2)}
+        if bms is not None:
+            bf = bms / (BATCH_FRAMES * BATCH_LAUNCHES)
+            line["roofline"]["batched"] = {"what": "the resident scene as %d frames per kernel launch (blockIdx.y = frame, every frame recomputed from the raw edge list into "
+                                                   "its own buffers and framebuffer), %d launches, HIP events around them; last frame verified" % (BATCH_FRAMES, BATCH_LAUNCHES),
+                                           "frames_per_launch": BATCH_FRAMES, "launches": BATCH_LAUNCHES, "ms_per_frame": round(bf, 4),
+                                           "Mpixels_per_sec": round(W * H / (bf * 1e-3) / 1e6, 1),
+                                           "achieved": round(gbs(algo_bytes, bf), 2), "frac": round(gbs(algo_bytes, bf) / HBM_PEAK_GBS, 5)}
+        if s0_info is not None:
+            t0s, b0ms, ne0, np0, s0_ok = s0_info
+            n0 = max(t0s["timed_frames"], 1)
+            a0 = 4 * W * H + 16 * ne0 + 16 * np0
+            k0 = t0s["tiles_ms"] / n0
+            b0 = b0ms / (BATCH_FRAMES * BATCH_LAUNCHES)
+            line["roofline"]["s0"] = {"what": "S0: one full-frame opaque rectangle through the same path (the store roof of the tile pass)", "verified": s0_ok,
+                                      "algorithmic_bytes_per_launch": a0, "k2_tiles_ms": round(k0, 4), "achieved": round(gbs(a0, k0), 2), "frac": round(gbs(a0, k0) / HBM_PEAK_GBS, 5),
+                                      "frame_ms_one_in_flight": round(t0s["total_ms"] / 64, 4),
+                                      "batched": {"frames_per_launch": BATCH_FRAMES, "ms_per_frame": round(b0, 4), "achieved": round(gbs(a0, b0), 2), "frac": round(gbs(a0, b0) / HBM_PEAK_GBS, 5)}}
         if world == 1 and not args.no_full_path and args.workload == "s1":
             # ---- the reference's calling pattern: a different Stage every frame through swfr_render (blocking), timed below the
             #      C-ABI (swfr_render_sequence); four variants of S1 (the stars shifted by 0..3 px) so that no frame repeats the last
@@ -338,6 +418,16 @@ def main():
                     "build_host_ms": round(acc["build_ms"] / nfr, 4), "upload_host_ms": round(acc["upload_host_ms"] / nfr, 4),
                     "h2d_ms": round(acc["h2d_ms"] / nfr, 4), "h2d_bytes": int(acc["h2d_bytes"] / nfr), "device_ms": round(acc["device_ms"] / nfr, 4),
                     "d2h_ms": round(d2h * 1e3, 3), "d2h_what": "swfr_read_image of the 33 MB frame into pageable host memory"}
+            # render + get_image of every frame (the reference's test loop): mapped read-back through the handle's pinned staging buffer
+            t0 = time.perf_counter()
+            r.read_image_async(premultiplied=True)
+            r.read_image_wait()
+            full["d2h_pinned_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+            mv = r.marshal_stages(variants)
+            r.render_sequence_readback(mv, 1)
+            full["with_readback_frames_per_sec"] = round(nfr / r.render_sequence_readback(mv, 8, premultiplied=True, overlap=True), 1)
+            full["with_readback_blocking_frames_per_sec"] = round(nfr / r.render_sequence_readback(mv, 8, premultiplied=True, overlap=False), 1)
+            full["with_readback_what"] = "swfr_render + swfr_read_image_async/_wait (pinned staging, mapped) per frame; the copy of frame i overlaps the host build of frame i+1 / is waited for at once"
             # the same frames as one pipelined batch (swfr_render_batch: the host builds frame i+1 while frame i is rasterized)
             frames_t = torch.empty((16, H, W, 4), dtype=torch.uint8, device="cuda")
             batch = r.marshal_stages(variants * 4)                # (the ctypes form once: the C call is what is timed)

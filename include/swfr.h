@@ -160,6 +160,16 @@ int  swfr_register_bitmap(swfr_renderer *r, uint32_t id, uint32_t width, uint32_
                           const uint8_t *rgba_straight, size_t stride);
 int  swfr_render(swfr_renderer *r, const swfr_stage *stage);               /* blocking */
 int  swfr_read_image(swfr_renderer *r, uint8_t *dst, size_t dst_stride, int premultiplied);
+/* Mapped read-back in two halves (HeadlessGfxRenderer::get_image maps its staging buffer the same way:
+   rs/src/headless_renderer.rs:725-868): _async queues the device-to-host copy of the last frame into the handle's PINNED staging
+   buffer behind the frame's kernels and returns; _wait blocks until it has arrived and hands out the staging buffer itself
+   (width*4-byte rows, valid until the next read-back or swfr_destroy) -- no second copy on the host.  One read-back in flight per
+   handle; the next swfr_render may be called before _wait (its host build then overlaps the copy). */
+int  swfr_read_image_async(swfr_renderer *r, int premultiplied);
+int  swfr_read_image_wait(swfr_renderer *r, const uint8_t **data, size_t *stride);
+/* render + mapped read-back of every frame, timed below the ABI (the reference's test loop: render, get_image). */
+int  swfr_render_sequence_readback(swfr_renderer *r, const swfr_stage *stages, uint32_t n_stages, uint32_t repeat, int premultiplied,
+                                   int overlap, double *seconds, uint64_t *checksum);
 
 /* ---- low-level entry: the hot path proper (edge list -> RGBA8 in HBM) ---------------------- */
 /* One edge of a flattened, limit-clipped polygon in 24.8 device coordinates: the line
@@ -202,6 +212,10 @@ int  swfr_upload_edges(swfr_renderer *r, const swfr_edge *edges, size_t n_edges,
                        const swfr_path *paths, size_t n_paths,
                        const swfr_style *styles, size_t n_styles);
 int  swfr_render_resident(swfr_renderer *r, uint32_t frames);              /* blocking; frames >= 1 */
+/* Measurement entry: the resident scene as `frames_per_launch` (1..64) frames per kernel launch, every frame with its own
+   kernel-written buffers and framebuffer, `launches` launches back to back (after one warm-up launch); *total_ms = HIP-event time of
+   the `launches` launches.  The last frame is readable with swfr_read_image.  The saturated-GPU figure of bench.py. */
+int  swfr_render_resident_batched(swfr_renderer *r, uint32_t frames_per_launch, uint32_t launches, float *total_ms);
 int  swfr_render_edges(swfr_renderer *r, const swfr_edge *edges, size_t n_edges,
                        const swfr_path *paths, size_t n_paths,
                        const swfr_style *styles, size_t n_styles);

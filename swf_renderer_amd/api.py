@@ -29,6 +29,7 @@ EXPORTS = [
     "swfr_render_resident", "swfr_render_edges", "swfr_build_frame", "swfr_shape_json", "swfr_last_timing",
     "swfr_band_slab_bytes", "swfr_copy_band_slab", "swfr_device_framebuffer", "swfr_debug_copy", "swfr_last_path_timing", "swfr_get_stats",
     "swfr_render_sequence", "swfr_set_targets", "swfr_render_resident_async", "swfr_stream_handle", "swfr_wait",
+    "swfr_render_resident_batched", "swfr_read_image_async", "swfr_read_image_wait", "swfr_render_sequence_readback",
 ]
 
 
@@ -182,6 +183,14 @@ def load_library():
         getattr(L, fn).argtypes = [P, P, C.c_size_t, P, C.c_size_t, P, C.c_size_t]
     L.swfr_render_resident.restype = I
     L.swfr_render_resident.argtypes = [P, U]
+    L.swfr_render_resident_batched.restype = I
+    L.swfr_render_resident_batched.argtypes = [P, U, U, C.POINTER(C.c_float)]
+    L.swfr_read_image_async.restype = I
+    L.swfr_read_image_async.argtypes = [P, I]
+    L.swfr_read_image_wait.restype = I
+    L.swfr_read_image_wait.argtypes = [P, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
+    L.swfr_render_sequence_readback.restype = I
+    L.swfr_render_sequence_readback.argtypes = [P, C.POINTER(Stage), U, U, I, I, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.swfr_build_frame.restype = I
     L.swfr_build_frame.argtypes = [P, C.POINTER(Stage), C.POINTER(P), C.POINTER(C.c_size_t), C.POINTER(P), C.POINTER(C.c_size_t),
                                    C.POINTER(P), C.POINTER(C.c_size_t)]
@@ -539,6 +548,12 @@ class Renderer:
     def render_resident(self, frames=1):
         self._check(self.L.swfr_render_resident(self.h, frames))
 
+    def render_resident_batched(self, frames_per_launch: int, launches: int) -> float:
+        """The resident scene as `frames_per_launch` frames per kernel launch, `launches` launches; returns their HIP-event time in ms."""
+        ms = C.c_float()
+        self._check(self.L.swfr_render_resident_batched(self.h, frames_per_launch, launches, C.byref(ms)))
+        return float(ms.value)
+
     def render_edges(self, edges, paths, styles):
         self.upload_edges(edges, paths, styles)
         self.render_resident(1)
@@ -565,6 +580,23 @@ class Renderer:
         out = np.empty((self.height, self.width, 4), dtype=np.uint8)
         self._check(self.L.swfr_read_image(self.h, out.ctypes.data, self.width * 4, 1 if premultiplied else 0))
         return out
+
+    def read_image_async(self, premultiplied=False) -> None:
+        """Queues the read-back of the last frame into the handle's pinned staging buffer, behind the frame's kernels."""
+        self._check(self.L.swfr_read_image_async(self.h, 1 if premultiplied else 0))
+
+    def read_image_wait(self) -> np.ndarray:
+        """Waits for read_image_async; returns the pinned staging buffer as an HxWx4 uint8 view (valid until the next read-back)."""
+        data, stride = C.POINTER(C.c_uint8)(), C.c_size_t()
+        self._check(self.L.swfr_read_image_wait(self.h, C.byref(data), C.byref(stride)))
+        return np.ctypeslib.as_array(data, shape=(self.height, self.width, 4))
+
+    def render_sequence_readback(self, stages, repeat=1, premultiplied=False, overlap=True):
+        """render + mapped read-back of every frame (the reference's test loop), timed below the C-ABI; returns seconds."""
+        _, arr, n = stages if isinstance(stages, tuple) else self.marshal_stages(stages)
+        secs, chk = C.c_double(), C.c_uint64()
+        self._check(self.L.swfr_render_sequence_readback(self.h, arr, n, int(repeat), 1 if premultiplied else 0, 1 if overlap else 0, C.byref(secs), C.byref(chk)))
+        return secs.value
 
     def band_slab_bytes(self) -> int:
         return self.L.swfr_band_slab_bytes(self.h)

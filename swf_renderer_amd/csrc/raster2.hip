@@ -557,6 +557,7 @@ __device__ __forceinline__ void rows2_fast(EPTR E, uint32_t n_list, const DevPat
     R2PHASE(4);
     // ---- FULL rows: the cells of every boundary edge, from the exact end points, into the row's room -- before the sample passes, so
     //      that the end points' registers are free while those run
+#ifndef ABL_R_NOFULLCELLS
     if (mode == ROW_FULL && ri != ~0u && live && !overflow && !defer && wave_base != ~0u) {
         uint32_t off = wave_base + incl_cells - (uint32_t)room;
 #pragma unroll
@@ -569,12 +570,16 @@ __device__ __forceinline__ void rows2_fast(EPTR E, uint32_t n_list, const DevPat
             }
         }
     }
+#endif
     R2PHASE(6);
     lds_barrier();                                          // F.* written by the row owners, read by the sample lanes
     // ---- the wave's SUB rows, 4 rows per pass: lanes 16g .. 16g + 14 are the fifteen sample rows of the pass's g-th row (lane 16g + 15
     //      idles), so everything the samples of one row have to combine -- role bits, column range, cell positions -- is a reduction
     //      over one DPP row or a ballot: no LDS atomics.  Roles for the classification, cells for the tile pass.
     unsigned long long pending = __ballot(is_sub);
+#ifdef ABL_R_NOSUB
+    pending = 0ull;
+#endif
     const int g = lane >> 4, sub = lane & 15;
     const unsigned long long group_mask = 0xffffull << (16 * g);
     const unsigned long long below = group_mask & ((1ull << lane) - 1ull);
@@ -795,6 +800,9 @@ __device__ __forceinline__ void rows2_chunk_body(FramePtr FR, uint32_t block) {
     // ---- classification of this chunk's (tile, path) pairs from the row summaries still in registers: lanes 16g..16g+15 are the
     //      pixel rows of tile-row g.  Only the columns of the path's rectangle are written (the rest of the class matrix was
     //      cleared when the scene was uploaded and nothing ever writes there).
+#ifdef ABL_R_NOCLASS
+    if (ck.slot0 == 0x7fffffffu)
+#endif
     if (ck.slot0 != ~0u && P.kind == SWFR_PATH_TOR) {
         const int width = FR->width, height = FR->height;
         uint8_t* out = FR->cls;

@@ -156,6 +156,8 @@ struct swfr_renderer {
         bool any_shader = false;
         int shader_level = 0;
         size_t n_incidences = 0, n_strips = 0, n_strip_slots = 0;   // (edge, pixel row) pairs: bounds the cells of a frame; k2_tiles wavefronts / launch list slots
+        size_t n_slots = 0, cell_total = 0;
+        Frame2 proto{};                           // the scene fields and sizes of a frame descriptor (per-frame buffers not filled in)
         Frame2* frames_dev = nullptr;            // one descriptor per frame set (contiguous, in the arena)
         uint32_t slow_passes = SLOW_PASSES;      // passes of the slow-row kernels the scene needs (known after a frame of a resident scene)
         bool slow_verified = false;              // slow_state / slow_passes come from this scene's own counters, not from the previous scene
@@ -214,12 +216,26 @@ struct swfr_renderer {
     int batch_frames = 64;                  // SWFR_BATCH_FRAMES: frames per launch in swfr_render_batch
     uint32_t* targets[4] = {nullptr, nullptr, nullptr, nullptr};   // swfr_set_targets: frame set k renders into targets[k]
     swfr_stats stats = {};
+    // swfr_render_resident_batched: B copies of the kernel-written buffers + B framebuffers, the B descriptors, events
+    DevBuf<uint8_t> rb_work, rb_cls;
+    DevBuf<Frame2> rb_frames;
+    DevBuf<uint32_t> rb_fb;
+    uint32_t rb_count = 0;
+    hipEvent_t rb_ev[2] = {nullptr, nullptr};
+    // swfr_read_image: pinned staging (a pageable destination costs 7x the copy time), swfr_read_image_async: the copy in flight
+    uint8_t* h_image = nullptr; size_t h_image_cap = 0;
+    hipEvent_t read_done = nullptr;
+    bool read_pending = false;
     uint32_t n_targets = 0, async_next = 0, async_used = 0;   // async_used: bit k = frame set k has run since the last wait
 
     ~swfr_renderer() {
         if (has_device) {
             (void)hipSetDevice(cfg.device);
             d_bitmap_table.release(); d_tmp.release(); d_counters.release();
+            rb_work.release(); rb_cls.release(); rb_frames.release(); rb_fb.release();
+            for (auto& e : rb_ev) if (e) (void)hipEventDestroy(e);
+            if (h_image) (void)hipHostFree(h_image);
+            if (read_done) (void)hipEventDestroy(read_done);
             for (int k = 0; k < 4; ++k) {
                 FrameSet& x = fs[k];
                 x.d_edges.release(); x.d_cls.release(); x.d_fb.release();
@@ -672,6 +688,7 @@ int upload2(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, siz
     sc.n_edges = n_edges; sc.n_paths = n_paths; sc.n_styles = n_styles; sc.any_shader = L.any_shader; sc.shader_level = L.shader_level;
     sc.n_chunks = L.n_chunks; sc.chunk_rows = L.chunk_rows; sc.n_bands = L.n_bands; sc.n_rows = L.n_rows;
     sc.n_strips = L.n_strips; sc.n_strip_slots = L.n_strip_slots; sc.n_incidences = L.incidences;
+    sc.n_slots = L.n_slots; sc.cell_total = L.cell_total;
     SceneArena& A = sc.arena;
     A.begin(scene_arena_bytes(L, n_edges, n_paths, n_styles) + SceneArena::padded(4 * sizeof(Frame2)) + 4096);
     Frame2 proto;
@@ -708,6 +725,7 @@ int upload2(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, siz
     }
     if (r->bitmap_table_dirty) r->d_bitmap_table.reserve(r->bitmap_table.size());     // (filled below; the address is what the descriptor needs)
     proto.src.bitmaps = r->d_bitmap_table.ptr;
+    sc.proto = proto;
     Frame2 fr[4];
     std::memset(fr, 0, sizeof fr);
     for (int k = 0; k < 4; ++k) {
@@ -1041,6 +1059,84 @@ int render_batch2(swfr_renderer* r, const swfr_stage* stages, uint32_t n, void* 
     return rc;
 }
 
+// The resident scene as `per_launch` frames per kernel launch (blockIdx.y = frame, every frame with its own kernel-written buffers
+// and its own framebuffer), `launches` times back to back on one stream: the GPU saturated by one scene -- what frames in flight
+// approximate with streams.  Every frame recomputes everything from the raw edge list, as in swfr_render_resident.
+int render_resident_batched(swfr_renderer* r, uint32_t per_launch, uint32_t launches, float* ms_out) {
+    if (!r->has_device) return fail(r, SWFR_ERR_NO_DEVICE, "host-only handle cannot rasterize");
+    if (!r->scene_ready) return fail(r, SWFR_ERR_INVALID, "no scene uploaded");
+    if (per_launch == 0 || per_launch > 64 || launches == 0) return fail(r, SWFR_ERR_INVALID, "1..64 frames per launch, at least one launch");
+    // which queued-row kernels the scene needs: from a blocking frame of the scene itself
+    if (!r->scn[0].slow_verified) { const int rc = render_resident(r, 1); if (rc != SWFR_OK) return rc; }
+    const swfr_renderer::Scene& sc = r->scn[0];
+    const uint32_t B = per_launch, tiles_x = (r->width + TILE_W - 1) / TILE_W;
+    auto pad = [](size_t b) { return (b + 255) & ~size_t(255); };
+    const size_t n_px = size_t(r->width) * r->height;
+    const size_t work_one = pad(sc.n_edges * sizeof(DevEdge)) + pad(sc.n_slots * sizeof(BandEntry2)) + pad((sc.n_slots * TILE_H + 64) * sizeof(RowInfo2)) +
+                            pad(sc.cell_total * sizeof(Cell)) + 2 * pad(2 * (sc.n_rows + 64) * sizeof(SlowRow)) + 2 * pad((sc.n_paths + 64) * sizeof(uint32_t)) +
+                            pad((sc.n_chunks + 1) * sizeof(ChunkInfo)) + pad((sc.n_slots + 1) * sizeof(BandSlot)) + pad((sc.n_strip_slots + 1) * sizeof(StripDesc)) +
+                            pad((sc.n_strips + 1) * sizeof(uint32_t)) + pad(COUNTER_WORDS * sizeof(uint32_t));
+    const size_t cls_one = pad(STRIPS_PER_TILE * sc.n_slots * tiles_x + 64);
+    const hipStream_t st = r->stream;
+    r->rb_work.reserve(work_one * B + 4096); r->rb_cls.reserve(cls_one * B + 4096); r->rb_frames.reserve(B); r->rb_fb.reserve(n_px * B);
+    HIP_CHECK(hipMemsetAsync(r->rb_work.ptr, 0, work_one * B, st));           // (strip costs start at zero; class bytes outside the paths' rectangles)
+    HIP_CHECK(hipMemsetAsync(r->rb_cls.ptr, 0, cls_one * B, st));
+    std::vector<Frame2> fr(B);
+    uint8_t* w = r->rb_work.ptr;
+    auto carve = [&](size_t bytes) { uint8_t* q = w; w += pad(bytes); return q; };
+    for (uint32_t k = 0; k < B; ++k) {
+        Frame2& f = fr[k];
+        f = sc.proto;
+        f.edges = reinterpret_cast<DevEdge*>(carve(sc.n_edges * sizeof(DevEdge)));
+        f.band_list = reinterpret_cast<BandEntry2*>(carve(sc.n_slots * sizeof(BandEntry2)));
+        f.rows = reinterpret_cast<RowInfo2*>(carve((sc.n_slots * TILE_H + 64) * sizeof(RowInfo2)));
+        f.cells = reinterpret_cast<Cell*>(carve(sc.cell_total * sizeof(Cell)));
+        f.slow = reinterpret_cast<SlowRow*>(carve(2 * (sc.n_rows + 64) * sizeof(SlowRow)));
+        f.huge = reinterpret_cast<SlowRow*>(carve(2 * (sc.n_rows + 64) * sizeof(SlowRow)));
+        f.path_flag = reinterpret_cast<uint32_t*>(carve((sc.n_paths + 64) * sizeof(uint32_t)));
+        f.path_queue = reinterpret_cast<uint32_t*>(carve((sc.n_paths + 64) * sizeof(uint32_t)));
+        f.chunks = reinterpret_cast<ChunkInfo*>(carve((sc.n_chunks + 1) * sizeof(ChunkInfo)));
+        f.band_slots = reinterpret_cast<BandSlot*>(carve((sc.n_slots + 1) * sizeof(BandSlot)));
+        f.strips = reinterpret_cast<StripDesc*>(carve((sc.n_strip_slots + 1) * sizeof(StripDesc)));
+        f.strip_cost = reinterpret_cast<uint32_t*>(carve((sc.n_strips + 1) * sizeof(uint32_t)));
+        f.counters = reinterpret_cast<uint32_t*>(carve(COUNTER_WORDS * sizeof(uint32_t)));
+        f.cls = r->rb_cls.ptr + cls_one * k;
+        f.fb = r->rb_fb.ptr + n_px * k;
+    }
+    HIP_CHECK(hipMemcpyAsync(r->rb_frames.ptr, fr.data(), B * sizeof(Frame2), hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipStreamSynchronize(st));                       // (fr is a local)
+    if (!r->rb_ev[0]) { HIP_CHECK(hipEventCreate(&r->rb_ev[0])); HIP_CHECK(hipEventCreate(&r->rb_ev[1])); }
+    auto one_launch = [&]() {
+        launch2_bin(st, r->rb_frames.ptr, B, uint32_t(std::max(sc.n_edges, sc.n_paths)), uint32_t(sc.n_bands));
+        launch2_rows(st, r->rb_frames.ptr, B, uint32_t(sc.n_chunks));
+        if (sc.n_chunks && sc.slow_state != 1) launch2_rows_slow(st, r->rb_frames.ptr, B, 256u, sc.slow_state == 2 ? 0u : 64u, sc.slow_passes);
+        launch2_tiles(st, r->rb_frames.ptr, B, uint32_t(sc.n_strip_slots), ~0u, sc.shader_level);
+    };
+    one_launch();                                              // warm-up: leaves a cost history for the strip order
+    HIP_CHECK(hipEventRecord(r->rb_ev[0], st));
+    for (uint32_t l = 0; l < launches; ++l) one_launch();
+    HIP_CHECK(hipEventRecord(r->rb_ev[1], st));
+    HIP_CHECK(hipGetLastError());
+    std::vector<uint32_t> hc(size_t(B) * COUNTER_WORDS);
+    for (uint32_t k = 0; k < B; ++k)
+        HIP_CHECK(hipMemcpyAsync(hc.data() + size_t(k) * COUNTER_WORDS, fr[k].counters, COUNTER_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    float ms = 0;
+    HIP_CHECK(hipEventElapsedTime(&ms, r->rb_ev[0], r->rb_ev[1]));
+    if (ms_out) *ms_out = ms;
+    r->rb_count = B;
+    r->fb_cur = fr[B - 1].fb;
+    r->fb_valid = true;
+    int rc = SWFR_OK;
+    for (uint32_t k = 0; k < B && rc == SWFR_OK; ++k) {
+        const uint32_t* c = hc.data() + size_t(k) * COUNTER_WORDS;
+        // a frame that queued rows for kernels this call did not launch is not valid
+        if ((sc.slow_state == 1 && c[C2_SLOW]) || (sc.slow_state == 2 && c[C2_HUGE])) rc = fail(r, SWFR_ERR_DEVICE, "queued rows without their kernels in a batched launch");
+        if (rc == SWFR_OK) rc = check_counters(r, c);
+    }
+    return rc;
+}
+
 int render_batch(swfr_renderer* r, const swfr_stage* stages, uint32_t n, void* device_dst, size_t frame_stride) {
     if (!r->has_device) return fail(r, SWFR_ERR_NO_DEVICE, "host-only handle cannot rasterize");
     if (n == 0) return SWFR_OK;
@@ -1085,6 +1181,38 @@ int render_batch(swfr_renderer* r, const swfr_stage* stages, uint32_t n, void* d
         for (uint32_t i = 0; i < n && rc == SWFR_OK; ++i) rc = check_counters(r, hc + size_t(i) * COUNTER_WORDS);
     (void)hipHostFree(hc);
     return rc;
+}
+
+// Mapped read-back of the last frame: the framebuffer (or its un-premultiplied copy) goes to the handle's PINNED staging buffer by
+// one asynchronous copy on the handle's stream behind the frame's kernels, and the caller reads it there (a pageable destination makes
+// the runtime stage the copy through its own pinned pieces and a host memcpy: 2.3 ms for a 4K frame instead of 0.6).
+int start_read(swfr_renderer* r, int premultiplied) {
+    if (r->read_pending) { HIP_CHECK(hipEventSynchronize(r->read_done)); r->read_pending = false; }      // (an earlier read-back nobody waited for)
+    const size_t n = size_t(r->width) * r->height, bytes = n * 4;
+    const uint32_t* src = r->fb_cur ? r->fb_cur : r->fs[0].d_fb.ptr;
+    if (!src) return fail(r, SWFR_ERR_INVALID, "no framebuffer");
+    if (!premultiplied) {
+        r->d_tmp.reserve(n);
+        launch_unpremultiply(r->stream, src, r->d_tmp.ptr, n);
+        src = r->d_tmp.ptr;
+    }
+    if (r->h_image_cap < bytes) {
+        if (r->h_image) (void)hipHostFree(r->h_image);
+        r->h_image = nullptr; r->h_image_cap = 0;
+        HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&r->h_image), bytes, hipHostMallocDefault));
+        r->h_image_cap = bytes;
+    }
+    if (!r->read_done) HIP_CHECK(hipEventCreateWithFlags(&r->read_done, hipEventDisableTiming));
+    HIP_CHECK(hipMemcpyAsync(r->h_image, src, bytes, hipMemcpyDeviceToHost, r->stream));
+    HIP_CHECK(hipEventRecord(r->read_done, r->stream));
+    r->read_pending = true;
+    return SWFR_OK;
+}
+int finish_read(swfr_renderer* r) {
+    if (!r->read_pending) return fail(r, SWFR_ERR_INVALID, "no read-back in flight");
+    HIP_CHECK(hipEventSynchronize(r->read_done));
+    r->read_pending = false;
+    return SWFR_OK;
 }
 
 }  // namespace
@@ -1276,6 +1404,34 @@ int swfr_render_sequence(swfr_renderer* r, const swfr_stage* stages, uint32_t n_
     return SWFR_OK;
 }
 
+// render + get_image per frame, the loop of the reference's own tests (HeadlessGfxRenderer::get_image after every render,
+// rs/src/headless_renderer.rs:233-244): the mapped read-back of every frame, waited for at once (overlap == 0) or after the NEXT
+// frame's swfr_render has returned -- its copy then overlaps that frame's host build (overlap != 0).  *checksum: the sum of one
+// pixel per frame, so that every frame's image has been looked at.
+int swfr_render_sequence_readback(swfr_renderer* r, const swfr_stage* stages, uint32_t n_stages, uint32_t repeat, int premultiplied, int overlap,
+                                  double* seconds, uint64_t* checksum) {
+    if (!r || (!stages && n_stages) || !seconds) return fail(r, SWFR_ERR_INVALID, "null argument");
+    const auto t0 = std::chrono::steady_clock::now();
+    uint64_t sum = 0;
+    bool pending = false;
+    const uint8_t* data = nullptr;
+    const size_t mid = (size_t(r->height / 2) * r->width + r->width / 2) * 4;
+    for (uint32_t rep = 0; rep < repeat; ++rep)
+        for (uint32_t i = 0; i < n_stages; ++i) {
+            int rc = swfr_render(r, &stages[i]);
+            if (rc != SWFR_OK) return rc;
+            if (pending) { rc = swfr_read_image_wait(r, &data, nullptr); if (rc != SWFR_OK) return rc; sum += data[mid] + data[mid + 3]; pending = false; }
+            rc = swfr_read_image_async(r, premultiplied);
+            if (rc != SWFR_OK) return rc;
+            pending = true;
+            if (!overlap) { rc = swfr_read_image_wait(r, &data, nullptr); if (rc != SWFR_OK) return rc; sum += data[mid] + data[mid + 3]; pending = false; }
+        }
+    if (pending) { const int rc = swfr_read_image_wait(r, &data, nullptr); if (rc != SWFR_OK) return rc; sum += data[mid] + data[mid + 3]; }
+    *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (checksum) *checksum = sum;
+    return SWFR_OK;
+}
+
 int swfr_render_batch(swfr_renderer* r, const swfr_stage* stages, uint32_t n_stages, void* device_dst, size_t frame_stride) {
     if (!r || (!stages && n_stages)) return fail(r, SWFR_ERR_INVALID, "null argument");
     if (!r->has_device) return fail(r, SWFR_ERR_NO_DEVICE, "host-only handle cannot rasterize");
@@ -1299,6 +1455,28 @@ int swfr_read_image(swfr_renderer* r, uint8_t* dst, size_t dst_stride, int premu
         HIP_CHECK(hipStreamSynchronize(r->stream));
         return int(SWFR_OK);
     });
+}
+
+int swfr_read_image_async(swfr_renderer* r, int premultiplied) {
+    if (!r) return SWFR_ERR_INVALID;
+    if (!r->has_device) return fail(r, SWFR_ERR_NO_DEVICE, "host-only handle has no image");
+    if (!r->fb_valid) return fail(r, SWFR_ERR_INVALID, "nothing rendered yet");
+    return guarded(r, [&]() { return start_read(r, premultiplied); });
+}
+
+int swfr_read_image_wait(swfr_renderer* r, const uint8_t** data, size_t* stride) {
+    if (!r || !data) return fail(r, SWFR_ERR_INVALID, "null argument");
+    if (!r->has_device) return fail(r, SWFR_ERR_NO_DEVICE, "host-only handle has no image");
+    return guarded(r, [&]() {
+        const int rc = finish_read(r);
+        if (rc == SWFR_OK) { *data = r->h_image; if (stride) *stride = size_t(r->width) * 4; }
+        return rc;
+    });
+}
+
+int swfr_render_resident_batched(swfr_renderer* r, uint32_t frames_per_launch, uint32_t launches, float* total_ms) {
+    if (!r) return SWFR_ERR_INVALID;
+    return guarded(r, [&]() { return render_resident_batched(r, frames_per_launch, launches, total_ms); });
 }
 
 int swfr_shape_json(swfr_renderer* r, uint32_t id, int morph, const char** json) {

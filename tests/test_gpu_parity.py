@@ -167,6 +167,36 @@ def test_edges_outside_every_path_and_overlapping_edge_ranges_are_refused():
         r.close()
 
 
+def test_resident_scene_as_frames_per_launch_and_mapped_read_back():
+    """swfr_render_resident_batched (the saturated-GPU measurement of bench.py): every frame of every launch is a full recomputation
+    into its own buffers -- the last one equals the oracle, for a scene with queued rows too; swfr_read_image_async/_wait hand out the
+    same pixels as swfr_read_image, and the render + read-back loop timed below the ABI leaves the last frame readable."""
+    import swf_renderer_amd as S
+    from swf_renderer_amd import api
+    for name in ("translucent_stack", "morph_round_stroke_090", "fixture_homestuck-beta-1"):
+        sc = SC[name]
+        r = S.Renderer(sc["width"], sc["height"])
+        try:
+            host = S.Renderer(sc["width"], sc["height"], device=api.DEVICE_HOST_ONLY)
+            scene = host.build_frame(sc["stage"])
+            host.close()
+            r.upload_edges(*scene)
+            ms = r.render_resident_batched(5, 3)
+            assert ms > 0
+            want = oracle_render(sc)
+            got = r.read_image(premultiplied=True)
+            assert diff_stats(got, want) == (0, 0), name
+            r.read_image_async(premultiplied=True)
+            assert (np.asarray(r.read_image_wait()) == got).all()
+            r.read_image_async(premultiplied=False)
+            assert (np.asarray(r.read_image_wait()) == r.read_image(premultiplied=False)).all()
+            for overlap in (True, False):
+                assert r.render_sequence_readback([sc["stage"], sc["stage"]], 2, premultiplied=True, overlap=overlap) > 0
+                assert diff_stats(r.read_image(premultiplied=True), want) == (0, 0), (name, overlap)
+        finally:
+            r.close()
+
+
 # ---- BASELINE config 3: 256 morph ratios through one handle (reduced frame; oracle finishes in seconds)
 def test_morph_256_ratios_vs_oracle():
     import swf_renderer_amd as S
