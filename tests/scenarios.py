@@ -101,6 +101,27 @@ def scenarios():
     lin = {"type": "linear-gradient", "matrix": _m(1000 / 16384, 1000 / 16384, 1300, 1100, 0.02, 0.0),
            "gradient": _grad([(0, (0, 0, 0)), (80, (255, 128, 0)), (255, (255, 255, 255))])}
     out["gradient_linear_ext"] = dict(width=130, height=115, exact=False, stage={"children": [{"type": "shape", "definition": _poly_shape(circ, lin)}]})
+    # --- BASELINE config 2, gradient half: the same radial / focal / linear(-extension) fills scaled to 1024x1024 through the
+    #     placement matrix ("scale the placement matrix, not the twips")
+    gsx, gsy = 1024 / 130, 1024 / 115
+    for gname, gfill, gexact in (("radial", rad, True), ("focal", foc, True), ("linear_ext", lin, False)):
+        out["config2_gradient_" + gname] = dict(width=1024, height=1024, exact=gexact, stage={"children": [
+            {"type": "shape", "definition": _poly_shape(circ, gfill), "matrix": _m(gsx, gsy, 0, 0)}]})
+    # --- colour quantisation pins: translucent solids at alpha 1, 37, 127, 128, 200, 254 over an opaque backdrop and over each other
+    #     (the Cairo half of fromNormalizedColor: css-color.ts:11-13 -> node-canvas parse -> 8-bit premultiplied source), and an
+    #     interpolated morph colour (fractional channels and alpha) at ratio 0.3
+    kids = [{"type": "shape", "definition": _poly_shape([(100, 100), (1900, 150), (1850, 900), (150, 850)], {"type": "solid", "color": _rgba(250, 240, 20)})}]
+    for i, a in enumerate((1, 37, 127, 128, 200, 254)):
+        x = 60 + 300 * i
+        kids.append({"type": "shape", "definition": _poly_shape([(x, 40 + 30 * i), (x + 520, 300), (x + 430, 1900 - 40 * i), (x - 30, 1500)],
+                                                                {"type": "solid", "color": _rgba(30 + 35 * i, 200 - 30 * i, 90 + 25 * i, a)})})
+    out["alpha_sweep"] = dict(width=110, height=100, exact=True, stage={"children": kids})
+    ctag = json.loads(json.dumps(load_fixture("homestuck-beta-29")))
+    for i, fl in enumerate(ctag["shape"]["initial_styles"]["fill"]):
+        fl["color"], fl["morph_color"] = _rgba(200 - 60 * i, 40 + 50 * i, 40, 255), _rgba(40, 220 - 70 * i, 90 + 60 * i, 100 + 70 * i)
+    out["morph_color_030"] = dict(width=w, height=h, exact=True, stage={"children": [
+        {"type": "shape", "definition": _poly_shape([(0, 0), (w * 20, 0), (w * 20, h * 10), (0, h * 12)], {"type": "solid", "color": _rgba(10, 20, 30)})},
+        {"type": "morph-shape", "definition": ctag, "ratio": 0.3, "matrix": _m(tx=-x0, ty=-y0)}]})
     # --- translucent paths over each other, nested containers, even-odd
     star = [(1000 + (900 if k % 2 == 0 else 350) * math.cos(2 * math.pi * k / 10 + 0.3),
              1000 + (900 if k % 2 == 0 else 350) * math.sin(2 * math.pi * k / 10 + 0.3)) for k in range(10)]

@@ -57,6 +57,26 @@ for k, name in enumerate(("k2_bin", "k2_rows", "k2_tiles")):
         alive = np.cumsum(ev[:, 1])
         print("   workgroups alive: max %d, time-weighted mean %.0f" % (alive.max(), float((alive[:-1] * np.diff(ev[:, 0])).sum() / max(ev[-1, 0] - ev[0, 0], 1))))
     if name == "k2_rows":
+        # which wavefronts are the slow ones: duration against the chunk's path (width, rows of the path in the chunk)
+        raw = buf[k].astype(np.int64)
+        edges_a, paths_a, _ = scene
+        cr = int(os.environ.get("SWFR_CHUNK_ROWS", "64"))
+        rows_, widths_, nedge_ = [], [], []
+        for pth in paths_a:
+            if pth["y_max"] <= pth["y_min"]: continue
+            a0 = int(pth["y_min"]) // 16 * 16
+            for c0 in range(a0, int(pth["y_max"]), cr):
+                rows_.append(min(c0 + cr, int(pth["y_max"])) - max(c0, int(pth["y_min"])))
+                widths_.append(int(pth["x_max"]) - int(pth["x_min"]))
+                nedge_.append(int(pth["n_edges"]))
+        nck = min(len(rows_), len(raw))
+        dd = (raw[:nck, 7] - raw[:nck, 0]) * 0.01
+        rows_, widths_ = np.array(rows_[:nck]), np.array(widths_[:nck])
+        order = np.argsort(-dd)[:12]
+        print("   slowest wavefronts (us, path width, live rows): " + ", ".join("%.1f/%d/%d" % (dd[i], widths_[i], rows_[i]) for i in order))
+        for lo, hi in ((0, 64), (64, 128), (128, 256), (256, 384), (384, 1024)):
+            m = (widths_ >= lo) & (widths_ < hi)
+            if m.any(): print("   path width %4d..%4d: %5d wavefronts, duration p50 %.1f max %.1f us, live rows mean %.0f" % (lo, hi, m.sum(), np.percentile(dd[m], 50), dd[m].max(), rows_[m].mean()))
         d = (b[:, 1] - b[:, 0]) * 0.01
         print("   descriptor + chunk count p50 %.2f p90 %.2f us" % tuple(np.percentile(d, [50, 90])))
 r.close()
