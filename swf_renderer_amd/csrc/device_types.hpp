@@ -12,7 +12,7 @@ constexpr int TILE_H = 16;   // tile-rows ("bands") are the unit of band lists a
 constexpr int STRIP_H = 8;   // pixel rows per k2_tiles wavefront: a 64x16 tile is rasterized as two independent 64x8 strips
 constexpr int STRIPS_PER_TILE = TILE_H / STRIP_H;
 
-// Per-edge constants of the tor scan converter (SURVEY.md A.5 make_edge), 64 bytes.
+// Per-edge constants of the tor scan converter (SURVEY.md A.5 make_edge), 96 bytes.
 struct DevEdge {
     int32_t ytop, ybot;      // active sub-rows [ytop, ybot), 15 per pixel row, clamped to the path's rows
     int32_t x1, y1;          // upper end point of the line (24.8)
@@ -23,8 +23,14 @@ struct DevEdge {
     int64_t dy;              // (y2 - y1) * 15 * 512, 0 for vertical edges
     int64_t dq, dr;          // per-sub-row slope: truncated quotient / remainder of ex*512 / dy
     double inv_dy;           // 1.0 / dy (correctly rounded): quotient estimates need one multiply, the integer fix-up makes them exact
+    // constants of the rows the edge crosses completely (A.5 render_edge; all zero for vertical edges): over one pixel row x advances
+    // by 7680 * ex / dy exactly, so the row's extent in units of 1/dy is the same for every such row
+    double inv_dx;           // 1.0 / (7680 * |ex|)
+    int64_t fr;              // floor_div(3840 * dy, 7680 * |ex|): sample rows per pixel column, quotient fq / remainder fr
+    int64_t r15;             // floor_div(7680 * ex, dy): x advance per pixel row, quotient q15 / remainder r15 (edges at least 200/256 px tall)
+    int32_t fq, q15;
 };
-static_assert(sizeof(DevEdge) == 64, "DevEdge layout");
+static_assert(sizeof(DevEdge) == 96, "DevEdge layout");
 
 using DevPath = swfr_path;   // 40 bytes: first_edge, n_edges, kind, fill_rule, style, lerp, pixel rect
 

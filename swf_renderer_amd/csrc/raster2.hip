@@ -109,16 +109,25 @@ __device__ __forceinline__ int full_span(int32_t q1, int32_t q2) {
 // Cells of a FULL-row edge (A.5 render_edge) from its exact x at the row top (q1 + r1/dy) and bottom (q2 + r2/dy); writes exactly
 // full_span(q1, q2) cells.  An edge that spans more columns than that has at most 17 cells with a non-zero height (the heights add
 // up to the row's fifteen sample rows): the zero ones are skipped.
-__device__ __forceinline__ void full_cells(int32_t q1, int64_t r1, int32_t q2, int64_t r2, int64_t edy, int sign, int xminp, int xmaxp, Cell* __restrict__ dst) {
+// inv_dx, fq0, fr0: the edge's constants (DevEdge): 1 / dx and floor_div(15 * 256 * edy, dx) -- dx, the row's x extent in units of
+// 1 / edy, is 7680 * |ex| in every row the edge crosses completely
+__device__ __forceinline__ void full_cells(int32_t q1, int64_t r1, int32_t q2, int64_t r2, int64_t edy, double inv_dx, int32_t fq0, int64_t fr0, int sign, int xminp, int xmaxp, Cell* __restrict__ dst) {
     int ix1 = q1 >> 8, f1 = q1 & 255, ix2 = q2 >> 8, f2 = q2 & 255;
     if (ix1 == ix2) { put_cell_h(dst, ix1, sign * 15, f1 + f2, xminp, xmaxp); return; }
     if (ix2 < ix1) { int t = ix1; ix1 = ix2; ix2 = t; t = f1; f1 = f2; f2 = t; int32_t tq = q1; q1 = q2; q2 = tq; int64_t tr = r1; r1 = r2; r2 = tr; }
     const int span = ix2 - ix1 + 1;
     const int64_t dx = (int64_t)(q2 - q1) * edy + (r2 - r1);
     const int64_t t0 = ((int64_t)((ix1 + 1) * 256 - q1) * edy - r1) * 15;
-    int64_t yq, yr, fq = 0, fr = 0;
-    floor_div(t0, dx, yq, yr);
-    if (span > 2) floor_div(15ll * 256 * edy, dx, fq, fr);
+    int64_t yq, yr;
+    floor_div_inv(t0, dx, inv_dx, yq, yr);
+    const int64_t fq = fq0, fr = fr0;
+#ifdef SWFR_EMU
+    {   // (emulator builds check the per-edge constants against the row's own numbers)
+        int64_t cq, cr2; floor_div(15ll * 256 * edy, dx, cq, cr2);
+        int64_t dq2, dr2; floor_div(t0, dx, dq2, dr2);
+        if (cq != fq || cr2 != fr || dq2 != yq || dr2 != yr || inv_dx != 1.0 / (double)dx) { std::fprintf(stderr, "full_cells: per-edge row constants disagree\n"); std::abort(); }
+    }
+#endif
     int y_prev = (int)yq;
     if (span <= MAX_CELLS_PER_EDGE_ROW) {
         put_cell_h(dst, ix1, sign * y_prev, 256 + f1, xminp, xmaxp);
@@ -448,7 +457,10 @@ __device__ __forceinline__ void rows2_fast(EPTR E, uint32_t n_list, const DevPat
             int c0 = e.x1, c1 = e.x1, cpv = e.x1;
             if (e.dy) {
                 edge_x_at(e, s0, qa, ra);
-                edge_x_at(e, s0 + 15, qb, rb);
+                // fifteen sample rows on: + 7680 * ex / dy, the same floor representation (quotient, remainder in [0, dy)) as
+                // edge_x_at(e, s0 + 15) gives -- it is unique
+                qb = qa + e.q15; rb = ra + e.r15;
+                if (rb >= e.dy) { ++qb; rb -= e.dy; }
                 c0 = cell_of(qa, ra, e.dy);
                 c1 = cell_of(qb, rb, e.dy);
                 cpv = c0;
@@ -565,7 +577,7 @@ __device__ __forceinline__ void rows2_fast(EPTR E, uint32_t n_list, const DevPat
             if (s >= nmax) continue;
             if (s < n && roles[s] != 0) {
                 const int64_t edy = E[el[s]].dy;
-                full_cells(Q1[s], R1[s], Q2[s], R2[s], edy, ((uint32_t)roles[s] & 1u) ? +1 : -1, P.x_min, P.x_max, &FR->cells[off]);
+                full_cells(Q1[s], R1[s], Q2[s], R2[s], edy, E[el[s]].inv_dx, E[el[s]].fq, E[el[s]].fr, ((uint32_t)roles[s] & 1u) ? +1 : -1, P.x_min, P.x_max, &FR->cells[off]);
                 off += (uint32_t)full_span(Q1[s], Q2[s]);
             }
         }
@@ -1201,7 +1213,7 @@ __device__ __forceinline__ void slow_row_body(FramePtr FR, const SlowRow sr, uin
     const uint32_t base = alloc_cells(FR, total, lane);
     if (has && base != ~0u) {
         Cell* dst = &FR->cells[base + incl - (uint32_t)n_cells];
-        if (role & REC_FULL) full_cells(q1, r1, q2, r2, e.dy, (role & 1u) ? +1 : -1, P.x_min, P.x_max, dst);
+        if (role & REC_FULL) full_cells(q1, r1, q2, r2, e.dy, e.inv_dx, e.fq, e.fr, (role & 1u) ? +1 : -1, P.x_min, P.x_max, dst);
         else {
             for (int sub = 0; sub < 15; ++sub) {
                 const uint32_t f = (role >> (2 * sub)) & 3u;
@@ -1433,7 +1445,7 @@ __device__ __forceinline__ void huge_row_body(FramePtr FR, const SlowRow sr, uin
             if (role[m] & REC_FULL) {
                 int c0, c1, cpv; int32_t q1, q2; int64_t r1, r2;
                 huge_full_keys(e, s0, c0, c1, cpv, q1, r1, q2, r2);
-                full_cells(q1, r1, q2, r2, e.dy, (role[m] & 1u) ? +1 : -1, P.x_min, P.x_max, dst);
+                full_cells(q1, r1, q2, r2, e.dy, e.inv_dx, e.fq, e.fr, (role[m] & 1u) ? +1 : -1, P.x_min, P.x_max, dst);
                 dst += full_span(q1, q2);
             } else {
                 for (int sub = 0; sub < 15; ++sub) {
@@ -1830,7 +1842,7 @@ __device__ __forceinline__ void tiles3_body(FramePtr FR) {
                         if (ty0 + cr < height) {
                             const uint2 hq = *reinterpret_cast<const uint2*>(&hdr[li][2 * cr]);
                             off = hq.x; n_c = (int)(hq.y & 0xffffu);
-                            if ((uint64_t)off + (uint32_t)n_c > (uint64_t)FR->cell_slice) { atomicOr(&FR->counters[C2_ERROR], E2_CELL_RANGE); n_c = 0; }
+                            if (off > FR->cell_slice - min((uint32_t)n_c, FR->cell_slice)) { atomicOr(&FR->counters[C2_ERROR], E2_CELL_RANGE); n_c = 0; }   // off + n_c > cell_slice
                         }
                         const Cell* __restrict__ cp = FR->cells + off;
                         // the first sixteen cells of every row in one round trip, the rest (long shallow edges) eight per round

@@ -8,6 +8,10 @@
 // the CPU scan converter.  No MFMA: there is no dense contraction on this path; the roof is HBM bandwidth.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#ifdef SWFR_EMU
+#include <cstdio>
+#include <cstdlib>
+#endif
 
 #include "device_types.hpp"
 
@@ -79,6 +83,7 @@ __device__ __forceinline__ int wave_scan_incl(int v) {
 __device__ __forceinline__ DevEdge make_dev_edge(const swfr_edge& e, const DevPath& p) {
     DevEdge d;
     d.x1 = e.x1; d.y1 = e.y1; d.dir = e.dir; d.pad = 0; d.inv_dy = 0.0;
+    d.inv_dx = 0.0; d.fr = 0; d.r15 = 0; d.fq = 0; d.q15 = 0;
     if (p.kind != SWFR_PATH_TOR) {          // boxes are consumed raw by k2_tiles
         d.ytop = d.ybot = 0; d.dy = 0; d.ex = 0; d.dq = d.dr = 0;
         return d;
@@ -95,6 +100,14 @@ __device__ __forceinline__ DevEdge make_dev_edge(const swfr_edge& e, const DevPa
         d.dy = (int64_t)(e.y2 - e.y1) * 15 * 512;
         d.inv_dy = 1.0 / (double)d.dy;
         trunc_div(d.ex * 512, d.dy, d.dq, d.dr);
+        const int64_t adx = (d.ex < 0 ? -d.ex : d.ex) * 7680;
+        d.inv_dx = 1.0 / (double)adx;
+        int64_t fq; floor_div_inv(3840 * d.dy, adx, d.inv_dx, fq, d.fr);     // (estimates from the reciprocals, exact after the integer fix-up)
+        d.fq = (int32_t)fq;                                   // (dy < 2^37, |ex| >= 256: below 2^28)
+        if (e.y2 - e.y1 >= 200) {                             // only an edge that crosses a whole pixel row (>= 14/15 px tall) is ever stepped by a row
+            int64_t q15; floor_div_inv(d.ex * 7680, d.dy, d.inv_dy, q15, d.r15);
+            d.q15 = (int32_t)q15;                             // (|ex| <= 2^32, dy >= 200 * 7680: below 2^25)
+        }
     }
     return d;
 }
@@ -113,7 +126,9 @@ __device__ __forceinline__ DevEdge make_dev_edge(const swfr_edge& e, const DevPa
 
 #define ROWS_FAST_N 8            // active edges per row handled in registers by k2_rows
 #define ROWS_BIG_MAXA 64         // capacity of the generic (LDS list) routine of k2_rows_slow
-#define ROWS_STAGE 48            // chunks with at most this many edges of their path in reach are staged into LDS
+#ifndef ROWS_STAGE
+#define ROWS_STAGE 32            // chunks with at most this many edges of their path in reach are staged into LDS (3 KB of 96-byte records:
+#endif                           // with 4.5 KB -- 48 of them -- two wavefronts fewer fit a CU and the pipelined frame rate drops by a tenth)
 
 // All edges of one path, whichever form the kernel has them in (k_front's DevEdge array, or the raw edges when the row pass
 // computes the constants itself).

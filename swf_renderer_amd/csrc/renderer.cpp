@@ -186,7 +186,7 @@ struct swfr_renderer {
     DevBuf<DevBitmap> d_bitmap_table;
     DevBuf<uint32_t> d_tmp;
     DevBuf<uint32_t> d_counters;            // 4 x COUNTER_WORDS: the frame sets' counters, contiguous
-    int in_flight = 3;
+    int in_flight = 4;
     bool scene_from_builder = false;        // the scene in slot 0 is the frame builder's last frame (its arrays are still there)
     uint32_t sets_ready = 0;                // frame sets whose descriptors belong to the scene in slot 0 (swfr_render prepares one, swfr_upload_edges all)
     int hint_slow_state = 0; uint32_t hint_slow_passes = SLOW_PASSES;   // what the last rendered scene needed of the queued-row kernels
@@ -558,11 +558,22 @@ void layout_scene(const swfr_renderer* r, const swfr_edge* edges, size_t n_edges
     const uint32_t tiles_x = (r->width + TILE_W - 1) / TILE_W;
     // rows per k2_rows wavefront: 64 when that already gives the GPU a thousand wavefronts, fewer (whole tile-rows) for scenes made
     // of a few tall paths
+    // (a handle that owns a share of the tile-rows counts the chunks that have rows of its own: the others exit at once, and a
+    //  rank with an eighth of the frame wants its thousand wavefronts from that eighth)
+    const BandShare share = band_share(r);
+    auto owns_tile_row = [&](uint32_t t) { return t >= share.first && (t - share.first) % share.stride == 0 && (t - share.first) / share.stride < share.count; };
     auto count_chunks = [&](uint32_t cr) {
         size_t n = 0;
-        for (size_t i = 0; i < n_paths; ++i)
-            if (paths[i].kind == SWFR_PATH_TOR && paths[i].y_max > paths[i].y_min)
-                n += (size_t(paths[i].y_max) - size_t(paths[i].y_min) / TILE_H * TILE_H + cr - 1) / cr;
+        for (size_t i = 0; i < n_paths; ++i) {
+            if (paths[i].kind != SWFR_PATH_TOR || paths[i].y_max <= paths[i].y_min) continue;
+            const uint32_t a0 = uint32_t(paths[i].y_min) / TILE_H * TILE_H, y1 = uint32_t(paths[i].y_max);
+            if (r->cfg.band_count <= 1) { n += (y1 - a0 + cr - 1) / cr; continue; }
+            for (uint32_t a = a0; a < y1; a += cr) {
+                bool live = false;
+                for (uint32_t t = a / TILE_H; t < (std::min(a + cr, y1) + TILE_H - 1) / TILE_H && !live; ++t) live = owns_tile_row(t);
+                n += live ? 1 : 0;
+            }
+        }
         return n;
     };
     L.chunk_rows = ROWS_CHUNK;

@@ -128,8 +128,8 @@ class FramePipeline:
     def __init__(self, renderer, width, height, rank, world, device="cuda", depth=None, dst=0, frames_device="cuda"):
         import os
         import torch
-        if depth is None:                                            # one buffer per frame set of the handle (SWFR_FRAMES_IN_FLIGHT, default 3)
-            depth = min(4, max(1, int(os.environ.get("SWFR_FRAMES_IN_FLIGHT", "3"))))
+        if depth is None:                                            # one buffer per frame set of the handle (SWFR_FRAMES_IN_FLIGHT, default 4)
+            depth = min(4, max(1, int(os.environ.get("SWFR_FRAMES_IN_FLIGHT", "4"))))
         self.r, self.w, self.h, self.rank, self.world, self.dst = renderer, width, height, rank, world, dst
         self.on_gpu = device != "cpu"                                # where the collective runs (NCCL/RCCL on device tensors, gloo on CPU ones)
         self.streams = frames_device != "cpu"                        # False only under tools/emu, whose "device" memory is host memory

@@ -1,7 +1,7 @@
 #!/bin/bash
 # ablation of k2_tiles (timing-only builds: wrong pixels): per variant the bench line's kernel times and the SQ instruction counts
 R=$GRAFT_REPO_ROOT; cd /tmp; export TMPDIR=/tmp
-B="--no-cpu-baseline --no-full-path --no-verify"
+B="--no-cpu-baseline --no-full-path --no-verify --no-batched"
 for v in "$@"; do
   lib=build/$v/libswfr.so; [ "$v" = base ] && lib=swf_renderer_amd/libswfr.so
   python3 $R/tools/bench_with_lib.py $lib --steps 200 --warmup 20 $B 2>/dev/null | python3 -c "

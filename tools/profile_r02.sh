@@ -6,7 +6,7 @@ TAG=${1:-prof}; shift
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py --steps 300 --warmup 30 "$@" > $R/gpurun_out/${TAG}_bench.json 2> $R/gpurun_out/${TAG}_bench.err || { tail -5 $R/gpurun_out/${TAG}_bench.err; exit 1; }
-B="--no-cpu-baseline --no-full-path --no-verify"
+B="--no-cpu-baseline --no-full-path --no-verify --no-batched"
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_trace --output-format csv -- python3 $R/bench.py --steps 100 --warmup 10 $B "$@" > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/${TAG}_fetch --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 $B "$@" > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/${TAG}_write --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 $B "$@" > /dev/null 2>&1
