@@ -712,6 +712,9 @@ __device__ __forceinline__ void rows2_fast(EPTR E, uint32_t n_list, const DevPat
 }
 
 
+// STAGE: edges of the path a chunk can keep in LDS (two instances of the kernel: 32 -- fifteen wavefronts per CU -- for scenes whose
+// paths have at most 32 edges, 64 for the others)
+template <int STAGE>
 __device__ __forceinline__ void rows2_chunk_body(FramePtr FR, uint32_t block) {
     uint32_t r2ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long r2ph_t = 0;
@@ -720,7 +723,7 @@ __device__ __forceinline__ void rows2_chunk_body(FramePtr FR, uint32_t block) {
 #endif
     __shared__ FastLds2 F;
     __shared__ SubStage S;
-    __shared__ DevEdge staged[ROWS_STAGE];
+    __shared__ DevEdge staged[STAGE];
     const int lane = threadIdx.x;
     const ChunkInfo ck = FR->chunks[block];                               // wave-uniform: path and edge reads are scalar
     const uint32_t lo = ck.path;
@@ -765,9 +768,9 @@ __device__ __forceinline__ void rows2_chunk_body(FramePtr FR, uint32_t block) {
         const bool hit = use_lds && valid && ek.ytop < hi_s && ek.ybot > lo_s;
         const unsigned long long hb = __ballot(hit);
         const uint32_t at = n_list + (uint32_t)__popcll(hb & ((1ull << lane) - 1ull));
-        if (hit && at < ROWS_STAGE) staged[at] = ek;
+        if (hit && at < (uint32_t)STAGE) staged[at] = ek;
         n_list += (uint32_t)__popcll(hb);
-        if (n_list > ROWS_STAGE) use_lds = false;                        // (the loop goes on: every edge of the path counts for inc_before)
+        if (n_list > (uint32_t)STAGE) use_lds = false;                        // (the loop goes on: every edge of the path counts for inc_before)
     }
     const uint32_t chunk_cell_base = (ck.rec_base + (uint32_t)__builtin_amdgcn_readlane(wave_scan_incl(inc_before), 63)) * (uint32_t)MAX_CELLS_PER_EDGE_ROW;
     lds_barrier();
@@ -915,9 +918,14 @@ __global__ __launch_bounds__(64) R2_ATTR void k2_rows_b(const Frame2* __restrict
     FramePtr FR = FRAME_PTR(frames, blockIdx.y);
     if (blockIdx.x >= FR->n_chunks) return;
     TRACE(1);
-    rows2_chunk_body(FR, blockIdx.x);
+    rows2_chunk_body<ROWS_STAGE>(FR, blockIdx.x);
     TRACE(7);
     TRACE_OUT(1, blockIdx.x);
+}
+__global__ __launch_bounds__(64) R2_ATTR void k2_rows_wide_b(const Frame2* __restrict__ frames) {
+    FramePtr FR = FRAME_PTR(frames, blockIdx.y);
+    if (blockIdx.x >= FR->n_chunks) return;
+    rows2_chunk_body<ROWS_STAGE_WIDE>(FR, blockIdx.x);
 }
 
 
@@ -1478,9 +1486,8 @@ __global__ __launch_bounds__(256) void k2_rows_huge_b(const Frame2* __restrict__
 // clamped / wrapped into the bitmap, so the loads can be issued unconditionally and several pixels' loads together -- which of them lie
 // outside a non-repeating bitmap, and the weights
 struct BilinearTap {
-    const uint32_t* p[2][2];             // [x][y]
-    uint32_t wx, wy;
-    bool oxa, oxb, oya, oyb;
+    uint32_t o[2][2];                    // [x][y]: texel index in the bitmap (32-bit offsets from the bitmap's base: half the registers of pointers)
+    uint32_t wf;                         // weights and the outside flags in one register: wx | wy << 7 | oxa << 14 | oxb << 15 | oya << 16 | oyb << 17
 };
 __device__ __forceinline__ void bilinear_taps(const DevFilter& flt, int px, int py, BilinearTap& t) {
     const bool repeat = flt.extend == 1;
@@ -1489,27 +1496,28 @@ __device__ __forceinline__ void bilinear_taps(const DevFilter& flt, int px, int 
     const long long byp = flt.base_y + (long long)px * flt.m10 + (long long)py * flt.m11 - 0x8000;
     const int bw = (int)bm.width, bh = (int)bm.height;
     const int x0 = (int)(bxp >> 16), y0 = (int)(byp >> 16);
-    t.wx = (uint32_t)((bxp >> 9) & 0x7f); t.wy = (uint32_t)((byp >> 9) & 0x7f);
+    uint32_t wf = (uint32_t)((bxp >> 9) & 0x7f) | ((uint32_t)((byp >> 9) & 0x7f) << 7);
     int xa = x0, xb = x0 + 1, ya = y0, yb = y0 + 1;
-    t.oxa = t.oxb = t.oya = t.oyb = false;
     if (repeat) {
         xa = ((xa % bw) + bw) % bw; xb = xa + 1 == bw ? 0 : xa + 1;
         ya = ((ya % bh) + bh) % bh; yb = ya + 1 == bh ? 0 : ya + 1;
     } else {
-        t.oxa = xa < 0 || xa >= bw; t.oxb = xb < 0 || xb >= bw; t.oya = ya < 0 || ya >= bh; t.oyb = yb < 0 || yb >= bh;
+        wf |= (xa < 0 || xa >= bw ? 1u << 14 : 0u) | (xb < 0 || xb >= bw ? 1u << 15 : 0u) | (ya < 0 || ya >= bh ? 1u << 16 : 0u) | (yb < 0 || yb >= bh ? 1u << 17 : 0u);
         xa = min(max(xa, 0), bw - 1); xb = min(max(xb, 0), bw - 1); ya = min(max(ya, 0), bh - 1); yb = min(max(yb, 0), bh - 1);
     }
-    const uint32_t* rowa = bm.pixels + (size_t)ya * bm.width;
-    const uint32_t* rowb = bm.pixels + (size_t)yb * bm.width;
-    t.p[0][0] = rowa + xa; t.p[1][0] = rowa + xb; t.p[0][1] = rowb + xa; t.p[1][1] = rowb + xb;
+    const uint32_t rowa = (uint32_t)ya * bm.width, rowb = (uint32_t)yb * bm.width;     // (a bitmap has fewer than 2^32 texels)
+    t.o[0][0] = rowa + (uint32_t)xa; t.o[1][0] = rowa + (uint32_t)xb; t.o[0][1] = rowb + (uint32_t)xa; t.o[1][1] = rowb + (uint32_t)xb;
+    t.wf = wf;
 }
 __device__ __forceinline__ uint32_t bilinear_mix(const BilinearTap& t, const uint32_t* q00, const uint32_t* q10, const uint32_t* q01, const uint32_t* q11) {
     uint32_t c00 = *q00, c10 = *q10, c01 = *q01, c11 = *q11;
-    if (t.oxa || t.oya) c00 = 0;
-    if (t.oxb || t.oya) c10 = 0;
-    if (t.oxa || t.oyb) c01 = 0;
-    if (t.oxb || t.oyb) c11 = 0;
-    const uint32_t w00 = (128 - t.wx) * (128 - t.wy), w10 = t.wx * (128 - t.wy), w01 = (128 - t.wx) * t.wy, w11 = t.wx * t.wy;
+    const uint32_t wx = t.wf & 0x7fu, wy = (t.wf >> 7) & 0x7fu;
+    const bool oxa = (t.wf >> 14) & 1u, oxb = (t.wf >> 15) & 1u, oya = (t.wf >> 16) & 1u, oyb = (t.wf >> 17) & 1u;
+    if (oxa || oya) c00 = 0;
+    if (oxb || oya) c10 = 0;
+    if (oxa || oyb) c01 = 0;
+    if (oxb || oyb) c11 = 0;
+    const uint32_t w00 = (128 - wx) * (128 - wy), w10 = wx * (128 - wy), w01 = (128 - wx) * wy, w11 = wx * wy;
     uint32_t out = 0;
 #pragma unroll
     for (int sh = 0; sh < 32; sh += 8) {
@@ -1560,7 +1568,7 @@ __device__ __forceinline__ uint32_t shade_bitmap(uint32_t style_index, const Sou
     }
     BilinearTap t;
     bilinear_taps(flt, px, py, t);
-    return bilinear_mix(t, t.p[0][0], t.p[1][0], t.p[0][1], t.p[1][1]);
+    return bilinear_mix(t, flt.pixels + t.o[0][0], flt.pixels + t.o[1][0], flt.pixels + t.o[0][1], flt.pixels + t.o[1][1]);
 }
 // SHADERS: 0 solid colours only, 1 + bitmaps, 2 + gradients
 template <int SHADERS>
@@ -1676,20 +1684,31 @@ __device__ __forceinline__ void blend8(uint32_t (&px)[8], const uint32_t (&al)[8
     }
     const DevFilter& flt = src.filters[style];
     if (flt.kind == SWFR_STYLE_BITMAP && !flt.on) {
+        // Bilinear bitmap: the texels are fetched TRANSPOSED -- in round i a lane samples column 16 i + cg of its pixel row, so that
+        // neighbouring lanes read neighbouring texels (a lane's own four pixels are four columns apart from its neighbour's: a
+        // quarter of every cache line per load) -- and the colours go back to the lanes that own the pixels through LDS.
+        const int cgl = lane & 15, tx0 = cx0 - 4 * cgl;
+        uint32_t* tq = bq + 64 * (lane >> 4);                        // this pixel row's 64 colours (bq: 4 rows x 64)
+        const uint32_t* __restrict__ texels = flt.pixels;            // (wave-uniform base: scalar address + 32-bit lane offsets)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             if (!(__ballot((al[4 * h] | al[4 * h + 1] | al[4 * h + 2] | al[4 * h + 3]) != 0u))) continue;       // wave-uniform: nothing to paint in these rows
             BilinearTap t[4];
             uint32_t c[4][4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) bilinear_taps(flt, cx0 + i, cy0 + 4 * h, t[i]);
+            for (int i = 0; i < 4; ++i) bilinear_taps(flt, tx0 + 16 * i + cgl, cy0 + 4 * h, t[i]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { c[i][0] = *t[i].p[0][0]; c[i][1] = *t[i].p[1][0]; c[i][2] = *t[i].p[0][1]; c[i][3] = *t[i].p[1][1]; }
+            for (int i = 0; i < 4; ++i) { c[i][0] = texels[t[i].o[0][0]]; c[i][1] = texels[t[i].o[1][0]]; c[i][2] = texels[t[i].o[0][1]]; c[i][3] = texels[t[i].o[1][1]]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tq[16 * i + cgl] = bilinear_mix(t[i], &c[i][0], &c[i][1], &c[i][2], &c[i][3]);
+            lds_barrier();
+            const uint4 mine = *reinterpret_cast<const uint4*>(tq + 4 * cgl);
+            lds_barrier();                                        // (the next half / the next path rewrites the rows)
+            const uint32_t col[4] = {mine.x, mine.y, mine.z, mine.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int j = 4 * h + i;
-                const uint32_t col = bilinear_mix(t[i], &c[i][0], &c[i][1], &c[i][2], &c[i][3]);
-                const uint32_t sc = mul_un8(col, al[j]);
+                const uint32_t sc = mul_un8(col[i], al[j]);
                 const uint32_t b = (eflags & BE_LERP) ? sc : over_pixel(sc, px[j]);
                 px[j] = al[j] ? b : px[j];
             }
@@ -1811,23 +1830,28 @@ __device__ __forceinline__ void tiles3_body(FramePtr FR) {
                     if (fe & CLS_BOX) {
                         // ---- rectilinear (A.6): exact area of disjoint boxes, alpha = (c>>8) - (c>>16)
                         const uint32_t e_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)eb.y), e_nedges = (uint32_t)__builtin_amdgcn_readfirstlane((int)eb.z);
-                        uint32_t cov[8];
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) cov[j] = 0u;
-                        for (uint32_t k = 0; k < e_nedges; ++k) {
-                            const swfr_edge bx = FR->raw[e_first + k];
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) {
-                                const int cx = cx0 + (j & 3), cy = cy0 + 4 * (j >> 2);
-                                const int wx = min(bx.x2, (cx + 1) * 256) - max(bx.x1, cx * 256);
+                        // (one pixel row of the lane at a time: eight running sums at once cost the shaded instances a wavefront per SIMD)
+#pragma unroll 1
+                        for (int h = 0; h < 2; ++h) {
+                            uint32_t cov[4] = {0u, 0u, 0u, 0u};
+                            const int cy = cy0 + 4 * h;
+                            for (uint32_t k = 0; k < e_nedges; ++k) {
+                                const swfr_edge bx = FR->raw[e_first + k];
                                 const int wy = min(bx.y2, (cy + 1) * 256) - max(bx.y1, cy * 256);
-                                if (wx > 0 && wy > 0) cov[j] += (uint32_t)(wx * wy);
-                            }
-                        }
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const int rr = g + 4 * (j >> 2);
-                            al[j] = (rr >= row_lo && rr < row_hi) ? (((cov[j] >> 8) - (cov[j] >> 16)) & 255u) : 0u;
+                                for (int i = 0; i < 4; ++i) {
+                                    const int cx = cx0 + i;
+                                    const int wx = min(bx.x2, (cx + 1) * 256) - max(bx.x1, cx * 256);
+                                    if (wx > 0 && wy > 0) cov[i] += (uint32_t)(wx * wy);
+                                }
+                            }
+                            const int rr = g + 4 * h;
+                            const bool in = rr >= row_lo && rr < row_hi;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const uint32_t a = in ? (((cov[i] >> 8) - (cov[i] >> 16)) & 255u) : 0u;
+                                if (h == 0) al[i] = a; else al[4 + i] = a;
+                            }
                         }
                     } else if (fe & CLS_PARTIAL) {
                         // ---- tor (A.5): the cells of this strip's eight rows of the path, lane = (row, k-th cell)
@@ -1967,8 +1991,11 @@ __device__ __forceinline__ void tiles3_body(FramePtr FR) {
 // (two entry points per kernel: one frame, its descriptor passed by value -- the fields arrive with the kernel arguments, no memory
 //  round trip -- and a batch of frames, blockIdx.y indexing an array of descriptors in device memory)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(T2_WAVES))) void k2_tiles_solid_b(const Frame2* __restrict__ frames) { tiles3_body<0>(FRAME_PTR(frames, blockIdx.y)); }
-__global__ __launch_bounds__(64) void k2_tiles_bitmap_b(const Frame2* __restrict__ frames) { tiles3_body<1>(FRAME_PTR(frames, blockIdx.y)); }
-__global__ __launch_bounds__(64) void k2_tiles_shaded_b(const Frame2* __restrict__ frames) { tiles3_body<2>(FRAME_PTR(frames, blockIdx.y)); }
+#ifndef T2_WAVES_SHADED
+#define T2_WAVES_SHADED 4              // the samplers wait for texels: four wavefronts per SIMD (128 VGPRs) rather than the three 137 would allow
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(T2_WAVES_SHADED))) void k2_tiles_bitmap_b(const Frame2* __restrict__ frames) { tiles3_body<1>(FRAME_PTR(frames, blockIdx.y)); }
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(T2_WAVES_SHADED))) void k2_tiles_shaded_b(const Frame2* __restrict__ frames) { tiles3_body<2>(FRAME_PTR(frames, blockIdx.y)); }
 
 // ---------------------------------------------------------------------------------------------
 // launchers: `frames` is a device array of n_frames descriptors, blockIdx.y picks one
@@ -1977,9 +2004,10 @@ void launch2_bin(hipStream_t st, const Frame2* frames, uint32_t n_frames, uint32
     const uint32_t g = max_bands + (max_edges_or_paths + BIN_THREADS - 1) / BIN_THREADS + XCDS;   // + the workgroups that order the strips
     hipLaunchKernelGGL(k2_bin_b, dim3(g, n_frames), dim3(BIN_THREADS), 0, st, frames);
 }
-void launch2_rows(hipStream_t st, const Frame2* frames, uint32_t n_frames, uint32_t max_chunks) {
+void launch2_rows(hipStream_t st, const Frame2* frames, uint32_t n_frames, uint32_t max_chunks, uint32_t max_path_edges) {
     if (!max_chunks) return;
-    hipLaunchKernelGGL(k2_rows_b, dim3(max_chunks, n_frames), dim3(64), 0, st, frames);
+    if (max_path_edges > ROWS_STAGE) hipLaunchKernelGGL(k2_rows_wide_b, dim3(max_chunks, n_frames), dim3(64), 0, st, frames);
+    else hipLaunchKernelGGL(k2_rows_b, dim3(max_chunks, n_frames), dim3(64), 0, st, frames);
 }
 void launch2_rows_slow(hipStream_t st, const Frame2* frames, uint32_t n_frames, uint32_t grid_slow, uint32_t grid_huge, uint32_t max_passes) {
     if (grid_slow) hipLaunchKernelGGL(k2_start_ranks_b, dim3(grid_slow / 4 + 1, n_frames), dim3(256), 0, st, frames);

@@ -129,6 +129,7 @@ __device__ __forceinline__ DevEdge make_dev_edge(const swfr_edge& e, const DevPa
 #ifndef ROWS_STAGE
 #define ROWS_STAGE 32            // chunks with at most this many edges of their path in reach are staged into LDS (3 KB of 96-byte records:
 #endif                           // with 4.5 KB -- 48 of them -- two wavefronts fewer fit a CU and the pipelined frame rate drops by a tenth)
+#define ROWS_STAGE_WIDE 64       // ... of the row kernel's second instance, for scenes with a path of more than ROWS_STAGE edges
 
 // All edges of one path, whichever form the kernel has them in (k_front's DevEdge array, or the raw edges when the row pass
 // computes the constants itself).

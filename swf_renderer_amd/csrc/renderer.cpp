@@ -25,7 +25,7 @@
 
 namespace swfr {
 void launch2_bin(hipStream_t, const Frame2*, uint32_t, uint32_t, uint32_t);
-void launch2_rows(hipStream_t, const Frame2*, uint32_t, uint32_t);
+void launch2_rows(hipStream_t, const Frame2*, uint32_t, uint32_t, uint32_t);
 void launch2_rows_slow(hipStream_t, const Frame2*, uint32_t, uint32_t, uint32_t, uint32_t);
 void launch2_tiles(hipStream_t, const Frame2*, uint32_t, uint32_t, uint32_t, int);
 void launch_unpremultiply(hipStream_t, const uint32_t*, uint32_t*, size_t);
@@ -157,6 +157,7 @@ struct swfr_renderer {
         int shader_level = 0;
         size_t n_incidences = 0, n_strips = 0, n_strip_slots = 0;   // (edge, pixel row) pairs: bounds the cells of a frame; k2_tiles wavefronts / launch list slots
         size_t n_slots = 0, cell_total = 0;
+        uint32_t max_path_edges = 0;              // picks the row kernel's instance (edges staged in LDS per chunk)
         Frame2 proto{};                           // the scene fields and sizes of a frame descriptor (per-frame buffers not filled in)
         Frame2* frames_dev = nullptr;            // one descriptor per frame set (contiguous, in the arena)
         uint32_t slow_passes = SLOW_PASSES;      // passes of the slow-row kernels the scene needs (known after a frame of a resident scene)
@@ -545,6 +546,7 @@ struct SceneLayout {
     uint32_t chunk_rows = ROWS_CHUNK;
     size_t n_chunks = 0, n_slots = 0, n_rows = 0, n_bands = 0, n_strips = 0, n_strip_slots = 0, incidences = 0, cell_main = 0, cell_total = 0;
     bool any_shader = false;
+    uint32_t max_path_edges = 0;
     int shader_level = 0;       // 0 solid colours only, 1 + bitmap fills, 2 + gradients: picks the tile kernel's instance
     std::vector<uint32_t> chunk_base, slot_base, inc_base, band_off;
     std::vector<DevFilter> filters;
@@ -586,7 +588,7 @@ void layout_scene(const swfr_renderer* r, const swfr_edge* edges, size_t n_edges
     }
     // exclusive prefixes over the paths (first chunk, first band slot) and over the tile-rows (band list offsets, by a difference
     // array over the paths' tile-row ranges)
-    L.n_chunks = L.n_slots = L.n_rows = 0;
+    L.n_chunks = L.n_slots = L.n_rows = 0; L.max_path_edges = 0;
     L.chunk_base.assign(n_paths + 1, 0); L.slot_base.assign(n_paths + 1, 0); L.inc_base.assign(n_paths + 1, 0); L.band_off.assign(L.n_bands + 2, 0);
     for (size_t i = 0; i < n_paths; ++i) {
         const swfr_path& p = paths[i];
@@ -599,7 +601,7 @@ void layout_scene(const swfr_renderer* r, const swfr_edge* edges, size_t n_edges
             L.n_slots += b1 - b0 + 1;
             ++L.band_off[b0 + 1]; --L.band_off[b1 + 2];
         }
-        if (p.kind == SWFR_PATH_TOR) L.n_rows += size_t(p.y_max - p.y_min);
+        if (p.kind == SWFR_PATH_TOR) { L.n_rows += size_t(p.y_max - p.y_min); L.max_path_edges = std::max(L.max_path_edges, p.n_edges); }
     }
     L.chunk_base[n_paths] = uint32_t(L.n_chunks); L.slot_base[n_paths] = uint32_t(L.n_slots);
     for (size_t b = 1; b <= L.n_bands + 1; ++b) L.band_off[b] += L.band_off[b - 1];       // difference array -> counts, shifted by one
@@ -699,7 +701,7 @@ int upload2(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, siz
     sc.n_edges = n_edges; sc.n_paths = n_paths; sc.n_styles = n_styles; sc.any_shader = L.any_shader; sc.shader_level = L.shader_level;
     sc.n_chunks = L.n_chunks; sc.chunk_rows = L.chunk_rows; sc.n_bands = L.n_bands; sc.n_rows = L.n_rows;
     sc.n_strips = L.n_strips; sc.n_strip_slots = L.n_strip_slots; sc.n_incidences = L.incidences;
-    sc.n_slots = L.n_slots; sc.cell_total = L.cell_total;
+    sc.n_slots = L.n_slots; sc.cell_total = L.cell_total; sc.max_path_edges = L.max_path_edges;
     SceneArena& A = sc.arena;
     A.begin(scene_arena_bytes(L, n_edges, n_paths, n_styles) + SceneArena::padded(4 * sizeof(Frame2)) + 4096);
     Frame2 proto;
@@ -787,7 +789,7 @@ void launch_frame(swfr_renderer* r, const swfr_renderer::Scene& sc, swfr_rendere
         if (e) HIP_CHECK(hipEventRecord(e[0], st));
         launch2_bin(st, fh, 1, uint32_t(std::max(sc.n_edges, sc.n_paths)), uint32_t(sc.n_bands));
         if (e) HIP_CHECK(hipEventRecord(e[1], st));
-        launch2_rows(st, fh, 1, uint32_t(sc.n_chunks));
+        launch2_rows(st, fh, 1, uint32_t(sc.n_chunks), sc.max_path_edges);
         // the queued rows (coincident edges, crowded rows): skipped once a frame of this resident scene has shown there are none
         if (sc.n_chunks && sc.slow_state != 1) launch2_rows_slow(st, fh, 1, 1024u, sc.slow_state == 2 ? 0u : 256u, sc.slow_passes);
         if (e) HIP_CHECK(hipEventRecord(e[2], st));
@@ -980,6 +982,7 @@ int render_batch2(swfr_renderer* r, const swfr_stage* stages, uint32_t n, void* 
         size_t arena_bytes = pad(cnt * sizeof(Frame2)) + 4096, work_bytes = 0, cls_bytes = 0;
         size_t max_ep = 0, max_bands = 0, max_chunks = 0, max_strips = 0;
         int shader_level = 0;
+        uint32_t max_pe = 0;
         auto t0 = clk::now();
         for (uint32_t k = 0; k < cnt; ++k) {
             FrameData& F = fd[k];
@@ -997,6 +1000,7 @@ int render_batch2(swfr_renderer* r, const swfr_stage* stages, uint32_t n, void* 
             max_ep = std::max(max_ep, std::max(F.e.size(), F.p.size())); max_bands = std::max(max_bands, L.n_bands);
             max_chunks = std::max(max_chunks, L.n_chunks); max_strips = std::max(max_strips, L.n_strip_slots);
             shader_level = std::max(shader_level, L.shader_level);
+            max_pe = std::max(max_pe, L.max_path_edges);
         }
         t_build += ms_since(t0); t0 = clk::now();
         // ---- this group's previous use must be over before its staging and device buffers are rewritten
@@ -1048,7 +1052,7 @@ int render_batch2(swfr_renderer* r, const swfr_stage* stages, uint32_t n, void* 
         if (!G.ev_begin) { HIP_CHECK(hipEventCreate(&G.ev_begin)); HIP_CHECK(hipEventCreate(&G.ev_end)); }
         HIP_CHECK(hipEventRecord(G.ev_begin, G.stream));
         launch2_bin(G.stream, frames_dev, cnt, uint32_t(max_ep), uint32_t(max_bands));
-        launch2_rows(G.stream, frames_dev, cnt, uint32_t(max_chunks));
+        launch2_rows(G.stream, frames_dev, cnt, uint32_t(max_chunks), max_pe);
         if (max_chunks) launch2_rows_slow(G.stream, frames_dev, cnt, 256u, 64u, SLOW_PASSES);
         launch2_tiles(G.stream, frames_dev, cnt, uint32_t(max_strips), ~0u, shader_level);
         HIP_CHECK(hipEventRecord(G.ev_end, G.stream));
@@ -1119,7 +1123,7 @@ int render_resident_batched(swfr_renderer* r, uint32_t per_launch, uint32_t laun
     if (!r->rb_ev[0]) { HIP_CHECK(hipEventCreate(&r->rb_ev[0])); HIP_CHECK(hipEventCreate(&r->rb_ev[1])); }
     auto one_launch = [&]() {
         launch2_bin(st, r->rb_frames.ptr, B, uint32_t(std::max(sc.n_edges, sc.n_paths)), uint32_t(sc.n_bands));
-        launch2_rows(st, r->rb_frames.ptr, B, uint32_t(sc.n_chunks));
+        launch2_rows(st, r->rb_frames.ptr, B, uint32_t(sc.n_chunks), sc.max_path_edges);
         if (sc.n_chunks && sc.slow_state != 1) launch2_rows_slow(st, r->rb_frames.ptr, B, 256u, sc.slow_state == 2 ? 0u : 64u, sc.slow_passes);
         launch2_tiles(st, r->rb_frames.ptr, B, uint32_t(sc.n_strip_slots), ~0u, sc.shader_level);
     };

@@ -8,6 +8,10 @@ import json, math, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
+if os.environ.get("SWFR_LIB"):                          # another build of the library (tuning experiments)
+    from swf_renderer_amd import api as _api
+    _lib = os.path.abspath(os.environ["SWFR_LIB"])
+    _api.library_path = lambda: _lib
 import swf_renderer_amd as S
 import scenarios
 from helpers import fixture
