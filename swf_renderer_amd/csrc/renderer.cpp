@@ -560,24 +560,16 @@ void layout_scene(const swfr_renderer* r, const swfr_edge* edges, size_t n_edges
     const uint32_t tiles_x = (r->width + TILE_W - 1) / TILE_W;
     // rows per k2_rows wavefront: 64 when that already gives the GPU a thousand wavefronts, fewer (whole tile-rows) for scenes made
     // of a few tall paths
-    // (a handle that owns a share of the tile-rows counts the chunks that have rows of its own: the others exit at once, and a
-    //  rank with an eighth of the frame wants its thousand wavefronts from that eighth)
-    const BandShare share = band_share(r);
-    auto owns_tile_row = [&](uint32_t t) { return t >= share.first && (t - share.first) % share.stride == 0 && (t - share.first) / share.stride < share.count; };
     auto count_chunks = [&](uint32_t cr) {
         size_t n = 0;
-        for (size_t i = 0; i < n_paths; ++i) {
-            if (paths[i].kind != SWFR_PATH_TOR || paths[i].y_max <= paths[i].y_min) continue;
-            const uint32_t a0 = uint32_t(paths[i].y_min) / TILE_H * TILE_H, y1 = uint32_t(paths[i].y_max);
-            if (r->cfg.band_count <= 1) { n += (y1 - a0 + cr - 1) / cr; continue; }
-            for (uint32_t a = a0; a < y1; a += cr) {
-                bool live = false;
-                for (uint32_t t = a / TILE_H; t < (std::min(a + cr, y1) + TILE_H - 1) / TILE_H && !live; ++t) live = owns_tile_row(t);
-                n += live ? 1 : 0;
-            }
-        }
+        for (size_t i = 0; i < n_paths; ++i)
+            if (paths[i].kind == SWFR_PATH_TOR && paths[i].y_max > paths[i].y_min)
+                n += (size_t(paths[i].y_max) - size_t(paths[i].y_min) / TILE_H * TILE_H + cr - 1) / cr;
         return n;
     };
+    // (counted over the whole frame also for a handle that owns a share of the tile-rows: with chunks sized for the share alone
+    //  -- 16 rows at an eighth of S1 -- k2_bin writes four times the chunk descriptors and loses what k2_rows gains:
+    //  profiles/r03o_blocks_timing.json)
     L.chunk_rows = ROWS_CHUNK;
     if (r->force_chunk_rows == 16 || r->force_chunk_rows == 32 || r->force_chunk_rows == 64) L.chunk_rows = uint32_t(r->force_chunk_rows);
     else while (L.chunk_rows > uint32_t(TILE_H) && count_chunks(L.chunk_rows) < 1024) L.chunk_rows >>= 1;
