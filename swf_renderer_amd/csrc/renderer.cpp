@@ -182,8 +182,22 @@ struct swfr_renderer {
         DevBuf<BandSlot> d_band_slots;
         DevBuf<StripDesc> d_strips;
         DevBuf<uint32_t> d_strip_cost;
+        // the kernels of one frame of the resident scene on this set, captured once per uploaded scene: a frame is then ONE
+        // hipGraphLaunch for the host instead of three to twelve kernel launches
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t graph_exec = nullptr;
+        uint64_t graph_key = 0;                  // scene generation | slow_state | slow_passes the graph was captured for (0: none)
     };
     FrameSet fs[4];
+    uint64_t scene_gen = 0;                 // counts uploads into scene slot 0
+    int resident_batch = 0;                 // SWFR_RESIDENT_BATCH: frames per kernel launch of swfr_render_resident (blockIdx.y = frame; 0/1: one launch chain per frame)
+#ifdef SWFR_EMU
+    int use_graphs = 0;                     // (the emulator's runtime has no graphs)
+#else
+    int use_graphs = 0;                     // SWFR_GRAPHS=1: frames of a resident scene as graph launches.  Off by default: measured on MI355X /
+                                            // ROCm 7.2 a graph launch per frame is SLOWER than its three kernel launches (S1: 162 000 instead of
+                                            // 218 000 Mpx/s at 300 frames, 143 000 instead of 178 000 at 20: profiles/r03p_graphs.txt)
+#endif
     DevBuf<DevBitmap> d_bitmap_table;
     DevBuf<uint32_t> d_tmp;
     DevBuf<uint32_t> d_counters;            // 4 x COUNTER_WORDS: the frame sets' counters, contiguous
@@ -242,6 +256,8 @@ struct swfr_renderer {
                 x.d_edges.release(); x.d_cls.release(); x.d_fb.release();
                 x.d_band2.release(); x.d_rows2.release(); x.d_cells.release(); x.d_slow.release(); x.d_huge.release(); x.d_path_flag.release(); x.d_path_queue.release(); x.d_chunks.release(); x.d_band_slots.release(); x.d_strips.release();
                 x.d_strip_cost.release();
+                if (x.graph_exec) (void)hipGraphExecDestroy(x.graph_exec);
+                if (x.graph) (void)hipGraphDestroy(x.graph);
                 if (k > 0 && x.stream) (void)hipStreamDestroy(x.stream);
                 scn[k].arena.release();
             }
@@ -760,7 +776,7 @@ int upload2(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, siz
         r->bitmap_table_dirty_copied = true;
     }
     if (r->bitmap_table_dirty_copied) { HIP_CHECK(hipStreamSynchronize(r->stream)); r->bitmap_table_dirty_copied = false; }   // bitmap_table may be edited next
-    if (si == 0) { r->scene_ready = true; r->sets_ready = all_sets ? uint32_t(n_sets) : 1u; r->scene_from_builder = edges_tagged; }
+    if (si == 0) { r->scene_ready = true; r->sets_ready = all_sets ? uint32_t(n_sets) : 1u; r->scene_from_builder = edges_tagged; ++r->scene_gen; }
     return SWFR_OK;
 }
 
@@ -822,6 +838,31 @@ int check_counters(swfr_renderer* r, const uint32_t* counters) {
     }
 }
 
+// One frame of the resident scene on frame set F as a graph launch: the set's kernels (with the queued-row kernels the scene is
+// known to need) are captured from the set's own stream the first time and replayed afterwards; a new upload, or a change in what
+// the scene needs of the queued-row kernels, captures again.
+void launch_frame_graph(swfr_renderer* r, const swfr_renderer::Scene& sc, swfr_renderer::FrameSet& F) {
+    const uint64_t key = (r->scene_gen << 16) | (uint64_t(sc.slow_state & 3) << 8) | uint64_t(sc.slow_passes & 0xffu) | (uint64_t(1) << 63);
+    if (F.graph_key != key) {
+        if (F.graph_exec) { (void)hipGraphExecDestroy(F.graph_exec); F.graph_exec = nullptr; }
+        if (F.graph) { (void)hipGraphDestroy(F.graph); F.graph = nullptr; }
+        F.graph_key = 0;
+        HIP_CHECK(hipStreamBeginCapture(F.stream, hipStreamCaptureModeRelaxed));
+        try {
+            launch_frame(r, sc, F, nullptr, nullptr);
+        } catch (...) {
+            hipGraph_t g = nullptr;
+            (void)hipStreamEndCapture(F.stream, &g);
+            if (g) (void)hipGraphDestroy(g);
+            throw;
+        }
+        HIP_CHECK(hipStreamEndCapture(F.stream, &F.graph));
+        HIP_CHECK(hipGraphInstantiate(&F.graph_exec, F.graph, nullptr, nullptr, 0));
+        F.graph_key = key;
+    }
+    HIP_CHECK(hipGraphLaunch(F.graph_exec, F.stream));
+}
+
 int render_resident(swfr_renderer* r, uint32_t frames) {
     if (!r->has_device) return fail(r, SWFR_ERR_NO_DEVICE, "host-only handle cannot rasterize");
     if (!r->scene_ready) return fail(r, SWFR_ERR_INVALID, "no scene uploaded");
@@ -831,6 +872,13 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
         const auto& e = r->builder->edges(); const auto& p = r->builder->paths(); const auto& st = r->builder->styles();
         const int rc = upload2(r, 0, true, e.data(), e.size(), p.data(), p.size(), st.data(), st.size(), nullptr, true);
         if (rc != SWFR_OK) return rc;
+    }
+    if (frames > 1 && r->use_graphs && !r->scn[0].slow_verified) {
+        // which queued-row kernels the scene needs is learnt from one blocking frame, so that the graphs of the frames behind it
+        // are captured once (with exactly those kernels) and a later call finds them ready
+        const int rc = render_resident(r, 1);
+        if (rc != SWFR_OK) return rc;
+        --frames;
     }
     const swfr_renderer::Scene& sc = r->scn[0];
     float setup_ms = 0, rows_ms = 0, tiles_ms = 0, total_ms = 0;
@@ -856,10 +904,33 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
     // (no clearing of the counters here: k2_bin zeroes its frame's counters itself)
     HIP_CHECK(hipEventRecord(ev_begin, r->stream));
     for (uint32_t k = 1; k < n_sets; ++k) HIP_CHECK(hipStreamWaitEvent(r->fs[k].stream, ev_begin, 0));
-    for (uint32_t f = 0; f < frames; ++f) {
+    // Frames per launch: the frame sets are cut into groups of `rb` (their descriptors are contiguous), a group's frames are one launch
+    // per kernel (blockIdx.y = frame) on the group's first stream, and the groups alternate -- a third of the host's launches per
+    // frame (three launches take the host about as long as a frame takes the GPU) and the GPU still has two streams to overlap.
+    // Only without per-kernel events (a timed frame is launched alone).
+    uint32_t rb = (r->resident_batch >= 2 && stride > frames) ? uint32_t(r->resident_batch) : 1u;
+    while (rb > 1 && (rb > n_sets || n_sets % rb != 0)) --rb;
+    const bool batched = rb > 1 && frames >= 2;
+    uint32_t last_set = (frames - 1) % n_sets;
+    if (batched) {
+        const uint32_t groups = n_sets / rb;
+        uint32_t gi = 0;
+        for (uint32_t f = 0; f < frames; f += rb, ++gi) {
+            const uint32_t g = gi % groups, cnt = std::min(rb, frames - f);
+            const hipStream_t st = r->fs[g * rb].stream;
+            const Frame2* fh = sc.frames_dev + g * rb;
+            launch2_bin(st, fh, cnt, uint32_t(std::max(sc.n_edges, sc.n_paths)), uint32_t(sc.n_bands));
+            launch2_rows(st, fh, cnt, uint32_t(sc.n_chunks), sc.max_path_edges);
+            if (sc.n_chunks && sc.slow_state != 1) launch2_rows_slow(st, fh, cnt, 1024u, sc.slow_state == 2 ? 0u : 256u, sc.slow_passes);
+            launch2_tiles(st, fh, cnt, uint32_t(sc.n_strip_slots), r->tiles_grid > 0 ? uint32_t(r->tiles_grid) : ~0u, sc.shader_level);
+            last_set = g * rb + cnt - 1;
+        }
+    }
+    for (uint32_t f = 0; f < frames && !batched; ++f) {
         swfr_renderer::FrameSet& F = r->fs[f % n_sets];
         const bool timed = f >= first_timed && (f - first_timed) % stride == 0;   // per-kernel events on every stride-th frame (each costs a queue packet)
-        launch_frame(r, sc, F, F.d_fb.ptr, timed ? &r->ev[size_t((f - first_timed) / stride) * 4] : nullptr);
+        if (!timed && frames > 1 && r->use_graphs && sc.slow_verified) launch_frame_graph(r, sc, F);
+        else launch_frame(r, sc, F, F.d_fb.ptr, timed ? &r->ev[size_t((f - first_timed) / stride) * 4] : nullptr);
     }
     for (uint32_t k = 1; k < n_sets; ++k) {
         HIP_CHECK(hipEventRecord(ev_join[k - 1], r->fs[k].stream));
@@ -872,9 +943,9 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
     const uint32_t used_sets = std::min(frames, n_sets);               // (a set that rendered no frame of this call holds an older frame's counters)
     HIP_CHECK(hipMemcpyAsync(r->h_counters, r->d_counters.ptr, size_t(used_sets) * COUNTER_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
     HIP_CHECK(hipStreamSynchronize(r->stream));
-    r->fb_cur = r->n_targets ? r->targets[((frames - 1) % n_sets) % r->n_targets] : r->fs[(frames - 1) % n_sets].d_fb.ptr;
+    r->fb_cur = r->n_targets ? r->targets[last_set % r->n_targets] : r->fs[last_set].d_fb.ptr;
     uint32_t timed_frames = 0;
-    for (uint32_t f = first_timed; f < frames; f += stride, ++timed_frames) {
+    for (uint32_t f = batched ? frames : first_timed; f < frames; f += stride, ++timed_frames) {      // (frames per launch: no per-kernel events)
         hipEvent_t* e = &r->ev[size_t(timed_frames) * 4];
         float a = 0, b = 0, c = 0;
         HIP_CHECK(hipEventElapsedTime(&a, e[0], e[1]));
@@ -1249,6 +1320,8 @@ int swfr_create(uint32_t width, uint32_t height, const swfr_config* cfg, swfr_re
     if (const char* so = std::getenv("SWFR_STRIP_ORDER")) r->strip_order = std::atoi(so);
     if (const char* fi = std::getenv("SWFR_FRAMES_IN_FLIGHT")) r->in_flight = std::atoi(fi);
     if (const char* es = std::getenv("SWFR_EVENT_STRIDE")) r->event_stride = std::atoi(es);
+    if (const char* ug = std::getenv("SWFR_GRAPHS")) r->use_graphs = std::atoi(ug);
+    if (const char* rb = std::getenv("SWFR_RESIDENT_BATCH")) r->resident_batch = std::atoi(rb);
     if (r->cfg.device == SWFR_DEVICE_HOST_ONLY) {
         *out = r.release();
         return SWFR_OK;

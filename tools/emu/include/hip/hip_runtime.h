@@ -103,6 +103,18 @@ typedef struct emu_event* hipEvent_t;
 enum { hipSuccess = 0, hipErrorInvalidValue = 1 };
 enum { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
 enum { hipStreamNonBlocking = 1, hipHostMallocDefault = 0, hipEventDisableTiming = 2 };
+// graphs: the emulator executes launches eagerly, so "capturing" a frame runs it and launching the graph runs nothing more -- the
+// product is therefore told (SWFR_GRAPHS defaults to 0 under SWFR_EMU) not to use them
+typedef void* hipGraph_t;
+typedef void* hipGraphExec_t;
+typedef void* hipGraphNode_t;
+enum { hipStreamCaptureModeRelaxed = 2 };
+static inline hipError_t hipStreamBeginCapture(hipStream_t, int) { return hipErrorInvalidValue; }
+static inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) { *g = nullptr; return hipErrorInvalidValue; }
+static inline hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t, hipGraphNode_t*, char*, size_t) { *e = nullptr; return hipErrorInvalidValue; }
+static inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipErrorInvalidValue; }
+static inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
+static inline hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
 hipError_t hipMalloc(void** p, size_t n);
 hipError_t hipFree(void* p);
 hipError_t hipHostMalloc(void** p, size_t n, unsigned flags);
