@@ -112,6 +112,27 @@ def latest_traffic():
         return None, None
 
 
+def latest_rocprof_kernel_us(kernel):
+    """rocprofv3's average duration (us) of `kernel` with one frame in flight from the newest committed kernel-trace summary of this
+    bench (tools/profile_r02.sh), with its source; (None, None) when there is none."""
+    import csv
+    import glob
+    import re
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_stats_one_frame_in_flight.csv"))):
+        if re.fullmatch(r"r\d+[a-z]_kernel_stats_one_frame_in_flight\.csv", os.path.basename(f)):
+            best = f
+    if not best:
+        return None, None
+    try:
+        for row in csv.DictReader(open(best)):
+            if kernel in row["Name"]:
+                return float(row["AverageNs"]) / 1000.0, os.path.relpath(best, ROOT)
+    except Exception:
+        pass
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -382,6 +403,14 @@ def main():
                          "step_achieved": round(gbs(algo_bytes * (frames_total / args.steps), ms_per_step), 2),
                          "step_frac": round(gbs(algo_bytes * (frames_total / args.steps), ms_per_step) / HBM_PEAK_GBS, 5)},
         }
+        if not bands and args.workload == "s1":
+            rp_us, rp_src = latest_rocprof_kernel_us("k2_tiles_solid_b")
+            if rp_us:
+                # (the HIP events of this run bracket the kernel on its stream and so include the ~3 us between the end of k2_rows and the
+                #  start of k2_tiles; rocprofv3's kernel trace does not)
+                line["roofline"]["rocprofv3_committed"] = {"kernel_us": round(rp_us, 2), "achieved": round(gbs(algo_bytes, rp_us * 1e-3), 2),
+                                                           "frac": round(gbs(algo_bytes, rp_us * 1e-3) / HBM_PEAK_GBS, 5),
+                                                           "source": "%s (rocprofv3 --kernel-trace --stats of this bench, one frame in flight; not measured in this run)" % rp_src}
         line.update(extra)
         if t1 is not None:
             line["roofline"]["one_frame_in_flight"] = {"k2_tiles_ms": round(tiles_ms, 4), "k2_rows_ms": round(rows_ms, 4), "k2_bin_ms": round(bin_ms, 4),

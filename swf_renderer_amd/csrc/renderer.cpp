@@ -1321,6 +1321,9 @@ int swfr_create(uint32_t width, uint32_t height, const swfr_config* cfg, swfr_re
     if (const char* fi = std::getenv("SWFR_FRAMES_IN_FLIGHT")) r->in_flight = std::atoi(fi);
     if (const char* es = std::getenv("SWFR_EVENT_STRIDE")) r->event_stride = std::atoi(es);
     if (const char* ug = std::getenv("SWFR_GRAPHS")) r->use_graphs = std::atoi(ug);
+#ifdef SWFR_EMU
+    r->use_graphs = 0;                                              // (the emulator's runtime has no graphs)
+#endif
     if (const char* rb = std::getenv("SWFR_RESIDENT_BATCH")) r->resident_batch = std::atoi(rb);
     if (r->cfg.device == SWFR_DEVICE_HOST_ONLY) {
         *out = r.release();

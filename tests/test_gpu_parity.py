@@ -366,6 +366,32 @@ def test_kernel_route_knobs_are_pixel_identical(env, monkeypatch):
         assert diff_stats(product_render(sc), oracle_render(sc)) == (0, 0), (env, name)
 
 
+@pytest.mark.parametrize("env", [{"SWFR_GRAPHS": "1"}, {"SWFR_RESIDENT_BATCH": "2"}, {"SWFR_RESIDENT_BATCH": "4"}, {"SWFR_RESIDENT_BATCH": "2", "SWFR_FRAMES_IN_FLIGHT": "2"}])
+def test_resident_frames_as_graph_launches_and_as_frames_per_launch(env, monkeypatch):
+    """The opt-in ways swfr_render_resident can issue its frames -- every frame one hipGraphLaunch (SWFR_GRAPHS=1), or groups of frame
+    sets as one launch per kernel (SWFR_RESIDENT_BATCH) -- render the same frames: the last of 7 (and of 2) equals the oracle, for a
+    scene without and one with queued rows."""
+    import swf_renderer_amd as S
+    from swf_renderer_amd import api
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setenv("SWFR_EVENT_STRIDE", "1000000")
+    for name in ("translucent_stack", "morph_round_stroke_090"):
+        sc = SC[name]
+        host = S.Renderer(sc["width"], sc["height"], device=api.DEVICE_HOST_ONLY)
+        scene = host.build_frame(sc["stage"])
+        host.close()
+        r = S.Renderer(sc["width"], sc["height"])
+        try:
+            r.upload_edges(*scene)
+            want = oracle_render(sc)
+            for frames in (7, 2, 5):
+                r.render_resident(frames)
+                assert diff_stats(r.read_image(premultiplied=True), want) == (0, 0), (env, name, frames)
+        finally:
+            r.close()
+
+
 # ---- BASELINE configs 3 and 4 at their full frame sizes (a few frames; the oracle needs seconds)
 def test_config3_morph_1080p_vs_oracle():
     tag = fixture("homestuck-beta-29")

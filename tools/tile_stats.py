@@ -1,6 +1,5 @@
 """Work counts of k2_tiles per strip from the -DSWFR_TSTATS build (build/stats/libswfr.so): band entries of the tile-row, entries
-with a non-empty class, entries walked, partial (path, strip) pairs, cells fetched for them, edge pixels queued for the compacted
-blend.  One frame in flight, scene S1 (argv[1] = s2 for S2).   gpurun: bash tools/build_variant.sh stats -DSWFR_TSTATS && python tools/tile_stats.py"""
+above the last opaque cover, entries walked, partial (path, strip) pairs, cells fetched for them.  One frame in flight, scene S1 (argv[1] = s2 for S2).   gpurun: bash tools/build_variant.sh stats -DSWFR_TSTATS && python tools/tile_stats.py"""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -26,11 +25,12 @@ buf = np.zeros((3, 32768, 8), dtype=np.uint32)
 L.swfr_debug_trace.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
 assert L.swfr_debug_trace(buf.ctypes.data, buf.nbytes) > 0
 b = buf[2][buf[2][:, 7] != 0].astype(np.int64)
-names = ["band entries of the tile-row (n_b)", "entries with a non-empty class", "entries walked (after the cull)", "partial (path, strip) pairs", "cells fetched", "edge pixels queued"]
+names = ["class bytes scanned (64 per round)", "non-empty entries above the last opaque cover", "entries walked", "partial (path, strip) pairs",
+         "cells of the pairs' first row (lane 0)"]
 print("%s: %d strips recorded" % (which, len(b)))
 for i, n in enumerate(names):
     c = b[:, i]
     print("  %-40s total %9d  mean %7.2f  p50 %5d  p90 %5d  p99 %5d  max %6d  strips with none %6d" % (n, c.sum(), c.mean(), np.percentile(c, 50), np.percentile(c, 90), np.percentile(c, 99), c.max(), int((c == 0).sum())))
 pairs = b[:, 3]
-print("  cells per pair %.1f, edge pixels per pair %.1f" % (b[:, 4].sum() / max(pairs.sum(), 1), b[:, 5].sum() / max(pairs.sum(), 1)))
+print("  cells per (pair, row) %.1f" % (b[:, 4].sum() / max(pairs.sum(), 1)))
 print("  strips without a partial pair: %d of %d; of those with no entry walked at all: %d" % (int((pairs == 0).sum()), len(b), int(((pairs == 0) & (b[:, 2] == 0)).sum())))
