@@ -392,15 +392,19 @@ __global__ __launch_bounds__(1024) void k2_bin_b(const Frame2* __restrict__ fram
 #else
 #define R2PHASE(i) do { } while (0)
 #endif
-struct SubStage {
-    uint32_t cells[4][ROWS_FAST_N * 15];   // the cells (Cell::w) of the (up to four) SUB rows of one pass
-};
-// (per-row slots of the fast row routine: 7 KB; with the packed staging and the staged edges a k2_rows wavefront needs 12.9 KB of
-//  LDS -- twelve of them fit a CU, as many as its registers allow)
-struct FastLds2 {
-    uint16_t eid[ROWS_FAST_N][64];
-    int32_t roles[ROWS_FAST_N][64];
-    uint16_t clo[ROWS_FAST_N][64], chi[ROWS_FAST_N][64];   // pixel columns, clamped to [0, 65535]
+// LDS of the fast row routine besides the staged edges: 2.8 KB (3.3 KB in the wide instance) -- round 2 kept role and column tables
+// for all 64 rows (7 KB); a wavefront now needs 5.9 KB with its 32 staged edges, so that the registers, not LDS, bound the
+// wavefronts per CU.
+//   eid       the rows' active edges (index into the chunk's edge list): what the sample lanes of a SUB row look up
+//   sub_*     roles and column range per edge of the FOUR rows of the current sample pass (their row lanes take them over in
+//             the same pass)
+//   u.key     per-lane scratch of the coincident-cells check (dynamic indexing of a row's cells), before the sample passes;
+//   u.cells   ... whose staging of the pass's cells (Cell::w per (row of the pass, edge, sample row)) reuses the same bytes
+template <class EID>
+struct FastLds3 {
+    EID eid[ROWS_FAST_N][64];
+    uint32_t sub_roles[ROWS_FAST_N][4], sub_cols[ROWS_FAST_N][4];
+    union { int32_t key[ROWS_FAST_N][64]; uint32_t cells[4][ROWS_FAST_N * 15]; } u;
 };
 // a SUB cell: the span end at cell position x (24.8) opens (sgn > 0) or closes a span
 __device__ __forceinline__ uint32_t pack_sub_cell(int x, int sgn, int xminp, int xmaxp) {
@@ -414,8 +418,8 @@ __device__ __forceinline__ uint32_t pack_sub_cell(int x, int sgn, int xminp, int
 // at the first sample row (their order is a matter of Cairo's list history) is not decided here: `defer_out`.  (2) The sample lanes
 // of a SUB row do not only set role bits, they produce the row's cells: staged in LDS per pass of four rows, then allocated and copied out by the
 // whole wavefront, and the rows' RowInfo2 written (index `ri` per row lane; ~0u: the path has no band entry, nothing is kept).
-template <class EPTR>
-__device__ __forceinline__ void rows2_fast(EPTR E, uint32_t n_list, const DevPath& P, int r, bool live, int fast_limit, FastLds2& F, SubStage& S, int lane,
+template <class EPTR, class FLDS>
+__device__ __forceinline__ void rows2_fast(EPTR E, uint32_t n_list, const DevPath& P, int r, bool live, int fast_limit, FLDS& F, int lane,
                                            uint32_t& mode_out, int& n_out_edges, bool& overflow_out, bool& defer_out,
                                            int32_t (&roles)[ROWS_FAST_N], int32_t (&cols)[ROWS_FAST_N], int (&el)[ROWS_FAST_N],
                                            int32_t (&Q1)[ROWS_FAST_N], int64_t (&R1)[ROWS_FAST_N], int32_t (&Q2)[ROWS_FAST_N], int64_t (&R2)[ROWS_FAST_N],
@@ -474,7 +478,10 @@ __device__ __forceinline__ void rows2_fast(EPTR E, uint32_t n_list, const DevPat
                 qb -= hq; rb -= hr; if (rb < 0) { --qb; rb += e.dy; } else if (rb >= e.dy) { ++qb; rb -= e.dy; }
             }
             cs[s] = c0; ce[s] = c1; cp[s] = cpv; dr[s] = e.dir; nw[s] = (e.ytop == s0) ? 1 : 0;
-            Q1[s] = qa; R1[s] = ra; Q2[s] = qb; R2[s] = rb;
+            Q1[s] = qa; Q2[s] = qb;
+#ifdef R2_KEEP_REMAINDERS
+            R1[s] = ra; R2[s] = rb;
+#endif
         }
     }
     R2PHASE(3);
@@ -512,13 +519,15 @@ __device__ __forceinline__ void rows2_fast(EPTR E, uint32_t n_list, const DevPat
         // order -- index order was used above; any other tie needs the history of Cairo's edge list: the slow-row kernel's job
         if (__ballot(deep && !mid_row) != 0ull) {
 #pragma unroll
-            for (int s = 0; s < ROWS_FAST_N; ++s) { F.roles[s][lane] = cs[s]; F.eid[s][lane] = (uint16_t)el[s]; }
+            for (int s = 0; s < ROWS_FAST_N; ++s) F.u.key[s][lane] = cs[s];
             if (deep && !mid_row) {
                 bool real = false;
                 for (int i = 0; i < n && !real; ++i)
                     for (int j = i + 1; j < n && !real; ++j)
-                        if (F.roles[i][lane] == F.roles[j][lane]) {
-                            const int a = F.eid[i][lane], b = F.eid[j][lane];
+                        if (F.u.key[i][lane] == F.u.key[j][lane]) {
+                            int a = 0, b = 0;
+#pragma unroll
+                            for (int s = 0; s < ROWS_FAST_N; ++s) { if (s == i) a = el[s]; if (s == j) b = el[s]; }
                             real = !(E[a].x1 == E[b].x1 && E[a].y1 == E[b].y1 && E[a].ex == E[b].ex && E[a].dy == E[b].dy);       // same_line
                         }
                 defer = real;
@@ -546,7 +555,7 @@ __device__ __forceinline__ void rows2_fast(EPTR E, uint32_t n_list, const DevPat
 #pragma unroll
             for (int s = 0; s < ROWS_FAST_N; ++s) {
                 if (s >= nmax) continue;                      // wave-uniform: the sample lanes stop at nmax as well
-                F.eid[s][lane] = (uint16_t)el[s]; F.roles[s][lane] = 0; F.clo[s][lane] = 65535; F.chi[s][lane] = 0;
+                F.eid[s][lane] = (decltype(F.eid[0][0] + 0))el[s];
             }
         }
     }
@@ -577,7 +586,24 @@ __device__ __forceinline__ void rows2_fast(EPTR E, uint32_t n_list, const DevPat
             if (s >= nmax) continue;
             if (s < n && roles[s] != 0) {
                 const int64_t edy = E[el[s]].dy;
+#ifndef R2_KEEP_REMAINDERS
+                // the remainders of the row's end points are worked out again here rather than kept in sixteen 64-bit registers per lane
+                // from the evaluation on (the quotients are the ones kept: the same formulas give the same numbers)
+                int64_t ra = 0, rb = 0;
+                if (edy) {
+                    const DevEdge e = E[el[s]];
+                    int32_t qa, qb;
+                    edge_x_at(e, s0, qa, ra);
+                    qb = qa + e.q15; rb = ra + e.r15;
+                    if (rb >= e.dy) { ++qb; rb -= e.dy; }
+                    const int64_t hr = e.dr / 2;
+                    ra -= hr; if (ra < 0) ra += e.dy; else if (ra >= e.dy) ra -= e.dy;
+                    rb -= hr; if (rb < 0) rb += e.dy; else if (rb >= e.dy) rb -= e.dy;
+                }
+                full_cells(Q1[s], ra, Q2[s], rb, edy, E[el[s]].inv_dx, E[el[s]].fq, E[el[s]].fr, ((uint32_t)roles[s] & 1u) ? +1 : -1, P.x_min, P.x_max, &FR->cells[off]);
+#else
                 full_cells(Q1[s], R1[s], Q2[s], R2[s], edy, E[el[s]].inv_dx, E[el[s]].fq, E[el[s]].fr, ((uint32_t)roles[s] & 1u) ? +1 : -1, P.x_min, P.x_max, &FR->cells[off]);
+#endif
                 off += (uint32_t)full_span(Q1[s], Q2[s]);
             }
         }
@@ -660,13 +686,23 @@ __device__ __forceinline__ void rows2_fast(EPTR E, uint32_t n_list, const DevPat
             rb |= __builtin_amdgcn_update_dpp(0, rb, 0x121, 0xf, 0xf, false);
             lo = min(lo, __builtin_amdgcn_update_dpp(0, lo, 0x121, 0xf, 0xf, false));
             hi = max(hi, __builtin_amdgcn_update_dpp(0, hi, 0x121, 0xf, 0xf, false));
-            if (sub == 0 && R >= 0) { F.roles[j][R] = rb; F.clo[j][R] = (uint16_t)lo; F.chi[j][R] = (uint16_t)hi; }
+            if (sub == 0 && R >= 0) { F.sub_roles[j][g] = (uint32_t)rb; F.sub_cols[j][g] = (uint32_t)lo | ((uint32_t)hi << 16); }
             const bool cell = contributes && riR != ~0u;
             const unsigned long long cb = __ballot(cell);
-            if (cell) S.cells[g][cnt_g + (uint32_t)__popcll(cb & below)] = pack_sub_cell(cc[j], in_a ? 1 : -1, P.x_min, P.x_max);
+            if (cell) F.u.cells[g][cnt_g + (uint32_t)__popcll(cb & below)] = pack_sub_cell(cc[j], in_a ? 1 : -1, P.x_min, P.x_max);
             cnt_g += (uint32_t)__popcll(cb & group_mask);
         }
-        lds_barrier();                                      // the pass's cells are staged
+        lds_barrier();                                      // the pass's cells, roles and column ranges are staged
+        {   // the row lanes of this pass take their roles and column ranges over (my_t: the lane's place among the pass's four rows)
+            const int my_t = (int)__popcll(pass_rows & ((1ull << lane) - 1ull));
+            if (((pass_rows >> lane) & 1ull) != 0ull && my_t < 4) {
+#pragma unroll
+                for (int s = 0; s < ROWS_FAST_N; ++s) {
+                    if (s >= nmax) continue;
+                    roles[s] = (int32_t)F.sub_roles[s][my_t]; cols[s] = (int32_t)F.sub_cols[s][my_t];
+                }
+            }
+        }
         // ---- copy out (coalesced) into the rows' room, row headers
         {
             const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)cnt_g, 0), c1 = (uint32_t)__builtin_amdgcn_readlane((int)cnt_g, 16);
@@ -687,7 +723,7 @@ __device__ __forceinline__ void rows2_fast(EPTR E, uint32_t n_list, const DevPat
                     const int gg = t < c0 ? 0 : (t < c0 + c1 ? 1 : (t < c0 + c1 + c2 ? 2 : 3));
                     const uint32_t pre = gg == 0 ? 0u : (gg == 1 ? c0 : (gg == 2 ? c0 + c1 : c0 + c1 + c2));
                     const uint32_t bb = gg == 0 ? b0 : (gg == 1 ? b1 : (gg == 2 ? b2 : b3));
-                    FR->cells[bb + (t - pre)] = Cell{S.cells[gg][t - pre]};
+                    FR->cells[bb + (t - pre)] = Cell{F.u.cells[gg][t - pre]};
                 }
             }
             if (sub == 0 && R >= 0 && riR != ~0u) {          // the first sample lane of each of the pass's rows writes its header
@@ -697,14 +733,6 @@ __device__ __forceinline__ void rows2_fast(EPTR E, uint32_t n_list, const DevPat
             }
         }
         lds_barrier();                                      // the staging has been read: the next pass may overwrite it
-    }
-    lds_barrier();                                          // role bits OR-ed in by the sample lanes
-    if (is_sub) {
-#pragma unroll
-        for (int s = 0; s < ROWS_FAST_N; ++s) {
-            if (s >= nmax) continue;
-            roles[s] = F.roles[s][lane]; cols[s] = (int32_t)((uint32_t)F.clo[s][lane] | ((uint32_t)F.chi[s][lane] << 16));
-        }
     }
     R2PHASE(5);
     mode_out = mode; n_out_edges = n; overflow_out = overflow; defer_out = defer;
@@ -721,8 +749,8 @@ __device__ __forceinline__ void rows2_chunk_body(FramePtr FR, uint32_t block) {
 #ifdef SWFR_PHASES
     r2ph_t = __builtin_amdgcn_s_memtime();
 #endif
-    __shared__ FastLds2 F;
-    __shared__ SubStage S;
+    // (the 32-edge instance runs scenes whose paths have at most 32 edges: an edge's index in the chunk's list fits a byte)
+    __shared__ FastLds3<typename std::conditional<(STAGE <= 32), uint8_t, uint16_t>::type> F;
     __shared__ DevEdge staged[STAGE];
     const int lane = threadIdx.x;
     const ChunkInfo ck = FR->chunks[block];                               // wave-uniform: path and edge reads are scalar
@@ -753,7 +781,7 @@ __device__ __forceinline__ void rows2_chunk_body(FramePtr FR, uint32_t block) {
         return;
     }
     int fast_limit = (int)FR->fast_limit;
-    if (P.n_edges > 65535u) fast_limit = 0;                             // 16-bit local edge indices in the fast path
+    if (P.n_edges > (sizeof(F.eid[0][0]) == 1 ? 255u : 65535u)) fast_limit = 0;   // 8- / 16-bit local edge indices in the fast path
     R2PHASE(0);
     // ---- stage the edges that can be active in this chunk's rows (path order kept)
     const int lo_s = (int)ck.first_row * 15, hi_s = lo_s + chunk_rows * 15;
@@ -779,8 +807,8 @@ __device__ __forceinline__ void rows2_chunk_body(FramePtr FR, uint32_t block) {
     int32_t roles[ROWS_FAST_N], cols[ROWS_FAST_N]; int el[ROWS_FAST_N];
     int32_t Q1[ROWS_FAST_N], Q2[ROWS_FAST_N]; int64_t R1[ROWS_FAST_N], R2[ROWS_FAST_N];
     int n_cells; uint32_t incl, base;
-    if (use_lds) rows2_fast((const DevEdge*)staged, n_list, P, r, live, fast_limit, F, S, lane, mode, n, overflow, defer, roles, cols, el, Q1, R1, Q2, R2, nmax, ri, FR, n_cells, incl, base, r2ph, r2ph_t, chunk_cell_base);
-    else rows2_fast(FR->edges + P.first_edge, P.n_edges, P, r, live, fast_limit, F, S, lane, mode, n, overflow, defer, roles, cols, el, Q1, R1, Q2, R2, nmax, ri, FR, n_cells, incl, base, r2ph, r2ph_t, chunk_cell_base);
+    if (use_lds) rows2_fast((const DevEdge*)staged, n_list, P, r, live, fast_limit, F, lane, mode, n, overflow, defer, roles, cols, el, Q1, R1, Q2, R2, nmax, ri, FR, n_cells, incl, base, r2ph, r2ph_t, chunk_cell_base);
+    else rows2_fast(FR->edges + P.first_edge, P.n_edges, P, r, live, fast_limit, F, lane, mode, n, overflow, defer, roles, cols, el, Q1, R1, Q2, R2, nmax, ri, FR, n_cells, incl, base, r2ph, r2ph_t, chunk_cell_base);
     const bool slow = live && (overflow || defer);
     // ---- headers of the rows that are not SUB (those were written with their cells); a FULL row's cells are in place already
     const bool emit = mode == ROW_FULL && ri != ~0u && !slow;
@@ -907,11 +935,10 @@ __device__ __forceinline__ void rows2_chunk_body(FramePtr FR, uint32_t block) {
 #endif
 }
 
-#ifdef R2_WAVES
-#define R2_ATTR __attribute__((amdgpu_waves_per_eu(R2_WAVES)))
-#else
-#define R2_ATTR
+#ifndef R2_WAVES
+#define R2_WAVES 5                 // 95 VGPRs (five dwords of scratch) and 5.9 KB of LDS: five wavefronts per SIMD
 #endif
+#define R2_ATTR __attribute__((amdgpu_waves_per_eu(R2_WAVES)))
 __global__ __launch_bounds__(64) R2_ATTR void k2_rows_b(const Frame2* __restrict__ frames) {
     TRACE_DECL;
     TRACE_NOWAIT(0);

@@ -8,6 +8,7 @@
 // the CPU scan converter.  No MFMA: there is no dense contraction on this path; the roof is HBM bandwidth.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #ifdef SWFR_EMU
 #include <cstdio>
 #include <cstdlib>
