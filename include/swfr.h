@@ -50,7 +50,7 @@ enum {
     SWFR_ERR_NOT_FOUND = 3,        /* unknown shape / bitmap id (reference: BitmapNotFound) */
     SWFR_ERR_NO_DEVICE = 4,        /* no HIP device, or a host-only handle was asked to rasterize */
     SWFR_ERR_DEVICE = 5,           /* HIP runtime error */
-    SWFR_ERR_CAPACITY = 6          /* a capacity limit of the scan converter: more than 2048 active edges of one path in a pixel row (or
+    SWFR_ERR_CAPACITY = 6          /* a capacity limit of the scan converter: more than 8192 active edges of one path in a pixel row (or
                                       starting at one sample row), a single path wider than 8192 px, or a limit of the replay of Cairo's
                                       edge-list order for coincident edges (swfr_get_stats) -- the frame is refused, never approximated */
 };
@@ -269,7 +269,7 @@ typedef struct swfr_stats {
     uint64_t crowded_rows;               /* ... of which handed on to k2_rows_huge (> 64 active edges) */
     uint64_t tie_rows;                   /* rows whose edge order came from the list-order replay */
     uint64_t pairtest_limit;             /* frames refused: crossing test over more than 2^21 edge pairs */
-    uint64_t start_group_limit;          /* frames refused: more than 2048 edges of a path start at one sample row / are active in a row */
+    uint64_t start_group_limit;          /* frames refused: more than 8192 edges of a path start at one sample row / are active in a row */
     uint64_t history_limit;              /* frames refused: order of two older coincident edges needs history deeper than two levels */
     uint64_t reserved;
 } swfr_stats;

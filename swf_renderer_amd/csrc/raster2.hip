@@ -13,7 +13,7 @@
 //              more than eight active edges, goes to a queue.
 //   k2_start_ranks / k2_rows_slow / k2_rows_huge   the queued rows (launched only while a resident scene may have any): the order
 //              Cairo's bucket sort gives edges that start together, then one wavefront (<= 64 active edges) or one 256-thread
-//              workgroup (<= 2048) per row, up to SLOW_PASSES passes (a row whose history runs through another queued row waits)
+//              workgroup (<= 8192) per row, up to SLOW_PASSES passes (a row whose history runs through another queued row waits)
 //   k2_tiles   one wavefront per 64x8-pixel strip of the launch list: class bytes -> surviving band entries (everything under the
 //              last opaque full cover is culled from the class bytes alone) -> the cells of the partial paths as one coalesced
 //              stream -> LDS accumulators -> wave64 prefix sum -> alpha -> shade -> blend in registers -> one store per pixel.
@@ -876,6 +876,23 @@ __device__ __forceinline__ void rows2_chunk_body(FramePtr FR, uint32_t block) {
 #pragma unroll
             for (int s2 = 0; s2 < ROWS_FAST_N; ++s2) { roles[s2] = __shfl(roles[s2], src); cols[s2] = __shfl(cols[s2], src); }
         }
+        // (which of the handle's tile-rows this lane's band is -- two integer divisions by the band stride -- does not depend on the column)
+        uint32_t local_trow = 0;
+        const bool own_band = FR->strip_order && band_ok_c && owns_band(FR, band_c, local_trow);
+        // per record of the row, once for all columns: its net height (0: no record), the last column it occupies when it can lie left
+        // of a tile (else "never left") and the first when it can lie right of one -- the loop over the tile columns is then two
+        // compares, a select and an add per record, without branches
+        int hgt[ROWS_FAST_N], chiL[ROWS_FAST_N], cloR[ROWS_FAST_N];
+#pragma unroll
+        for (int s2 = 0; s2 < ROWS_FAST_N; ++s2) {
+            hgt[s2] = 0; chiL[s2] = 0x7fffffff; cloR[s2] = 0x7fffffff;       // (no record: left of nothing, right of everything -- never "inter")
+            if (s2 >= nmax) continue;                                        // wave-uniform
+            const bool has = s2 < n_c && roles[s2] != 0;
+            const int clo = (int)((uint32_t)cols[s2] & 0xffffu), chi = (int)((uint32_t)cols[s2] >> 16);
+            hgt[s2] = has ? record_height((uint32_t)roles[s2]) : 0;
+            chiL[s2] = has ? (chi < 65535 ? chi : 0x7fffffff) : 0x7fffffff;
+            cloR[s2] = has ? (clo < 65535 ? clo : -0x7fffffff) : 0x7fffffff;
+        }
         for (int tcb = tc0; tcb <= tc1; tcb += groups) {      // wave-uniform
             const int tc = tcb + gi;
             const bool tcv = tc <= tc1;
@@ -891,11 +908,9 @@ __device__ __forceinline__ void rows2_chunk_body(FramePtr FR, uint32_t block) {
 #pragma unroll
                     for (int s2 = 0; s2 < ROWS_FAST_N; ++s2) {
                         if (s2 >= nmax) continue;                        // wave-uniform
-                        if (s2 >= n_c || roles[s2] == 0) continue;
-                        const int clo = (int)((uint32_t)cols[s2] & 0xffffu), chi = (int)((uint32_t)cols[s2] >> 16);
-                        if (chi < tx0 && chi < 65535) carry += record_height((uint32_t)roles[s2]);
-                        else if (clo >= tx0 + TILE_W && clo < 65535) { /* right of the tile */ }
-                        else inter = true;
+                        const bool left = chiL[s2] < tx0, right = cloR[s2] >= tx0 + TILE_W;
+                        carry += left ? hgt[s2] : 0;
+                        inter |= !left && !right;
                     }
                     const bool inside_x = P.x_min <= tx0 && P.x_max >= tile_x1;
                     const uint32_t a = (uint32_t)((carry * 512 * 17 + 256) >> 9) & 255u;
@@ -913,13 +928,12 @@ __device__ __forceinline__ void rows2_chunk_body(FramePtr FR, uint32_t block) {
             if ((f & (CLS_HOLE | CLS_NONEMPTY)) == (CLS_HOLE | CLS_NONEMPTY)) f |= CLS_PARTIAL;
             f &= ~CLS_HOLE;
             if ((f & (CLS_PARTIAL | CLS_NOTFULL | CLS_NONEMPTY)) == CLS_NONEMPTY) f |= opq;        // a full cover that hides what lies below
-            if ((lane & 7) == 0 && band_ok_c && tcv) out[(size_t)(tc * STRIPS_PER_TILE + ((lane >> 3) & 1)) * n_b_c] = (uint8_t)f;
+            if ((lane & 7) == 0 && band_ok_c && tcv) out[(uint32_t)(tc * STRIPS_PER_TILE + ((lane >> 3) & 1)) * n_b_c] = (uint8_t)f;   // (< 2^32: strips of a tile-row x its entries)
             // the tile's strips get heavier by the rows of this path with a boundary in the tile (the tile pass starts its heaviest
             // strips first): lanes 0 and 8 of the tile-row's sixteen add their half's rows
             if (FR->strip_order) {
                 const unsigned long long pb = __ballot(row_partial);
-                uint32_t local_trow = 0;
-                if ((lane & 7) == 0 && band_ok_c && tcv && (f & CLS_PARTIAL) && owns_band(FR, band_c, local_trow)) {
+                if ((lane & 7) == 0 && own_band && tcv && (f & CLS_PARTIAL)) {
                     const uint32_t wgt = (uint32_t)__popcll((pb >> lane) & 0xffull);
                     if (wgt) atomicAdd(&FR->strip_cost[((size_t)local_trow * FR->tiles_x + tc) * STRIPS_PER_TILE + ((lane >> 3) & 1)], wgt);
                 }
@@ -990,7 +1004,7 @@ __device__ __forceinline__ void merge_step(const uint16_t* __restrict__ src, uin
 // the order Cairo's sort of that bucket gives them (DevEdge::pad): what new_order_before needs, for any number of edges.  One
 // 256-thread workgroup per path; an edge alone at its sample row keeps 0, a pair is ordered directly, larger groups are replayed
 // one after the other with the merge sort above.
-#define START_MAX 2048                 // edges of one path that may start at one sample row (more: the frame fails loudly)
+#define START_MAX 8192                 // edges of one path that may start at one sample row (more: the frame fails loudly); 104 KB of LDS
 __device__ __forceinline__ void rank_tmp(DevEdge* E, int i, int rank) { E[i].pad = rank; }
 #define START_LDS 1024                 // paths with at most this many edges keep their start rows and marks in LDS while they are ranked
 __device__ __forceinline__ void start_ranks_body(FramePtr FR, uint32_t p) {
@@ -1275,13 +1289,14 @@ __device__ __forceinline__ void slow_rows_loop(FramePtr FR, uint32_t pass) {
 }
 __global__ __launch_bounds__(64) void k2_rows_slow_b(const Frame2* __restrict__ frames, uint32_t pass) { slow_rows_loop(FRAME_PTR(frames, blockIdx.y), pass); }
 
-// k2_rows_huge: rows with 65 .. 2048 active edges of one path, one 256-thread workgroup each:
-// thread t owns the active edges t, t + 256, ... and ranks each against the row's sort keys in LDS.
+// k2_rows_huge: rows with 65 .. 8192 active edges of one path, one 1024-thread workgroup each (136 KB of LDS: one workgroup per CU):
+// thread t owns the active edges t, t + 1024, ... and ranks each against the row's sort keys in LDS.
 __device__ __forceinline__ void huge_row_body(FramePtr FR, const SlowRow sr, uint32_t pass) {
     __shared__ uint32_t retry;
     __shared__ uint32_t active[ROWS_HUGE_MAXA];
-    __shared__ int k_a[ROWS_HUGE_MAXA], k_b[ROWS_HUGE_MAXA], k_c[ROWS_HUGE_MAXA], k_d[ROWS_HUGE_MAXA];
-    __shared__ uint32_t wave_cnt[4];
+    __shared__ int k_a[ROWS_HUGE_MAXA], k_b[ROWS_HUGE_MAXA], k_c[ROWS_HUGE_MAXA];
+    __shared__ int8_t k_d[ROWS_HUGE_MAXA];                           // new / direction / "lets a tying new edge go first" bits, or the direction alone
+    __shared__ uint32_t wave_cnt[HUGE_THREADS / 64];
     __shared__ int flags;                                            // bit 0: some edge starts / ends inside the row, bit 1: FULL test failed
     __shared__ uint32_t cell_base;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1292,7 +1307,7 @@ __device__ __forceinline__ void huge_row_body(FramePtr FR, const SlowRow sr, uin
     const PathEdges PE = {FR->edges, nullptr, &P, false, FR->counters, FR->rows, FR->band_slots, sr.pad & 0x7fffffffu, pass + 1 < SLOW_PASSES ? &retry : nullptr};
     if (tid == 0) { flags = 0; retry = 0; }
     int n = 0;
-    for (uint32_t base = 0; base < P.n_edges; base += 256) {
+    for (uint32_t base = 0; base < P.n_edges; base += HUGE_THREADS) {
         const uint32_t k = base + (uint32_t)tid;
         bool act = false;
         if (k < P.n_edges) { const int ytop = E[k].ytop, ybot = E[k].ybot; act = !(ybot <= s0 || ytop >= s0 + 15); }
@@ -1303,7 +1318,7 @@ __device__ __forceinline__ void huge_row_body(FramePtr FR, const SlowRow sr, uin
         for (int w = 0; w < wave; ++w) at += (int)wave_cnt[w];
         at += __popcll(b & ((1ull << lane) - 1ull));
         if (act && at < ROWS_HUGE_MAXA) active[at] = k;
-        n += (int)(wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3]);
+        for (int w = 0; w < HUGE_THREADS / 64; ++w) n += (int)wave_cnt[w];
         __syncthreads();
     }
     RowInfo2 ri; ri.off = 0; ri.n = 0; ri.mode = ROW_EMPTY;
@@ -1311,18 +1326,18 @@ __device__ __forceinline__ void huge_row_body(FramePtr FR, const SlowRow sr, uin
         if (tid == 0) { atomicOr(&FR->counters[C2_ERROR], E2_ACTIVE_EDGES); FR->rows[sr.ri] = ri; }
         return;
     }
-    const int nb = (n + 255) >> 8;                                   // owned edges per thread (workgroup-uniform)
+    const int nb = (n + HUGE_THREADS - 1) / HUGE_THREADS;                                   // owned edges per thread (workgroup-uniform)
     uint32_t role[ROWS_HUGE_EPT];
 #pragma unroll
     for (int m = 0; m < ROWS_HUGE_EPT; ++m) role[m] = 0;
-    for (int j = tid; j < n; j += 256) {
+    for (int j = tid; j < n; j += HUGE_THREADS) {
         const DevEdge e = E[active[j]];
         if ((e.ytop > s0) | (e.ybot < s0 + 15)) atomicOr(&flags, 1);
     }
     __syncthreads();
     bool full = (flags & 1) == 0;
     if (full) {
-        for (int j = tid; j < n; j += 256) {
+        for (int j = tid; j < n; j += HUGE_THREADS) {
             const DevEdge e = E[active[j]];
             int c0, c1, cpv; int32_t q1, q2; int64_t r1, r2;
             huge_full_keys(e, s0, c0, c1, cpv, q1, r1, q2, r2);
@@ -1332,7 +1347,7 @@ __device__ __forceinline__ void huge_row_body(FramePtr FR, const SlowRow sr, uin
         for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
             for (int m = 0; m < ROWS_HUGE_EPT; ++m) {
-                const int j = m * 256 + tid;
+                const int j = m * HUGE_THREADS + tid;
                 role[m] = 0;
                 if (m >= nb || j >= n) continue;
                 const int c0 = k_a[j], c1 = k_b[j], nw = (k_d[j] >> 2) & 1, dr = (k_d[j] & 3) - 1, nfj = (k_d[j] >> 3) & 1;
@@ -1368,7 +1383,7 @@ __device__ __forceinline__ void huge_row_body(FramePtr FR, const SlowRow sr, uin
             unsigned nfbits = 0;
 #pragma unroll
             for (int m = 0; m < ROWS_HUGE_EPT; ++m) {
-                const int j = m * 256 + tid;
+                const int j = m * HUGE_THREADS + tid;
                 if (m >= nb || j >= n || ((k_d[j] >> 2) & 1)) continue;
                 const int c0 = k_a[j], cpv = k_c[j];
                 int L = INT_MIN; bool tied_before = false, any_new = false;
@@ -1388,7 +1403,7 @@ __device__ __forceinline__ void huge_row_body(FramePtr FR, const SlowRow sr, uin
             __syncthreads();                                         // every thread has read the keys it needs
 #pragma unroll
             for (int m = 0; m < ROWS_HUGE_EPT; ++m) {
-                const int j = m * 256 + tid;
+                const int j = m * HUGE_THREADS + tid;
                 if (m < nb && j < n && ((nfbits >> m) & 1u)) k_d[j] |= 8;
             }
             __syncthreads();
@@ -1402,7 +1417,7 @@ __device__ __forceinline__ void huge_row_body(FramePtr FR, const SlowRow sr, uin
         for (int m = 0; m < ROWS_HUGE_EPT; ++m) role[m] = 0;
         for (int sub = 0; sub < 15; ++sub) {
             const int ss = s0 + sub;
-            for (int j = tid; j < n; j += 256) {
+            for (int j = tid; j < n; j += HUGE_THREADS) {
                 const DevEdge e = E[active[j]];
                 const bool act = e.ytop <= ss && ss < e.ybot;
                 int cc = e.x1;
@@ -1412,7 +1427,7 @@ __device__ __forceinline__ void huge_row_body(FramePtr FR, const SlowRow sr, uin
             __syncthreads();
 #pragma unroll
             for (int m = 0; m < ROWS_HUGE_EPT; ++m) {
-                const int j = m * 256 + tid;
+                const int j = m * HUGE_THREADS + tid;
                 if (m >= nb || j >= n) continue;
                 const int dd = k_d[j], cc = k_a[j];
                 if (dd == 0) continue;
@@ -1444,7 +1459,7 @@ __device__ __forceinline__ void huge_row_body(FramePtr FR, const SlowRow sr, uin
     uint32_t mine_cells = 0;
 #pragma unroll
     for (int m = 0; m < ROWS_HUGE_EPT; ++m) {
-        const int j = m * 256 + tid;
+        const int j = m * HUGE_THREADS + tid;
         if (m >= nb || j >= n || role[m] == 0) continue;
         if (role[m] & REC_FULL) {
             const DevEdge e = E[active[j]];
@@ -1458,7 +1473,8 @@ __device__ __forceinline__ void huge_row_body(FramePtr FR, const SlowRow sr, uin
     __syncthreads();
     uint32_t before = incl - mine_cells;
     for (int w = 0; w < wave; ++w) before += wave_cnt[w];
-    const uint32_t total = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    uint32_t total = 0;
+    for (int w = 0; w < HUGE_THREADS / 64; ++w) total += wave_cnt[w];
     if (tid == 0) {
         uint32_t base = 0;
         if (total) {
@@ -1474,7 +1490,7 @@ __device__ __forceinline__ void huge_row_body(FramePtr FR, const SlowRow sr, uin
         Cell* dst = &FR->cells[base + before];
 #pragma unroll
         for (int m = 0; m < ROWS_HUGE_EPT; ++m) {
-            const int j = m * 256 + tid;
+            const int j = m * HUGE_THREADS + tid;
             if (m >= nb || j >= n || role[m] == 0) continue;
             const DevEdge e = E[active[j]];
             if (role[m] & REC_FULL) {
@@ -1502,7 +1518,7 @@ __device__ __forceinline__ void huge_rows_loop(FramePtr FR, uint32_t pass) {
         __syncthreads();
     }
 }
-__global__ __launch_bounds__(256) void k2_rows_huge_b(const Frame2* __restrict__ frames, uint32_t pass) { huge_rows_loop(FRAME_PTR(frames, blockIdx.y), pass); }
+__global__ __launch_bounds__(HUGE_THREADS) void k2_rows_huge_b(const Frame2* __restrict__ frames, uint32_t pass) { huge_rows_loop(FRAME_PTR(frames, blockIdx.y), pass); }
 
 // ---------------------------------------------------------------------------------------------
 // shading: three instances of the tile kernel -- solid colours only; + bitmap fills (integer arithmetic only: pixman's
@@ -2041,7 +2057,7 @@ void launch2_rows_slow(hipStream_t st, const Frame2* frames, uint32_t n_frames, 
     // a queued row whose edge-order history runs through another queued row is queued again for the next pass
     for (uint32_t pass = 0; pass < SLOW_PASSES; ++pass) {
         if (grid_slow) hipLaunchKernelGGL(k2_rows_slow_b, dim3(grid_slow, n_frames), dim3(64), 0, st, frames, pass);
-        if (grid_huge) hipLaunchKernelGGL(k2_rows_huge_b, dim3(grid_huge, n_frames), dim3(256), 0, st, frames, pass);
+        if (grid_huge) hipLaunchKernelGGL(k2_rows_huge_b, dim3(grid_huge, n_frames), dim3(HUGE_THREADS), 0, st, frames, pass);
         if (pass + 1 >= max_passes) break;
     }
 }

@@ -357,12 +357,13 @@ __device__ __forceinline__ bool tied_order(const PathEdges& PE, const DevEdge& a
     return tied_order_at<2>(PE, a, b, ka, kb, s0, path_order);
 }
 
-// Rows with more than ROWS_BIG_MAXA (64) and up to ROWS_HUGE_MAXA (2048) active edges of one path (a line of text outlines
-// filled with one style, hatching): one 256-thread workgroup per row; thread t owns the active edges t, t + 256, ... (path
+// Rows with more than ROWS_BIG_MAXA (64) and up to ROWS_HUGE_MAXA (8192) active edges of one path (a line of text outlines
+// filled with one style, hatching): one 1024-thread workgroup per row; thread t owns the active edges t, t + 1024, ... (path
 // order), the sort keys of all of them sit in LDS and every owned edge is ranked against them.  Same decisions as big_row_body;
 // launched only when the host listed such rows.
-#define ROWS_HUGE_MAXA 2048
-#define ROWS_HUGE_EPT (ROWS_HUGE_MAXA / 256)
+#define ROWS_HUGE_MAXA 8192
+#define HUGE_THREADS 1024
+#define ROWS_HUGE_EPT (ROWS_HUGE_MAXA / HUGE_THREADS)
 // x of edge e at the top and bottom of pixel row s0/15 (exact end points of a FULL record) and the sort keys of the row
 __device__ __forceinline__ void huge_full_keys(const DevEdge& e, int s0, int& c0, int& c1, int& cpv, int32_t& q1, int64_t& r1, int32_t& q2, int64_t& r2) {
     c0 = c1 = cpv = e.x1; q1 = q2 = e.x1; r1 = r2 = 0;

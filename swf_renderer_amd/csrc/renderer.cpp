@@ -823,7 +823,7 @@ int check_counters(swfr_renderer* r, const uint32_t* counters) {
         if (err) {
             r->fb_valid = false;
             return fail(r, SWFR_ERR_CAPACITY, err & E2_CELL_ARENA ? "cell arena exhausted (uneven allocator shares)" :
-                        "a pixel row has more than 2048 active edges of one path, or more than 2048 of its edges start at one sample row (scan converter capacity)");
+                        "a pixel row has more than 8192 active edges of one path, or more than 8192 of its edges start at one sample row (scan converter capacity)");
         }
         // the replay of Cairo's edge-list order for coincident edges has capacity limits; a scene that reaches one is refused,
         // never rendered approximately

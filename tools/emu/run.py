@@ -31,5 +31,6 @@ if __name__ == "__main__":
     import pytest
     import torch
     torch.cuda.is_available = lambda: True   # the `gpu` fixture of tests/conftest.py: the emulator plays the device
+    os.environ["SWFR_EMULATOR"] = "1"        # (tests skip the cases that are only a matter of time on the emulator)
     args = sys.argv[1:] or ["-x", "-q"]
     sys.exit(pytest.main([os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-p", "no:cacheprovider"] + args))
