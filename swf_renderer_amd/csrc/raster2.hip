@@ -1781,7 +1781,16 @@ __device__ __forceinline__ void tiles3_body(FramePtr FR) {
 
     for (uint32_t w = blockIdx.x; w < FR->n_strip_slots; w += gridDim.x) {
         TRACE(1);                                                        // descriptor fields in
+#if defined(SWFR_EMU) || defined(T3_VECTOR_DESC)
         const StripDesc sd = FR->strips[w];
+#else
+        // (a scalar load through the constant address space: the slot is wave-uniform, and k2_bin wrote the list in an earlier kernel)
+        StripDesc sd;
+        {
+            const uint32_t __attribute__((address_space(4)))* sp = reinterpret_cast<const uint32_t __attribute__((address_space(4)))*>(reinterpret_cast<uintptr_t>(FR->strips + w));
+            sd.wg = sp[0]; sd.band_begin = sp[1]; sd.n_b = sp[2]; sd.pad = 0;
+        }
+#endif
         const uint32_t wg = sd.wg;
         if (wg == ~0u) continue;                                         // a padding slot of the launch list
         TRACE(2);                                                        // strip descriptor in
