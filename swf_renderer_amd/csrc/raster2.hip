@@ -777,7 +777,7 @@ __device__ __forceinline__ void rows2_chunk_body(FramePtr FR, uint32_t block) {
     { uint32_t lb; if (live && !owns_band(FR, r / TILE_H, lb)) live = false; }         // another rank's tile-row
     if (__ballot(live) == 0ull) {
         // nothing of this chunk is this handle's (multi-GPU): its rows stay "not known here" for the slow rows' history look-ups
-        if (ri != ~0u && lane < chunk_rows) { RowInfo2 h; h.off = 0; h.n = 0; h.mode = (uint16_t)(in_path ? ROW_FOREIGN : ROW_EMPTY); FR->rows[ri] = h; }
+        if (ri != ~0u && lane < chunk_rows) { RowInfo2 h; h.off = 0; h.n = 0; h.mode = (uint16_t)(in_path ? (uint32_t)ROW_FOREIGN : (uint32_t)ROW_EMPTY); FR->rows[ri] = h; }
         return;
     }
     int fast_limit = (int)FR->fast_limit;
@@ -813,7 +813,7 @@ __device__ __forceinline__ void rows2_chunk_body(FramePtr FR, uint32_t block) {
     // ---- headers of the rows that are not SUB (those were written with their cells); a FULL row's cells are in place already
     const bool emit = mode == ROW_FULL && ri != ~0u && !slow;
     if (ri != ~0u && lane < chunk_rows && mode != ROW_SUB) {
-        RowInfo2 h; h.off = 0; h.n = 0; h.mode = (uint16_t)(slow ? ROW_DEFER : (in_path && !live) ? ROW_FOREIGN : mode);   // (another rank's row: not known here)
+        RowInfo2 h; h.off = 0; h.n = 0; h.mode = (uint16_t)(slow ? (uint32_t)ROW_DEFER : (in_path && !live) ? (uint32_t)ROW_FOREIGN : mode);   // (another rank's row: not known here)
         if (emit && base != ~0u) { h.off = base + incl - (uint32_t)n_cells; h.n = (uint16_t)n_cells; }
         FR->rows[ri] = h;
     }

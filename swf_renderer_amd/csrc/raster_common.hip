@@ -572,16 +572,6 @@ __device__ __noinline__ uint32_t shade(const swfr_style& s, uint32_t style_index
 }
 
 // ---------------------------------------------------------------------------------------------
-// tile kernel constants
-// ---------------------------------------------------------------------------------------------
-#define ACC_CARRY 64
-
-#ifndef BLEND_QUEUE
-#define BLEND_QUEUE 256                // edge pixels of one (path, strip) blended in compacted form; the accumulator holds 264 pairs
-#endif
-#define PBATCH (64 / STRIP_H)           // partial paths whose row headers and cells are fetched in one round trip each
-
-// ---------------------------------------------------------------------------------------------
 // auxiliary kernels
 // ---------------------------------------------------------------------------------------------
 // un-premultiply (node-canvas getImageData / PNG encode): c' = (c*255 + a/2) / a, a == 0 -> 0
