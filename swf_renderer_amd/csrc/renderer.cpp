@@ -602,7 +602,7 @@ void layout_scene(const swfr_renderer* r, const swfr_edge* edges, size_t n_edges
         const swfr_path& p = paths[i];
         L.chunk_base[i] = uint32_t(L.n_chunks); L.slot_base[i] = uint32_t(L.n_slots);
         if (p.kind == SWFR_PATH_TOR && p.x_max - p.x_min > MAX_PATH_WIDTH)
-            throw StatusError{SWFR_ERR_CAPACITY, "a path wider than 8192 px (cell columns are kept in 13 bits relative to the path)"};
+            throw StatusError{SWFR_ERR_CAPACITY, "a bitmap- or gradient-filled path wider than 8192 px (cell columns are kept in 13 bits relative to the path; solid paths are split)"};
         if (p.kind == SWFR_PATH_TOR && p.y_max > p.y_min) L.n_chunks += (size_t(p.y_max) - size_t(p.y_min) / TILE_H * TILE_H + L.chunk_rows - 1) / L.chunk_rows;
         if (p.y_max > p.y_min && p.x_max > p.x_min) {
             const size_t b0 = size_t(p.y_min / TILE_H), b1 = size_t((p.y_max - 1) / TILE_H);
@@ -633,6 +633,38 @@ void layout_scene(const swfr_renderer* r, const swfr_edge* edges, size_t n_edges
     L.filters.clear(); L.gradients.clear(); L.fparams.clear();
     prepare_sources(paths, n_paths, styles, n_styles, L.filters, L.gradients, L.fparams, r->bitmap_table);
 }
+// A tor path wider than the 13-bit column field of a cell (only possible in frames wider than 8192 px) is rasterized as several
+// paths over the SAME edges, one per block of 8192 pixel columns: the scan converter clips a path's cells to its column range
+// exactly the way a tile does -- a cell left of the range only adds its height to the range's first column, a cell right of it is
+// dropped -- so the blocks' pixels are the pixels of the whole path, and the blocks do not overlap.  Solid colours only (a bitmap or
+// gradient style is anchored at the centre of its ONE drawing operation's rectangle; such a path is still refused).  Returns false
+// when the scene has no such path; otherwise the new edge list (tagged with the owning path) and path table.
+bool split_wide_paths(const swfr_edge* edges, const swfr_path* paths, size_t n_paths, const swfr_style* styles,
+                      std::vector<swfr_edge>& out_e, std::vector<swfr_path>& out_p) {
+    bool any = false;
+    for (size_t i = 0; i < n_paths && !any; ++i)
+        any = paths[i].kind == SWFR_PATH_TOR && paths[i].x_max - paths[i].x_min > MAX_PATH_WIDTH && styles[paths[i].style].kind == SWFR_STYLE_SOLID;
+    if (!any) return false;
+    out_e.clear(); out_p.clear();
+    for (size_t i = 0; i < n_paths; ++i) {
+        const swfr_path& p = paths[i];
+        const bool wide = p.kind == SWFR_PATH_TOR && p.x_max - p.x_min > MAX_PATH_WIDTH && styles[p.style].kind == SWFR_STYLE_SOLID;
+        const int blocks = wide ? (p.x_max - p.x_min + MAX_PATH_WIDTH - 1) / MAX_PATH_WIDTH : 1;
+        for (int k = 0; k < blocks; ++k) {
+            swfr_path q = p;
+            if (wide) { q.x_min = p.x_min + k * MAX_PATH_WIDTH; q.x_max = std::min(p.x_max, q.x_min + MAX_PATH_WIDTH); }
+            q.first_edge = uint32_t(out_e.size());
+            for (uint32_t j = 0; j < p.n_edges; ++j) {
+                swfr_edge e = edges[p.first_edge + j];
+                e.reserved = int32_t(out_p.size());
+                out_e.push_back(e);
+            }
+            out_p.push_back(q);
+        }
+    }
+    return true;
+}
+
 // bytes of the scene's read-only part in an arena (raw arrays + layout prefixes + sources), each piece padded
 size_t scene_arena_bytes(const SceneLayout& L, size_t n_edges, size_t n_paths, size_t n_styles) {
     auto P = SceneArena::padded;
@@ -702,6 +734,11 @@ int upload2(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, siz
         for (size_t i = 0; i < n_paths; ++i)
             for (uint32_t k = 0; k < paths[i].n_edges; ++k) tagged[paths[i].first_edge + k].reserved = int32_t(i);
         edges = tagged.data();
+    }
+    static thread_local std::vector<swfr_edge> split_e;
+    static thread_local std::vector<swfr_path> split_p;
+    if (split_wide_paths(edges, paths, n_paths, styles, split_e, split_p)) {      // (frames wider than 8192 px only)
+        edges = split_e.data(); n_edges = split_e.size(); paths = split_p.data(); n_paths = split_p.size();
     }
     static thread_local SceneLayout layout_scratch;        // (vectors keep their capacity from frame to frame)
     SceneLayout& L = layout_scratch;
@@ -1052,6 +1089,10 @@ int render_batch2(swfr_renderer* r, const swfr_stage* stages, uint32_t n, void* 
             r->builder->build(stages[first + k]);
             F.e = r->builder->edges(); F.p = r->builder->paths(); F.s = r->builder->styles();
             validate_scene(r, F.e.data(), F.e.size(), F.p.data(), F.p.size(), F.s.data(), F.s.size());
+            {
+                std::vector<swfr_edge> se; std::vector<swfr_path> sp;
+                if (split_wide_paths(F.e.data(), F.p.data(), F.p.size(), F.s.data(), se, sp)) { F.e.swap(se); F.p.swap(sp); }
+            }
             layout_scene(r, F.e.data(), F.e.size(), F.p.data(), F.p.size(), F.s.data(), F.s.size(), F.L);
             arena_bytes += scene_arena_bytes(F.L, F.e.size(), F.p.size(), F.s.size());
             const SceneLayout& L = F.L;

@@ -722,7 +722,11 @@ def test_one_handle_alternating_plain_and_crowded_frames():
 
 def test_frames_wider_than_a_cell_column_field():
     """Cells keep their column in 13 bits relative to the path's left edge: in a frame wider than 8192 px a path may lie anywhere
-    (here: beyond column 9000) and is bit-exact, a single path wider than 8192 px is refused with SWFR_ERR_CAPACITY."""
+    (here: beyond column 9000); a single SOLID path wider than 8192 px is rasterized as one path per block of 8192 columns over the
+    same edges (round 3; refused before) -- translucent, so that a seam or a doubled column would show -- and stays bit-exact, also
+    on top of other paths, through swfr_render_batch and with the blocks' boundary inside an anti-aliased edge; a wide path with a
+    gradient fill is still refused with SWFR_ERR_CAPACITY."""
+    import torch
     import swf_renderer_amd as S
     from swf_renderer_amd import api
     w, h = 9600, 48
@@ -730,12 +734,31 @@ def test_frames_wider_than_a_cell_column_field():
     near = scenarios._poly_shape([(50, 60), (4000, 130), (900, 880)], {"type": "solid", "color": scenarios._rgba(20, 200, 50)})
     sc = dict(width=w, height=h, stage={"children": [{"type": "shape", "definition": near}, {"type": "shape", "definition": far}]})
     assert diff_stats(product_render(sc), oracle_render(sc)) == (0, 0)
-    wide = scenarios._poly_shape([(100, 100), (9400 * 20, 200), (9400 * 20, 700), (100, 600), (3000 * 20, 350)], {"type": "solid", "color": scenarios._rgba(1, 2, 3)})
+    pts = [(100, 100), (9400 * 20, 200), (9400 * 20, 700), (100, 600), (3000 * 20, 350)]
+    wide = scenarios._poly_shape(pts, {"type": "solid", "color": scenarios._rgba(1, 2, 3)})
+    wide_t = scenarios._poly_shape(pts, {"type": "solid", "color": scenarios._rgba(200, 30, 90, 140)})
+    # a shallow edge crossing column 5 + 8192 (the block boundary of a path that starts at x = 5) inside an anti-aliased span
+    sliver = scenarios._poly_shape([(100, 400), (9590 * 20, 470), (9590 * 20, 520), (100, 430)], {"type": "solid", "color": scenarios._rgba(10, 90, 250, 200)})
+    for kids in ([wide], [near, wide_t, far], [wide, sliver, wide_t]):
+        sc = dict(width=w, height=h, stage={"children": [{"type": "shape", "definition": k} for k in kids]})
+        assert diff_stats(product_render(sc), oracle_render(sc)) == (0, 0), len(kids)
     r = S.Renderer(w, h)
-    with pytest.raises(S.SwfrError) as e:
-        r.render({"children": [{"type": "shape", "definition": wide}]})
-    assert e.value.code == api.ERR_CAPACITY
-    r.close()
+    try:
+        stage = {"children": [{"type": "shape", "definition": wide}, {"type": "shape", "definition": sliver}]}
+        want = oracle_render(dict(width=w, height=h, stage=stage))
+        if not os.environ.get("SWFR_EMULATOR"):                  # (device tensors need the GPU)
+            out = torch.zeros((2, h, w, 4), dtype=torch.uint8, device="cuda")
+            r.render_batch([stage, stage], out.data_ptr(), h * w * 4)
+            assert diff_stats(out[1].cpu().numpy(), want) == (0, 0)
+        r.render_batch([stage, stage])                           # (the per-frame route)
+        assert diff_stats(r.read_image(premultiplied=True), want) == (0, 0)
+        grad = {"type": "radial-gradient", "matrix": scenarios._m(3.0, 0.02, 4800 * 20, 400),
+                "gradient": scenarios._grad([(0, (255, 0, 0)), (255, (0, 0, 255))])}
+        with pytest.raises(S.SwfrError) as e:
+            r.render({"children": [{"type": "shape", "definition": scenarios._poly_shape(pts, grad)}]})
+        assert e.value.code == api.ERR_CAPACITY
+    finally:
+        r.close()
 
 
 def test_many_active_edges_fails_loudly_not_silently():
