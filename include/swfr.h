@@ -51,7 +51,7 @@ enum {
     SWFR_ERR_NO_DEVICE = 4,        /* no HIP device, or a host-only handle was asked to rasterize */
     SWFR_ERR_DEVICE = 5,           /* HIP runtime error */
     SWFR_ERR_CAPACITY = 6          /* a capacity limit of the scan converter: more than 8192 active edges of one path in a pixel row (or
-                                      starting at one sample row), a bitmap- or gradient-filled path wider than 8192 px, or a limit of the replay of Cairo's
+                                      starting at one sample row), or a limit of the replay of Cairo's
                                       edge-list order for coincident edges (swfr_get_stats) -- the frame is refused, never approximated */
 };
 

@@ -570,8 +570,10 @@ struct SceneLayout {
     std::vector<int32_t> fparams;
 };
 // `edges` carry their path index in `reserved`
+// src_paths: the paths as the caller drew them, when `paths` holds the column blocks of wide ones (split_wide_paths): a bitmap or
+// gradient style is anchored at the rectangle of its drawing operation, not of a block
 void layout_scene(const swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_path* paths, size_t n_paths,
-                  const swfr_style* styles, size_t n_styles, SceneLayout& L) {
+                  const swfr_style* styles, size_t n_styles, SceneLayout& L, const swfr_path* src_paths = nullptr, size_t n_src_paths = 0) {
     L.n_bands = (r->height + TILE_H - 1) / TILE_H;
     const uint32_t tiles_x = (r->width + TILE_W - 1) / TILE_W;
     // rows per k2_rows wavefront: 64 when that already gives the GPU a thousand wavefronts, fewer (whole tile-rows) for scenes made
@@ -602,7 +604,7 @@ void layout_scene(const swfr_renderer* r, const swfr_edge* edges, size_t n_edges
         const swfr_path& p = paths[i];
         L.chunk_base[i] = uint32_t(L.n_chunks); L.slot_base[i] = uint32_t(L.n_slots);
         if (p.kind == SWFR_PATH_TOR && p.x_max - p.x_min > MAX_PATH_WIDTH)
-            throw StatusError{SWFR_ERR_CAPACITY, "a bitmap- or gradient-filled path wider than 8192 px (cell columns are kept in 13 bits relative to the path; solid paths are split)"};
+            throw StatusError{SWFR_ERR_CAPACITY, "a path wider than 8192 px reached the layout unsplit (cell columns are kept in 13 bits relative to the path)"};
         if (p.kind == SWFR_PATH_TOR && p.y_max > p.y_min) L.n_chunks += (size_t(p.y_max) - size_t(p.y_min) / TILE_H * TILE_H + L.chunk_rows - 1) / L.chunk_rows;
         if (p.y_max > p.y_min && p.x_max > p.x_min) {
             const size_t b0 = size_t(p.y_min / TILE_H), b1 = size_t((p.y_max - 1) / TILE_H);
@@ -631,24 +633,23 @@ void layout_scene(const swfr_renderer* r, const swfr_edge* edges, size_t n_edges
     L.n_strips = size_t(local_tile_rows(r)) * tiles_x * STRIPS_PER_TILE;
     L.n_strip_slots = strip_slots(local_tile_rows(r), uint32_t(tiles_x * STRIPS_PER_TILE));
     L.filters.clear(); L.gradients.clear(); L.fparams.clear();
-    prepare_sources(paths, n_paths, styles, n_styles, L.filters, L.gradients, L.fparams, r->bitmap_table);
+    if (src_paths) prepare_sources(src_paths, n_src_paths, styles, n_styles, L.filters, L.gradients, L.fparams, r->bitmap_table);
+    else prepare_sources(paths, n_paths, styles, n_styles, L.filters, L.gradients, L.fparams, r->bitmap_table);
 }
 // A tor path wider than the 13-bit column field of a cell (only possible in frames wider than 8192 px) is rasterized as several
 // paths over the SAME edges, one per block of 8192 pixel columns: the scan converter clips a path's cells to its column range
 // exactly the way a tile does -- a cell left of the range only adds its height to the range's first column, a cell right of it is
-// dropped -- so the blocks' pixels are the pixels of the whole path, and the blocks do not overlap.  Solid colours only (a bitmap or
-// gradient style is anchored at the centre of its ONE drawing operation's rectangle; such a path is still refused).  Returns false
-// when the scene has no such path; otherwise the new edge list (tagged with the owning path) and path table.
-bool split_wide_paths(const swfr_edge* edges, const swfr_path* paths, size_t n_paths, const swfr_style* styles,
-                      std::vector<swfr_edge>& out_e, std::vector<swfr_path>& out_p) {
+// dropped -- so the blocks' pixels are the pixels of the whole path, and the blocks do not overlap.  (A bitmap or gradient style stays
+// anchored at the rectangle of the unsplit path: layout_scene gets the original paths for that.)  Returns false when the scene
+// has no such path; otherwise the new edge list (tagged with the owning path) and path table.
+bool split_wide_paths(const swfr_edge* edges, const swfr_path* paths, size_t n_paths, std::vector<swfr_edge>& out_e, std::vector<swfr_path>& out_p) {
     bool any = false;
-    for (size_t i = 0; i < n_paths && !any; ++i)
-        any = paths[i].kind == SWFR_PATH_TOR && paths[i].x_max - paths[i].x_min > MAX_PATH_WIDTH && styles[paths[i].style].kind == SWFR_STYLE_SOLID;
+    for (size_t i = 0; i < n_paths && !any; ++i) any = paths[i].kind == SWFR_PATH_TOR && paths[i].x_max - paths[i].x_min > MAX_PATH_WIDTH;
     if (!any) return false;
     out_e.clear(); out_p.clear();
     for (size_t i = 0; i < n_paths; ++i) {
         const swfr_path& p = paths[i];
-        const bool wide = p.kind == SWFR_PATH_TOR && p.x_max - p.x_min > MAX_PATH_WIDTH && styles[p.style].kind == SWFR_STYLE_SOLID;
+        const bool wide = p.kind == SWFR_PATH_TOR && p.x_max - p.x_min > MAX_PATH_WIDTH;
         const int blocks = wide ? (p.x_max - p.x_min + MAX_PATH_WIDTH - 1) / MAX_PATH_WIDTH : 1;
         for (int k = 0; k < blocks; ++k) {
             swfr_path q = p;
@@ -737,12 +738,14 @@ int upload2(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, siz
     }
     static thread_local std::vector<swfr_edge> split_e;
     static thread_local std::vector<swfr_path> split_p;
-    if (split_wide_paths(edges, paths, n_paths, styles, split_e, split_p)) {      // (frames wider than 8192 px only)
+    const swfr_path* src_paths = nullptr; size_t n_src_paths = 0;
+    if (split_wide_paths(edges, paths, n_paths, split_e, split_p)) {             // (frames wider than 8192 px only)
+        src_paths = paths; n_src_paths = n_paths;
         edges = split_e.data(); n_edges = split_e.size(); paths = split_p.data(); n_paths = split_p.size();
     }
     static thread_local SceneLayout layout_scratch;        // (vectors keep their capacity from frame to frame)
     SceneLayout& L = layout_scratch;
-    layout_scene(r, edges, n_edges, paths, n_paths, styles, n_styles, L);
+    layout_scene(r, edges, n_edges, paths, n_paths, styles, n_styles, L, src_paths, n_src_paths);
     sc.n_edges = n_edges; sc.n_paths = n_paths; sc.n_styles = n_styles; sc.any_shader = L.any_shader; sc.shader_level = L.shader_level;
     sc.n_chunks = L.n_chunks; sc.chunk_rows = L.chunk_rows; sc.n_bands = L.n_bands; sc.n_rows = L.n_rows;
     sc.n_strips = L.n_strips; sc.n_strip_slots = L.n_strip_slots; sc.n_incidences = L.incidences;
@@ -1091,9 +1094,12 @@ int render_batch2(swfr_renderer* r, const swfr_stage* stages, uint32_t n, void* 
             validate_scene(r, F.e.data(), F.e.size(), F.p.data(), F.p.size(), F.s.data(), F.s.size());
             {
                 std::vector<swfr_edge> se; std::vector<swfr_path> sp;
-                if (split_wide_paths(F.e.data(), F.p.data(), F.p.size(), F.s.data(), se, sp)) { F.e.swap(se); F.p.swap(sp); }
+                if (split_wide_paths(F.e.data(), F.p.data(), F.p.size(), se, sp)) {
+                    const std::vector<swfr_path> orig = F.p;
+                    F.e.swap(se); F.p.swap(sp);
+                    layout_scene(r, F.e.data(), F.e.size(), F.p.data(), F.p.size(), F.s.data(), F.s.size(), F.L, orig.data(), orig.size());
+                } else layout_scene(r, F.e.data(), F.e.size(), F.p.data(), F.p.size(), F.s.data(), F.s.size(), F.L);
             }
-            layout_scene(r, F.e.data(), F.e.size(), F.p.data(), F.p.size(), F.s.data(), F.s.size(), F.L);
             arena_bytes += scene_arena_bytes(F.L, F.e.size(), F.p.size(), F.s.size());
             const SceneLayout& L = F.L;
             work_bytes += pad(F.e.size() * sizeof(DevEdge)) + pad(L.n_slots * sizeof(BandEntry2)) + pad((L.n_slots * TILE_H + 64) * sizeof(RowInfo2)) +

@@ -724,8 +724,8 @@ def test_frames_wider_than_a_cell_column_field():
     """Cells keep their column in 13 bits relative to the path's left edge: in a frame wider than 8192 px a path may lie anywhere
     (here: beyond column 9000); a single SOLID path wider than 8192 px is rasterized as one path per block of 8192 columns over the
     same edges (round 3; refused before) -- translucent, so that a seam or a doubled column would show -- and stays bit-exact, also
-    on top of other paths, through swfr_render_batch and with the blocks' boundary inside an anti-aliased edge; a wide path with a
-    gradient fill is still refused with SWFR_ERR_CAPACITY."""
+    on top of other paths, through swfr_render_batch and with the blocks' boundary inside an anti-aliased edge; so does a wide path
+    with a radial gradient (its style stays anchored at the unsplit rectangle)."""
     import torch
     import swf_renderer_amd as S
     from swf_renderer_amd import api
@@ -752,11 +752,12 @@ def test_frames_wider_than_a_cell_column_field():
             assert diff_stats(out[1].cpu().numpy(), want) == (0, 0)
         r.render_batch([stage, stage])                           # (the per-frame route)
         assert diff_stats(r.read_image(premultiplied=True), want) == (0, 0)
-        grad = {"type": "radial-gradient", "matrix": scenarios._m(3.0, 0.02, 4800 * 20, 400),
-                "gradient": scenarios._grad([(0, (255, 0, 0)), (255, (0, 0, 255))])}
-        with pytest.raises(S.SwfrError) as e:
-            r.render({"children": [{"type": "shape", "definition": scenarios._poly_shape(pts, grad)}]})
-        assert e.value.code == api.ERR_CAPACITY
+        # a wide path with a radial gradient: the blocks share the style, which stays anchored at the unsplit path's rectangle
+        grad = {"type": "radial-gradient", "matrix": scenarios._m(4.0, 0.02, 4800 * 20, 400),
+                "gradient": scenarios._grad([(0, (255, 0, 0)), (128, (0, 255, 0, 90)), (255, (0, 0, 255))])}
+        gstage = {"children": [{"type": "shape", "definition": near}, {"type": "shape", "definition": scenarios._poly_shape(pts, grad)}]}
+        r.render(gstage)
+        assert diff_stats(r.read_image(premultiplied=True), oracle_render(dict(width=w, height=h, stage=gstage))) == (0, 0)
     finally:
         r.close()
 
