@@ -1203,6 +1203,8 @@ int render_resident_batched(swfr_renderer* r, uint32_t per_launch, uint32_t laun
                             pad((sc.n_strips + 1) * sizeof(uint32_t)) + pad(COUNTER_WORDS * sizeof(uint32_t));
     const size_t cls_one = pad(STRIPS_PER_TILE * sc.n_slots * tiles_x + 64);
     const hipStream_t st = r->stream;
+    r->fb_valid = false;                                       // (fb_cur may point into a buffer the next lines reallocate; set again below)
+    r->fb_cur = nullptr;
     r->rb_work.reserve(work_one * B + 4096); r->rb_cls.reserve(cls_one * B + 4096); r->rb_frames.reserve(B); r->rb_fb.reserve(n_px * B);
     HIP_CHECK(hipMemsetAsync(r->rb_work.ptr, 0, work_one * B, st));           // (strip costs start at zero; class bytes outside the paths' rectangles)
     HIP_CHECK(hipMemsetAsync(r->rb_cls.ptr, 0, cls_one * B, st));
