@@ -943,7 +943,11 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
     hipEvent_t* ev_join = &r->ev[size_t(n_timed) * 4 + 2];
     // (no clearing of the counters here: k2_bin zeroes its frame's counters itself)
     HIP_CHECK(hipEventRecord(ev_begin, r->stream));
+#ifdef SWFR_BEGIN_WAIT
     for (uint32_t k = 1; k < n_sets; ++k) HIP_CHECK(hipStreamWaitEvent(r->fs[k].stream, ev_begin, 0));
+#endif
+    // (the other sets' streams are not ordered behind ev_begin: every call ends with all streams joined and waited for, an upload orders
+    //  them behind its copy, and three more API calls before the first launch cost a short call a microsecond per frame)
     // Frames per launch: the frame sets are cut into groups of `rb` (their descriptors are contiguous), a group's frames are one launch
     // per kernel (blockIdx.y = frame) on the group's first stream, and the groups alternate -- a third of the host's launches per
     // frame (three launches take the host about as long as a frame takes the GPU) and the GPU still has two streams to overlap.
