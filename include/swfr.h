@@ -173,7 +173,9 @@ int  swfr_render_sequence_readback(swfr_renderer *r, const swfr_stage *stages, u
 
 /* ---- low-level entry: the hot path proper (edge list -> RGBA8 in HBM) ---------------------- */
 /* One edge of a flattened, limit-clipped polygon in 24.8 device coordinates: the line
-   (x1,y1)-(x2,y2) with y1 < y2 is active for y in [top,bottom); dir is the winding direction.
+   (x1,y1)-(x2,y2) with y1 < y2 is active for y in [top,bottom), y1 <= top < bottom <= y2 (an edge
+   with top >= bottom is never active; any other edge active outside its own line is refused with
+   SWFR_ERR_INVALID); dir is the winding direction.
    `reserved` is the index of the owning path (the device bins edges by it): swfr_build_frame fills
    it in, swfr_upload_edges / swfr_render_edges overwrite it from the paths' edge ranges. */
 typedef struct { int32_t x1, y1, x2, y2, top, bottom, dir, reserved; } swfr_edge;

@@ -32,6 +32,23 @@ struct DevEdge {
 };
 static_assert(sizeof(DevEdge) == 96, "DevEdge layout");
 
+// The same edge as the fast row routine of k2_rows uses it (rows3.hip): every remainder of the scan converter in units of
+// 1 / D, D = 30 * (y2 - y1) -- Cairo's dy = 7680 * (y2 - y1) is 256 D and all of its remainders are multiples of 256 -- so that they
+// fit 32 bits (D < 2^29 for end points within +-32768 px), with the steps in FLOOR form (quotient, remainder in [0, D): one add, one
+// compare, one carry per step; the floor representation of a sum is unique, so this is Cairo's "normalise once").  Products that
+// need more than 32 bits (A * DX < 2^53) are exact in double precision.  80 bytes, five 16-byte blocks in the order the kernel reads them.
+struct FastEdge {
+    int32_t x1, a0, DX, D;           // x1 (24.8); a0 = 256 - 30 y1, so that A(s) = (2 s + 1) 256 - 30 y1 = 512 s + a0; DX = x2 - x1 (0: vertical); D = 30 (y2 - y1)
+    double invD;                     // 1 / D
+    int32_t q15, r15;                // x advance per pixel row, 7680 DX / D (edges at least 200/256 px tall; else 0)
+    int32_t hq, hr;                  // Cairo's half sample row (truncated halves of the truncated per-sample step), floor form
+    int32_t dqf, drf;                // x advance per sample row, 512 DX / D, floor form
+    int32_t ytop, ybot;              // active sample rows [ytop, ybot) (as DevEdge)
+    int32_t dir, fq;                 // fq: sample rows per pixel column, floor(256 D / W), W = 512 |DX|
+    double invW, fr;                 // 1 / W; fr = 256 D - fq W
+};
+static_assert(sizeof(FastEdge) == 80, "FastEdge layout");
+
 using DevPath = swfr_path;   // 40 bytes: first_edge, n_edges, kind, fill_rule, style, lerp, pixel rect
 
 enum : uint32_t { ROW_EMPTY = 0, ROW_FULL = 1, ROW_SUB = 2 };

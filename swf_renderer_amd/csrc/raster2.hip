@@ -260,7 +260,26 @@ __device__ __forceinline__ void bin_body(FramePtr F) {
     // ---- one thread per edge: scan converter constants
     if (i < F->n_edges) {
         const swfr_edge e = F->raw[i];
-        F->edges[i] = make_dev_edge(e, F->paths[e.reserved]);
+        const DevPath EP = F->paths[e.reserved];
+        const DevEdge de = make_dev_edge(e, EP);
+        F->edges[i] = de;
+        const FastEdge fe = make_fast_edge(e, de, EP);
+        fast_edges_of(F->edges, F->n_edges)[i] = fe;
+#ifdef SWFR_EMU
+        // (emulator builds: the 32-bit form gives Cairo's numbers -- quotient equal, remainder 1/256 of the 64-bit one)
+        if (de.ybot > de.ytop && de.dy) {
+            const int probe[3] = {de.ytop, (de.ytop + de.ybot) / 2, de.ybot};
+            for (int t = 0; t < 3; ++t) {
+                int32_t q0, q1, r1; int64_t r0;
+                edge_x_at(de, probe[t], q0, r0);
+                fast_x_at(fe.a0, fe.DX, fe.D, fe.invD, probe[t], q1, r1);
+                if (q0 != fe.x1 + q1 || r0 != 256ll * r1) { std::fprintf(stderr, "fast_x_at disagrees with edge_x_at\n"); std::abort(); }
+            }
+            int64_t tq = fe.dqf, tr = fe.drf;
+            if (fe.DX < 0 && tr != 0) { tq += 1; tr -= fe.D; }
+            if (tq != de.dq || 256 * tr != de.dr || (e.y2 - e.y1 >= 200 && (fe.q15 != de.q15 || 256ll * fe.r15 != de.r15)) || fe.fq != de.fq) { std::fprintf(stderr, "FastEdge constants disagree with DevEdge\n"); std::abort(); }
+        }
+#endif
     }
     // ---- one thread per path: its chunk descriptors
     if (i < F->n_paths) {
@@ -740,6 +759,8 @@ __device__ __forceinline__ void rows2_fast(EPTR E, uint32_t n_list, const DevPat
 }
 
 
+#include "rows3.hip"
+
 // STAGE: edges of the path a chunk can keep in LDS (two instances of the kernel: 32 -- fifteen wavefronts per CU -- for scenes whose
 // paths have at most 32 edges, 64 for the others)
 template <int STAGE>
@@ -950,7 +971,7 @@ __device__ __forceinline__ void rows2_chunk_body(FramePtr FR, uint32_t block) {
 }
 
 #ifndef R2_WAVES
-#define R2_WAVES 5                 // 95 VGPRs (five dwords of scratch) and 5.9 KB of LDS: five wavefronts per SIMD
+#define R2_WAVES 4                 // 119 VGPRs, 8.1 KB of LDS: four wavefronts per SIMD
 #endif
 #define R2_ATTR __attribute__((amdgpu_waves_per_eu(R2_WAVES)))
 __global__ __launch_bounds__(64) R2_ATTR void k2_rows_b(const Frame2* __restrict__ frames) {
@@ -959,14 +980,14 @@ __global__ __launch_bounds__(64) R2_ATTR void k2_rows_b(const Frame2* __restrict
     FramePtr FR = FRAME_PTR(frames, blockIdx.y);
     if (blockIdx.x >= FR->n_chunks) return;
     TRACE(1);
-    rows2_chunk_body<ROWS_STAGE>(FR, blockIdx.x);
+    rows3_chunk_body<ROWS_STAGE>(FR, blockIdx.x);
     TRACE(7);
     TRACE_OUT(1, blockIdx.x);
 }
 __global__ __launch_bounds__(64) R2_ATTR void k2_rows_wide_b(const Frame2* __restrict__ frames) {
     FramePtr FR = FRAME_PTR(frames, blockIdx.y);
     if (blockIdx.x >= FR->n_chunks) return;
-    rows2_chunk_body<ROWS_STAGE_WIDE>(FR, blockIdx.x);
+    rows3_chunk_body<ROWS_STAGE_WIDE>(FR, blockIdx.x);
 }
 
 

@@ -113,6 +113,49 @@ __device__ __forceinline__ DevEdge make_dev_edge(const swfr_edge& e, const DevPa
     return d;
 }
 
+// ---- the 32-bit form of the same edge (FastEdge, device_types.hpp) for the fast row routine
+__device__ __forceinline__ FastEdge make_fast_edge(const swfr_edge& e, const DevEdge& d, const DevPath& p) {
+    FastEdge f;
+    f.x1 = e.x1; f.a0 = 256 - 30 * e.y1; f.DX = 0; f.D = 30; f.invD = 1.0 / 30.0; f.q15 = f.r15 = f.hq = f.hr = f.dqf = f.drf = 0;
+    f.ytop = d.ytop; f.ybot = d.ybot; f.dir = e.dir; f.fq = 0; f.invW = 0.0; f.fr = 0.0;
+    if (p.kind != SWFR_PATH_TOR || e.y2 <= e.y1) { f.ytop = f.ybot = 0; return f; }
+    const int64_t DX = (int64_t)e.x2 - e.x1, D = 30ll * ((int64_t)e.y2 - e.y1);
+    f.D = (int32_t)D; f.invD = 1.0 / (double)D;
+    if (DX == 0) return f;                                   // vertical: x = x1 everywhere (every step is 0)
+    f.DX = (int32_t)DX;
+    int64_t q, r;
+    floor_div_inv(512 * DX, D, f.invD, q, r);                 // per sample row (estimates from the reciprocal, exact after the integer fix-up)
+    f.dqf = (int32_t)q; f.drf = (int32_t)r;
+    // Cairo halves its TRUNCATED step (quotient and remainder each truncated towards zero; the remainder 512 DX - q D is even)
+    int64_t tq = q, tr = r;
+    if (DX < 0 && r != 0) { tq = q + 1; tr = r - D; }
+    int64_t hq = tq / 2, hr = tr / 2;
+    if (hr < 0) { --hq; hr += D; }
+    f.hq = (int32_t)hq; f.hr = (int32_t)hr;
+    if (e.y2 - e.y1 >= 200) {                                 // only an edge that crosses a whole pixel row is ever stepped by one
+        floor_div_inv(7680 * DX, D, f.invD, q, r);
+        f.q15 = (int32_t)q; f.r15 = (int32_t)r;
+    }
+    const int64_t W = 512 * (DX < 0 ? -DX : DX);
+    f.invW = 1.0 / (double)W;
+    floor_div_inv(256 * D, W, f.invW, q, r);
+    f.fq = (int32_t)q; f.fr = (double)r;
+    return f;
+}
+// x of the edge at the centre of sample row s, relative to x1: quo + rem / D with rem in [0, D).  A * DX < 2^53 is exact in double
+// precision, the quotient estimate is off by at most one, and the remainder of the estimate (an fma: exact) fits 32 bits.
+__device__ __forceinline__ void fast_x_at(int32_t a0, int32_t DX, int32_t D, double invD, int s, int32_t& quo, int32_t& rem) {
+    const double n = (double)(512 * s + a0) * (double)DX;
+    const double qf = floor(n * invD);
+    const double rf = fma(-qf, (double)D, n);
+    int32_t q = (int32_t)qf, r = (int32_t)rf;
+    if (r < 0) { --q; r += D; }
+    if (r >= D) { ++q; r -= D; }
+    quo = q; rem = r;
+}
+// the FastEdge array of a frame sits behind its DevEdge array (the host reserves 2 n + 1 DevEdge records: 80 <= 96 bytes each)
+__device__ __forceinline__ FastEdge* fast_edges_of(DevEdge* edges, uint32_t n_edges) { return reinterpret_cast<FastEdge*>(edges + n_edges); }
+
 // ---------------------------------------------------------------------------------------------
 // row kernels: classification bits, capacities, the order of coincident edges
 // ---------------------------------------------------------------------------------------------

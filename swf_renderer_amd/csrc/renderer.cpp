@@ -343,6 +343,15 @@ void validate_scene(const swfr_renderer* r, const swfr_edge* edges, size_t n_edg
         if (size_t(p.first_edge) + p.n_edges > n_edges) throw StatusError{SWFR_ERR_INVALID, "path edge range out of bounds"};
         if (p.style >= n_styles) throw StatusError{SWFR_ERR_INVALID, "path style index out of bounds"};
         if (p.kind > SWFR_PATH_BOXES) throw StatusError{SWFR_ERR_INVALID, "unknown path kind"};
+        if (p.kind == SWFR_PATH_TOR)
+            // an edge of the scan converter: a line (x1, y1)-(x2, y2) running downwards, active over [top, bottom) INSIDE its own extent
+            // (what the frame builder and Cairo's clipper produce); the per-row stepping of k2_rows is exact only there
+            for (size_t k = 0; k < p.n_edges; ++k) {
+                const swfr_edge& e = edges[p.first_edge + k];
+                if (e.top >= e.bottom) continue;                              // never active
+                if (!(e.y1 < e.y2 && e.y1 <= e.top && e.bottom <= e.y2))
+                    throw StatusError{SWFR_ERR_INVALID, "edge active outside its line: need y1 < y2 and y1 <= top < bottom <= y2"};
+            }
         if (p.x_min < 0 || p.y_min < 0 || p.x_max > int(r->width) || p.y_max > int(r->height) || p.x_min > p.x_max || p.y_min > p.y_max)
             throw StatusError{SWFR_ERR_INVALID, "path pixel rectangle outside the frame"};
     }
@@ -769,7 +778,7 @@ int upload2(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, siz
         if (all_sets ? k >= n_sets : k != si) continue;
         auto& x = r->fs[k];
         if (!x.stream) HIP_CHECK(hipStreamCreateWithFlags(&x.stream, hipStreamNonBlocking));
-        x.d_edges.reserve(n_edges); x.d_band2.reserve(n_slots); x.d_rows2.reserve(n_slots * TILE_H + 64); x.d_cells.reserve(L.cell_total);
+        x.d_edges.reserve(2 * n_edges + 1); x.d_band2.reserve(n_slots); x.d_rows2.reserve(n_slots * TILE_H + 64); x.d_cells.reserve(L.cell_total);
         x.d_slow.reserve(2 * (n_rows + 64)); x.d_huge.reserve(2 * (n_rows + 64));     // (two queues each: a pass reads one and refills the other)
         x.d_path_flag.reserve(n_paths + 64); x.d_path_queue.reserve(n_paths + 64);
         x.d_chunks.reserve(n_chunks + 1); x.d_band_slots.reserve(n_slots + 1); x.d_strips.reserve(L.n_strip_slots + 1);
@@ -1106,7 +1115,7 @@ int render_batch2(swfr_renderer* r, const swfr_stage* stages, uint32_t n, void* 
             }
             arena_bytes += scene_arena_bytes(F.L, F.e.size(), F.p.size(), F.s.size());
             const SceneLayout& L = F.L;
-            work_bytes += pad(F.e.size() * sizeof(DevEdge)) + pad(L.n_slots * sizeof(BandEntry2)) + pad((L.n_slots * TILE_H + 64) * sizeof(RowInfo2)) +
+            work_bytes += pad((2 * F.e.size() + 1) * sizeof(DevEdge)) + pad(L.n_slots * sizeof(BandEntry2)) + pad((L.n_slots * TILE_H + 64) * sizeof(RowInfo2)) +
                           pad(L.cell_total * sizeof(Cell)) + 2 * pad(2 * (L.n_rows + 64) * sizeof(SlowRow)) + 2 * pad((F.p.size() + 64) * sizeof(uint32_t)) +
                           pad((L.n_chunks + 1) * sizeof(ChunkInfo)) + pad((L.n_slots + 1) * sizeof(BandSlot)) + pad((L.n_strip_slots + 1) * sizeof(StripDesc)) +
                           pad((L.n_strips + 1) * sizeof(uint32_t)) + pad(COUNTER_WORDS * sizeof(uint32_t));
@@ -1143,7 +1152,7 @@ int render_batch2(swfr_renderer* r, const swfr_stage* stages, uint32_t n, void* 
             push_scene(G.arena, L, F.e.data(), F.e.size(), F.p.data(), F.p.size(), F.s.data(), F.s.size(), f);
             fill_frame_sizes(r, L, F.e.size(), F.p.size(), f);
             f.src.bitmaps = r->d_bitmap_table.ptr;
-            f.edges = reinterpret_cast<DevEdge*>(carve(F.e.size() * sizeof(DevEdge)));
+            f.edges = reinterpret_cast<DevEdge*>(carve((2 * F.e.size() + 1) * sizeof(DevEdge)));
             f.band_list = reinterpret_cast<BandEntry2*>(carve(L.n_slots * sizeof(BandEntry2)));
             f.rows = reinterpret_cast<RowInfo2*>(carve((L.n_slots * TILE_H + 64) * sizeof(RowInfo2)));
             f.cells = reinterpret_cast<Cell*>(carve(L.cell_total * sizeof(Cell)));
@@ -1201,7 +1210,7 @@ int render_resident_batched(swfr_renderer* r, uint32_t per_launch, uint32_t laun
     const uint32_t B = per_launch, tiles_x = (r->width + TILE_W - 1) / TILE_W;
     auto pad = [](size_t b) { return (b + 255) & ~size_t(255); };
     const size_t n_px = size_t(r->width) * r->height;
-    const size_t work_one = pad(sc.n_edges * sizeof(DevEdge)) + pad(sc.n_slots * sizeof(BandEntry2)) + pad((sc.n_slots * TILE_H + 64) * sizeof(RowInfo2)) +
+    const size_t work_one = pad((2 * sc.n_edges + 1) * sizeof(DevEdge)) + pad(sc.n_slots * sizeof(BandEntry2)) + pad((sc.n_slots * TILE_H + 64) * sizeof(RowInfo2)) +
                             pad(sc.cell_total * sizeof(Cell)) + 2 * pad(2 * (sc.n_rows + 64) * sizeof(SlowRow)) + 2 * pad((sc.n_paths + 64) * sizeof(uint32_t)) +
                             pad((sc.n_chunks + 1) * sizeof(ChunkInfo)) + pad((sc.n_slots + 1) * sizeof(BandSlot)) + pad((sc.n_strip_slots + 1) * sizeof(StripDesc)) +
                             pad((sc.n_strips + 1) * sizeof(uint32_t)) + pad(COUNTER_WORDS * sizeof(uint32_t));
@@ -1218,7 +1227,7 @@ int render_resident_batched(swfr_renderer* r, uint32_t per_launch, uint32_t laun
     for (uint32_t k = 0; k < B; ++k) {
         Frame2& f = fr[k];
         f = sc.proto;
-        f.edges = reinterpret_cast<DevEdge*>(carve(sc.n_edges * sizeof(DevEdge)));
+        f.edges = reinterpret_cast<DevEdge*>(carve((2 * sc.n_edges + 1) * sizeof(DevEdge)));
         f.band_list = reinterpret_cast<BandEntry2*>(carve(sc.n_slots * sizeof(BandEntry2)));
         f.rows = reinterpret_cast<RowInfo2*>(carve((sc.n_slots * TILE_H + 64) * sizeof(RowInfo2)));
         f.cells = reinterpret_cast<Cell*>(carve(sc.cell_total * sizeof(Cell)));
