@@ -190,6 +190,16 @@ struct StripDesc {
     uint32_t pad;
 };
 
+// What the row pass (and k2_bin, for box paths) already knows about a strip as a whole, so that the tile pass need not walk anything
+// for a strip without a partial (path, strip) pair: the position (1-based, in its tile-row's band list) of the topmost entry that
+// paints anything in the strip, and of the topmost OPAQUE FULL COVER together with its colour -- maxima kept with atomics (the colour
+// rides in the low half of a 64-bit maximum).  any == 0: nothing is painted; cover's position == any: the strip is that colour.
+struct StripTop {
+    uint32_t any, pad;
+    unsigned long long cover;        // position << 32 | premultiplied pixel
+};
+static_assert(sizeof(StripTop) == 16, "StripTop layout");
+
 // Everything the kernels need to know about one frame (device memory; blockIdx.y indexes an array of these).
 constexpr uint32_t XCDS = 8;            // a launch's workgroups go round-robin over the chip's eight XCDs, each with its own L2
 // slots of the tile pass's launch list: slot % XCDS = the XCD the hardware hands the workgroup to = (local tile-row) % XCDS, so that
@@ -212,6 +222,7 @@ struct Frame2 {
     DevEdge* edges; BandEntry2* band_list; uint8_t* cls; RowInfo2* rows; Cell* cells; SlowRow* slow; SlowRow* huge; uint32_t* counters;
     uint32_t* path_flag; uint32_t* path_queue;     // paths with queued rows: their edges get start ranks (k2_start_ranks)
     uint32_t* fb;
+    StripTop* strip_top;                 // per strip of the handle (cleared at upload, and by the tile pass once read)
     uint32_t n_edges, n_paths, n_chunks, n_bands, n_strips, cell_slice, slow_cap;
     int32_t width, height, tiles_x;
     uint32_t fast_limit;     // active edges per row the fast routine of k2_rows keeps (<= 8)

@@ -83,6 +83,15 @@ __device__ __forceinline__ bool owns_band(FramePtr FR, int band, uint32_t& local
 
 #define CLS_OPAQUE 32u                // the path is an opaque solid blended with the lerp rule: a full cover of it hides what lies below
 
+// a (path, strip) pair's class, noted in the strip's StripTop record (device_types.hpp): pos1 = the entry's position in its tile-row's
+// band list + 1; device-scope atomics are resolved behind the XCDs' L2s, so workgroups on different XCDs agree
+__device__ __forceinline__ void strip_top_note(FramePtr FR, uint32_t strip_id, uint32_t pos1, uint32_t f, uint32_t pixel) {
+    if (!(f & CLS_NONEMPTY)) return;
+    StripTop* t = FR->strip_top + strip_id;
+    atomicMax(&t->any, pos1);
+    if ((f & 0x3fu) == (CLS_NONEMPTY | CLS_OPAQUE)) atomicMax(&t->cover, ((unsigned long long)pos1 << 32) | (unsigned long long)pixel);
+}
+
 // ---------------------------------------------------------------------------------------------
 // cells
 // ---------------------------------------------------------------------------------------------
@@ -242,11 +251,16 @@ __device__ __forceinline__ void bin_body(FramePtr F) {
                     const uint32_t opq = (e.flags & BE_OPAQUE_COVER) ? CLS_OPAQUE : 0u;
                     const swfr_edge bx = F->raw[P.first_edge];             // (only looked at when the path is a single box)
                     const bool one_box = P.n_edges == 1 && bx.y1 <= ty0 * 256 && bx.y2 >= tile_y1 * 256;
+                    uint32_t local_trow = 0;
+                    const bool own = owns_band(F, band, local_trow);
                     for (int tc = P.x_min / TILE_W; tc <= (P.x_max - 1) / TILE_W; ++tc) {
                         const int tx0 = tc * TILE_W, tile_x1 = min(tx0 + TILE_W, F->width);
                         uint32_t f = CLS_BOX | CLS_NONEMPTY | CLS_NOTFULL;
                         if (one_box && bx.x1 <= tx0 * 256 && bx.x2 >= tile_x1 * 256) f = CLS_NONEMPTY | opq;     // the box contains the whole tile: full cover
-                        for (int sp = 0; sp < STRIPS_PER_TILE; ++sp) out[(size_t)(tc * STRIPS_PER_TILE + sp) * n_b] = (uint8_t)f;
+                        for (int sp = 0; sp < STRIPS_PER_TILE; ++sp) {
+                            out[(size_t)(tc * STRIPS_PER_TILE + sp) * n_b] = (uint8_t)f;
+                            if (own && ty0 + sp * STRIP_H < F->height) strip_top_note(F, (local_trow * (uint32_t)F->tiles_x + (uint32_t)tc) * STRIPS_PER_TILE + (uint32_t)sp, at + 1u, f, e.solid);
+                        }
                     }
                 }
             }
@@ -1814,6 +1828,16 @@ __device__ __forceinline__ void tiles3_body(FramePtr FR) {
 #endif
         const uint32_t wg = sd.wg;
         if (wg == ~0u) continue;                                         // a padding slot of the launch list
+        // what the row pass knows about the strip as a whole (StripTop): read together with the class bytes below, one round trip
+        StripTop top;
+#ifdef SWFR_EMU
+        top = FR->strip_top[wg];
+#else
+        {
+            const uint32_t __attribute__((address_space(4)))* tp = reinterpret_cast<const uint32_t __attribute__((address_space(4)))*>(reinterpret_cast<uintptr_t>(FR->strip_top + wg));
+            top.any = tp[0]; top.pad = 0; top.cover = ((unsigned long long)tp[3] << 32) | (unsigned long long)tp[2];
+        }
+#endif
         TRACE(2);                                                        // strip descriptor in
         const int tile = (int)(wg / STRIPS_PER_TILE), strip = (int)(wg % STRIPS_PER_TILE);
         const int tcol = tile % tiles_x;
@@ -1840,16 +1864,19 @@ __device__ __forceinline__ void tiles3_body(FramePtr FR) {
             }
             return c0 + lane < n_b ? (uint32_t)mycls[c0 + lane] : 0u;
         };
-        // ---- occlusion, from the class bytes alone: everything below the last opaque full cover is invisible in this strip
-        uint32_t start = 0;
-        for (uint32_t c0 = (n_b + 63u) & ~63u; c0 != 0u;) {              // chunks from the top of the painter's order down
-            c0 -= 64u;
-            const uint32_t f = cls_chunk(c0);
-            const unsigned long long b = __ballot((f & (CLS_PARTIAL | CLS_NOTFULL | CLS_BOX | CLS_OPAQUE)) == CLS_OPAQUE);
-            if (b) { start = c0 + 63u - (uint32_t)__clzll((long long)b); break; }
+        // ---- occlusion: everything below the topmost opaque full cover is invisible in this strip -- and when nothing paints above it
+        //      (or nothing paints at all) the strip is that colour: no walk.  The record is cleared for the next frame once read.
+        const uint32_t cover_pos = (uint32_t)(top.cover >> 32);
+        if (lane == 0 && top.any != 0u) { StripTop z; z.any = 0u; z.pad = 0u; z.cover = 0ull; FR->strip_top[wg] = z; }      // (depends on the loaded value: never overtakes the read)
+        const bool uniform = top.any == cover_pos;                        // (wave-uniform)
+        if (uniform) {
+            const uint32_t colour = top.any ? (uint32_t)top.cover : 0u;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) px[j] = colour;
         }
+        const uint32_t start = cover_pos ? cover_pos - 1u : 0u;
         TRACE(3);                                                        // class bytes in
-        for (uint32_t c0 = start & ~63u; c0 < n_b; c0 += 64u) {
+        for (uint32_t c0 = uniform ? n_b : (start & ~63u); c0 < n_b; c0 += 64u) {
             const uint32_t f = cls_chunk(c0);
             const uint32_t bi = c0 + (uint32_t)lane;
             const bool hit = (f & CLS_NONEMPTY) != 0u && bi >= start;

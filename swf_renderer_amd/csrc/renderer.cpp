@@ -313,6 +313,11 @@ BandShare band_share(const swfr_renderer* r) {
 uint32_t local_tile_rows(const swfr_renderer* r) { return band_share(r).count; }
 
 // Validate a caller-supplied scene so that no kernel can index out of bounds.
+// The class bytes of a frame and, behind them (16-byte aligned), one StripTop record per strip of the handle: both are cleared when a
+// scene is uploaded (the tile pass clears a strip's record again when it has read it).
+inline size_t cls_bytes_of(size_t n_slots, size_t tiles_x) { return (size_t(STRIPS_PER_TILE) * n_slots * tiles_x + 64 + 15) & ~size_t(15); }
+inline size_t cls_region_bytes(size_t n_slots, size_t tiles_x, size_t n_strips) { return cls_bytes_of(n_slots, tiles_x) + (n_strips + 1) * sizeof(StripTop); }
+
 void validate_scene(const swfr_renderer* r, const swfr_edge* edges, size_t n_edges, const swfr_path* paths, size_t n_paths,
                     const swfr_style* styles, size_t n_styles) {
     // end points within +-32768 px (2^23 in 24.8): inside that range the int64 products of the closed-form edge evaluation cannot overflow
@@ -785,9 +790,9 @@ int upload2(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, siz
         reserve_zeroed(x.d_strip_cost, L.n_strips + 1);                                 // (zero between frames: the ordering workgroup clears what it has read)
         r->d_counters.reserve(4 * COUNTER_WORDS);
         x.counters = r->d_counters.ptr + size_t(k) * COUNTER_WORDS;
-        x.d_cls.reserve(STRIPS_PER_TILE * n_slots * tiles_x + 64);
+        x.d_cls.reserve(cls_region_bytes(n_slots, tiles_x, L.n_strips));
         // class bytes outside the paths' rectangles are never written by a kernel: cleared once per uploaded scene
-        HIP_CHECK(hipMemsetAsync(x.d_cls.ptr, 0, STRIPS_PER_TILE * n_slots * tiles_x + 64, up_stream));
+        HIP_CHECK(hipMemsetAsync(x.d_cls.ptr, 0, cls_region_bytes(n_slots, tiles_x, L.n_strips), up_stream));
         if (!x.d_fb.ptr && !r->n_targets) {                                             // (a handle with caller targets never renders into a buffer of its own)
             x.d_fb.reserve(size_t(r->width) * r->height);
             HIP_CHECK(hipMemsetAsync(x.d_fb.ptr, 0, size_t(r->width) * r->height * 4, up_stream));
@@ -805,7 +810,7 @@ int upload2(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, siz
         f = proto;
         f.chunks = x.d_chunks.ptr; f.band_slots = x.d_band_slots.ptr; f.strips = x.d_strips.ptr;
         f.strip_cost = x.d_strip_cost.ptr;
-        f.edges = x.d_edges.ptr; f.band_list = x.d_band2.ptr; f.cls = x.d_cls.ptr; f.rows = x.d_rows2.ptr; f.cells = x.d_cells.ptr;
+        f.edges = x.d_edges.ptr; f.band_list = x.d_band2.ptr; f.cls = x.d_cls.ptr; f.strip_top = reinterpret_cast<StripTop*>(x.d_cls.ptr + cls_bytes_of(n_slots, tiles_x)); f.rows = x.d_rows2.ptr; f.cells = x.d_cells.ptr;
         f.slow = x.d_slow.ptr; f.huge = x.d_huge.ptr; f.counters = x.counters;
         f.path_flag = x.d_path_flag.ptr; f.path_queue = x.d_path_queue.ptr;
         f.fb = (fb_override && k == si) ? fb_override : (r->n_targets ? r->targets[uint32_t(k) % r->n_targets] : x.d_fb.ptr);
@@ -1119,7 +1124,7 @@ int render_batch2(swfr_renderer* r, const swfr_stage* stages, uint32_t n, void* 
                           pad(L.cell_total * sizeof(Cell)) + 2 * pad(2 * (L.n_rows + 64) * sizeof(SlowRow)) + 2 * pad((F.p.size() + 64) * sizeof(uint32_t)) +
                           pad((L.n_chunks + 1) * sizeof(ChunkInfo)) + pad((L.n_slots + 1) * sizeof(BandSlot)) + pad((L.n_strip_slots + 1) * sizeof(StripDesc)) +
                           pad((L.n_strips + 1) * sizeof(uint32_t)) + pad(COUNTER_WORDS * sizeof(uint32_t));
-            cls_bytes += pad(STRIPS_PER_TILE * L.n_slots * tiles_x + 64);
+            cls_bytes += pad(cls_region_bytes(L.n_slots, tiles_x, L.n_strips));
             max_ep = std::max(max_ep, std::max(F.e.size(), F.p.size())); max_bands = std::max(max_bands, L.n_bands);
             max_chunks = std::max(max_chunks, L.n_chunks); max_strips = std::max(max_strips, L.n_strip_slots);
             shader_level = std::max(shader_level, L.shader_level);
@@ -1165,7 +1170,7 @@ int render_batch2(swfr_renderer* r, const swfr_stage* stages, uint32_t n, void* 
             f.strips = reinterpret_cast<StripDesc*>(carve((L.n_strip_slots + 1) * sizeof(StripDesc)));
             f.strip_cost = reinterpret_cast<uint32_t*>(carve((L.n_strips + 1) * sizeof(uint32_t)));
             f.counters = reinterpret_cast<uint32_t*>(carve(COUNTER_WORDS * sizeof(uint32_t)));
-            f.cls = c; c += pad(STRIPS_PER_TILE * L.n_slots * tiles_x + 64);
+            f.cls = c; f.strip_top = reinterpret_cast<StripTop*>(c + cls_bytes_of(L.n_slots, tiles_x)); c += pad(cls_region_bytes(L.n_slots, tiles_x, L.n_strips));
             f.strip_order = 0;                              // (a frame's buffers held another frame before: no cost history to order by)
             f.fb = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(device_dst) + size_t(first + k) * frame_stride);
         }
@@ -1214,7 +1219,7 @@ int render_resident_batched(swfr_renderer* r, uint32_t per_launch, uint32_t laun
                             pad(sc.cell_total * sizeof(Cell)) + 2 * pad(2 * (sc.n_rows + 64) * sizeof(SlowRow)) + 2 * pad((sc.n_paths + 64) * sizeof(uint32_t)) +
                             pad((sc.n_chunks + 1) * sizeof(ChunkInfo)) + pad((sc.n_slots + 1) * sizeof(BandSlot)) + pad((sc.n_strip_slots + 1) * sizeof(StripDesc)) +
                             pad((sc.n_strips + 1) * sizeof(uint32_t)) + pad(COUNTER_WORDS * sizeof(uint32_t));
-    const size_t cls_one = pad(STRIPS_PER_TILE * sc.n_slots * tiles_x + 64);
+    const size_t cls_one = pad(cls_region_bytes(sc.n_slots, tiles_x, sc.n_strips));
     const hipStream_t st = r->stream;
     r->fb_valid = false;                                       // (fb_cur may point into a buffer the next lines reallocate; set again below)
     r->fb_cur = nullptr;
@@ -1240,7 +1245,7 @@ int render_resident_batched(swfr_renderer* r, uint32_t per_launch, uint32_t laun
         f.strips = reinterpret_cast<StripDesc*>(carve((sc.n_strip_slots + 1) * sizeof(StripDesc)));
         f.strip_cost = reinterpret_cast<uint32_t*>(carve((sc.n_strips + 1) * sizeof(uint32_t)));
         f.counters = reinterpret_cast<uint32_t*>(carve(COUNTER_WORDS * sizeof(uint32_t)));
-        f.cls = r->rb_cls.ptr + cls_one * k;
+        f.cls = r->rb_cls.ptr + cls_one * k; f.strip_top = reinterpret_cast<StripTop*>(f.cls + cls_bytes_of(sc.n_slots, tiles_x));
         f.fb = r->rb_fb.ptr + n_px * k;
     }
     HIP_CHECK(hipMemcpyAsync(r->rb_frames.ptr, fr.data(), B * sizeof(Frame2), hipMemcpyHostToDevice, st));

@@ -577,7 +577,9 @@ __device__ __forceinline__ void rows3_chunk_body(FramePtr FR, uint32_t block) {
         const uint32_t opq = (st.kind == SWFR_STYLE_SOLID && P.lerp && (st.pixel >> 24) == 0xffu) ? CLS_OPAQUE : 0u;
         const bool in_frame = r < height && band_ok, in_rows = in_frame && in_path;
         uint32_t local_trow = 0;
-        const bool own_band = FR->strip_order && band_ok && owns_band(FR, band, local_trow);
+        const bool own_band = band_ok && owns_band(FR, band, local_trow);
+        const bool cost_order = FR->strip_order != 0u;
+        const uint32_t pos1 = cls_bs.slot - cls_b0 + 1u;         // the path's position in its tile-row's band list, 1-based
         const int strip_in_tile = (lane >> 3) & 1, tsub = lane & 7;
         for (int tb = 0; tb < ntc; tb += 32) {                   // wave-uniform
             const int nb = min(ntc - tb, 32);
@@ -620,10 +622,14 @@ __device__ __forceinline__ void rows3_chunk_body(FramePtr FR, uint32_t block) {
                 const int tc = tc0 + tb + t;
                 if (t < nb && band_ok && lane < chunk_rows) {
                     out[(uint32_t)(tc * STRIPS_PER_TILE + strip_in_tile) * n_b] = (uint8_t)f;          // (< 2^32: strips of a tile-row x its entries)
-                    // the tile's strips get heavier by the rows of this path with a boundary (the tile pass starts its heaviest strips first)
-                    if (own_band && (f & CLS_PARTIAL)) {
-                        const uint32_t wgt = (uint32_t)__popcll((pb >> (lane & ~7)) & 0xffull);
-                        if (wgt) atomicAdd(&FR->strip_cost[((size_t)local_trow * FR->tiles_x + tc) * STRIPS_PER_TILE + strip_in_tile], wgt);
+                    if (own_band) {
+                        const uint32_t strip_id = (local_trow * (uint32_t)FR->tiles_x + (uint32_t)tc) * STRIPS_PER_TILE + (uint32_t)strip_in_tile;
+                        strip_top_note(FR, strip_id, pos1, f, st.pixel);
+                        // the tile's strips get heavier by the rows of this path with a boundary (the tile pass starts its heaviest strips first)
+                        if (cost_order && (f & CLS_PARTIAL)) {
+                            const uint32_t wgt = (uint32_t)__popcll((pb >> (lane & ~7)) & 0xffull);
+                            if (wgt) atomicAdd(&FR->strip_cost[strip_id], wgt);
+                        }
                     }
                 }
             }
