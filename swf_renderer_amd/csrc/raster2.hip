@@ -104,7 +104,7 @@ __device__ __forceinline__ void put_cell(Cell* __restrict__ dst, int col, int ch
 }
 // the same for a cell whose area is `area_per_h` times its height: V = h * (CELL_H + area_per_h), one multiplication
 __device__ __forceinline__ void put_cell_h(Cell* __restrict__ dst, int col, int h, int area_per_h, int xminp, int xmaxp) {
-    int v = h * (CELL_H + area_per_h);
+    int v = mul_i24(h, CELL_H + area_per_h);                   // (|h| <= 15, the factor < 2^15: the full-rate 24-bit multiply)
     if (col >= xmaxp) { col = xmaxp - 1; v = 0; }
     else if (col < xminp) { col = xminp; v = h * CELL_H; }
     *dst = make_cell_v(col - xminp, v);
@@ -444,7 +444,8 @@ __device__ __forceinline__ uint32_t pack_sub_cell(int x, int sgn, int xminp, int
     int col = x >> 8, f = x & 255, live = 1;
     if (col >= xmaxp) { col = xmaxp - 1; f = 0; live = 0; }
     else if (col < xminp) { col = xminp; f = 0; }
-    return make_cell(col - xminp, sgn * live, sgn * 2 * f).w;          // (the staged word is the cell itself)
+    const int v = live * CELL_H + 2 * f, neg = sgn < 0 ? -1 : 0;       // (negated without a multiply)
+    return make_cell_v(col - xminp, (v ^ neg) - neg).w;                // (the staged word is the cell itself)
 }
 
 // The fast row routine (rows with at most eight active edges, lane = row).  (1) A row in which two edges on different lines coincide

@@ -66,6 +66,27 @@ __device__ __forceinline__ int record_height(uint32_t roles) {
     return __popc(roles & 0x15555555u) - __popc(roles & 0x2aaaaaaau);
 }
 
+// 24-bit signed multiply at the full VALU rate (v_mul_i32_i24; `a * b` on 32-bit operands is v_mul_lo_u32: a quarter of the rate)
+__device__ __forceinline__ int mul_i24(int a, int b) {
+#ifdef SWFR_EMU
+    return a * b;
+#else
+    int r;
+    asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#endif
+}
+// (a << SH) + b as ONE full-rate instruction (the compiler canonicalises shift-adds by a constant into a multiply, i.e. v_mul_lo_u32)
+template <int SH>
+__device__ __forceinline__ int lshl_add(int a, int b) {
+#ifdef SWFR_EMU
+    return (int)(((uint32_t)a << SH) + (uint32_t)b);
+#else
+    int r;
+    asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "i"(SH), "v"(b));
+    return r;
+#endif
+}
 // wave64 inclusive prefix sum with DPP row shifts + row broadcasts (no LDS traffic)
 __device__ __forceinline__ int wave_scan_incl(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1

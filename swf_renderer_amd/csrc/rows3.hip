@@ -58,10 +58,11 @@ __device__ __forceinline__ uint32_t col_bit(int t) { return (uint32_t)t < 32u ? 
 // bottom, rl = the remainder (units of 1 / D) of the LEFT one of the two; writes exactly full_span(qt, qb) cells.  The row's x extent
 // in units of 1 / D is W = 512 |DX| in every row the edge crosses completely, the first column's share of the fifteen sample rows
 // floor(((X - x_left) D) / W) with X the column's right side; products below 2^53: exact in double precision.
-__device__ __forceinline__ void full_cells3(int32_t qt, int32_t qb, int32_t rl, int32_t DX, int32_t D, double invW, int32_t fq0, double fr0, int sign,
+__device__ __forceinline__ void full_cells3(int32_t qt, int32_t qb, int32_t rl, int32_t DX, int32_t D, double invW, int32_t fq0, double fr0, int neg,
                                             int xminp, int xmaxp, Cell* __restrict__ dst) {
+    // neg: 0 for a left edge (+ heights), -1 for a right edge: (h ^ neg) - neg negates without a multiply
     int ix1 = qt >> 8, f1 = qt & 255, ix2 = qb >> 8, f2 = qb & 255;
-    if (ix1 == ix2) { put_cell_h(dst, ix1, sign * 15, f1 + f2, xminp, xmaxp); return; }
+    if (ix1 == ix2) { put_cell_h(dst, ix1, (15 ^ neg) - neg, f1 + f2, xminp, xmaxp); return; }
     int32_t ql = qt;
     if (ix2 < ix1) { int t = ix1; ix1 = ix2; ix2 = t; t = f1; f1 = f2; f2 = t; ql = qb; }
     const int span = ix2 - ix1 + 1;
@@ -74,27 +75,27 @@ __device__ __forceinline__ void full_cells3(int32_t qt, int32_t qb, int32_t rl, 
     int yq = (int)yqf;
     int y_prev = yq;
     if (span <= MAX_CELLS_PER_EDGE_ROW) {
-        put_cell_h(dst, ix1, sign * y_prev, 256 + f1, xminp, xmaxp);
+        put_cell_h(dst, ix1, (y_prev ^ neg) - neg, 256 + f1, xminp, xmaxp);
 #pragma unroll 1
         for (int k = 1; k < span - 1; ++k) {
             yq += fq0; yr += fr0; if (yr >= W) { ++yq; yr -= W; }
-            put_cell_h(dst + k, ix1 + k, sign * (yq - y_prev), 256, xminp, xmaxp);
+            put_cell_h(dst + k, ix1 + k, ((yq - y_prev) ^ neg) - neg, 256, xminp, xmaxp);
             y_prev = yq;
         }
-        put_cell_h(dst + span - 1, ix2, sign * (15 - y_prev), f2, xminp, xmaxp);
+        put_cell_h(dst + span - 1, ix2, ((15 - y_prev) ^ neg) - neg, f2, xminp, xmaxp);
         return;
     }
     // an edge over more columns than that: at most 17 of its cells have a height (they add up to the fifteen sample rows)
     int n = 0;
-    if (y_prev) put_cell_h(dst + n++, ix1, sign * y_prev, 256 + f1, xminp, xmaxp);
+    if (y_prev) put_cell_h(dst + n++, ix1, (y_prev ^ neg) - neg, 256 + f1, xminp, xmaxp);
 #pragma unroll 1
     for (int c = ix1 + 1; c < ix2; ++c) {
         yq += fq0; yr += fr0; if (yr >= W) { ++yq; yr -= W; }
         const int h = yq - y_prev;
-        if (h && n < MAX_CELLS_PER_EDGE_ROW - 1) put_cell_h(dst + n++, c, sign * h, 256, xminp, xmaxp);
+        if (h && n < MAX_CELLS_PER_EDGE_ROW - 1) put_cell_h(dst + n++, c, (h ^ neg) - neg, 256, xminp, xmaxp);
         y_prev = yq;
     }
-    if (15 - y_prev) put_cell_h(dst + n++, ix2, sign * (15 - y_prev), f2, xminp, xmaxp);
+    if (15 - y_prev) put_cell_h(dst + n++, ix2, ((15 - y_prev) ^ neg) - neg, f2, xminp, xmaxp);
     while (n < MAX_CELLS_PER_EDGE_ROW) put_cell(dst + n++, xminp, 0, 0, xminp, xmaxp);
 }
 
@@ -358,7 +359,7 @@ __device__ __forceinline__ void rows3_chunk_body(FramePtr FR, uint32_t block) {
             if (s >= nmax) continue;
             if (role[s] != 0) {
                 const FastEdge& e = staged[ke[s]];
-                full_cells3(qt[s], qb[s], rl[s], e.DX, e.D, e.invW, e.fq, e.fr, (role[s] & 1u) ? +1 : -1, P.x_min, P.x_max, &FR->cells[off]);
+                full_cells3(qt[s], qb[s], rl[s], e.DX, e.D, e.invW, e.fq, e.fr, (role[s] & 1u) ? 0 : -1, P.x_min, P.x_max, &FR->cells[off]);
                 off += (uint32_t)full_span(qt[s], qb[s]);
             }
         }
