@@ -420,25 +420,6 @@ __global__ __launch_bounds__(1024) void k2_bin_b(const Frame2* __restrict__ fram
 // ---------------------------------------------------------------------------------------------
 // k2_rows
 // ---------------------------------------------------------------------------------------------
-#ifdef SWFR_PHASES                 // -DSWFR_PHASES: clocks per phase of a k2_rows wavefront, summed into counters[24..31] (diagnostic builds only)
-#define R2PHASE(i) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); r2ph[i] += (uint32_t)(now_ - r2ph_t); r2ph_t = now_; } while (0)
-#else
-#define R2PHASE(i) do { } while (0)
-#endif
-// LDS of the fast row routine besides the staged edges: 2.8 KB (3.3 KB in the wide instance) -- round 2 kept role and column tables
-// for all 64 rows (7 KB); a wavefront now needs 5.9 KB with its 32 staged edges, so that the registers, not LDS, bound the
-// wavefronts per CU.
-//   eid       the rows' active edges (index into the chunk's edge list): what the sample lanes of a SUB row look up
-//   sub_*     roles and column range per edge of the FOUR rows of the current sample pass (their row lanes take them over in
-//             the same pass)
-//   u.key     per-lane scratch of the coincident-cells check (dynamic indexing of a row's cells), before the sample passes;
-//   u.cells   ... whose staging of the pass's cells (Cell::w per (row of the pass, edge, sample row)) reuses the same bytes
-template <class EID>
-struct FastLds3 {
-    EID eid[ROWS_FAST_N][64];
-    uint32_t sub_roles[ROWS_FAST_N][4], sub_cols[ROWS_FAST_N][4];
-    union { int32_t key[ROWS_FAST_N][64]; uint32_t cells[4][ROWS_FAST_N * 15]; } u;
-};
 // a SUB cell: the span end at cell position x (24.8) opens (sgn > 0) or closes a span
 __device__ __forceinline__ uint32_t pack_sub_cell(int x, int sgn, int xminp, int xmaxp) {
     int col = x >> 8, f = x & 255, live = 1;
@@ -448,542 +429,7 @@ __device__ __forceinline__ uint32_t pack_sub_cell(int x, int sgn, int xminp, int
     return make_cell_v(col - xminp, (v ^ neg) - neg).w;                // (the staged word is the cell itself)
 }
 
-// The fast row routine (rows with at most eight active edges, lane = row).  (1) A row in which two edges on different lines coincide
-// at the first sample row (their order is a matter of Cairo's list history) is not decided here: `defer_out`.  (2) The sample lanes
-// of a SUB row do not only set role bits, they produce the row's cells: staged in LDS per pass of four rows, then allocated and copied out by the
-// whole wavefront, and the rows' RowInfo2 written (index `ri` per row lane; ~0u: the path has no band entry, nothing is kept).
-template <class EPTR, class FLDS>
-__device__ __forceinline__ void rows2_fast(EPTR E, uint32_t n_list, const DevPath& P, int r, bool live, int fast_limit, FLDS& F, int lane,
-                                           uint32_t& mode_out, int& n_out_edges, bool& overflow_out, bool& defer_out,
-                                           int32_t (&roles)[ROWS_FAST_N], int32_t (&cols)[ROWS_FAST_N], int (&el)[ROWS_FAST_N],
-                                           int32_t (&Q1)[ROWS_FAST_N], int64_t (&R1)[ROWS_FAST_N], int32_t (&Q2)[ROWS_FAST_N], int64_t (&R2)[ROWS_FAST_N],
-                                           int& nmax_out, uint32_t ri, FramePtr FR, int& n_cells_out, uint32_t& incl_out, uint32_t& base_out,
-                                           uint32_t* r2ph, unsigned long long& r2ph_t, uint32_t chunk_cell_base) {
-    (void)r2ph; (void)r2ph_t;
-    const int s0 = r * 15;
-    const unsigned mask = P.fill_rule ? 1u : ~0u;
-    int n = 0;
-    bool mid_row = false, overflow = false;
-    int cs[ROWS_FAST_N], ce[ROWS_FAST_N], cp[ROWS_FAST_N], dr[ROWS_FAST_N], nw[ROWS_FAST_N];
-#pragma unroll
-    for (int s = 0; s < ROWS_FAST_N; ++s) { cs[s] = ce[s] = cp[s] = dr[s] = nw[s] = 0; el[s] = 0; roles[s] = 0; cols[s] = 0; Q1[s] = Q2[s] = 0; R1[s] = R2[s] = 0; }
-    // ---- gather: which edges are active in this row (sample rows [ytop, ybot) against the row's fifteen); no arithmetic yet
-    if (live) {
-        for (uint32_t k = 0; k < n_list; ++k) {
-            const int ytop = E[k].ytop, ybot = E[k].ybot;
-            if (ybot <= s0 || ytop >= s0 + 15) continue;
-            if (n >= fast_limit) { overflow = true; break; }
-            mid_row |= (ytop > s0) | (ybot < s0 + 15);
-#pragma unroll
-            for (int s = 0; s < ROWS_FAST_N; ++s) if (s == n) el[s] = (int)k;
-            ++n;
-        }
-    }
-    if (overflow) n = 0;
-    R2PHASE(2);
-    // wave-uniform bound on the active edges of any row of this wave: the unrolled slot loops stop there
-    const int nmax = __ballot(n > 6) ? 8 : __ballot(n > 4) ? 6 : __ballot(n > 2) ? 4 : 2;
-    nmax_out = nmax;
-    // ---- rows that can still be FULL: x of every active edge at the first sample row of this pixel row and of the next
-    if (n > 0 && !mid_row) {
-#pragma unroll
-        for (int s = 0; s < ROWS_FAST_N; ++s) {
-            if (s >= nmax) continue;                          // wave-uniform
-            if (s >= n) continue;
-            const DevEdge e = E[el[s]];
-            int32_t qa = e.x1, qb = e.x1; int64_t ra = 0, rb = 0;
-            int c0 = e.x1, c1 = e.x1, cpv = e.x1;
-            if (e.dy) {
-                edge_x_at(e, s0, qa, ra);
-                // fifteen sample rows on: + 7680 * ex / dy, the same floor representation (quotient, remainder in [0, dy)) as
-                // edge_x_at(e, s0 + 15) gives -- it is unique
-                qb = qa + e.q15; rb = ra + e.r15;
-                if (rb >= e.dy) { ++qb; rb -= e.dy; }
-                c0 = cell_of(qa, ra, e.dy);
-                c1 = cell_of(qb, rb, e.dy);
-                cpv = c0;
-                if (e.ytop < s0) {                        // cell one sample row earlier
-                    int32_t q = qa - (int32_t)e.dq; int64_t rm = ra - e.dr;
-                    if (rm < 0) { --q; rm += e.dy; } else if (rm >= e.dy) { ++q; rm -= e.dy; }
-                    cpv = cell_of(q, rm, e.dy);
-                }
-                const int32_t hq = (int32_t)(e.dq / 2); const int64_t hr = e.dr / 2;   // half a sample row back: row top / bottom
-                qa -= hq; ra -= hr; if (ra < 0) { --qa; ra += e.dy; } else if (ra >= e.dy) { ++qa; ra -= e.dy; }
-                qb -= hq; rb -= hr; if (rb < 0) { --qb; rb += e.dy; } else if (rb >= e.dy) { ++qb; rb -= e.dy; }
-            }
-            cs[s] = c0; ce[s] = c1; cp[s] = cpv; dr[s] = e.dir; nw[s] = (e.ytop == s0) ? 1 : 0;
-            Q1[s] = qa; Q2[s] = qb;
-#ifdef R2_KEEP_REMAINDERS
-            R1[s] = ra; R2[s] = rb;
-#endif
-        }
-    }
-    R2PHASE(3);
-    uint32_t mode = ROW_EMPTY;
-    bool is_sub = false, defer = false;
-    if (n > 0) {
-        bool full = !mid_row;
-        bool deep = false;
-        int wb[ROWS_FAST_N];
-        unsigned firstg = 0, lastg = 0;
-#pragma unroll
-        for (int j = 0; j < ROWS_FAST_N; ++j) wb[j] = 0;
-        if (full) {
-#pragma unroll
-            for (int j = 0; j < ROWS_FAST_N; ++j) {
-                if (j >= nmax) continue;                  // wave-uniform
-                int w = 0; bool fg = true, lg = true;
-#pragma unroll
-                for (int i = 0; i < ROWS_FAST_N; ++i) {
-                    if (i == j || i >= nmax) continue;
-                    const bool valid = i < n && j < n;
-                    // does edge i sort before edge j?  Only the cell decides here; rows with coincident cells are settled below
-                    const bool tie = cs[i] == cs[j];
-                    const bool before = cs[i] < cs[j] || (tie && i < j);
-                    deep |= valid && tie;
-                    if (valid && before) { w += dr[i]; if (ce[i] > ce[j]) full = false; if (tie) fg = false; }
-                    if (valid && !before && tie) lg = false;
-                }
-                wb[j] = w;
-                if (fg) firstg |= 1u << j;
-                if (lg) lastg |= 1u << j;
-            }
-        }
-        // coincident cells: edges on one and the same line (a shape edge with fill0 == fill1 is there twice) can go in either
-        // order -- index order was used above; any other tie needs the history of Cairo's edge list: the slow-row kernel's job
-        if (__ballot(deep && !mid_row) != 0ull) {
-#pragma unroll
-            for (int s = 0; s < ROWS_FAST_N; ++s) F.u.key[s][lane] = cs[s];
-            if (deep && !mid_row) {
-                bool real = false;
-                for (int i = 0; i < n && !real; ++i)
-                    for (int j = i + 1; j < n && !real; ++j)
-                        if (F.u.key[i][lane] == F.u.key[j][lane]) {
-                            int a = 0, b = 0;
-#pragma unroll
-                            for (int s = 0; s < ROWS_FAST_N; ++s) { if (s == i) a = el[s]; if (s == j) b = el[s]; }
-                            real = !(E[a].x1 == E[b].x1 && E[a].y1 == E[b].y1 && E[a].ex == E[b].ex && E[a].dy == E[b].dy);       // same_line
-                        }
-                defer = real;
-            }
-        }
-        if (defer) mode = ROW_DEFER;
-        else if (full) {
-            mode = ROW_FULL;
-#pragma unroll
-            for (int j = 0; j < ROWS_FAST_N; ++j) {
-                if (j >= n) continue;
-                const bool in_b = ((unsigned)wb[j] & mask) != 0, in_a = ((unsigned)(wb[j] + dr[j]) & mask) != 0;
-                uint32_t role = 0;
-                if (!in_b && ((firstg >> j) & 1u)) role = REC_FULL | 1u;          // left edge of a span
-                else if (!in_a && ((lastg >> j) & 1u)) role = REC_FULL | 2u;      // right edge
-                if (role) {
-                    const int a = Q1[j] >> 8, b = Q2[j] >> 8;
-                    cols[j] = (int32_t)(clamp_col(min(a, b)) | (clamp_col(max(a, b)) << 16));
-                }
-                roles[j] = (int32_t)role;
-            }
-        } else {
-            mode = ROW_SUB;
-            is_sub = true;
-#pragma unroll
-            for (int s = 0; s < ROWS_FAST_N; ++s) {
-                if (s >= nmax) continue;                      // wave-uniform: the sample lanes stop at nmax as well
-                F.eid[s][lane] = (decltype(F.eid[0][0] + 0))el[s];
-            }
-        }
-    }
-    // ---- room for the rows' cells inside the wavefront's region: a FULL row takes the exact number of its cells, a SUB row room for
-    //      one cell per (active edge, sample row) -- its cells are counted while they are made, so the row uses a prefix of its room
-    int n_cells = 0;
-    if (mode == ROW_FULL && ri != ~0u) {
-#pragma unroll
-        for (int s = 0; s < ROWS_FAST_N; ++s) {
-            if (s >= nmax) continue;                          // wave-uniform
-            if (s < n && roles[s] != 0) n_cells += full_span(Q1[s], Q2[s]);
-        }
-    }
-    const int room = is_sub && ri != ~0u ? n * 15 : n_cells;
-    const uint32_t incl_cells = (uint32_t)wave_scan_incl(room);
-    const uint32_t total_cells = (uint32_t)__builtin_amdgcn_readlane((int)incl_cells, 63);
-    // the wavefront's cells start at its chunk's slot: (edge, row) pairs before it x MAX_CELLS_PER_EDGE_ROW -- no allocator in this kernel
-    const uint32_t wave_base = ((uint64_t)chunk_cell_base + total_cells <= (uint64_t)FR->cell_slice) ? chunk_cell_base : ~0u;
-    if (wave_base == ~0u && lane == 0) atomicOr(&FR->counters[C2_ERROR], E2_CELL_ARENA);
-    R2PHASE(4);
-    // ---- FULL rows: the cells of every boundary edge, from the exact end points, into the row's room -- before the sample passes, so
-    //      that the end points' registers are free while those run
-#ifndef ABL_R_NOFULLCELLS
-    if (mode == ROW_FULL && ri != ~0u && live && !overflow && !defer && wave_base != ~0u) {
-        uint32_t off = wave_base + incl_cells - (uint32_t)room;
-#pragma unroll
-        for (int s = 0; s < ROWS_FAST_N; ++s) {
-            if (s >= nmax) continue;
-            if (s < n && roles[s] != 0) {
-                const int64_t edy = E[el[s]].dy;
-#ifndef R2_KEEP_REMAINDERS
-                // the remainders of the row's end points are worked out again here rather than kept in sixteen 64-bit registers per lane
-                // from the evaluation on (the quotients are the ones kept: the same formulas give the same numbers)
-                int64_t ra = 0, rb = 0;
-                if (edy) {
-                    const DevEdge e = E[el[s]];
-                    int32_t qa, qb;
-                    edge_x_at(e, s0, qa, ra);
-                    qb = qa + e.q15; rb = ra + e.r15;
-                    if (rb >= e.dy) { ++qb; rb -= e.dy; }
-                    const int64_t hr = e.dr / 2;
-                    ra -= hr; if (ra < 0) ra += e.dy; else if (ra >= e.dy) ra -= e.dy;
-                    rb -= hr; if (rb < 0) rb += e.dy; else if (rb >= e.dy) rb -= e.dy;
-                }
-                full_cells(Q1[s], ra, Q2[s], rb, edy, E[el[s]].inv_dx, E[el[s]].fq, E[el[s]].fr, ((uint32_t)roles[s] & 1u) ? +1 : -1, P.x_min, P.x_max, &FR->cells[off]);
-#else
-                full_cells(Q1[s], R1[s], Q2[s], R2[s], edy, E[el[s]].inv_dx, E[el[s]].fq, E[el[s]].fr, ((uint32_t)roles[s] & 1u) ? +1 : -1, P.x_min, P.x_max, &FR->cells[off]);
-#endif
-                off += (uint32_t)full_span(Q1[s], Q2[s]);
-            }
-        }
-    }
-#endif
-    R2PHASE(6);
-    lds_barrier();                                          // F.* written by the row owners, read by the sample lanes
-    // ---- the wave's SUB rows, 4 rows per pass: lanes 16g .. 16g + 14 are the fifteen sample rows of the pass's g-th row (lane 16g + 15
-    //      idles), so everything the samples of one row have to combine -- role bits, column range, cell positions -- is a reduction
-    //      over one DPP row or a ballot: no LDS atomics.  Roles for the classification, cells for the tile pass.
-    unsigned long long pending = __ballot(is_sub);
-#ifdef ABL_R_NOSUB
-    pending = 0ull;
-#endif
-    const int g = lane >> 4, sub = lane & 15;
-    const unsigned long long group_mask = 0xffffull << (16 * g);
-    const unsigned long long below = group_mask & ((1ull << lane) - 1ull);
-    const int n_all = n;
-    while (pending) {
-        unsigned long long m = pending;
-        int R = -1;
-        for (int t = 0; t <= g; ++t) { if (!m) { R = -1; break; } R = __ffsll((long long)m) - 1; m &= m - 1; }
-        const unsigned long long pass_rows = pending;           // its four lowest bits set are this pass's rows
-        for (int t = 0; t < 4 && pending; ++t) pending &= pending - 1;
-        // cross-lane reads must run with every lane active: ds_bpermute returns 0 for a disabled source lane
-        const int Rsrc = R >= 0 ? R : 0;
-        const int nR = __shfl(n_all, Rsrc);
-        const int rR = __shfl(r, Rsrc);
-        const uint32_t riR = (uint32_t)__shfl((int)ri, Rsrc);
-        const bool sampling = R >= 0 && sub < 15;
-        const int ss = rR * 15 + sub;
-        int cc[ROWS_FAST_N], dd[ROWS_FAST_N];
-        unsigned act = 0;
-#pragma unroll
-        for (int s = 0; s < ROWS_FAST_N; ++s) {
-            cc[s] = 0; dd[s] = 0;
-            if (s >= nmax) continue;
-            if (sampling && s < nR) {
-                const DevEdge e = E[F.eid[s][Rsrc]];
-                if (e.ytop <= ss && ss < e.ybot) {
-                    act |= 1u << s;
-                    dd[s] = e.dir;
-                    if (e.dy) { int32_t q; int64_t rm; edge_x_at(e, ss, q, rm); cc[s] = cell_of(q, rm, e.dy); } else cc[s] = e.x1;
-                }
-            }
-        }
-        uint32_t cnt_g = 0;                                 // cells of this lane's row so far (the same number in the row's sixteen lanes)
-#pragma unroll
-        for (int j = 0; j < ROWS_FAST_N; ++j) {
-            if (j >= nmax) continue;                         // wave-uniform: every lane runs the reductions below
-            bool contributes = false, in_a = false;
-            if ((act >> j) & 1u) {
-                int wbj = 0, gsum = dd[j]; bool rep = true;
-#pragma unroll
-                for (int i = 0; i < ROWS_FAST_N; ++i) {
-                    if (i >= nmax) continue;
-                    if (i == j || !((act >> i) & 1u)) continue;
-                    if (cc[i] < cc[j]) wbj += dd[i];
-                    else if (cc[i] == cc[j]) { gsum += dd[i]; if (i < j) rep = false; }
-                }
-                if (rep) {                                   // one edge per group of equal cells carries the role
-                    const bool in_b = ((unsigned)wbj & mask) != 0;
-                    in_a = ((unsigned)(wbj + gsum) & mask) != 0;
-                    contributes = in_a != in_b;
-                }
-            }
-            const int col = (int)clamp_col(cc[j] >> 8);
-            int rb = contributes ? (int)((in_a ? 1u : 2u) << (2 * sub)) : 0;
-            int lo = contributes ? col : 65535, hi = contributes ? col : 0;
-            // all-reduce over the row's sixteen lanes: four rotations each
-            rb |= __builtin_amdgcn_update_dpp(0, rb, 0x128, 0xf, 0xf, false);
-            lo = min(lo, __builtin_amdgcn_update_dpp(0, lo, 0x128, 0xf, 0xf, false));
-            hi = max(hi, __builtin_amdgcn_update_dpp(0, hi, 0x128, 0xf, 0xf, false));
-            rb |= __builtin_amdgcn_update_dpp(0, rb, 0x124, 0xf, 0xf, false);
-            lo = min(lo, __builtin_amdgcn_update_dpp(0, lo, 0x124, 0xf, 0xf, false));
-            hi = max(hi, __builtin_amdgcn_update_dpp(0, hi, 0x124, 0xf, 0xf, false));
-            rb |= __builtin_amdgcn_update_dpp(0, rb, 0x122, 0xf, 0xf, false);
-            lo = min(lo, __builtin_amdgcn_update_dpp(0, lo, 0x122, 0xf, 0xf, false));
-            hi = max(hi, __builtin_amdgcn_update_dpp(0, hi, 0x122, 0xf, 0xf, false));
-            rb |= __builtin_amdgcn_update_dpp(0, rb, 0x121, 0xf, 0xf, false);
-            lo = min(lo, __builtin_amdgcn_update_dpp(0, lo, 0x121, 0xf, 0xf, false));
-            hi = max(hi, __builtin_amdgcn_update_dpp(0, hi, 0x121, 0xf, 0xf, false));
-            if (sub == 0 && R >= 0) { F.sub_roles[j][g] = (uint32_t)rb; F.sub_cols[j][g] = (uint32_t)lo | ((uint32_t)hi << 16); }
-            const bool cell = contributes && riR != ~0u;
-            const unsigned long long cb = __ballot(cell);
-            if (cell) F.u.cells[g][cnt_g + (uint32_t)__popcll(cb & below)] = pack_sub_cell(cc[j], in_a ? 1 : -1, P.x_min, P.x_max);
-            cnt_g += (uint32_t)__popcll(cb & group_mask);
-        }
-        lds_barrier();                                      // the pass's cells, roles and column ranges are staged
-        {   // the row lanes of this pass take their roles and column ranges over (my_t: the lane's place among the pass's four rows)
-            const int my_t = (int)__popcll(pass_rows & ((1ull << lane) - 1ull));
-            if (((pass_rows >> lane) & 1ull) != 0ull && my_t < 4) {
-#pragma unroll
-                for (int s = 0; s < ROWS_FAST_N; ++s) {
-                    if (s >= nmax) continue;
-                    roles[s] = (int32_t)F.sub_roles[s][my_t]; cols[s] = (int32_t)F.sub_cols[s][my_t];
-                }
-            }
-        }
-        // ---- copy out (coalesced) into the rows' room, row headers
-        {
-            const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)cnt_g, 0), c1 = (uint32_t)__builtin_amdgcn_readlane((int)cnt_g, 16);
-            const uint32_t c2 = (uint32_t)__builtin_amdgcn_readlane((int)cnt_g, 32), c3 = (uint32_t)__builtin_amdgcn_readlane((int)cnt_g, 48);
-            const uint32_t total = c0 + c1 + c2 + c3;
-            // where the rooms of the pass's rows start: the row lanes know (exclusive prefix of the rooms), every lane asks
-            const uint32_t my_room = wave_base + incl_cells - (uint32_t)room;
-            int Rg[4];
-            {
-                unsigned long long m2 = pass_rows;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) { Rg[t] = m2 ? __ffsll((long long)m2) - 1 : 0; m2 &= m2 - 1; }
-            }
-            const uint32_t b0 = (uint32_t)__shfl((int)my_room, Rg[0]), b1 = (uint32_t)__shfl((int)my_room, Rg[1]);
-            const uint32_t b2 = (uint32_t)__shfl((int)my_room, Rg[2]), b3 = (uint32_t)__shfl((int)my_room, Rg[3]);
-            if (wave_base != ~0u) {
-                for (uint32_t t = (uint32_t)lane; t < total; t += 64) {
-                    const int gg = t < c0 ? 0 : (t < c0 + c1 ? 1 : (t < c0 + c1 + c2 ? 2 : 3));
-                    const uint32_t pre = gg == 0 ? 0u : (gg == 1 ? c0 : (gg == 2 ? c0 + c1 : c0 + c1 + c2));
-                    const uint32_t bb = gg == 0 ? b0 : (gg == 1 ? b1 : (gg == 2 ? b2 : b3));
-                    FR->cells[bb + (t - pre)] = Cell{F.u.cells[gg][t - pre]};
-                }
-            }
-            if (sub == 0 && R >= 0 && riR != ~0u) {          // the first sample lane of each of the pass's rows writes its header
-                const uint32_t bb = g == 0 ? b0 : (g == 1 ? b1 : (g == 2 ? b2 : b3));
-                RowInfo2 h; h.off = wave_base == ~0u ? 0u : bb; h.n = wave_base == ~0u ? (uint16_t)0 : (uint16_t)cnt_g; h.mode = (uint16_t)ROW_SUB;
-                FR->rows[riR] = h;
-            }
-        }
-        lds_barrier();                                      // the staging has been read: the next pass may overwrite it
-    }
-    R2PHASE(5);
-    mode_out = mode; n_out_edges = n; overflow_out = overflow; defer_out = defer;
-    n_cells_out = n_cells; incl_out = incl_cells - (uint32_t)room + (uint32_t)n_cells; base_out = wave_base;     // (the caller's offset is base + incl - n_cells)
-}
-
-
 #include "rows3.hip"
-
-// STAGE: edges of the path a chunk can keep in LDS (two instances of the kernel: 32 -- fifteen wavefronts per CU -- for scenes whose
-// paths have at most 32 edges, 64 for the others)
-template <int STAGE>
-__device__ __forceinline__ void rows2_chunk_body(FramePtr FR, uint32_t block) {
-    uint32_t r2ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long r2ph_t = 0;
-#ifdef SWFR_PHASES
-    r2ph_t = __builtin_amdgcn_s_memtime();
-#endif
-    // (the 32-edge instance runs scenes whose paths have at most 32 edges: an edge's index in the chunk's list fits a byte)
-    __shared__ FastLds3<typename std::conditional<(STAGE <= 32), uint8_t, uint16_t>::type> F;
-    __shared__ DevEdge staged[STAGE];
-    const int lane = threadIdx.x;
-    const ChunkInfo ck = FR->chunks[block];                               // wave-uniform: path and edge reads are scalar
-    const uint32_t lo = ck.path;
-    const DevPath P = FR->paths[lo];
-    const int r = (int)ck.first_row + lane;
-    const int chunk_rows = (int)ck.rows;                                 // 16, 32 or 64: whole tile-rows, starting on a tile-row boundary
-
-    // the band entry of this lane's tile-row: where its row headers and class bytes go
-    const int g16 = lane >> 4;
-    const int band = (int)ck.first_row / TILE_H + g16;
-    const int band_lo = P.y_min / TILE_H, band_hi = (P.y_max - 1) / TILE_H;
-    const bool band_ok = ck.slot0 != ~0u && g16 < chunk_rows / TILE_H && band >= band_lo && band <= band_hi && P.kind == SWFR_PATH_TOR;
-    BandSlot cls_bs = {0u, 0u, 0u, 0u};
-    uint32_t cls_b0 = 0, cls_b1 = 0;
-    if (band_ok) {
-        cls_bs = FR->band_slots[ck.slot0 + (uint32_t)g16];
-        cls_b0 = FR->band_off[band];
-        cls_b1 = FR->band_off[band + 1];
-    }
-    const uint32_t ri = band_ok ? cls_bs.slot * TILE_H + (uint32_t)(lane & (TILE_H - 1)) : ~0u;
-    const bool in_path = P.kind == SWFR_PATH_TOR && lane < chunk_rows && r >= P.y_min && r < P.y_max;
-    bool live = in_path;
-    { uint32_t lb; if (live && !owns_band(FR, r / TILE_H, lb)) live = false; }         // another rank's tile-row
-    if (__ballot(live) == 0ull) {
-        // nothing of this chunk is this handle's (multi-GPU): its rows stay "not known here" for the slow rows' history look-ups
-        if (ri != ~0u && lane < chunk_rows) { RowInfo2 h; h.off = 0; h.n = 0; h.mode = (uint16_t)(in_path ? (uint32_t)ROW_FOREIGN : (uint32_t)ROW_EMPTY); FR->rows[ri] = h; }
-        return;
-    }
-    int fast_limit = (int)FR->fast_limit;
-    if (P.n_edges > (sizeof(F.eid[0][0]) == 1 ? 255u : 65535u)) fast_limit = 0;   // 8- / 16-bit local edge indices in the fast path
-    R2PHASE(0);
-    // ---- stage the edges that can be active in this chunk's rows (path order kept)
-    const int lo_s = (int)ck.first_row * 15, hi_s = lo_s + chunk_rows * 15;
-    uint32_t n_list = 0;
-    bool use_lds = true;
-    int inc_before = 0;                                                  // (edge, pixel row) pairs of this path above the chunk: where its cells start
-    for (uint32_t eb = 0; eb < P.n_edges; eb += 64) {
-        const uint32_t k = eb + (uint32_t)lane;
-        const DevEdge ek = FR->edges[P.first_edge + min(k, P.n_edges - 1u)];
-        const bool valid = k < P.n_edges && ek.ybot > ek.ytop;
-        if (valid) inc_before += max(0, min((ek.ybot - 1) / 15 + 1, (int)ck.first_row) - ek.ytop / 15);
-        const bool hit = use_lds && valid && ek.ytop < hi_s && ek.ybot > lo_s;
-        const unsigned long long hb = __ballot(hit);
-        const uint32_t at = n_list + (uint32_t)__popcll(hb & ((1ull << lane) - 1ull));
-        if (hit && at < (uint32_t)STAGE) staged[at] = ek;
-        n_list += (uint32_t)__popcll(hb);
-        if (n_list > (uint32_t)STAGE) use_lds = false;                        // (the loop goes on: every edge of the path counts for inc_before)
-    }
-    const uint32_t chunk_cell_base = (ck.rec_base + (uint32_t)__builtin_amdgcn_readlane(wave_scan_incl(inc_before), 63)) * (uint32_t)MAX_CELLS_PER_EDGE_ROW;
-    lds_barrier();
-    R2PHASE(1);
-    uint32_t mode; int n, nmax = ROWS_FAST_N; bool overflow, defer;
-    int32_t roles[ROWS_FAST_N], cols[ROWS_FAST_N]; int el[ROWS_FAST_N];
-    int32_t Q1[ROWS_FAST_N], Q2[ROWS_FAST_N]; int64_t R1[ROWS_FAST_N], R2[ROWS_FAST_N];
-    int n_cells; uint32_t incl, base;
-    if (use_lds) rows2_fast((const DevEdge*)staged, n_list, P, r, live, fast_limit, F, lane, mode, n, overflow, defer, roles, cols, el, Q1, R1, Q2, R2, nmax, ri, FR, n_cells, incl, base, r2ph, r2ph_t, chunk_cell_base);
-    else rows2_fast(FR->edges + P.first_edge, P.n_edges, P, r, live, fast_limit, F, lane, mode, n, overflow, defer, roles, cols, el, Q1, R1, Q2, R2, nmax, ri, FR, n_cells, incl, base, r2ph, r2ph_t, chunk_cell_base);
-    const bool slow = live && (overflow || defer);
-    // ---- headers of the rows that are not SUB (those were written with their cells); a FULL row's cells are in place already
-    const bool emit = mode == ROW_FULL && ri != ~0u && !slow;
-    if (ri != ~0u && lane < chunk_rows && mode != ROW_SUB) {
-        RowInfo2 h; h.off = 0; h.n = 0; h.mode = (uint16_t)(slow ? (uint32_t)ROW_DEFER : (in_path && !live) ? (uint32_t)ROW_FOREIGN : mode);   // (another rank's row: not known here)
-        if (emit && base != ~0u) { h.off = base + incl - (uint32_t)n_cells; h.n = (uint16_t)n_cells; }
-        FR->rows[ri] = h;
-    }
-    // ---- rows left to the slow-row kernel
-    {
-        const bool q = slow && ri != ~0u;
-        const unsigned long long qm = __ballot(q);
-        if (qm) {
-            uint32_t qb = 0;
-            if (lane == 0) {
-                qb = atomicAdd(&FR->counters[C2_SLOW], (uint32_t)__popcll(qm));
-                if (atomicOr(&FR->path_flag[lo], 1u) == 0u) FR->path_queue[atomicAdd(&FR->counters[C2_PATHQ], 1u)] = lo;   // once per path
-            }
-            qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)qb);
-            if (q) {
-                const uint32_t at = qb + (uint32_t)__popcll(qm & ((1ull << lane) - 1ull));
-                if (at < FR->slow_cap) {
-                    SlowRow sr; sr.path = lo; sr.row = r; sr.ri = ri;
-                    // where the path's (path, tile-row) pairs start in band_slots (the slow kernel looks up earlier rows' headers) | tie flag
-                    sr.pad = (ck.slot0 - (uint32_t)((int)ck.first_row / TILE_H - band_lo)) | (defer ? 0x80000000u : 0u);
-                    FR->slow[at] = sr;
-                }
-                else atomicOr(&FR->counters[C2_ERROR], E2_SLOW_QUEUE);
-            }
-        }
-    }
-    // ---- classification of this chunk's (tile, path) pairs from the row summaries still in registers: lanes 16g..16g+15 are the
-    //      pixel rows of tile-row g.  Only the columns of the path's rectangle are written (the rest of the class matrix was
-    //      cleared when the scene was uploaded and nothing ever writes there).
-#ifdef ABL_R_NOCLASS
-    if (ck.slot0 == 0x7fffffffu)
-#endif
-    if (ck.slot0 != ~0u && P.kind == SWFR_PATH_TOR) {
-        const int width = FR->width, height = FR->height;
-        uint8_t* out = FR->cls;
-        uint32_t n_b = 0;
-        if (band_ok) {
-            n_b = cls_b1 - cls_b0;
-            out = FR->cls + (size_t)STRIPS_PER_TILE * FR->tiles_x * cls_b0 + (cls_bs.slot - cls_b0);
-        }
-        const swfr_style& st = style_at(FR, P.style);           // (kind and pixel only)
-        const uint32_t opq = (st.kind == SWFR_STYLE_SOLID && P.lerp && (st.pixel >> 24) == 0xffu) ? CLS_OPAQUE : 0u;
-        const int tc0 = P.x_min / TILE_W, tc1 = (P.x_max - 1) / TILE_W;
-        const int y = r;
-        bool in_frame = y < height && band_ok, in_rows = in_frame && in_path;
-        // A chunk of 16 or 32 rows leaves three quarters or half of the wavefront idle here: the idle lanes take copies of the rows'
-        // summaries and the wavefront classifies 4 or 2 tile columns per step (lane = (tile column of the step, row)).
-        const int groups = 64 / chunk_rows, gi = lane / chunk_rows;   // (wave-uniform / this lane's column within a step)
-        bool slow_c = slow, band_ok_c = band_ok;
-        int band_c = band, n_c = n;
-        uint32_t n_b_c = n_b;
-        if (groups > 1) {
-            const int src = lane % chunk_rows;
-            in_frame = __shfl((int)in_frame, src) != 0; in_rows = __shfl((int)in_rows, src) != 0;
-            slow_c = __shfl((int)slow, src) != 0; band_ok_c = __shfl((int)band_ok, src) != 0;
-            band_c = __shfl(band, src); n_c = __shfl(n, src); n_b_c = (uint32_t)__shfl((int)n_b, src);
-            const unsigned long long o = (unsigned long long)(uintptr_t)out;
-            const uint32_t olo = (uint32_t)__shfl((int)(uint32_t)o, src), ohi = (uint32_t)__shfl((int)(uint32_t)(o >> 32), src);
-            out = (uint8_t*)(uintptr_t)(((unsigned long long)ohi << 32) | olo);
-#pragma unroll
-            for (int s2 = 0; s2 < ROWS_FAST_N; ++s2) { roles[s2] = __shfl(roles[s2], src); cols[s2] = __shfl(cols[s2], src); }
-        }
-        // (which of the handle's tile-rows this lane's band is -- two integer divisions by the band stride -- does not depend on the column)
-        uint32_t local_trow = 0;
-        const bool own_band = FR->strip_order && band_ok_c && owns_band(FR, band_c, local_trow);
-        // per record of the row, once for all columns: its net height (0: no record), the last column it occupies when it can lie left
-        // of a tile (else "never left") and the first when it can lie right of one -- the loop over the tile columns is then two
-        // compares, a select and an add per record, without branches
-        int hgt[ROWS_FAST_N], chiL[ROWS_FAST_N], cloR[ROWS_FAST_N];
-#pragma unroll
-        for (int s2 = 0; s2 < ROWS_FAST_N; ++s2) {
-            hgt[s2] = 0; chiL[s2] = 0x7fffffff; cloR[s2] = 0x7fffffff;       // (no record: left of nothing, right of everything -- never "inter")
-            if (s2 >= nmax) continue;                                        // wave-uniform
-            const bool has = s2 < n_c && roles[s2] != 0;
-            const int clo = (int)((uint32_t)cols[s2] & 0xffffu), chi = (int)((uint32_t)cols[s2] >> 16);
-            hgt[s2] = has ? record_height((uint32_t)roles[s2]) : 0;
-            chiL[s2] = has ? (chi < 65535 ? chi : 0x7fffffff) : 0x7fffffff;
-            cloR[s2] = has ? (clo < 65535 ? clo : -0x7fffffff) : 0x7fffffff;
-        }
-        for (int tcb = tc0; tcb <= tc1; tcb += groups) {      // wave-uniform
-            const int tc = tcb + gi;
-            const bool tcv = tc <= tc1;
-            const int tx0 = tc * TILE_W, tile_x1 = min(tx0 + TILE_W, width);
-            uint32_t f = 0;
-            bool row_partial = false;                                    // this lane's row has a boundary of the path in this tile
-            if (in_frame && tcv) {
-                if (!in_rows) f = CLS_NOTFULL;
-                else if (slow_c) { f = CLS_PARTIAL | CLS_NOTFULL | CLS_NONEMPTY; row_partial = true; }    // not known yet: the general route is always right
-                else {
-                    int carry = 0;
-                    bool inter = false;
-#pragma unroll
-                    for (int s2 = 0; s2 < ROWS_FAST_N; ++s2) {
-                        if (s2 >= nmax) continue;                        // wave-uniform
-                        const bool left = chiL[s2] < tx0, right = cloR[s2] >= tx0 + TILE_W;
-                        carry += left ? hgt[s2] : 0;
-                        inter |= !left && !right;
-                    }
-                    const bool inside_x = P.x_min <= tx0 && P.x_max >= tile_x1;
-                    const uint32_t a = (uint32_t)((carry * 512 * 17 + 256) >> 9) & 255u;
-                    if (inter) f = CLS_PARTIAL | CLS_NOTFULL | CLS_NONEMPTY;
-                    else if (a == 0) f = CLS_NOTFULL | CLS_HOLE;
-                    else if (a == 255 && inside_x) f = CLS_NONEMPTY;
-                    else f = CLS_PARTIAL | CLS_NOTFULL | CLS_NONEMPTY;
-                    row_partial = inter;
-                }
-            }
-            // OR over the strip's eight lanes (half a DPP row): mirror the half, then two quad permutations; every lane is active here
-            f |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f, 0x141, 0xf, 0xf, false);   // row_half_mirror
-            f |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f, 0xb1, 0xf, 0xf, false);    // quad_perm:[1,0,3,2]
-            f |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f, 0x4e, 0xf, 0xf, false);    // quad_perm:[2,3,0,1]
-            if ((f & (CLS_HOLE | CLS_NONEMPTY)) == (CLS_HOLE | CLS_NONEMPTY)) f |= CLS_PARTIAL;
-            f &= ~CLS_HOLE;
-            if ((f & (CLS_PARTIAL | CLS_NOTFULL | CLS_NONEMPTY)) == CLS_NONEMPTY) f |= opq;        // a full cover that hides what lies below
-            if ((lane & 7) == 0 && band_ok_c && tcv) out[(uint32_t)(tc * STRIPS_PER_TILE + ((lane >> 3) & 1)) * n_b_c] = (uint8_t)f;   // (< 2^32: strips of a tile-row x its entries)
-            // the tile's strips get heavier by the rows of this path with a boundary in the tile (the tile pass starts its heaviest
-            // strips first): lanes 0 and 8 of the tile-row's sixteen add their half's rows
-            if (FR->strip_order) {
-                const unsigned long long pb = __ballot(row_partial);
-                if ((lane & 7) == 0 && own_band && tcv && (f & CLS_PARTIAL)) {
-                    const uint32_t wgt = (uint32_t)__popcll((pb >> lane) & 0xffull);
-                    if (wgt) atomicAdd(&FR->strip_cost[((size_t)local_trow * FR->tiles_x + tc) * STRIPS_PER_TILE + ((lane >> 3) & 1)], wgt);
-                }
-            }
-        }
-    }
-    R2PHASE(7);
-#ifdef SWFR_PHASES
-    if (lane == 0 && (block & 63u) == 0u) {                                      // a sample of the wavefronts: contended atomics are slow
-        for (int i = 0; i < 8; ++i) atomicAdd(&FR->counters[24 + i], r2ph[i] >> 4);   // units of 16 clocks
-        atomicAdd(&FR->counters[C2_CELLS], 1u);
-    }
-#endif
-}
 
 #ifndef R2_WAVES
 #define R2_WAVES 4                 // 119 VGPRs, 8.1 KB of LDS: four wavefronts per SIMD
@@ -1833,6 +1279,9 @@ __device__ __forceinline__ void tiles3_body(FramePtr FR) {
         StripTop top;
 #ifdef SWFR_EMU
         top = FR->strip_top[wg];
+        // (the emulator's lanes are fibers: the rendezvous keeps lane 0 from clearing the record below before the others have read it)
+        top.any = (uint32_t)__builtin_amdgcn_readfirstlane((int)top.any);
+        top.cover = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(top.cover >> 32)) << 32) | (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)top.cover);
 #else
         {
             const uint32_t __attribute__((address_space(4)))* tp = reinterpret_cast<const uint32_t __attribute__((address_space(4)))*>(reinterpret_cast<uintptr_t>(FR->strip_top + wg));
