@@ -12,7 +12,7 @@
  *                                   (decode: ts/src/lib/shape/decode-swf-shape.ts:22-39)
  *   swfr_register_morph_shape       ClientAssetStore::register_morph_shape      rs/src/asset.rs:9-12
  *                                   (decode: ts/src/lib/shape/decode-swf-morph-shape.ts:21-41)
- *   swfr_register_bitmap            Renderer.addBitmap(tag)                     ts/src/lib/renderer.ts:4-8,
+ *   swfr_register_bitmap(_tag)      Renderer.addBitmap(tag)                     ts/src/lib/renderer.ts:4-8,
  *                                   ts/src/lib/renderers/node-canvas-bitmap-service.ts:14-37
  *   swfr_render                     SwfRenderer::render(&mut self, Stage)       rs/src/swf_renderer.rs:3-5
  *                                   Renderer.render(stage)                      ts/src/lib/renderer.ts:4-8
@@ -158,6 +158,15 @@ int  swfr_register_shape(swfr_renderer *r, const swfr_define_shape *tag, uint32_
 int  swfr_register_morph_shape(swfr_renderer *r, const swfr_define_shape *tag, uint32_t *out_id);
 int  swfr_register_bitmap(swfr_renderer *r, uint32_t id, uint32_t width, uint32_t height,
                           const uint8_t *rgba_straight, size_t stride);
+/* Renderer.addBitmap(tag) with the tag's own bytes (ts/src/lib/renderers/node-canvas-bitmap-service.ts:14-37): media type
+   "image/x-swf-bmp" is decoded by the library (decodeXSwfBmpSync, ts/src/lib/decode-x-swf-bmp.ts:9-41: format 3, zlib colour-mapped,
+   rows padded to 4 bytes, opaque palette, an index past the palette is opaque black) and registered as by swfr_register_bitmap;
+   any other media type, or another format id, is SWFR_ERR_NOT_IMPLEMENTED like the reference's "NotImplemented: Support for ...
+   images" / "UnsupportedXSwfBmpFormatId"; a damaged stream is SWFR_ERR_INVALID. */
+int  swfr_register_bitmap_tag(swfr_renderer *r, uint32_t id, const char *media_type, const uint8_t *data, size_t len);
+/* The decoder alone (no handle, no device): dimensions, and -- when rgba is not NULL -- straight RGBA8 with tight rows into the
+   caller's buffer of rgba_cap bytes (SWFR_ERR_CAPACITY when it is too small; call with NULL first to size it). */
+int  swfr_decode_x_swf_bmp(const uint8_t *data, size_t len, uint32_t *width, uint32_t *height, uint8_t *rgba, size_t rgba_cap);
 int  swfr_render(swfr_renderer *r, const swfr_stage *stage);               /* blocking */
 int  swfr_read_image(swfr_renderer *r, uint8_t *dst, size_t dst_stride, int premultiplied);
 /* Mapped read-back in two halves (HeadlessGfxRenderer::get_image maps its staging buffer the same way:

@@ -30,6 +30,7 @@ EXPORTS = [
     "swfr_band_slab_bytes", "swfr_copy_band_slab", "swfr_device_framebuffer", "swfr_debug_copy", "swfr_last_path_timing", "swfr_get_stats",
     "swfr_render_sequence", "swfr_set_targets", "swfr_render_resident_async", "swfr_stream_handle", "swfr_wait",
     "swfr_render_resident_batched", "swfr_read_image_async", "swfr_read_image_wait", "swfr_render_sequence_readback",
+    "swfr_register_bitmap_tag", "swfr_decode_x_swf_bmp",
 ]
 
 
@@ -172,6 +173,10 @@ def load_library():
         getattr(L, fn).argtypes = [P, C.POINTER(DefineShape), C.POINTER(U)]
     L.swfr_register_bitmap.restype = I
     L.swfr_register_bitmap.argtypes = [P, U, U, U, P, C.c_size_t]
+    L.swfr_register_bitmap_tag.restype = I
+    L.swfr_register_bitmap_tag.argtypes = [P, U, C.c_char_p, P, C.c_size_t]
+    L.swfr_decode_x_swf_bmp.restype = I
+    L.swfr_decode_x_swf_bmp.argtypes = [P, C.c_size_t, C.POINTER(U), C.POINTER(U), P, C.c_size_t]
     L.swfr_render.restype = I
     L.swfr_render.argtypes = [P, C.POINTER(Stage)]
     L.swfr_render_batch.restype = I
@@ -361,21 +366,23 @@ def image_to_png(width: int, height: int, rgba: bytes) -> bytes:
 def decode_x_swf_bmp(data: bytes):
     """`image/x-swf-bmp` format 3 (zlib colour-mapped) -> (width, height, straight RGBA bytes).
 
-    Host-side mirror of decodeXSwfBmpSync (ts/src/lib/decode-x-swf-bmp.ts:9-41): rows are padded to 4
-    bytes, the palette is opaque, out-of-range indices are opaque black.
+    decodeXSwfBmpSync (ts/src/lib/decode-x-swf-bmp.ts:9-41) as libswfr.so restates it (csrc/bitmap_decode.cpp, its own
+    inflater): rows are padded to 4 bytes, the palette is opaque, out-of-range indices are opaque black.  Needs no device.
     """
-    import zlib
-    if data[0] != 3:
-        raise SwfrError(ERR_NOT_IMPLEMENTED, "UnsupportedXSwfBmpFormatId: %d" % data[0])
-    width, height = int.from_bytes(data[1:3], "little"), int.from_bytes(data[3:5], "little")
-    padded = width + ((4 - (width % 4)) % 4)
-    n_colors = data[5] + 1
-    src = np.frombuffer(zlib.decompress(bytes(data[6:])), dtype=np.uint8)
-    palette = np.zeros((256, 4), dtype=np.uint8)
-    palette[:, 3] = 255
-    palette[:n_colors, :3] = src[:3 * n_colors].reshape(n_colors, 3)
-    idx = src[3 * n_colors:3 * n_colors + padded * height].reshape(height, padded)[:, :width]
-    return width, height, palette[idx].tobytes()
+    L = load_library()
+    data = bytes(data)
+    buf = (C.c_uint8 * max(len(data), 1)).from_buffer_copy(data or b"\0")
+    w, h = C.c_uint32(), C.c_uint32()
+    rc = L.swfr_decode_x_swf_bmp(C.cast(buf, C.c_void_p), len(data), C.byref(w), C.byref(h), None, 0)
+    if rc == ERR_NOT_IMPLEMENTED:
+        raise SwfrError(rc, "UnsupportedXSwfBmpFormatId: %d" % (data[0] if data else -1))
+    if rc != OK:
+        raise SwfrError(rc, "corrupt image/x-swf-bmp data")
+    out = (C.c_uint8 * (w.value * h.value * 4))()
+    rc = L.swfr_decode_x_swf_bmp(C.cast(buf, C.c_void_p), len(data), C.byref(w), C.byref(h), C.cast(out, C.c_void_p), len(out))
+    if rc != OK:
+        raise SwfrError(rc, "corrupt image/x-swf-bmp data")
+    return w.value, h.value, bytes(out)
 
 
 class Renderer:
@@ -420,13 +427,11 @@ class Renderer:
 
     def add_bitmap(self, tag):
         """Renderer.addBitmap(tag: DefineBitmap)."""
-        if tag["media_type"] != "image/x-swf-bmp":
-            raise SwfrError(ERR_NOT_IMPLEMENTED, "NotImplemented: Support for %s images" % tag["media_type"])
         data = tag["data"]
         if isinstance(data, str):
             data = bytes.fromhex(data)
-        w, h, rgba = decode_x_swf_bmp(data)
-        self.register_bitmap(tag["id"], w, h, rgba)
+        buf = (C.c_uint8 * max(len(data), 1)).from_buffer_copy(bytes(data) or b"\0")
+        self._check(self.L.swfr_register_bitmap_tag(self.h, tag["id"], tag["media_type"].encode("utf-8"), C.cast(buf, C.c_void_p), len(data)))
 
     def register_bitmap(self, bitmap_id, width, height, rgba_straight: bytes):
         buf = (C.c_uint8 * len(rgba_straight)).from_buffer_copy(rgba_straight)

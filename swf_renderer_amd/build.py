@@ -7,7 +7,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["raster2.hip", "renderer.cpp", "geometry.cpp", "shape_decoder.cpp", "frame_builder.cpp"]
+SOURCES = ["raster2.hip", "renderer.cpp", "geometry.cpp", "shape_decoder.cpp", "frame_builder.cpp", "bitmap_decode.cpp"]
 LIB = os.path.join(HERE, "libswfr.so")
 
 

@@ -22,6 +22,7 @@
 #include "device_types.hpp"
 #include "frame_builder.hpp"
 #include "shape_decoder.hpp"
+#include "bitmap_decode.hpp"
 
 namespace swfr {
 void launch2_bin(hipStream_t, const Frame2*, uint32_t, uint32_t, uint32_t);
@@ -1435,6 +1436,34 @@ int swfr_register_morph_shape(swfr_renderer* r, const swfr_define_shape* tag, ui
         *out_id = r->builder->add_morph_shape(decode_shape(*tag, true));
         return int(SWFR_OK);
     });
+}
+
+int swfr_decode_x_swf_bmp(const uint8_t* data, size_t len, uint32_t* width, uint32_t* height, uint8_t* rgba, size_t rgba_cap) {
+    if (!data || !width || !height) return SWFR_ERR_INVALID;
+    try {
+        std::vector<uint8_t> px;
+        const XSwfBmpStatus st = decode_x_swf_bmp(data, len, *width, *height, px);
+        if (st == XSwfBmpStatus::UnsupportedFormat) return SWFR_ERR_NOT_IMPLEMENTED;
+        if (st != XSwfBmpStatus::Ok) return SWFR_ERR_INVALID;
+        if (rgba) {
+            if (rgba_cap < px.size()) return SWFR_ERR_CAPACITY;
+            std::memcpy(rgba, px.data(), px.size());
+        }
+        return SWFR_OK;
+    } catch (...) { return SWFR_ERR_DEVICE; }
+}
+
+int swfr_register_bitmap_tag(swfr_renderer* r, uint32_t id, const char* media_type, const uint8_t* data, size_t len) {
+    if (!r || !media_type || !data) return fail(r, SWFR_ERR_INVALID, "null argument");
+    if (std::strcmp(media_type, "image/x-swf-bmp") != 0)
+        return fail(r, SWFR_ERR_NOT_IMPLEMENTED, std::string("NotImplemented: Support for ") + media_type + " images");   // node-canvas-bitmap-service.ts:34-35
+    uint32_t w = 0, h = 0;
+    std::vector<uint8_t> px;
+    XSwfBmpStatus st = XSwfBmpStatus::Corrupt;
+    try { st = decode_x_swf_bmp(data, len, w, h, px); } catch (...) { return fail(r, SWFR_ERR_DEVICE, "out of memory decoding a bitmap"); }
+    if (st == XSwfBmpStatus::UnsupportedFormat) return fail(r, SWFR_ERR_NOT_IMPLEMENTED, std::string("UnsupportedXSwfBmpFormatId: ") + std::to_string(len ? int(data[0]) : -1));
+    if (st != XSwfBmpStatus::Ok) return fail(r, SWFR_ERR_INVALID, "corrupt image/x-swf-bmp data");
+    return swfr_register_bitmap(r, id, w, h, px.data(), size_t(w) * 4);
 }
 
 int swfr_register_bitmap(swfr_renderer* r, uint32_t id, uint32_t width, uint32_t height, const uint8_t* rgba, size_t stride) {

@@ -73,6 +73,63 @@ def test_bitmap_decode_matches_reference_pam():
     assert api.image_to_pam(w, h, rgba) == want        # the product's own PAM writer (rs/src/pam.rs format)
 
 
+def _xswfbmp(width, height, palette, indices, level=6, strategy=0):
+    """An image/x-swf-bmp tag body (format 3) as the SWF parser hands it over: header, zlib(palette RGB + rows padded to 4)."""
+    import zlib
+    padded = width + ((4 - width % 4) % 4)
+    rows = np.zeros((height, padded), dtype=np.uint8)
+    rows[:, :width] = indices
+    co = zlib.compressobj(level, zlib.DEFLATED, 15, 8, strategy)
+    body = co.compress(bytes(np.asarray(palette, dtype=np.uint8).tobytes()) + rows.tobytes()) + co.flush()
+    return bytes([3, width & 255, width >> 8, height & 255, height >> 8, len(palette) - 1]) + body
+
+
+def test_bitmap_decoder_of_the_library_against_zlib_and_numpy():
+    """swfr_decode_x_swf_bmp (csrc/bitmap_decode.cpp: its own inflater) on stored, fixed-Huffman and dynamic-Huffman streams of random
+    and of compressible images, ragged widths (row padding), a full and a short palette (indices past it are opaque black)."""
+    import zlib
+    rng = np.random.default_rng(7)
+    cases = 0
+    for (w, h, ncol) in [(1, 1, 1), (3, 5, 2), (139, 208, 256), (64, 64, 17), (257, 3, 255), (5, 300, 4)]:
+        for level, strategy in [(0, 0), (1, zlib.Z_FIXED), (6, 0), (9, zlib.Z_FILTERED)]:
+            pal = rng.integers(0, 256, (ncol, 3), dtype=np.uint8)
+            idx = rng.integers(0, 256 if ncol < 200 else ncol, (h, w), dtype=np.uint8)
+            if level == 9:
+                idx = np.repeat(np.repeat(idx[:(h + 7) // 8, :(w + 7) // 8], 8, axis=0), 8, axis=1)[:h, :w]      # long matches, far back
+            gw, gh, rgba = api.decode_x_swf_bmp(_xswfbmp(w, h, pal, idx, level, strategy))
+            want = np.zeros((h, w, 4), dtype=np.uint8)
+            want[..., 3] = 255
+            ok = idx < ncol
+            want[ok, :3] = pal[idx[ok]]
+            assert (gw, gh) == (w, h) and rgba == want.tobytes(), (w, h, ncol, level)
+            cases += 1
+    assert cases == 24
+
+
+def test_bitmap_tag_errors_like_the_reference():
+    """Another format id: UnsupportedXSwfBmpFormatId (decode-x-swf-bmp.ts:12-14); another media type: NotImplemented
+    (node-canvas-bitmap-service.ts:34-35); a damaged stream is refused, never decoded into something else."""
+    good = _xswfbmp(4, 4, [[1, 2, 3]], np.zeros((4, 4), dtype=np.uint8))
+    with pytest.raises(S.SwfrError) as e:
+        api.decode_x_swf_bmp(bytes([5]) + good[1:])
+    assert e.value.code == api.ERR_NOT_IMPLEMENTED
+    for bad in (good[:-3], good[:8] + bytes([good[8] ^ 0x55]) + good[9:], good[:6]):
+        with pytest.raises(S.SwfrError) as e:
+            api.decode_x_swf_bmp(bad)
+        assert e.value.code == api.ERR_INVALID
+    r = S.Renderer(8, 8, device=api.DEVICE_HOST_ONLY)
+    try:
+        with pytest.raises(S.SwfrError) as e:
+            r.add_bitmap({"id": 1, "media_type": "image/jpeg", "data": good})
+        assert e.value.code == api.ERR_NOT_IMPLEMENTED and "NotImplemented: Support for image/jpeg images" in str(e.value)
+        with pytest.raises(S.SwfrError) as e:
+            r.add_bitmap({"id": 1, "media_type": "image/x-swf-bmp", "data": bytes([7]) + good[1:]})
+        assert e.value.code == api.ERR_NOT_IMPLEMENTED and "UnsupportedXSwfBmpFormatId: 7" in str(e.value)
+        r.add_bitmap({"id": 1, "media_type": "image/x-swf-bmp", "data": good})          # (a host-only handle keeps the dimensions)
+    finally:
+        r.close()
+
+
 class _Tap(ob.OracleBackend):
     """Oracle backend that records the polygon of every fill()/stroke()."""
 
