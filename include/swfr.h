@@ -306,6 +306,14 @@ int  swfr_copy_band_slab(swfr_renderer *r, void *device_dst);
    reports the kernels' error state like swfr_render_resident does. */
 int  swfr_set_targets(swfr_renderer *r, void *const *device_targets, uint32_t n_targets);
 int  swfr_render_resident_async(swfr_renderer *r, uint32_t *out_set);
+/* The same, with THIS frame's pixels going to block_target: a device buffer that holds only the handle's own block of tile-rows
+   (a handle with SWFR_FLAG_BANDS_CONTIGUOUS: rows_of_the_block * width * 4 bytes, the block's first pixel row first).  Any number of
+   such buffers may be in flight -- they are not tied to the handle's frame sets -- which is what an exchange of SEVERAL frames at once
+   needs (frame f assembled on rank f mod N, the N frames' blocks sent in one grouped all-to-all: DESIGN.md, multi-GPU). */
+int  swfr_render_resident_async_to(swfr_renderer *r, void *block_target, uint32_t *out_set);
+/* n_frames such frames (<= 64), one per block target, queued in one call; *sets_used: bit k set when frame set k's stream carries
+   one of them (the caller orders its exchange behind exactly those streams). */
+int  swfr_render_resident_group_to(swfr_renderer *r, void *const *block_targets, uint32_t n_frames, uint32_t *sets_used);
 void *swfr_stream_handle(swfr_renderer *r, uint32_t set);
 int  swfr_wait(swfr_renderer *r);
 

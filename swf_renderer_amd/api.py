@@ -30,7 +30,7 @@ EXPORTS = [
     "swfr_band_slab_bytes", "swfr_copy_band_slab", "swfr_device_framebuffer", "swfr_debug_copy", "swfr_last_path_timing", "swfr_get_stats",
     "swfr_render_sequence", "swfr_set_targets", "swfr_render_resident_async", "swfr_stream_handle", "swfr_wait",
     "swfr_render_resident_batched", "swfr_read_image_async", "swfr_read_image_wait", "swfr_render_sequence_readback",
-    "swfr_register_bitmap_tag", "swfr_decode_x_swf_bmp",
+    "swfr_register_bitmap_tag", "swfr_decode_x_swf_bmp", "swfr_render_resident_async_to", "swfr_render_resident_group_to",
 ]
 
 
@@ -215,6 +215,10 @@ def load_library():
     L.swfr_set_targets.argtypes = [P, C.POINTER(C.c_void_p), U]
     L.swfr_render_resident_async.restype = I
     L.swfr_render_resident_async.argtypes = [P, C.POINTER(U)]
+    L.swfr_render_resident_async_to.restype = I
+    L.swfr_render_resident_async_to.argtypes = [P, P, C.POINTER(U)]
+    L.swfr_render_resident_group_to.restype = I
+    L.swfr_render_resident_group_to.argtypes = [P, P, U, C.POINTER(U)]
     L.swfr_stream_handle.restype = P
     L.swfr_stream_handle.argtypes = [P, U]
     L.swfr_wait.restype = I
@@ -619,6 +623,21 @@ class Renderer:
         k = C.c_uint32()
         self._check(self.L.swfr_render_resident_async(self.h, C.byref(k)))
         return int(k.value)
+
+    def render_resident_async_to(self, block_ptr: int) -> int:
+        """Queues one frame whose pixels go to the device buffer at block_ptr -- this handle's block of tile-rows only (contiguous
+        bands); returns the frame set (stream) it runs on."""
+        k = C.c_uint32()
+        self._check(self.L.swfr_render_resident_async_to(self.h, C.c_void_p(block_ptr), C.byref(k)))
+        return int(k.value)
+
+    def render_resident_group_to(self, block_ptrs) -> int:
+        """Queues len(block_ptrs) frames, frame i into the block buffer at block_ptrs[i], in one call below Python; returns the bit
+        mask of the frame sets (streams) that carry them."""
+        arr = (C.c_void_p * len(block_ptrs))(*[C.c_void_p(p) for p in block_ptrs])
+        used = C.c_uint32()
+        self._check(self.L.swfr_render_resident_group_to(self.h, arr, len(block_ptrs), C.byref(used)))
+        return int(used.value)
 
     def stream_handle(self, frame_set: int) -> int:
         return int(self.L.swfr_stream_handle(self.h, frame_set) or 0)

@@ -1245,7 +1245,7 @@ __device__ __forceinline__ void blend8(uint32_t (&px)[8], const uint32_t (&al)[8
 }
 
 template <int SHADERS>
-__device__ __forceinline__ void tiles3_body(FramePtr FR) {
+__device__ __forceinline__ void tiles3_body(FramePtr FR, uint32_t* fb_to) {
     __shared__ __attribute__((aligned(16))) int acc[STRIP_H][T3_ACC_STRIDE];     // per pixel: covered height << 20 | uncovered area (20 bits, signed)
     __shared__ __attribute__((aligned(16))) uint32_t ent[T3_LIST][12];         // BandEntry2 as dwords, [8] = its class byte for this strip
     __shared__ __attribute__((aligned(16))) uint32_t hdr[T3_LIST][2 * STRIP_H]; // the strip's eight RowInfo2 of a partial tor entry
@@ -1517,12 +1517,13 @@ __device__ __forceinline__ void tiles3_body(FramePtr FR) {
             px[j] = __builtin_amdgcn_perm(p, p, 0x03000102u);          // bytes 0 and 2 swapped
 #endif
         }
-        const bool vec_ok = (width & 3) == 0 && ((uintptr_t)FR->fb & 15u) == 0u;      // (wave-uniform) every row of the frame starts 16-byte aligned
+        uint32_t* const fbp = fb_to ? fb_to : FR->fb;                     // (wave-uniform) this frame's own target, or the descriptor's
+        const bool vec_ok = (width & 3) == 0 && ((uintptr_t)fbp & 15u) == 0u;      // (wave-uniform) every row of the frame starts 16-byte aligned
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int y = cy0 + 4 * h;
             if (y >= height) continue;
-            uint32_t* rowp = FR->fb + (size_t)y * (size_t)width + cx0;
+            uint32_t* rowp = fbp + (size_t)y * (size_t)width + cx0;
             if (vec_ok && cx0 + 4 <= width) *reinterpret_cast<uint4*>(rowp) = make_uint4(px[4 * h], px[4 * h + 1], px[4 * h + 2], px[4 * h + 3]);
             else {
 #pragma unroll
@@ -1540,12 +1541,12 @@ __device__ __forceinline__ void tiles3_body(FramePtr FR) {
 #endif
 // (two entry points per kernel: one frame, its descriptor passed by value -- the fields arrive with the kernel arguments, no memory
 //  round trip -- and a batch of frames, blockIdx.y indexing an array of descriptors in device memory)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(T2_WAVES))) void k2_tiles_solid_b(const Frame2* __restrict__ frames) { tiles3_body<0>(FRAME_PTR(frames, blockIdx.y)); }
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(T2_WAVES))) void k2_tiles_solid_b(const Frame2* __restrict__ frames, uint32_t* fb_to) { tiles3_body<0>(FRAME_PTR(frames, blockIdx.y), fb_to); }
 #ifndef T2_WAVES_SHADED
 #define T2_WAVES_SHADED 4              // the samplers wait for texels: four wavefronts per SIMD (128 VGPRs) rather than the three 137 would allow
 #endif
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(T2_WAVES_SHADED))) void k2_tiles_bitmap_b(const Frame2* __restrict__ frames) { tiles3_body<1>(FRAME_PTR(frames, blockIdx.y)); }
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(T2_WAVES_SHADED))) void k2_tiles_shaded_b(const Frame2* __restrict__ frames) { tiles3_body<2>(FRAME_PTR(frames, blockIdx.y)); }
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(T2_WAVES_SHADED))) void k2_tiles_bitmap_b(const Frame2* __restrict__ frames, uint32_t* fb_to) { tiles3_body<1>(FRAME_PTR(frames, blockIdx.y), fb_to); }
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(T2_WAVES_SHADED))) void k2_tiles_shaded_b(const Frame2* __restrict__ frames, uint32_t* fb_to) { tiles3_body<2>(FRAME_PTR(frames, blockIdx.y), fb_to); }
 
 // ---------------------------------------------------------------------------------------------
 // launchers: `frames` is a device array of n_frames descriptors, blockIdx.y picks one
@@ -1568,12 +1569,13 @@ void launch2_rows_slow(hipStream_t st, const Frame2* frames, uint32_t n_frames, 
         if (pass + 1 >= max_passes) break;
     }
 }
-void launch2_tiles(hipStream_t st, const Frame2* frames, uint32_t n_frames, uint32_t max_strips, uint32_t grid_cap, int shader_level) {
+// fb_to: where THIS launch's pixels go instead of the descriptors' framebuffer (one frame per launch only), or nullptr
+void launch2_tiles(hipStream_t st, const Frame2* frames, uint32_t n_frames, uint32_t max_strips, uint32_t grid_cap, int shader_level, uint32_t* fb_to) {
     if (!max_strips) return;
     const uint32_t g = max_strips < grid_cap ? max_strips : grid_cap;
-    if (shader_level >= 2) hipLaunchKernelGGL(k2_tiles_shaded_b, dim3(g, n_frames), dim3(64), 0, st, frames);
-    else if (shader_level == 1) hipLaunchKernelGGL(k2_tiles_bitmap_b, dim3(g, n_frames), dim3(64), 0, st, frames);
-    else hipLaunchKernelGGL(k2_tiles_solid_b, dim3(g, n_frames), dim3(64), 0, st, frames);
+    if (shader_level >= 2) hipLaunchKernelGGL(k2_tiles_shaded_b, dim3(g, n_frames), dim3(64), 0, st, frames, fb_to);
+    else if (shader_level == 1) hipLaunchKernelGGL(k2_tiles_bitmap_b, dim3(g, n_frames), dim3(64), 0, st, frames, fb_to);
+    else hipLaunchKernelGGL(k2_tiles_solid_b, dim3(g, n_frames), dim3(64), 0, st, frames, fb_to);
 }
 
 }  // namespace swfr

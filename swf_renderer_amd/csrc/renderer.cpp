@@ -28,7 +28,7 @@ namespace swfr {
 void launch2_bin(hipStream_t, const Frame2*, uint32_t, uint32_t, uint32_t);
 void launch2_rows(hipStream_t, const Frame2*, uint32_t, uint32_t, uint32_t);
 void launch2_rows_slow(hipStream_t, const Frame2*, uint32_t, uint32_t, uint32_t, uint32_t);
-void launch2_tiles(hipStream_t, const Frame2*, uint32_t, uint32_t, uint32_t, int);
+void launch2_tiles(hipStream_t, const Frame2*, uint32_t, uint32_t, uint32_t, int, uint32_t*);
 void launch_unpremultiply(hipStream_t, const uint32_t*, uint32_t*, size_t);
 void launch_pack_band(hipStream_t, const uint32_t*, uint32_t*, int, int, uint32_t, uint32_t, uint32_t);
 }  // namespace swfr
@@ -857,9 +857,8 @@ void launch_frame(swfr_renderer* r, const swfr_renderer::Scene& sc, swfr_rendere
         if (sc.n_chunks && sc.slow_state != 1) launch2_rows_slow(st, fh, 1, 1024u, sc.slow_state == 2 ? 0u : 256u, sc.slow_passes);
         if (e) HIP_CHECK(hipEventRecord(e[2], st));
         const uint32_t grid = r->tiles_grid > 0 ? uint32_t(r->tiles_grid) : ~0u;
-        launch2_tiles(st, fh, 1, uint32_t(sc.n_strip_slots), grid, sc.shader_level);
+        launch2_tiles(st, fh, 1, uint32_t(sc.n_strip_slots), grid, sc.shader_level, fb);      // (fb: this frame's own target, else the descriptor's)
         if (e) HIP_CHECK(hipEventRecord(e[3], st));
-        (void)fb;                                            // (the descriptor carries the framebuffer's address)
     }
 }
 
@@ -981,7 +980,7 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
             launch2_bin(st, fh, cnt, uint32_t(std::max(sc.n_edges, sc.n_paths)), uint32_t(sc.n_bands));
             launch2_rows(st, fh, cnt, uint32_t(sc.n_chunks), sc.max_path_edges);
             if (sc.n_chunks && sc.slow_state != 1) launch2_rows_slow(st, fh, cnt, 1024u, sc.slow_state == 2 ? 0u : 256u, sc.slow_passes);
-            launch2_tiles(st, fh, cnt, uint32_t(sc.n_strip_slots), r->tiles_grid > 0 ? uint32_t(r->tiles_grid) : ~0u, sc.shader_level);
+            launch2_tiles(st, fh, cnt, uint32_t(sc.n_strip_slots), r->tiles_grid > 0 ? uint32_t(r->tiles_grid) : ~0u, sc.shader_level, nullptr);
             last_set = g * rb + cnt - 1;
         }
     }
@@ -989,7 +988,7 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
         swfr_renderer::FrameSet& F = r->fs[f % n_sets];
         const bool timed = f >= first_timed && (f - first_timed) % stride == 0;   // per-kernel events on every stride-th frame (each costs a queue packet)
         if (!timed && frames > 1 && r->use_graphs && sc.slow_verified) launch_frame_graph(r, sc, F);
-        else launch_frame(r, sc, F, F.d_fb.ptr, timed ? &r->ev[size_t((f - first_timed) / stride) * 4] : nullptr);
+        else launch_frame(r, sc, F, nullptr, timed ? &r->ev[size_t((f - first_timed) / stride) * 4] : nullptr);
     }
     for (uint32_t k = 1; k < n_sets; ++k) {
         HIP_CHECK(hipEventRecord(ev_join[k - 1], r->fs[k].stream));
@@ -1183,7 +1182,7 @@ int render_batch2(swfr_renderer* r, const swfr_stage* stages, uint32_t n, void* 
         launch2_bin(G.stream, frames_dev, cnt, uint32_t(max_ep), uint32_t(max_bands));
         launch2_rows(G.stream, frames_dev, cnt, uint32_t(max_chunks), max_pe);
         if (max_chunks) launch2_rows_slow(G.stream, frames_dev, cnt, 256u, 64u, SLOW_PASSES);
-        launch2_tiles(G.stream, frames_dev, cnt, uint32_t(max_strips), ~0u, shader_level);
+        launch2_tiles(G.stream, frames_dev, cnt, uint32_t(max_strips), ~0u, shader_level, nullptr);
         HIP_CHECK(hipEventRecord(G.ev_end, G.stream));
         for (uint32_t k = 0; k < cnt; ++k)
             HIP_CHECK(hipMemcpyAsync(G.h_counters + size_t(k) * COUNTER_WORDS, fr[k].counters, COUNTER_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, G.stream));
@@ -1256,7 +1255,7 @@ int render_resident_batched(swfr_renderer* r, uint32_t per_launch, uint32_t laun
         launch2_bin(st, r->rb_frames.ptr, B, uint32_t(std::max(sc.n_edges, sc.n_paths)), uint32_t(sc.n_bands));
         launch2_rows(st, r->rb_frames.ptr, B, uint32_t(sc.n_chunks), sc.max_path_edges);
         if (sc.n_chunks && sc.slow_state != 1) launch2_rows_slow(st, r->rb_frames.ptr, B, 256u, sc.slow_state == 2 ? 0u : 64u, sc.slow_passes);
-        launch2_tiles(st, r->rb_frames.ptr, B, uint32_t(sc.n_strip_slots), ~0u, sc.shader_level);
+        launch2_tiles(st, r->rb_frames.ptr, B, uint32_t(sc.n_strip_slots), ~0u, sc.shader_level, nullptr);
     };
     one_launch();                                              // warm-up: leaves a cost history for the strip order
     HIP_CHECK(hipEventRecord(r->rb_ev[0], st));
@@ -1310,7 +1309,7 @@ int render_batch(swfr_renderer* r, const swfr_stage* stages, uint32_t n, void* d
             swfr_renderer::FrameSet& F = r->fs[k];
             if (k > 0 && i < n_sets) HIP_CHECK(hipStreamSynchronize(r->stream));   // first use of the set: bitmap table etc. are in place
             uint32_t* fb = device_dst ? reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(device_dst) + size_t(i) * frame_stride) : F.d_fb.ptr;
-            launch_frame(r, r->scn[k], F, fb, nullptr);
+            launch_frame(r, r->scn[k], F, nullptr, nullptr);     // (the descriptor carries fb)
             HIP_CHECK(hipMemcpyAsync(hc + size_t(i) * COUNTER_WORDS, F.counters, COUNTER_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, F.stream));
             r->fb_cur = fb;
         }
@@ -1729,6 +1728,43 @@ int swfr_render_resident_async(swfr_renderer* r, uint32_t* out_set) {
         if (out_set) *out_set = k;
         return int(SWFR_OK);
     });
+}
+
+int swfr_render_resident_async_to(swfr_renderer* r, void* block_target, uint32_t* out_set) {
+    if (!r || !block_target) return SWFR_ERR_INVALID;
+    if (!r->has_device) return fail(r, SWFR_ERR_NO_DEVICE, "host-only handle cannot rasterize");
+    if (!r->scene_ready) return fail(r, SWFR_ERR_INVALID, "no scene uploaded");
+    const BandShare bs = band_share(r);
+    if (bs.stride != 1) return fail(r, SWFR_ERR_INVALID, "a block target needs a handle that owns one contiguous block of tile-rows");
+    return guarded(r, [&]() {
+        uint32_t n_sets = 1;
+        while (n_sets < uint32_t(std::min(r->in_flight, 4)) && n_sets < r->sets_ready && r->fs[n_sets].stream && r->fs[n_sets].d_cells.ptr) ++n_sets;
+        const uint32_t k = r->async_next++ % n_sets;
+        r->async_used |= 1u << k;
+        swfr_renderer::FrameSet& F = r->fs[k];
+        if (!r->scn[0].slow_verified) { r->scn[0].slow_state = 0; r->scn[0].slow_passes = SLOW_PASSES; }
+        // row y of the frame is row y - (first tile-row) * 16 of the block: the kernels address the frame, so they get the block's
+        // address moved up by the rows above it (only the handle's own rows are ever written)
+        uint32_t* fb = static_cast<uint32_t*>(block_target) - size_t(bs.first) * TILE_H * r->width;
+        launch_frame(r, r->scn[0], F, fb, nullptr);
+        HIP_CHECK(hipGetLastError());
+        r->fb_cur = nullptr; r->fb_valid = false;              // (the frame is the caller's: nothing to read back from the handle)
+        if (out_set) *out_set = k;
+        return int(SWFR_OK);
+    });
+}
+
+int swfr_render_resident_group_to(swfr_renderer* r, void* const* block_targets, uint32_t n_frames, uint32_t* sets_used) {
+    if (!r || !block_targets || n_frames == 0 || n_frames > 64) return SWFR_ERR_INVALID;
+    uint32_t used = 0;
+    for (uint32_t i = 0; i < n_frames; ++i) {
+        uint32_t k = 0;
+        const int rc = swfr_render_resident_async_to(r, block_targets[i], &k);
+        if (rc != SWFR_OK) return rc;
+        used |= 1u << k;
+    }
+    if (sets_used) *sets_used = used;
+    return SWFR_OK;
 }
 
 int swfr_get_stats(swfr_renderer* r, swfr_stats* out) {

@@ -208,3 +208,90 @@ class FramePipeline:
         if self.streams:
             torch.cuda.synchronize()
         return self.last
+
+
+class RotatingPipeline:
+    """N>1 step with an assembly that is NOT bound by one rank's inbound links: frame f is assembled on rank f mod N.
+
+    FramePipeline lands every frame on one root, whose inbound xGMI links then carry the whole frame whatever the other ranks do
+    (multi-GPU).  Here N consecutive frames form a group: every rank renders its block of tile-rows of each of them into
+    `send[g][j]` -- a buffer of the block alone (`swfr_render_resident_group_to`: one call below Python queues the whole group) --
+    and ONE all-to-all per group moves block (frame j, rows of rank q) from rank q to rank j, where it lands at its final place in
+    that rank's image: every rank sends N - 1 blocks and receives N - 1 at once, all links of all ranks busy in both directions.
+    The consumer of a frame (an encoder, a presenter) sits on the rank that assembled it.  Two groups are kept in flight: the
+    exchange of group g overlaps the rasterization of group g + 1; a group's buffers are rendered into again only behind the event
+    of the exchange that read them (on the device: no host wait in step()).
+    """
+
+    def __init__(self, renderer, width, height, rank, world, device="cuda", frames_device="cuda", groups=2):
+        import torch
+        self.r, self.w, self.h, self.rank, self.world = renderer, width, height, rank, world
+        self.on_gpu = device != "cpu"                                # where the collective runs (RCCL on device tensors, gloo on CPU ones)
+        self.streams = frames_device != "cpu"                        # False only under tools/emu, whose "device" memory is host memory
+        self.rows = block_rows(height, world) * TILE_H               # pixel rows per rank (padded: the last block may reach past the frame)
+        self.hp = self.rows * world
+        self.G = groups
+        # non-assembling buffers hold the rank's block only: N blocks per group (one per frame of the group)
+        self.send = [torch.zeros((world, self.rows, width, 4), dtype=torch.uint8, device=frames_device) for _ in range(groups)]
+        self.image = [torch.zeros((world, self.rows, width, 4), dtype=torch.uint8, device=device) for _ in range(groups)]   # [rank q's rows] = the padded frame
+        self.cpu_send = None if (self.on_gpu or not self.streams) else [torch.zeros((world, self.rows, width, 4), dtype=torch.uint8) for _ in range(groups)]
+        self.events = [None] * groups
+        self.ext = {}
+        self.n_groups = 0
+        self.assembled = []                                          # (frame number, image view) this rank has assembled, newest last (at most `groups` are still intact)
+
+    def upload(self, edges, paths, styles):
+        self.r.upload_edges(edges, paths, styles)
+        self.r.render_resident(1)                                    # one blocking frame: the handle learns which queued-row kernels this scene needs
+
+    def _stream(self, k):
+        import torch
+        if k not in self.ext:
+            self.ext[k] = torch.cuda.ExternalStream(self.r.stream_handle(k))
+        return self.ext[k]
+
+    def step_group(self, n_frames=None):
+        """Queues the next N frames (one per rank to assemble) and their exchange; returns this rank's assembled frame of the group
+        (a view: valid on the device once the exchange has run -- after finish(), or for work queued on torch's current stream).
+        n_frames < N: a last, partial group -- only the frames for ranks 0 .. n_frames - 1 are rendered (the exchange still runs whole;
+        the other ranks' images of this group are not new frames and None is returned there)."""
+        import torch
+        import torch.distributed as dist
+        n_frames = self.world if n_frames is None else int(n_frames)
+        gi = self.n_groups
+        g = gi % self.G
+        self.n_groups = gi + 1
+        if self.streams and self.events[g] is not None:
+            for k in range(4):                                       # the handle's streams: behind the exchange that last read this group's buffers
+                if self.r.stream_handle(k):
+                    self._stream(k).wait_event(self.events[g])
+        used = self.r.render_resident_group_to([self.send[g][j].data_ptr() for j in range(n_frames)])
+        if self.streams:
+            cur = torch.cuda.current_stream()
+            for k in range(4):
+                if (used >> k) & 1:
+                    cur.wait_stream(self._stream(k))                 # torch's stream: behind the group's kernels
+        else:
+            self.r.wait()
+        src = self.send[g]
+        if not self.on_gpu and self.streams:                         # gloo rehearsal on a GPU box: the collective runs on CPU tensors
+            self.cpu_send[g].copy_(src)
+            src = self.cpu_send[g]
+        dist.all_to_all_single(self.image[g], src)                   # block (frame j, my rows) -> rank j; lands as rows of rank q in image[g]
+        if self.on_gpu:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.events[g] = ev
+        if self.rank >= n_frames:
+            return None
+        out = self.image[g].view(self.hp, self.w, 4)[: self.h]
+        self.assembled.append((gi * self.world + self.rank, out))
+        self.assembled = self.assembled[-self.G:]
+        return out
+
+    def finish(self):
+        import torch
+        self.r.wait()
+        if self.streams:
+            torch.cuda.synchronize()
+        return self.assembled[-1][1] if self.assembled else None

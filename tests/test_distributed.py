@@ -58,6 +58,26 @@ def test_gloo_world2_frame_pipeline_renders_blocks_and_gathers_in_place():
     assert "DIST_OK" in outs[0] and "stroke_curves 3 (0, 0)" in outs[0]
 
 
+def test_gloo_world2_rotating_assembly_every_frame_on_its_rank_vs_oracle():
+    """The assembly that is not bound by one rank's inbound links (RotatingPipeline): frame f is assembled on rank f mod 2, each
+    rank renders only block buffers (swfr_render_resident_group_to: one call per group of N frames), ONE all-to-all per group over
+    gloo moves the blocks into place; three groups over two group buffers, the product's kernels under the emulator; every rank
+    compares every frame it assembled with the oracle."""
+    import shutil
+    if shutil.which("g++") is None:
+        import pytest
+        pytest.skip("the emulator build needs g++")
+    sys.path.insert(0, os.path.join(ROOT, "tools", "emu"))
+    import build as emu_build
+    emu_build.build()
+    procs, outs = _spawn(os.path.join(ROOT, "tools", "emu", "dist_rotate_check.py"), 2, 900, ("stroke_curves",))
+    assert all(p.returncode == 0 for p in procs), outs
+    for rk in (0, 1):
+        assert "ROTATE_OK" in outs[rk]
+        for f in (rk, rk + 2, rk + 4):
+            assert "rank %d stroke_curves frame %d (0, 0)" % (rk, f) in outs[rk], outs[rk]
+
+
 def test_gloo_world2_gather_assembles_frame(tmp_path):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     script = tmp_path / "worker.py"
