@@ -1014,25 +1014,41 @@ struct BilinearTap {
     uint32_t o[2][2];                    // [x][y]: texel index in the bitmap (32-bit offsets from the bitmap's base: half the registers of pointers)
     uint32_t wf;                         // weights and the outside flags in one register: wx | wy << 7 | oxa << 14 | oxb << 15 | oya << 16 | oyb << 17
 };
-__device__ __forceinline__ void bilinear_taps(const DevFilter& flt, int px, int py, BilinearTap& t) {
+// x mod n in [0, n) for n > 0: a reciprocal estimate with an integer fix-up wherever the quotient is exact in single precision
+// (|x| < 2^22: every 16.16 position pixman can represent), the integer remainder -- some forty instructions -- only beyond
+__device__ __forceinline__ int wrap_mod(int x, int n, float inv_n) {
+    if ((unsigned)(x + (1 << 22)) < (1u << 23)) {
+        const int q = (int)floorf((float)x * inv_n);
+        int r = x - mul_i24(q, n);
+        if (r < 0) r += n;
+        if (r >= n) r -= n;
+        return r;
+    }
+    const int r = x % n;
+    return r < 0 ? r + n : r;
+}
+// bxp, byp: pixman's 16.16 sample position of the pixel centre, half a texel back (64-bit sums; the caller steps them along a row:
+// whole multiples of the matrix entries, so every position is the exact sum)
+__device__ __forceinline__ void bilinear_taps_at(const DevFilter& flt, long long bxp, long long byp, BilinearTap& t) {
     const bool repeat = flt.extend == 1;
-    const struct { const uint32_t* pixels; uint32_t width, height; } bm = {flt.pixels, flt.width, flt.height};
-    const long long bxp = flt.base_x + (long long)px * flt.m00 + (long long)py * flt.m01 - 0x8000;     // pixman's 16.16 sample position, half a texel back
-    const long long byp = flt.base_y + (long long)px * flt.m10 + (long long)py * flt.m11 - 0x8000;
-    const int bw = (int)bm.width, bh = (int)bm.height;
+    const int bw = (int)flt.width, bh = (int)flt.height;
     const int x0 = (int)(bxp >> 16), y0 = (int)(byp >> 16);
-    uint32_t wf = (uint32_t)((bxp >> 9) & 0x7f) | ((uint32_t)((byp >> 9) & 0x7f) << 7);
+    uint32_t wf = ((uint32_t)bxp >> 9 & 0x7fu) | (((uint32_t)byp >> 9 & 0x7fu) << 7);
     int xa = x0, xb = x0 + 1, ya = y0, yb = y0 + 1;
     if (repeat) {
-        xa = ((xa % bw) + bw) % bw; xb = xa + 1 == bw ? 0 : xa + 1;
-        ya = ((ya % bh) + bh) % bh; yb = ya + 1 == bh ? 0 : ya + 1;
+        xa = wrap_mod(xa, bw, 1.0f / (float)bw); xb = xa + 1 == bw ? 0 : xa + 1;
+        ya = wrap_mod(ya, bh, 1.0f / (float)bh); yb = ya + 1 == bh ? 0 : ya + 1;
     } else {
         wf |= (xa < 0 || xa >= bw ? 1u << 14 : 0u) | (xb < 0 || xb >= bw ? 1u << 15 : 0u) | (ya < 0 || ya >= bh ? 1u << 16 : 0u) | (yb < 0 || yb >= bh ? 1u << 17 : 0u);
         xa = min(max(xa, 0), bw - 1); xb = min(max(xb, 0), bw - 1); ya = min(max(ya, 0), bh - 1); yb = min(max(yb, 0), bh - 1);
     }
-    const uint32_t rowa = (uint32_t)ya * bm.width, rowb = (uint32_t)yb * bm.width;     // (a bitmap has fewer than 2^32 texels)
+    const uint32_t rowa = (uint32_t)ya * flt.width, rowb = (uint32_t)yb * flt.width;     // (a bitmap has fewer than 2^32 texels)
     t.o[0][0] = rowa + (uint32_t)xa; t.o[1][0] = rowa + (uint32_t)xb; t.o[0][1] = rowb + (uint32_t)xa; t.o[1][1] = rowb + (uint32_t)xb;
     t.wf = wf;
+}
+__device__ __forceinline__ void bilinear_taps(const DevFilter& flt, int px, int py, BilinearTap& t) {
+    bilinear_taps_at(flt, flt.base_x + (long long)px * flt.m00 + (long long)py * flt.m01 - 0x8000,
+                     flt.base_y + (long long)px * flt.m10 + (long long)py * flt.m11 - 0x8000, t);
 }
 __device__ __forceinline__ uint32_t bilinear_mix(const BilinearTap& t, const uint32_t* q00, const uint32_t* q10, const uint32_t* q01, const uint32_t* q11) {
     uint32_t c00 = *q00, c10 = *q10, c01 = *q01, c11 = *q11;
@@ -1220,8 +1236,33 @@ __device__ __forceinline__ void blend8(uint32_t (&px)[8], const uint32_t (&al)[8
             if (!(__ballot((al[4 * h] | al[4 * h + 1] | al[4 * h + 2] | al[4 * h + 3]) != 0u))) continue;       // wave-uniform: nothing to paint in these rows
             BilinearTap t[4];
             uint32_t c[4][4];
+            // Every sample of the wavefront strictly inside the bitmap -- the usual strip -- needs no clamping, no wrap and no outside
+            // flags: the four texels are o, o + 1, o + width, o + width + 1.  Anything else takes the general routine.
+            {
+                const int bw1 = (int)flt.width - 1, bh1 = (int)flt.height - 1;
+                bool inside = flt.width < (1u << 23) && flt.height < (1u << 23);
+                int x0s[4], y0s[4]; uint32_t wfs[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) bilinear_taps(flt, tx0 + 16 * i + cgl, cy0 + 4 * h, t[i]);
+                for (int i = 0; i < 4; ++i) {
+                    const int px_ = tx0 + 16 * i + cgl, py_ = cy0 + 4 * h;
+                    const long long bxp = flt.base_x + (long long)px_ * flt.m00 + (long long)py_ * flt.m01 - 0x8000;
+                    const long long byp = flt.base_y + (long long)px_ * flt.m10 + (long long)py_ * flt.m11 - 0x8000;
+                    x0s[i] = (int)(bxp >> 16); y0s[i] = (int)(byp >> 16);
+                    wfs[i] = ((uint32_t)bxp >> 9 & 0x7fu) | (((uint32_t)byp >> 9 & 0x7fu) << 7);
+                    inside = inside && (unsigned)x0s[i] < (unsigned)bw1 && (unsigned)y0s[i] < (unsigned)bh1;
+                }
+                if (__ballot(!inside) == 0ull) {                   // wave-uniform
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const uint32_t o = __umul24((uint32_t)y0s[i], flt.width) + (uint32_t)x0s[i];
+                        t[i].o[0][0] = o; t[i].o[1][0] = o + 1u; t[i].o[0][1] = o + flt.width; t[i].o[1][1] = o + flt.width + 1u;
+                        t[i].wf = wfs[i];
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) bilinear_taps(flt, tx0 + 16 * i + cgl, cy0 + 4 * h, t[i]);
+                }
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) { c[i][0] = texels[t[i].o[0][0]]; c[i][1] = texels[t[i].o[1][0]]; c[i][2] = texels[t[i].o[0][1]]; c[i][3] = texels[t[i].o[1][1]]; }
 #pragma unroll
@@ -1230,6 +1271,14 @@ __device__ __forceinline__ void blend8(uint32_t (&px)[8], const uint32_t (&al)[8
             const uint4 mine = *reinterpret_cast<const uint4*>(tq + 4 * cgl);
             lds_barrier();                                        // (the next half / the next path rewrites the rows)
             const uint32_t col[4] = {mine.x, mine.y, mine.z, mine.w};
+            // the whole wavefront at coverage 255 with opaque texels (the inside of a bitmap-filled shape; SWF bitmaps are opaque away
+            // from a non-repeating bitmap's rim): MUL_UN8(c, 255) = c and OVER of an opaque source is the source -- no arithmetic
+            const bool plain = (al[4 * h] & al[4 * h + 1] & al[4 * h + 2] & al[4 * h + 3]) == 255u && (mine.x & mine.y & mine.z & mine.w) >> 24 == 255u;
+            if (__ballot(!plain) == 0ull) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) px[4 * h + i] = col[i];
+                continue;
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int j = 4 * h + i;
