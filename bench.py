@@ -95,21 +95,28 @@ def oracle_frame(fx, cols, W, H):
     return np.stack([(px >> 16) & 255, (px >> 8) & 255, px & 255, px >> 24], -1).astype(np.uint8)
 
 
-def latest_traffic():
-    """HBM bytes per launch of the tile kernel from the newest committed PMC profile (FETCH_SIZE / WRITE_SIZE passes,
-    gfx950 corrections: tools/profile_r02.py), with its source; (None, None) when there is none."""
+def latest_traffic(kernel=None):
+    """HBM bytes per launch from the newest committed PMC profile of the S1 bench (FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections:
+    tools/profile_r02.py), with its source: of `kernel` (a substring of its name), or -- kernel None -- of the whole frame (the sum
+    over the frame's kernels); (None, None) when there is none."""
     import glob
     import re
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_k_tiles.json"))):
-        if re.fullmatch(r"r\d+[a-z]_pmc_k_tiles\.json", os.path.basename(f)):      # (the S1 profiles, not the shaded-kernel ones)
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json"))):
+        if re.fullmatch(r"r\d+[a-z]_pmc_summary\.json", os.path.basename(f)):      # (the S1 profiles, not the shaded-kernel / batched ones)
             best = f
     if not best:
         return None, None
     try:
-        return json.load(open(best)).get("hbm_bytes_per_launch"), os.path.relpath(best, ROOT)
+        d = json.load(open(best))
+        if kernel is None:
+            return sum(int(v.get("hbm_bytes_per_launch", 0)) for k, v in d.items() if any(n in k for n in ("k2_bin_b", "k2_rows_b", "k2_tiles_solid_b"))), os.path.relpath(best, ROOT)
+        for k, v in d.items():
+            if kernel in k:
+                return v.get("hbm_bytes_per_launch"), os.path.relpath(best, ROOT)
     except Exception:
-        return None, None
+        pass
+    return None, None
 
 
 def latest_rocprof_kernel_us(kernel):
@@ -404,8 +411,16 @@ def main():
         nk = max(tk["timed_frames"], 1)
         bin_ms, rows_ms, tiles_ms = tk["setup_ms"] / nk, tk["rows_ms"] / nk, tk["tiles_ms"] / nk
         gbs = lambda nbytes, ms: nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        achieved = gbs(algo_bytes, tiles_ms)
-        traffic, traffic_src = latest_traffic() if (not bands and args.workload == "s1") else (None, None)
+        # the roofline's lead entry is the kernel with the LONGEST isolated duration (the frame is bounded by it), against the frame's
+        # algorithmic bytes; every kernel of the frame is listed beside it, and frame_frac prices the frame against the sum of them
+        kern = {"k2_bin": ("k2_bin_b", bin_ms), "k2_rows": ("k2_rows_b", rows_ms), "k2_tiles": ("k2_tiles_solid_b", tiles_ms)}
+        lead = max(("k2_rows", "k2_tiles"), key=lambda k: kern[k][1])
+        lead_sym, lead_ms = kern[lead]
+        achieved = gbs(algo_bytes, lead_ms)
+        single_s1 = not bands and args.workload == "s1"
+        traffic, traffic_src = latest_traffic(lead_sym) if single_s1 else (None, None)
+        frame_traffic, _ = latest_traffic(None) if single_s1 else (None, None)
+        sum_ms = bin_ms + rows_ms + tiles_ms
         line = {
             "metric": "Mpixels/sec rasterized @ 4K, 10k-edge synthetic shape set" if args.workload == "s1" else "Mpixels/sec rasterized @ 8K, 100k-edge synthetic shape set",
             # bands sharding: one frame over all ranks per step; frames sharding: a step is one frame on every rank (N frames)
@@ -417,7 +432,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong" if bands else "weak",
             "vs_baseline": None,
-            "dtype": "int64/u8",
+            "dtype": "i32+f64(exact integers)/u8",
             "data": "synthetic",
             "verified": verified,
             "config": {"workload": "%s: %dx%d, %d ten-vertex stars, opaque solid, nonzero, seed 0xC0FFEE" % (args.workload.upper(), W, H, len(fx)),
@@ -430,24 +445,31 @@ def main():
             "kernel_ms_per_frame": {"k2_bin": round(bin_ms, 4), "k2_rows": round(rows_ms, 4), "k2_tiles": round(tiles_ms, 4),
                                     "how": "HIP events on the kernels' stream, one frame in flight (each kernel alone on the GPU), %d frames; in the timed region "
                                            "%d frames overlap, so these add up to more than ms_per_step" % (nk, in_flight)},
-            "roofline": {"bound": "hbm", "kernel": "k2_tiles", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": lead, "kernel_why": "the kernel of the frame with the longest duration when it has the GPU to itself",
+                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": traffic, "traffic_source": ("committed profile %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench; not measured in this run)" % traffic_src) if traffic_src else None,
+                         "frame_traffic": frame_traffic,
                          "algorithmic_bytes_per_launch": algo_bytes,
-                         "kernel_ms": round(tiles_ms, 4), "kernel_ms_how": "one frame in flight, HIP events around the kernel on its own stream",
-                         # the co-dominant kernel and the whole step against the same roof
-                         "k2_rows": {"kernel_ms": round(rows_ms, 4), "achieved": round(gbs(algo_bytes, rows_ms), 2), "frac": round(gbs(algo_bytes, rows_ms) / HBM_PEAK_GBS, 5)},
+                         "kernel_ms": round(lead_ms, 4), "kernel_ms_how": "one frame in flight, HIP events around the kernel on its own stream",
+                         # every kernel of the frame against the same bytes, the sum of them, and the whole pipelined step
+                         "kernels": {k: {"kernel_ms": round(v[1], 4), "achieved": round(gbs(algo_bytes, v[1]), 2), "frac": round(gbs(algo_bytes, v[1]) / HBM_PEAK_GBS, 5)} for k, v in kern.items()},
+                         "frame_frac": round(gbs(algo_bytes, sum_ms) / HBM_PEAK_GBS, 5),
+                         "frame_frac_how": "algorithmic bytes / (k2_bin + k2_rows + k2_tiles durations, one frame in flight)",
                          "step_achieved": round(gbs(algo_bytes * (frames_total / args.steps), ms_per_step), 2),
                          "step_frac": round(gbs(algo_bytes * (frames_total / args.steps), ms_per_step) / HBM_PEAK_GBS, 5)},
         }
-        if not bands and args.workload == "s1":
-            rp_us, rp_src = latest_rocprof_kernel_us("k2_tiles_solid_b")
-            if rp_us:
-                # (the HIP events of this run bracket the kernel on its stream and so include the ~3 us between the end of k2_rows and the
-                #  start of k2_tiles; rocprofv3's kernel trace does not)
-                line["roofline"]["rocprofv3_committed"] = {"kernel_us": round(rp_us, 2), "achieved": round(gbs(algo_bytes, rp_us * 1e-3), 2),
-                                                           "frac": round(gbs(algo_bytes, rp_us * 1e-3) / HBM_PEAK_GBS, 5),
-                                                           "source": "%s (rocprofv3 --kernel-trace --stats of this bench, one frame in flight; not measured in this run)" % rp_src}
+        if single_s1:
+            committed = {}
+            for k, (sym, _) in kern.items():
+                rp_us, rp_src = latest_rocprof_kernel_us(sym)
+                if rp_us:
+                    # (the HIP events of this run bracket a kernel on its stream and so include the ~3 us between the end of the kernel before
+                    #  it and its own start; rocprofv3's kernel trace does not)
+                    committed[k] = {"kernel_us": round(rp_us, 2), "achieved": round(gbs(algo_bytes, rp_us * 1e-3), 2), "frac": round(gbs(algo_bytes, rp_us * 1e-3) / HBM_PEAK_GBS, 5)}
+                    committed["source"] = "%s (rocprofv3 --kernel-trace --stats of this bench, one frame in flight; not measured in this run)" % rp_src
+            if committed:
+                line["roofline"]["rocprofv3_committed"] = committed
         line.update(extra)
         if t1 is not None:
             line["roofline"]["one_frame_in_flight"] = {"k2_tiles_ms": round(tiles_ms, 4), "k2_rows_ms": round(rows_ms, 4), "k2_bin_ms": round(bin_ms, 4),

@@ -441,14 +441,16 @@ __global__ __launch_bounds__(64) R2_ATTR void k2_rows_b(const Frame2* __restrict
     FramePtr FR = FRAME_PTR(frames, blockIdx.y);
     if (blockIdx.x >= FR->n_chunks) return;
     TRACE(1);
-    rows3_chunk_body<ROWS_STAGE>(FR, blockIdx.x);
+    rows3_chunk_body<ROWS_STAGE, ROWS_FAST_N>(FR, blockIdx.x);
     TRACE(7);
     TRACE_OUT(1, blockIdx.x);
 }
-__global__ __launch_bounds__(64) R2_ATTR void k2_rows_wide_b(const Frame2* __restrict__ frames) {
+// (the instance for scenes with a path of more than ROWS_STAGE edges: 64 staged edges and SIXTEEN edge slots per row -- the rows of a
+//  stroke outline or of a shape with a hole inside a hole -- at two to three wavefronts per SIMD)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k2_rows_wide_b(const Frame2* __restrict__ frames) {
     FramePtr FR = FRAME_PTR(frames, blockIdx.y);
     if (blockIdx.x >= FR->n_chunks) return;
-    rows3_chunk_body<ROWS_STAGE_WIDE>(FR, blockIdx.x);
+    rows3_chunk_body<ROWS_STAGE_WIDE, ROWS_FAST_WIDE>(FR, blockIdx.x);
 }
 
 

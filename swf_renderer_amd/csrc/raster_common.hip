@@ -190,6 +190,7 @@ __device__ __forceinline__ FastEdge* fast_edges_of(DevEdge* edges, uint32_t n_ed
 #define CLS_BOX 8u                    // rectilinear path evaluated per pixel from its boxes
 
 #define ROWS_FAST_N 8            // active edges per row handled in registers by k2_rows
+#define ROWS_FAST_WIDE 16         // ... by its second instance (k2_rows_wide: scenes with a path of more than ROWS_STAGE edges)
 #define ROWS_BIG_MAXA 64         // capacity of the generic (LDS list) routine of k2_rows_slow
 #ifndef ROWS_STAGE
 #define ROWS_STAGE 32            // chunks with at most this many edges of their path in reach are staged into LDS (3 KB of 96-byte records:

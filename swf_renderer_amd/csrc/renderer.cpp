@@ -216,7 +216,7 @@ struct swfr_renderer {
     int force_chunk_rows = 0;               // SWFR_CHUNK_ROWS: test knob
     int strip_order = 1;                    // SWFR_STRIP_ORDER=0: launch the k2_tiles wavefronts in row-major order (per XCD class)
     int event_stride = 16;                  // SWFR_EVENT_STRIDE: per-kernel HIP events on every n-th resident frame
-    int fast_limit = 8;                     // rows with more active edges go to k2_rows_slow (SWFR_FAST_LIMIT: test knob)
+    int fast_limit = 16;                    // rows with more active edges go to k2_rows_slow; the row kernel's instance caps it at its 8 or 16 slots (SWFR_FAST_LIMIT: test knob)
     int tiles_grid = 0;                     // SWFR_TILES_GRID: persistent k2_tiles wavefronts per frame (0 = default)
     // swfr_render_batch: groups of frames rendered by ONE launch per kernel (blockIdx.y = frame); two groups alternate,
     // the host builds one while the GPU works on the other
@@ -720,7 +720,7 @@ void fill_frame_sizes(const swfr_renderer* r, const SceneLayout& L, size_t n_edg
     f.n_edges = uint32_t(n_edges); f.n_paths = uint32_t(n_paths); f.n_chunks = uint32_t(L.n_chunks);
     f.n_bands = uint32_t(L.n_bands); f.n_strips = uint32_t(L.n_strips); f.n_strip_slots = uint32_t(L.n_strip_slots); f.cell_slice = uint32_t(L.cell_total); f.slow_cap = uint32_t(L.n_rows + 64);
     f.width = int32_t(r->width); f.height = int32_t(r->height); f.tiles_x = int32_t((r->width + TILE_W - 1) / TILE_W);
-    f.fast_limit = uint32_t(std::min(std::max(r->fast_limit, 0), 8));
+    f.fast_limit = uint32_t(std::min(std::max(r->fast_limit, 0), 16));       // (the row kernel's instance caps it at its own slots: 8 or 16)
     const BandShare bs = band_share(r);
     f.band_first = bs.first; f.band_stride = bs.stride;
     f.cell_main = uint32_t(L.cell_main);

@@ -44,13 +44,15 @@ __device__ __forceinline__ uint32_t cols_from(int u) { return u >= 32 ? 0u : (u 
 __device__ __forceinline__ uint32_t col_bit(int t) { return (uint32_t)t < 32u ? (1u << t) : 0u; }
 
 #define R3_BIAS (1 << 24)                                                   // cells are 24.8 positions within +-2^23: biased keys are positive
-#define R3_INVALID(s) (0xF0000000u | ((uint32_t)(s) << 4) | (uint32_t)(s))   // sorts behind every cell; distinct per slot; low bits = the slot
+#define R3_INVALID(s) (0xF0000000u | ((uint32_t)(s) << 5) | (uint32_t)(s))   // sorts behind every cell; distinct per slot; low bits = the slot
+#define R3_KEY(c, dir, s) ((((uint32_t)((c) + R3_BIAS)) << 5) | ((dir) > 0 ? 16u : 0u) | (uint32_t)(s))          // (cell, direction, slot): cell < 2^25, slot < 16
 // compare-exchange of the sort networks: keys alone, or keys with one payload word
 #define R3_CE(i, j) do { const uint32_t lo_ = min(key[i], key[j]), hi_ = max(key[i], key[j]); key[i] = lo_; key[j] = hi_; } while (0)
 #define R3_CEP(i, j) do { const bool sw_ = key[i] > key[j]; const uint32_t lo_ = min(key[i], key[j]), hi_ = max(key[i], key[j]); \
                           const int a_ = sw_ ? c1[j] : c1[i], b_ = sw_ ? c1[i] : c1[j]; key[i] = lo_; key[j] = hi_; c1[i] = a_; c1[j] = b_; } while (0)
 #define R3_NET4(CE) do { CE(0, 1); CE(2, 3); CE(0, 2); CE(1, 3); CE(1, 2); } while (0)
 #define R3_NET6(CE) do { CE(1, 2); CE(4, 5); CE(0, 2); CE(3, 5); CE(0, 1); CE(3, 4); CE(2, 5); CE(0, 3); CE(1, 4); CE(2, 4); CE(1, 3); CE(2, 3); } while (0)
+#define R3_NET16(CE) do { CE(0, 1); CE(2, 3); CE(0, 2); CE(1, 3); CE(1, 2); CE(4, 5); CE(6, 7); CE(4, 6); CE(5, 7); CE(5, 6); CE(0, 4); CE(2, 6); CE(2, 4); CE(1, 5); CE(3, 7); CE(3, 5); CE(1, 2); CE(3, 4); CE(5, 6); CE(8, 9); CE(10, 11); CE(8, 10); CE(9, 11); CE(9, 10); CE(12, 13); CE(14, 15); CE(12, 14); CE(13, 15); CE(13, 14); CE(8, 12); CE(10, 14); CE(10, 12); CE(9, 13); CE(11, 15); CE(11, 13); CE(9, 10); CE(11, 12); CE(13, 14); CE(0, 8); CE(4, 12); CE(4, 8); CE(2, 10); CE(6, 14); CE(6, 10); CE(2, 4); CE(6, 8); CE(10, 12); CE(1, 9); CE(5, 13); CE(5, 9); CE(3, 11); CE(7, 15); CE(7, 11); CE(3, 5); CE(7, 9); CE(11, 13); CE(1, 2); CE(3, 4); CE(5, 6); CE(7, 8); CE(9, 10); CE(11, 12); CE(13, 14); } while (0)     /* Batcher's odd-even merge sort: 63 compare-exchanges */
 #define R3_NET8(CE) do { CE(0, 1); CE(2, 3); CE(4, 5); CE(6, 7); CE(0, 2); CE(1, 3); CE(4, 6); CE(5, 7); CE(1, 2); CE(5, 6); CE(0, 4); CE(3, 7); \
                          CE(1, 5); CE(2, 6); CE(1, 4); CE(3, 6); CE(2, 4); CE(3, 5); CE(3, 4); } while (0)
 
@@ -101,14 +103,14 @@ __device__ __forceinline__ void full_cells3(int32_t qt, int32_t qb, int32_t rl, 
 
 // STAGE: edges of the path a chunk keeps in LDS (two instances of the kernel: 32 for scenes whose paths have at most 32 edges, 64
 // for the others; a chunk with more edges in reach leaves its rows to the queue)
-template <int STAGE>
+template <int STAGE, int NS>
 __device__ __forceinline__ void rows3_chunk_body(FramePtr FR, uint32_t block) {
     typedef typename R3Mask<STAGE>::type amask_t;
     __shared__ __attribute__((aligned(16))) FastEdge staged[STAGE];
-    __shared__ uint32_t sub_cells[4][ROWS_FAST_N * 15];        // the cells of the four rows of a sample pass, before they are copied out coalesced
+    __shared__ uint32_t sub_cells[4][NS * 15];        // the cells of the four rows of a sample pass, before they are copied out coalesced
     __shared__ uint32_t sub_masks[4][4];                       // ... and the rows' tile-column masks: cells, covered in all / in some sample rows
-    __shared__ uint8_t slot_role[ROWS_FAST_N][64];             // role per edge slot, scattered there from the sorted order (column = lane: private)
-    __shared__ uint8_t slot_edge[ROWS_FAST_N][64];             // staged edge per slot (the tie check looks edges up by sorted position)
+    __shared__ uint8_t slot_role[NS][64];             // role per edge slot, scattered there from the sorted order (column = lane: private)
+    __shared__ uint8_t slot_edge[NS][64];             // staged edge per slot (the tie check looks edges up by sorted position)
     __shared__ uint32_t mid_bits[2];                           // rows of the chunk in which a staged edge starts or ends
     const int lane = threadIdx.x;
     const ChunkInfo ck = FR->chunks[block];                               // wave-uniform: path and edge reads are scalar
@@ -139,7 +141,7 @@ __device__ __forceinline__ void rows3_chunk_body(FramePtr FR, uint32_t block) {
         return;
     }
     R3MARK(1);
-    const int fast_limit = min((int)FR->fast_limit, ROWS_FAST_N);
+    const int fast_limit = min((int)FR->fast_limit, NS);
     // ---- stage the edges that can be active in this chunk's rows (path order kept)
     const int lo_s = (int)ck.first_row * 15, hi_s = lo_s + chunk_rows * 15;
     const FastEdge* __restrict__ FE = fast_edges_of(FR->edges, FR->n_edges) + P.first_edge;
@@ -224,14 +226,14 @@ __device__ __forceinline__ void rows3_chunk_body(FramePtr FR, uint32_t block) {
     const bool overflow = live && (forced_over || n > fast_limit);
     if (overflow) { n = 0; amask = 0; }
     // wave-uniform bound on the active edges of any row of this wave: the unrolled slot loops stop there
-    const int nmax = __ballot(n > 6) ? 8 : __ballot(n > 4) ? 6 : __ballot(n > 2) ? 4 : 2;
+    const int nmax = (NS > 8 && __ballot(n > 8)) ? 16 : __ballot(n > 6) ? 8 : __ballot(n > 4) ? 6 : __ballot(n > 2) ? 4 : 2;
     const int s0 = r * 15;
     const unsigned fmask = P.fill_rule ? 1u : ~0u;
 
     R3MARK(4);
     // ---- rows that can be converted analytically: x of every active edge at the first sample row of this pixel row and of the next
-    uint32_t key[ROWS_FAST_N]; int c1[ROWS_FAST_N];
-    int32_t qt[ROWS_FAST_N], qb[ROWS_FAST_N], rl[ROWS_FAST_N]; int ke[ROWS_FAST_N];
+    uint32_t key[NS]; int c1[NS];
+    int32_t qt[NS], qb[NS], rl[NS]; int ke[NS];
 #ifdef ABL3_NOEVAL
     const bool can_full = false;
 #else
@@ -240,7 +242,7 @@ __device__ __forceinline__ void rows3_chunk_body(FramePtr FR, uint32_t block) {
     {
         amask_t m = amask;
 #pragma unroll
-        for (int s = 0; s < ROWS_FAST_N; ++s) {
+        for (int s = 0; s < NS; ++s) {
             key[s] = R3_INVALID(s); c1[s] = 0x7fffffff; qt[s] = qb[s] = 0; rl[s] = 0; ke[s] = 0;
             if (s >= nmax) continue;                          // wave-uniform
             const int k = m ? r3_first(m) : 0;                // (no edge left: the first staged record, the results are not used)
@@ -262,7 +264,7 @@ __device__ __forceinline__ void rows3_chunk_body(FramePtr FR, uint32_t block) {
             int32_t qa = xa - hq, ra = rm - hr; if (ra < 0) { --qa; ra += D; }
             int32_t qz = xb - hq, rz = rn - hr; if (rz < 0) { --qz; rz += D; }
             const bool valid = can_full && s < n;
-            if (valid) { key[s] = ((uint32_t)(c0 + R3_BIAS) << 4) | (e.dir > 0 ? 8u : 0u) | (uint32_t)s; c1[s] = c1v; }
+            if (valid) { key[s] = R3_KEY(c0, e.dir, s); c1[s] = c1v; }
             qt[s] = qa; qb[s] = qz; rl[s] = DX < 0 ? rz : ra;
         }
     }
@@ -271,14 +273,15 @@ __device__ __forceinline__ void rows3_chunk_body(FramePtr FR, uint32_t block) {
     if (nmax <= 2) R3_CEP(0, 1);
     else if (nmax <= 4) R3_NET4(R3_CEP);
     else if (nmax <= 6) R3_NET6(R3_CEP);
-    else R3_NET8(R3_CEP);
+    else if (nmax <= 8) R3_NET8(R3_CEP);
+    else if constexpr (NS > 8) R3_NET16(R3_CEP);
     bool full = can_full, deep = false;
     unsigned tie_bits = 0;                                     // bit p: the edges at sorted positions p and p + 1 share a cell
 #pragma unroll
-    for (int p = 0; p + 1 < ROWS_FAST_N; ++p) {
+    for (int p = 0; p + 1 < NS; ++p) {
         if (p + 1 >= nmax) continue;                          // wave-uniform
         if (c1[p] > c1[p + 1]) full = false;                  // (slots without an edge sort last with the largest c1: never a violation)
-        if ((key[p] >> 4) == (key[p + 1] >> 4)) { tie_bits |= 1u << p; deep = true; }
+        if ((key[p] >> 5) == (key[p + 1] >> 5)) { tie_bits |= 1u << p; deep = true; }
     }
     // coincident cells: edges on one and the same line (a shape edge with fill0 == fill1 is there twice) can go in either order -- slot
     // order is used; any other tie needs the history of Cairo's edge list: the slow-row kernel's job
@@ -287,11 +290,11 @@ __device__ __forceinline__ void rows3_chunk_body(FramePtr FR, uint32_t block) {
         if (deep && can_full) {
             bool real = false;
 #pragma unroll
-            for (int p = 0; p + 1 < ROWS_FAST_N; ++p) {
+            for (int p = 0; p + 1 < NS; ++p) {
                 if (p + 1 >= nmax) continue;
                 if ((tie_bits >> p) & 1u) {
-                    const FastEdge& ea = staged[slot_edge[key[p] & 7u][lane]];
-                    const FastEdge& eb = staged[slot_edge[key[p + 1] & 7u][lane]];
+                    const FastEdge& ea = staged[slot_edge[key[p] & 15u][lane]];
+                    const FastEdge& eb = staged[slot_edge[key[p + 1] & 15u][lane]];
                     real |= !(ea.x1 == eb.x1 && ea.a0 == eb.a0 && ea.DX == eb.DX && ea.D == eb.D);       // same_line
                 }
             }
@@ -300,9 +303,9 @@ __device__ __forceinline__ void rows3_chunk_body(FramePtr FR, uint32_t block) {
     }
     uint32_t mode = ROW_EMPTY;
     bool is_sub = false;
-    uint32_t role[ROWS_FAST_N];
+    uint32_t role[NS];
 #pragma unroll
-    for (int s = 0; s < ROWS_FAST_N; ++s) role[s] = 0;
+    for (int s = 0; s < NS; ++s) role[s] = 0;
     if (n > 0) {
         if (defer) mode = ROW_DEFER;
         else if (full) mode = ROW_FULL;
@@ -312,19 +315,19 @@ __device__ __forceinline__ void rows3_chunk_body(FramePtr FR, uint32_t block) {
         // winding walk over the sorted edges; the roles go back to the edges' slots through the lane's own LDS column
         int w = 0;
 #pragma unroll
-        for (int p = 0; p < ROWS_FAST_N; ++p) {
+        for (int p = 0; p < NS; ++p) {
             if (p >= nmax) continue;                          // wave-uniform
             const bool in_b = ((unsigned)w & fmask) != 0;
-            w += (key[p] & 8u) ? 1 : -1;
+            w += (key[p] & 16u) ? 1 : -1;
             const bool in_a = ((unsigned)w & fmask) != 0;
             const bool fg = p == 0 || !((tie_bits >> (p - 1)) & 1u), lg = !((tie_bits >> p) & 1u);
             uint32_t ro = 0;
             if (!in_b && fg) ro = 1u;                         // left edge of a span
             else if (!in_a && lg) ro = 2u;                    // right edge
-            slot_role[key[p] & 7u][lane] = (uint8_t)ro;
+            slot_role[key[p] & 15u][lane] = (uint8_t)ro;
         }
 #pragma unroll
-        for (int s = 0; s < ROWS_FAST_N; ++s) {
+        for (int s = 0; s < NS; ++s) {
             if (s >= nmax) continue;
             role[s] = (mode == ROW_FULL && s < n) ? (uint32_t)slot_role[s][lane] : 0u;
         }
@@ -335,7 +338,7 @@ __device__ __forceinline__ void rows3_chunk_body(FramePtr FR, uint32_t block) {
     int n_cells = 0;
     if (mode == ROW_FULL && ri != ~0u) {
 #pragma unroll
-        for (int s = 0; s < ROWS_FAST_N; ++s) {
+        for (int s = 0; s < NS; ++s) {
             if (s >= nmax) continue;                          // wave-uniform
             if (role[s] != 0) n_cells += full_span(qt[s], qb[s]);
         }
@@ -355,7 +358,7 @@ __device__ __forceinline__ void rows3_chunk_body(FramePtr FR, uint32_t block) {
     if (mode == ROW_FULL && ri != ~0u && wave_base != ~0u) {
         uint32_t off = my_room;
 #pragma unroll
-        for (int s = 0; s < ROWS_FAST_N; ++s) {
+        for (int s = 0; s < NS; ++s) {
             if (s >= nmax) continue;
             if (role[s] != 0) {
                 const FastEdge& e = staged[ke[s]];
@@ -373,7 +376,7 @@ __device__ __forceinline__ void rows3_chunk_body(FramePtr FR, uint32_t block) {
         // a boundary edge's cells lie in the pixel columns [clo, chi]; everything right of it changes sides
         inter = 0; cov = 0;
 #pragma unroll
-        for (int s = 0; s < ROWS_FAST_N; ++s) {
+        for (int s = 0; s < NS; ++s) {
             if (s >= nmax) continue;
             if (role[s] != 0) {
                 const int a = qt[s] >> 8, b = qb[s] >> 8;
@@ -413,12 +416,12 @@ __device__ __forceinline__ void rows3_chunk_body(FramePtr FR, uint32_t block) {
         {
             unsigned long long m2 = pass_rows;
             for (int t = 0; t < 4 && m2; ++t) { nmaxp = max(nmaxp, __builtin_amdgcn_readlane(n, __ffsll((long long)m2) - 1)); m2 &= m2 - 1; }
-            nmaxp = nmaxp > 6 ? 8 : nmaxp > 4 ? 6 : nmaxp > 2 ? 4 : 2;
+            nmaxp = nmaxp > 8 ? 16 : nmaxp > 6 ? 8 : nmaxp > 4 ? 6 : nmaxp > 2 ? 4 : 2;
         }
         const bool sampling = R >= 0 && sub < 15;
         const int ss = rR * 15 + sub;
 #pragma unroll
-        for (int s = 0; s < ROWS_FAST_N; ++s) {
+        for (int s = 0; s < NS; ++s) {
             key[s] = R3_INVALID(s);
             if (s >= nmaxp) continue;                            // wave-uniform
             const int k = mR ? r3_first(mR) : 0;
@@ -427,26 +430,27 @@ __device__ __forceinline__ void rows3_chunk_body(FramePtr FR, uint32_t block) {
             int32_t q, rm;
             fast_x_at(e.a0, e.DX, e.D, e.invD, ss, q, rm);
             const int c = e.x1 + q + (rm >= (e.D >> 1) ? 1 : 0);
-            if (sampling && s < nR && e.ytop <= ss && ss < e.ybot) key[s] = ((uint32_t)(c + R3_BIAS) << 4) | (e.dir > 0 ? 8u : 0u) | (uint32_t)s;
+            if (sampling && s < nR && e.ytop <= ss && ss < e.ybot) key[s] = R3_KEY(c, e.dir, s);
         }
         if (nmaxp <= 2) R3_CE(0, 1);
         else if (nmaxp <= 4) R3_NET4(R3_CE);
         else if (nmaxp <= 6) R3_NET6(R3_CE);
-        else R3_NET8(R3_CE);
+        else if (nmaxp <= 8) R3_NET8(R3_CE);
+        else if constexpr (NS > 8) R3_NET16(R3_CE);
         // walk: a cell where the inside state differs before and after a group of edges in one cell
-        uint32_t cw[ROWS_FAST_N];
+        uint32_t cw[NS];
         unsigned em = 0;
         uint32_t s_inter = 0, s_cov = 0;
         {
             int w = 0; bool in_prev = false;
 #pragma unroll
-            for (int p = 0; p < ROWS_FAST_N; ++p) {
+            for (int p = 0; p < NS; ++p) {
                 cw[p] = 0;
                 if (p >= nmaxp) continue;                        // wave-uniform
                 const bool valid = key[p] < 0xF0000000u;
-                const uint32_t cellp = key[p] >> 4, celln = key[p + 1 < ROWS_FAST_N ? p + 1 : p] >> 4;
-                if (valid) w += (key[p] & 8u) ? 1 : -1;
-                const bool last = p + 1 >= ROWS_FAST_N || cellp != celln;
+                const uint32_t cellp = key[p] >> 5, celln = key[p + 1 < NS ? p + 1 : p] >> 5;
+                if (valid) w += (key[p] & 16u) ? 1 : -1;
+                const bool last = p + 1 >= NS || cellp != celln;
                 const bool in_now = ((unsigned)w & fmask) != 0;
                 const bool emit = valid && last && in_now != in_prev;
                 if (valid && last) in_prev = in_now;
@@ -472,7 +476,7 @@ __device__ __forceinline__ void rows3_chunk_body(FramePtr FR, uint32_t block) {
         {
             uint32_t at = (uint32_t)(sc - cnt);
 #pragma unroll
-            for (int p = 0; p < ROWS_FAST_N; ++p) {
+            for (int p = 0; p < NS; ++p) {
                 if (p >= nmaxp) continue;
                 if (keep && ((em >> p) & 1u)) sub_cells[g][at++] = cw[p];
             }
