@@ -1588,7 +1588,7 @@ __device__ __forceinline__ void tiles3_body(FramePtr FR, uint32_t* fb_to) {
 
 
 #ifndef T2_WAVES
-#define T2_WAVES 6
+#define T2_WAVES 5                    // (96 VGPRs; round 4: five or six wavefronts per SIMD time alike on S1, five is a tenth faster on S0)
 #endif
 // (two entry points per kernel: one frame, its descriptor passed by value -- the fields arrive with the kernel arguments, no memory
 //  round trip -- and a batch of frames, blockIdx.y indexing an array of descriptors in device memory)
