@@ -1570,15 +1570,22 @@ __device__ __forceinline__ void tiles3_body(FramePtr FR, uint32_t* fb_to) {
         }
         uint32_t* const fbp = fb_to ? fb_to : FR->fb;                     // (wave-uniform) this frame's own target, or the descriptor's
         const bool vec_ok = (width & 3) == 0 && ((uintptr_t)fbp & 15u) == 0u;      // (wave-uniform) every row of the frame starts 16-byte aligned
+        if (vec_ok && tx0 + TILE_W <= width && ty0 + STRIP_H <= height) {
+            // the strip lies inside the frame (wave-uniform: all but the last tile column / tile row): two stores, no per-lane tests
+            uint32_t* rowp = fbp + (size_t)cy0 * (size_t)width + cx0;
+            *reinterpret_cast<uint4*>(rowp) = make_uint4(px[0], px[1], px[2], px[3]);
+            *reinterpret_cast<uint4*>(rowp + 4 * (size_t)width) = make_uint4(px[4], px[5], px[6], px[7]);
+        } else {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int y = cy0 + 4 * h;
-            if (y >= height) continue;
-            uint32_t* rowp = fbp + (size_t)y * (size_t)width + cx0;
-            if (vec_ok && cx0 + 4 <= width) *reinterpret_cast<uint4*>(rowp) = make_uint4(px[4 * h], px[4 * h + 1], px[4 * h + 2], px[4 * h + 3]);
-            else {
+            for (int h = 0; h < 2; ++h) {
+                const int y = cy0 + 4 * h;
+                if (y >= height) continue;
+                uint32_t* rowp = fbp + (size_t)y * (size_t)width + cx0;
+                if (vec_ok && cx0 + 4 <= width) *reinterpret_cast<uint4*>(rowp) = make_uint4(px[4 * h], px[4 * h + 1], px[4 * h + 2], px[4 * h + 3]);
+                else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) if (cx0 + i < width) rowp[i] = px[4 * h + i];
+                    for (int i = 0; i < 4; ++i) if (cx0 + i < width) rowp[i] = px[4 * h + i];
+                }
             }
         }
         TRACE(7);                                                        // stores acknowledged
