@@ -519,8 +519,11 @@ void FrameBuilder::emit_stroke(const StyledPath& p, bool morph, double ratio) {
     Polygon& poly = poly_;
     bool done = false;
     if (path_.stroke_is_rectilinear()) {
-        // Cairo's box stroker when it accepts the style: the union of one box per segment, painted like a rectilinear fill
-        poly.reset(needs_clip, frame_lo, frame_hi);
+        // Cairo's box stroker when it accepts the style: the union of one box per segment, painted like a rectilinear fill.  Its
+        // boxes are NOT clipped against the frame first: a stroke whose boxes all lie outside is then "boxes that miss the operation's
+        // rectangle" (nothing drawn, the surface keeps its clear state) and not "no boxes at all" (which counts as drawn) -- found by
+        // the soak (mixed 7100/2196: the next translucent fill is then still composited with the SOURCE rule)
+        poly.reset(false, frame_lo, frame_hi);
         if (stroke_rectilinear_to_boxes(path_, sp, st.ctm, poly)) {
             emit_polygon(poly, true, push_solid(px), opaque, bx0, by0, bx1, by1);
             done = true;

@@ -332,6 +332,19 @@ def test_tie_of_two_older_edges_decides_whether_the_row_before_was_sampled():
     assert diff_stats(product_render(sc), ref) == (0, 0)
 
 
+def test_rectilinear_stroke_outside_the_frame_leaves_the_surface_clear():
+    """Soak finding of round 4 (mixed 7100/2196, children 0 and 1): an axis-parallel stroke that lies below the frame while its
+    approximate extents (the miter reach) still touch it.  Cairo's box stroker hands over boxes that miss the operation's rectangle:
+    nothing is drawn and the surface KEEPS its clear state, so the translucent fill that follows is composited with the SOURCE rule
+    (0x7f rounding); the frame builder used to clip those boxes away first and then took "no boxes at all" for drawn (OVER, 0x80
+    rounding: four pixels off by one)."""
+    import json
+    sc = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "soak_mixed_7100_2196_child0_1.json")))
+    ref = oracle_render(sc)
+    assert (np.asarray(ref)[..., 3] > 0).sum() > 500
+    assert diff_stats(product_render(sc), ref) == (0, 0)
+
+
 def test_tile_with_an_uncovered_path_row_is_not_a_full_cover():
     """Soak finding (large frames): a path whose bottom lies less than a sample row below a pixel boundary has a last pixel row with
     no active sample row at all.  A tile that the path covers completely in its other rows is then neither empty nor full although

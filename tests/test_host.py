@@ -130,6 +130,23 @@ def test_bitmap_tag_errors_like_the_reference():
         r.close()
 
 
+def test_clear_state_after_a_rectilinear_stroke_outside_the_frame():
+    """The host half of test_rectilinear_stroke_outside_the_frame_leaves_the_surface_clear (no GPU): after the off-frame box stroke
+    the oracle's surface is still clear, and the frame builder marks the next translucent path as a SOURCE lerp, not an OVER."""
+    import json
+    sc = json.load(open(os.path.join(ROOT, "tests", "golden", "soak_mixed_7100_2196_child0_1.json")))
+    be = ob.OracleBackend(sc["width"], sc["height"])
+    be.set_fill_rule(True)
+    cr.CanvasReplay(be, linear_extension=True).render({"children": sc["stage"]["children"][:1]})
+    assert be.L.swfo_is_clear(be.ctx) == 1
+    r = S.Renderer(sc["width"], sc["height"], device=api.DEVICE_HOST_ONLY, even_odd=True)
+    try:
+        edges, paths, styles = r.build_frame(sc["stage"])
+        assert len(paths) == 1 and int(paths[0]["lerp"]) == 1
+    finally:
+        r.close()
+
+
 class _Tap(ob.OracleBackend):
     """Oracle backend that records the polygon of every fill()/stroke()."""
 
