@@ -218,7 +218,7 @@ __device__ __forceinline__ uint32_t order_bucket(uint32_t cost) { return ORDER_B
 
 __device__ __forceinline__ void order_body(FramePtr F, uint32_t xcd_class);
 constexpr uint32_t BIN_THREADS = 1024;
-__device__ __forceinline__ void bin_body(FramePtr F) {
+__device__ __forceinline__ void bin_body(FramePtr F, uint32_t slow_kernels) {
     __shared__ uint32_t wave_cnt[BIN_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (blockIdx.x == 0 && tid < C2_WORDS) F->counters[tid] = 0;
@@ -275,11 +275,13 @@ __device__ __forceinline__ void bin_body(FramePtr F) {
     if (i < F->n_edges) {
         const swfr_edge e = F->raw[i];
         const DevPath EP = F->paths[e.reserved];
-        const DevEdge de = make_dev_edge(e, EP);
-        F->edges[i] = de;
-        const FastEdge fe = make_fast_edge(e, de, EP);
+        // (the 64-bit form is read by the queued-row kernels only: neither computed nor written for a scene known to have no queued rows)
+        if (slow_kernels) F->edges[i] = make_dev_edge(e, EP);
+        const FastEdge fe = make_fast_edge(e, EP);
         fast_edges_of(F->edges, F->n_edges)[i] = fe;
 #ifdef SWFR_EMU
+        const DevEdge de = make_dev_edge(e, EP);
+        if (de.ytop != fe.ytop || de.ybot != fe.ybot) { std::fprintf(stderr, "FastEdge span disagrees with DevEdge\n"); std::abort(); }
         // (emulator builds: the 32-bit form gives Cairo's numbers -- quotient equal, remainder 1/256 of the 64-bit one)
         if (de.ybot > de.ytop && de.dy) {
             const int probe[3] = {de.ytop, (de.ytop + de.ybot) / 2, de.ybot};
@@ -415,7 +417,7 @@ __device__ __forceinline__ void order_body(FramePtr F, uint32_t x) {
         F->strips[(size_t)rank * XCDS + x] = sd;
     }
 }
-__global__ __launch_bounds__(1024) void k2_bin_b(const Frame2* __restrict__ frames) { TRACE_DECL; TRACE_NOWAIT(0); bin_body(FRAME_PTR(frames, blockIdx.y)); TRACE(7); TRACE_OUT(0, blockIdx.x); }
+__global__ __launch_bounds__(1024) void k2_bin_b(const Frame2* __restrict__ frames, uint32_t slow_kernels) { TRACE_DECL; TRACE_NOWAIT(0); bin_body(FRAME_PTR(frames, blockIdx.y), slow_kernels); TRACE(7); TRACE_OUT(0, blockIdx.x); }
 
 // ---------------------------------------------------------------------------------------------
 // k2_rows
@@ -1609,9 +1611,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(T2_WAVES_SHA
 // ---------------------------------------------------------------------------------------------
 // launchers: `frames` is a device array of n_frames descriptors, blockIdx.y picks one
 // ---------------------------------------------------------------------------------------------
-void launch2_bin(hipStream_t st, const Frame2* frames, uint32_t n_frames, uint32_t max_edges_or_paths, uint32_t max_bands) {
+// slow_kernels: 0 when the queued-row kernels will not be launched behind this k2_bin (their DevEdge records are then not written)
+void launch2_bin(hipStream_t st, const Frame2* frames, uint32_t n_frames, uint32_t max_edges_or_paths, uint32_t max_bands, uint32_t slow_kernels) {
     const uint32_t g = max_bands + (max_edges_or_paths + BIN_THREADS - 1) / BIN_THREADS + XCDS;   // + the workgroups that order the strips
-    hipLaunchKernelGGL(k2_bin_b, dim3(g, n_frames), dim3(BIN_THREADS), 0, st, frames);
+    hipLaunchKernelGGL(k2_bin_b, dim3(g, n_frames), dim3(BIN_THREADS), 0, st, frames, slow_kernels);
 }
 void launch2_rows(hipStream_t st, const Frame2* frames, uint32_t n_frames, uint32_t max_chunks, uint32_t max_path_edges) {
     if (!max_chunks) return;

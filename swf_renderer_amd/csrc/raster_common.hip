@@ -135,10 +135,17 @@ __device__ __forceinline__ DevEdge make_dev_edge(const swfr_edge& e, const DevPa
 }
 
 // ---- the 32-bit form of the same edge (FastEdge, device_types.hpp) for the fast row routine
-__device__ __forceinline__ FastEdge make_fast_edge(const swfr_edge& e, const DevEdge& d, const DevPath& p) {
+__device__ __forceinline__ FastEdge make_fast_edge(const swfr_edge& e, const DevPath& p) {
     FastEdge f;
     f.x1 = e.x1; f.a0 = 256 - 30 * e.y1; f.DX = 0; f.D = 30; f.invD = 1.0 / 30.0; f.q15 = f.r15 = f.hq = f.hr = f.dqf = f.drf = 0;
-    f.ytop = d.ytop; f.ybot = d.ybot; f.dir = e.dir; f.fq = 0; f.invW = 0.0; f.fr = 0.0;
+    {   // active sample rows, clamped to the path's rows (as make_dev_edge)
+        int ytop = (int)((15ll * e.top + 128) >> 8), ybot = (int)((15ll * e.bottom + 128) >> 8);
+        ytop = max(ytop, p.y_min * 15);
+        ybot = min(ybot, p.y_max * 15);
+        if (ybot <= ytop) { ytop = ybot = 0; }
+        f.ytop = ytop; f.ybot = ybot;
+    }
+    f.dir = e.dir; f.fq = 0; f.invW = 0.0; f.fr = 0.0;
     if (p.kind != SWFR_PATH_TOR || e.y2 <= e.y1) { f.ytop = f.ybot = 0; return f; }
     const int64_t DX = (int64_t)e.x2 - e.x1, D = 30ll * ((int64_t)e.y2 - e.y1);
     f.D = (int32_t)D; f.invD = 1.0 / (double)D;

@@ -25,7 +25,7 @@
 #include "bitmap_decode.hpp"
 
 namespace swfr {
-void launch2_bin(hipStream_t, const Frame2*, uint32_t, uint32_t, uint32_t);
+void launch2_bin(hipStream_t, const Frame2*, uint32_t, uint32_t, uint32_t, uint32_t);
 void launch2_rows(hipStream_t, const Frame2*, uint32_t, uint32_t, uint32_t);
 void launch2_rows_slow(hipStream_t, const Frame2*, uint32_t, uint32_t, uint32_t, uint32_t);
 void launch2_tiles(hipStream_t, const Frame2*, uint32_t, uint32_t, uint32_t, int, uint32_t*);
@@ -850,7 +850,7 @@ void launch_frame(swfr_renderer* r, const swfr_renderer::Scene& sc, swfr_rendere
         // the frame's descriptor (scene arrays, this set's buffers, the framebuffer) was written with the scene
         const Frame2* fh = sc.frames_dev + (&F - r->fs);        // the set's descriptor, uploaded with the scene
         if (e) HIP_CHECK(hipEventRecord(e[0], st));
-        launch2_bin(st, fh, 1, uint32_t(std::max(sc.n_edges, sc.n_paths)), uint32_t(sc.n_bands));
+        launch2_bin(st, fh, 1, uint32_t(std::max(sc.n_edges, sc.n_paths)), uint32_t(sc.n_bands), (sc.n_chunks && sc.slow_state != 1) ? 1u : 0u);
         if (e) HIP_CHECK(hipEventRecord(e[1], st));
         launch2_rows(st, fh, 1, uint32_t(sc.n_chunks), sc.max_path_edges);
         // the queued rows (coincident edges, crowded rows): skipped once a frame of this resident scene has shown there are none
@@ -977,7 +977,7 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
             const uint32_t g = gi % groups, cnt = std::min(rb, frames - f);
             const hipStream_t st = r->fs[g * rb].stream;
             const Frame2* fh = sc.frames_dev + g * rb;
-            launch2_bin(st, fh, cnt, uint32_t(std::max(sc.n_edges, sc.n_paths)), uint32_t(sc.n_bands));
+            launch2_bin(st, fh, cnt, uint32_t(std::max(sc.n_edges, sc.n_paths)), uint32_t(sc.n_bands), (sc.n_chunks && sc.slow_state != 1) ? 1u : 0u);
             launch2_rows(st, fh, cnt, uint32_t(sc.n_chunks), sc.max_path_edges);
             if (sc.n_chunks && sc.slow_state != 1) launch2_rows_slow(st, fh, cnt, 1024u, sc.slow_state == 2 ? 0u : 256u, sc.slow_passes);
             launch2_tiles(st, fh, cnt, uint32_t(sc.n_strip_slots), r->tiles_grid > 0 ? uint32_t(r->tiles_grid) : ~0u, sc.shader_level, nullptr);
@@ -1179,7 +1179,7 @@ int render_batch2(swfr_renderer* r, const swfr_stage* stages, uint32_t n, void* 
         t_stage += ms_since(t0); t0 = clk::now();
         if (!G.ev_begin) { HIP_CHECK(hipEventCreate(&G.ev_begin)); HIP_CHECK(hipEventCreate(&G.ev_end)); }
         HIP_CHECK(hipEventRecord(G.ev_begin, G.stream));
-        launch2_bin(G.stream, frames_dev, cnt, uint32_t(max_ep), uint32_t(max_bands));
+        launch2_bin(G.stream, frames_dev, cnt, uint32_t(max_ep), uint32_t(max_bands), 1u);
         launch2_rows(G.stream, frames_dev, cnt, uint32_t(max_chunks), max_pe);
         if (max_chunks) launch2_rows_slow(G.stream, frames_dev, cnt, 256u, 64u, SLOW_PASSES);
         launch2_tiles(G.stream, frames_dev, cnt, uint32_t(max_strips), ~0u, shader_level, nullptr);
@@ -1252,7 +1252,7 @@ int render_resident_batched(swfr_renderer* r, uint32_t per_launch, uint32_t laun
     HIP_CHECK(hipStreamSynchronize(st));                       // (fr is a local)
     if (!r->rb_ev[0]) { HIP_CHECK(hipEventCreate(&r->rb_ev[0])); HIP_CHECK(hipEventCreate(&r->rb_ev[1])); }
     auto one_launch = [&]() {
-        launch2_bin(st, r->rb_frames.ptr, B, uint32_t(std::max(sc.n_edges, sc.n_paths)), uint32_t(sc.n_bands));
+        launch2_bin(st, r->rb_frames.ptr, B, uint32_t(std::max(sc.n_edges, sc.n_paths)), uint32_t(sc.n_bands), (sc.n_chunks && sc.slow_state != 1) ? 1u : 0u);
         launch2_rows(st, r->rb_frames.ptr, B, uint32_t(sc.n_chunks), sc.max_path_edges);
         if (sc.n_chunks && sc.slow_state != 1) launch2_rows_slow(st, r->rb_frames.ptr, B, 256u, sc.slow_state == 2 ? 0u : 64u, sc.slow_passes);
         launch2_tiles(st, r->rb_frames.ptr, B, uint32_t(sc.n_strip_slots), ~0u, sc.shader_level, nullptr);
