@@ -173,7 +173,9 @@ int  swfr_read_image(swfr_renderer *r, uint8_t *dst, size_t dst_stride, int prem
    rs/src/headless_renderer.rs:725-868): _async queues the device-to-host copy of the last frame into the handle's PINNED staging
    buffer behind the frame's kernels and returns; _wait blocks until it has arrived and hands out the staging buffer itself
    (width*4-byte rows, valid until the next read-back or swfr_destroy) -- no second copy on the host.  One read-back in flight per
-   handle; the next swfr_render may be called before _wait (its host build then overlaps the copy). */
+   handle; ANY render call (swfr_render, swfr_render_resident(_async / _to), swfr_render_batch) may be issued before _wait: the
+   host build overlaps the copy, and the streams of the handle's other frame sets are made to wait for the copy on the device before
+   a frame is rasterized, so the image read back is never torn. */
 int  swfr_read_image_async(swfr_renderer *r, int premultiplied);
 int  swfr_read_image_wait(swfr_renderer *r, const uint8_t **data, size_t *stride);
 /* render + mapped read-back of every frame, timed below the ABI (the reference's test loop: render, get_image). */
@@ -225,7 +227,8 @@ int  swfr_upload_edges(swfr_renderer *r, const swfr_edge *edges, size_t n_edges,
 int  swfr_render_resident(swfr_renderer *r, uint32_t frames);              /* blocking; frames >= 1 */
 /* Measurement entry: the resident scene as `frames_per_launch` (1..64) frames per kernel launch, every frame with its own
    kernel-written buffers and framebuffer, `launches` launches back to back (after one warm-up launch); *total_ms = HIP-event time of
-   the `launches` launches.  The last frame is readable with swfr_read_image.  The saturated-GPU figure of bench.py. */
+   the `launches` launches.  The last frame is readable with swfr_read_image.  The saturated-GPU figure of bench.py.  The handle keeps
+   the frames_per_launch framebuffers and work buffers (grow-only, like the frame sets': 64 x 33 MB at 4K) until swfr_destroy. */
 int  swfr_render_resident_batched(swfr_renderer *r, uint32_t frames_per_launch, uint32_t launches, float *total_ms);
 int  swfr_render_edges(swfr_renderer *r, const swfr_edge *edges, size_t n_edges,
                        const swfr_path *paths, size_t n_paths,

@@ -917,6 +917,16 @@ void launch_frame_graph(swfr_renderer* r, const swfr_renderer::Scene& sc, swfr_r
     HIP_CHECK(hipGraphLaunch(F.graph_exec, F.stream));
 }
 
+// A mapped read-back that nobody has waited for yet (swfr_read_image_async) reads the last frame's framebuffer -- or its
+// un-premultiplied copy -- on the handle's stream; frame sets 1..3 render on streams of their own and are not ordered behind it.
+// Before anything is launched on them they wait for the copy ON THE DEVICE (no host wait; nothing at all when no read is pending),
+// so that a frame can never be rasterized into the buffer the copy is still reading.
+void order_frames_behind_pending_read(swfr_renderer* r) {
+    if (!r->read_pending || !r->read_done) return;
+    for (int k = 1; k < 4; ++k)
+        if (r->fs[k].stream) HIP_CHECK(hipStreamWaitEvent(r->fs[k].stream, r->read_done, 0));
+}
+
 int render_resident(swfr_renderer* r, uint32_t frames) {
     if (!r->has_device) return fail(r, SWFR_ERR_NO_DEVICE, "host-only handle cannot rasterize");
     if (!r->scene_ready) return fail(r, SWFR_ERR_INVALID, "no scene uploaded");
@@ -957,6 +967,7 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
     hipEvent_t* ev_join = &r->ev[size_t(n_timed) * 4 + 2];
     // (no clearing of the counters here: k2_bin zeroes its frame's counters itself)
     HIP_CHECK(hipEventRecord(ev_begin, r->stream));
+    order_frames_behind_pending_read(r);
 #ifdef SWFR_BEGIN_WAIT
     for (uint32_t k = 1; k < n_sets; ++k) HIP_CHECK(hipStreamWaitEvent(r->fs[k].stream, ev_begin, 0));
 #endif
@@ -1223,7 +1234,10 @@ int render_resident_batched(swfr_renderer* r, uint32_t per_launch, uint32_t laun
     const hipStream_t st = r->stream;
     r->fb_valid = false;                                       // (fb_cur may point into a buffer the next lines reallocate; set again below)
     r->fb_cur = nullptr;
+    const uint32_t* rb_fb_before = r->rb_fb.ptr;
     r->rb_work.reserve(work_one * B + 4096); r->rb_cls.reserve(cls_one * B + 4096); r->rb_frames.reserve(B); r->rb_fb.reserve(n_px * B);
+    // (a handle that owns only some tile-rows writes only those: the rest of a fresh framebuffer is cleared once, as upload2 does for d_fb)
+    if (r->rb_fb.ptr != rb_fb_before) HIP_CHECK(hipMemsetAsync(r->rb_fb.ptr, 0, r->rb_fb.cap * sizeof(uint32_t), st));
     HIP_CHECK(hipMemsetAsync(r->rb_work.ptr, 0, work_one * B, st));           // (strip costs start at zero; class bytes outside the paths' rectangles)
     HIP_CHECK(hipMemsetAsync(r->rb_cls.ptr, 0, cls_one * B, st));
     std::vector<Frame2> fr(B);
@@ -1287,6 +1301,7 @@ int render_batch(swfr_renderer* r, const swfr_stage* stages, uint32_t n, void* d
     if (n == 0) return SWFR_OK;
     if (device_dst && frame_stride < size_t(r->width) * r->height * 4) return fail(r, SWFR_ERR_INVALID, "frame stride smaller than a frame");
     if (device_dst && r->batch_frames > 1) return render_batch2(r, stages, n, device_dst, frame_stride);
+    order_frames_behind_pending_read(r);                       // (frames without a device_dst land in the frame sets' own framebuffers)
     const uint32_t n_sets = uint32_t(std::max(1, std::min(r->in_flight, 4)));
     std::vector<uint32_t*> pinned_counters;
     uint32_t* hc = nullptr;
@@ -1722,6 +1737,7 @@ int swfr_render_resident_async(swfr_renderer* r, uint32_t* out_set) {
         r->async_used |= 1u << k;
         swfr_renderer::FrameSet& F = r->fs[k];
         if (!r->scn[0].slow_verified) { r->scn[0].slow_state = 0; r->scn[0].slow_passes = SLOW_PASSES; }   // (nothing checks an async frame's queues: launch everything unless a blocking frame of this scene has shown what it needs)
+        order_frames_behind_pending_read(r);
         launch_frame(r, r->scn[0], F, nullptr, nullptr);
         HIP_CHECK(hipGetLastError());
         r->fb_cur = r->n_targets ? r->targets[k % r->n_targets] : F.d_fb.ptr;
@@ -1746,6 +1762,7 @@ int swfr_render_resident_async_to(swfr_renderer* r, void* block_target, uint32_t
         // row y of the frame is row y - (first tile-row) * 16 of the block: the kernels address the frame, so they get the block's
         // address moved up by the rows above it (only the handle's own rows are ever written)
         uint32_t* fb = static_cast<uint32_t*>(block_target) - size_t(bs.first) * TILE_H * r->width;
+        order_frames_behind_pending_read(r);
         launch_frame(r, r->scn[0], F, fb, nullptr);
         HIP_CHECK(hipGetLastError());
         r->fb_cur = nullptr; r->fb_valid = false;              // (the frame is the caller's: nothing to read back from the handle)

@@ -197,6 +197,38 @@ def test_resident_scene_as_frames_per_launch_and_mapped_read_back():
             r.close()
 
 
+def test_mapped_read_back_is_not_torn_by_frames_queued_before_the_wait():
+    """swfr_read_image_async queues the copy of the last frame and returns; a multi-frame render of ANOTHER scene issued before
+    swfr_read_image_wait runs on the other frame sets' streams -- which wait for the copy on the device -- so the image that comes
+    back is the first scene's, bit for bit (the advisor's round-3 finding: frame sets 1..3 were not ordered behind the handle's stream)."""
+    import swf_renderer_amd as S
+    from swf_renderer_amd import api, synth
+    cfg = dict(synth.S1)
+    W, H = cfg["width"], cfg["height"]                      # a 33 MB frame: the copy takes long enough for seven frames to overtake it
+    pts, cols = synth.scene(**cfg)
+    host = S.Renderer(W, H, device=api.DEVICE_HOST_ONLY)
+    a = host.build_frame(api.stars_to_stage(pts, cols))
+    b = host.build_frame(api.stars_to_stage(pts[::-1] + 40, cols[::-1]))       # other painter's order, shifted: different pixels
+    host.close()
+    r = S.Renderer(W, H)
+    try:
+        r.upload_edges(*a)
+        r.render_resident(7)                                 # the last frame lies in a frame set other than 0
+        first = np.array(r.read_image(premultiplied=True))
+        for _ in range(3):
+            r.upload_edges(*a)
+            r.render_resident(7)
+            r.read_image_async(premultiplied=True)
+            r.upload_edges(*b)
+            r.render_resident(7)                             # rasterizes into every frame set, the one being read included
+            got = np.asarray(r.read_image_wait())
+            assert (got == first).all()
+        second = np.array(r.read_image(premultiplied=True))
+        assert (second != first).any()
+    finally:
+        r.close()
+
+
 # ---- BASELINE config 3: 256 morph ratios through one handle (reduced frame; oracle finishes in seconds)
 def test_morph_256_ratios_vs_oracle():
     import swf_renderer_amd as S
