@@ -1245,24 +1245,19 @@ __device__ __forceinline__ void blend8(uint32_t (&px)[8], const uint32_t (&al)[8
             {
                 const int bw1 = (int)flt.width - 1, bh1 = (int)flt.height - 1;
                 bool inside = flt.width < (1u << 23) && flt.height < (1u << 23);
-                int x0s[4], y0s[4]; uint32_t wfs[4];
+                // (the taps are written as if inside -- no temporaries kept beside them -- and redone by the general routine otherwise)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int px_ = tx0 + 16 * i + cgl, py_ = cy0 + 4 * h;
                     const long long bxp = flt.base_x + (long long)px_ * flt.m00 + (long long)py_ * flt.m01 - 0x8000;
                     const long long byp = flt.base_y + (long long)px_ * flt.m10 + (long long)py_ * flt.m11 - 0x8000;
-                    x0s[i] = (int)(bxp >> 16); y0s[i] = (int)(byp >> 16);
-                    wfs[i] = ((uint32_t)bxp >> 9 & 0x7fu) | (((uint32_t)byp >> 9 & 0x7fu) << 7);
-                    inside = inside && (unsigned)x0s[i] < (unsigned)bw1 && (unsigned)y0s[i] < (unsigned)bh1;
+                    const int x0 = (int)(bxp >> 16), y0 = (int)(byp >> 16);
+                    inside = inside && (unsigned)x0 < (unsigned)bw1 && (unsigned)y0 < (unsigned)bh1;
+                    const uint32_t o = __umul24((uint32_t)y0, flt.width) + (uint32_t)x0;
+                    t[i].o[0][0] = o; t[i].o[1][0] = o + 1u; t[i].o[0][1] = o + flt.width; t[i].o[1][1] = o + flt.width + 1u;
+                    t[i].wf = ((uint32_t)bxp >> 9 & 0x7fu) | (((uint32_t)byp >> 9 & 0x7fu) << 7);
                 }
-                if (__ballot(!inside) == 0ull) {                   // wave-uniform
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const uint32_t o = __umul24((uint32_t)y0s[i], flt.width) + (uint32_t)x0s[i];
-                        t[i].o[0][0] = o; t[i].o[1][0] = o + 1u; t[i].o[0][1] = o + flt.width; t[i].o[1][1] = o + flt.width + 1u;
-                        t[i].wf = wfs[i];
-                    }
-                } else {
+                if (__ballot(!inside) != 0ull) {                   // wave-uniform
 #pragma unroll
                     for (int i = 0; i < 4; ++i) bilinear_taps(flt, tx0 + 16 * i + cgl, cy0 + 4 * h, t[i]);
                 }
