@@ -18,11 +18,20 @@ def kname(n):
     return n[5:] if n.startswith("void ") else n
 
 
-def counters(path):
+def counters(path, full_launches_only=False):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(path)):
         agg[kname(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    return {k: {c: (sum(v) / len(v), len(v)) for c, v in d.items()} for k, d in agg.items() if k.startswith("swfr::")}
+    out = {}
+    for k, d in agg.items():
+        if not k.startswith("swfr::"):
+            continue
+        out[k] = {}
+        for c, v in d.items():
+            if full_launches_only:                      # (the run also holds one-frame warm-up launches: keep the 8-frame ones, the large values)
+                v = [x for x in v if x >= 0.5 * max(v)]
+            out[k][c] = (sum(v) / len(v), len(v))
+    return out
 
 
 def kernel_us(path):
@@ -57,7 +66,7 @@ for w in ("s1", "s0"):
     fe, wr = newest("%s_batched_%s_fetch/*/*counter_collection.csv" % (tag, w)), newest("%s_batched_%s_write/*/*counter_collection.csv" % (tag, w))
     summ = {}
     if fe and wr:
-        F, W = counters(fe), counters(wr)
+        F, W = counters(fe, True), counters(wr, True)
         for k in sorted(set(F) | set(W)):
             fk, n = F.get(k, {}).get("FETCH_SIZE", (0.0, 0))
             wk, _ = W.get(k, {}).get("WRITE_SIZE", (0.0, 0))
