@@ -31,7 +31,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB
     cmd = [hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-fvisibility=hidden",
            "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
-           "-DSWFR_BUILD"] + (["-DSWFR_PHASES"] if os.environ.get("SWFR_PHASES") else []) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+           "-DSWFR_BUILD"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

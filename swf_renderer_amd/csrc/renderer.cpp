@@ -1028,14 +1028,6 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
         for (uint32_t w : {uint32_t(C2_ERROR), uint32_t(C2_TIE_PAIRTEST_SKIPPED), uint32_t(C2_TIE_SORT_OVERFLOW), uint32_t(C2_TIE_DEPTH)})
             counters[w] |= r->h_counters[k * COUNTER_WORDS + w];
     r->timing = swfr_timing{total_ms, setup_ms, rows_ms, tiles_ms, frames, sc.n_edges, sc.n_paths, sc.n_rows, 0, timed_frames};
-#ifdef SWFR_PHASES
-    if (std::getenv("SWFR_PRINT_PHASES") && counters[C2_CELLS]) {
-        static const char* names[8] = {"descriptors", "stage edges", "gather", "evaluate", "full test + alloc", "sample rows", "full cells", "queue + class"};
-        std::fprintf(stderr, "[swfr] k2_rows phases, clocks per wavefront (%u wavefronts):", counters[C2_CELLS]);
-        for (int i = 0; i < 8; ++i) std::fprintf(stderr, " %s %.0f", names[i], 16.0 * counters[24 + i] / counters[C2_CELLS]);
-        std::fprintf(stderr, "\n");
-    }
-#endif
     r->fb_valid = true;
     {
         uint32_t slow = 0, huge = 0;
