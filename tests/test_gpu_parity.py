@@ -605,6 +605,40 @@ def test_frame_pipeline_over_rccl_single_rank():
     assert p.returncode == 0 and b"PIPELINE_OK" in p.stdout, p.stdout.decode()[-3000:]
 
 
+def test_block_targets_three_handles_render_into_block_buffers():
+    """swfr_render_resident_group_to (what RotatingPipeline queues per group): every handle of a three-way split renders several
+    frames into device buffers that hold ONLY its own block of tile-rows -- more buffers than the handle has frame sets -- and the blocks
+    stacked in rank order are the oracle's frame, for every one of the frames."""
+    import torch
+    import swf_renderer_amd as S
+    from swf_renderer_amd import api, distributed as D
+    sc = SC["translucent_stack"]
+    w, h = sc["width"], sc["height"]
+    want = oracle_render(sc)
+    host = S.Renderer(w, h, device=api.DEVICE_HOST_ONLY)
+    scene = host.build_frame(sc["stage"])
+    host.close()
+    world, frames = 3, 6
+    rows = D.block_rows(h, world) * D.TILE_H
+    blocks = []
+    for rank in range(world):
+        rb = S.Renderer(w, h, band_index=rank, band_count=world, contiguous_bands=True)
+        try:
+            bufs = torch.zeros((frames, rows, w, 4), dtype=torch.uint8, device="cuda")
+            rb.upload_edges(*scene)
+            rb.render_resident(1)
+            used = rb.render_resident_group_to([bufs[f].data_ptr() for f in range(frames)])
+            assert used != 0
+            rb.wait()
+            torch.cuda.synchronize()
+            blocks.append(bufs.cpu().numpy())
+        finally:
+            rb.close()
+    for f in range(frames):
+        img = np.concatenate([blocks[rank][f] for rank in range(world)], axis=0)[:h]
+        assert diff_stats(img, want) == (0, 0), f
+
+
 def test_contiguous_blocks_three_handles_ragged_height_and_slab_copy():
     """A frame whose tile-rows do not divide by the handle count (the last block is short, and one handle may own nothing):
     per-handle block slabs (swfr_copy_band_slab) stacked by distributed.assemble_blocks equal the oracle."""
