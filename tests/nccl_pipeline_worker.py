@@ -35,6 +35,16 @@ ok = True
 if rank == 0:
     digest = hashlib.sha256(np.ascontiguousarray(out.cpu().numpy()).tobytes()).hexdigest()
     ok = digest == synth.S1_SHA256_PREMUL
+rb.close()
+# the rotating assembly on the same backend: groups of `world` frames, block buffers, one all-to-all per group (world 1: a copy to self)
+rb = S.Renderer(W, H, band_index=rank, band_count=world, contiguous_bands=True)
+rot = D.RotatingPipeline(rb, W, H, rank, world)
+rot.upload(*scene)
+for step in range(5):                               # both group buffers are reused: the event ordering is exercised
+    rot.step_group()
+out2 = rot.finish()
+if rank == 0:
+    ok = ok and hashlib.sha256(np.ascontiguousarray(out2.cpu().numpy()).tobytes()).hexdigest() == synth.S1_SHA256_PREMUL
 dist.barrier()
 dist.destroy_process_group()
 rb.close()

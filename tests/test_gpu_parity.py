@@ -594,7 +594,8 @@ def test_s2_8k_eight_contiguous_block_handles_render_into_one_image():
 def test_frame_pipeline_over_rccl_single_rank():
     """FramePipeline on the real backend ("nccl" = RCCL) with the one rank this box has: set_targets, async frames on the handle's
     streams, torch's stream waiting for them, the in-place gather (send-to-self here) and the buffer-release events, eight steps
-    over three buffers; the S1 frame equals the libcairo known answer.  (N>1 ranks: tests/test_distributed.py, gloo.)"""
+    over three buffers; the S1 frame equals the libcairo known answer; then RotatingPipeline on the same backend (block buffers, one
+    all-to-all per group, five groups over two group buffers).  (N>1 ranks: tests/test_distributed.py, gloo.)"""
     import socket
     import subprocess
     import sys
