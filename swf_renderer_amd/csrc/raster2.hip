@@ -1367,12 +1367,14 @@ __device__ __forceinline__ void tiles3_body(FramePtr FR, uint32_t* fb_to) {
         const uint32_t cover_pos = (uint32_t)(top.cover >> 32);
         if (lane == 0 && top.any != 0u) { StripTop z; z.any = 0u; z.pad = 0u; z.cover = 0ull; FR->strip_top[wg] = z; }      // (depends on the loaded value: never overtakes the read)
         const bool uniform = top.any == cover_pos;                        // (wave-uniform)
-        if (uniform) {
-            const uint32_t colour = top.any ? (uint32_t)top.cover : 0u;
+        if (cover_pos) {
+            // the topmost opaque full cover paints every pixel of the strip with the record's colour: the walk starts BEHIND it
+            // (its band entry is never fetched); with nothing above it the strip is done
+            const uint32_t colour = (uint32_t)top.cover;
 #pragma unroll
             for (int j = 0; j < 8; ++j) px[j] = colour;
         }
-        const uint32_t start = cover_pos ? cover_pos - 1u : 0u;
+        const uint32_t start = cover_pos;                                // (first entry above the cover; 0: the whole list)
         TRACE(3);                                                        // class bytes in
         for (uint32_t c0 = uniform ? n_b : (start & ~63u); c0 < n_b; c0 += 64u) {
             const uint32_t f = cls_chunk(c0);
