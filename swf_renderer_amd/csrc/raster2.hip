@@ -1376,7 +1376,8 @@ __device__ __forceinline__ void tiles3_body(FramePtr FR, uint32_t* fb_to) {
         }
         const uint32_t start = cover_pos;                                // (first entry above the cover; 0: the whole list)
         TRACE(3);                                                        // class bytes in
-        for (uint32_t c0 = uniform ? n_b : (start & ~63u); c0 < n_b; c0 += 64u) {
+        const uint32_t walk_end = min(n_b, top.any);                     // (nothing paints above the record's topmost painting entry)
+        for (uint32_t c0 = uniform ? walk_end : (start & ~63u); c0 < walk_end; c0 += 64u) {
             const uint32_t f = cls_chunk(c0);
             const uint32_t bi = c0 + (uint32_t)lane;
             const bool hit = (f & CLS_NONEMPTY) != 0u && bi >= start;
