@@ -213,8 +213,6 @@ __device__ __forceinline__ uint32_t path_chunk_count(const DevPath& P, uint32_t 
     if (P.kind != SWFR_PATH_TOR || P.y_max <= P.y_min) return 0u;
     return ((uint32_t)P.y_max - a0 + chunk_rows - 1) / chunk_rows;
 }
-constexpr uint32_t ORDER_BUCKETS = 128;
-__device__ __forceinline__ uint32_t order_bucket(uint32_t cost) { return ORDER_BUCKETS - 1 - min(cost / 2, ORDER_BUCKETS - 1); }   // bucket 0 = heaviest
 
 __device__ __forceinline__ void order_body(FramePtr F, uint32_t xcd_class);
 constexpr uint32_t BIN_THREADS = 1024;
@@ -270,7 +268,12 @@ __device__ __forceinline__ void bin_body(FramePtr F, uint32_t slow_kernels) {
         if (n != n_b && tid == 0) atomicOr(&F->counters[C2_ERROR], E2_ROW_TABLE);      // the host counted the same rectangles: cannot happen
         return;
     }
-    const uint32_t i = (blockIdx.x - F->n_bands) * BIN_THREADS + (uint32_t)tid;       // (batched launches: a frame with fewer tile-rows leaves blocks idle)
+    // the workgroups behind the tile-rows': first one thread per edge, then -- in workgroups of their own, so that the two run side by
+    // side (round 4: the workgroup that did both was the kernel's long pole) -- one thread per path
+    // (batched launches: a frame with fewer tile-rows, edges or paths leaves blocks idle)
+    const uint32_t rel = blockIdx.x - F->n_bands, edge_blocks = (F->n_edges + BIN_THREADS - 1) / BIN_THREADS;
+    const bool path_block = rel >= edge_blocks;
+    const uint32_t i = path_block ? ~0u : rel * BIN_THREADS + (uint32_t)tid;
     // ---- one thread per edge: scan converter constants
     if (i < F->n_edges) {
         const swfr_edge e = F->raw[i];
@@ -298,7 +301,9 @@ __device__ __forceinline__ void bin_body(FramePtr F, uint32_t slow_kernels) {
 #endif
     }
     // ---- one thread per path: its chunk descriptors
-    if (i < F->n_paths) {
+    const uint32_t ip = path_block ? (rel - edge_blocks) * BIN_THREADS + (uint32_t)tid : ~0u;
+    if (ip < F->n_paths) {
+        const uint32_t i = ip;
         const DevPath P = F->paths[i];
         F->path_flag[i] = 0;
         uint32_t a0;
@@ -314,107 +319,103 @@ __device__ __forceinline__ void bin_body(FramePtr F, uint32_t slow_kernels) {
         }
     }
 }
-// the launch list of the tile pass: counting sort of the strips by the cost k2_rows added up during the PREVIOUS frame rendered with
-// these buffers (heaviest first; any order inside a bucket; a scheduling hint only -- a scene's first frame runs in row-major
-// order); the costs are cleared for this frame's k2_rows.  One 1024-thread workgroup, the last one of the k2_bin launch.
-// bucket[k] += 1 for every lane with `valid`; `slot`, when given, receives the lane's old value.  When the wavefront's lanes all
-// name the same bucket (a frame whose strips all cost the same: sixty-four atomics on one LDS word would serialise, every time) one
-// lane adds for all of them; otherwise every lane adds for itself.
-__device__ __forceinline__ void wave_bucket_add(uint32_t* bucket, uint32_t k, bool valid, uint32_t* slot) {
-#ifdef SWFR_NO_AGG
-    if (valid) { const uint32_t old = atomicAdd(&bucket[k], 1u); if (slot) *slot = old; }
-    return;
-#endif
-    const int lane = threadIdx.x & 63;
-    const unsigned long long todo = __ballot(valid);
-    if (!todo) return;                                                    // wave-uniform
-    const int leader = __ffsll((long long)todo) - 1;
-    const uint32_t kk = (uint32_t)__builtin_amdgcn_readlane((int)k, leader);
-    const unsigned long long m = __ballot(valid && k == kk);
-    if (m == todo) {                                                      // wave-uniform
-        uint32_t base = 0;
-        if (lane == leader) base = atomicAdd(&bucket[kk], (uint32_t)__popcll(m));
-        base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
-        if (slot && valid) *slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    } else if (valid) {
-        const uint32_t old = atomicAdd(&bucket[k], 1u);
-        if (slot) *slot = old;
-    }
+// The launch list of the tile pass.  Slot of a strip: XCDS * (its rank among the strips of its class) + class, class = local
+// tile-row % XCDS -- the hardware deals a launch's workgroups round-robin over the XCDs, so all strips of a tile-row run on one XCD
+// and share its L2.  Ranks: heaviest first by the cost k2_rows added up during the PREVIOUS frame rendered with these buffers (a
+// scheduling hint only -- a scene's first frame runs in row-major order); the costs are cleared for this frame's k2_rows.
+// One 1024-thread workgroup per XCD class (the last XCDS workgroups of the k2_bin launch).  Round 4: a stable partition into eight
+// cost ranges by wave ballots -- one round of loads, per-wavefront counts in LDS, one scan by one wavefront, two barriers -- instead of
+// a 128-bucket counting sort with returning LDS atomics (these workgroups were k2_bin's long pole: 9-11 us beside the others' 3-4).
+constexpr uint32_t ORDER_RANGES = 8;
+__device__ __forceinline__ uint32_t order_range(uint32_t cost) {          // 0 = heaviest
+    return cost >= 48u ? 0u : cost >= 32u ? 1u : cost >= 24u ? 2u : cost >= 16u ? 3u : cost >= 8u ? 4u : cost >= 4u ? 5u : cost >= 1u ? 6u : 7u;
 }
-#define ORDER_LDS_STRIPS 16384         // strips of one class whose bucket numbers fit the workgroup's LDS (a 16K x 8K frame); larger frames re-read the costs
-// Slot of a strip in the launch list: XCDS * (its rank among the strips of its class) + class, class = local tile-row % XCDS.  The
-// hardware deals a launch's workgroups round-robin over the XCDs, so all strips of a tile-row run on one XCD and share its L2.
-// Ranks: heaviest first by the previous frame's costs (counting sort per class), or row-major when there is no cost history.
-// One 1024-thread workgroup per class (the last XCDS workgroups of the k2_bin launch): the eight sorts run side by side.
+constexpr uint32_t ORDER_U = 16;                                           // strips per thread and round: 16 384 strips of a class per round
 __device__ __forceinline__ void order_body(FramePtr F, uint32_t x) {
-    constexpr uint32_t NB = ORDER_BUCKETS + 1;
-    __shared__ uint32_t bucket[NB];
     __shared__ uint2 rowinfo[256];                         // per tile-row of the class: {first band list entry, entries}
-    __shared__ uint8_t bkt[ORDER_LDS_STRIPS];
-    const int tid = threadIdx.x;
+    __shared__ uint32_t cnt[ORDER_RANGES][ORDER_U][BIN_THREADS / 64];      // strips per (cost range, round of 1024, wavefront); then their exclusive prefix
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t n_strips = F->n_strips, bc = F->band_stride, bi = F->band_first;
     const uint32_t per_row = STRIPS_PER_TILE * (uint32_t)F->tiles_x;
     const uint32_t n_local = n_strips / per_row;
     const uint32_t rows_x = (n_local + XCDS - 1 - x) / XCDS, max_rows = (n_local + XCDS - 1) / XCDS;     // tile-rows x, x + 8, ... of this class
     const uint32_t n_mine = rows_x * per_row;
-    const bool cached = n_mine <= ORDER_LDS_STRIPS;
-    for (uint32_t j = (uint32_t)tid; j < rows_x && j < 256u; j += 1024) {
+    const bool by_cost = F->strip_order != 0u;
+    for (uint32_t j = (uint32_t)tid; j < rows_x && j < 256u; j += BIN_THREADS) {
         const uint32_t trow = (x + j * XCDS) * bc + bi, b0 = F->band_off[trow];
         rowinfo[j] = make_uint2(b0, F->band_off[trow + 1] - b0);
     }
     // a class one tile-row short of the largest: its last slots stay without a strip
     if (rows_x < max_rows)
-        for (uint32_t j = (uint32_t)tid; j < per_row; j += 1024) {
+        for (uint32_t j = (uint32_t)tid; j < per_row; j += BIN_THREADS) {
             StripDesc sd; sd.wg = ~0u; sd.band_begin = 0; sd.n_b = 0; sd.pad = 0;
             F->strips[(size_t)(n_mine + j) * XCDS + x] = sd;
         }
+    __syncthreads();                                       // rowinfo is complete
     // strip i of the class: tile-row x + 8 * (i / per_row), position i % per_row in it
     auto strip_of = [&](uint32_t i) { const uint32_t j = i / per_row; return (x + j * XCDS) * per_row + (i - j * per_row); };
-    if (F->strip_order) {
-        for (uint32_t b = (uint32_t)tid; b < NB; b += 1024) bucket[b] = 0;
-        lds_barrier();
-        // every cost is read once (four independent loads in flight per thread), its bucket number kept in LDS, the costs cleared
-        for (uint32_t i0 = (uint32_t)tid; i0 < n_mine; i0 += 4096) {
-            uint32_t c[4], w[4];
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (uint32_t base = 0; base < n_mine; base += ORDER_U * BIN_THREADS) {                // (one round unless a class has more than 16 384 strips)
+        const uint32_t n_round = min(n_mine - base, ORDER_U * BIN_THREADS), U = (n_round + BIN_THREADS - 1) / BIN_THREADS;   // workgroup-uniform
+        unsigned long long ranges = 0;                     // this thread's strips' cost ranges, three bits each
+        uint32_t behind[ORDER_U];                          // strips of the same range before this one in its wavefront
+        if (by_cost) {
+            // every cost is read once (all of a thread's loads in flight together) and cleared
+            uint32_t c[ORDER_U];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + (uint32_t)u * 1024; w[u] = i < n_mine ? strip_of(i) : 0u; c[u] = i < n_mine ? F->strip_cost[w[u]] : 0u; }
+            for (uint32_t u = 0; u < ORDER_U; ++u) {
+                c[u] = 0;
+                if (u >= U) continue;                      // workgroup-uniform
+                const uint32_t i = base + u * BIN_THREADS + (uint32_t)tid;
+                if (i < n_mine) { const uint32_t w = strip_of(i); c[u] = F->strip_cost[w]; }
+            }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t i = i0 + (uint32_t)u * 1024;
+            for (uint32_t u = 0; u < ORDER_U; ++u) {
+                behind[u] = 0;
+                if (u >= U) continue;
+                const uint32_t i = base + u * BIN_THREADS + (uint32_t)tid;
                 const bool valid = i < n_mine;
-                const uint32_t k = order_bucket(c[u]);
-                wave_bucket_add(bucket, k + 1, valid, nullptr);          // (one LDS atomic per wavefront when its lanes agree; k + 1 <= ORDER_BUCKETS)
-                if (valid && cached) { bkt[i] = (uint8_t)k; F->strip_cost[w[u]] = 0; }       // (not cached: read again below, cleared there)
+                if (valid && c[u]) F->strip_cost[strip_of(i)] = 0;
+                const uint32_t k = order_range(c[u]);
+                ranges |= (unsigned long long)k << (3 * u);
+                for (uint32_t q = 0; q < ORDER_RANGES; ++q) {                            // every wavefront votes on every range
+                    const unsigned long long b = __ballot(valid && k == q);
+                    if (lane == 0) cnt[q][u][wave] = (uint32_t)__popcll(b);
+                    if (k == q) behind[u] = (uint32_t)__popcll(b & below);
+                }
             }
-        }
-        lds_barrier();
-        if (tid < 64) {                                   // prefix of the bucket sizes by one wavefront
-            uint32_t carry = 0;
-            for (uint32_t base = 0; base < NB; base += 64) {
-                const uint32_t b = base + (uint32_t)tid;
-                const uint32_t v = b < NB ? bucket[b] : 0u;
-                const uint32_t incl = (uint32_t)wave_scan_incl((int)v);
-                if (b < NB) bucket[b] = carry + incl;                    // bucket[b] = first rank of bucket b (its size was stored at b + 1)
-                carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            __syncthreads();
+            if (tid < 64) {                                // exclusive prefix in (range, round, wavefront) order by one wavefront
+                uint32_t* flat = &cnt[0][0][0];
+                uint32_t carry = 0;
+                for (uint32_t q = 0; q < ORDER_RANGES; ++q)
+                    for (uint32_t e0 = 0; e0 < U * (BIN_THREADS / 64); e0 += 64) {       // (the rounds in use: U * 16 counts per range, contiguous)
+                        const uint32_t e = e0 + (uint32_t)tid, lim = U * (BIN_THREADS / 64);
+                        const uint32_t v = e < lim ? flat[q * ORDER_U * (BIN_THREADS / 64) + e] : 0u;
+                        const uint32_t incl = (uint32_t)wave_scan_incl((int)v);
+                        if (e < lim) flat[q * ORDER_U * (BIN_THREADS / 64) + e] = carry + incl - v;
+                        carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                    }
             }
+            __syncthreads();
+        } else {
+#pragma unroll
+            for (uint32_t u = 0; u < ORDER_U; ++u) behind[u] = 0;
         }
-    }
-    lds_barrier();
-    for (uint32_t i0 = 0; i0 < n_mine; i0 += 1024) {                    // (workgroup-uniform trip count: the wavefronts vote inside)
-        const uint32_t i = i0 + (uint32_t)tid;
-        const bool valid = i < n_mine;
-        uint32_t rank = i;                                               // row-major inside the class
-        if (F->strip_order) {
-            uint32_t k = 0;
-            if (valid) { if (cached) k = bkt[i]; else { const uint32_t w = strip_of(i); k = order_bucket(F->strip_cost[w]); F->strip_cost[w] = 0; } }
-            wave_bucket_add(bucket, k, valid, &rank);
+#pragma unroll
+        for (uint32_t u = 0; u < ORDER_U; ++u) {
+            if (u >= U) continue;
+            const uint32_t i = base + u * BIN_THREADS + (uint32_t)tid;
+            if (i >= n_mine) continue;
+            uint32_t rank = i;                                               // row-major inside the class
+            if (by_cost) rank = base + cnt[(uint32_t)(ranges >> (3 * u)) & 7u][u][wave] + behind[u];
+            const uint32_t j = i / per_row;
+            uint2 ri;
+            if (j < 256u) ri = rowinfo[j]; else { const uint32_t trow = (x + j * XCDS) * bc + bi, b0 = F->band_off[trow]; ri = make_uint2(b0, F->band_off[trow + 1] - b0); }
+            StripDesc sd; sd.wg = strip_of(i); sd.band_begin = ri.x; sd.n_b = ri.y; sd.pad = 0;
+            F->strips[(size_t)rank * XCDS + x] = sd;
         }
-        if (!valid) continue;
-        const uint32_t j = i / per_row;
-        uint2 ri;
-        if (j < 256u) ri = rowinfo[j]; else { const uint32_t trow = (x + j * XCDS) * bc + bi, b0 = F->band_off[trow]; ri = make_uint2(b0, F->band_off[trow + 1] - b0); }
-        StripDesc sd; sd.wg = strip_of(i); sd.band_begin = ri.x; sd.n_b = ri.y; sd.pad = 0;
-        F->strips[(size_t)rank * XCDS + x] = sd;
+        __syncthreads();                                   // (cnt is rewritten by the next round)
     }
 }
 __global__ __launch_bounds__(1024) void k2_bin_b(const Frame2* __restrict__ frames, uint32_t slow_kernels) { TRACE_DECL; TRACE_NOWAIT(0); bin_body(FRAME_PTR(frames, blockIdx.y), slow_kernels); TRACE(7); TRACE_OUT(0, blockIdx.x); }
@@ -1611,7 +1612,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(T2_WAVES_SHA
 // ---------------------------------------------------------------------------------------------
 // slow_kernels: 0 when the queued-row kernels will not be launched behind this k2_bin (their DevEdge records are then not written)
 void launch2_bin(hipStream_t st, const Frame2* frames, uint32_t n_frames, uint32_t max_edges_or_paths, uint32_t max_bands, uint32_t slow_kernels) {
-    const uint32_t g = max_bands + (max_edges_or_paths + BIN_THREADS - 1) / BIN_THREADS + XCDS;   // + the workgroups that order the strips
+    const uint32_t g = max_bands + 2 * ((max_edges_or_paths + BIN_THREADS - 1) / BIN_THREADS) + XCDS;   // edge workgroups, path workgroups, + the workgroups that order the strips
     hipLaunchKernelGGL(k2_bin_b, dim3(g, n_frames), dim3(BIN_THREADS), 0, st, frames, slow_kernels);
 }
 void launch2_rows(hipStream_t st, const Frame2* frames, uint32_t n_frames, uint32_t max_chunks, uint32_t max_path_edges) {

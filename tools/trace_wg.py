@@ -42,6 +42,11 @@ for k, name in enumerate(("k2_bin", "k2_rows", "k2_tiles")):
     dur = (b[:, 7] - b[:, 0]) * 0.01
     print("%s: %d workgroups, starts at %.2f us, span %.2f us; workgroup duration us: p10 %.2f p50 %.2f p90 %.2f max %.2f; entries spread over %.2f us" %
           (name, len(b), (t0 - t_all0) * 0.01, (t1 - t0) * 0.01, *np.percentile(dur, [10, 50, 90]), dur.max(), (b[:, 0].max() - t0) * 0.01))
+    if name == "k2_bin":
+        # which workgroups are the long ones: tile-row workgroups first, then the edge / path workgroups, the last eight order the strips
+        used_idx = np.nonzero(used)[0]
+        worst = np.argsort(-dur)[:10]
+        print("   slowest workgroups (blockIdx: us): " + ", ".join("%d: %.1f" % (int(used_idx[i]), dur[i]) for i in worst) + "; the last eight blockIdx are the ordering workgroups (grid %d)" % (int(used_idx.max()) + 1))
     if name == "k2_tiles":
         names = ["descriptor fields", "strip descriptor", "class bytes", "entries + row headers", "first cells", "blend (to the store)", "stores acknowledged"]
         prev = b[:, 0].copy()
