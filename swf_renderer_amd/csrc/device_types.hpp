@@ -66,7 +66,8 @@ enum : uint32_t { BE_BOXES = 1u, BE_LERP = 2u, BE_SOLID = 4u, BE_OPAQUE_COVER = 
 struct ChunkInfo {
     uint32_t path, first_row, rec_base, rows;
     uint32_t slot0;          // index into band_slots of the (path, tile-row) pair of the chunk's first tile-row; ~0u if none
-    uint32_t pad[3];
+    uint32_t first_edge, n_edges;   // the path's edge range again: the wavefront's edge loads start with the chunk record, beside the path's
+    uint32_t pad;
 };
 
 // One (path, tile-row) pair: where its BandEntry goes.  The host assigns the slots (painter's order inside every

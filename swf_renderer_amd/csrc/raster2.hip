@@ -314,7 +314,7 @@ __device__ __forceinline__ void bin_body(FramePtr F, uint32_t slow_kernels) {
             ChunkInfo ck;
             ck.path = i; ck.first_row = a0 + c * F->chunk_rows; ck.rec_base = inc0; ck.rows = F->chunk_rows;
             ck.slot0 = area ? F->path_slots[i] + (ck.first_row / TILE_H - (uint32_t)P.y_min / TILE_H) : ~0u;
-            ck.pad[0] = ck.pad[1] = ck.pad[2] = 0;
+            ck.first_edge = P.first_edge; ck.n_edges = P.n_edges; ck.pad = 0;
             if (c0 + c < F->chunk_cap) F->chunks[c0 + c] = ck;
         }
     }
@@ -439,14 +439,9 @@ __device__ __forceinline__ uint32_t pack_sub_cell(int x, int sgn, int xminp, int
 #endif
 #define R2_ATTR __attribute__((amdgpu_waves_per_eu(R2_WAVES)))
 __global__ __launch_bounds__(64) R2_ATTR void k2_rows_b(const Frame2* __restrict__ frames) {
-    TRACE_DECL;
-    TRACE_NOWAIT(0);
     FramePtr FR = FRAME_PTR(frames, blockIdx.y);
     if (blockIdx.x >= FR->n_chunks) return;
-    TRACE(1);
-    rows3_chunk_body<ROWS_STAGE, ROWS_FAST_N>(FR, blockIdx.x);
-    TRACE(7);
-    TRACE_OUT(1, blockIdx.x);
+    rows3_chunk_body<ROWS_STAGE, ROWS_FAST_N>(FR, blockIdx.x);      // (the trace build's stamps are taken inside)
 }
 // (the instance for scenes with a path of more than ROWS_STAGE edges: 64 staged edges and SIXTEEN edge slots per row -- the rows of a
 //  stroke outline or of a shape with a hole inside a hole -- at two to three wavefronts per SIMD)

@@ -787,7 +787,7 @@ int upload2(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, siz
         x.d_edges.reserve(2 * n_edges + 1); x.d_band2.reserve(n_slots); x.d_rows2.reserve(n_slots * TILE_H + 64); x.d_cells.reserve(L.cell_total);
         x.d_slow.reserve(2 * (n_rows + 64)); x.d_huge.reserve(2 * (n_rows + 64));     // (two queues each: a pass reads one and refills the other)
         x.d_path_flag.reserve(n_paths + 64); x.d_path_queue.reserve(n_paths + 64);
-        x.d_chunks.reserve(n_chunks + 1); x.d_band_slots.reserve(n_slots + 1); x.d_strips.reserve(L.n_strip_slots + 1);
+        x.d_chunks.reserve(n_chunks + 1); x.d_band_slots.reserve(n_slots + 8); x.d_strips.reserve(L.n_strip_slots + 1);
         reserve_zeroed(x.d_strip_cost, L.n_strips + 1);                                 // (zero between frames: the ordering workgroup clears what it has read)
         r->d_counters.reserve(4 * COUNTER_WORDS);
         x.counters = r->d_counters.ptr + size_t(k) * COUNTER_WORDS;
@@ -1125,7 +1125,7 @@ int render_batch2(swfr_renderer* r, const swfr_stage* stages, uint32_t n, void* 
             const SceneLayout& L = F.L;
             work_bytes += pad((2 * F.e.size() + 1) * sizeof(DevEdge)) + pad(L.n_slots * sizeof(BandEntry2)) + pad((L.n_slots * TILE_H + 64) * sizeof(RowInfo2)) +
                           pad(L.cell_total * sizeof(Cell)) + 2 * pad(2 * (L.n_rows + 64) * sizeof(SlowRow)) + 2 * pad((F.p.size() + 64) * sizeof(uint32_t)) +
-                          pad((L.n_chunks + 1) * sizeof(ChunkInfo)) + pad((L.n_slots + 1) * sizeof(BandSlot)) + pad((L.n_strip_slots + 1) * sizeof(StripDesc)) +
+                          pad((L.n_chunks + 1) * sizeof(ChunkInfo)) + pad((L.n_slots + 8) * sizeof(BandSlot)) + pad((L.n_strip_slots + 1) * sizeof(StripDesc)) +
                           pad((L.n_strips + 1) * sizeof(uint32_t)) + pad(COUNTER_WORDS * sizeof(uint32_t));
             cls_bytes += pad(cls_region_bytes(L.n_slots, tiles_x, L.n_strips));
             max_ep = std::max(max_ep, std::max(F.e.size(), F.p.size())); max_bands = std::max(max_bands, L.n_bands);
@@ -1169,7 +1169,7 @@ int render_batch2(swfr_renderer* r, const swfr_stage* stages, uint32_t n, void* 
             f.path_flag = reinterpret_cast<uint32_t*>(carve((F.p.size() + 64) * sizeof(uint32_t)));
             f.path_queue = reinterpret_cast<uint32_t*>(carve((F.p.size() + 64) * sizeof(uint32_t)));
             f.chunks = reinterpret_cast<ChunkInfo*>(carve((L.n_chunks + 1) * sizeof(ChunkInfo)));
-            f.band_slots = reinterpret_cast<BandSlot*>(carve((L.n_slots + 1) * sizeof(BandSlot)));
+            f.band_slots = reinterpret_cast<BandSlot*>(carve((L.n_slots + 8) * sizeof(BandSlot)));
             f.strips = reinterpret_cast<StripDesc*>(carve((L.n_strip_slots + 1) * sizeof(StripDesc)));
             f.strip_cost = reinterpret_cast<uint32_t*>(carve((L.n_strips + 1) * sizeof(uint32_t)));
             f.counters = reinterpret_cast<uint32_t*>(carve(COUNTER_WORDS * sizeof(uint32_t)));
@@ -1220,7 +1220,7 @@ int render_resident_batched(swfr_renderer* r, uint32_t per_launch, uint32_t laun
     const size_t n_px = size_t(r->width) * r->height;
     const size_t work_one = pad((2 * sc.n_edges + 1) * sizeof(DevEdge)) + pad(sc.n_slots * sizeof(BandEntry2)) + pad((sc.n_slots * TILE_H + 64) * sizeof(RowInfo2)) +
                             pad(sc.cell_total * sizeof(Cell)) + 2 * pad(2 * (sc.n_rows + 64) * sizeof(SlowRow)) + 2 * pad((sc.n_paths + 64) * sizeof(uint32_t)) +
-                            pad((sc.n_chunks + 1) * sizeof(ChunkInfo)) + pad((sc.n_slots + 1) * sizeof(BandSlot)) + pad((sc.n_strip_slots + 1) * sizeof(StripDesc)) +
+                            pad((sc.n_chunks + 1) * sizeof(ChunkInfo)) + pad((sc.n_slots + 8) * sizeof(BandSlot)) + pad((sc.n_strip_slots + 1) * sizeof(StripDesc)) +
                             pad((sc.n_strips + 1) * sizeof(uint32_t)) + pad(COUNTER_WORDS * sizeof(uint32_t));
     const size_t cls_one = pad(cls_region_bytes(sc.n_slots, tiles_x, sc.n_strips));
     const hipStream_t st = r->stream;
@@ -1247,7 +1247,7 @@ int render_resident_batched(swfr_renderer* r, uint32_t per_launch, uint32_t laun
         f.path_flag = reinterpret_cast<uint32_t*>(carve((sc.n_paths + 64) * sizeof(uint32_t)));
         f.path_queue = reinterpret_cast<uint32_t*>(carve((sc.n_paths + 64) * sizeof(uint32_t)));
         f.chunks = reinterpret_cast<ChunkInfo*>(carve((sc.n_chunks + 1) * sizeof(ChunkInfo)));
-        f.band_slots = reinterpret_cast<BandSlot*>(carve((sc.n_slots + 1) * sizeof(BandSlot)));
+        f.band_slots = reinterpret_cast<BandSlot*>(carve((sc.n_slots + 8) * sizeof(BandSlot)));
         f.strips = reinterpret_cast<StripDesc*>(carve((sc.n_strip_slots + 1) * sizeof(StripDesc)));
         f.strip_cost = reinterpret_cast<uint32_t*>(carve((sc.n_strips + 1) * sizeof(uint32_t)));
         f.counters = reinterpret_cast<uint32_t*>(carve(COUNTER_WORDS * sizeof(uint32_t)));

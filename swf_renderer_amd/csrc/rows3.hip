@@ -112,9 +112,15 @@ __device__ __forceinline__ void rows3_chunk_body(FramePtr FR, uint32_t block) {
     __shared__ uint8_t slot_role[NS][64];             // role per edge slot, scattered there from the sorted order (column = lane: private)
     __shared__ uint8_t slot_edge[NS][64];             // staged edge per slot (the tie check looks edges up by sorted position)
     __shared__ uint32_t mid_bits[2];                           // rows of the chunk in which a staged edge starts or ends
+    TRACE_DECL;
+    TRACE_NOWAIT(0);
     const int lane = threadIdx.x;
     const ChunkInfo ck = FR->chunks[block];                               // wave-uniform: path and edge reads are scalar
     const uint32_t lo = ck.path;
+    // the first sixty-four edges of the path are requested at once -- the chunk record carries the path's edge range -- so that they
+    // travel beside the path record and the band slots instead of behind them
+    const FastEdge* __restrict__ FE = fast_edges_of(FR->edges, FR->n_edges) + ck.first_edge;
+    const FastEdge ek_first = FE[min((uint32_t)lane, ck.n_edges ? ck.n_edges - 1u : 0u)];
     const DevPath P = FR->paths[lo];
     const int r = (int)ck.first_row + lane;
     const int chunk_rows = (int)ck.rows;                                 // 16, 32 or 64: whole tile-rows, starting on a tile-row boundary
@@ -123,14 +129,17 @@ __device__ __forceinline__ void rows3_chunk_body(FramePtr FR, uint32_t block) {
     const int g16 = lane >> 4;
     const int band = (int)ck.first_row / TILE_H + g16;
     const int band_lo = P.y_min / TILE_H, band_hi = (P.y_max - 1) / TILE_H;
-    const bool band_ok = ck.slot0 != ~0u && g16 < chunk_rows / TILE_H && band >= band_lo && band <= band_hi && P.kind == SWFR_PATH_TOR;
+    // (the band records are requested with what the CHUNK record says -- clamped where the path may turn out not to reach -- so that
+    //  they travel beside the path record, not behind it; band_ok decides afterwards whether they mean anything)
     BandSlot cls_bs = {0u, 0u, 0u, 0u};
     uint32_t cls_b0 = 0, cls_b1 = 0;
-    if (band_ok) {
-        cls_bs = FR->band_slots[ck.slot0 + (uint32_t)g16];
-        cls_b0 = FR->band_off[band];
-        cls_b1 = FR->band_off[band + 1];
+    if (ck.slot0 != ~0u && g16 < chunk_rows / TILE_H) {
+        cls_bs = FR->band_slots[ck.slot0 + (uint32_t)g16];                 // (at most three records past the path's own: the host reserves eight spare ones)
+        const uint32_t bclamp = min((uint32_t)band, FR->n_bands - 1u);
+        cls_b0 = FR->band_off[bclamp];
+        cls_b1 = FR->band_off[bclamp + 1u];
     }
+    const bool band_ok = ck.slot0 != ~0u && g16 < chunk_rows / TILE_H && band >= band_lo && band <= band_hi && P.kind == SWFR_PATH_TOR;
     const uint32_t ri = band_ok ? cls_bs.slot * TILE_H + (uint32_t)(lane & (TILE_H - 1)) : ~0u;
     const bool in_path = P.kind == SWFR_PATH_TOR && lane < chunk_rows && r >= P.y_min && r < P.y_max;
     bool live = in_path;
@@ -140,19 +149,19 @@ __device__ __forceinline__ void rows3_chunk_body(FramePtr FR, uint32_t block) {
         if (ri != ~0u && lane < chunk_rows) { RowInfo2 h; h.off = 0; h.n = 0; h.mode = (uint16_t)(in_path ? (uint32_t)ROW_FOREIGN : (uint32_t)ROW_EMPTY); FR->rows[ri] = h; }
         return;
     }
+    TRACE(1);                                                            // chunk, path and band records in
     R3MARK(1);
     const int fast_limit = min((int)FR->fast_limit, NS);
     // ---- stage the edges that can be active in this chunk's rows (path order kept)
     const int lo_s = (int)ck.first_row * 15, hi_s = lo_s + chunk_rows * 15;
-    const FastEdge* __restrict__ FE = fast_edges_of(FR->edges, FR->n_edges) + P.first_edge;
     if (lane < 2) mid_bits[lane] = 0u;
     uint32_t n_list = 0;
     bool use_lds = true;
     int inc_before = 0;                                                  // (edge, pixel row) pairs of this path above the chunk: where its cells start
-    for (uint32_t eb = 0; eb < P.n_edges; eb += 64) {
+    for (uint32_t eb = 0; eb < ck.n_edges; eb += 64) {
         const uint32_t k = eb + (uint32_t)lane;
-        const FastEdge ek = FE[min(k, P.n_edges - 1u)];
-        const bool valid = k < P.n_edges && ek.ybot > ek.ytop;
+        const FastEdge ek = eb == 0 ? ek_first : FE[min(k, ck.n_edges - 1u)];
+        const bool valid = k < ck.n_edges && ek.ybot > ek.ytop;
         if (valid) inc_before += max(0, min((ek.ybot - 1) / 15 + 1, (int)ck.first_row) - ek.ytop / 15);
         const bool hit = use_lds && valid && ek.ytop < hi_s && ek.ybot > lo_s;
         const unsigned long long hb = __ballot(hit);
@@ -211,6 +220,7 @@ __device__ __forceinline__ void rows3_chunk_body(FramePtr FR, uint32_t block) {
         if ((uint32_t)(mb >> 32)) atomicOr(&mid_bits[1], (uint32_t)(mb >> 32));
     }
     lds_barrier();
+    TRACE(2);                                                            // edges staged, their row masks made
     R3MARK(3);
     // ---- lanes = rows: the row's active edges as a bit mask over the staged edges (bit k from edge k's row mask: wave-uniform)
     amask_t amask = 0;
@@ -268,6 +278,7 @@ __device__ __forceinline__ void rows3_chunk_body(FramePtr FR, uint32_t block) {
             qt[s] = qa; qb[s] = qz; rl[s] = DX < 0 ? rz : ra;
         }
     }
+    TRACE(3);                                                            // gathered and evaluated
     R3MARK(5);
     // ---- sort by (cell, slot); the analytic test, ties and the winding walk then look at neighbours only
     if (nmax <= 2) R3_CEP(0, 1);
@@ -388,6 +399,7 @@ __device__ __forceinline__ void rows3_chunk_body(FramePtr FR, uint32_t block) {
     };
     if (mode == ROW_FULL) { uint32_t iv, cv; full_row_masks(tc0, iv, cv); m_inter = iv; m_and = cv; m_or = cv; }
     lds_barrier();
+    TRACE(4);                                                            // sorted, roles, FULL cells and masks
     R3MARK(9);
     // ---- the wave's SUB rows, 4 rows per pass: lanes 16g .. 16g + 14 are the fifteen sample rows of the pass's g-th row (lane 16g + 15
     //      idles): a lane sorts its sample row's cells, walks them once and emits Cairo's cells (A.5 add_subspan); a row's lanes are one
@@ -532,6 +544,7 @@ __device__ __forceinline__ void rows3_chunk_body(FramePtr FR, uint32_t block) {
         }
         lds_barrier();                                          // the staging has been read: the next pass may overwrite it
     }
+    TRACE(5);                                                            // sample passes
     R3MARK(10);
     const bool slow = live && (overflow || defer);
     // ---- headers of the rows that are not SUB (those were written with their cells); a FULL row's cells are in place already
@@ -640,5 +653,6 @@ __device__ __forceinline__ void rows3_chunk_body(FramePtr FR, uint32_t block) {
             }
         }
     }
+    TRACE(7);
+    TRACE_OUT(1, block);
 }
-

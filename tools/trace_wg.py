@@ -62,6 +62,14 @@ for k, name in enumerate(("k2_bin", "k2_rows", "k2_tiles")):
         alive = np.cumsum(ev[:, 1])
         print("   workgroups alive: max %d, time-weighted mean %.0f" % (alive.max(), float((alive[:-1] * np.diff(ev[:, 0])).sum() / max(ev[-1, 0] - ev[0, 0], 1))))
     if name == "k2_rows":
+        names = ["chunk, path, band records", "edges staged, row masks", "gather + evaluate", "sort, roles, FULL cells, masks", "sample passes", "", "headers, queue, classification"]
+        prev = b[:, 0].copy()
+        for i in range(1, 8):
+            cur = b[:, i]
+            ok = cur != 0
+            d = (cur[ok] - prev[ok]) * 0.01
+            if len(d) and names[i - 1]: print("   %-32s p50 %.2f  p90 %.2f  max %.2f us  (%d wavefronts)" % (names[i - 1], *np.percentile(d, [50, 90]), d.max(), len(d)))
+            prev = np.where(ok, cur, prev)
         # which wavefronts are the slow ones: duration against the chunk's path (width, rows of the path in the chunk)
         raw = buf[k].astype(np.int64)
         edges_a, paths_a, _ = scene
