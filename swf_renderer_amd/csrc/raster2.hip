@@ -216,8 +216,9 @@ __device__ __forceinline__ uint32_t path_chunk_count(const DevPath& P, uint32_t 
 
 __device__ __forceinline__ void order_body(FramePtr F, uint32_t xcd_class);
 constexpr uint32_t BIN_THREADS = 1024;
+constexpr uint32_t BAND_U = 4;                                             // BAND_U * BIN_THREADS / 64 == 64: one wavefront scans a round's counts
 __device__ __forceinline__ void bin_body(FramePtr F, uint32_t slow_kernels) {
-    __shared__ uint32_t wave_cnt[BIN_THREADS / 64];
+    __shared__ uint32_t wave_cnt[2][BAND_U * (BIN_THREADS / 64)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (blockIdx.x == 0 && tid < C2_WORDS) F->counters[tid] = 0;
     if (blockIdx.x >= gridDim.x - XCDS) { order_body(F, blockIdx.x - (gridDim.x - XCDS)); return; }   // the last eight workgroups: the tile pass's launch list
@@ -225,19 +226,34 @@ __device__ __forceinline__ void bin_body(FramePtr F, uint32_t slow_kernels) {
         // ---- the paths that touch tile-row `band`, in painter's order
         const int band = (int)blockIdx.x;
         const uint32_t b0 = F->band_off[band], n_b = F->band_off[band + 1] - b0;
+        // BAND_U paths per thread and round (path = base + u * 1024 + thread: painter's order is (u, wavefront, lane) order); one
+        // barrier per round: the per-(u, wavefront) hit counts alternate between two LDS buffers and every wavefront scans all 64 itself
         uint32_t n = 0;
-        for (uint32_t base = 0; base < F->n_paths && n < n_b; base += BIN_THREADS) {    // (workgroup-uniform: stops when the list is complete)
-            const uint32_t p = base + (uint32_t)tid;
-            bool hit = false;
-            DevPath P;
-            if (p < F->n_paths) { P = F->paths[p]; hit = path_has_area(P) && P.y_min / TILE_H <= band && band <= (P.y_max - 1) / TILE_H; }
-            const unsigned long long bal = __ballot(hit);
-            if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(bal);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        for (uint32_t base = 0, buf = 0; base < F->n_paths && n < n_b; base += BAND_U * BIN_THREADS, buf ^= 1u) {    // (workgroup-uniform: stops when the list is complete)
+            unsigned long long bal[BAND_U];
+#pragma unroll
+            for (uint32_t u = 0; u < BAND_U; ++u) {
+                const uint32_t p = base + u * BIN_THREADS + (uint32_t)tid;
+                bool hit = false;
+                if (p < F->n_paths) {
+                    const DevPath& Q = F->paths[p];
+                    const int y0 = Q.y_min, y1 = Q.y_max;
+                    hit = y1 > y0 && Q.x_max > Q.x_min && y0 / TILE_H <= band && band <= (y1 - 1) / TILE_H;
+                }
+                bal[u] = __ballot(hit);
+                if (lane == 0) wave_cnt[buf][u * (BIN_THREADS / 64) + (uint32_t)wave] = (uint32_t)__popcll(bal[u]);
+            }
             __syncthreads();
-            uint32_t at = n;
-            for (int w = 0; w < wave; ++w) at += wave_cnt[w];
-            at += (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-            if (hit && at < n_b) {
+            const uint32_t v = wave_cnt[buf][lane];
+            const uint32_t incl = (uint32_t)wave_scan_incl((int)v);
+#pragma unroll
+            for (uint32_t u = 0; u < BAND_U; ++u) {
+                const uint32_t p = base + u * BIN_THREADS + (uint32_t)tid;
+                const uint32_t at = n + (uint32_t)__builtin_amdgcn_readlane((int)(incl - v), (int)(u * (BIN_THREADS / 64) + (uint32_t)wave))
+                                  + (uint32_t)__popcll(bal[u] & below);
+                if (!((bal[u] >> lane) & 1ull) || at >= n_b) continue;
+                const DevPath P = F->paths[p];
                 const uint32_t slot = b0 + at;
                 const BandEntry2 e = make_band_entry2(P, p, (uint32_t)band, F);
                 F->band_list[slot] = e;
@@ -262,8 +278,7 @@ __device__ __forceinline__ void bin_body(FramePtr F, uint32_t slow_kernels) {
                     }
                 }
             }
-            for (uint32_t w = 0; w < BIN_THREADS / 64; ++w) n += wave_cnt[w];
-            __syncthreads();
+            n += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         }
         if (n != n_b && tid == 0) atomicOr(&F->counters[C2_ERROR], E2_ROW_TABLE);      // the host counted the same rectangles: cannot happen
         return;
@@ -418,7 +433,10 @@ __device__ __forceinline__ void order_body(FramePtr F, uint32_t x) {
         __syncthreads();                                   // (cnt is rewritten by the next round)
     }
 }
-__global__ __launch_bounds__(1024) void k2_bin_b(const Frame2* __restrict__ frames, uint32_t slow_kernels) { TRACE_DECL; TRACE_NOWAIT(0); bin_body(FRAME_PTR(frames, blockIdx.y), slow_kernels); TRACE(7); TRACE_OUT(0, blockIdx.x); }
+// At most 80 SGPRs: the hardware hands a wavefront its SGPRs in blocks of 16 plus 16 (MI355X_MICROARCH.md, "Occupancy API one block/CU
+// high"), so 81-96 leave room for 7 wavefronts per SIMD -- ONE 1024-thread workgroup per CU instead of two, and a frame with more
+// than 256 of them (S2: 386) ran k2_bin in two rounds (r04y: 44.6 us; its edge and path workgroups entered when the tile-rows' left).
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) void k2_bin_b(const Frame2* __restrict__ frames, uint32_t slow_kernels) { TRACE_DECL; TRACE_NOWAIT(0); bin_body(FRAME_PTR(frames, blockIdx.y), slow_kernels); TRACE(7); TRACE_OUT(0, blockIdx.x); }
 
 // ---------------------------------------------------------------------------------------------
 // k2_rows
@@ -1137,6 +1155,7 @@ __device__ __forceinline__ uint32_t blend2(uint32_t dst, uint32_t a, uint32_t ef
 #define T3_LIST 16                     // non-empty band entries of a strip staged per round (painter's order)
 #define T3_ACC_STRIDE 68               // ints per accumulator row: 64 columns, padded so that every row starts 16-byte aligned
 #define T3_UNITS 32                    // units (a lane's four pixels of a row) of one (path, strip) blended in compacted form per round
+#define T3_PAIR_FROM 8192u            // strips per frame from which a frame's wavefronts paint two strips each
 #define T3_CLS_PRE 2                   // x 64 class bytes of a strip fetched up front
 
 // 24-bit multiplies (v_mul_u32_u24 / v_mad_u32_u24 issue at full rate, v_mul_lo_u32 at a quarter): two 8-bit channels in the
@@ -1305,50 +1324,65 @@ __device__ __forceinline__ void tiles3_body(FramePtr FR, uint32_t* fb_to) {
     const Sources bitmaps = {FR->src.bitmaps, FR->src.filters, FR->src.fparams, FR->src.gradients};
     bool acc_clean = false;                                // the accumulators are zeroed before the first partial path needs them (many strips have none)
 
-    for (uint32_t w = blockIdx.x; w < FR->n_strip_slots; w += gridDim.x) {
+    // The wavefront's strips: slots blockIdx.x, + gridDim.x, ... of the launch list.  Two strips' records are in flight while a strip is
+    // painted (a persistent launch -- fewer wavefronts than strips -- hides three of a strip's dependent round trips this way): the
+    // descriptor of the strip after next, and the next strip's StripTop and first class bytes.  VECTOR loads, a few lanes each, moved
+    // to the scalar unit with v_readlane when their turn comes: vector loads return in order, so the waits of the strip being painted
+    // do not wait for them (scalar loads return out of order: every lgkmcnt wait would).
+    const uint32_t n_slots = FR->n_strip_slots, G = gridDim.x;
+    auto fetch_desc = [&](uint32_t slot) -> uint32_t {                   // lanes 0..2: the StripDesc of a slot ({~0, ..} beyond the list)
+        uint32_t v = ~0u;
+        if (slot < n_slots && lane < 3) v = reinterpret_cast<const uint32_t*>(FR->strips + slot)[lane];
+        return v;
+    };
+    uint32_t n_wg = ~0u, n_band_begin = 0u, n_nb = 0u;                    // the next strip (wave-uniform) ...
+    int n_tcol = 0, n_ty0 = 0;
+    uint32_t n_top = 0u, n_cls[T3_CLS_PRE];                              // ... and, on their way: its StripTop (lanes 0..3), its first class bytes
+    auto prepare = [&](uint32_t dv) {
+        n_wg = (uint32_t)__builtin_amdgcn_readlane((int)dv, 0); n_band_begin = (uint32_t)__builtin_amdgcn_readlane((int)dv, 1); n_nb = (uint32_t)__builtin_amdgcn_readlane((int)dv, 2);
+        n_top = 0u; n_tcol = 0; n_ty0 = height;
+#pragma unroll
+        for (int u = 0; u < T3_CLS_PRE; ++u) n_cls[u] = 0u;
+        if (n_wg == ~0u) return;                                         // a padding slot of the launch list, or the list's end
+        const int tile = (int)(n_wg / STRIPS_PER_TILE), strip = (int)(n_wg % STRIPS_PER_TILE);
+        n_tcol = tile % tiles_x;
+        const int trow = (int)FR->band_first + (tile / tiles_x) * (int)FR->band_stride;
+        n_ty0 = trow * TILE_H + strip * STRIP_H;
+        // what the row pass knows about the strip as a whole (StripTop), and the strip's class byte per band entry
+        if (lane < 4) n_top = reinterpret_cast<const uint32_t*>(FR->strip_top + n_wg)[lane];
+        const uint8_t* cl = FR->cls + (size_t)STRIPS_PER_TILE * tiles_x * n_band_begin + (size_t)(n_tcol * STRIPS_PER_TILE + strip) * n_nb;
+#pragma unroll
+        for (int u = 0; u < T3_CLS_PRE; ++u) if ((uint32_t)(u * 64 + lane) < n_nb) n_cls[u] = (uint32_t)cl[u * 64 + lane];
+    };
+    uint32_t dv2;
+    {
+        const uint32_t dv1 = fetch_desc(blockIdx.x);
+        dv2 = fetch_desc(blockIdx.x + G);
+        prepare(dv1);
+    }
+    for (uint32_t w = blockIdx.x; w < n_slots; w += G) {
         TRACE(1);                                                        // descriptor fields in
-#if defined(SWFR_EMU) || defined(T3_VECTOR_DESC)
-        const StripDesc sd = FR->strips[w];
-#else
-        // (a scalar load through the constant address space: the slot is wave-uniform, and k2_bin wrote the list in an earlier kernel)
-        StripDesc sd;
-        {
-            const uint32_t __attribute__((address_space(4)))* sp = reinterpret_cast<const uint32_t __attribute__((address_space(4)))*>(reinterpret_cast<uintptr_t>(FR->strips + w));
-            sd.wg = sp[0]; sd.band_begin = sp[1]; sd.n_b = sp[2]; sd.pad = 0;
-        }
-#endif
-        const uint32_t wg = sd.wg;
-        if (wg == ~0u) continue;                                         // a padding slot of the launch list
-        // what the row pass knows about the strip as a whole (StripTop): read together with the class bytes below, one round trip
+        const uint32_t wg = n_wg, band_begin = n_band_begin, n_b = n_nb;
+        const int tcol = n_tcol, ty0 = n_ty0;
         StripTop top;
-#ifdef SWFR_EMU
-        top = FR->strip_top[wg];
-        // (the emulator's lanes are fibers: the rendezvous keeps lane 0 from clearing the record below before the others have read it)
-        top.any = (uint32_t)__builtin_amdgcn_readfirstlane((int)top.any);
-        top.cover = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(top.cover >> 32)) << 32) | (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)top.cover);
-#else
-        {
-            const uint32_t __attribute__((address_space(4)))* tp = reinterpret_cast<const uint32_t __attribute__((address_space(4)))*>(reinterpret_cast<uintptr_t>(FR->strip_top + wg));
-            top.any = tp[0]; top.pad = 0; top.cover = ((unsigned long long)tp[3] << 32) | (unsigned long long)tp[2];
-        }
-#endif
+        top.any = (uint32_t)__builtin_amdgcn_readlane((int)n_top, 0); top.pad = 0u;
+        top.cover = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)n_top, 3) << 32) | (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)n_top, 2);
+        uint32_t cpre[T3_CLS_PRE];
+#pragma unroll
+        for (int u = 0; u < T3_CLS_PRE; ++u) cpre[u] = n_cls[u];
+        prepare(dv2);
+        dv2 = fetch_desc(w + 2u * G);
+        if (wg == ~0u) continue;                                         // a padding slot of the launch list
         TRACE(2);                                                        // strip descriptor in
-        const int tile = (int)(wg / STRIPS_PER_TILE), strip = (int)(wg % STRIPS_PER_TILE);
-        const int tcol = tile % tiles_x;
-        int trow = tile / tiles_x;
-        trow = (int)FR->band_first + trow * (int)FR->band_stride;
-        const int tx0 = tcol * TILE_W, ty0 = trow * TILE_H + strip * STRIP_H;
+        const int strip = (int)(wg % STRIPS_PER_TILE);
+        const int tx0 = tcol * TILE_W;
         if (ty0 >= height) continue;
         const int cx0 = tx0 + 4 * cg, cy0 = ty0 + g;
         uint32_t px[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) px[j] = 0u;
 
-        const uint32_t band_begin = sd.band_begin, n_b = sd.n_b;
         const uint8_t* mycls = FR->cls + (size_t)STRIPS_PER_TILE * tiles_x * band_begin + (size_t)(tcol * STRIPS_PER_TILE + strip) * n_b;   // this strip's class byte per band entry
-        uint32_t cpre[T3_CLS_PRE];
-#pragma unroll
-        for (int u = 0; u < T3_CLS_PRE; ++u) cpre[u] = (uint32_t)(u * 64 + lane) < n_b ? (uint32_t)mycls[u * 64 + lane] : 0u;
         auto cls_chunk = [&](uint32_t c0) -> uint32_t {               // the class bytes of entries c0 .. c0 + 63 (c0 a multiple of 64, wave-uniform)
             if (c0 < 64u * T3_CLS_PRE) {
                 uint32_t f = cpre[0];
@@ -1606,8 +1640,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(T2_WAVES_SHA
 // launchers: `frames` is a device array of n_frames descriptors, blockIdx.y picks one
 // ---------------------------------------------------------------------------------------------
 // slow_kernels: 0 when the queued-row kernels will not be launched behind this k2_bin (their DevEdge records are then not written)
-void launch2_bin(hipStream_t st, const Frame2* frames, uint32_t n_frames, uint32_t max_edges_or_paths, uint32_t max_bands, uint32_t slow_kernels) {
-    const uint32_t g = max_bands + 2 * ((max_edges_or_paths + BIN_THREADS - 1) / BIN_THREADS) + XCDS;   // edge workgroups, path workgroups, + the workgroups that order the strips
+void launch2_bin(hipStream_t st, const Frame2* frames, uint32_t n_frames, uint32_t max_edges, uint32_t max_paths, uint32_t max_bands, uint32_t slow_kernels) {
+    // tile-rows' workgroups, edge workgroups, path workgroups (a frame's own follow its own edge workgroups), + the eight that order the strips
+    const uint32_t g = max_bands + (max_edges + BIN_THREADS - 1) / BIN_THREADS + (max_paths + BIN_THREADS - 1) / BIN_THREADS + XCDS;
     hipLaunchKernelGGL(k2_bin_b, dim3(g, n_frames), dim3(BIN_THREADS), 0, st, frames, slow_kernels);
 }
 void launch2_rows(hipStream_t st, const Frame2* frames, uint32_t n_frames, uint32_t max_chunks, uint32_t max_path_edges) {
@@ -1627,7 +1662,12 @@ void launch2_rows_slow(hipStream_t st, const Frame2* frames, uint32_t n_frames, 
 // fb_to: where THIS launch's pixels go instead of the descriptors' framebuffer (one frame per launch only), or nullptr
 void launch2_tiles(hipStream_t st, const Frame2* frames, uint32_t n_frames, uint32_t max_strips, uint32_t grid_cap, int shader_level, uint32_t* fb_to) {
     if (!max_strips) return;
-    const uint32_t g = max_strips < grid_cap ? max_strips : grid_cap;
+    // Default shape (grid_cap == ~0u): a frame of more than T3_PAIR_FROM strips is launched as HALF as many
+    // wavefronts as strips -- each paints slot k (the heavier half of the cost-ordered list) and slot k + grid (the lighter half), the
+    // second strip's records fetched while the first is painted (round 4: S1 31.0-31.7 us per frame against 32.3; S2 2 %, the textured 4K frames 3 % faster);
+    // smaller frames do not fill the GPU and keep one wavefront per strip.
+    uint32_t g = max_strips < grid_cap ? max_strips : grid_cap;
+    if (grid_cap == ~0u && max_strips > T3_PAIR_FROM) g = (max_strips + 1u) / 2u;
     if (shader_level >= 2) hipLaunchKernelGGL(k2_tiles_shaded_b, dim3(g, n_frames), dim3(64), 0, st, frames, fb_to);
     else if (shader_level == 1) hipLaunchKernelGGL(k2_tiles_bitmap_b, dim3(g, n_frames), dim3(64), 0, st, frames, fb_to);
     else hipLaunchKernelGGL(k2_tiles_solid_b, dim3(g, n_frames), dim3(64), 0, st, frames, fb_to);

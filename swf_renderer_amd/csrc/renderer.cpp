@@ -25,7 +25,7 @@
 #include "bitmap_decode.hpp"
 
 namespace swfr {
-void launch2_bin(hipStream_t, const Frame2*, uint32_t, uint32_t, uint32_t, uint32_t);
+void launch2_bin(hipStream_t, const Frame2*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t);
 void launch2_rows(hipStream_t, const Frame2*, uint32_t, uint32_t, uint32_t);
 void launch2_rows_slow(hipStream_t, const Frame2*, uint32_t, uint32_t, uint32_t, uint32_t);
 void launch2_tiles(hipStream_t, const Frame2*, uint32_t, uint32_t, uint32_t, int, uint32_t*);
@@ -850,7 +850,7 @@ void launch_frame(swfr_renderer* r, const swfr_renderer::Scene& sc, swfr_rendere
         // the frame's descriptor (scene arrays, this set's buffers, the framebuffer) was written with the scene
         const Frame2* fh = sc.frames_dev + (&F - r->fs);        // the set's descriptor, uploaded with the scene
         if (e) HIP_CHECK(hipEventRecord(e[0], st));
-        launch2_bin(st, fh, 1, uint32_t(std::max(sc.n_edges, sc.n_paths)), uint32_t(sc.n_bands), (sc.n_chunks && sc.slow_state != 1) ? 1u : 0u);
+        launch2_bin(st, fh, 1, uint32_t(sc.n_edges), uint32_t(sc.n_paths), uint32_t(sc.n_bands), (sc.n_chunks && sc.slow_state != 1) ? 1u : 0u);
         if (e) HIP_CHECK(hipEventRecord(e[1], st));
         launch2_rows(st, fh, 1, uint32_t(sc.n_chunks), sc.max_path_edges);
         // the queued rows (coincident edges, crowded rows): skipped once a frame of this resident scene has shown there are none
@@ -988,7 +988,7 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
             const uint32_t g = gi % groups, cnt = std::min(rb, frames - f);
             const hipStream_t st = r->fs[g * rb].stream;
             const Frame2* fh = sc.frames_dev + g * rb;
-            launch2_bin(st, fh, cnt, uint32_t(std::max(sc.n_edges, sc.n_paths)), uint32_t(sc.n_bands), (sc.n_chunks && sc.slow_state != 1) ? 1u : 0u);
+            launch2_bin(st, fh, cnt, uint32_t(sc.n_edges), uint32_t(sc.n_paths), uint32_t(sc.n_bands), (sc.n_chunks && sc.slow_state != 1) ? 1u : 0u);
             launch2_rows(st, fh, cnt, uint32_t(sc.n_chunks), sc.max_path_edges);
             if (sc.n_chunks && sc.slow_state != 1) launch2_rows_slow(st, fh, cnt, 1024u, sc.slow_state == 2 ? 0u : 256u, sc.slow_passes);
             launch2_tiles(st, fh, cnt, uint32_t(sc.n_strip_slots), r->tiles_grid > 0 ? uint32_t(r->tiles_grid) : ~0u, sc.shader_level, nullptr);
@@ -1104,7 +1104,7 @@ int render_batch2(swfr_renderer* r, const swfr_stage* stages, uint32_t n, void* 
         // ---- host: build the group's frames (the other group is being rasterized meanwhile)
         if (fd.size() < cnt) fd.resize(cnt);
         size_t arena_bytes = pad(cnt * sizeof(Frame2)) + 4096, work_bytes = 0, cls_bytes = 0;
-        size_t max_ep = 0, max_bands = 0, max_chunks = 0, max_strips = 0;
+        size_t max_e = 0, max_p = 0, max_bands = 0, max_chunks = 0, max_strips = 0;
         int shader_level = 0;
         uint32_t max_pe = 0;
         auto t0 = clk::now();
@@ -1128,7 +1128,7 @@ int render_batch2(swfr_renderer* r, const swfr_stage* stages, uint32_t n, void* 
                           pad((L.n_chunks + 1) * sizeof(ChunkInfo)) + pad((L.n_slots + 8) * sizeof(BandSlot)) + pad((L.n_strip_slots + 1) * sizeof(StripDesc)) +
                           pad((L.n_strips + 1) * sizeof(uint32_t)) + pad(COUNTER_WORDS * sizeof(uint32_t));
             cls_bytes += pad(cls_region_bytes(L.n_slots, tiles_x, L.n_strips));
-            max_ep = std::max(max_ep, std::max(F.e.size(), F.p.size())); max_bands = std::max(max_bands, L.n_bands);
+            max_e = std::max(max_e, F.e.size()); max_p = std::max(max_p, F.p.size()); max_bands = std::max(max_bands, L.n_bands);
             max_chunks = std::max(max_chunks, L.n_chunks); max_strips = std::max(max_strips, L.n_strip_slots);
             shader_level = std::max(shader_level, L.shader_level);
             max_pe = std::max(max_pe, L.max_path_edges);
@@ -1182,7 +1182,7 @@ int render_batch2(swfr_renderer* r, const swfr_stage* stages, uint32_t n, void* 
         t_stage += ms_since(t0); t0 = clk::now();
         if (!G.ev_begin) { HIP_CHECK(hipEventCreate(&G.ev_begin)); HIP_CHECK(hipEventCreate(&G.ev_end)); }
         HIP_CHECK(hipEventRecord(G.ev_begin, G.stream));
-        launch2_bin(G.stream, frames_dev, cnt, uint32_t(max_ep), uint32_t(max_bands), 1u);
+        launch2_bin(G.stream, frames_dev, cnt, uint32_t(max_e), uint32_t(max_p), uint32_t(max_bands), 1u);
         launch2_rows(G.stream, frames_dev, cnt, uint32_t(max_chunks), max_pe);
         if (max_chunks) launch2_rows_slow(G.stream, frames_dev, cnt, 256u, 64u, SLOW_PASSES);
         launch2_tiles(G.stream, frames_dev, cnt, uint32_t(max_strips), ~0u, shader_level, nullptr);
@@ -1258,7 +1258,7 @@ int render_resident_batched(swfr_renderer* r, uint32_t per_launch, uint32_t laun
     HIP_CHECK(hipStreamSynchronize(st));                       // (fr is a local)
     if (!r->rb_ev[0]) { HIP_CHECK(hipEventCreate(&r->rb_ev[0])); HIP_CHECK(hipEventCreate(&r->rb_ev[1])); }
     auto one_launch = [&]() {
-        launch2_bin(st, r->rb_frames.ptr, B, uint32_t(std::max(sc.n_edges, sc.n_paths)), uint32_t(sc.n_bands), (sc.n_chunks && sc.slow_state != 1) ? 1u : 0u);
+        launch2_bin(st, r->rb_frames.ptr, B, uint32_t(sc.n_edges), uint32_t(sc.n_paths), uint32_t(sc.n_bands), (sc.n_chunks && sc.slow_state != 1) ? 1u : 0u);
         launch2_rows(st, r->rb_frames.ptr, B, uint32_t(sc.n_chunks), sc.max_path_edges);
         if (sc.n_chunks && sc.slow_state != 1) launch2_rows_slow(st, r->rb_frames.ptr, B, 256u, sc.slow_state == 2 ? 0u : 64u, sc.slow_passes);
         launch2_tiles(st, r->rb_frames.ptr, B, uint32_t(sc.n_strip_slots), ~0u, sc.shader_level, nullptr);

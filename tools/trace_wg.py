@@ -13,11 +13,28 @@ api.library_path = lambda: LIB
 import swf_renderer_amd as S
 from swf_renderer_amd import synth
 which = sys.argv[1] if len(sys.argv) > 1 else "s1"
-cfg = synth.S1 if which == "s1" else synth.S2
-W, H = cfg["width"], cfg["height"]
-pts, cols = synth.scene(**cfg)
+if which in ("s1", "s2"):
+    cfg = synth.S1 if which == "s1" else synth.S2
+    W, H = cfg["width"], cfg["height"]
+    pts, cols = synth.scene(**cfg)
+    stage = api.stars_to_stage(pts, cols)
+else:                                                   # config3: the morph shape at ratio 1 (1080p); config2h: homestuck-beta-1 (1024x1024)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import scenarios
+    from helpers import fixture
+    if which == "config3":
+        tag = fixture("homestuck-beta-29")
+        b, mb = tag["bounds"], tag["morph_bounds"]
+        x0, x1 = min(b["x_min"], mb["x_min"]), max(b["x_max"], mb["x_max"])
+        y0, y1 = min(b["y_min"], mb["y_min"]), max(b["y_max"], mb["y_max"])
+        W, H = 1920, 1080
+        sx, sy = W * 20 / (x1 - x0), H * 20 / (y1 - y0)
+        stage = {"children": [{"type": "morph-shape", "definition": tag, "ratio": 1.0, "matrix": scenarios._m(sx, sy, -x0 * sx, -y0 * sy)}]}
+    else:
+        W, H = 1024, 1024
+        stage = scenarios.scenarios()["config2_homestuck-beta-1"]["stage"]
 host = S.Renderer(W, H, device=api.DEVICE_HOST_ONLY)
-scene = host.build_frame(api.stars_to_stage(pts, cols)); host.close()
+scene = host.build_frame(stage); host.close()
 share = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 r = S.Renderer(W, H, band_index=share // 2, band_count=share, contiguous_bands=True)
 r.upload_edges(*scene)
@@ -47,6 +64,13 @@ for k, name in enumerate(("k2_bin", "k2_rows", "k2_tiles")):
         used_idx = np.nonzero(used)[0]
         worst = np.argsort(-dur)[:10]
         print("   slowest workgroups (blockIdx: us): " + ", ".join("%d: %.1f" % (int(used_idx[i]), dur[i]) for i in worst) + "; the last eight blockIdx are the ordering workgroups (grid %d)" % (int(used_idx.max()) + 1))
+        # entry time and duration along blockIdx (tile-rows' workgroups, edge workgroups, path workgroups, the ordering eight)
+        ent = (b[:, 0] - t0) * 0.01
+        g = int(used_idx.max()) + 1
+        cuts = sorted(set(list(range(0, g - 8, max((g - 8) // 12, 1))) + [g - 8, g]))
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            m = (used_idx >= lo) & (used_idx < hi)
+            if m.any(): print("   blockIdx %4d..%4d: entry %.2f..%.2f us, duration mean %.2f max %.2f us" % (lo, hi - 1, ent[m].min(), ent[m].max(), dur[m].mean(), dur[m].max()))
     if name == "k2_tiles":
         names = ["descriptor fields", "strip descriptor", "class bytes", "entries + row headers", "first cells", "blend (to the store)", "stores acknowledged"]
         prev = b[:, 0].copy()
