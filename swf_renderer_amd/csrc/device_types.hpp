@@ -188,7 +188,7 @@ struct Sources {
 struct StripDesc {
     uint32_t wg;             // tile * STRIPS_PER_TILE + strip, tiles counted over the handle's own tile-rows
     uint32_t band_begin, n_b;
-    uint32_t pad;
+    uint32_t pad;            // the strip's tile column | its local tile-row << 16 (so that k2_tiles divides nothing)
 };
 
 // What the row pass (and k2_bin, for box paths) already knows about a strip as a whole, so that the tile pass need not walk anything

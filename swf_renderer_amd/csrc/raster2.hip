@@ -427,7 +427,9 @@ __device__ __forceinline__ void order_body(FramePtr F, uint32_t x) {
             const uint32_t j = i / per_row;
             uint2 ri;
             if (j < 256u) ri = rowinfo[j]; else { const uint32_t trow = (x + j * XCDS) * bc + bi, b0 = F->band_off[trow]; ri = make_uint2(b0, F->band_off[trow + 1] - b0); }
-            StripDesc sd; sd.wg = strip_of(i); sd.band_begin = ri.x; sd.n_b = ri.y; sd.pad = 0;
+            // (the strip's tile column and local tile-row travel with it: k2_tiles divides nothing)
+            const uint32_t pos = i - j * per_row;
+            StripDesc sd; sd.wg = strip_of(i); sd.band_begin = ri.x; sd.n_b = ri.y; sd.pad = (pos / STRIPS_PER_TILE) | ((x + j * XCDS) << 16);
             F->strips[(size_t)rank * XCDS + x] = sd;
         }
         __syncthreads();                                   // (cnt is rewritten by the next round)
@@ -1330,9 +1332,9 @@ __device__ __forceinline__ void tiles3_body(FramePtr FR, uint32_t* fb_to) {
     // to the scalar unit with v_readlane when their turn comes: vector loads return in order, so the waits of the strip being painted
     // do not wait for them (scalar loads return out of order: every lgkmcnt wait would).
     const uint32_t n_slots = FR->n_strip_slots, G = gridDim.x;
-    auto fetch_desc = [&](uint32_t slot) -> uint32_t {                   // lanes 0..2: the StripDesc of a slot ({~0, ..} beyond the list)
+    auto fetch_desc = [&](uint32_t slot) -> uint32_t {                   // lanes 0..3: the StripDesc of a slot ({~0, ..} beyond the list)
         uint32_t v = ~0u;
-        if (slot < n_slots && lane < 3) v = reinterpret_cast<const uint32_t*>(FR->strips + slot)[lane];
+        if (slot < n_slots && lane < 4) v = reinterpret_cast<const uint32_t*>(FR->strips + slot)[lane];
         return v;
     };
     uint32_t n_wg = ~0u, n_band_begin = 0u, n_nb = 0u;                    // the next strip (wave-uniform) ...
@@ -1344,9 +1346,10 @@ __device__ __forceinline__ void tiles3_body(FramePtr FR, uint32_t* fb_to) {
 #pragma unroll
         for (int u = 0; u < T3_CLS_PRE; ++u) n_cls[u] = 0u;
         if (n_wg == ~0u) return;                                         // a padding slot of the launch list, or the list's end
-        const int tile = (int)(n_wg / STRIPS_PER_TILE), strip = (int)(n_wg % STRIPS_PER_TILE);
-        n_tcol = tile % tiles_x;
-        const int trow = (int)FR->band_first + (tile / tiles_x) * (int)FR->band_stride;
+        const uint32_t where = (uint32_t)__builtin_amdgcn_readlane((int)dv, 3);        // tile column | local tile-row << 16 (k2_bin's launch list)
+        const int strip = (int)(n_wg % STRIPS_PER_TILE);
+        n_tcol = (int)(where & 0xffffu);
+        const int trow = (int)FR->band_first + (int)(where >> 16) * (int)FR->band_stride;
         n_ty0 = trow * TILE_H + strip * STRIP_H;
         // what the row pass knows about the strip as a whole (StripTop), and the strip's class byte per band entry
         if (lane < 4) n_top = reinterpret_cast<const uint32_t*>(FR->strip_top + n_wg)[lane];
