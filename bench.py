@@ -274,10 +274,17 @@ def main():
         r = None
     else:
         W, H, pts, cols, fx, stage, (edges, paths, styles), t_host = scene_of(cfg)
+        # the timed handle first (its allocations and its upload leave the GPU idle for milliseconds) ...
+        os.environ["SWFR_FRAMES_IN_FLIGHT"] = str(in_flight)
+        os.environ["SWFR_EVENT_STRIDE"] = "1000000"               # (the timed region carries no per-kernel events: each costs a queue packet)
+        r = S.Renderer(W, H, device=local_rank)
+        r.upload_edges(edges, paths, styles)                      # inputs resident in HBM before the timed region
+        r1 = None
         if world == 1 and in_flight > 1:
-            # the timed region below overlaps consecutive frames on several streams, which stretches every kernel's own duration;
-            # the same kernels timed with one frame in flight (a second handle, its own 80 frames, before the timed region so that
-            # the device is out of its idle clocks when the W warm-up frames start) are reported beside it
+            # ... then, directly before the W warm-up frames, the per-kernel times: the timed region below overlaps consecutive frames
+            # on several streams, which stretches every kernel's own duration; the same kernels timed with one frame in flight (a second
+            # handle, its own 80 frames) are reported beside it -- and the device is out of its idle clocks when the warm-up starts
+            # (20 frames after 1-50 ms of idling and 5 warm-up frames take 7 % longer than back to back: tools/short_run_probe.py)
             os.environ["SWFR_FRAMES_IN_FLIGHT"] = "1"
             os.environ["SWFR_EVENT_STRIDE"] = "4"
             r1 = S.Renderer(W, H, device=local_rank)
@@ -285,11 +292,8 @@ def main():
             r1.render_resident(16)
             r1.render_resident(64)
             t1 = r1.timing()
-            r1.close()
             os.environ["SWFR_FRAMES_IN_FLIGHT"] = str(in_flight)
-            os.environ["SWFR_EVENT_STRIDE"] = "1000000"           # (the timed region carries no per-kernel events: each costs a queue packet)
-        r = S.Renderer(W, H, device=local_rank)
-        r.upload_edges(edges, paths, styles)                      # inputs resident in HBM before the timed region
+            os.environ["SWFR_EVENT_STRIDE"] = "1000000"
         r.render_resident(min(max(args.warmup, 1), 2048))
         sync_all()
         t0 = time.perf_counter()
@@ -302,6 +306,8 @@ def main():
         dt = time.perf_counter() - t0
         tm = r.timing()
         out = None
+        if r1 is not None:
+            r1.close()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

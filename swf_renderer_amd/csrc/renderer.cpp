@@ -216,6 +216,7 @@ struct swfr_renderer {
     int force_chunk_rows = 0;               // SWFR_CHUNK_ROWS: test knob
     int strip_order = 1;                    // SWFR_STRIP_ORDER=0: launch the k2_tiles wavefronts in row-major order (per XCD class)
     int event_stride = 16;                  // SWFR_EVENT_STRIDE: per-kernel HIP events on every n-th resident frame
+    bool event_stride_given = false;        // (set explicitly: short runs do not lower it)
     int fast_limit = 16;                    // rows with more active edges go to k2_rows_slow; the row kernel's instance caps it at its 8 or 16 slots (SWFR_FAST_LIMIT: test knob)
     int tiles_grid = 0;                     // SWFR_TILES_GRID: persistent k2_tiles wavefronts per frame (0 = default)
     // swfr_render_batch: groups of frames rendered by ONE launch per kernel (blockIdx.y = frame); two groups alternate,
@@ -895,7 +896,7 @@ int check_counters(swfr_renderer* r, const uint32_t* counters) {
 // One frame of the resident scene on frame set F as a graph launch: the set's kernels (with the queued-row kernels the scene is
 // known to need) are captured from the set's own stream the first time and replayed afterwards; a new upload, or a change in what
 // the scene needs of the queued-row kernels, captures again.
-void launch_frame_graph(swfr_renderer* r, const swfr_renderer::Scene& sc, swfr_renderer::FrameSet& F) {
+void ensure_frame_graph(swfr_renderer* r, const swfr_renderer::Scene& sc, swfr_renderer::FrameSet& F) {
     const uint64_t key = (r->scene_gen << 16) | (uint64_t(sc.slow_state & 3) << 8) | uint64_t(sc.slow_passes & 0xffu) | (uint64_t(1) << 63);
     if (F.graph_key != key) {
         if (F.graph_exec) { (void)hipGraphExecDestroy(F.graph_exec); F.graph_exec = nullptr; }
@@ -914,6 +915,9 @@ void launch_frame_graph(swfr_renderer* r, const swfr_renderer::Scene& sc, swfr_r
         HIP_CHECK(hipGraphInstantiate(&F.graph_exec, F.graph, nullptr, nullptr, 0));
         F.graph_key = key;
     }
+}
+void launch_frame_graph(swfr_renderer* r, const swfr_renderer::Scene& sc, swfr_renderer::FrameSet& F) {
+    ensure_frame_graph(r, sc, F);
     HIP_CHECK(hipGraphLaunch(F.graph_exec, F.stream));
 }
 
@@ -953,7 +957,7 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
     if (frames > 1)
         while (n_sets < uint32_t(std::min(r->in_flight, 4)) && n_sets < r->sets_ready && r->fs[n_sets].stream && (r->n_targets || r->fs[n_sets].d_fb.ptr)) ++n_sets;
     uint32_t stride = r->event_stride < 1 ? 1u : uint32_t(r->event_stride);
-    if (frames < 64) stride = std::min(stride, 8u);        // (a short run still gets two or three frames with per-kernel times)
+    if (frames < 64 && !r->event_stride_given) stride = std::min(stride, 8u);   // (a short run still gets two or three frames with per-kernel times, unless SWFR_EVENT_STRIDE says otherwise)
     const uint32_t first_timed = std::min(stride / 2, frames - 1);      // (not frame 0: the first frames run before the pipeline is full)
     const uint32_t n_timed = (frames - first_timed + stride - 1) / stride;
     // events: four per timed frame (indexed by the timed frame's ordinal), then begin, end and the joins; created once, never inside
@@ -966,6 +970,10 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
     hipEvent_t ev_begin = r->ev[size_t(n_timed) * 4], ev_end = r->ev[size_t(n_timed) * 4 + 1];
     hipEvent_t* ev_join = &r->ev[size_t(n_timed) * 4 + 2];
     // (no clearing of the counters here: k2_bin zeroes its frame's counters itself)
+    // every frame set's graph exists before the first launch: a call never captures one between two frames (a short first call --
+    // a warm-up of a few frames -- would otherwise leave the capture of the sets it launched with events to the next call)
+    if (frames > 1 && r->use_graphs && sc.slow_verified && !(r->resident_batch >= 2 && stride > frames))
+        for (uint32_t k = 0; k < n_sets; ++k) ensure_frame_graph(r, sc, r->fs[k]);
     HIP_CHECK(hipEventRecord(ev_begin, r->stream));
     order_frames_behind_pending_read(r);
 #ifdef SWFR_BEGIN_WAIT
@@ -1393,7 +1401,7 @@ int swfr_create(uint32_t width, uint32_t height, const swfr_config* cfg, swfr_re
     if (const char* cr = std::getenv("SWFR_CHUNK_ROWS")) r->force_chunk_rows = std::atoi(cr);
     if (const char* so = std::getenv("SWFR_STRIP_ORDER")) r->strip_order = std::atoi(so);
     if (const char* fi = std::getenv("SWFR_FRAMES_IN_FLIGHT")) r->in_flight = std::atoi(fi);
-    if (const char* es = std::getenv("SWFR_EVENT_STRIDE")) r->event_stride = std::atoi(es);
+    if (const char* es = std::getenv("SWFR_EVENT_STRIDE")) { r->event_stride = std::atoi(es); r->event_stride_given = true; }
     if (const char* ug = std::getenv("SWFR_GRAPHS")) r->use_graphs = std::atoi(ug);
 #ifdef SWFR_EMU
     r->use_graphs = 0;                                              // (the emulator's runtime has no graphs)
