@@ -216,6 +216,7 @@ struct Frame2 {
     // layout of the tables below, from the paths' rectangles alone (host: prefix sums over the paths / the tile-rows)
     const uint32_t* path_chunks; const uint32_t* path_slots; const uint32_t* path_inc;   // per path: first chunk, first band slot, first (edge, row) pair
     const uint32_t* band_off;                                          // per tile-row: first entry of its band list
+    const uint32_t* path_bands;                                        // per path: first | last << 16 tile-row of its rectangle (0xffff: none); 16 paths of padding behind the last
     // binning, per frame in flight (kernel-written: k2_bin, k2_rows)
     ChunkInfo* chunks; BandSlot* band_slots; StripDesc* strips;
     uint32_t* strip_cost;                                              // zero between frames (the ordering workgroups of k2_bin clear what they have read)

@@ -216,9 +216,11 @@ __device__ __forceinline__ uint32_t path_chunk_count(const DevPath& P, uint32_t 
 
 __device__ __forceinline__ void order_body(FramePtr F, uint32_t xcd_class);
 constexpr uint32_t BIN_THREADS = 1024;
-constexpr uint32_t BAND_U = 4;                                             // BAND_U * BIN_THREADS / 64 == 64: one wavefront scans a round's counts
+constexpr uint32_t BAND_PER_THREAD = 16;                                  // paths a thread tests per round
+constexpr uint32_t BAND_LIST = 4096;                                      // hits of a round staged at a time
 __device__ __forceinline__ void bin_body(FramePtr F, uint32_t slow_kernels) {
-    __shared__ uint32_t wave_cnt[2][BAND_U * (BIN_THREADS / 64)];
+    __shared__ uint32_t wave_cnt[BIN_THREADS / 64];
+    __shared__ uint32_t band_hits[BAND_LIST];                // a tile-row's hits of one round, in painter's order
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (blockIdx.x == 0 && tid < C2_WORDS) F->counters[tid] = 0;
     if (blockIdx.x >= gridDim.x - XCDS) { order_body(F, blockIdx.x - (gridDim.x - XCDS)); return; }   // the last eight workgroups: the tile pass's launch list
@@ -226,59 +228,74 @@ __device__ __forceinline__ void bin_body(FramePtr F, uint32_t slow_kernels) {
         // ---- the paths that touch tile-row `band`, in painter's order
         const int band = (int)blockIdx.x;
         const uint32_t b0 = F->band_off[band], n_b = F->band_off[band + 1] - b0;
-        // BAND_U paths per thread and round (path = base + u * 1024 + thread: painter's order is (u, wavefront, lane) order); one
-        // barrier per round: the per-(u, wavefront) hit counts alternate between two LDS buffers and every wavefront scans all 64 itself
+        // Two steps per round of BAND_PER_THREAD * 1024 paths (one round for a scene of up to 16 384 paths).  Step 1: every thread tests
+        // sixteen consecutive paths against the host's table of tile-row spans (four bytes a path, 64 contiguous bytes a thread) and
+        // the hits are compacted in painter's order into an LDS list: per-thread counts, one wavefront scan, sixteen wavefront totals.
+        // Step 2: one thread per HIT fetches the path and its style and writes the band entry -- every hit's chain of dependent loads
+        // runs side by side (round 4, before: four paths per thread and three rounds of the whole chain for S2's 10 000 paths, 22 us).
         uint32_t n = 0;
-        const unsigned long long below = (1ull << lane) - 1ull;
-        for (uint32_t base = 0, buf = 0; base < F->n_paths && n < n_b; base += BAND_U * BIN_THREADS, buf ^= 1u) {    // (workgroup-uniform: stops when the list is complete)
-            unsigned long long bal[BAND_U];
+        const uint32_t n_paths = F->n_paths;
+        for (uint32_t base = 0; base < n_paths && n < n_b; base += BAND_PER_THREAD * BIN_THREADS) {    // (workgroup-uniform: stops when the list is complete)
+            const uint32_t p0 = base + (uint32_t)tid * BAND_PER_THREAD;
+            uint32_t mask = 0;
+            if (p0 < n_paths) {                                          // (the table has sixteen "no tile-row" entries behind the last path)
+                const uint4* t4 = reinterpret_cast<const uint4*>(F->path_bands + p0);
+                const uint4 q[4] = {t4[0], t4[1], t4[2], t4[3]};
 #pragma unroll
-            for (uint32_t u = 0; u < BAND_U; ++u) {
-                const uint32_t p = base + u * BIN_THREADS + (uint32_t)tid;
-                bool hit = false;
-                if (p < F->n_paths) {
-                    const DevPath& Q = F->paths[p];
-                    const int y0 = Q.y_min, y1 = Q.y_max;
-                    hit = y1 > y0 && Q.x_max > Q.x_min && y0 / TILE_H <= band && band <= (y1 - 1) / TILE_H;
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t v[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) if ((v[i] & 0xffffu) <= (uint32_t)band && (uint32_t)band <= (v[i] >> 16)) mask |= 1u << (4 * k + i);
                 }
-                bal[u] = __ballot(hit);
-                if (lane == 0) wave_cnt[buf][u * (BIN_THREADS / 64) + (uint32_t)wave] = (uint32_t)__popcll(bal[u]);
             }
+            const uint32_t cnt = (uint32_t)__popc(mask);
+            const uint32_t incl = (uint32_t)wave_scan_incl((int)cnt);
+            if (lane == 63) wave_cnt[wave] = incl;
             __syncthreads();
-            const uint32_t v = wave_cnt[buf][lane];
-            const uint32_t incl = (uint32_t)wave_scan_incl((int)v);
-#pragma unroll
-            for (uint32_t u = 0; u < BAND_U; ++u) {
-                const uint32_t p = base + u * BIN_THREADS + (uint32_t)tid;
-                const uint32_t at = n + (uint32_t)__builtin_amdgcn_readlane((int)(incl - v), (int)(u * (BIN_THREADS / 64) + (uint32_t)wave))
-                                  + (uint32_t)__popcll(bal[u] & below);
-                if (!((bal[u] >> lane) & 1ull) || at >= n_b) continue;
-                const DevPath P = F->paths[p];
-                const uint32_t slot = b0 + at;
-                const BandEntry2 e = make_band_entry2(P, p, (uint32_t)band, F);
-                F->band_list[slot] = e;
-                BandSlot bs; bs.path = p; bs.slot = slot; bs.band = (uint32_t)band; bs.pad = 0;
-                F->band_slots[F->path_slots[p] + (uint32_t)(band - P.y_min / TILE_H)] = bs;
-                if (P.kind == SWFR_PATH_BOXES) {
-                    uint8_t* out = F->cls + (size_t)STRIPS_PER_TILE * F->tiles_x * b0 + at;    // [tile column][strip][entry] inside the tile-row
-                    const int ty0 = band * TILE_H, tile_y1 = min(ty0 + TILE_H, F->height);
-                    const uint32_t opq = (e.flags & BE_OPAQUE_COVER) ? CLS_OPAQUE : 0u;
-                    const swfr_edge bx = F->raw[P.first_edge];             // (only looked at when the path is a single box)
-                    const bool one_box = P.n_edges == 1 && bx.y1 <= ty0 * 256 && bx.y2 >= tile_y1 * 256;
-                    uint32_t local_trow = 0;
-                    const bool own = owns_band(F, band, local_trow);
-                    for (int tc = P.x_min / TILE_W; tc <= (P.x_max - 1) / TILE_W; ++tc) {
-                        const int tx0 = tc * TILE_W, tile_x1 = min(tx0 + TILE_W, F->width);
-                        uint32_t f = CLS_BOX | CLS_NONEMPTY | CLS_NOTFULL;
-                        if (one_box && bx.x1 <= tx0 * 256 && bx.x2 >= tile_x1 * 256) f = CLS_NONEMPTY | opq;     // the box contains the whole tile: full cover
-                        for (int sp = 0; sp < STRIPS_PER_TILE; ++sp) {
-                            out[(size_t)(tc * STRIPS_PER_TILE + sp) * n_b] = (uint8_t)f;
-                            if (own && ty0 + sp * STRIP_H < F->height) strip_top_note(F, (local_trow * (uint32_t)F->tiles_x + (uint32_t)tc) * STRIPS_PER_TILE + (uint32_t)sp, at + 1u, f, e.solid);
+            uint32_t before = 0, total = 0;
+            for (int w = 0; w < (int)(BIN_THREADS / 64); ++w) { const uint32_t t = wave_cnt[w]; if (w < wave) before += t; total += t; }
+            const uint32_t first = before + incl - cnt;                  // this thread's first hit among the round's
+            for (uint32_t lo = 0; lo < total; lo += BAND_LIST) {         // (workgroup-uniform; one window unless a tile-row has more than 4 096 hits in a round)
+                uint32_t m = mask, idx = first;
+                while (m) {
+                    const uint32_t bit = (uint32_t)__ffs((int)m) - 1u; m &= m - 1u;
+                    if (idx >= lo && idx < lo + BAND_LIST) band_hits[idx - lo] = p0 + bit;
+                    ++idx;
+                }
+                __syncthreads();
+                const uint32_t in_window = min(total - lo, BAND_LIST);
+                for (uint32_t i = (uint32_t)tid; i < in_window; i += BIN_THREADS) {
+                    const uint32_t p = band_hits[i], at = n + lo + i;
+                    if (at >= n_b) continue;
+                    const DevPath P = F->paths[p];
+                    const uint32_t slot = b0 + at;
+                    const BandEntry2 e = make_band_entry2(P, p, (uint32_t)band, F);
+                    F->band_list[slot] = e;
+                    BandSlot bs; bs.path = p; bs.slot = slot; bs.band = (uint32_t)band; bs.pad = 0;
+                    F->band_slots[F->path_slots[p] + (uint32_t)(band - P.y_min / TILE_H)] = bs;
+                    if (P.kind == SWFR_PATH_BOXES) {
+                        uint8_t* out = F->cls + (size_t)STRIPS_PER_TILE * F->tiles_x * b0 + at;    // [tile column][strip][entry] inside the tile-row
+                        const int ty0 = band * TILE_H, tile_y1 = min(ty0 + TILE_H, F->height);
+                        const uint32_t opq = (e.flags & BE_OPAQUE_COVER) ? CLS_OPAQUE : 0u;
+                        const swfr_edge bx = F->raw[P.first_edge];             // (only looked at when the path is a single box)
+                        const bool one_box = P.n_edges == 1 && bx.y1 <= ty0 * 256 && bx.y2 >= tile_y1 * 256;
+                        uint32_t local_trow = 0;
+                        const bool own = owns_band(F, band, local_trow);
+                        for (int tc = P.x_min / TILE_W; tc <= (P.x_max - 1) / TILE_W; ++tc) {
+                            const int tx0 = tc * TILE_W, tile_x1 = min(tx0 + TILE_W, F->width);
+                            uint32_t f = CLS_BOX | CLS_NONEMPTY | CLS_NOTFULL;
+                            if (one_box && bx.x1 <= tx0 * 256 && bx.x2 >= tile_x1 * 256) f = CLS_NONEMPTY | opq;     // the box contains the whole tile: full cover
+                            for (int sp = 0; sp < STRIPS_PER_TILE; ++sp) {
+                                out[(size_t)(tc * STRIPS_PER_TILE + sp) * n_b] = (uint8_t)f;
+                                if (own && ty0 + sp * STRIP_H < F->height) strip_top_note(F, (local_trow * (uint32_t)F->tiles_x + (uint32_t)tc) * STRIPS_PER_TILE + (uint32_t)sp, at + 1u, f, e.solid);
+                            }
                         }
                     }
                 }
+                __syncthreads();                                         // (the list is rewritten by the next window / round)
             }
-            n += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            n += total;
+            __syncthreads();                                             // (the wavefront totals are rewritten by the next round)
         }
         if (n != n_b && tid == 0) atomicOr(&F->counters[C2_ERROR], E2_ROW_TABLE);      // the host counted the same rectangles: cannot happen
         return;
@@ -339,7 +356,8 @@ __device__ __forceinline__ void bin_body(FramePtr F, uint32_t slow_kernels) {
 // and share its L2.  Ranks: heaviest first by the cost k2_rows added up during the PREVIOUS frame rendered with these buffers (a
 // scheduling hint only -- a scene's first frame runs in row-major order); the costs are cleared for this frame's k2_rows.
 // One 1024-thread workgroup per XCD class (the last XCDS workgroups of the k2_bin launch).  Round 4: a stable partition into eight
-// cost ranges by wave ballots -- one round of loads, per-wavefront counts in LDS, one scan by one wavefront, two barriers -- instead of
+// cost ranges -- one round of loads, per-wavefront counts (eight byte counters in two words, one DPP scan each) in LDS, one scan by one
+// wavefront, two barriers -- instead of
 // a 128-bucket counting sort with returning LDS atomics (these workgroups were k2_bin's long pole: 9-11 us beside the others' 3-4).
 constexpr uint32_t ORDER_RANGES = 8;
 __device__ __forceinline__ uint32_t order_range(uint32_t cost) {          // 0 = heaviest
@@ -367,37 +385,47 @@ __device__ __forceinline__ void order_body(FramePtr F, uint32_t x) {
             F->strips[(size_t)(n_mine + j) * XCDS + x] = sd;
         }
     __syncthreads();                                       // rowinfo is complete
-    // strip i of the class: tile-row x + 8 * (i / per_row), position i % per_row in it
-    auto strip_of = [&](uint32_t i) { const uint32_t j = i / per_row; return (x + j * XCDS) * per_row + (i - j * per_row); };
-    const unsigned long long below = (1ull << lane) - 1ull;
+    // strip i of the class: tile-row x + 8 * (i / per_row), position i % per_row in it.  A thread's strips are 1024 apart: one division
+    // per thread and round, then (row, position) advance by the (workgroup-uniform) quotient and remainder of 1024 / per_row
+    // (three divisions per strip made these workgroups k2_bin's long pole on S2: 18.6 us of the kernel's 19.4).
+    const uint32_t dq = BIN_THREADS / per_row, dr = BIN_THREADS - dq * per_row;
+    auto advance = [&](uint32_t& j, uint32_t& pos) { j += dq; pos += dr; if (pos >= per_row) { pos -= per_row; ++j; } };
+    auto strip_at = [&](uint32_t j, uint32_t pos) { return (x + j * XCDS) * per_row + pos; };
     for (uint32_t base = 0; base < n_mine; base += ORDER_U * BIN_THREADS) {                // (one round unless a class has more than 16 384 strips)
         const uint32_t n_round = min(n_mine - base, ORDER_U * BIN_THREADS), U = (n_round + BIN_THREADS - 1) / BIN_THREADS;   // workgroup-uniform
         unsigned long long ranges = 0;                     // this thread's strips' cost ranges, three bits each
         uint32_t behind[ORDER_U];                          // strips of the same range before this one in its wavefront
+        const uint32_t i0 = base + (uint32_t)tid, j0 = i0 / per_row, pos0 = i0 - j0 * per_row;
         if (by_cost) {
             // every cost is read once (all of a thread's loads in flight together) and cleared
             uint32_t c[ORDER_U];
+            uint32_t j = j0, pos = pos0;
 #pragma unroll
             for (uint32_t u = 0; u < ORDER_U; ++u) {
                 c[u] = 0;
                 if (u >= U) continue;                      // workgroup-uniform
                 const uint32_t i = base + u * BIN_THREADS + (uint32_t)tid;
-                if (i < n_mine) { const uint32_t w = strip_of(i); c[u] = F->strip_cost[w]; }
+                if (i < n_mine) c[u] = F->strip_cost[strip_at(j, pos)];
+                advance(j, pos);
             }
+            j = j0; pos = pos0;
 #pragma unroll
             for (uint32_t u = 0; u < ORDER_U; ++u) {
                 behind[u] = 0;
                 if (u >= U) continue;
                 const uint32_t i = base + u * BIN_THREADS + (uint32_t)tid;
                 const bool valid = i < n_mine;
-                if (valid && c[u]) F->strip_cost[strip_of(i)] = 0;
+                if (valid && c[u]) F->strip_cost[strip_at(j, pos)] = 0;
+                advance(j, pos);
                 const uint32_t k = order_range(c[u]);
                 ranges |= (unsigned long long)k << (3 * u);
-                for (uint32_t q = 0; q < ORDER_RANGES; ++q) {                            // every wavefront votes on every range
-                    const unsigned long long b = __ballot(valid && k == q);
-                    if (lane == 0) cnt[q][u][wave] = (uint32_t)__popcll(b);
-                    if (k == q) behind[u] = (uint32_t)__popcll(b & below);
-                }
+                // the wavefront's strips per range, and this strip's place among those of its range: eight 8-bit counters (a
+                // wavefront has at most 64 strips of one range) packed in two words, one inclusive scan of each
+                const uint32_t sh = 8u * (k & 3u), one = valid ? 1u << sh : 0u;
+                const uint32_t lo = (uint32_t)wave_scan_incl((int)(k < 4u ? one : 0u)), hi = (uint32_t)wave_scan_incl((int)(k < 4u ? 0u : one));
+                behind[u] = (((k < 4u ? lo : hi) >> sh) & 0xffu) - 1u;                   // (unused when !valid)
+                const uint32_t tot_lo = (uint32_t)__builtin_amdgcn_readlane((int)lo, 63), tot_hi = (uint32_t)__builtin_amdgcn_readlane((int)hi, 63);
+                if (lane < (int)ORDER_RANGES) cnt[lane][u][wave] = ((lane < 4 ? tot_lo : tot_hi) >> (8 * (lane & 3))) & 0xffu;
             }
             __syncthreads();
             if (tid < 64) {                                // exclusive prefix in (range, round, wavefront) order by one wavefront
@@ -417,20 +445,21 @@ __device__ __forceinline__ void order_body(FramePtr F, uint32_t x) {
 #pragma unroll
             for (uint32_t u = 0; u < ORDER_U; ++u) behind[u] = 0;
         }
+        uint32_t j = j0, pos = pos0;
 #pragma unroll
         for (uint32_t u = 0; u < ORDER_U; ++u) {
             if (u >= U) continue;
             const uint32_t i = base + u * BIN_THREADS + (uint32_t)tid;
-            if (i >= n_mine) continue;
-            uint32_t rank = i;                                               // row-major inside the class
-            if (by_cost) rank = base + cnt[(uint32_t)(ranges >> (3 * u)) & 7u][u][wave] + behind[u];
-            const uint32_t j = i / per_row;
-            uint2 ri;
-            if (j < 256u) ri = rowinfo[j]; else { const uint32_t trow = (x + j * XCDS) * bc + bi, b0 = F->band_off[trow]; ri = make_uint2(b0, F->band_off[trow + 1] - b0); }
-            // (the strip's tile column and local tile-row travel with it: k2_tiles divides nothing)
-            const uint32_t pos = i - j * per_row;
-            StripDesc sd; sd.wg = strip_of(i); sd.band_begin = ri.x; sd.n_b = ri.y; sd.pad = (pos / STRIPS_PER_TILE) | ((x + j * XCDS) << 16);
-            F->strips[(size_t)rank * XCDS + x] = sd;
+            if (i < n_mine) {
+                uint32_t rank = i;                                           // row-major inside the class
+                if (by_cost) rank = base + cnt[(uint32_t)(ranges >> (3 * u)) & 7u][u][wave] + behind[u];
+                uint2 ri;
+                if (j < 256u) ri = rowinfo[j]; else { const uint32_t trow = (x + j * XCDS) * bc + bi, b0 = F->band_off[trow]; ri = make_uint2(b0, F->band_off[trow + 1] - b0); }
+                // (the strip's tile column and local tile-row travel with it: k2_tiles divides nothing)
+                StripDesc sd; sd.wg = strip_at(j, pos); sd.band_begin = ri.x; sd.n_b = ri.y; sd.pad = (pos / STRIPS_PER_TILE) | ((x + j * XCDS) << 16);
+                F->strips[(size_t)rank * XCDS + x] = sd;
+            }
+            advance(j, pos);
         }
         __syncthreads();                                   // (cnt is rewritten by the next round)
     }

@@ -581,6 +581,7 @@ struct SceneLayout {
     uint32_t max_path_edges = 0;
     int shader_level = 0;       // 0 solid colours only, 1 + bitmap fills, 2 + gradients: picks the tile kernel's instance
     std::vector<uint32_t> chunk_base, slot_base, inc_base, band_off;
+    std::vector<uint32_t> band_span;     // per path: first tile-row | last tile-row << 16 of its rectangle (0xffff | 0 << 16: none); padded to a multiple of 16 paths
     std::vector<DevFilter> filters;
     std::vector<DevGradient> gradients;
     std::vector<int32_t> fparams;
@@ -616,6 +617,7 @@ void layout_scene(const swfr_renderer* r, const swfr_edge* edges, size_t n_edges
     // array over the paths' tile-row ranges)
     L.n_chunks = L.n_slots = L.n_rows = 0; L.max_path_edges = 0;
     L.chunk_base.assign(n_paths + 1, 0); L.slot_base.assign(n_paths + 1, 0); L.inc_base.assign(n_paths + 1, 0); L.band_off.assign(L.n_bands + 2, 0);
+    L.band_span.assign((n_paths + 15) / 16 * 16 + 16, 0xffffu);
     for (size_t i = 0; i < n_paths; ++i) {
         const swfr_path& p = paths[i];
         L.chunk_base[i] = uint32_t(L.n_chunks); L.slot_base[i] = uint32_t(L.n_slots);
@@ -626,6 +628,7 @@ void layout_scene(const swfr_renderer* r, const swfr_edge* edges, size_t n_edges
             const size_t b0 = size_t(p.y_min / TILE_H), b1 = size_t((p.y_max - 1) / TILE_H);
             L.n_slots += b1 - b0 + 1;
             ++L.band_off[b0 + 1]; --L.band_off[b1 + 2];
+            L.band_span[i] = uint32_t(b0) | (uint32_t(b1) << 16);
         }
         if (p.kind == SWFR_PATH_TOR) { L.n_rows += size_t(p.y_max - p.y_min); L.max_path_edges = std::max(L.max_path_edges, p.n_edges); }
     }
@@ -688,7 +691,7 @@ size_t scene_arena_bytes(const SceneLayout& L, size_t n_edges, size_t n_paths, s
     // (a scene of solid colours only: the styles' {kind, pixel} heads, no filter records)
     return P(n_edges * sizeof(swfr_edge)) + P(n_paths * sizeof(swfr_path)) + (L.shader_level == 0 ? P(n_styles * 8) : P(n_styles * sizeof(swfr_style)) + P(n_styles * sizeof(DevFilter))) +
            P(L.fparams.size() * sizeof(int32_t)) + P(L.gradients.size() * sizeof(DevGradient)) + 3 * P((n_paths + 1) * sizeof(uint32_t)) +
-           P((L.n_bands + 2) * sizeof(uint32_t));
+           P((L.n_bands + 2) * sizeof(uint32_t)) + P(L.band_span.size() * sizeof(uint32_t));
 }
 // pushes that part and fills the descriptor's scene fields; the edge array's host staging copy is returned (for tagging)
 swfr_edge* push_scene(SceneArena& A, const SceneLayout& L, const swfr_edge* edges, size_t n_edges, const swfr_path* paths, size_t n_paths,
@@ -715,6 +718,7 @@ swfr_edge* push_scene(SceneArena& A, const SceneLayout& L, const swfr_edge* edge
     f.path_slots = static_cast<uint32_t*>(A.push(L.slot_base.data(), (n_paths + 1) * sizeof(uint32_t)));
     f.path_inc = static_cast<uint32_t*>(A.push(L.inc_base.data(), (n_paths + 1) * sizeof(uint32_t)));
     f.band_off = static_cast<uint32_t*>(A.push(L.band_off.data(), (L.n_bands + 2) * sizeof(uint32_t)));
+    f.path_bands = static_cast<uint32_t*>(A.push(L.band_span.data(), L.band_span.size() * sizeof(uint32_t)));
     return staged;
 }
 void fill_frame_sizes(const swfr_renderer* r, const SceneLayout& L, size_t n_edges, size_t n_paths, Frame2& f) {
