@@ -547,6 +547,23 @@ def test_s2_8k_100k_edges_vs_oracle():
     assert diff_stats(img, _oracle_polys(fx, cols, W, H)) == (0, 0)
 
 
+def test_twenty_thousand_paths_in_three_tile_rows_vs_oracle():
+    """k2_bin builds a tile-row's list in rounds of 16 384 paths and windows of 4 096 hits: here 20 000 small stars crowd a 640x48
+    frame, so every tile-row's list takes two rounds and more than one window (S2's 10 000 paths: one round, one window)."""
+    import swf_renderer_amd as S
+    cfg = dict(seed=77, n_shapes=20000, width=640, height=48, rmin=2.0, rmax=9.0)
+    W, H, fx, cols, (edges, paths, styles) = _s_scene(cfg)
+    assert len(paths) > 16384
+    r = S.Renderer(W, H)
+    r.render_edges(edges, paths, styles)
+    img = r.read_image(premultiplied=True)
+    r.render_resident(3)                                                  # (the strips' launch order by the previous frame's costs)
+    again = r.read_image(premultiplied=True)
+    r.close()
+    assert diff_stats(img, _oracle_polys(fx, cols, W, H)) == (0, 0)
+    assert (again == img).all()
+
+
 def test_s2_8k_sharded_over_eight_band_handles_vs_oracle():
     """BASELINE.json config 5 on one GPU: the 100k-edge 8K scene rasterized by eight handles, handle k taking the tile-rows
     t with t % 8 == k exactly as rank k of an 8-GPU node does; the eight slabs assembled by
