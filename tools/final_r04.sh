@@ -18,6 +18,8 @@ cd $R
 timeout -k 10 300 python tools/config_bench.py > gpurun_out/${TAG}_config_bench.txt 2>&1; tail -2 gpurun_out/${TAG}_config_bench.txt | cut -c1-300
 bash tools/build_variant.sh trace -DSWFR_TRACE > /dev/null 2>&1
 for w in s1 s2; do TRACE_BUILD=trace timeout -k 10 120 python tools/trace_wg.py $w 2>&1 | grep -v amdgpu > gpurun_out/${TAG}_wg_timeline_$w.txt; done
+for w in config3 config2h; do TRACE_BUILD=trace SWFR_CHUNK_ROWS=16 timeout -k 10 120 python tools/trace_wg.py $w 2>&1 | grep -v amdgpu > gpurun_out/${TAG}_wg_timeline_$w.txt; done
+timeout -k 10 300 python tools/short_run_probe.py 2>&1 | grep -v amdgpu > gpurun_out/${TAG}_short_run.txt
 SWFR_FRAMES_IN_FLIGHT=1 timeout -k 10 300 python tools/pipeline_timing.py 2>/dev/null | tail -1 > gpurun_out/${TAG}_blocks_timing.json
 timeout -k 10 300 python bench.py --workload s2 --steps 100 --warmup 10 --no-cpu-baseline --no-batched > gpurun_out/${TAG}_bench_s2.json 2>/dev/null; cut -c1-200 gpurun_out/${TAG}_bench_s2.json
 for a in rotate root; do
