@@ -1116,6 +1116,18 @@ __device__ __forceinline__ uint32_t bilinear_mix(const BilinearTap& t, const uin
     }
     return out;
 }
+// the same for a sample whose four texels all lie inside the bitmap (no outside flags to apply)
+__device__ __forceinline__ uint32_t bilinear_mix_inside(uint32_t wf, uint32_t c00, uint32_t c10, uint32_t c01, uint32_t c11) {
+    const uint32_t wx = wf & 0x7fu, wy = (wf >> 7) & 0x7fu;
+    const uint32_t w11 = __umul24(wx, wy), w10 = (wx << 7) - w11, w01 = (wy << 7) - w11, w00 = 16384u - (wx << 7) - w01;   // (128 - wx)(128 - wy) etc.
+    uint32_t out = 0;
+#pragma unroll
+    for (int sh = 0; sh < 32; sh += 8) {
+        const uint32_t acc = __umul24((c00 >> sh) & 255u, w00) + __umul24((c10 >> sh) & 255u, w10) + __umul24((c01 >> sh) & 255u, w01) + __umul24((c11 >> sh) & 255u, w11);
+        out |= (acc >> 14) << sh;                                  // (the weights add up to 2^14: acc >> 14 <= 255)
+    }
+    return out;
+}
 __device__ __forceinline__ uint32_t shade_bitmap(uint32_t style_index, const Sources& src, int px, int py) {
     const DevFilter& flt = src.filters[style_index];
     const struct { const uint32_t* pixels; uint32_t width, height; } bm = {flt.pixels, flt.width, flt.height};
@@ -1281,37 +1293,44 @@ __device__ __forceinline__ void blend8(uint32_t (&px)[8], const uint32_t (&al)[8
         const int cgl = lane & 15, tx0 = cx0 - 4 * cgl;
         uint32_t* tq = bq + 64 * (lane >> 4);                        // this pixel row's 64 colours (bq: 4 rows x 64)
         const uint32_t* __restrict__ texels = flt.pixels;            // (wave-uniform base: scalar address + 32-bit lane offsets)
+        // pixman's 16.16 sample position of the lane's first sample (column tx0 + cgl, row cy0), evaluated once; the other seven are
+        // wave-uniform steps away (16 columns, 4 rows): 64-bit additions instead of four 32 x 32 -> 64 multiplies per sample (the
+        // quarter-rate multiplies were a quarter of this kernel's vector issue time) -- the same integers, modulo 2^64
+        const long long bx00 = flt.base_x + (long long)(tx0 + cgl) * flt.m00 + (long long)cy0 * flt.m01 - 0x8000;
+        const long long by00 = flt.base_y + (long long)(tx0 + cgl) * flt.m10 + (long long)cy0 * flt.m11 - 0x8000;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             if (!(__ballot((al[4 * h] | al[4 * h + 1] | al[4 * h + 2] | al[4 * h + 3]) != 0u))) continue;       // wave-uniform: nothing to paint in these rows
-            BilinearTap t[4];
-            uint32_t c[4][4];
             // Every sample of the wavefront strictly inside the bitmap -- the usual strip -- needs no clamping, no wrap and no outside
-            // flags: the four texels are o, o + 1, o + width, o + width + 1.  Anything else takes the general routine.
-            {
-                const int bw1 = (int)flt.width - 1, bh1 = (int)flt.height - 1;
-                bool inside = flt.width < (1u << 23) && flt.height < (1u << 23);
-                // (the taps are written as if inside -- no temporaries kept beside them -- and redone by the general routine otherwise)
+            // flags: the four texels are o, o + 1, o + width, o + width + 1 (ONE lane offset, two scalar bases, two immediate offsets).
+            // Anything else takes the general routine.
+            const int bw1 = (int)flt.width - 1, bh1 = (int)flt.height - 1;
+            bool inside = flt.width < (1u << 23) && flt.height < (1u << 23);
+            uint32_t o[4], wf[4];
 #pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const long long bxp = bx00 + (long long)(16 * i) * flt.m00 + (long long)(4 * h) * flt.m01;
+                const long long byp = by00 + (long long)(16 * i) * flt.m10 + (long long)(4 * h) * flt.m11;
+                const int x0 = (int)(bxp >> 16), y0 = (int)(byp >> 16);
+                inside = inside && (unsigned)x0 < (unsigned)bw1 && (unsigned)y0 < (unsigned)bh1;
+                o[i] = __umul24((uint32_t)y0, flt.width) + (uint32_t)x0;          // (meaningless unless inside)
+                wf[i] = ((uint32_t)bxp >> 9 & 0x7fu) | (((uint32_t)byp >> 9 & 0x7fu) << 7);
+            }
+            if (__ballot(!inside) == 0ull) {                       // wave-uniform
+                const uint32_t* __restrict__ row_b = texels + flt.width;
+                uint32_t c[4][4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { c[i][0] = texels[o[i]]; c[i][1] = (texels + 1)[o[i]]; c[i][2] = row_b[o[i]]; c[i][3] = (row_b + 1)[o[i]]; }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) tq[16 * i + cgl] = bilinear_mix_inside(wf[i], c[i][0], c[i][1], c[i][2], c[i][3]);
+            } else {
+#pragma unroll 1
                 for (int i = 0; i < 4; ++i) {
-                    const int px_ = tx0 + 16 * i + cgl, py_ = cy0 + 4 * h;
-                    const long long bxp = flt.base_x + (long long)px_ * flt.m00 + (long long)py_ * flt.m01 - 0x8000;
-                    const long long byp = flt.base_y + (long long)px_ * flt.m10 + (long long)py_ * flt.m11 - 0x8000;
-                    const int x0 = (int)(bxp >> 16), y0 = (int)(byp >> 16);
-                    inside = inside && (unsigned)x0 < (unsigned)bw1 && (unsigned)y0 < (unsigned)bh1;
-                    const uint32_t o = __umul24((uint32_t)y0, flt.width) + (uint32_t)x0;
-                    t[i].o[0][0] = o; t[i].o[1][0] = o + 1u; t[i].o[0][1] = o + flt.width; t[i].o[1][1] = o + flt.width + 1u;
-                    t[i].wf = ((uint32_t)bxp >> 9 & 0x7fu) | (((uint32_t)byp >> 9 & 0x7fu) << 7);
-                }
-                if (__ballot(!inside) != 0ull) {                   // wave-uniform
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) bilinear_taps(flt, tx0 + 16 * i + cgl, cy0 + 4 * h, t[i]);
+                    BilinearTap t;
+                    bilinear_taps(flt, tx0 + 16 * i + cgl, cy0 + 4 * h, t);
+                    tq[16 * i + cgl] = bilinear_mix(t, texels + t.o[0][0], texels + t.o[1][0], texels + t.o[0][1], texels + t.o[1][1]);
                 }
             }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { c[i][0] = texels[t[i].o[0][0]]; c[i][1] = texels[t[i].o[1][0]]; c[i][2] = texels[t[i].o[0][1]]; c[i][3] = texels[t[i].o[1][1]]; }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) tq[16 * i + cgl] = bilinear_mix(t[i], &c[i][0], &c[i][1], &c[i][2], &c[i][3]);
             lds_barrier();
             const uint4 mine = *reinterpret_cast<const uint4*>(tq + 4 * cgl);
             lds_barrier();                                        // (the next half / the next path rewrites the rows)
