@@ -191,7 +191,9 @@ struct swfr_renderer {
     };
     FrameSet fs[4];
     uint64_t scene_gen = 0;                 // counts uploads into scene slot 0
-    int resident_batch = 0;                 // SWFR_RESIDENT_BATCH: frames per kernel launch of swfr_render_resident (blockIdx.y = frame; 0/1: one launch chain per frame)
+    int resident_batch = 2;                 // SWFR_RESIDENT_BATCH: frames per kernel launch of swfr_render_resident (blockIdx.y = frame; 0/1: one launch chain per frame).
+                                            // Two since round 4 (calls without per-kernel events only): half the launches fill the pipeline sooner -- 20 frames 640 us instead of 690,
+                                            // 300 frames alike (tools/short_run_probe.py); four per launch lose the overlap of consecutive groups (33.9 us per frame)
 #ifdef SWFR_EMU
     int use_graphs = 0;                     // (the emulator's runtime has no graphs)
 #else
@@ -993,6 +995,7 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
     while (rb > 1 && (rb > n_sets || n_sets % rb != 0)) --rb;
     const bool batched = rb > 1 && frames >= 2;
     uint32_t last_set = (frames - 1) % n_sets;
+    int64_t last_on[4] = {-1, -1, -1, -1};                 // per frame set's stream: the last launch of this call it carries (none: -1)
     if (batched) {
         const uint32_t groups = n_sets / rb;
         uint32_t gi = 0;
@@ -1005,6 +1008,7 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
             if (sc.n_chunks && sc.slow_state != 1) launch2_rows_slow(st, fh, cnt, 1024u, sc.slow_state == 2 ? 0u : 256u, sc.slow_passes);
             launch2_tiles(st, fh, cnt, uint32_t(sc.n_strip_slots), r->tiles_grid > 0 ? uint32_t(r->tiles_grid) : ~0u, sc.shader_level, nullptr);
             last_set = g * rb + cnt - 1;
+            last_on[g * rb] = int64_t(gi);
         }
     }
     for (uint32_t f = 0; f < frames && !batched; ++f) {
@@ -1012,8 +1016,10 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
         const bool timed = f >= first_timed && (f - first_timed) % stride == 0;   // per-kernel events on every stride-th frame (each costs a queue packet)
         if (!timed && frames > 1 && r->use_graphs && sc.slow_verified) launch_frame_graph(r, sc, F);
         else launch_frame(r, sc, F, nullptr, timed ? &r->ev[size_t((f - first_timed) / stride) * 4] : nullptr);
+        last_on[f % n_sets] = int64_t(f);
     }
-    for (uint32_t k = 1; k < n_sets; ++k) {
+    for (uint32_t k = 1; k < n_sets; ++k) {                // (only the streams that carried something join)
+        if (last_on[k] < 0) continue;
         HIP_CHECK(hipEventRecord(ev_join[k - 1], r->fs[k].stream));
         HIP_CHECK(hipStreamWaitEvent(r->stream, ev_join[k - 1], 0));
     }
@@ -1026,11 +1032,14 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
     // The other sets' streams are waited for too, in the order their last frames finish: the runtime then knows them idle, and a
     // hipDeviceSynchronize behind this call (torch.cuda.synchronize()) costs 3 us instead of 47 (it drains every stream it has not seen
     // idle, 12 us apiece).  All but the last of these waits return while the GPU is still at the call's last frames.
-    if (frames > 1 && !batched)
-        for (uint32_t back = std::min(frames, n_sets); back-- > 0;) {
-            const uint32_t k = (frames - 1 - back) % n_sets;                 // the set of the frame `back` before the last
-            if (k != 0 && r->fs[k].stream) HIP_CHECK(hipStreamSynchronize(r->fs[k].stream));
-        }
+    for (;;) {
+        int pick = -1;
+        for (uint32_t k = 1; k < n_sets; ++k)
+            if (last_on[k] >= 0 && (pick < 0 || last_on[k] < last_on[pick])) pick = int(k);
+        if (pick < 0) break;
+        if (r->fs[pick].stream) HIP_CHECK(hipStreamSynchronize(r->fs[pick].stream));
+        last_on[pick] = -1;
+    }
     HIP_CHECK(hipStreamSynchronize(r->stream));
     r->fb_cur = r->n_targets ? r->targets[last_set % r->n_targets] : r->fs[last_set].d_fb.ptr;
     uint32_t timed_frames = 0;
