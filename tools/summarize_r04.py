@@ -98,7 +98,7 @@ if os.path.exists(os.path.join(OUT, tag + "_bench.json")):
     bench = json.loads([l for l in open(os.path.join(OUT, tag + "_bench.json")).read().splitlines() if l.startswith("{")][-1])
 L.append("**S1, per kernel** (rocprofv3 `--kernel-trace --stats`; PMC `FETCH_SIZE` / `WRITE_SIZE` in their own passes, FETCH doubled for gfx950; SQ counters per wavefront):")
 L.append("")
-L.append("| kernel | one frame in flight, us (calls) | four in flight, us | of the 8 TB/s roof (33 353 408 B / duration) | HBM bytes per launch (fetch + write) | wavefronts | VALU / SALU / LDS per wavefront |")
+L.append("| kernel | one frame in flight, us (calls) | the bench's mode: two frames per launch, two launches in flight, us per launch | of the 8 TB/s roof (33 353 408 B / duration) | HBM bytes per launch (fetch + write) | wavefronts | VALU / SALU / LDS per wavefront |")
 L.append("|---|---|---|---|---|---|---|")
 tot_traffic, tot_us = 0, 0.0
 for k in ("swfr::k2_bin_b", "swfr::k2_rows_b", "swfr::k2_tiles_solid_b"):
