@@ -48,7 +48,7 @@ for t in (tag, tag + "_large", tag + "_magnified"):
     subprocess.call([sys.executable, os.path.join(ROOT, "tools", "profile_r02.py"), t], stdout=subprocess.DEVNULL)
 # ---- plain copies
 for name in ("bench_driver_command.json", "bench_s2.json", "bench_gloo_2ranks_one_gpu_rotate.json", "bench_gloo_2ranks_one_gpu_root.json", "config_bench.txt",
-             "wg_timeline_s1.txt", "wg_timeline_s2.txt", "blocks_timing.json", "tile_stats_s1.txt", "store_shape.txt", "sq_detail.txt", "batched_s1.json", "batched_s0.json",
+             "wg_timeline_s1.txt", "wg_timeline_s2.txt", "wg_timeline_config3.txt", "wg_timeline_config2h.txt", "short_run.txt", "blocks_timing.json", "tile_stats_s1.txt", "store_shape.txt", "sq_detail.txt", "batched_s1.json", "batched_s0.json",
              "lib_sha16.txt"):
     src = os.path.join(G, "%s_%s" % (tag, name))
     if os.path.exists(src) and os.path.getsize(src):
