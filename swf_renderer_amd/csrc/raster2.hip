@@ -1446,7 +1446,17 @@ __device__ __forceinline__ void tiles3_body(FramePtr FR, uint32_t* fb_to) {
         // ---- occlusion: everything below the topmost opaque full cover is invisible in this strip -- and when nothing paints above it
         //      (or nothing paints at all) the strip is that colour: no walk.  The record is cleared for the next frame once read.
         const uint32_t cover_pos = (uint32_t)(top.cover >> 32);
-        if (lane == 0 && top.any != 0u) { StripTop z; z.any = 0u; z.pad = 0u; z.cover = 0ull; FR->strip_top[wg] = z; }      // (depends on the loaded value: never overtakes the read)
+        if (lane == 0 && top.any != 0u) {                                  // (depends on the loaded value: never overtakes the read)
+#ifdef SWFR_EMU
+            StripTop z; z.any = 0u; z.pad = 0u; z.cover = 0ull; FR->strip_top[wg] = z;
+#else
+            // (the zero is made here: as a loop invariant the compiler kept four zeroed registers alive across the whole strip loop --
+            //  in the bitmap instance it spilled them at kernel entry, 16 bytes of scratch per lane)
+            uint32_t z = 0u;
+            asm volatile("" : "+v"(z));
+            *reinterpret_cast<uint4*>(&FR->strip_top[wg]) = make_uint4(z, z, z, z);
+#endif
+        }
         const bool uniform = top.any == cover_pos;                        // (wave-uniform)
         if (cover_pos) {
             // the topmost opaque full cover paints every pixel of the strip with the record's colour: the walk starts BEHIND it
