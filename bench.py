@@ -95,6 +95,18 @@ def oracle_frame(fx, cols, W, H):
     return np.stack([(px >> 16) & 255, (px >> 8) & 255, px & 255, px >> 24], -1).astype(np.uint8)
 
 
+def profile_commit(path):
+    """' taken at commit <hash>' for a committed profile file profiles/<tag>_*.*: the tree the evidence was taken from (profiles/<tag>_commit.txt)."""
+    import re
+    m = re.match(r"(r\d+[a-z])_", os.path.basename(path or ""))
+    if not m:
+        return ""
+    try:
+        return " taken at commit " + open(os.path.join(ROOT, "profiles", m.group(1) + "_commit.txt")).read().split()[0]
+    except Exception:
+        return ""
+
+
 def latest_traffic(kernel=None):
     """HBM bytes per launch from the newest committed PMC profile of the S1 bench (FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections:
     tools/profile_r02.py), with its source: of `kernel` (a substring of its name), or -- kernel None -- of the whole frame (the sum
@@ -454,7 +466,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": lead, "kernel_why": "the kernel of the frame with the longest duration when it has the GPU to itself",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": traffic, "traffic_source": ("committed profile %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench; not measured in this run)" % traffic_src) if traffic_src else None,
+                         "traffic": traffic, "traffic_source": ("committed profile %s%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench; not measured in this run)" % (traffic_src, profile_commit(traffic_src))) if traffic_src else None,
                          "frame_traffic": frame_traffic,
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "kernel_ms": round(lead_ms, 4), "kernel_ms_how": "one frame in flight, HIP events around the kernel on its own stream",
@@ -473,7 +485,7 @@ def main():
                     # (the HIP events of this run bracket a kernel on its stream and so include the ~3 us between the end of the kernel before
                     #  it and its own start; rocprofv3's kernel trace does not)
                     committed[k] = {"kernel_us": round(rp_us, 2), "achieved": round(gbs(algo_bytes, rp_us * 1e-3), 2), "frac": round(gbs(algo_bytes, rp_us * 1e-3) / HBM_PEAK_GBS, 5)}
-                    committed["source"] = "%s (rocprofv3 --kernel-trace --stats of this bench, one frame in flight; not measured in this run)" % rp_src
+                    committed["source"] = "%s%s (rocprofv3 --kernel-trace --stats of this bench, one frame in flight; not measured in this run)" % (rp_src, profile_commit(rp_src))
             if committed:
                 line["roofline"]["rocprofv3_committed"] = committed
         line.update(extra)
