@@ -414,10 +414,12 @@ def test_kernel_route_knobs_are_pixel_identical(env, monkeypatch):
         assert diff_stats(product_render(sc), oracle_render(sc)) == (0, 0), (env, name)
 
 
-@pytest.mark.parametrize("env", [{"SWFR_GRAPHS": "1"}, {"SWFR_RESIDENT_BATCH": "2"}, {"SWFR_RESIDENT_BATCH": "4"}, {"SWFR_RESIDENT_BATCH": "2", "SWFR_FRAMES_IN_FLIGHT": "2"}])
+@pytest.mark.parametrize("env", [{"SWFR_GRAPHS": "1"}, {"SWFR_RESIDENT_BATCH": "1"}, {"SWFR_RESIDENT_BATCH": "2"}, {"SWFR_RESIDENT_BATCH": "4"}, {"SWFR_RESIDENT_BATCH": "2", "SWFR_FRAMES_IN_FLIGHT": "2"},
+                                 {"SWFR_RESIDENT_BATCH": "1", "SWFR_EVENT_STRIDE": "1000"}, {"SWFR_EVENT_STRIDE": "1000"}])
 def test_resident_frames_as_graph_launches_and_as_frames_per_launch(env, monkeypatch):
-    """The opt-in ways swfr_render_resident can issue its frames -- every frame one hipGraphLaunch (SWFR_GRAPHS=1), or groups of frame
-    sets as one launch per kernel (SWFR_RESIDENT_BATCH) -- render the same frames: the last of 7 (and of 2) equals the oracle, for a
+    """The ways swfr_render_resident can issue its frames -- every frame one hipGraphLaunch (SWFR_GRAPHS=1), one launch chain per frame
+    (SWFR_RESIDENT_BATCH=1), or groups of frame sets as one launch per kernel (SWFR_RESIDENT_BATCH, default 2 for calls without per-kernel
+    events: SWFR_EVENT_STRIDE larger than the call) -- render the same frames: the last of 7 (and of 2) equals the oracle, for a
     scene without and one with queued rows."""
     import swf_renderer_amd as S
     from swf_renderer_amd import api
