@@ -851,7 +851,10 @@ int upload(swfr_renderer* r, int si, bool all_sets, const swfr_edge* edges, size
 }
 
 // the kernels of one frame of scene `sc` on frame set `F`, writing the framebuffer `fb`; e (optional): four events around them
-void launch_frame(swfr_renderer* r, const swfr_renderer::Scene& sc, swfr_renderer::FrameSet& F, uint32_t* fb, hipEvent_t* e) {
+// overlapped: other frames run beside this one (several frame sets in flight) -- the tile pass is then launched in its paired shape (two
+// strips per wavefront, better for the frame rate); a frame that has the GPU to itself (a blocking swfr_render, a handle with one frame
+// in flight) gets one wavefront per strip, which finishes 2-3 us sooner ("Two strips per wavefront")
+void launch_frame(swfr_renderer* r, const swfr_renderer::Scene& sc, swfr_renderer::FrameSet& F, uint32_t* fb, hipEvent_t* e, bool overlapped) {
     const hipStream_t st = F.stream;
     {
         // the frame's descriptor (scene arrays, this set's buffers, the framebuffer) was written with the scene
@@ -863,7 +866,7 @@ void launch_frame(swfr_renderer* r, const swfr_renderer::Scene& sc, swfr_rendere
         // the queued rows (coincident edges, crowded rows): skipped once a frame of this resident scene has shown there are none
         if (sc.n_chunks && sc.slow_state != 1) launch2_rows_slow(st, fh, 1, 1024u, sc.slow_state == 2 ? 0u : 256u, sc.slow_passes);
         if (e) HIP_CHECK(hipEventRecord(e[2], st));
-        const uint32_t grid = r->tiles_grid > 0 ? uint32_t(r->tiles_grid) : ~0u;
+        const uint32_t grid = r->tiles_grid > 0 ? uint32_t(r->tiles_grid) : (overlapped ? ~0u : 0x7fffffffu);   // (~0u: the default shape; any other value caps the wavefronts)
         launch2_tiles(st, fh, 1, uint32_t(sc.n_strip_slots), grid, sc.shader_level, fb);      // (fb: this frame's own target, else the descriptor's)
         if (e) HIP_CHECK(hipEventRecord(e[3], st));
     }
@@ -910,7 +913,7 @@ void ensure_frame_graph(swfr_renderer* r, const swfr_renderer::Scene& sc, swfr_r
         F.graph_key = 0;
         HIP_CHECK(hipStreamBeginCapture(F.stream, hipStreamCaptureModeRelaxed));
         try {
-            launch_frame(r, sc, F, nullptr, nullptr);
+            launch_frame(r, sc, F, nullptr, nullptr, true);
         } catch (...) {
             hipGraph_t g = nullptr;
             (void)hipStreamEndCapture(F.stream, &g);
@@ -1015,7 +1018,7 @@ int render_resident(swfr_renderer* r, uint32_t frames) {
         swfr_renderer::FrameSet& F = r->fs[f % n_sets];
         const bool timed = f >= first_timed && (f - first_timed) % stride == 0;   // per-kernel events on every stride-th frame (each costs a queue packet)
         if (!timed && frames > 1 && r->use_graphs && sc.slow_verified) launch_frame_graph(r, sc, F);
-        else launch_frame(r, sc, F, nullptr, timed ? &r->ev[size_t((f - first_timed) / stride) * 4] : nullptr);
+        else launch_frame(r, sc, F, nullptr, timed ? &r->ev[size_t((f - first_timed) / stride) * 4] : nullptr, n_sets > 1 && frames > 1);
         last_on[f % n_sets] = int64_t(f);
     }
     for (uint32_t k = 1; k < n_sets; ++k) {                // (only the streams that carried something join)
@@ -1345,7 +1348,7 @@ int render_batch(swfr_renderer* r, const swfr_stage* stages, uint32_t n, void* d
             swfr_renderer::FrameSet& F = r->fs[k];
             if (k > 0 && i < n_sets) HIP_CHECK(hipStreamSynchronize(r->stream));   // first use of the set: bitmap table etc. are in place
             uint32_t* fb = device_dst ? reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(device_dst) + size_t(i) * frame_stride) : F.d_fb.ptr;
-            launch_frame(r, r->scn[k], F, nullptr, nullptr);     // (the descriptor carries fb)
+            launch_frame(r, r->scn[k], F, nullptr, nullptr, n_sets > 1 && n > 1);     // (the descriptor carries fb)
             HIP_CHECK(hipMemcpyAsync(hc + size_t(i) * COUNTER_WORDS, F.counters, COUNTER_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, F.stream));
             r->fb_cur = fb;
         }
@@ -1759,7 +1762,7 @@ int swfr_render_resident_async(swfr_renderer* r, uint32_t* out_set) {
         swfr_renderer::FrameSet& F = r->fs[k];
         if (!r->scn[0].slow_verified) { r->scn[0].slow_state = 0; r->scn[0].slow_passes = SLOW_PASSES; }   // (nothing checks an async frame's queues: launch everything unless a blocking frame of this scene has shown what it needs)
         order_frames_behind_pending_read(r);
-        launch_frame(r, r->scn[0], F, nullptr, nullptr);
+        launch_frame(r, r->scn[0], F, nullptr, nullptr, n_sets > 1);
         HIP_CHECK(hipGetLastError());
         r->fb_cur = r->n_targets ? r->targets[k % r->n_targets] : F.d_fb.ptr;
         if (out_set) *out_set = k;
@@ -1784,7 +1787,7 @@ int swfr_render_resident_async_to(swfr_renderer* r, void* block_target, uint32_t
         // address moved up by the rows above it (only the handle's own rows are ever written)
         uint32_t* fb = static_cast<uint32_t*>(block_target) - size_t(bs.first) * TILE_H * r->width;
         order_frames_behind_pending_read(r);
-        launch_frame(r, r->scn[0], F, fb, nullptr);
+        launch_frame(r, r->scn[0], F, fb, nullptr, true);
         HIP_CHECK(hipGetLastError());
         r->fb_cur = nullptr; r->fb_valid = false;              // (the frame is the caller's: nothing to read back from the handle)
         if (out_set) *out_set = k;
