@@ -147,7 +147,7 @@ for t, label in ((tag + "_large", "4096x4096 texture (about 1:1)"), (tag + "_mag
     s = json.load(open(os.path.join(OUT, t + "_sq_summary.json"))) if os.path.exists(os.path.join(OUT, t + "_sq_summary.json")) else {}
     k = "swfr::k2_tiles_bitmap_b"
     if k in ks:
-        L.append("Config 4, %s: `k2_tiles_bitmap_b` %.2f us, HBM traffic %.1f MB per launch, %.0f VALU / %.0f SALU per wavefront (two strips each since the paired launch)." % (
+        L.append("Config 4, %s: `k2_tiles_bitmap_b` %.2f us, HBM traffic %.1f MB per launch, %.0f VALU / %.0f SALU per wavefront = per strip (one frame in flight: one wavefront per strip)." % (
             label, ks[k][0], p.get(k, {}).get("hbm_bytes_per_launch", 0) / 1e6, s.get(k, {}).get("valu_per_wave", 0), s.get(k, {}).get("salu_per_wave", 0)))
 cb = os.path.join(OUT, tag + "_config_bench.txt")
 if os.path.exists(cb):
