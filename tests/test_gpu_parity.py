@@ -546,10 +546,14 @@ def test_s2_8k_100k_edges_vs_oracle():
     r = S.Renderer(W, H)
     r.render_edges(edges, paths, styles)
     img = r.read_image(premultiplied=True)
+    # several frames in flight: two frames per kernel launch, the tile pass in its paired shape (two strips per wavefront, cost-ordered)
+    r.render_resident(5)
+    again = r.read_image(premultiplied=True)
     r.close()
     # the oracle closes polygons (close_path); the scene builder draws the reference's explicit final lineTo.
     # Both merge the same collinear vertices, so the pixels agree (checked for S1 against libcairo).
     assert diff_stats(img, _oracle_polys(fx, cols, W, H)) == (0, 0)
+    assert (again == img).all()
 
 
 def test_twenty_thousand_paths_in_three_tile_rows_vs_oracle():
