@@ -484,7 +484,8 @@ __device__ __forceinline__ uint32_t pack_sub_cell(int x, int sgn, int xminp, int
 #include "rows3.hip"
 
 #ifndef R2_WAVES
-#define R2_WAVES 4                 // 119 VGPRs, 8.1 KB of LDS: four wavefronts per SIMD
+#define R2_WAVES 5                 // five wavefronts per SIMD: 96 VGPRs + 24 spilled (56 B of scratch per lane) beat four without spills (108 VGPRs)
+                                   // at the end of round 4 -- S1 29.3 -> 28.8 us per frame, S2 0.200 -> 0.198 ms, k2_rows alone 111.6 -> 104.3 us on S2; six lose (tools/lib_sweep.sh)
 #endif
 #define R2_ATTR __attribute__((amdgpu_waves_per_eu(R2_WAVES)))
 __global__ __launch_bounds__(64) R2_ATTR void k2_rows_b(const Frame2* __restrict__ frames) {
