@@ -484,9 +484,9 @@ __device__ __forceinline__ uint32_t pack_sub_cell(int x, int sgn, int xminp, int
 #include "rows3.hip"
 
 #ifndef R2_WAVES
-#define R2_WAVES 4                 // 108 VGPRs, no scratch, 8.1 KB of LDS: four wavefronts per SIMD.  Five (-DR2_WAVES=5: 96 VGPRs + 24 spilled, 56 B of
-                                   // scratch per lane) were measured at the end of round 4: S1 -1.5 % per frame, S2 -2.5 %, k2_rows 12.2 -> 11.5 us per frame
-                                   // saturated -- and +10 MB of scratch traffic per S1 frame (1.76x -> 2.08x algorithmic), 24.4 -> 25.1 us alone: not taken
+#define R2_WAVES 5                 // 92 VGPRs, no scratch, 5.4 KB of LDS: five wavefronts per SIMD (end of round 4: a slot's role lives in two bits of one
+                                   // register and its staged edge is looked up in LDS -- 108 -> 92 registers; with 24 SPILLED registers five wavefronts were
+                                   // already 1.5 % faster per S1 frame than four, and cost 10 MB of scratch traffic; six lose: tools/lib_sweep.sh)
 #endif
 #define R2_ATTR __attribute__((amdgpu_waves_per_eu(R2_WAVES)))
 __global__ __launch_bounds__(64) R2_ATTR void k2_rows_b(const Frame2* __restrict__ frames) {

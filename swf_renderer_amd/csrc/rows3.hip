@@ -243,7 +243,7 @@ __device__ __forceinline__ void rows3_chunk_body(FramePtr FR, uint32_t block) {
     R3MARK(4);
     // ---- rows that can be converted analytically: x of every active edge at the first sample row of this pixel row and of the next
     uint32_t key[NS]; int c1[NS];
-    int32_t qt[NS], qb[NS], rl[NS]; int ke[NS];
+    int32_t qt[NS], qb[NS], rl[NS];                    // (a slot's staged edge is looked up in slot_edge[], its role in `roles`: registers are this kernel's occupancy)
 #ifdef ABL3_NOEVAL
     const bool can_full = false;
 #else
@@ -253,11 +253,10 @@ __device__ __forceinline__ void rows3_chunk_body(FramePtr FR, uint32_t block) {
         amask_t m = amask;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            key[s] = R3_INVALID(s); c1[s] = 0x7fffffff; qt[s] = qb[s] = 0; rl[s] = 0; ke[s] = 0;
+            key[s] = R3_INVALID(s); c1[s] = 0x7fffffff; qt[s] = qb[s] = 0; rl[s] = 0;
             if (s >= nmax) continue;                          // wave-uniform
             const int k = m ? r3_first(m) : 0;                // (no edge left: the first staged record, the results are not used)
             m &= m - 1;
-            ke[s] = k;
             slot_edge[s][lane] = (uint8_t)k;
             const FastEdge& e = staged[k];
             const int32_t x1 = e.x1, DX = e.DX, D = e.D, hD = D >> 1;
@@ -314,9 +313,8 @@ __device__ __forceinline__ void rows3_chunk_body(FramePtr FR, uint32_t block) {
     }
     uint32_t mode = ROW_EMPTY;
     bool is_sub = false;
-    uint32_t role[NS];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) role[s] = 0;
+    uint32_t roles = 0;                                        // two bits per slot: 0 no boundary, 1 left edge of a span, 2 right edge
+#define R3_ROLE(s) ((roles >> (2 * (s))) & 3u)
     if (n > 0) {
         if (defer) mode = ROW_DEFER;
         else if (full) mode = ROW_FULL;
@@ -340,7 +338,7 @@ __device__ __forceinline__ void rows3_chunk_body(FramePtr FR, uint32_t block) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             if (s >= nmax) continue;
-            role[s] = (mode == ROW_FULL && s < n) ? (uint32_t)slot_role[s][lane] : 0u;
+            if (mode == ROW_FULL && s < n) roles |= (uint32_t)slot_role[s][lane] << (2 * s);
         }
     }
     R3MARK(6);
@@ -351,7 +349,7 @@ __device__ __forceinline__ void rows3_chunk_body(FramePtr FR, uint32_t block) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             if (s >= nmax) continue;                          // wave-uniform
-            if (role[s] != 0) n_cells += full_span(qt[s], qb[s]);
+            if (R3_ROLE(s) != 0) n_cells += full_span(qt[s], qb[s]);
         }
     }
     const int room = is_sub && ri != ~0u ? n * 15 : n_cells;
@@ -371,9 +369,9 @@ __device__ __forceinline__ void rows3_chunk_body(FramePtr FR, uint32_t block) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             if (s >= nmax) continue;
-            if (role[s] != 0) {
-                const FastEdge& e = staged[ke[s]];
-                full_cells3(qt[s], qb[s], rl[s], e.DX, e.D, e.invW, e.fq, e.fr, (role[s] & 1u) ? 0 : -1, P.x_min, P.x_max, &FR->cells[off]);
+            if (R3_ROLE(s) != 0) {
+                const FastEdge& e = staged[slot_edge[s][lane]];
+                full_cells3(qt[s], qb[s], rl[s], e.DX, e.D, e.invW, e.fq, e.fr, (R3_ROLE(s) & 1u) ? 0 : -1, P.x_min, P.x_max, &FR->cells[off]);
                 off += (uint32_t)full_span(qt[s], qb[s]);
             }
         }
@@ -389,7 +387,7 @@ __device__ __forceinline__ void rows3_chunk_body(FramePtr FR, uint32_t block) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             if (s >= nmax) continue;
-            if (role[s] != 0) {
+            if (R3_ROLE(s) != 0) {
                 const int a = qt[s] >> 8, b = qb[s] >> 8;
                 const int tlo = (min(a, b) >> 6) - tbase, thi = (max(a, b) >> 6) - tbase;          // (arithmetic shifts: floor)
                 inter |= cols_from(tlo) & ~cols_from(thi + 1);
