@@ -489,6 +489,9 @@ __device__ __forceinline__ uint32_t pack_sub_cell(int x, int sgn, int xminp, int
                                    // already 1.5 % faster per S1 frame than four, and cost 10 MB of scratch traffic; six lose: tools/lib_sweep.sh)
 #endif
 #define R2_ATTR __attribute__((amdgpu_waves_per_eu(R2_WAVES)))
+#ifndef R2_WIDE_WAVES
+#define R2_WIDE_WAVES 3            // the sixteen-slot instance: 168 VGPRs, 11 KB of LDS (two until the roles were packed: 192 VGPRs)
+#endif
 __global__ __launch_bounds__(64) R2_ATTR void k2_rows_b(const Frame2* __restrict__ frames) {
     FramePtr FR = FRAME_PTR(frames, blockIdx.y);
     if (blockIdx.x >= FR->n_chunks) return;
@@ -496,7 +499,7 @@ __global__ __launch_bounds__(64) R2_ATTR void k2_rows_b(const Frame2* __restrict
 }
 // (the instance for scenes with a path of more than ROWS_STAGE edges: 64 staged edges and SIXTEEN edge slots per row -- the rows of a
 //  stroke outline or of a shape with a hole inside a hole -- at two to three wavefronts per SIMD)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k2_rows_wide_b(const Frame2* __restrict__ frames) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R2_WIDE_WAVES))) void k2_rows_wide_b(const Frame2* __restrict__ frames) {
     FramePtr FR = FRAME_PTR(frames, blockIdx.y);
     if (blockIdx.x >= FR->n_chunks) return;
     rows3_chunk_body<ROWS_STAGE_WIDE, ROWS_FAST_WIDE>(FR, blockIdx.x);
