@@ -332,23 +332,35 @@ __device__ __forceinline__ void bin_body(FramePtr F, uint32_t slow_kernels) {
         }
 #endif
     }
-    // ---- one thread per path: its chunk descriptors
+    // ---- one thread per path: its chunk descriptors.  A path of many chunks (a frame of a few tall paths cut into 8-row chunks: a 1080-row
+    //      path has 135) is written by its whole WAVEFRONT, a chunk per lane -- one thread looping over them was the kernel's long pole there
     const uint32_t ip = path_block ? (rel - edge_blocks) * BIN_THREADS + (uint32_t)tid : ~0u;
+    if (!path_block) return;                                             // (wave-uniform: blockIdx decides)
+    uint32_t nc = 0, a0 = 0, c0 = 0, inc0 = 0, slots0 = ~0u, first_edge = 0, n_path_edges = 0, band0 = 0;
     if (ip < F->n_paths) {
-        const uint32_t i = ip;
-        const DevPath P = F->paths[i];
-        F->path_flag[i] = 0;
-        uint32_t a0;
-        const uint32_t nc = path_chunk_count(P, F->chunk_rows, a0);
-        const uint32_t c0 = F->path_chunks[i], inc0 = F->path_inc[i];
-        const bool area = path_has_area(P);
-        for (uint32_t c = 0; c < nc; ++c) {
-            ChunkInfo ck;
-            ck.path = i; ck.first_row = a0 + c * F->chunk_rows; ck.rec_base = inc0; ck.rows = F->chunk_rows;
-            ck.slot0 = area ? F->path_slots[i] + (ck.first_row / TILE_H - (uint32_t)P.y_min / TILE_H) : ~0u;
-            ck.first_edge = P.first_edge; ck.n_edges = P.n_edges; ck.pad = 0;
-            if (c0 + c < F->chunk_cap) F->chunks[c0 + c] = ck;
-        }
+        const DevPath P = F->paths[ip];
+        F->path_flag[ip] = 0;
+        nc = path_chunk_count(P, F->chunk_rows, a0);
+        c0 = F->path_chunks[ip]; inc0 = F->path_inc[ip];
+        slots0 = path_has_area(P) ? F->path_slots[ip] : ~0u;
+        first_edge = P.first_edge; n_path_edges = P.n_edges; band0 = (uint32_t)P.y_min / TILE_H;
+    }
+    auto write_chunk = [&](uint32_t path, uint32_t c, uint32_t a0_, uint32_t c0_, uint32_t inc0_, uint32_t slots0_, uint32_t fe_, uint32_t ne_, uint32_t band0_) {
+        ChunkInfo ck;
+        ck.path = path; ck.first_row = a0_ + c * F->chunk_rows; ck.rec_base = inc0_; ck.rows = F->chunk_rows;
+        ck.slot0 = slots0_ != ~0u ? slots0_ + (ck.first_row / TILE_H - band0_) : ~0u;
+        ck.first_edge = fe_; ck.n_edges = ne_; ck.pad = 0;
+        if (c0_ + c < F->chunk_cap) F->chunks[c0_ + c] = ck;
+    };
+    constexpr uint32_t OWN_CHUNKS = 8;                                   // up to this many a thread writes itself
+    if (nc <= OWN_CHUNKS)
+        for (uint32_t c = 0; c < nc; ++c) write_chunk(ip, c, a0, c0, inc0, slots0, first_edge, n_path_edges, band0);
+    for (unsigned long long big = __ballot(nc > OWN_CHUNKS); big; big &= big - 1ull) {    // wave-uniform
+        const int src = __ffsll((long long)big) - 1;
+        const uint32_t b_nc = (uint32_t)__shfl((int)nc, src), b_path = (uint32_t)__shfl((int)ip, src), b_a0 = (uint32_t)__shfl((int)a0, src);
+        const uint32_t b_c0 = (uint32_t)__shfl((int)c0, src), b_inc0 = (uint32_t)__shfl((int)inc0, src), b_slots0 = (uint32_t)__shfl((int)slots0, src);
+        const uint32_t b_fe = (uint32_t)__shfl((int)first_edge, src), b_ne = (uint32_t)__shfl((int)n_path_edges, src), b_band0 = (uint32_t)__shfl((int)band0, src);
+        for (uint32_t c = (uint32_t)lane; c < b_nc; c += 64u) write_chunk(b_path, c, b_a0, b_c0, b_inc0, b_slots0, b_fe, b_ne, b_band0);
     }
 }
 // The launch list of the tile pass.  Slot of a strip: XCDS * (its rank among the strips of its class) + class, class = local

@@ -608,8 +608,10 @@ void layout_scene(const swfr_renderer* r, const swfr_edge* edges, size_t n_edges
     //  -- 16 rows at an eighth of S1 -- k2_bin writes four times the chunk descriptors and loses what k2_rows gains:
     //  profiles/r03o_blocks_timing.json)
     L.chunk_rows = ROWS_CHUNK;
-    if (r->force_chunk_rows == 16 || r->force_chunk_rows == 32 || r->force_chunk_rows == 64) L.chunk_rows = uint32_t(r->force_chunk_rows);
-    else while (L.chunk_rows > uint32_t(TILE_H) && count_chunks(L.chunk_rows) < 1024) L.chunk_rows >>= 1;
+    // (down to the rows of ONE STRIP for a frame of a few tall paths: its row kernel is as slow as its slowest wavefront, and a wavefront
+    //  whose rows all need sample passes runs one pass per four rows)
+    if (r->force_chunk_rows == 8 || r->force_chunk_rows == 16 || r->force_chunk_rows == 32 || r->force_chunk_rows == 64) L.chunk_rows = uint32_t(r->force_chunk_rows);
+    else while (L.chunk_rows > uint32_t(STRIP_H) && count_chunks(L.chunk_rows) < 1024) L.chunk_rows >>= 1;
     L.any_shader = false; L.shader_level = 0;
     for (size_t i = 0; i < n_styles; ++i) {
         L.any_shader = L.any_shader || styles[i].kind != SWFR_STYLE_SOLID;

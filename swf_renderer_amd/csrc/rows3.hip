@@ -123,24 +123,24 @@ __device__ __forceinline__ void rows3_chunk_body(FramePtr FR, uint32_t block) {
     const FastEdge ek_first = FE[min((uint32_t)lane, ck.n_edges ? ck.n_edges - 1u : 0u)];
     const DevPath P = FR->paths[lo];
     const int r = (int)ck.first_row + lane;
-    const int chunk_rows = (int)ck.rows;                                 // 16, 32 or 64: whole tile-rows, starting on a tile-row boundary
+    const int chunk_rows = (int)ck.rows;                                 // 16, 32 or 64: whole tile-rows, starting on a tile-row boundary -- or 8: one strip's rows (a frame of few, tall paths)
 
     // the band entry of this lane's tile-row: where its row headers and class bytes go
-    const int g16 = lane >> 4;
+    const int g16 = (((int)ck.first_row & (TILE_H - 1)) + lane) >> 4;     // the lane's tile-row, counted from the chunk's first (an 8-row chunk may start in the middle of one)
     const int band = (int)ck.first_row / TILE_H + g16;
     const int band_lo = P.y_min / TILE_H, band_hi = (P.y_max - 1) / TILE_H;
     // (the band records are requested with what the CHUNK record says -- clamped where the path may turn out not to reach -- so that
     //  they travel beside the path record, not behind it; band_ok decides afterwards whether they mean anything)
     BandSlot cls_bs = {0u, 0u, 0u, 0u};
     uint32_t cls_b0 = 0, cls_b1 = 0;
-    if (ck.slot0 != ~0u && g16 < chunk_rows / TILE_H) {
+    if (ck.slot0 != ~0u && lane < chunk_rows) {
         cls_bs = FR->band_slots[ck.slot0 + (uint32_t)g16];                 // (at most three records past the path's own: the host reserves eight spare ones)
         const uint32_t bclamp = min((uint32_t)band, FR->n_bands - 1u);
         cls_b0 = FR->band_off[bclamp];
         cls_b1 = FR->band_off[bclamp + 1u];
     }
-    const bool band_ok = ck.slot0 != ~0u && g16 < chunk_rows / TILE_H && band >= band_lo && band <= band_hi && P.kind == SWFR_PATH_TOR;
-    const uint32_t ri = band_ok ? cls_bs.slot * TILE_H + (uint32_t)(lane & (TILE_H - 1)) : ~0u;
+    const bool band_ok = ck.slot0 != ~0u && lane < chunk_rows && band >= band_lo && band <= band_hi && P.kind == SWFR_PATH_TOR;
+    const uint32_t ri = band_ok ? cls_bs.slot * TILE_H + (uint32_t)(r & (TILE_H - 1)) : ~0u;
     const bool in_path = P.kind == SWFR_PATH_TOR && lane < chunk_rows && r >= P.y_min && r < P.y_max;
     bool live = in_path;
     { uint32_t lb; if (live && !owns_band(FR, r / TILE_H, lb)) live = false; }         // another rank's tile-row
@@ -596,7 +596,7 @@ __device__ __forceinline__ void rows3_chunk_body(FramePtr FR, uint32_t block) {
         const bool own_band = band_ok && owns_band(FR, band, local_trow);
         const bool cost_order = FR->strip_order != 0u;
         const uint32_t pos1 = cls_bs.slot - cls_b0 + 1u;         // the path's position in its tile-row's band list, 1-based
-        const int strip_in_tile = (lane >> 3) & 1, tsub = lane & 7;
+        const int strip_in_tile = (r >> 3) & 1, tsub = lane & 7;          // (a chunk starts on a strip boundary: lanes 8j .. 8j + 7 are one strip's rows)
         for (int tb = 0; tb < ntc; tb += 32) {                   // wave-uniform
             const int nb = min(ntc - tb, 32);
             const uint32_t colmask = nb >= 32 ? ~0u : ((1u << nb) - 1u);

@@ -394,13 +394,14 @@ def test_tile_with_an_uncovered_path_row_is_not_a_full_cover():
 
 
 # ---- every internal route of the row/tile kernels gives the same pixels
-@pytest.mark.parametrize("env", [{"SWFR_FAST_LIMIT": "0"}, {"SWFR_FAST_LIMIT": "3"}, {"SWFR_CHUNK_ROWS": "64"}, {"SWFR_CHUNK_ROWS": "16"},
+@pytest.mark.parametrize("env", [{"SWFR_FAST_LIMIT": "0"}, {"SWFR_FAST_LIMIT": "3"}, {"SWFR_CHUNK_ROWS": "64"}, {"SWFR_CHUNK_ROWS": "16"}, {"SWFR_CHUNK_ROWS": "8"},
+                                 {"SWFR_CHUNK_ROWS": "8", "SWFR_FAST_LIMIT": "3"},
                                  {"SWFR_CHUNK_ROWS": "32", "SWFR_FAST_LIMIT": "3"}, {"SWFR_STRIP_ORDER": "0"}, {"SWFR_FRAMES_IN_FLIGHT": "1"},
                                  {"SWFR_FRAMES_IN_FLIGHT": "4", "SWFR_CHUNK_ROWS": "16"}, {"SWFR_BATCH_FRAMES": "1"},
                                  {"SWFR_TILES_GRID": "7"}, {"SWFR_TILES_GRID": "300", "SWFR_STRIP_ORDER": "0"}])
 def test_kernel_route_knobs_are_pixel_identical(env, monkeypatch):
     """SWFR_FAST_LIMIT sends rows with more active edges than the limit (0: every row) to the queued-row kernels (k2_rows_slow /
-    k2_rows_huge) instead of the fast routine of k2_rows; SWFR_CHUNK_ROWS picks the pixel rows per k2_rows wavefront (16, 32 or 64;
+    k2_rows_huge) instead of the fast routine of k2_rows; SWFR_CHUNK_ROWS picks the pixel rows per k2_rows wavefront (8, 16, 32 or 64;
     by default the largest that still gives a thousand wavefronts); SWFR_STRIP_ORDER=0 launches the strips of k2_tiles row-major
     instead of heaviest first; SWFR_FRAMES_IN_FLIGHT is the number of frame sets (streams, intermediate buffers) consecutive
     frames rotate over; SWFR_BATCH_FRAMES=1 makes swfr_render_batch launch every frame by itself; SWFR_TILES_GRID is the number of
