@@ -264,31 +264,48 @@ __device__ __forceinline__ void bin_body(FramePtr F, uint32_t slow_kernels) {
                 }
                 __syncthreads();
                 const uint32_t in_window = min(total - lo, BAND_LIST);
-                for (uint32_t i = (uint32_t)tid; i < in_window; i += BIN_THREADS) {
-                    const uint32_t p = band_hits[i], at = n + lo + i;
-                    if (at >= n_b) continue;
-                    const DevPath P = F->paths[p];
-                    const uint32_t slot = b0 + at;
-                    const BandEntry2 e = make_band_entry2(P, p, (uint32_t)band, F);
-                    F->band_list[slot] = e;
-                    BandSlot bs; bs.path = p; bs.slot = slot; bs.band = (uint32_t)band; bs.pad = 0;
-                    F->band_slots[F->path_slots[p] + (uint32_t)(band - P.y_min / TILE_H)] = bs;
-                    if (P.kind == SWFR_PATH_BOXES) {
-                        uint8_t* out = F->cls + (size_t)STRIPS_PER_TILE * F->tiles_x * b0 + at;    // [tile column][strip][entry] inside the tile-row
-                        const int ty0 = band * TILE_H, tile_y1 = min(ty0 + TILE_H, F->height);
-                        const uint32_t opq = (e.flags & BE_OPAQUE_COVER) ? CLS_OPAQUE : 0u;
-                        const swfr_edge bx = F->raw[P.first_edge];             // (only looked at when the path is a single box)
-                        const bool one_box = P.n_edges == 1 && bx.y1 <= ty0 * 256 && bx.y2 >= tile_y1 * 256;
-                        uint32_t local_trow = 0;
-                        const bool own = owns_band(F, band, local_trow);
-                        for (int tc = P.x_min / TILE_W; tc <= (P.x_max - 1) / TILE_W; ++tc) {
+                uint32_t local_trow = 0;
+                const bool own = owns_band(F, band, local_trow);             // (workgroup-uniform: the tile-row)
+                const int ty0 = band * TILE_H, tile_y1 = min(ty0 + TILE_H, F->height);
+                for (uint32_t ib = 0; ib < in_window; ib += BIN_THREADS) {   // (workgroup-uniform trip count: the box step below is a wavefront's)
+                    const uint32_t i = ib + (uint32_t)tid;
+                    uint32_t p = 0, at = 0;
+                    bool valid = i < in_window;
+                    if (valid) { p = band_hits[i]; at = n + lo + i; valid = at < n_b; }
+                    int x_min = 0, x_max = 0;
+                    uint32_t e_flags = 0, e_solid = 0, p_first = 0, p_nedges = 0;
+                    bool box = false;
+                    if (valid) {
+                        const DevPath P = F->paths[p];
+                        const uint32_t slot = b0 + at;
+                        const BandEntry2 e = make_band_entry2(P, p, (uint32_t)band, F);
+                        F->band_list[slot] = e;
+                        BandSlot bs; bs.path = p; bs.slot = slot; bs.band = (uint32_t)band; bs.pad = 0;
+                        F->band_slots[F->path_slots[p] + (uint32_t)(band - P.y_min / TILE_H)] = bs;
+                        box = P.kind == SWFR_PATH_BOXES;
+                        x_min = P.x_min; x_max = P.x_max; e_flags = e.flags; e_solid = e.solid; p_first = P.first_edge; p_nedges = P.n_edges;
+                    }
+                    // box paths: the class bytes and strip records of the hit's tile columns, shared by the wavefront -- (tile column,
+                    // strip) pairs over the lanes (one thread looping over a full-frame rectangle's 120 was this kernel's long pole
+                    // on a textured 4K frame: 27-40 us)
+                    for (unsigned long long bm = __ballot(box); bm; bm &= bm - 1ull) {          // wave-uniform
+                        const int src = __ffsll((long long)bm) - 1;
+                        const uint32_t b_at = (uint32_t)__shfl((int)at, src), b_flags = (uint32_t)__shfl((int)e_flags, src), b_solid = (uint32_t)__shfl((int)e_solid, src);
+                        const uint32_t b_first = (uint32_t)__shfl((int)p_first, src), b_nedges = (uint32_t)__shfl((int)p_nedges, src);
+                        const int b_xmin = __shfl(x_min, src), b_xmax = __shfl(x_max, src);
+                        uint8_t* out = F->cls + (size_t)STRIPS_PER_TILE * F->tiles_x * b0 + b_at;    // [tile column][strip][entry] inside the tile-row
+                        const uint32_t opq = (b_flags & BE_OPAQUE_COVER) ? CLS_OPAQUE : 0u;
+                        const swfr_edge bx = F->raw[b_first];                  // (only looked at when the path is a single box)
+                        const bool one_box = b_nedges == 1 && bx.y1 <= ty0 * 256 && bx.y2 >= tile_y1 * 256;
+                        const int tc_a = b_xmin / TILE_W, tc_b = (b_xmax - 1) / TILE_W;
+                        const int items = (tc_b - tc_a + 1) * STRIPS_PER_TILE;
+                        for (int k = lane; k < items; k += 64) {
+                            const int tc = tc_a + k / STRIPS_PER_TILE, sp = k % STRIPS_PER_TILE;
                             const int tx0 = tc * TILE_W, tile_x1 = min(tx0 + TILE_W, F->width);
                             uint32_t f = CLS_BOX | CLS_NONEMPTY | CLS_NOTFULL;
                             if (one_box && bx.x1 <= tx0 * 256 && bx.x2 >= tile_x1 * 256) f = CLS_NONEMPTY | opq;     // the box contains the whole tile: full cover
-                            for (int sp = 0; sp < STRIPS_PER_TILE; ++sp) {
-                                out[(size_t)(tc * STRIPS_PER_TILE + sp) * n_b] = (uint8_t)f;
-                                if (own && ty0 + sp * STRIP_H < F->height) strip_top_note(F, (local_trow * (uint32_t)F->tiles_x + (uint32_t)tc) * STRIPS_PER_TILE + (uint32_t)sp, at + 1u, f, e.solid);
-                            }
+                            out[(size_t)(tc * STRIPS_PER_TILE + sp) * n_b] = (uint8_t)f;
+                            if (own && ty0 + sp * STRIP_H < F->height) strip_top_note(F, (local_trow * (uint32_t)F->tiles_x + (uint32_t)tc) * STRIPS_PER_TILE + (uint32_t)sp, b_at + 1u, f, b_solid);
                         }
                     }
                 }
